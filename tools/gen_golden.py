@@ -1,0 +1,535 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by importing the reference Python from /root/reference.
+
+Runs ONLY in the build container (the reference never travels to the GPU box). The
+reference sources are imported, never copied: uninstalled third-party modules
+(gym, mujoco_py, cv2, OpenGL, glfw, tensorflow, torchvision, imageio, scipy.misc) are
+replaced by empty stub modules, and MuJoCo-dependent methods are exercised as unbound
+functions on duck-typed stand-ins for ``env``.
+
+Every fixture is data: seeded inputs + the reference's outputs (float64).
+"""
+import importlib.machinery
+import multiprocessing
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+import yaml
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+
+def _stub(name):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    for n in ["gym", "gym.envs", "gym.envs.mujoco", "gym.envs.mujoco.mujoco_env", "gym.utils",
+              "gym.utils.seeding", "gym.spaces", "OpenGL", "OpenGL.GL", "glfw", "cv2", "tensorflow",
+              "scipy.misc", "imageio", "torchvision", "torchvision.models", "mujoco_py",
+              "mujoco_py.functions", "mujoco_py.builder", "mujoco_py.generated", "mujoco_py.utils",
+              "mujoco_py.generated.const"]:
+        if n not in sys.modules:
+            _stub(n)
+    sys.modules["gym"].error = types.SimpleNamespace()
+    sys.modules["gym"].spaces = sys.modules["gym.spaces"]
+    sys.modules["gym.spaces"].Box = lambda low=None, high=None, dtype=None, shape=None: types.SimpleNamespace(
+        low=low, high=high, shape=np.asarray(low).shape)
+    sys.modules["gym.utils"].seeding = sys.modules["gym.utils.seeding"]
+    sys.modules["gym.utils.seeding"].np_random = lambda seed=None: (np.random.RandomState(seed), seed)
+    sys.modules["gym.envs.mujoco.mujoco_env"].MujocoEnv = object
+    sys.modules["mujoco_py"].functions = sys.modules["mujoco_py.functions"]
+    sys.modules["mujoco_py.functions"].mj_fullM = None   # monkey-patched per call below
+    for n in ["MjViewer", "MjSim", "load_model_from_path", "MjSimState", "MjRenderContextOffscreen",
+              "MjViewerBasic"]:
+        setattr(sys.modules["mujoco_py"], n, object)
+    sys.modules["mujoco_py.generated"].const = sys.modules["mujoco_py.generated.const"]
+    sys.modules["mujoco_py.builder"].cymj = types.SimpleNamespace(MjRenderContextWindow=object)
+    sys.modules["mujoco_py.utils"].rec_copy = lambda x: x
+    sys.modules["mujoco_py.utils"].rec_assign = lambda a, b: None
+
+
+def enter_workdir():
+    """cwd with config/ + a synthetic datasets/meta file, as Config() expects."""
+    wd = tempfile.mkdtemp(prefix="egp_golden_")
+    shutil.copytree(os.path.join(REF, "config"), os.path.join(wd, "config"))
+    os.makedirs(os.path.join(wd, "datasets", "meta"))
+    for mid in ["meta_subject_03", "meta_cross_01"]:
+        with open(os.path.join(wd, "datasets", "meta", mid + ".yml"), "w") as f:
+            yaml.safe_dump({"train": ["take_%02d" % i for i in range(4)], "test": ["take_98", "take_99"]}, f)
+    os.chdir(wd)
+    return wd
+
+
+def rand_unit_quat(rng, n):
+    q = rng.normal(size=(n, 4))
+    return q / np.linalg.norm(q, axis=1, keepdims=True)
+
+
+def yaw_tilt_quat(rng, tilt=0.05):
+    from utils.transformation import quaternion_about_axis, quaternion_multiply
+    yaw = rng.uniform(-np.pi, np.pi)
+    q = quaternion_about_axis(yaw, [0, 0, 1])
+    tq = quaternion_about_axis(rng.normal() * tilt, rng.normal(size=3))
+    return quaternion_multiply(q, tq)
+
+
+def synth_qpos(rng, sk, n, joint_scale=0.3):
+    qpos = np.zeros((n, sk.nq))
+    for i in range(n):
+        qpos[i, :2] = rng.normal(size=2)
+        qpos[i, 2] = rng.uniform(0.85, 0.95)
+        qpos[i, 3:7] = yaw_tilt_quat(rng)
+        j = rng.normal(size=sk.nq - 7) * joint_scale
+        qpos[i, 7:] = np.clip(j, sk.joint_range[:, 0], sk.joint_range[:, 1])
+    return qpos
+
+
+class FakeData:
+    pass
+
+
+def make_fake_env(sk, cfg, HumanoidEnv):
+    """Duck-typed stand-in exposing exactly what the unbound reference methods touch."""
+    env = types.SimpleNamespace()
+    env.cfg = cfg
+    env.data = FakeData()
+    env.model = types.SimpleNamespace(
+        body_names=["world"] + list(sk.body_names), nv=sk.nv, nq=sk.nq,
+        opt=types.SimpleNamespace(timestep=sk.timestep),
+        _body_name2id={n: i + 1 for i, n in enumerate(sk.body_names)})
+    env.body_qposaddr = sk.body_qposaddr()
+    env.dt = sk.timestep * 15
+    env.get_body_quat = lambda: HumanoidEnv.get_body_quat(env)
+    env.get_ee_pos = lambda transform: HumanoidEnv.get_ee_pos(env, transform)
+    env.get_full_obs = lambda: HumanoidEnv.get_full_obs(env)
+    env.compute_desired_accel = lambda a, b: HumanoidEnv.compute_desired_accel(env, a, b)
+    env.get_expert_index = lambda t: env.start_ind + t
+    env.get_expert_attr = lambda attr, ind: env.expert[attr][ind, :]
+    return env
+
+
+def main():
+    install_stubs()
+    sys.path.insert(0, REF)
+    wd = enter_workdir()
+    import torch
+    torch.set_default_dtype(torch.float64)
+    import utils as ru                                        # reference utils (star exports)
+    import utils.transformation, utils.math
+    T = sys.modules['utils.transformation']
+    rmath = sys.modules['utils.math']
+    from utils.zfilter import ZFilter
+    from core.common import estimate_advantages
+    from core.logger_rl import LoggerRL
+    from core.policy_gaussian import PolicyGaussian
+    from core.critic import Value
+    from models.mlp import MLP
+    from models.video_state_net import VideoStateNet
+    from ego_pose.envs import humanoid_v1 as hv1
+    from ego_pose.envs.humanoid_v1 import HumanoidEnv
+    from ego_pose.core.reward_function import quat_space_reward_v3, reward_func
+    from ego_pose.core.agent_ego import AgentEgo
+    from ego_pose.core.trajbatch_ego import TrajBatchEgo
+    from ego_pose.utils.egomimic_config import Config
+    from ego_pose.utils import metrics as rmetrics
+    from agents.agent import Agent
+    from egopose_amd.skeleton import load_skeleton
+
+    os.makedirs(OUT, exist_ok=True)
+    sk = load_skeleton(os.path.join(REF, "assets/mujoco_models/humanoid_1205_v1.xml"))
+    cfg = Config("subject_03", create_dirs=False)
+    rng = np.random.RandomState(20260928)
+
+    # ------------------------------------------------------------------ G15 config arrays
+    cfg.update_adaptive_params(0)
+    np.savez(os.path.join(OUT, "config_subject_03.npz"),
+             jkp=cfg.jkp, jkd=cfg.jkd, a_ref=cfg.a_ref, a_scale=cfg.a_scale, torque_lim=cfg.torque_lim,
+             b_diffw=cfg.b_diffw, gamma=cfg.gamma, tau=cfg.tau, clip_epsilon=cfg.clip_epsilon,
+             log_std=cfg.log_std, fix_std=cfg.fix_std, min_batch_size=cfg.min_batch_size,
+             num_optim_epoch=cfg.num_optim_epoch, env_episode_len=cfg.env_episode_len,
+             fr_margin=cfg.fr_margin, policy_lr=cfg.policy_lr, value_lr=cfg.value_lr,
+             adp_noise_rate=cfg.adp_noise_rate, adp_log_std=cfg.adp_log_std, adp_policy_lr=cfg.adp_policy_lr,
+             policy_hsize=np.array(cfg.policy_hsize), policy_v_hdim=cfg.policy_v_hdim,
+             reward_keys=np.array(sorted(cfg.reward_weights.keys())),
+             reward_vals=np.array([float(cfg.reward_weights[k]) for k in sorted(cfg.reward_weights.keys())]))
+
+    # ------------------------------------------------------------------ G1 quaternion KATs + random cases
+    n = 256
+    q1 = rand_unit_quat(rng, n)
+    q0 = rand_unit_quat(rng, n) * rng.uniform(0.5, 2.0, size=(n, 1))      # inverse must handle |q| != 1
+    qn = rand_unit_quat(rng, n)
+    # special rows: identity / near identity (1-w<1e-8 branch) / negative w / w=-1
+    qn[0] = [1, 0, 0, 0]
+    qn[1] = [1 - 1e-9, 4e-5, 0, 0]
+    qn[1] /= np.linalg.norm(qn[1])
+    qn[2] = -np.abs(qn[2])
+    qn[3] = [np.cos(1e-3), np.sin(1e-3), 0, 0]
+    eul = rng.uniform(-np.pi, np.pi, size=(n, 3))
+    v3 = rng.normal(size=(n, 3))
+    ang = rng.uniform(-np.pi, np.pi, size=n)
+    emap = rng.normal(size=(n, 3))
+    emap[0] = 0
+    out = dict(
+        q1=q1, q0=q0, qn=qn, eul=eul, v3=v3, ang=ang, emap=emap,
+        mul=np.stack([T.quaternion_multiply(a, b) for a, b in zip(q1, q0)]),
+        inv=np.stack([T.quaternion_inverse(b) for b in q0]),
+        mat=np.stack([T.quaternion_matrix(b)[:3, :3] for b in q0]),
+        from_euler=np.stack([T.quaternion_from_euler(*e) for e in eul]),
+        about_axis=np.stack([T.quaternion_about_axis(a, v) for a, v in zip(ang, v3)]),
+        rot_vec=np.stack([T.rotation_from_quaternion(q) for q in qn]),
+        rot_axis=np.stack([T.rotation_from_quaternion(q, True)[0] for q in qn]),
+        rot_angle=np.array([T.rotation_from_quaternion(q, True)[1] for q in qn]),
+        heading_q=np.stack([rmath.get_heading_q(q) for q in qn[4:]]),
+        heading=np.array([rmath.get_heading(q) for q in qn[4:]]),
+        de_heading=np.stack([rmath.de_heading(q) for q in qn[4:]]),
+        tv_root=np.stack([rmath.transform_vec(v, q, 'root') for v, q in zip(v3, qn)]),
+        tv_heading=np.stack([rmath.transform_vec(v, q, 'heading') for v, q in zip(v3[4:], qn[4:])]),
+        quat_mul_vec=np.stack([rmath.quat_mul_vec(q, v) for v, q in zip(v3, qn)]),
+        expmap=np.stack([rmath.quat_from_expmap(e) for e in emap]),
+        euler_from_quat=np.stack([T.euler_from_quaternion(q) for q in qn]),
+        multi_diff=rmath.multi_quat_diff(q1.ravel(), qn.ravel()),
+        multi_norm=rmath.multi_quat_norm(rmath.multi_quat_diff(q1.ravel(), qn.ravel())),
+        # doctest known answers quoted in utils/transformation.py (:1200-1202, :1254-1256, :1382-1384)
+        kat_from_euler_ryxz=T.quaternion_from_euler(1, 2, 3, 'ryxz'),
+        kat_about_axis=T.quaternion_about_axis(0.123, [1, 0, 0]),
+        kat_mul=T.quaternion_multiply([4, 1, -2, 3], [8, -5, 6, 7]),
+        kat_mat=T.quaternion_matrix([0, 1, 0, 0])[:3, :3],
+    )
+    np.savez(os.path.join(OUT, "quat.npz"), **out)
+
+    # ------------------------------------------------------------------ G2/G3 body_quat + obs
+    env = make_fake_env(sk, cfg, HumanoidEnv)
+    n = 64
+    qpos = synth_qpos(rng, sk, n)
+    qpos[0, 7:] = 0.0
+    qpos[1, 3:7] = [1, 0, 0, 0]
+    qvel = rng.normal(size=(n, sk.nv)) * 2.0
+    bq, obs = [], []
+    for i in range(n):
+        env.data.qpos, env.data.qvel = qpos[i].copy(), qvel[i].copy()
+        bq.append(HumanoidEnv.get_body_quat(env))
+        obs.append(HumanoidEnv.get_full_obs(env))
+    np.savez(os.path.join(OUT, "body_quat_obs.npz"), qpos=qpos, qvel=qvel, bquat=np.stack(bq), obs=np.stack(obs))
+
+    # ------------------------------------------------------------------ G4 stable-PD torque
+    M0 = sk.zero_pose_inertia()
+    n = 64
+    qpos = synth_qpos(rng, sk, n)
+    qvel = rng.normal(size=(n, sk.nv)) * 3.0
+    action = rng.normal(size=(n, sk.nu)) * 0.5
+    Ms, qMs, Cs, tq, tqc = [], [], [], [], []
+    for i in range(n):
+        d = 1.0 + 0.2 * rng.uniform(-1, 1, size=sk.nv)
+        M = M0 * d[:, None] * d[None, :]
+        qM = sk.sparse_from_full(M)
+        M = sk.full_from_sparse(qM)
+        C = rng.normal(size=sk.nv) * 20.0
+        env.data.qpos, env.data.qvel = qpos[i].copy(), qvel[i].copy()
+        env.data.qM, env.data.qfrc_bias = qM, C
+
+        def fake_fullM(model, dst, qM_, _M=M):
+            dst[:] = _M.ravel()
+        hv1.mjf.mj_fullM = fake_fullM
+        ctrl = cfg.a_ref + action[i] * cfg.a_scale
+        t = HumanoidEnv.compute_torque(env, ctrl)
+        Ms.append(M); qMs.append(qM); Cs.append(C); tq.append(t)
+        tqc.append(np.clip(t, -cfg.torque_lim, cfg.torque_lim))
+    np.savez(os.path.join(OUT, "pd_torque.npz"), qpos=qpos, qvel=qvel, action=action, M=np.stack(Ms[:2]),
+             qM=np.stack(qMs), C=np.stack(Cs), torque=np.stack(tq), torque_clipped=np.stack(tqc),
+             dt=sk.timestep)
+
+    # ------------------------------------------------------------------ G5 imitation reward
+    # a small expert take derived from a smooth synthetic qpos sequence with the reference formulas
+    L = 64
+    base = synth_qpos(rng, sk, 1)[0]
+    e_qpos = np.zeros((L, sk.nq))
+    ph = rng.uniform(0, 2 * np.pi, size=sk.nq)
+    fr = rng.uniform(0.5, 2.0, size=sk.nq)
+    yaw0 = rng.uniform(-np.pi, np.pi)
+    for f in range(L):
+        tt = f / 30.0
+        e_qpos[f, :2] = base[:2] + np.array([0.8 * tt, 0.1 * np.sin(tt)])
+        e_qpos[f, 2] = 0.9 + 0.02 * np.sin(2 * tt)
+        qy = T.quaternion_about_axis(yaw0 + 0.3 * tt, [0, 0, 1])
+        qt = T.quaternion_about_axis(0.05 * np.sin(3 * tt), [1, 0.3, 0])
+        e_qpos[f, 3:7] = T.quaternion_multiply(qy, qt)
+        e_qpos[f, 7:] = np.clip(base[7:] + 0.2 * np.sin(fr[7:] * tt + ph[7:]), sk.joint_range[:, 0], sk.joint_range[:, 1])
+    e_qpos[:, 32:35] = 0.0
+    e_qpos[:, 42:45] = 0.0
+    dt = env.dt
+    expert = {k: [] for k in ['rlinv_local', 'rangv', 'rq_rmh', 'ee_pos', 'bquat', 'bangvel', 'qvel']}
+    for f in range(L):
+        env.data.qpos = e_qpos[f].copy()
+        env.data.body_xpos = np.vstack([np.zeros(3), sk.body_xpos(e_qpos[f])])
+        expert['rq_rmh'].append(rmath.de_heading(e_qpos[f, 3:7]))
+        expert['ee_pos'].append(HumanoidEnv.get_ee_pos(env, cfg.obs_coord))
+        expert['bquat'].append(HumanoidEnv.get_body_quat(env))
+        if f > 0:
+            qv = rmath.get_qvel_fd(e_qpos[f - 1], e_qpos[f], dt)
+            expert['qvel'].append(qv)
+            expert['rlinv_local'].append(rmath.transform_vec(qv[:3].copy(), e_qpos[f, 3:7], cfg.obs_coord))
+            expert['rangv'].append(qv[3:6].copy())
+            expert['bangvel'].append(rmath.get_angvel_fd(expert['bquat'][f - 1], expert['bquat'][f], dt))
+    for k in ['qvel', 'rlinv_local', 'rangv', 'bangvel']:
+        expert[k].insert(0, expert[k][0].copy())
+    expert = {k: np.vstack(v) for k, v in expert.items()}
+    expert['qpos'] = e_qpos
+    env.expert = expert
+
+    n = 256
+    cases = dict(cur_qpos=[], prev_qpos=[], prev_bquat=[], ee_wpos=[], t=[], start_ind=[], end=[],
+                 wset=[], end_reward=[], reward=[], c_info=[])
+    wsets = [dict(cfg.reward_weights), {}, dict(cfg.reward_weights, decay=True, w_v=0.1, v_ord=2)]
+    for i in range(n):
+        start = int(rng.randint(0, L - 40))
+        t = int(rng.randint(1, 30))
+        ind = start + t
+        noise = 0.0 if i % 8 == 0 else (0.02 if i % 2 else 0.15)
+        prev = e_qpos[ind - 1].copy()
+        cur = e_qpos[ind].copy()
+        for q in (prev, cur):
+            q[:3] += rng.normal(size=3) * noise * 0.3
+            q[3:7] = T.quaternion_multiply(q[3:7], T.quaternion_about_axis(rng.normal() * noise, rng.normal(size=3)))
+            q[7:] += rng.normal(size=sk.nq - 7) * noise
+        if i % 16 == 4:
+            cur = prev.copy()                       # zero motion: 1-w<1e-8 branch for every body
+        if i % 16 == 5:
+            cur[3:7] *= -1.0                        # w<0 root quaternion
+        env.data.qpos = prev.copy()
+        prev_bquat = HumanoidEnv.get_body_quat(env)
+        env.data.qpos = cur.copy()
+        xpos = sk.body_xpos(cur) + rng.normal(size=(21, 3)) * noise * 0.05
+        env.data.body_xpos = np.vstack([np.zeros(3), xpos])
+        env.prev_qpos, env.prev_bquat = prev, prev_bquat
+        env.cur_t, env.start_ind = t, start
+        env.end_reward = float(rng.uniform(0, 5))
+        wi = i % 3
+        cfg.reward_weights = wsets[wi]
+        end = bool(i % 5 == 0)
+        r, ci = quat_space_reward_v3(env, None, None, {'end': end})
+        cases['cur_qpos'].append(cur); cases['prev_qpos'].append(prev); cases['prev_bquat'].append(prev_bquat)
+        cases['ee_wpos'].append(xpos[sk.ee_body].ravel()); cases['t'].append(t); cases['start_ind'].append(start)
+        cases['end'].append(end); cases['wset'].append(wi); cases['end_reward'].append(env.end_reward)
+        cases['reward'].append(r); cases['c_info'].append(ci)
+    cfg.reward_weights = wsets[0]
+    np.savez(os.path.join(OUT, "reward.npz"),
+             **{k: np.array(v) for k, v in cases.items()},
+             **{"expert_" + k: v for k, v in expert.items()},
+             episode_len=cfg.env_episode_len, dt=dt,
+             wset_json=np.array([yaml.safe_dump(w) for w in wsets]))
+
+    # ------------------------------------------------------------------ G6 GAE
+    N = 4096
+    rewards = rng.uniform(0, 1.2, size=N)
+    masks = np.ones(N)
+    pos = 0
+    while pos < N:
+        pos += int(rng.randint(3, 330))
+        if pos - 1 < N:
+            masks[pos - 1] = 0
+    masks[-1] = 0
+    values = rng.normal(size=(N, 1)) * 3
+    adv, ret = estimate_advantages(torch.from_numpy(rewards), torch.from_numpy(masks), torch.from_numpy(values), 0.95, 0.95)
+    # a second case whose last episode is cut by the batch end (mask==1 at the tail)
+    masks2 = masks.copy()
+    masks2[-1] = 1
+    adv2, ret2 = estimate_advantages(torch.from_numpy(rewards), torch.from_numpy(masks2), torch.from_numpy(values), 0.99, 0.9)
+    np.savez(os.path.join(OUT, "gae.npz"), rewards=rewards, masks=masks, values=values, adv=adv.numpy(), ret=ret.numpy(),
+             masks2=masks2, adv2=adv2.numpy(), ret2=ret2.numpy(), gamma=0.95, tau=0.95, gamma2=0.99, tau2=0.9)
+
+    # ------------------------------------------------------------------ G7 ZFilter
+    zf = ZFilter((115,), clip=5)
+    X = rng.normal(size=(300, 115)) * rng.uniform(0.1, 4.0, size=115) + rng.normal(size=115)
+    X[:, 7] = 0.25                                     # constant column: std -> 0
+    Y = np.stack([zf(x) for x in X])
+    Yfrozen = np.stack([zf(x, update=False) for x in X[:16]])
+    zf1 = ZFilter((115,), clip=5)
+    y_first = zf1(X[0])                                # n == 1 branch (var = mean^2)
+    np.savez(os.path.join(OUT, "zfilter.npz"), X=X, Y=Y, mean=zf.rs.mean, std=zf.rs.std, n=zf.rs.n, S=zf.rs._S,
+             Yfrozen=Yfrozen, y_first=y_first)
+
+    # ------------------------------------------------------------------ G13 VideoStateNet test-mode / G8 train-mode init / G14 policy
+    torch.manual_seed(7)
+    cdim, hdim, margin, T_ep = 8, 16, 3, 12
+    vs = VideoStateNet(cdim, hdim, margin, 'lstm', None, False)
+    sd = {k: v.numpy().copy() for k, v in vs.state_dict().items()}
+    win = rng.normal(size=(T_ep + 2 * margin, cdim))
+    vs.set_mode('test')
+    with torch.no_grad():
+        vs.initialize(torch.tensor(win))
+        v_out = vs.v_out.numpy().copy()
+        st = torch.tensor(rng.normal(size=(1, 5)))
+        cat0 = vs(st).numpy().copy()
+        cat1 = vs(st).numpy().copy()
+    # train-mode init on a small flat batch
+    cnn_feat = [rng.normal(size=(60, cdim)), rng.normal(size=(50, cdim))]
+    ep_lens = [12, 5, 9, 12, 1, 7]
+    masks_t, v_metas = [], []
+    for L_ep in ep_lens:
+        e_ind = int(rng.randint(2))
+        s_ind = int(rng.randint(margin, cnn_feat[e_ind].shape[0] - T_ep - margin))
+        for k in range(L_ep):
+            masks_t.append(0.0 if k == L_ep - 1 else 1.0)
+            v_metas.append([e_ind, s_ind])
+    masks_t = torch.tensor(masks_t)
+    v_metas = np.array(v_metas)
+    vs.set_mode('train')
+    vs.initialize((masks_t, cnn_feat, v_metas))
+    states_t = torch.tensor(rng.normal(size=(len(masks_t), 5)))
+    with torch.no_grad():
+        train_out = vs(states_t).numpy().copy()
+    np.savez(os.path.join(OUT, "video_state_net.npz"), win=win, v_out=v_out, st=st.numpy(), cat0=cat0, cat1=cat1,
+             cnn_feat0=cnn_feat[0], cnn_feat1=cnn_feat[1], masks=masks_t.numpy(), v_metas=v_metas,
+             indices=vs.indices, cnn_feat_ctx=vs.cnn_feat_ctx.numpy(), states=states_t.numpy(), train_out=train_out,
+             cdim=cdim, hdim=hdim, margin=margin, **{"sd_" + k: v for k, v in sd.items()})
+
+    torch.manual_seed(11)
+    pol = PolicyGaussian(MLP(13, [10, 6], 'relu'), 4, log_std=-2.3, fix_std=True)
+    val = Value(MLP(13, [10, 6], 'relu'))
+    xs = torch.tensor(rng.normal(size=(9, 13)))
+    acts = torch.tensor(rng.normal(size=(9, 4)) * 0.2)
+    with torch.no_grad():
+        dist = pol(xs)
+        np.savez(os.path.join(OUT, "policy_value.npz"), x=xs.numpy(), a=acts.numpy(), mean=dist.loc.numpy(),
+                 std=dist.scale.numpy(), logp=pol.get_log_prob(xs, acts).numpy(), value=val(xs).numpy(),
+                 **{"pol_" + k: v.numpy() for k, v in pol.state_dict().items()},
+                 **{"val_" + k: v.numpy() for k, v in val.state_dict().items()})
+
+    # ------------------------------------------------------------------ G9 AgentEgo.update_params on a small batch
+    torch.manual_seed(3)
+    sdim, adim, cdim, hdim, margin, T_ep = 9, 4, 6, 8, 2, 10
+    p_vs = VideoStateNet(cdim, hdim, margin, 'lstm', None, False)
+    v_vs = VideoStateNet(cdim, hdim, margin, 'lstm', None, False)
+    p_net = PolicyGaussian(MLP(sdim + hdim, [12, 10], 'relu'), adim, log_std=-1.0, fix_std=True)
+    v_net = Value(MLP(sdim + hdim, [12, 10], 'relu'))
+    init_sd = {"p_vs": p_vs.state_dict(), "v_vs": v_vs.state_dict(), "p": p_net.state_dict(), "v": v_net.state_dict()}
+    init_np = {"%s__%s" % (a, k): v.numpy().copy() for a, d in init_sd.items() for k, v in d.items()}
+    p_params = list(p_net.parameters()) + list(p_vs.parameters())
+    v_params = list(v_net.parameters()) + list(v_vs.parameters())
+    opt_p = torch.optim.Adam(p_params, lr=5e-3)
+    opt_v = torch.optim.Adam(v_params, lr=3e-3)
+    cnn_feat = [rng.normal(size=(40, cdim)), rng.normal(size=(36, cdim))]
+    fenv = types.SimpleNamespace(cnn_feat=cnn_feat)
+    agent = AgentEgo(env=fenv, dtype=torch.float64, device=torch.device('cpu'), running_state=None,
+                     custom_reward=None, mean_action=False, render=False, num_threads=1,
+                     policy_net=p_net, policy_vs_net=p_vs, value_net=v_net, value_vs_net=v_vs,
+                     optimizer_policy=opt_p, optimizer_value=opt_v, opt_num_epochs=3,
+                     gamma=0.95, tau=0.95, clip_epsilon=0.2, policy_grad_clip=[(p_params, 0.5)])
+    ep_lens = [10, 4, 7, 10, 2, 10, 5]
+    rows = dict(states=[], actions=[], masks=[], rewards=[], exps=[], v_metas=[])
+    for L_ep in ep_lens:
+        e_ind = int(rng.randint(2))
+        s_ind = int(rng.randint(margin, cnn_feat[e_ind].shape[0] - T_ep - margin))
+        for k in range(L_ep):
+            rows['states'].append(rng.normal(size=sdim)); rows['actions'].append(rng.normal(size=adim) * 0.5)
+            rows['masks'].append(0 if k == L_ep - 1 else 1); rows['rewards'].append(rng.uniform(0, 1))
+            rows['exps'].append(1 if rng.uniform() < 0.8 else 0); rows['v_metas'].append([e_ind, s_ind])
+    batch = types.SimpleNamespace(**{k: np.array(v) for k, v in rows.items()})
+    # record intermediate quantities by re-running the first half by hand on copies
+    import copy
+    snap = copy.deepcopy((p_vs, v_vs, p_net, v_net))
+    s_p_vs, s_v_vs, s_p, s_v = snap
+    st_t = torch.from_numpy(batch.states); ac_t = torch.from_numpy(batch.actions)
+    mk_t = torch.from_numpy(batch.masks).to(torch.float64); rw_t = torch.from_numpy(batch.rewards)
+    for m in (s_p_vs, s_v_vs):
+        m.set_mode('train'); m.initialize((mk_t, cnn_feat, batch.v_metas))
+    with torch.no_grad():
+        values0 = s_v(s_v_vs(st_t))
+        adv0, ret0 = estimate_advantages(rw_t, mk_t, values0, 0.95, 0.95)
+        logp0 = s_p.get_log_prob(s_p_vs(st_t), ac_t)
+    agent.update_params(batch)
+    final_np = {}
+    for a, mod in [("p_vs", p_vs), ("v_vs", v_vs), ("p", p_net), ("v", v_net)]:
+        for k, v in mod.state_dict().items():
+            final_np["final_%s__%s" % (a, k)] = v.detach().numpy().copy()
+    np.savez(os.path.join(OUT, "ppo_update.npz"), cnn_feat0=cnn_feat[0], cnn_feat1=cnn_feat[1],
+             **{k: v for k, v in vars(batch).items()}, values0=values0.numpy(), adv0=adv0.numpy(), ret0=ret0.numpy(),
+             logp0=logp0.numpy(), dims=np.array([sdim, adim, cdim, hdim, margin, T_ep]),
+             **{"init_" + k: v for k, v in init_np.items()}, **final_np)
+
+    # ------------------------------------------------------------------ G10 LoggerRL.merge
+    logs = []
+    for w in range(3):
+        lg = LoggerRL()
+        for ep in range(2 + w):
+            lg.start_episode(None)
+            for s in range(int(rng.randint(2, 9))):
+                lg.step(None, 1.0, float(rng.uniform(0, 1)), rng.uniform(0, 1, size=5))
+            lg.end_episode(None)
+        lg.end_sampling()
+        logs.append(lg)
+    mg = LoggerRL.merge(logs)
+    fields = ["num_steps", "num_episodes", "total_reward", "min_episode_reward", "max_episode_reward",
+              "total_c_reward", "min_c_reward", "max_c_reward", "avg_episode_reward", "avg_c_reward"]
+    np.savez(os.path.join(OUT, "logger_merge.npz"),
+             per_worker=np.array([[getattr(l, f) for f in fields] for l in logs], float),
+             per_worker_c_info=np.stack([l.total_c_info for l in logs]),
+             merged=np.array([getattr(mg, f) for f in fields], float), merged_avg_c_info=mg.avg_c_info,
+             fields=np.array(fields))
+
+    # ------------------------------------------------------------------ G11 Agent.sample semantics on a toy env
+    class ToyEnv:
+        """Deterministic 3-dim linear env with variable-length episodes (ends when |x0| > 1.5 or t >= 7)."""
+        def __init__(self):
+            self.np_random = np.random.RandomState(5)
+            self.t = 0
+            self.x = None
+        def reset(self):
+            self.t = 0
+            self.x = self.np_random.uniform(-1, 1, size=3)
+            return self.x.copy()
+        def step(self, a):
+            self.t += 1
+            self.x = 0.9 * self.x + np.array([a[0], a[1], a[0] - a[1]])
+            done = bool(abs(self.x[0]) > 1.5 or self.t >= 7)
+            return self.x.copy(), 1.0, done, {'end': self.t >= 7, 'fail': abs(self.x[0]) > 1.5}
+    torch.manual_seed(21)
+    np.random.seed(21)
+    tp = PolicyGaussian(MLP(3, [8], 'tanh'), 2, log_std=-0.5)
+    toy_sd = {k: v.numpy().copy() for k, v in tp.state_dict().items()}
+    rs = ZFilter((3,), clip=5)
+
+    def toy_reward(env_, state, action, info):
+        return float(np.exp(-np.sum(np.square(action)))), np.array([float(state[0]), float(action[0])])
+    ag = Agent(env=ToyEnv(), policy_net=tp, value_net=None, dtype=torch.float64, device=torch.device('cpu'),
+               custom_reward=toy_reward, running_state=rs, num_threads=2)
+    multiprocessing.set_start_method('fork', force=True)
+    torch.manual_seed(33)
+    np.random.seed(33)
+    tb, lg = ag.sample(41)
+    np.savez(os.path.join(OUT, "sampler_toy.npz"), states=tb.states, actions=tb.actions, masks=tb.masks,
+             next_states=tb.next_states, rewards=tb.rewards, exps=tb.exps, num_steps=lg.num_steps,
+             num_episodes=lg.num_episodes, avg_c_reward=lg.avg_c_reward, avg_c_info=lg.avg_c_info,
+             rs_n=rs.rs.n, rs_mean=rs.rs.mean, rs_S=rs.rs._S,
+             **{"pol_" + k: v for k, v in toy_sd.items()})
+
+    # ------------------------------------------------------------------ G12 eval metrics
+    traj = e_qpos[:30].copy()
+    ja = rmetrics.get_joint_angles(traj)
+    jv = rmetrics.get_joint_vels(traj, dt)
+    jacc = rmetrics.get_joint_accels(jv, dt)
+    traj2 = traj + rng.normal(size=traj.shape) * 0.01
+    ja2 = rmetrics.get_joint_angles(traj2)
+    np.savez(os.path.join(OUT, "metrics.npz"), traj=traj, traj2=traj2, angles=ja, vels=jv, accels=jacc, dt=dt,
+             mean_dist=rmetrics.get_mean_dist(ja, ja2), mean_abs=rmetrics.get_mean_abs(jacc))
+
+    os.chdir(REPO)
+    shutil.rmtree(wd, ignore_errors=True)
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("wrote", sorted(os.listdir(OUT)), "total %.1f kB" % (tot / 1024))
+
+
+if __name__ == "__main__":
+    main()
