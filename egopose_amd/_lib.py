@@ -1,0 +1,153 @@
+"""ctypes binding of libegopose_hip.so (the C-ABI in include/egopose_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a symbol cannot be
+resolved this module raises, loudly, at import of the first function that needs it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libegopose_hip.so")
+
+EGP_OK = 0
+EGP_EXPERT_ROW = 168
+
+c_int_p = C.POINTER(C.c_int32)
+c_dbl_p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("nq", C.c_int32), ("nv", C.c_int32), ("nu", C.c_int32), ("nbody", C.c_int32), ("nM", C.c_int32),
+        ("body_qpos_start", c_int_p), ("body_ndof", c_int_p), ("dof_parentid", c_int_p), ("dof_Madr", c_int_p),
+        ("ee_body", c_int_p),
+        ("jkp", c_dbl_p), ("jkd", c_dbl_p), ("a_ref", c_dbl_p), ("a_scale", c_dbl_p), ("torque_lim", c_dbl_p),
+        ("b_diffw", c_dbl_p),
+        ("sub_dt", C.c_double), ("frame_skip", C.c_int32), ("episode_len", C.c_int32),
+        ("w_p", C.c_double), ("w_v", C.c_double), ("w_e", C.c_double), ("w_rp", C.c_double), ("w_rv", C.c_double),
+        ("k_p", C.c_double), ("k_v", C.c_double), ("k_e", C.c_double), ("k_rh", C.c_double), ("k_rq", C.c_double),
+        ("k_rl", C.c_double), ("k_ra", C.c_double),
+        ("v_ord", C.c_double), ("decay", C.c_int32),
+    ]
+
+
+class ExpertTable(C.Structure):
+    _fields_ = [
+        ("n_takes", C.c_int32), ("n_frames", C.c_int32), ("take_offset", c_int_p),
+        ("qpos", c_dbl_p), ("qvel", c_dbl_p), ("rlinv_local", c_dbl_p), ("rangv", c_dbl_p), ("rq_rmh", c_dbl_p),
+        ("ee_pos", c_dbl_p), ("bquat", c_dbl_p), ("bangvel", c_dbl_p), ("head_height_lb", c_dbl_p),
+    ]
+
+
+class SurrogateDesc(C.Structure):
+    _fields_ = [
+        ("nq", C.c_int32), ("nv", C.c_int32), ("nu", C.c_int32), ("nbody", C.c_int32), ("nM", C.c_int32),
+        ("njoint", C.c_int32),
+        ("qM0", c_dbl_p), ("Minv0", c_dbl_p), ("body_parent", c_int_p), ("body_pos", c_dbl_p), ("body_ndof", c_int_p),
+        ("joint_axis", c_dbl_p), ("joint_anchor", c_dbl_p),
+        ("sub_dt", C.c_double), ("damping", C.c_double), ("support_k", C.c_double), ("support_c", C.c_double),
+    ]
+
+
+class EngineDesc(C.Structure):
+    _fields_ = [("n_env", C.c_int32), ("n_threads", C.c_int32), ("n_groups", C.c_int32)]
+
+
+PHYS_RESET = C.CFUNCTYPE(C.c_int, vp, C.c_int32, c_dbl_p, c_dbl_p)
+PHYS_STEP = C.CFUNCTYPE(C.c_int, vp, C.c_int32, c_dbl_p)
+PHYS_DRAIN = C.CFUNCTYPE(C.c_int, vp, C.c_int32, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p)
+PHYS_DESTROY = C.CFUNCTYPE(None, vp)
+
+
+class PhysicsVtable(C.Structure):
+    _fields_ = [("user", vp), ("reset", PHYS_RESET), ("step", PHYS_STEP), ("drain", PHYS_DRAIN),
+                ("destroy", PHYS_DESTROY), ("name", C.c_char_p)]
+
+
+# name -> (restype, argtypes); must list every symbol include/egopose_hip.h declares
+_i32, _i64, _f64 = C.c_int32, C.c_int64, C.c_double
+SIGNATURES = {
+    "egp_last_error": (C.c_char_p, []),
+    "egp_version": (C.c_char_p, []),
+    "egp_create": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(vp)]),
+    "egp_destroy": (C.c_int, [vp]),
+    "egp_set_reward_weights": (C.c_int, [vp, C.POINTER(ModelDesc)]),
+    "egp_set_pd_variant": (C.c_int, [vp, C.c_int]),
+    "egp_upload_experts": (C.c_int, [vp, C.POINTER(ExpertTable)]),
+    "egp_body_quat_f64": (C.c_int, [vp, vp, _i32, vp, vp]),
+    "egp_body_quat_f32": (C.c_int, [vp, vp, _i32, vp, vp]),
+    "egp_obs_f64": (C.c_int, [vp, vp, vp, _i32, vp, vp]),
+    "egp_obs_f32": (C.c_int, [vp, vp, vp, _i32, vp, vp]),
+    "egp_pd_torque_f64": (C.c_int, [vp, vp, vp, vp, vp, vp, _i32, vp, vp, vp]),
+    "egp_pd_torque_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, _i32, vp, vp, vp]),
+    "egp_reward_quat_v3_f64": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, _f64, _i32, vp, vp, vp]),
+    "egp_reward_quat_v3_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, _f64, _i32, vp, vp, vp]),
+    "egp_zfilter_workspace_bytes": (_i64, [_i32, _i32]),
+    "egp_zfilter_f64": (C.c_int, [vp, vp, _i32, _i32, vp, vp, _i32, _f64, vp, vp, vp]),
+    "egp_zfilter_f32": (C.c_int, [vp, vp, _i32, _i32, vp, vp, _i32, _f64, vp, vp, vp]),
+    "egp_gae_workspace_bytes": (_i64, [_i32]),
+    "egp_gae_f64": (C.c_int, [vp, vp, vp, _i32, _f64, _f64, vp, vp, vp, vp, vp]),
+    "egp_gae_f32": (C.c_int, [vp, vp, vp, _i32, _f64, _f64, vp, vp, vp, vp, vp]),
+    "egp_gae_standardize_f64": (C.c_int, [vp, _i32, vp, vp]),
+    "egp_gae_standardize_f32": (C.c_int, [vp, _i32, vp, vp]),
+    "egp_physics_register": (C.c_int, [C.POINTER(PhysicsVtable), _i32, C.POINTER(vp)]),
+    "egp_physics_create_surrogate": (C.c_int, [C.POINTER(SurrogateDesc), _i32, C.POINTER(vp)]),
+    "egp_physics_destroy": (C.c_int, [vp]),
+    "egp_physics_name": (C.c_char_p, [vp]),
+    "egp_physics_n_env": (_i32, [vp]),
+    "egp_physics_reset_host": (C.c_int, [vp, _i32, vp, vp]),
+    "egp_physics_step_host": (C.c_int, [vp, _i32, vp]),
+    "egp_physics_drain_host": (C.c_int, [vp, _i32, vp, vp, vp, vp, vp]),
+    "egp_engine_create": (C.c_int, [vp, vp, C.POINTER(EngineDesc), C.POINTER(vp)]),
+    "egp_engine_destroy": (C.c_int, [vp]),
+    "egp_engine_state": (C.c_int, [vp] + [C.POINTER(vp)] * 6),
+    "egp_engine_reset": (C.c_int, [vp, vp, _i32, vp, vp, vp]),
+    "egp_engine_step_async": (C.c_int, [vp, _i32, vp, vp, vp]),
+    "egp_engine_wait": (C.c_int, [vp, _i32, vp]),
+    "egp_engine_timing": (C.c_int, [vp, c_dbl_p, c_dbl_p, c_dbl_p, C.POINTER(_i64)]),
+    "egp_engine_reset_timing": (C.c_int, [vp]),
+    "egp_engine_set_profile": (C.c_int, [vp, C.c_int]),
+    "egp_engine_layout": (C.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p]),
+    "egp_engine_group_range": (C.c_int, [vp, _i32, c_int_p, c_int_p]),
+}
+
+_lib = None
+
+
+class EgpError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library and type every entry point. Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EgpError(
+            "egopose_amd: %s is missing -- build it with `python -m egopose_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise EgpError("egopose_amd: symbol %s not exported by %s" % (name, LIB_PATH)) from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    """C status -> Python exception (ValueError for bad arguments, RuntimeError otherwise)."""
+    if rc == EGP_OK:
+        return
+    msg = load().egp_last_error().decode("utf-8", "replace")
+    text = "%s failed (%d): %s" % (what or "egp call", rc, msg)
+    if rc == -1:
+        raise ValueError(text)
+    raise EgpError(text)

@@ -1,0 +1,74 @@
+// Internal declarations shared by the kernel, physics and engine translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/egopose_hip.h"
+
+namespace egp {
+
+void set_error(const char *fmt, ...);
+
+#define EGP_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            egp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return EGP_E_HIP;                                                                \
+        }                                                                                    \
+    } while (0)
+
+#define EGP_REQUIRE(cond, msg)                       \
+    do {                                             \
+        if (!(cond)) {                               \
+            egp::set_error("invalid argument: %s", msg); \
+            return EGP_E_INVALID;                    \
+        }                                            \
+    } while (0)
+
+// Reward coefficients, passed to the kernel by value (SGPR-resident).
+struct RewardW {
+    double w_p, w_v, w_e, w_rp, w_rv, w_sum;
+    double k_p, k_v, k_e, k_rh, k_rq, k_rl, k_ra;
+    double v_ord;
+    int decay;
+    int episode_len;
+};
+
+// Device-side view of the model: small read-only tables the kernels stage in LDS.
+struct DevModel {
+    int nq, nv, nu, nbody, nM;
+    const int *body_qpos_start;   // [nbody]
+    const int *body_ndof;         // [nbody]
+    const int *m_row;             // [nM] row of sparse-inertia entry
+    const int *m_col;             // [nM] col
+    const short *m_map;           // [nv*nv] dense (i,j) -> index into qM, or -1
+    const double *jkp, *jkd, *a_ref, *a_scale, *torque_lim;   // [nu]
+    const double *b_diffw;        // [nbody-1]
+    double sub_dt;                // model timestep
+    double dt;                    // env step = frame_skip * sub_dt
+};
+
+}  // namespace egp
+
+struct egp_ctx {
+    int device = 0;
+    egp::DevModel dm{};
+    egp::RewardW rw{};
+    int frame_skip = 15;
+    std::vector<int> ee_body;
+    std::vector<void *> allocs;        // every device allocation owned by the ctx
+    // expert table in HBM
+    int n_takes = 0, n_frames = 0;
+    double *expert_rows_f64 = nullptr; // [n_frames][EGP_EXPERT_ROW]
+    float *expert_rows_f32 = nullptr;
+    int pd_variant = 0;                // 0 = register Gauss-Jordan (nv==58), 1 = generic LDS kernel
+};
+
+// launches used by the engine (same TU as the kernels)
+int egp_launch_pd_torque_packed(egp_ctx *ctx, const double *pack, long pack_ld, int off_qpos, int off_qvel, int off_bias,
+                                int off_qM, const double *action, int32_t n, double *torque, hipStream_t stream);
+const egp_physics_vtable *egp_physics_vt(const egp_physics *p);
+extern "C" int32_t egp_physics_n_env(const egp_physics *p);

@@ -1,0 +1,903 @@
+// HIP kernels K1-K6 of the EgoPose rollout+update hot path for gfx950 (MI355X), plus the
+// context object and the C-ABI entry points declared in include/egopose_hip.h.
+//
+// Data layout: every per-env array is env-major and row-contiguous (qpos[n][59], qvel[n][58],
+// qM[n][910], ...), which is what the host physics writes and what TrajBatch exposes. Kernels
+// map work so that consecutive lanes touch consecutive addresses of one env row (or of adjacent
+// rows), and the shared skeleton tables (body->qpos map, dof tree, PD gains) are staged in LDS.
+//
+//   K1 pd_torque     one 64-lane wavefront per env, one dof per lane; MuJoCo sparse inertia is
+//                    expanded (mj_fullM) through LDS, the 58x58 system lives in VGPRs (lane i owns
+//                    row i) and is solved by in-register Gauss-Jordan with v_readlane broadcasts.
+//   K2 reward        one half-wavefront per env: lane = body (pose / body ang-vel terms), lane 0 =
+//                    root terms, 5 lanes = end effectors; width-32 butterfly reduction.
+//   K3 obs, K4 body_quat   one thread per output element / body.
+//   K5 gae           chunked affine-recurrence scan (3 launches) + Welford statistics.
+//   K6 zfilter       per-tile (count, mean, M2) partials + Chan merge + normalise.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "egp_internal.hpp"
+#include "egp_quat.hpp"
+
+namespace egp {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ============================================================================================ K4
+// get_body_quat (ego_pose/envs/humanoid_v1.py:113-125)
+template <typename T>
+__global__ __launch_bounds__(256) void k_body_quat(DevModel m, const T *__restrict__ qpos, int n,
+                                                   T *__restrict__ bquat) {
+    __shared__ int s_start[EGP_MAX_BODY], s_ndof[EGP_MAX_BODY];
+    if (threadIdx.x < m.nbody) {
+        s_start[threadIdx.x] = m.body_qpos_start[threadIdx.x];
+        s_ndof[threadIdx.x] = m.body_ndof[threadIdx.x];
+    }
+    __syncthreads();
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)n * m.nbody) return;
+    const int env = gid / m.nbody, b = gid % m.nbody;
+    const T *q = qpos + (long)env * m.nq;
+    Q4<T> o;
+    if (b == 0) {
+        o.w = q[3]; o.x = q[4]; o.y = q[5]; o.z = q[6];
+    } else {
+        const int s = s_start[b], nd = s_ndof[b];
+        const T e0 = nd > 0 ? q[s] : T(0), e1 = nd > 1 ? q[s + 1] : T(0), e2 = nd > 2 ? q[s + 2] : T(0);
+        o = q_from_euler_sxyz<T>(e0, e1, e2);
+    }
+    T *dst = bquat + gid * 4;
+    dst[0] = o.w; dst[1] = o.x; dst[2] = o.y; dst[3] = o.z;
+}
+
+// ============================================================================================ K3
+// get_full_obs (ego_pose/envs/humanoid_v1.py:73-96): obs = [qpos[2:] (root quat de-headed), qvel
+// (root linear velocity in the heading frame)]
+template <typename T>
+__global__ __launch_bounds__(256) void k_obs(DevModel m, const T *__restrict__ qpos, const T *__restrict__ qvel,
+                                             int n, T *__restrict__ obs) {
+    const int od = m.nq - 2 + m.nv;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)n * od) return;
+    const int env = gid / od, c = gid % od;
+    const T *q = qpos + (long)env * m.nq;
+    const T *v = qvel + (long)env * m.nv;
+    const int np = m.nq - 2;
+    T out;
+    if (c >= 1 && c <= 4) {
+        Q4<T> r{q[3], q[4], q[5], q[6]};
+        Q4<T> d = de_heading(r);
+        out = c == 1 ? d.w : (c == 2 ? d.x : (c == 3 ? d.y : d.z));
+    } else if (c < np) {
+        out = q[c + 2];
+    } else if (c < np + 3) {
+        Q4<T> r{q[3], q[4], q[5], q[6]};
+        V3<T> lv{v[0], v[1], v[2]};
+        V3<T> o = rotate_T(heading_q(r), lv);
+        const int k = c - np;
+        out = k == 0 ? o.x : (k == 1 ? o.y : o.z);
+    } else {
+        out = v[c - np];
+    }
+    obs[gid] = out;
+}
+
+// ============================================================================================ K1
+// compute_torque / compute_desired_accel (ego_pose/envs/humanoid_v1.py:130-156) + clip (:172)
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// row strides (in elements) of the five K1 inputs: dense C-ABI arrays use (nq, nv, nu, nM, nv); the
+// rollout engine passes its packed per-env staging row instead
+struct PdLd { long qpos, qvel, action, qM, bias; };
+
+template <typename TIO>
+__device__ __forceinline__ void pd_rhs(const DevModel &m, const PdLd &ld, const TIO *qpos, const TIO *qvel, const TIO *action,
+                                       const TIO *C, long env, int row, double &kp, double &kd, double &eq,
+                                       double &qv, double &b) {
+    kp = 0.0; kd = 0.0; eq = 0.0;
+    if (row >= 6) {
+        const int a = row - 6;
+        kp = m.jkp[a];
+        kd = m.jkd[a];
+        const double target = m.a_ref[a] + (double)action[env * ld.action + a] * m.a_scale[a];
+        eq = (double)qpos[env * ld.qpos + 7 + a] - target;
+    }
+    qv = (double)qvel[env * ld.qvel + row];
+    b = -(double)C[env * ld.bias + row] - kp * eq - kd * qv;
+}
+
+template <typename TIO>
+__device__ __forceinline__ void pd_store(const DevModel &m, long env, int row, bool owner, double kp, double kd,
+                                         double eq, double qv, double qacc, TIO *torque, TIO *torque_raw) {
+    if (owner && row >= 6) {
+        const int a = row - 6;
+        const double ev = qv + qacc * m.sub_dt;
+        const double tau = -kp * eq - kd * ev;
+        const double lim = m.torque_lim[a];
+        const double tc = fmin(fmax(tau, -lim), lim);
+        torque[env * m.nu + a] = (TIO)tc;
+        if (torque_raw) torque_raw[env * m.nu + a] = (TIO)tau;
+    }
+}
+
+// Fast path for the humanoid (nv == 58): 4 envs per 256-thread block, one wavefront each.
+constexpr int PD_NV = 58;
+constexpr int PD_NM_MAX = 960;   // >= nM (910)
+
+template <typename TIO>
+__global__ __launch_bounds__(256) void k_pd_torque_reg58(DevModel m, PdLd ld, const TIO *__restrict__ qpos,
+                                                         const TIO *__restrict__ qvel, const TIO *__restrict__ action,
+                                                         const TIO *__restrict__ qM, const TIO *__restrict__ C, int n,
+                                                         TIO *__restrict__ torque, TIO *__restrict__ torque_raw) {
+    __shared__ short s_map[PD_NV * PD_NV];        // dense (i,j) -> qM index: the dof tree, staged once per block
+    __shared__ double s_qM[4][PD_NM_MAX];         // this wave's sparse inertia
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < PD_NV * PD_NV; i += 256) s_map[i] = m.m_map[i];
+    const long env = (long)blockIdx.x * 4 + wave;
+    const bool valid = env < n;
+    if (valid) {
+        const TIO *src = qM + env * ld.qM;
+        for (int i = lane; i < m.nM; i += 64) s_qM[wave][i] = (double)src[i];
+    }
+    __syncthreads();
+    if (!valid) return;
+    const int row = lane < PD_NV ? lane : PD_NV - 1;   // spare lanes shadow the last row
+    double kp, kd, eq, qv, b;
+    pd_rhs<TIO>(m, ld, qpos, qvel, action, C, env, row, kp, kd, eq, qv, b);
+    const double kd_dt = kd * m.sub_dt;
+    // mj_fullM: lane `row` gathers its dense row from the sparse chain layout; + Kd*dt on the diagonal
+    double a[PD_NV];
+#pragma unroll
+    for (int j = 0; j < PD_NV; ++j) {
+        const int id = s_map[row * PD_NV + j];
+        double v = id >= 0 ? s_qM[wave][id] : 0.0;
+        a[j] = v + (j == row ? kd_dt : 0.0);
+    }
+    // Gauss-Jordan without pivoting (matrix is SPD): after step k column k is zero off the diagonal.
+    double dinv = 0.0;
+#pragma unroll
+    for (int k = 0; k < PD_NV; ++k) {
+        const double pk = readlane_f64(a[k], k);
+        const double inv = 1.0 / pk;
+        const bool me = row == k;
+        const double f = me ? 0.0 : a[k] * inv;
+        dinv = me ? inv : dinv;
+#pragma unroll
+        for (int j = k + 1; j < PD_NV; ++j) {
+            const double r = readlane_f64(a[j], k);
+            a[j] = fma(-f, r, a[j]);
+        }
+        const double bk = readlane_f64(b, k);
+        b = fma(-f, bk, b);
+    }
+    const double qacc = b * dinv;
+    pd_store<TIO>(m, env, row, lane < PD_NV, kp, kd, eq, qv, qacc, torque, torque_raw);
+}
+
+// Generic path (any nv <= 64): one wavefront per env, system in LDS.
+template <typename TIO>
+__global__ __launch_bounds__(64) void k_pd_torque_lds(DevModel m, PdLd ld, const TIO *__restrict__ qpos,
+                                                      const TIO *__restrict__ qvel, const TIO *__restrict__ action,
+                                                      const TIO *__restrict__ qM, const TIO *__restrict__ C, int n,
+                                                      TIO *__restrict__ torque, TIO *__restrict__ torque_raw) {
+    extern __shared__ double s_dyn[];
+    const int nv = m.nv, lda = nv + 1;
+    double *A = s_dyn;            // [nv][ld]
+    double *rhs = s_dyn + nv * lda; // [nv]
+    const int lane = threadIdx.x;
+    const long env = blockIdx.x;
+    const int row = lane < nv ? lane : nv - 1;
+    for (int i = lane; i < nv * lda; i += 64) A[i] = 0.0;
+    __syncthreads();
+    for (int i = lane; i < m.nM; i += 64) {
+        const int r = m.m_row[i], c = m.m_col[i];
+        const double v = (double)qM[env * ld.qM + i];
+        A[r * lda + c] = v;
+        A[c * lda + r] = v;
+    }
+    __syncthreads();
+    double kp, kd, eq, qv, b;
+    pd_rhs<TIO>(m, ld, qpos, qvel, action, C, env, row, kp, kd, eq, qv, b);
+    if (lane < nv) {
+        A[row * lda + row] += kd * m.sub_dt;
+        rhs[row] = b;
+    }
+    __syncthreads();
+    for (int k = 0; k < nv; ++k) {
+        const double pk = A[k * lda + k];
+        if (lane < nv && row != k) {
+            const double f = A[row * lda + k] / pk;
+            for (int j = k + 1; j < nv; ++j) A[row * lda + j] -= f * A[k * lda + j];
+            rhs[row] -= f * rhs[k];
+        }
+        __syncthreads();
+    }
+    const double qacc = rhs[row] / A[row * lda + row];
+    pd_store<TIO>(m, env, row, lane < nv, kp, kd, eq, qv, qacc, torque, torque_raw);
+}
+
+// ============================================================================================ K2
+// quat_space_reward_v3 (ego_pose/core/reward_function.py:4-60)
+// packed expert row: [0] qpos_z | [1:4] rlinv_local | [4:7] rangv | [7:11] rq_rmh | [11:26] ee_pos |
+//                    [26:26+4(nb-1)] bquat[4:] | [106:106+3(nb-1)] bangvel[3:]
+constexpr int ER_Z = 0, ER_RLINV = 1, ER_RANGV = 4, ER_RQ = 7, ER_EE = 11, ER_BQ = 26, ER_BAV = 106;
+
+template <typename T>
+__device__ __forceinline__ T half_wave_sum(T v) {
+    v += __shfl_xor(v, 16, 32);
+    v += __shfl_xor(v, 8, 32);
+    v += __shfl_xor(v, 4, 32);
+    v += __shfl_xor(v, 2, 32);
+    v += __shfl_xor(v, 1, 32);
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_reward_quat_v3(DevModel m, RewardW w, const T *__restrict__ expert_rows,
+                                                        const T *__restrict__ cur_qpos, const T *__restrict__ prev_qpos,
+                                                        const T *__restrict__ ee_wpos, const int *__restrict__ tcur,
+                                                        const int *__restrict__ frame, const int *__restrict__ endf,
+                                                        const int *__restrict__ active, T end_reward, int n,
+                                                        T *__restrict__ reward, T *__restrict__ cinfo) {
+    __shared__ int s_start[EGP_MAX_BODY], s_ndof[EGP_MAX_BODY];
+    __shared__ double s_bw[EGP_MAX_BODY];
+    if (threadIdx.x < m.nbody) {
+        s_start[threadIdx.x] = m.body_qpos_start[threadIdx.x];
+        s_ndof[threadIdx.x] = m.body_ndof[threadIdx.x];
+        s_bw[threadIdx.x] = threadIdx.x > 0 ? m.b_diffw[threadIdx.x - 1] : 0.0;
+    }
+    __syncthreads();
+    const long env = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int l = threadIdx.x & 31;
+    if (env >= n) return;
+    if (active && !active[env]) {
+        if (l == 0) {
+            reward[env] = T(0);
+            for (int k = 0; k < 5; ++k) cinfo[env * 5 + k] = T(0);
+        }
+        return;
+    }
+    const T *cq = cur_qpos + env * m.nq;
+    const T *pq = prev_qpos + env * m.nq;
+    const T *er = expert_rows + (long)frame[env] * EGP_EXPERT_ROW;
+    const T dt = (T)m.dt;
+    T pose_sq = T(0), vel_acc = T(0), ee_sq = T(0);
+    T rp_r = T(0), rv_r = T(0);
+    if (l >= 1 && l < m.nbody) {
+        // body lanes: orientation + angular-velocity terms of one non-root body
+        const int s = s_start[l], nd = s_ndof[l];
+        const T c0 = nd > 0 ? cq[s] : T(0), c1 = nd > 1 ? cq[s + 1] : T(0), c2 = nd > 2 ? cq[s + 2] : T(0);
+        const T p0 = nd > 0 ? pq[s] : T(0), p1 = nd > 1 ? pq[s + 1] : T(0), p2 = nd > 2 ? pq[s + 2] : T(0);
+        const Q4<T> qc = q_from_euler_sxyz<T>(c0, c1, c2);
+        const Q4<T> qp = q_from_euler_sxyz<T>(p0, p1, p2);   // == env.prev_bquat (humanoid_v1.py:184,188)
+        const T *eb = er + ER_BQ + 4 * (l - 1);
+        const Q4<T> qe{eb[0], eb[1], eb[2], eb[3]};
+        const Q4<T> d = qmul(qc, qinv(qe));
+        const T pd = t_acos<T>(clamp1<T>(d.w)) * (T)s_bw[l];
+        pose_sq = pd * pd;
+        const Q4<T> dv = qmul(qc, qinv(qp));
+        V3<T> ax; T ang;
+        rot_axis_angle<T>(dv, &ax, &ang);
+        const T *ev = er + ER_BAV + 3 * (l - 1);
+        const T dx = ax.x * ang / dt - ev[0], dy = ax.y * ang / dt - ev[1], dz = ax.z * ang / dt - ev[2];
+        if (w.v_ord == 2.0) {
+            vel_acc = dx * dx + dy * dy + dz * dz;
+        } else {
+            const T p = (T)w.v_ord;
+            vel_acc = t_pow<T>(fabs(dx), p) + t_pow<T>(fabs(dy), p) + t_pow<T>(fabs(dz), p);
+        }
+    } else if (l == 0) {
+        // root lane: finite-difference root velocity (utils/math.py:20-35) + root pose
+        const Q4<T> rc{cq[3], cq[4], cq[5], cq[6]};
+        const Q4<T> rp{pq[3], pq[4], pq[5], pq[6]};
+        V3<T> v{(cq[0] - pq[0]) / dt, (cq[1] - pq[1]) / dt, (cq[2] - pq[2]) / dt};
+        const Q4<T> qrel = qmul(rc, qinv(rp));
+        V3<T> ax; T ang;
+        rot_axis_angle<T>(qrel, &ax, &ang);
+        const T pi = T(3.14159265358979323846);
+        if (ang > pi) ang -= T(2) * pi;
+        else if (ang < -pi) ang += T(2) * pi;
+        V3<T> rvw{ax.x * ang / dt, ax.y * ang / dt, ax.z * ang / dt};
+        const V3<T> rv = rotate_T(rp, rvw);                 // angular velocity in the (previous) root frame
+        const V3<T> vl = rotate_T(heading_q(rp), v);        // linear velocity in the (previous) heading frame
+        const T dl = (vl.x - er[ER_RLINV]) * (vl.x - er[ER_RLINV]) + (vl.y - er[ER_RLINV + 1]) * (vl.y - er[ER_RLINV + 1]) +
+                     (vl.z - er[ER_RLINV + 2]) * (vl.z - er[ER_RLINV + 2]);
+        const T da = (rv.x - er[ER_RANGV]) * (rv.x - er[ER_RANGV]) + (rv.y - er[ER_RANGV + 1]) * (rv.y - er[ER_RANGV + 1]) +
+                     (rv.z - er[ER_RANGV + 2]) * (rv.z - er[ER_RANGV + 2]);
+        rv_r = t_exp<T>(-(T)w.k_rl * dl - (T)w.k_ra * da);
+        const Q4<T> rq = de_heading(rc);
+        const Q4<T> erq{er[ER_RQ], er[ER_RQ + 1], er[ER_RQ + 2], er[ER_RQ + 3]};
+        const T dq = t_acos<T>(clamp1<T>(qmul(rq, qinv(erq)).w));
+        const T dh = cq[2] - er[ER_Z];
+        rp_r = t_exp<T>(-(T)w.k_rh * dh * dh - (T)w.k_rq * dq * dq);
+    } else if (l < m.nbody + 5) {
+        // end-effector lanes: root-relative position in the heading frame (humanoid_v1.py:98-111)
+        const int k = l - m.nbody;
+        const Q4<T> rc{cq[3], cq[4], cq[5], cq[6]};
+        const T *wp = ee_wpos + env * 15 + 3 * k;
+        V3<T> rel{wp[0] - cq[0], wp[1] - cq[1], wp[2] - cq[2]};
+        const V3<T> o = rotate_T(heading_q(rc), rel);
+        const T *ee = er + ER_EE + 3 * k;
+        ee_sq = (o.x - ee[0]) * (o.x - ee[0]) + (o.y - ee[1]) * (o.y - ee[1]) + (o.z - ee[2]) * (o.z - ee[2]);
+    }
+    pose_sq = half_wave_sum<T>(pose_sq);
+    vel_acc = half_wave_sum<T>(vel_acc);
+    ee_sq = half_wave_sum<T>(ee_sq);
+    if (l == 0) {
+        const T pose_r = t_exp<T>(-(T)w.k_p * pose_sq);
+        T vel_sq = vel_acc;
+        if (w.v_ord != 2.0) vel_sq = t_pow<T>(vel_acc, T(2) / (T)w.v_ord);
+        const T vel_r = t_exp<T>(-(T)w.k_v * vel_sq);
+        const T ee_r = t_exp<T>(-(T)w.k_e * ee_sq);
+        T r = ((T)w.w_p * pose_r + (T)w.w_v * vel_r + (T)w.w_e * ee_r + (T)w.w_rp * rp_r + (T)w.w_rv * rv_r) / (T)w.w_sum;
+        if (w.decay) r *= T(1) - (T)tcur[env] / (T)w.episode_len;
+        if (endf[env]) r += end_reward;
+        reward[env] = r;
+        T *ci = cinfo + env * 5;
+        ci[0] = pose_r; ci[1] = vel_r; ci[2] = ee_r; ci[3] = rp_r; ci[4] = rv_r;
+    }
+}
+
+// ============================================================================================ K6
+// RunningStat / ZFilter (utils/zfilter.py:7-67), batched.
+// partial layout per tile p: ws[p*(1+2*dim)] = count, then mean[dim], then M2[dim]  (float64)
+template <typename T>
+__global__ __launch_bounds__(128) void k_zf_partial(const T *__restrict__ x, const int *__restrict__ active, int n, int dim,
+                                                    int rows_per_tile, double *__restrict__ ws) {
+    const int p = blockIdx.x;
+    const int r0 = p * rows_per_tile, r1 = min(n, r0 + rows_per_tile);
+    double *out = ws + (long)p * (1 + 2 * dim);
+    int cnt = 0;
+    for (int r = r0; r < r1; ++r) cnt += (!active || active[r]) ? 1 : 0;
+    if (threadIdx.x == 0) out[0] = (double)cnt;
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+        double s = 0.0;
+        for (int r = r0; r < r1; ++r)
+            if (!active || active[r]) s += (double)x[(long)r * dim + c];
+        const double mean = cnt > 0 ? s / cnt : 0.0;
+        double m2 = 0.0;
+        for (int r = r0; r < r1; ++r)
+            if (!active || active[r]) {
+                const double d = (double)x[(long)r * dim + c] - mean;
+                m2 += d * d;
+            }
+        out[1 + c] = mean;
+        out[1 + dim + c] = m2;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void k_zf_apply(const T *__restrict__ x, int n, int dim, int rows_per_tile, int n_tiles,
+                                                  const double *__restrict__ ws, const double *__restrict__ st_in,
+                                                  double *__restrict__ st_out, int update, double clip,
+                                                  T *__restrict__ y) {
+    extern __shared__ double s_ms[];   // mean[dim], inv[dim]
+    const int p = blockIdx.x;
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+        double cnt = st_in[0], mean = st_in[1 + c], S = st_in[1 + dim + c];
+        if (update) {
+            for (int q = 0; q < n_tiles; ++q) {   // Chan merge, fixed order -> deterministic
+                const double *pp = ws + (long)q * (1 + 2 * dim);
+                const double nb = pp[0];
+                if (nb > 0.0) {
+                    const double mb = pp[1 + c], Sb = pp[1 + dim + c];
+                    if (cnt == 0.0) {
+                        cnt = nb; mean = mb; S = Sb;
+                    } else {
+                        const double d = mb - mean, tot = cnt + nb;
+                        S = S + Sb + d * d * (cnt * nb / tot);
+                        mean = mean + d * (nb / tot);
+                        cnt = tot;
+                    }
+                }
+            }
+            if (p == 0) {
+                st_out[1 + c] = mean;
+                st_out[1 + dim + c] = S;
+                if (c == 0) st_out[0] = cnt;
+            }
+        }
+        const double var = cnt > 1.0 ? S / (cnt - 1.0) : mean * mean;
+        s_ms[c] = mean;
+        s_ms[dim + c] = 1.0 / (sqrt(var) + 1e-8);
+    }
+    __syncthreads();
+    const int r0 = p * rows_per_tile, r1 = min(n, r0 + rows_per_tile);
+    const long e0 = (long)r0 * dim, e1 = (long)r1 * dim;
+    for (long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+        const int c = e % dim;
+        double v = ((double)x[e] - s_ms[c]) * s_ms[dim + c];
+        if (clip > 0.0) v = fmin(fmax(v, -clip), clip);
+        y[e] = (T)v;
+    }
+}
+
+// ============================================================================================ K5
+// estimate_advantages (core/common.py:5-25):  a_i = delta_i + (gamma*tau*m_i) a_{i+1},
+// delta_i = r_i + gamma*m_i*v_{i+1} - v_i   (v_N = a_N = 0; one reverse sweep over the flat batch).
+// Affine recurrence -> chunk summaries (P, A) -> block scan over chunks -> per-chunk replay.
+constexpr int GAE_CHUNK = 32;
+
+template <typename T>
+__device__ __forceinline__ void gae_coeffs(const T *r, const T *mk, const T *v, int i, int n, double gamma, double gt,
+                                           double &delta, double &c) {
+    const double mi = (double)mk[i];
+    const double vn = i + 1 < n ? (double)v[i + 1] : 0.0;
+    delta = (double)r[i] + gamma * vn * mi - (double)v[i];
+    c = gt * mi;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gae_summary(const T *__restrict__ r, const T *__restrict__ mk,
+                                                     const T *__restrict__ v, int n, double gamma, double gt,
+                                                     double *__restrict__ chunkP, double *__restrict__ chunkA) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i0 = ch * GAE_CHUNK;
+    if (i0 >= n) return;
+    const int i1 = min(n, i0 + GAE_CHUNK);
+    double P = 1.0, A = 0.0;
+    for (int i = i1 - 1; i >= i0; --i) {
+        double d, c;
+        gae_coeffs<T>(r, mk, v, i, n, gamma, gt, d, c);
+        A = d + c * A;      // value at i given zero carry
+        P = c * P;          // sensitivity of a_i0 to the carry entering the chunk
+    }
+    chunkP[ch] = P;
+    chunkA[ch] = A;
+}
+
+// one block: carry[ch] = a at the first element of chunk ch+1 (0 for the last chunk)
+__global__ __launch_bounds__(1024) void k_gae_scan(int n_chunks, const double *__restrict__ chunkP,
+                                                   const double *__restrict__ chunkA, double *__restrict__ carry) {
+    __shared__ double sP[1024], sA[1024];
+    const int t = threadIdx.x;
+    const int per = (n_chunks + 1023) / 1024;
+    // thread t owns chunks [hi-per+1 .. hi] counted from the END of the array (reverse scan)
+    const int lo_rev = t * per;                       // index in reversed order
+    double P = 1.0, A = 0.0;                          // composition of own chunks, applied right-to-left
+    for (int k = 0; k < per; ++k) {
+        const int rev = lo_rev + k;
+        if (rev < n_chunks) {
+            const int ch = n_chunks - 1 - rev;
+            A = chunkA[ch] + chunkP[ch] * A;
+            P = chunkP[ch] * P;
+        }
+    }
+    sP[t] = P; sA[t] = A;
+    __syncthreads();
+    // inclusive Hillis-Steele scan of affine maps in reversed order: f_t o f_{t-1} o ... o f_0
+    for (int off = 1; off < 1024; off <<= 1) {
+        double pP = 1.0, pA = 0.0;
+        if (t >= off) { pP = sP[t - off]; pA = sA[t - off]; }
+        __syncthreads();
+        if (t >= off) {
+            const double nA = sA[t] + sP[t] * pA;   // apply earlier (pA) first, then own map
+            const double nP = sP[t] * pP;
+            sA[t] = nA; sP[t] = nP;
+        }
+        __syncthreads();
+    }
+    // carry entering thread t's first (right-most) chunk = value produced by threads < t
+    double cin = t > 0 ? sA[t - 1] : 0.0;
+    for (int k = 0; k < per; ++k) {
+        const int rev = lo_rev + k;
+        if (rev < n_chunks) {
+            const int ch = n_chunks - 1 - rev;
+            carry[ch] = cin;
+            cin = chunkA[ch] + chunkP[ch] * cin;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gae_replay(const T *__restrict__ r, const T *__restrict__ mk,
+                                                    const T *__restrict__ v, int n, double gamma, double gt,
+                                                    const double *__restrict__ carry, T *__restrict__ adv,
+                                                    T *__restrict__ ret, double *__restrict__ part) {
+    __shared__ double s_n[256], s_mean[256], s_m2[256];
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i0 = ch * GAE_CHUNK;
+    double cnt = 0.0, mean = 0.0, m2 = 0.0;
+    if (i0 < n) {
+        const int i1 = min(n, i0 + GAE_CHUNK);
+        double A = carry[ch];
+        for (int i = i1 - 1; i >= i0; --i) {
+            double d, c;
+            gae_coeffs<T>(r, mk, v, i, n, gamma, gt, d, c);
+            A = d + c * A;
+            const T a_out = (T)A;
+            adv[i] = a_out;
+            ret[i] = (T)((double)v[i] + A);
+            cnt += 1.0;                                   // Welford on the stored (rounded) advantage
+            const double x = (double)a_out, dl = x - mean;
+            mean += dl / cnt;
+            m2 += dl * (x - mean);
+        }
+    }
+    s_n[threadIdx.x] = cnt; s_mean[threadIdx.x] = mean; s_m2[threadIdx.x] = m2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            const double na = s_n[threadIdx.x], nb = s_n[threadIdx.x + off];
+            if (nb > 0.0) {
+                const double tot = na + nb, d = s_mean[threadIdx.x + off] - s_mean[threadIdx.x];
+                s_m2[threadIdx.x] += s_m2[threadIdx.x + off] + d * d * (na * nb / tot);
+                s_mean[threadIdx.x] += d * (nb / tot);
+                s_n[threadIdx.x] = tot;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 3 + 0] = s_n[0];
+        part[blockIdx.x * 3 + 1] = s_mean[0];
+        part[blockIdx.x * 3 + 2] = s_m2[0];
+    }
+}
+
+// stats = {n, mean, M2}: serial Chan merge of the block partials (fixed order)
+__global__ void k_gae_stats(int n_parts, const double *__restrict__ part, double *__restrict__ stats) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double cnt = 0.0, mean = 0.0, m2 = 0.0;
+    for (int p = 0; p < n_parts; ++p) {
+        const double nb = part[p * 3];
+        if (nb > 0.0) {
+            const double tot = cnt + nb, d = part[p * 3 + 1] - mean;
+            m2 += part[p * 3 + 2] + d * d * (cnt * nb / tot);
+            mean += d * (nb / tot);
+            cnt = tot;
+        }
+    }
+    stats[0] = cnt; stats[1] = mean; stats[2] = m2;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_standardize(T *__restrict__ a, int n, const double *__restrict__ stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double mean = stats[1];
+    const double sd = sqrt(stats[2] / (stats[0] - 1.0));   // unbiased, as torch.std
+    a[i] = (T)(((double)a[i] - mean) / sd);
+}
+
+}  // namespace egp
+
+// ================================================================================================
+//                                           host side / C-ABI
+// ================================================================================================
+using namespace egp;
+
+template <typename T>
+static int dev_copy(egp_ctx *ctx, const T *host, size_t count, const T **out) {
+    void *d = nullptr;
+    EGP_HIP_CHECK(hipMalloc(&d, count * sizeof(T)));
+    ctx->allocs.push_back(d);
+    EGP_HIP_CHECK(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T *)d;
+    return EGP_OK;
+}
+
+static int fill_reward(egp_ctx *ctx, const egp_model_desc *d) {
+    RewardW &w = ctx->rw;
+    w.w_p = d->w_p; w.w_v = d->w_v; w.w_e = d->w_e; w.w_rp = d->w_rp; w.w_rv = d->w_rv;
+    w.w_sum = d->w_p + d->w_v + d->w_e + d->w_rp + d->w_rv;
+    w.k_p = d->k_p; w.k_v = d->k_v; w.k_e = d->k_e; w.k_rh = d->k_rh; w.k_rq = d->k_rq; w.k_rl = d->k_rl; w.k_ra = d->k_ra;
+    w.v_ord = d->v_ord; w.decay = d->decay; w.episode_len = d->episode_len;
+    EGP_REQUIRE(d->v_ord >= 1.0, "v_ord must be >= 1");
+    EGP_REQUIRE(d->episode_len > 0, "episode_len must be positive");
+    return EGP_OK;
+}
+
+extern "C" {
+
+const char *egp_last_error(void) { return g_err; }
+const char *egp_version(void) { return "egopose_hip 0.1.0 (gfx950)"; }
+
+int egp_create(const egp_model_desc *d, int device, egp_ctx **out) {
+    EGP_REQUIRE(d && out, "desc/out is NULL");
+    EGP_REQUIRE(d->nv > 6 && d->nv <= EGP_MAX_NV, "nv must be in (6, 64]");
+    EGP_REQUIRE(d->nq == d->nv + 1 && d->nu == d->nv - 6, "expects one free root joint + hinges (nq=nv+1, nu=nv-6)");
+    EGP_REQUIRE(d->nbody >= 2 && d->nbody + 5 <= EGP_MAX_BODY, "nbody must be in [2, 27]");
+    EGP_REQUIRE(d->nM > 0 && d->nM <= PD_NM_MAX, "nM out of range");
+    EGP_REQUIRE(d->body_qpos_start && d->body_ndof && d->dof_parentid && d->dof_Madr && d->ee_body, "skeleton table is NULL");
+    EGP_REQUIRE(d->jkp && d->jkd && d->a_ref && d->a_scale && d->torque_lim && d->b_diffw, "gain table is NULL");
+    EGP_REQUIRE(d->sub_dt > 0 && d->frame_skip > 0, "timestep/frame_skip must be positive");
+    EGP_REQUIRE(26 + 4 * (d->nbody - 1) <= 106 && 106 + 3 * (d->nbody - 1) <= EGP_EXPERT_ROW, "expert row overflow");
+    EGP_HIP_CHECK(hipSetDevice(device));
+    egp_ctx *ctx = new egp_ctx();
+    ctx->device = device;
+    ctx->frame_skip = d->frame_skip;
+    int rc = fill_reward(ctx, d);
+    if (rc != EGP_OK) { delete ctx; return rc; }
+    DevModel &m = ctx->dm;
+    m.nq = d->nq; m.nv = d->nv; m.nu = d->nu; m.nbody = d->nbody; m.nM = d->nM;
+    m.sub_dt = d->sub_dt;
+    m.dt = d->sub_dt * d->frame_skip;
+    // sparse-inertia index tables from the dof tree (what mj_fullM walks)
+    std::vector<int> rows(d->nM), cols(d->nM);
+    std::vector<short> mmap((size_t)d->nv * d->nv, (short)-1);
+    int total = 0;
+    for (int i = 0; i < d->nv; ++i) {
+        int adr = d->dof_Madr[i], j = i;
+        while (j >= 0) {
+            if (adr < 0 || adr >= d->nM) { delete ctx; set_error("dof_Madr/dof_parentid inconsistent with nM"); return EGP_E_INVALID; }
+            rows[adr] = i; cols[adr] = j;
+            mmap[(size_t)i * d->nv + j] = (short)adr;
+            mmap[(size_t)j * d->nv + i] = (short)adr;
+            ++adr; ++total;
+            j = d->dof_parentid[j];
+        }
+    }
+    if (total != d->nM) { delete ctx; set_error("dof tree has %d inertia entries, nM says %d", total, d->nM); return EGP_E_INVALID; }
+    for (int k = 0; k < 5; ++k) ctx->ee_body.push_back(d->ee_body[k]);
+#define EGP_TRY(x) do { rc = (x); if (rc != EGP_OK) { egp_destroy(ctx); return rc; } } while (0)
+    EGP_TRY(dev_copy<int>(ctx, d->body_qpos_start, d->nbody, &m.body_qpos_start));
+    EGP_TRY(dev_copy<int>(ctx, d->body_ndof, d->nbody, &m.body_ndof));
+    EGP_TRY(dev_copy<int>(ctx, rows.data(), d->nM, &m.m_row));
+    EGP_TRY(dev_copy<int>(ctx, cols.data(), d->nM, &m.m_col));
+    EGP_TRY(dev_copy<short>(ctx, mmap.data(), mmap.size(), &m.m_map));
+    EGP_TRY(dev_copy<double>(ctx, d->jkp, d->nu, &m.jkp));
+    EGP_TRY(dev_copy<double>(ctx, d->jkd, d->nu, &m.jkd));
+    EGP_TRY(dev_copy<double>(ctx, d->a_ref, d->nu, &m.a_ref));
+    EGP_TRY(dev_copy<double>(ctx, d->a_scale, d->nu, &m.a_scale));
+    EGP_TRY(dev_copy<double>(ctx, d->torque_lim, d->nu, &m.torque_lim));
+    EGP_TRY(dev_copy<double>(ctx, d->b_diffw, d->nbody - 1, &m.b_diffw));
+#undef EGP_TRY
+    const char *v = getenv("EGP_PD_VARIANT");
+    ctx->pd_variant = (v && atoi(v) == 1) || d->nv != PD_NV ? 1 : 0;
+    *out = ctx;
+    return EGP_OK;
+}
+
+int egp_destroy(egp_ctx *ctx) {
+    if (!ctx) return EGP_OK;
+    for (void *p : ctx->allocs) (void)hipFree(p);
+    delete ctx;
+    return EGP_OK;
+}
+
+int egp_set_reward_weights(egp_ctx *ctx, const egp_model_desc *d) {
+    EGP_REQUIRE(ctx && d, "ctx/desc is NULL");
+    return fill_reward(ctx, d);
+}
+
+int egp_set_pd_variant(egp_ctx *ctx, int variant) {
+    EGP_REQUIRE(ctx, "ctx is NULL");
+    EGP_REQUIRE(variant == 1 || (variant == 0 && ctx->dm.nv == PD_NV), "variant 0 needs nv == 58");
+    ctx->pd_variant = variant;
+    return EGP_OK;
+}
+
+int egp_upload_experts(egp_ctx *ctx, const egp_expert_table *t) {
+    EGP_REQUIRE(ctx && t, "ctx/table is NULL");
+    EGP_REQUIRE(t->n_takes > 0 && t->n_frames > 0 && t->take_offset, "empty expert table");
+    EGP_REQUIRE(t->qpos && t->rlinv_local && t->rangv && t->rq_rmh && t->ee_pos && t->bquat && t->bangvel, "expert column is NULL");
+    EGP_REQUIRE(t->take_offset[t->n_takes] == t->n_frames, "take_offset[n_takes] != n_frames");
+    const int nb = ctx->dm.nbody, nq = ctx->dm.nq;
+    std::vector<double> rows((size_t)t->n_frames * EGP_EXPERT_ROW, 0.0);
+    for (int f = 0; f < t->n_frames; ++f) {
+        double *r = rows.data() + (size_t)f * EGP_EXPERT_ROW;
+        r[ER_Z] = t->qpos[(size_t)f * nq + 2];
+        for (int k = 0; k < 3; ++k) r[ER_RLINV + k] = t->rlinv_local[(size_t)f * 3 + k];
+        for (int k = 0; k < 3; ++k) r[ER_RANGV + k] = t->rangv[(size_t)f * 3 + k];
+        for (int k = 0; k < 4; ++k) r[ER_RQ + k] = t->rq_rmh[(size_t)f * 4 + k];
+        for (int k = 0; k < 15; ++k) r[ER_EE + k] = t->ee_pos[(size_t)f * 15 + k];
+        for (int k = 0; k < 4 * (nb - 1); ++k) r[ER_BQ + k] = t->bquat[(size_t)f * 4 * nb + 4 + k];
+        for (int k = 0; k < 3 * (nb - 1); ++k) r[ER_BAV + k] = t->bangvel[(size_t)f * 3 * nb + 3 + k];
+    }
+    std::vector<float> rows32(rows.size());
+    for (size_t i = 0; i < rows.size(); ++i) rows32[i] = (float)rows[i];
+    EGP_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->expert_rows_f64) { (void)hipFree(ctx->expert_rows_f64); (void)hipFree(ctx->expert_rows_f32); }
+    EGP_HIP_CHECK(hipMalloc((void **)&ctx->expert_rows_f64, rows.size() * sizeof(double)));
+    EGP_HIP_CHECK(hipMalloc((void **)&ctx->expert_rows_f32, rows.size() * sizeof(float)));
+    EGP_HIP_CHECK(hipMemcpy(ctx->expert_rows_f64, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
+    EGP_HIP_CHECK(hipMemcpy(ctx->expert_rows_f32, rows32.data(), rows32.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->n_takes = t->n_takes;
+    ctx->n_frames = t->n_frames;
+    return EGP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------- launchers
+static inline int after_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return EGP_E_HIP;
+    }
+    return EGP_OK;
+}
+
+template <typename T>
+static int launch_body_quat(egp_ctx *ctx, const T *qpos, int n, T *bquat, void *stream) {
+    EGP_REQUIRE(ctx && qpos && bquat, "NULL pointer");
+    EGP_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return EGP_OK;
+    const long total = (long)n * ctx->dm.nbody;
+    k_body_quat<T><<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(ctx->dm, qpos, n, bquat);
+    return after_launch("k_body_quat");
+}
+
+template <typename T>
+static int launch_obs(egp_ctx *ctx, const T *qpos, const T *qvel, int n, T *obs, void *stream) {
+    EGP_REQUIRE(ctx && qpos && qvel && obs, "NULL pointer");
+    EGP_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return EGP_OK;
+    const long total = (long)n * (ctx->dm.nq - 2 + ctx->dm.nv);
+    k_obs<T><<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(ctx->dm, qpos, qvel, n, obs);
+    return after_launch("k_obs");
+}
+
+template <typename T>
+static int launch_pd(egp_ctx *ctx, const PdLd &ld, const T *qpos, const T *qvel, const T *action, const T *qM, const T *C, int n,
+                     T *torque, T *torque_raw, hipStream_t stream) {
+    EGP_REQUIRE(ctx && qpos && qvel && action && qM && C && torque, "NULL pointer");
+    EGP_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return EGP_OK;
+    if (ctx->pd_variant == 0) {
+        k_pd_torque_reg58<T><<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, C, n, torque, torque_raw);
+        return after_launch("k_pd_torque_reg58");
+    }
+    const int nv = ctx->dm.nv;
+    const size_t lds = ((size_t)nv * (nv + 1) + nv) * sizeof(double);
+    k_pd_torque_lds<T><<<dim3(n), dim3(64), lds, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, C, n, torque, torque_raw);
+    return after_launch("k_pd_torque_lds");
+}
+
+static inline PdLd dense_ld(const egp_ctx *c) { return PdLd{c->dm.nq, c->dm.nv, c->dm.nu, c->dm.nM, c->dm.nv}; }
+
+// engine entry: all five inputs live in one packed row per env (row stride `pack_ld` doubles)
+int egp_launch_pd_torque_packed(egp_ctx *ctx, const double *pack, long pack_ld, int off_qpos, int off_qvel, int off_bias,
+                                int off_qM, const double *action, int32_t n, double *torque, hipStream_t stream) {
+    PdLd ld{pack_ld, pack_ld, ctx->dm.nu, pack_ld, pack_ld};
+    return launch_pd<double>(ctx, ld, pack + off_qpos, pack + off_qvel, action, pack + off_qM, pack + off_bias, n, torque,
+                             nullptr, stream);
+}
+
+template <typename T>
+static int launch_reward(egp_ctx *ctx, const T *expert_rows, const T *cur_qpos, const T *prev_qpos, const T *ee_wpos,
+                         const int *t, const int *frame, const int *endf, const int *active, double end_reward, int n,
+                         T *reward, T *cinfo, void *stream) {
+    EGP_REQUIRE(ctx && cur_qpos && prev_qpos && ee_wpos && t && frame && endf && reward && cinfo, "NULL pointer");
+    EGP_REQUIRE(n >= 0, "n < 0");
+    if (!expert_rows) { set_error("egp_upload_experts must be called before the reward kernel"); return EGP_E_STATE; }
+    if (n == 0) return EGP_OK;
+    const long threads = (long)n * 32;
+    k_reward_quat_v3<T><<<dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
+        ctx->dm, ctx->rw, expert_rows, cur_qpos, prev_qpos, ee_wpos, t, frame, endf, active, (T)end_reward, n, reward, cinfo);
+    return after_launch("k_reward_quat_v3");
+}
+
+static inline void zf_tiling(int n, int *rows_per_tile, int *n_tiles) {
+    int tiles = (n + 63) / 64;
+    if (tiles > 256) tiles = 256;
+    if (tiles < 1) tiles = 1;
+    *rows_per_tile = (n + tiles - 1) / tiles;
+    *n_tiles = (n + *rows_per_tile - 1) / *rows_per_tile;
+    if (*n_tiles < 1) *n_tiles = 1;
+}
+
+template <typename T>
+static int launch_zfilter(const T *x, const int *active, int n, int dim, const double *st_in, double *st_out, int update,
+                          double clip, T *y, void *ws, void *stream) {
+    EGP_REQUIRE(x && st_in && y, "NULL pointer");
+    EGP_REQUIRE(n >= 0 && dim > 0 && dim <= 4096, "bad n/dim");
+    EGP_REQUIRE(!update || (st_out && ws && st_out != st_in), "update needs workspace and a distinct state_out");
+    if (n == 0) {
+        if (update) EGP_HIP_CHECK(hipMemcpyAsync(st_out, st_in, (1 + 2 * (size_t)dim) * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return EGP_OK;
+    }
+    int rpt, nt;
+    zf_tiling(n, &rpt, &nt);
+    if (update) {
+        k_zf_partial<T><<<dim3(nt), dim3(128), 0, (hipStream_t)stream>>>(x, active, n, dim, rpt, (double *)ws);
+        int rc = after_launch("k_zf_partial");
+        if (rc != EGP_OK) return rc;
+    }
+    k_zf_apply<T><<<dim3(nt), dim3(128), 2 * dim * sizeof(double), (hipStream_t)stream>>>(
+        x, n, dim, rpt, nt, (const double *)ws, st_in, st_out, update, clip, y);
+    return after_launch("k_zf_apply");
+}
+
+template <typename T>
+static int launch_gae(const T *r, const T *mk, const T *v, int n, double gamma, double tau, T *adv, T *ret, double *stats,
+                      void *ws, void *stream) {
+    EGP_REQUIRE(r && mk && v && adv && ret && stats && ws, "NULL pointer");
+    EGP_REQUIRE(n > 0, "n must be positive");
+    const int n_chunks = (n + GAE_CHUNK - 1) / GAE_CHUNK;
+    const int n_blocks = (n_chunks + 255) / 256;
+    double *chunkP = (double *)ws, *chunkA = chunkP + n_chunks, *carry = chunkA + n_chunks, *part = carry + n_chunks;
+    hipStream_t s = (hipStream_t)stream;
+    k_gae_summary<T><<<dim3(n_blocks), dim3(256), 0, s>>>(r, mk, v, n, gamma, gamma * tau, chunkP, chunkA);
+    k_gae_scan<<<dim3(1), dim3(1024), 0, s>>>(n_chunks, chunkP, chunkA, carry);
+    k_gae_replay<T><<<dim3(n_blocks), dim3(256), 0, s>>>(r, mk, v, n, gamma, gamma * tau, carry, adv, ret, part);
+    k_gae_stats<<<dim3(1), dim3(64), 0, s>>>(n_blocks, part, stats);
+    return after_launch("k_gae_*");
+}
+
+template <typename T>
+static int launch_standardize(T *a, int n, const double *stats, void *stream) {
+    EGP_REQUIRE(a && stats, "NULL pointer");
+    EGP_REQUIRE(n > 0, "n must be positive");
+    k_standardize<T><<<dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(a, n, stats);
+    return after_launch("k_standardize");
+}
+
+extern "C" {
+
+int egp_body_quat_f64(egp_ctx *c, const double *q, int32_t n, double *o, void *s) { return launch_body_quat<double>(c, q, n, o, s); }
+int egp_body_quat_f32(egp_ctx *c, const float *q, int32_t n, float *o, void *s) { return launch_body_quat<float>(c, q, n, o, s); }
+int egp_obs_f64(egp_ctx *c, const double *q, const double *v, int32_t n, double *o, void *s) { return launch_obs<double>(c, q, v, n, o, s); }
+int egp_obs_f32(egp_ctx *c, const float *q, const float *v, int32_t n, float *o, void *s) { return launch_obs<float>(c, q, v, n, o, s); }
+
+int egp_pd_torque_f64(egp_ctx *c, const double *qpos, const double *qvel, const double *action, const double *qM,
+                      const double *bias, int32_t n, double *torque, double *torque_raw, void *s) {
+    EGP_REQUIRE(c, "ctx is NULL");
+    return launch_pd<double>(c, dense_ld(c), qpos, qvel, action, qM, bias, n, torque, torque_raw, (hipStream_t)s);
+}
+int egp_pd_torque_f32(egp_ctx *c, const float *qpos, const float *qvel, const float *action, const float *qM,
+                      const float *bias, int32_t n, float *torque, float *torque_raw, void *s) {
+    EGP_REQUIRE(c, "ctx is NULL");
+    return launch_pd<float>(c, dense_ld(c), qpos, qvel, action, qM, bias, n, torque, torque_raw, (hipStream_t)s);
+}
+
+int egp_reward_quat_v3_f64(egp_ctx *c, const double *cq, const double *pq, const double *ee, const int32_t *t,
+                           const int32_t *frame, const int32_t *endf, const int32_t *active, double end_reward, int32_t n,
+                           double *reward, double *cinfo, void *s) {
+    EGP_REQUIRE(c, "ctx is NULL");
+    return launch_reward<double>(c, c->expert_rows_f64, cq, pq, ee, t, frame, endf, active, end_reward, n, reward, cinfo, s);
+}
+int egp_reward_quat_v3_f32(egp_ctx *c, const float *cq, const float *pq, const float *ee, const int32_t *t,
+                           const int32_t *frame, const int32_t *endf, const int32_t *active, double end_reward, int32_t n,
+                           float *reward, float *cinfo, void *s) {
+    EGP_REQUIRE(c, "ctx is NULL");
+    return launch_reward<float>(c, c->expert_rows_f32, cq, pq, ee, t, frame, endf, active, end_reward, n, reward, cinfo, s);
+}
+
+int64_t egp_zfilter_workspace_bytes(int32_t n, int32_t dim) {
+    int rpt, nt;
+    zf_tiling(n > 0 ? n : 1, &rpt, &nt);
+    return (int64_t)nt * (1 + 2 * (int64_t)dim) * sizeof(double);
+}
+int egp_zfilter_f64(const double *x, const int32_t *active, int32_t n, int32_t dim, const double *si, double *so,
+                    int32_t update, double clip, double *y, void *ws, void *s) {
+    return launch_zfilter<double>(x, active, n, dim, si, so, update, clip, y, ws, s);
+}
+int egp_zfilter_f32(const float *x, const int32_t *active, int32_t n, int32_t dim, const double *si, double *so,
+                    int32_t update, double clip, float *y, void *ws, void *s) {
+    return launch_zfilter<float>(x, active, n, dim, si, so, update, clip, y, ws, s);
+}
+
+int64_t egp_gae_workspace_bytes(int32_t n) {
+    const int64_t n_chunks = ((int64_t)n + GAE_CHUNK - 1) / GAE_CHUNK;
+    const int64_t n_blocks = (n_chunks + 255) / 256;
+    return (3 * n_chunks + 3 * n_blocks) * (int64_t)sizeof(double);
+}
+int egp_gae_f64(const double *r, const double *m, const double *v, int32_t n, double gamma, double tau, double *adv,
+                double *ret, double *stats, void *ws, void *s) {
+    return launch_gae<double>(r, m, v, n, gamma, tau, adv, ret, stats, ws, s);
+}
+int egp_gae_f32(const float *r, const float *m, const float *v, int32_t n, double gamma, double tau, float *adv,
+                float *ret, double *stats, void *ws, void *s) {
+    return launch_gae<float>(r, m, v, n, gamma, tau, adv, ret, stats, ws, s);
+}
+int egp_gae_standardize_f64(double *a, int32_t n, const double *stats, void *s) { return launch_standardize<double>(a, n, stats, s); }
+int egp_gae_standardize_f32(float *a, int32_t n, const double *stats, void *s) { return launch_standardize<float>(a, n, stats, s); }
+
+}  // extern "C"

@@ -1,0 +1,248 @@
+"""Thin torch-tensor front end of the C-ABI: device memory + streams come from torch, the
+arithmetic is the HIP library's. Every wrapper validates shapes/dtypes, launches on torch's
+current stream and raises on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .skeleton import Skeleton
+
+_DT = {torch.float64: "f64", torch.float32: "f32"}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need(t: torch.Tensor, shape, dtype, name):
+    if not t.is_cuda:
+        raise ValueError("%s must be a CUDA (HIP) tensor" % name)
+    if t.dtype != dtype:
+        raise ValueError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+
+
+def _np_i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def _np_f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _ip(a):
+    return a.ctypes.data_as(L.c_int_p)
+
+
+def _dp(a):
+    return a.ctypes.data_as(L.c_dbl_p)
+
+
+DEFAULT_REWARD = dict(w_p=0.5, w_v=0.1, w_e=0.2, w_rp=0.1, w_rv=0.1, k_p=2.0, k_v=0.005, k_e=20.0,
+                      k_rh=300.0, k_rq=300.0, k_rl=5.0, k_ra=0.5, v_ord=2, decay=False)
+
+
+class EgpContext:
+    """Model constants + expert table resident in HBM (``egp_ctx``)."""
+
+    def __init__(self, skel: Skeleton, jkp, jkd, a_ref, a_scale, torque_lim, b_diffw, reward_weights=None,
+                 episode_len=200, frame_skip=15, device: int = 0):
+        self.lib = L.load()
+        self.skel = skel
+        self.device = int(device)
+        self.frame_skip = int(frame_skip)
+        self.episode_len = int(episode_len)
+        self.nq, self.nv, self.nu, self.nbody, self.nM = skel.nq, skel.nv, skel.nu, len(skel.body_names), skel.nM
+        self.obs_dim = self.nq - 2 + self.nv
+        self._keep = dict(
+            bqs=_np_i32(skel.body_qpos_start), bnd=_np_i32(skel.body_ndof), dpar=_np_i32(skel.dof_parentid),
+            madr=_np_i32(skel.dof_Madr), ee=_np_i32(skel.ee_body), jkp=_np_f64(jkp), jkd=_np_f64(jkd),
+            a_ref=_np_f64(a_ref), a_scale=_np_f64(a_scale), tl=_np_f64(torque_lim), bw=_np_f64(b_diffw))
+        for k in ("jkp", "jkd", "a_ref", "a_scale", "tl"):
+            if self._keep[k].shape != (self.nu,):
+                raise ValueError("%s must have %d entries" % (k, self.nu))
+        if self._keep["bw"].shape != (self.nbody - 1,):
+            raise ValueError("b_diffw must have %d entries" % (self.nbody - 1))
+        self.reward_weights = None
+        desc = self._desc(reward_weights)
+        h = C.c_void_p()
+        L.check(self.lib.egp_create(C.byref(desc), self.device, C.byref(h)), "egp_create")
+        self.handle = h
+        self.n_frames = 0
+        self.take_offset = None
+        self.head_height_lb = None
+        self._ws = {}
+
+    def _desc(self, reward_weights):
+        ws = dict(DEFAULT_REWARD)
+        if reward_weights:
+            ws.update(reward_weights)
+        self.reward_weights = ws
+        k = self._keep
+        d = L.ModelDesc()
+        d.nq, d.nv, d.nu, d.nbody, d.nM = self.nq, self.nv, self.nu, self.nbody, self.nM
+        d.body_qpos_start, d.body_ndof, d.dof_parentid, d.dof_Madr, d.ee_body = (
+            _ip(k["bqs"]), _ip(k["bnd"]), _ip(k["dpar"]), _ip(k["madr"]), _ip(k["ee"]))
+        d.jkp, d.jkd, d.a_ref, d.a_scale, d.torque_lim, d.b_diffw = (
+            _dp(k["jkp"]), _dp(k["jkd"]), _dp(k["a_ref"]), _dp(k["a_scale"]), _dp(k["tl"]), _dp(k["bw"]))
+        d.sub_dt, d.frame_skip, d.episode_len = float(self.skel.timestep), self.frame_skip, self.episode_len
+        for f in ("w_p", "w_v", "w_e", "w_rp", "w_rv", "k_p", "k_v", "k_e", "k_rh", "k_rq", "k_rl", "k_ra", "v_ord"):
+            setattr(d, f, float(ws[f]))
+        d.decay = 1 if ws.get("decay", False) else 0
+        return d
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.egp_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ configuration
+    def set_reward_weights(self, reward_weights):
+        desc = self._desc(reward_weights)
+        L.check(self.lib.egp_set_reward_weights(self.handle, C.byref(desc)), "egp_set_reward_weights")
+
+    def set_pd_variant(self, variant: int):
+        L.check(self.lib.egp_set_pd_variant(self.handle, int(variant)), "egp_set_pd_variant")
+
+    def upload_experts(self, takes):
+        """takes: list of dicts with the expert keys of gen_expert.py:28-83 (float64 arrays)."""
+        if not takes:
+            raise ValueError("expert list is empty")
+        lens = [int(t["qpos"].shape[0]) for t in takes]
+        off = _np_i32(np.concatenate([[0], np.cumsum(lens)]))
+        cat = {k: _np_f64(np.concatenate([np.asarray(t[k]).reshape(n, -1) for t, n in zip(takes, lens)], axis=0))
+               for k in ("qpos", "qvel", "rlinv_local", "rangv", "rq_rmh", "ee_pos", "bquat", "bangvel")}
+        lb = _np_f64([float(t["head_height_lb"]) for t in takes])
+        tb = L.ExpertTable()
+        tb.n_takes, tb.n_frames, tb.take_offset = len(takes), int(off[-1]), _ip(off)
+        for k, v in cat.items():
+            setattr(tb, k, _dp(v))
+        tb.head_height_lb = _dp(lb)
+        L.check(self.lib.egp_upload_experts(self.handle, C.byref(tb)), "egp_upload_experts")
+        self.n_frames, self.take_offset, self.head_height_lb = int(off[-1]), off.astype(np.int64), lb
+
+    # ------------------------------------------------------------------ kernels
+    def _sfx(self, t):
+        try:
+            return _DT[t.dtype]
+        except KeyError:
+            raise ValueError("only float32/float64 tensors are supported, got %s" % t.dtype)
+
+    def body_quat(self, qpos, out=None):
+        n = qpos.shape[0]
+        _need(qpos, (n, self.nq), qpos.dtype, "qpos")
+        out = torch.empty(n, 4 * self.nbody, dtype=qpos.dtype, device=qpos.device) if out is None else out
+        _need(out, (n, 4 * self.nbody), qpos.dtype, "out")
+        fn = getattr(self.lib, "egp_body_quat_" + self._sfx(qpos))
+        L.check(fn(self.handle, _ptr(qpos), n, _ptr(out), _stream()), "egp_body_quat")
+        return out
+
+    def obs(self, qpos, qvel, out=None):
+        n = qpos.shape[0]
+        _need(qpos, (n, self.nq), qpos.dtype, "qpos")
+        _need(qvel, (n, self.nv), qpos.dtype, "qvel")
+        out = torch.empty(n, self.obs_dim, dtype=qpos.dtype, device=qpos.device) if out is None else out
+        _need(out, (n, self.obs_dim), qpos.dtype, "out")
+        fn = getattr(self.lib, "egp_obs_" + self._sfx(qpos))
+        L.check(fn(self.handle, _ptr(qpos), _ptr(qvel), n, _ptr(out), _stream()), "egp_obs")
+        return out
+
+    def pd_torque(self, qpos, qvel, action, qM, bias, want_raw=False):
+        n, dt = qpos.shape[0], qpos.dtype
+        _need(qpos, (n, self.nq), dt, "qpos")
+        _need(qvel, (n, self.nv), dt, "qvel")
+        _need(action, (n, self.nu), dt, "action")
+        _need(qM, (n, self.nM), dt, "qM")
+        _need(bias, (n, self.nv), dt, "qfrc_bias")
+        tq = torch.empty(n, self.nu, dtype=dt, device=qpos.device)
+        raw = torch.empty_like(tq) if want_raw else None
+        fn = getattr(self.lib, "egp_pd_torque_" + self._sfx(qpos))
+        L.check(fn(self.handle, _ptr(qpos), _ptr(qvel), _ptr(action), _ptr(qM), _ptr(bias), n, _ptr(tq), _ptr(raw),
+                   _stream()), "egp_pd_torque")
+        return (tq, raw) if want_raw else tq
+
+    def reward(self, cur_qpos, prev_qpos, ee_wpos, t, frame, end, end_reward, active=None, reward_out=None,
+               cinfo_out=None):
+        n, dt = cur_qpos.shape[0], cur_qpos.dtype
+        _need(cur_qpos, (n, self.nq), dt, "cur_qpos")
+        _need(prev_qpos, (n, self.nq), dt, "prev_qpos")
+        _need(ee_wpos, (n, 15), dt, "ee_wpos")
+        for name, a in (("t", t), ("frame", frame), ("end", end)):
+            _need(a, (n,), torch.int32, name)
+        if active is not None:
+            _need(active, (n,), torch.int32, "active")
+        r = torch.empty(n, dtype=dt, device=cur_qpos.device) if reward_out is None else reward_out
+        ci = torch.empty(n, 5, dtype=dt, device=cur_qpos.device) if cinfo_out is None else cinfo_out
+        _need(r, (n,), dt, "reward_out")
+        _need(ci, (n, 5), dt, "cinfo_out")
+        fn = getattr(self.lib, "egp_reward_quat_v3_" + self._sfx(cur_qpos))
+        L.check(fn(self.handle, _ptr(cur_qpos), _ptr(prev_qpos), _ptr(ee_wpos), _ptr(t), _ptr(frame), _ptr(end),
+                   _ptr(active), float(end_reward), n, _ptr(r), _ptr(ci), _stream()), "egp_reward_quat_v3")
+        return r, ci
+
+    def _workspace(self, key, nbytes, device):
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            ws = torch.empty(max(int(nbytes), 8), dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    def zfilter(self, x, state_in, state_out=None, update=True, clip=5.0, active=None, out=None):
+        """state = float64 [1 + 2*dim] = (count, mean, S). Returns y (and writes state_out when update)."""
+        n, dim = x.shape
+        _need(x, (n, dim), x.dtype, "x")
+        _need(state_in, (1 + 2 * dim,), torch.float64, "state_in")
+        if update:
+            if state_out is None:
+                raise ValueError("update=True needs state_out")
+            _need(state_out, (1 + 2 * dim,), torch.float64, "state_out")
+        if active is not None:
+            _need(active, (n,), torch.int32, "active")
+        y = torch.empty_like(x) if out is None else out
+        _need(y, (n, dim), x.dtype, "out")
+        ws = self._workspace("zf", self.lib.egp_zfilter_workspace_bytes(n, dim), x.device) if update else None
+        fn = getattr(self.lib, "egp_zfilter_" + self._sfx(x))
+        L.check(fn(_ptr(x), _ptr(active), n, dim, _ptr(state_in), _ptr(state_out if update else None), 1 if update else 0,
+                   float(clip or 0.0), _ptr(y), _ptr(ws), _stream()), "egp_zfilter")
+        return y
+
+    def gae(self, rewards, masks, values, gamma, tau):
+        """-> (adv_raw (n,), returns (n,), stats float64[3] = {n, mean, M2}) all on device."""
+        n, dt = rewards.shape[0], rewards.dtype
+        _need(rewards, (n,), dt, "rewards")
+        _need(masks, (n,), dt, "masks")
+        _need(values, (n,), dt, "values")
+        adv = torch.empty_like(rewards)
+        ret = torch.empty_like(rewards)
+        stats = torch.empty(3, dtype=torch.float64, device=rewards.device)
+        ws = self._workspace("gae", self.lib.egp_gae_workspace_bytes(n), rewards.device)
+        fn = getattr(self.lib, "egp_gae_" + self._sfx(rewards))
+        L.check(fn(_ptr(rewards), _ptr(masks), _ptr(values), n, float(gamma), float(tau), _ptr(adv), _ptr(ret),
+                   _ptr(stats), _ptr(ws), _stream()), "egp_gae")
+        return adv, ret, stats
+
+    def gae_standardize(self, adv, stats):
+        _need(adv, (adv.shape[0],), adv.dtype, "adv")
+        _need(stats, (3,), torch.float64, "stats")
+        fn = getattr(self.lib, "egp_gae_standardize_" + self._sfx(adv))
+        L.check(fn(_ptr(adv), adv.shape[0], _ptr(stats), _stream()), "egp_gae_standardize")
+        return adv

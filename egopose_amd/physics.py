@@ -1,0 +1,195 @@
+"""Python handles of the host physics boundary and the lockstep rollout engine (C-ABI: egp_physics_*,
+egp_engine_*). The reference couples HumanoidEnv to mujoco_py's MjSim
+(/root/reference/envs/common/mujoco_env.py:18-42); here physics is a pluggable host backend and the
+only built-in one is the deterministic surrogate (not MuJoCo -- physics parity is unpinned).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+from .skeleton import Skeleton
+
+
+def _np_i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def _np_f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+class SurrogatePhysics:
+    """egp_physics_create_surrogate: semi-implicit Euler on qacc = M0^-1 (tau - C)."""
+
+    def __init__(self, skel: Skeleton, n_env: int, damping: float = 1.0, support_k: float = 2000.0,
+                 support_c: float = 200.0):
+        self.lib = L.load()
+        self.skel = skel
+        self.n_env = int(n_env)
+        M0 = skel.zero_pose_inertia()
+        self.qM0 = _np_f64(skel.sparse_from_full(M0))
+        self.Minv0 = _np_f64(np.linalg.inv(M0))
+        self._keep = dict(
+            body_parent=_np_i32(skel.body_parent), body_pos=_np_f64(skel.body_pos.ravel()),
+            body_ndof=_np_i32(skel.body_ndof), joint_axis=_np_f64(skel.joint_axis.ravel()),
+            joint_anchor=_np_f64(skel.joint_anchor.ravel()))
+        d = L.SurrogateDesc()
+        d.nq, d.nv, d.nu, d.nbody, d.nM, d.njoint = skel.nq, skel.nv, skel.nu, len(skel.body_names), skel.nM, len(skel.joint_names)
+        d.qM0 = self.qM0.ctypes.data_as(L.c_dbl_p)
+        d.Minv0 = self.Minv0.ctypes.data_as(L.c_dbl_p)
+        d.body_parent = self._keep["body_parent"].ctypes.data_as(L.c_int_p)
+        d.body_pos = self._keep["body_pos"].ctypes.data_as(L.c_dbl_p)
+        d.body_ndof = self._keep["body_ndof"].ctypes.data_as(L.c_int_p)
+        d.joint_axis = self._keep["joint_axis"].ctypes.data_as(L.c_dbl_p)
+        d.joint_anchor = self._keep["joint_anchor"].ctypes.data_as(L.c_dbl_p)
+        d.sub_dt, d.damping, d.support_k, d.support_c = float(skel.timestep), float(damping), float(support_k), float(support_c)
+        h = C.c_void_p()
+        L.check(self.lib.egp_physics_create_surrogate(C.byref(d), self.n_env, C.byref(h)), "egp_physics_create_surrogate")
+        self.handle = h
+
+    @property
+    def name(self):
+        return self.lib.egp_physics_name(self.handle).decode()
+
+    # single-env host access (CPU baseline / tests)
+    def reset(self, env, qpos, qvel):
+        qpos, qvel = _np_f64(qpos), _np_f64(qvel)
+        L.check(self.lib.egp_physics_reset_host(self.handle, int(env), qpos.ctypes.data, qvel.ctypes.data), "physics reset")
+
+    def step(self, env, ctrl):
+        ctrl = _np_f64(ctrl)
+        L.check(self.lib.egp_physics_step_host(self.handle, int(env), ctrl.ctypes.data), "physics step")
+
+    def drain(self, env, want_xpos=True):
+        sk = self.skel
+        qpos, qvel = np.empty(sk.nq), np.empty(sk.nv)
+        qM, bias = np.empty(sk.nM), np.empty(sk.nv)
+        xpos = np.empty((len(sk.body_names), 3)) if want_xpos else None
+        L.check(self.lib.egp_physics_drain_host(self.handle, int(env), qpos.ctypes.data, qvel.ctypes.data, qM.ctypes.data,
+                                                bias.ctypes.data, xpos.ctypes.data if want_xpos else None), "physics drain")
+        return qpos, qvel, qM, bias, xpos
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.egp_physics_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def default_threads():
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
+class RolloutEngine:
+    """egp_engine: n_env envs advance one env-step per step_async/wait pair."""
+
+    def __init__(self, ctx, physics, n_env: int, n_threads: Optional[int] = None, n_groups: int = 1):
+        import torch
+        self.lib = L.load()
+        self.ctx, self.physics = ctx, physics
+        self.n_env = int(n_env)
+        n_threads = default_threads() if n_threads is None else int(n_threads)
+        n_threads = max(int(n_groups), min(n_threads, self.n_env))
+        d = L.EngineDesc(self.n_env, n_threads, int(n_groups))
+        h = C.c_void_p()
+        L.check(self.lib.egp_engine_create(ctx.handle, physics.handle, C.byref(d), C.byref(h)), "egp_engine_create")
+        self.handle = h
+        self.n_threads, self.n_groups = n_threads, int(n_groups)
+        ptrs = [C.c_void_p() for _ in range(6)]
+        L.check(self.lib.egp_engine_state(self.handle, *[C.byref(p) for p in ptrs]), "egp_engine_state")
+        dev = torch.device("cuda", ctx.device)
+        self.qpos = _wrap_device(ptrs[0].value, (self.n_env, ctx.nq), dev)
+        self.qvel = _wrap_device(ptrs[1].value, (self.n_env, ctx.nv), dev)
+        self.ee_wpos = _wrap_device(ptrs[2].value, (self.n_env, 15), dev)
+        self.head_z = _wrap_host(ptrs[3].value, (self.n_env,))
+        self.qpos_host = _wrap_host(ptrs[4].value, (self.n_env, ctx.nq))
+        self.qvel_host = _wrap_host(ptrs[5].value, (self.n_env, ctx.nv))
+
+    def group_range(self, g):
+        a, b = C.c_int32(), C.c_int32()
+        L.check(self.lib.egp_engine_group_range(self.handle, int(g), C.byref(a), C.byref(b)), "egp_engine_group_range")
+        return a.value, b.value
+
+    def reset(self, env_ids, qpos, qvel):
+        import torch
+        ids = _np_i32(env_ids)
+        qpos, qvel = _np_f64(qpos), _np_f64(qvel)
+        if qpos.shape != (ids.shape[0], self.ctx.nq) or qvel.shape != (ids.shape[0], self.ctx.nv):
+            raise ValueError("reset rows must be (n, nq) / (n, nv)")
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(self.lib.egp_engine_reset(self.handle, ids.ctypes.data, ids.shape[0], qpos.ctypes.data, qvel.ctypes.data, s),
+                "egp_engine_reset")
+
+    def step_async(self, group, action, active_host=None, ready_event=None):
+        if not action.is_cuda or action.dtype.is_floating_point is False or tuple(action.shape) != (self.n_env, self.ctx.nu):
+            raise ValueError("action must be a CUDA float64 tensor of shape (n_env, nu)")
+        import torch
+        if action.dtype != torch.float64 or not action.is_contiguous():
+            raise ValueError("action must be contiguous float64")
+        act = None if active_host is None else _np_i32(active_host)
+        self._keep_active = act
+        ev = C.c_void_p(ready_event.cuda_event) if ready_event is not None else C.c_void_p(0)
+        L.check(self.lib.egp_engine_step_async(self.handle, int(group), C.c_void_p(action.data_ptr()),
+                                               act.ctypes.data if act is not None else None, ev), "egp_engine_step_async")
+
+    def wait(self, group):
+        import torch
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(self.lib.egp_engine_wait(self.handle, int(group), s), "egp_engine_wait")
+
+    def set_profile(self, on=True):
+        L.check(self.lib.egp_engine_set_profile(self.handle, 1 if on else 0), "egp_engine_set_profile")
+
+    def reset_timing(self):
+        L.check(self.lib.egp_engine_reset_timing(self.handle), "egp_engine_reset_timing")
+
+    def timing(self):
+        p, w, k = C.c_double(), C.c_double(), C.c_double()
+        n = C.c_int64()
+        L.check(self.lib.egp_engine_timing(self.handle, C.byref(p), C.byref(w), C.byref(k), C.byref(n)), "egp_engine_timing")
+        return dict(phys_s=p.value, gpu_wait_s=w.value, k1_ms=k.value, k1_launches=n.value)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.egp_engine_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _DevArray:
+    """__cuda_array_interface__ shim so torch can alias engine-owned HBM without copying."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _wrap_device(ptr, shape, device):
+    import torch
+    return torch.as_tensor(_DevArray(ptr, shape), device=device)
+
+
+def _wrap_host(ptr, shape):
+    n = int(np.prod(shape))
+    buf = (C.c_double * n).from_address(int(ptr))
+    return np.frombuffer(buf, dtype=np.float64).reshape(shape)

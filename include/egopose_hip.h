@@ -1,0 +1,253 @@
+/*
+ * egopose_hip.h -- C-ABI of the MI355X-native EgoPose PPO rollout+update hot path.
+ *
+ * The reference (Khrylx/EgoPose) is 100 % Python and has no FFI of its own; every entry point
+ * below is the drop-in for a Python function on the hot path, cited as reference file:line.
+ * The binding a maintainer adds on the reference side is a ctypes stub.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types. All array arguments are DEVICE pointers
+ *     (HBM) unless the name ends in `_host`. Arrays are env-major, row-contiguous:
+ *     qpos[n_env][nq], qvel[n_env][nv], ... exactly the layout MuJoCo's mjData has per env and
+ *     the layout TrajBatch exposes ((N,115) rows).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). Calls are
+ *     stream-ordered and asynchronous; nothing is retained past the call except inside `egp_ctx`.
+ *   - every function returns an int status: EGP_OK (0) or a negative EGP_E_* code; it never
+ *     throws. egp_last_error() gives a thread-local message.
+ *   - two arithmetic variants per kernel: `_f64` (the reference's float64 arithmetic; parity
+ *     <= 1e-10) and `_f32` (parity <= 1e-5; K1 keeps a float64 factorisation inside).
+ */
+#ifndef EGOPOSE_HIP_H
+#define EGOPOSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGP_OK 0
+#define EGP_E_INVALID (-1)   /* bad argument (NULL pointer, size mismatch, unsupported dims) */
+#define EGP_E_HIP (-2)       /* a HIP runtime call failed; see egp_last_error() */
+#define EGP_E_STATE (-3)     /* call order violated (e.g. reward before egp_upload_experts) */
+#define EGP_E_PHYSICS (-4)   /* the physics backend reported a failure */
+
+#define EGP_MAX_NV 64        /* K1 maps one dof per lane of a 64-wide wavefront */
+#define EGP_MAX_BODY 32      /* K2 maps one body per lane of a half wavefront */
+#define EGP_EXPERT_ROW 168   /* packed reward row per expert frame (166 used, padded) */
+
+typedef struct egp_ctx egp_ctx;          /* model constants + expert table resident in HBM */
+typedef struct egp_physics egp_physics;  /* host physics backend (MuJoCo-shaped boundary) */
+typedef struct egp_engine egp_engine;    /* lockstep rollout engine: host threads + pinned staging */
+
+/* ----------------------------------------------------------------------------------------
+ * Model description: what the reference reads from mujoco_py's model + its YAML Config.
+ *   skeleton tables   utils/tools.py:55-68 (body -> qpos address), mj_fullM's dof tree
+ *   PD gains          ego_pose/utils/egomimic_config.py:108-116
+ *   reward weights    ego_pose/core/reward_function.py:6-12, config/egomimic/<id>.yml
+ * All pointers are HOST pointers, copied at egp_create. */
+typedef struct egp_model_desc {
+    int32_t nq, nv, nu, nbody, nM;        /* 59, 58, 52, 21, 910 for humanoid_1205_v1 */
+    const int32_t *body_qpos_start;       /* [nbody] first qpos index of the body's joints (root: 0) */
+    const int32_t *body_ndof;             /* [nbody] hinge count (root: 6) */
+    const int32_t *dof_parentid;          /* [nv]    MuJoCo dof tree */
+    const int32_t *dof_Madr;              /* [nv]    start of dof i's chain in the sparse inertia qM */
+    const int32_t *ee_body;               /* [5]     LeftFoot, RightFoot, LeftHand, RightHand, Head */
+    const double *jkp, *jkd, *a_ref, *a_scale, *torque_lim;   /* [nu] each */
+    const double *b_diffw;                /* [nbody-1] */
+    double sub_dt;                        /* model timestep (1/450 s) */
+    int32_t frame_skip;                   /* 15 */
+    int32_t episode_len;                  /* env_episode_len (200) */
+    double w_p, w_v, w_e, w_rp, w_rv;     /* reward blend weights */
+    double k_p, k_v, k_e, k_rh, k_rq, k_rl, k_ra;
+    double v_ord;                         /* norm order of the body-angular-velocity term (2) */
+    int32_t decay;                        /* reward *= 1 - t/episode_len */
+} egp_model_desc;
+
+/* Expert table (ego_pose/data_process/gen_expert.py:28-83): all takes concatenated, HOST pointers.
+ * frame f of take k lives at row take_offset[k] + f. */
+typedef struct egp_expert_table {
+    int32_t n_takes;
+    int32_t n_frames;                     /* total rows */
+    const int32_t *take_offset;           /* [n_takes + 1] */
+    const double *qpos;                   /* [n_frames][59] */
+    const double *qvel;                   /* [n_frames][58] */
+    const double *rlinv_local;            /* [n_frames][3]  */
+    const double *rangv;                  /* [n_frames][3]  */
+    const double *rq_rmh;                 /* [n_frames][4]  */
+    const double *ee_pos;                 /* [n_frames][15] */
+    const double *bquat;                  /* [n_frames][84] */
+    const double *bangvel;                /* [n_frames][63] */
+    const double *head_height_lb;         /* [n_takes] */
+} egp_expert_table;
+
+const char *egp_last_error(void);
+const char *egp_version(void);
+
+int egp_create(const egp_model_desc *desc, int device, egp_ctx **out);
+int egp_destroy(egp_ctx *ctx);
+/* replaces reward weights in place (cfg.reward_weights can change between iterations) */
+int egp_set_reward_weights(egp_ctx *ctx, const egp_model_desc *desc);
+/* K1 implementation switch: 0 = in-register Gauss-Jordan (nv == 58 only, default), 1 = generic LDS kernel */
+int egp_set_pd_variant(egp_ctx *ctx, int variant);
+/* HumanoidEnv.load_experts (ego_pose/envs/humanoid_v1.py:47-54): packs the reward rows into HBM */
+int egp_upload_experts(egp_ctx *ctx, const egp_expert_table *tbl);
+
+/* ---------------------------------------------------------------------------------------- K4
+ * HumanoidEnv.get_body_quat (ego_pose/envs/humanoid_v1.py:113-125): qpos[n][nq] -> bquat[n][4*nbody] */
+int egp_body_quat_f64(egp_ctx *ctx, const double *qpos, int32_t n, double *bquat, void *stream);
+int egp_body_quat_f32(egp_ctx *ctx, const float *qpos, int32_t n, float *bquat, void *stream);
+
+/* ---------------------------------------------------------------------------------------- K3
+ * HumanoidEnv.get_full_obs (ego_pose/envs/humanoid_v1.py:73-96), obs_coord='heading',
+ * root_deheading, obs_vel='full': obs[n][nq-2+nv] */
+int egp_obs_f64(egp_ctx *ctx, const double *qpos, const double *qvel, int32_t n, double *obs, void *stream);
+int egp_obs_f32(egp_ctx *ctx, const float *qpos, const float *qvel, int32_t n, float *obs, void *stream);
+
+/* ---------------------------------------------------------------------------------------- K1
+ * HumanoidEnv.compute_torque + compute_desired_accel + the target/clip lines of do_simulation
+ * (ego_pose/envs/humanoid_v1.py:130-156,167-172) for ONE physics substep of n envs.
+ *   qM        [n][nM]  MuJoCo sparse inertia as left by the previous mj_step (mj_fullM is done on device)
+ *   qfrc_bias [n][nv]
+ *   action    [n][nu]  policy action (target = a_ref + action*a_scale)
+ *   torque    [n][nu]  out: clipped to +-torque_lim (what is written to data.ctrl)
+ *   torque_raw[n][nu]  out, optional (NULL to skip): before the clip */
+int egp_pd_torque_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const double *action,
+                      const double *qM, const double *qfrc_bias, int32_t n,
+                      double *torque, double *torque_raw, void *stream);
+int egp_pd_torque_f32(egp_ctx *ctx, const float *qpos, const float *qvel, const float *action,
+                      const float *qM, const float *qfrc_bias, int32_t n,
+                      float *torque, float *torque_raw, void *stream);
+
+/* ---------------------------------------------------------------------------------------- K2
+ * quat_space_reward_v3 (ego_pose/core/reward_function.py:4-60) on drained per-env state.
+ *   cur_qpos, prev_qpos [n][nq];  ee_wpos [n][15] world positions of the 5 end effectors
+ *   t      [n] env.cur_t after the step;  frame [n] global expert row (take_offset + start_ind + t)
+ *   end    [n] info['end'] (0/1);  active [n] optional (NULL = all): inactive envs write 0
+ *   reward [n], c_info [n][5] */
+int egp_reward_quat_v3_f64(egp_ctx *ctx, const double *cur_qpos, const double *prev_qpos,
+                           const double *ee_wpos, const int32_t *t, const int32_t *frame,
+                           const int32_t *end, const int32_t *active, double end_reward, int32_t n,
+                           double *reward, double *c_info, void *stream);
+int egp_reward_quat_v3_f32(egp_ctx *ctx, const float *cur_qpos, const float *prev_qpos,
+                           const float *ee_wpos, const int32_t *t, const int32_t *frame,
+                           const int32_t *end, const int32_t *active, double end_reward, int32_t n,
+                           float *reward, float *c_info, void *stream);
+
+/* ---------------------------------------------------------------------------------------- K6
+ * ZFilter / RunningStat (utils/zfilter.py:7-67), batched: Chan-merge the `active` rows of
+ * x[n][dim] into the running state, then y = clip((x-mean)/(std+1e-8), +-clip) for all rows.
+ *   state layout (device, float64 always): [0]=count, [1..dim]=mean, [1+dim..2*dim]=S
+ *   state_in may equal state_out only when update==0.
+ *   workspace: >= egp_zfilter_workspace_bytes(n, dim) bytes of device scratch */
+int64_t egp_zfilter_workspace_bytes(int32_t n, int32_t dim);
+int egp_zfilter_f64(const double *x, const int32_t *active, int32_t n, int32_t dim,
+                    const double *state_in, double *state_out, int32_t update, double clip,
+                    double *y, void *workspace, void *stream);
+int egp_zfilter_f32(const float *x, const int32_t *active, int32_t n, int32_t dim,
+                    const double *state_in, double *state_out, int32_t update, double clip,
+                    float *y, void *workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------- K5
+ * estimate_advantages (core/common.py:5-25) over the flat concatenated batch.
+ *   rewards, masks, values [n] -> adv_raw [n] (before standardisation), returns [n]
+ *   stats (device, float64[3]) receives {n, mean, M2 = sum (a-mean)^2} of adv_raw so that several
+ *   ranks can Chan-merge before standardising; egp_gae_standardize applies
+ *   (a - stats[1]) / sqrt(stats[2] / (stats[0] - 1))  (torch.std is unbiased) reading stats on device. */
+int64_t egp_gae_workspace_bytes(int32_t n);
+int egp_gae_f64(const double *rewards, const double *masks, const double *values, int32_t n,
+                double gamma, double tau, double *adv_raw, double *returns, double *stats,
+                void *workspace, void *stream);
+int egp_gae_f32(const float *rewards, const float *masks, const float *values, int32_t n,
+                double gamma, double tau, float *adv_raw, float *returns, double *stats,
+                void *workspace, void *stream);
+int egp_gae_standardize_f64(double *adv, int32_t n, const double *stats, void *stream);
+int egp_gae_standardize_f32(float *adv, int32_t n, const double *stats, void *stream);
+
+/* ----------------------------------------------------------------------------------------
+ * Host physics boundary (replaces mujoco_py's MjSim inside HumanoidEnv: envs/common/mujoco_env.py:84-105,
+ * ego_pose/envs/humanoid_v1.py:158-177). A backend is a vtable of plain C callbacks working on one
+ * env at a time; all buffers are HOST memory owned by the engine.
+ *   reset(user, env, qpos[nq], qvel[nv])                      set_state + forward
+ *   step (user, env, ctrl[nu])                                data.ctrl = ctrl; mj_step
+ *   drain(user, env, qpos, qvel, qM[nM], qfrc_bias[nv], xpos[nbody*3])   copy out mjData fields
+ * A MuJoCo adapter fills this from mj_step / mjData; the built-in surrogate is egp_physics_create_surrogate. */
+typedef struct egp_physics_vtable {
+    void *user;
+    int (*reset)(void *user, int32_t env, const double *qpos, const double *qvel);
+    int (*step)(void *user, int32_t env, const double *ctrl);
+    int (*drain)(void *user, int32_t env, double *qpos, double *qvel, double *qM, double *qfrc_bias,
+                 double *xpos);
+    void (*destroy)(void *user);
+    const char *name;
+} egp_physics_vtable;
+
+int egp_physics_register(const egp_physics_vtable *vt, int32_t n_env, egp_physics **out);
+/* Deterministic surrogate: semi-implicit Euler on qacc = M0^-1 (tau - C), fixed tree-sparse SPD M0
+ * (host arrays: qM0[nM], Minv0[nv*nv], body tree for FK). NOT MuJoCo; physics parity is unpinned. */
+typedef struct egp_surrogate_desc {
+    int32_t nq, nv, nu, nbody, nM, njoint;
+    const double *qM0;            /* [nM] */
+    const double *Minv0;          /* [nv*nv] */
+    const int32_t *body_parent;   /* [nbody] */
+    const double *body_pos;       /* [nbody*3] */
+    const int32_t *body_ndof;     /* [nbody] */
+    const double *joint_axis;     /* [njoint*3] */
+    const double *joint_anchor;   /* [njoint*3] */
+    double sub_dt;
+    double damping;               /* viscous joint damping in the bias force */
+    double support_k, support_c;  /* vertical root support spring / damper (stands in for contacts) */
+} egp_surrogate_desc;
+int egp_physics_create_surrogate(const egp_surrogate_desc *desc, int32_t n_env, egp_physics **out);
+int egp_physics_destroy(egp_physics *p);
+const char *egp_physics_name(const egp_physics *p);
+/* single-env host access (used by the CPU baseline and tests) */
+int egp_physics_reset_host(egp_physics *p, int32_t env, const double *qpos_host, const double *qvel_host);
+int egp_physics_step_host(egp_physics *p, int32_t env, const double *ctrl_host);
+int egp_physics_drain_host(egp_physics *p, int32_t env, double *qpos_host, double *qvel_host,
+                           double *qM_host, double *qfrc_bias_host, double *xpos_host);
+
+/* ----------------------------------------------------------------------------------------
+ * Lockstep rollout engine: n_env envs advance one env-step (frame_skip substeps of
+ * {K1 on the GPU <-> physics on host threads}) per egp_engine_step. Replaces the 15x
+ * compute_torque/sim.step loop of do_simulation (ego_pose/envs/humanoid_v1.py:158-177) for all
+ * envs at once; state is staged through pinned buffers with hipMemcpyAsync on per-worker streams. */
+typedef struct egp_engine_desc {
+    int32_t n_env;
+    int32_t n_threads;       /* host physics worker threads (reference: --num-threads samplers) */
+    int32_t n_groups;        /* env groups that can be stepped independently (policy/physics overlap) */
+} egp_engine_desc;
+
+int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *desc, egp_engine **out);
+int egp_engine_destroy(egp_engine *e);
+/* state of all envs after reset/wait, env-major float64. Device: qpos[n][nq], qvel[n][nv], ee_wpos[n][15]
+ * (world positions of the 5 end effectors, data.body_xpos rows). Pinned host mirrors: head_z[n]
+ * (get_body_com('Head')[2], humanoid_v1.py:191-196), qpos/qvel. Any out-pointer may be NULL. */
+int egp_engine_state(egp_engine *e, double **qpos, double **qvel, double **ee_wpos, double **head_z_host,
+                     double **qpos_host, double **qvel_host);
+/* HumanoidEnv.reset_model's set_state (+ sim.forward) for the listed envs (strictly increasing ids):
+ * rows qpos_host[k][nq], qvel_host[k][nv]; their drained state is uploaded on `stream`. */
+int egp_engine_reset(egp_engine *e, const int32_t *env_ids_host, int32_t n, const double *qpos_host,
+                     const double *qvel_host, void *stream);
+/* start one env-step (frame_skip substeps) for group g: `action` is a DEVICE pointer [n_env][nu];
+ * `active_host` [n_env] (optional) marks the envs to step; `ready_event` (optional hipEvent_t) is waited
+ * on by every worker stream before its first K1 launch (action produced on another stream). */
+int egp_engine_step_async(egp_engine *e, int32_t group, const double *action, const int32_t *active_host,
+                          void *ready_event);
+/* block until group g finished; makes `stream` wait for the final uploads so kernels enqueued on it
+ * afterwards see the new device state */
+int egp_engine_wait(egp_engine *e, int32_t group, void *stream);
+/* accumulated since creation / egp_engine_reset_timing, summed over workers: host physics seconds,
+ * seconds blocked on the GPU round trip, and (when profiling) K1 time by HIP events on the launch
+ * streams + number of K1 launches */
+int egp_engine_timing(egp_engine *e, double *phys_s, double *gpu_wait_s, double *k1_ms_events, int64_t *k1_launches);
+int egp_engine_reset_timing(egp_engine *e);
+int egp_engine_set_profile(egp_engine *e, int on);   /* record HIP events around every K1 launch */
+int egp_engine_layout(egp_engine *e, int32_t *pack_ld, int32_t *n_env, int32_t *n_threads, int32_t *n_groups);
+int egp_engine_group_range(egp_engine *e, int32_t group, int32_t *env_begin, int32_t *env_end);
+int32_t egp_physics_n_env(const egp_physics *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGOPOSE_HIP_H */

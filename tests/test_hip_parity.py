@@ -1,0 +1,285 @@
+"""GPU parity: the HIP kernels (through the C-ABI) against the golden vectors generated from the
+reference and against the oracle on seeded inputs.
+
+Tolerances (BASELINE.md "parity gates"): float64 variants <= 1e-10 (abs, on O(1) quantities; torques are
+O(100) so they get rtol 1e-10), float32 variants <= 1e-5 relative to the quantity's scale.
+"""
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import load_golden
+from oracle import humanoid as H, reward as R, gae as G, zfilter as Z
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda")
+
+
+@pytest.fixture(scope="module")
+def ctx(skel):
+    from egopose_amd.hip import EgpContext
+    c = load_golden("config_subject_03.npz")
+    ws = dict(zip([str(k) for k in c["reward_keys"]], [float(v) for v in c["reward_vals"]]))
+    cx = EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"],
+                    reward_weights=ws, episode_len=int(c["env_episode_len"]))
+    yield cx
+    cx.close()
+
+
+# ------------------------------------------------------------------------------------------------ K4 / K3
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-6)])
+def test_body_quat_and_obs_golden(ctx, dtype, tol):
+    g = load_golden("body_quat_obs.npz")
+    bq = ctx.body_quat(dev(g["qpos"], dtype)).cpu().numpy()
+    np.testing.assert_allclose(bq, g["bquat"], rtol=0, atol=tol)
+    obs = ctx.obs(dev(g["qpos"], dtype), dev(g["qvel"], dtype)).cpu().numpy()
+    np.testing.assert_allclose(obs, g["obs"], rtol=tol, atol=tol * 10)
+
+
+def test_obs_and_body_quat_edge_sizes(ctx):
+    g = load_golden("body_quat_obs.npz")
+    assert ctx.body_quat(dev(g["qpos"][:0])).shape == (0, 84)          # empty batch is a no-op
+    assert ctx.obs(dev(g["qpos"][:0]), dev(g["qvel"][:0])).shape == (0, 115)
+    one = ctx.obs(dev(g["qpos"][:1]), dev(g["qvel"][:1])).cpu().numpy()
+    np.testing.assert_allclose(one, g["obs"][:1], rtol=1e-12, atol=1e-12)
+    with pytest.raises(ValueError):
+        ctx.obs(dev(g["qpos"][:4]), dev(g["qvel"][:3]))
+
+
+# ------------------------------------------------------------------------------------------------ K1
+@pytest.mark.parametrize("variant", [0, 1])
+def test_pd_torque_golden_f64(ctx, variant):
+    g = load_golden("pd_torque.npz")
+    ctx.set_pd_variant(variant)
+    try:
+        tq, raw = ctx.pd_torque(dev(g["qpos"]), dev(g["qvel"]), dev(g["action"]), dev(g["qM"]), dev(g["C"]), want_raw=True)
+    finally:
+        ctx.set_pd_variant(0)
+    np.testing.assert_allclose(raw.cpu().numpy(), g["torque"], rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(tq.cpu().numpy(), g["torque_clipped"], rtol=1e-10, atol=1e-9)
+
+
+def test_pd_torque_golden_f32_io(ctx):
+    g = load_golden("pd_torque.npz")
+    f = torch.float32
+    tq, raw = ctx.pd_torque(dev(g["qpos"], f), dev(g["qvel"], f), dev(g["action"], f), dev(g["qM"], f), dev(g["C"], f), want_raw=True)
+    scale = np.abs(g["torque"]).max()
+    assert np.abs(raw.cpu().numpy() - g["torque"]).max() / scale < 1e-5
+
+
+def test_pd_torque_ragged_and_large_vs_oracle(ctx, skel):
+    c = load_golden("config_subject_03.npz")
+    rng = np.random.RandomState(5)
+    M0 = skel.zero_pose_inertia()
+    for n in (1, 3, 5, 130):          # not multiples of the 4-envs-per-block tiling
+        d = 1.0 + 0.2 * rng.uniform(-1, 1, size=(n, 58))
+        qM = np.stack([skel.sparse_from_full(M0 * di[:, None] * di[None, :]) for di in d])
+        qpos = rng.normal(size=(n, 59)) * 0.3
+        qvel = rng.normal(size=(n, 58)) * 3
+        act = rng.normal(size=(n, 52)) * 0.5
+        C = rng.normal(size=(n, 58)) * 20
+        tq, raw = ctx.pd_torque(dev(qpos), dev(qvel), dev(act), dev(qM), dev(C), want_raw=True)
+        M = H.full_from_sparse(qM, skel.dof_parentid, skel.dof_Madr)
+        t_ref, tc_ref = H.pd_torque(qpos, qvel, act, M, C, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], skel.timestep)
+        np.testing.assert_allclose(raw.cpu().numpy(), t_ref, rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(tq.cpu().numpy(), tc_ref, rtol=1e-10, atol=1e-9)
+    # full size (BASELINE config 2): linearity-free property -- the solve satisfies its own equation
+    n = 1024
+    qM = np.tile(skel.sparse_from_full(M0), (n, 1))
+    qpos, qvel = rng.normal(size=(n, 59)) * 0.3, rng.normal(size=(n, 58))
+    act, C = rng.normal(size=(n, 52)) * 0.3, rng.normal(size=(n, 58)) * 5
+    _, raw = ctx.pd_torque(dev(qpos), dev(qvel), dev(act), dev(qM), dev(C), want_raw=True)
+    raw = raw.cpu().numpy()
+    kp, kd, dt = np.r_[np.zeros(6), c["jkp"]], np.r_[np.zeros(6), c["jkd"]], skel.timestep
+    e_q = np.c_[np.zeros((n, 6)), qpos[:, 7:] - (c["a_ref"] + act * c["a_scale"])]
+    # recover qacc from tau: tau = -kp e - kd (v + a dt)  =>  a = (-(tau + kp e)/kd - v)/dt   (actuated dofs)
+    acc_act = (-(raw + c["jkp"] * e_q[:, 6:]) / c["jkd"] - qvel[:, 6:]) / dt
+    A = M0 + np.diag(kd) * dt
+    rhs = -C - kp * e_q - kd * qvel
+    # residual of the actuated block after eliminating the 6 root rows
+    Arr, Ara, Aar, Aaa = A[:6, :6], A[:6, 6:], A[6:, :6], A[6:, 6:]
+    S = Aaa - Aar @ np.linalg.solve(Arr, Ara)
+    rs = rhs[:, 6:] - (Aar @ np.linalg.solve(Arr, rhs[:, :6].T)).T
+    resid = acc_act @ S.T - rs
+    assert np.abs(resid).max() / np.abs(rs).max() < 1e-8
+
+
+# ------------------------------------------------------------------------------------------------ K2
+def _upload_golden_expert(ctx, g):
+    take = {k: g["expert_" + k] for k in ["qpos", "qvel", "rlinv_local", "rangv", "rq_rmh", "ee_pos", "bquat", "bangvel"]}
+    take["head_height_lb"] = 1.2
+    ctx.upload_experts([take])
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-5)])
+def test_reward_golden(ctx, dtype, tol):
+    g = load_golden("reward.npz")
+    _upload_golden_expert(ctx, g)
+    wsets = [yaml.safe_load(str(s)) for s in g["wset_json"]]
+    i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32, device="cuda")
+    try:
+        for wi, ws in enumerate(wsets):
+            ctx.set_reward_weights(ws)
+            sel = np.where(g["wset"] == wi)[0]
+            # end_reward is a per-call scalar: group by value (each golden case has its own)
+            for j in sel:
+                r, ci = ctx.reward(dev(g["cur_qpos"][[j]], dtype), dev(g["prev_qpos"][[j]], dtype), dev(g["ee_wpos"][[j]], dtype),
+                                   i32(g["t"][[j]]), i32(g["start_ind"][[j]] + g["t"][[j]]), i32(g["end"][[j]]),
+                                   float(g["end_reward"][j]))
+                np.testing.assert_allclose(ci.cpu().numpy()[0], g["c_info"][j], rtol=0, atol=tol * 5)
+                np.testing.assert_allclose(r.cpu().numpy()[0], g["reward"][j], rtol=tol, atol=tol * 5)
+            # batched call, end_reward 0 -> compare with golden minus the per-case bonus
+            r, ci = ctx.reward(dev(g["cur_qpos"][sel], dtype), dev(g["prev_qpos"][sel], dtype), dev(g["ee_wpos"][sel], dtype),
+                               i32(g["t"][sel]), i32(g["start_ind"][sel] + g["t"][sel]), i32(g["end"][sel]), 0.0)
+            want = g["reward"][sel] - np.where(g["end"][sel], g["end_reward"][sel], 0.0)
+            np.testing.assert_allclose(r.cpu().numpy(), want, rtol=tol, atol=tol * 5)
+            np.testing.assert_allclose(ci.cpu().numpy(), g["c_info"][sel], rtol=0, atol=tol * 5)
+    finally:
+        ctx.set_reward_weights(wsets[0])
+
+
+def test_reward_active_mask_and_state_errors(ctx, skel):
+    from egopose_amd.hip import EgpContext
+    g = load_golden("reward.npz")
+    _upload_golden_expert(ctx, g)
+    i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32, device="cuda")
+    sel = np.arange(8)
+    act = np.array([1, 0, 1, 1, 0, 1, 1, 1])
+    r, ci = ctx.reward(dev(g["cur_qpos"][sel]), dev(g["prev_qpos"][sel]), dev(g["ee_wpos"][sel]), i32(g["t"][sel]),
+                       i32(g["start_ind"][sel] + g["t"][sel]), i32(g["end"][sel]), 0.0, active=i32(act))
+    r = r.cpu().numpy()
+    assert r[1] == 0.0 and r[4] == 0.0 and (ci.cpu().numpy()[[1, 4]] == 0).all() and (r[[0, 2, 3]] > 0).all()
+    c = load_golden("config_subject_03.npz")
+    fresh = EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"])
+    with pytest.raises(RuntimeError, match="egp_upload_experts"):      # reward before the expert table is resident
+        fresh.reward(dev(g["cur_qpos"][sel]), dev(g["prev_qpos"][sel]), dev(g["ee_wpos"][sel]), i32(g["t"][sel]),
+                     i32(g["t"][sel]), i32(g["end"][sel]), 0.0)
+    fresh.close()
+
+
+# ------------------------------------------------------------------------------------------------ K6
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 2e-5)])
+def test_zfilter_blocks_match_sequential_reference(ctx, dtype, tol):
+    g = load_golden("zfilter.npz")
+    X = g["X"]
+    st = torch.zeros(1 + 2 * 115, dtype=torch.float64, device="cuda")
+    ys = []
+    for lo, hi in [(0, 1), (1, 64), (64, 65), (65, 300)]:
+        st2 = torch.empty_like(st)
+        ys.append(ctx.zfilter(dev(X[lo:hi], dtype), st, st2, update=True, clip=5.0))
+        st = st2
+    s = st.cpu().numpy()
+    assert s[0] == float(g["n"])
+    np.testing.assert_allclose(s[1:116], g["mean"], rtol=1e-12, atol=1e-12 if dtype == torch.float64 else 1e-6)
+    np.testing.assert_allclose(s[116:], g["S"], rtol=1e-10 if dtype == torch.float64 else 1e-5, atol=1e-9)
+    # frozen filter == reference ZFilter.__call__(x, update=False) with the final statistics
+    y = ctx.zfilter(dev(X[:16], dtype), st, update=False, clip=5.0).cpu().numpy()
+    np.testing.assert_allclose(y, g["Yfrozen"], rtol=tol, atol=tol)
+    # first block of one sample: n==1 branch (var = mean^2)
+    np.testing.assert_allclose(ys[0].cpu().numpy()[0], g["y_first"], rtol=tol, atol=tol)
+    # the last sample of a block is normalised with the same statistics as in the sequential reference
+    np.testing.assert_allclose(ys[-1].cpu().numpy()[-1], g["Y"][-1], rtol=tol, atol=tol)
+
+
+def test_zfilter_active_mask_and_large(ctx):
+    rng = np.random.RandomState(0)
+    n, dim = 5000, 115
+    X = rng.normal(size=(n, dim)) * 3 + 1
+    act = (rng.uniform(size=n) < 0.7).astype(np.int32)
+    st0 = torch.zeros(1 + 2 * dim, dtype=torch.float64, device="cuda")
+    st1 = torch.empty_like(st0)
+    y = ctx.zfilter(dev(X), st0, st1, update=True, clip=5.0, active=torch.as_tensor(act, device="cuda")).cpu().numpy()
+    rs = Z.RunningStatOracle(dim)
+    rs.merge_block(X[act == 1])
+    s = st1.cpu().numpy()
+    assert s[0] == act.sum()
+    np.testing.assert_allclose(s[1:1 + dim], rs.mean, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(s[1 + dim:], rs.S, rtol=1e-10)
+    np.testing.assert_allclose(y, Z.zfilter_apply(X, rs.mean, rs.std, 5.0), rtol=1e-10, atol=1e-10)
+    # no active rows: state passes through unchanged
+    st2 = torch.empty_like(st0)
+    ctx.zfilter(dev(X[:10]), st1, st2, update=True, clip=5.0, active=torch.zeros(10, dtype=torch.int32, device="cuda"))
+    np.testing.assert_array_equal(st2.cpu().numpy(), s)
+
+
+# ------------------------------------------------------------------------------------------------ K5
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-4)])
+def test_gae_golden(ctx, dtype, tol):
+    g = load_golden("gae.npz")
+    for mk, gm, tu, a_key, r_key in [("masks", "gamma", "tau", "adv", "ret"), ("masks2", "gamma2", "tau2", "adv2", "ret2")]:
+        adv, ret, stats = ctx.gae(dev(g["rewards"], dtype), dev(g[mk], dtype), dev(g["values"].ravel(), dtype), float(g[gm]), float(g[tu]))
+        np.testing.assert_allclose(ret.cpu().numpy(), g[r_key].ravel(), rtol=tol, atol=tol)   # north-star: returns within 1e-4 fp32
+        ctx.gae_standardize(adv, stats)
+        np.testing.assert_allclose(adv.cpu().numpy(), g[a_key].ravel(), rtol=tol, atol=tol)   # advantages within 1e-4 fp32
+
+
+def test_gae_sizes_vs_oracle(ctx):
+    rng = np.random.RandomState(3)
+    for n in (1, 2, 31, 32, 33, 1000, 204800):      # chunk edges (32) and the config-2 sweep size
+        r = rng.uniform(0, 1.2, size=n)
+        m = (rng.uniform(size=n) > 0.02).astype(float)
+        v = rng.normal(size=n) * 2
+        adv, ret, stats = ctx.gae(dev(r), dev(m), dev(v), 0.95, 0.95)
+        if n <= 33000:
+            a_ref, r_ref, raw_ref = G.estimate_advantages(r, m, v, 0.95, 0.95)
+        else:   # size-independent check at full size: the recurrence holds element-wise
+            a = adv.cpu().numpy()
+            nxt_a = np.r_[a[1:], 0.0]
+            nxt_v = np.r_[v[1:], 0.0]
+            np.testing.assert_allclose(a, r + 0.95 * nxt_v * m - v + 0.95 * 0.95 * m * nxt_a, rtol=1e-11, atol=1e-11)
+            np.testing.assert_allclose(ret.cpu().numpy(), v + a, rtol=1e-12, atol=1e-12)
+            s = stats.cpu().numpy()
+            np.testing.assert_allclose([s[0], s[1], s[2]], [n, a.mean(), ((a - a.mean()) ** 2).sum()], rtol=1e-9)
+            continue
+        np.testing.assert_allclose(adv.cpu().numpy(), raw_ref.ravel(), rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(ret.cpu().numpy(), r_ref.ravel(), rtol=1e-11, atol=1e-11)
+        if n > 1:
+            ctx.gae_standardize(adv, stats)
+            np.testing.assert_allclose(adv.cpu().numpy(), a_ref.ravel(), rtol=1e-9, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------ engine
+def test_engine_step_matches_host_loop(ctx, skel):
+    """15 substeps of {K1 on GPU <-> surrogate physics on host threads} == the same loop done
+    env by env with the oracle's stable-PD on the CPU (do_simulation, humanoid_v1.py:158-177)."""
+    from egopose_amd.physics import SurrogatePhysics, RolloutEngine
+    c = load_golden("config_subject_03.npz")
+    g = load_golden("body_quat_obs.npz")
+    n = 37
+    rng = np.random.RandomState(9)
+    qpos0, qvel0 = g["qpos"][:n], g["qvel"][:n] * 0.2
+    action = rng.normal(size=(n, 52)) * 0.2
+    for n_groups, n_threads in [(1, 3), (2, 4)]:
+        ph = SurrogatePhysics(skel, n)
+        eng = RolloutEngine(ctx, ph, n, n_threads=n_threads, n_groups=n_groups)
+        eng.reset(np.arange(n), qpos0, qvel0)
+        act_d = dev(action)
+        torch.cuda.synchronize()
+        for gi in range(n_groups):
+            eng.step_async(gi, act_d)
+        for gi in range(n_groups):
+            eng.wait(gi)
+        torch.cuda.synchronize()
+        got_q, got_v, got_ee = eng.qpos.cpu().numpy(), eng.qvel.cpu().numpy(), eng.ee_wpos.cpu().numpy()
+        head_z = eng.head_z.copy()
+        eng.close()
+        ph.close()
+        # host loop
+        ref = SurrogatePhysics(skel, n)
+        for e in range(n):
+            ref.reset(e, qpos0[e], qvel0[e])
+            for s in range(15):
+                q, v, qM, bias, _ = ref.drain(e, want_xpos=False)
+                M = H.full_from_sparse(qM, skel.dof_parentid, skel.dof_Madr)
+                _, tc = H.pd_torque(q, v, action[e], M, bias, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], skel.timestep)
+                ref.step(e, tc[0])
+            q, v, _, _, xpos = ref.drain(e)
+            np.testing.assert_allclose(got_q[e], q, rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(got_v[e], v, rtol=1e-8, atol=1e-8)
+            np.testing.assert_allclose(got_ee[e], xpos[skel.ee_body].ravel(), rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(head_z[e], xpos[6, 2], rtol=1e-9, atol=1e-9)
+        ref.close()
