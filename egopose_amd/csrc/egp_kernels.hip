@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void k_reward_quat_v3(DevModel m, RewardW w, c
         const T *eb = er + ER_BQ + 4 * (l - 1);
         const Q4<T> qe{eb[0], eb[1], eb[2], eb[3]};
         const Q4<T> d = qmul(qc, qinv(qe));
-        const T pd = t_acos<T>(clamp1<T>(d.w)) * (T)s_bw[l];
+        const T pd = half_angle<T>(d) * (T)s_bw[l];
         pose_sq = pd * pd;
         const Q4<T> dv = qmul(qc, qinv(qp));
         V3<T> ax; T ang;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k_reward_quat_v3(DevModel m, RewardW w, c
         rv_r = t_exp<T>(-(T)w.k_rl * dl - (T)w.k_ra * da);
         const Q4<T> rq = de_heading(rc);
         const Q4<T> erq{er[ER_RQ], er[ER_RQ + 1], er[ER_RQ + 2], er[ER_RQ + 3]};
-        const T dq = t_acos<T>(clamp1<T>(qmul(rq, qinv(erq)).w));
+        const T dq = half_angle<T>(qmul(rq, qinv(erq)));
         const T dh = cq[2] - er[ER_Z];
         rp_r = t_exp<T>(-(T)w.k_rh * dh * dh - (T)w.k_rq * dq * dq);
     } else if (l < m.nbody + 5) {
@@ -726,9 +726,10 @@ static inline int after_launch(const char *what) {
 
 template <typename T>
 static int launch_body_quat(egp_ctx *ctx, const T *qpos, int n, T *bquat, void *stream) {
-    EGP_REQUIRE(ctx && qpos && bquat, "NULL pointer");
+    EGP_REQUIRE(ctx, "ctx is NULL");
     EGP_REQUIRE(n >= 0, "n < 0");
     if (n == 0) return EGP_OK;
+    EGP_REQUIRE(qpos && bquat, "NULL pointer");
     const long total = (long)n * ctx->dm.nbody;
     k_body_quat<T><<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(ctx->dm, qpos, n, bquat);
     return after_launch("k_body_quat");
@@ -736,9 +737,10 @@ static int launch_body_quat(egp_ctx *ctx, const T *qpos, int n, T *bquat, void *
 
 template <typename T>
 static int launch_obs(egp_ctx *ctx, const T *qpos, const T *qvel, int n, T *obs, void *stream) {
-    EGP_REQUIRE(ctx && qpos && qvel && obs, "NULL pointer");
+    EGP_REQUIRE(ctx, "ctx is NULL");
     EGP_REQUIRE(n >= 0, "n < 0");
     if (n == 0) return EGP_OK;
+    EGP_REQUIRE(qpos && qvel && obs, "NULL pointer");
     const long total = (long)n * (ctx->dm.nq - 2 + ctx->dm.nv);
     k_obs<T><<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(ctx->dm, qpos, qvel, n, obs);
     return after_launch("k_obs");
@@ -747,9 +749,10 @@ static int launch_obs(egp_ctx *ctx, const T *qpos, const T *qvel, int n, T *obs,
 template <typename T>
 static int launch_pd(egp_ctx *ctx, const PdLd &ld, const T *qpos, const T *qvel, const T *action, const T *qM, const T *C, int n,
                      T *torque, T *torque_raw, hipStream_t stream) {
-    EGP_REQUIRE(ctx && qpos && qvel && action && qM && C && torque, "NULL pointer");
+    EGP_REQUIRE(ctx, "ctx is NULL");
     EGP_REQUIRE(n >= 0, "n < 0");
     if (n == 0) return EGP_OK;
+    EGP_REQUIRE(qpos && qvel && action && qM && C && torque, "NULL pointer");
     if (ctx->pd_variant == 0) {
         k_pd_torque_reg58<T><<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, C, n, torque, torque_raw);
         return after_launch("k_pd_torque_reg58");
@@ -774,10 +777,11 @@ template <typename T>
 static int launch_reward(egp_ctx *ctx, const T *expert_rows, const T *cur_qpos, const T *prev_qpos, const T *ee_wpos,
                          const int *t, const int *frame, const int *endf, const int *active, double end_reward, int n,
                          T *reward, T *cinfo, void *stream) {
-    EGP_REQUIRE(ctx && cur_qpos && prev_qpos && ee_wpos && t && frame && endf && reward && cinfo, "NULL pointer");
+    EGP_REQUIRE(ctx, "ctx is NULL");
     EGP_REQUIRE(n >= 0, "n < 0");
     if (!expert_rows) { set_error("egp_upload_experts must be called before the reward kernel"); return EGP_E_STATE; }
     if (n == 0) return EGP_OK;
+    EGP_REQUIRE(cur_qpos && prev_qpos && ee_wpos && t && frame && endf && reward && cinfo, "NULL pointer");
     const long threads = (long)n * 32;
     k_reward_quat_v3<T><<<dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
         ctx->dm, ctx->rw, expert_rows, cur_qpos, prev_qpos, ee_wpos, t, frame, endf, active, (T)end_reward, n, reward, cinfo);
@@ -796,7 +800,7 @@ static inline void zf_tiling(int n, int *rows_per_tile, int *n_tiles) {
 template <typename T>
 static int launch_zfilter(const T *x, const int *active, int n, int dim, const double *st_in, double *st_out, int update,
                           double clip, T *y, void *ws, void *stream) {
-    EGP_REQUIRE(x && st_in && y, "NULL pointer");
+    EGP_REQUIRE(st_in && (n == 0 || (x && y)), "NULL pointer");
     EGP_REQUIRE(n >= 0 && dim > 0 && dim <= 4096, "bad n/dim");
     EGP_REQUIRE(!update || (st_out && ws && st_out != st_in), "update needs workspace and a distinct state_out");
     if (n == 0) {

@@ -95,13 +95,26 @@ template <typename T> __device__ __forceinline__ void rot_axis_angle(const Q4<T>
     if (T(1) - q.w < T(1e-8)) {
         axis->x = T(1); axis->y = T(0); axis->z = T(0);
         *angle = T(0);
-    } else {
+    } else if (sizeof(T) == 8) {
         const T s = t_sqrt<T>(T(1) - q.w * q.w);
         axis->x = q.x / s; axis->y = q.y / s; axis->z = q.z / s;
         *angle = T(2) * t_acos<T>(q.w);
+    } else {
+        // float32 variant: sqrt(1-w^2) and acos(w) lose all digits for small rotations; for a unit
+        // quaternion |xyz| == sqrt(1-w^2) and atan2(|xyz|, w) == acos(w), both well conditioned.
+        const T s = t_sqrt<T>(q.x * q.x + q.y * q.y + q.z * q.z);
+        axis->x = q.x / s; axis->y = q.y / s; axis->z = q.z / s;
+        *angle = T(2) * atan2f((float)s, (float)q.w);
     }
 }
 
 template <typename T> __device__ __forceinline__ T clamp1(T v) { return v < T(-1) ? T(-1) : (v > T(1) ? T(1) : v); }
+
+// multi_quat_norm: arccos(clip(w, -1, 1)) = HALF the rotation angle  (utils/math.py:96-100)
+template <typename T> __device__ __forceinline__ T half_angle(const Q4<T> &q) {
+    if (sizeof(T) == 8) return t_acos<T>(clamp1<T>(q.w));
+    const T s = t_sqrt<T>(q.x * q.x + q.y * q.y + q.z * q.z);   // float32: see rot_axis_angle
+    return (T)atan2f((float)s, (float)q.w);
+}
 
 }  // namespace egp
