@@ -85,6 +85,8 @@ SIGNATURES = {
     "egp_pd_torque_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, _i32, vp, vp, vp]),
     "egp_reward_quat_v3_f64": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, _f64, _i32, vp, vp, vp]),
     "egp_reward_quat_v3_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, _f64, _i32, vp, vp, vp]),
+    "egp_pose_features_f64": (C.c_int, [vp, vp, vp, vp, _i32, _i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "egp_pose_features_f32": (C.c_int, [vp, vp, vp, vp, _i32, _i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "egp_zfilter_workspace_bytes": (_i64, [_i32, _i32]),
     "egp_zfilter_f64": (C.c_int, [vp, vp, _i32, _i32, vp, vp, _i32, _f64, vp, vp, vp]),
     "egp_zfilter_f32": (C.c_int, [vp, vp, _i32, _i32, vp, vp, _i32, _f64, vp, vp, vp]),

@@ -1,0 +1,293 @@
+"""PPO agents on the batched rollout (drop-in for the reference's agent classes on the ego_mimic path).
+
+  Agent      agents/agent.py:9-122       sample() -> (TrajBatch, LoggerRL); hooks; set_noise_rate
+  AgentPG    agents/agent_pg.py:7-57     update_value / update_policy (A2C) / update_params
+  AgentPPO   agents/agent_ppo.py:6-65    clipped-surrogate update, grad-norm clip
+  AgentEgo   ego_pose/core/agent_ego.py:8-57   video-context nets, v_metas, TrajBatchEgo
+
+Constructor keywords are the reference's. ``sample`` does not fork Python workers: it drives
+``LockstepRollout`` over ``num_envs`` env slots of this rank's GPU (``num_threads`` becomes the number of
+host physics threads). ``update_params`` keeps everything in HBM: values -> K5 GAE (+ global
+standardisation) -> ``opt_num_epochs`` full-batch epochs; with ``torch.distributed`` initialised the flat
+policy+value gradient is all-reduced once per epoch (RCCL over xGMI) so that every rank applies the
+gradient of the global batch mean, exactly what the reference's single-process full batch computes.
+"""
+from __future__ import annotations
+
+import math
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import dist as D
+from .rl_core import LoggerRL, TrajBatch, TrajBatchEgo
+from .torch_utils import to_test, to_train
+
+
+def _column(batch, name, dtype, device):
+    col = batch.device_column(name) if hasattr(batch, "device_column") else None
+    if col is not None and col.device == device:
+        return col.to(dtype)
+    return torch.from_numpy(np.asarray(getattr(batch, name))).to(dtype).to(device)
+
+
+class Agent:
+
+    def __init__(self, env, policy_net, value_net, dtype, device, custom_reward=None, mean_action=False,
+                 render=False, running_state=None, num_threads=1, num_envs=None, num_groups=None):
+        self.env, self.policy_net, self.value_net = env, policy_net, value_net
+        self.dtype, self.device = dtype, device
+        self.custom_reward = custom_reward
+        self.mean_action, self.render = mean_action, render
+        self.running_state = running_state
+        self.num_threads = num_threads
+        self.num_envs = int(num_envs if num_envs is not None else os.environ.get("EGP_NUM_ENVS", 1024))
+        self.num_groups = int(num_groups if num_groups is not None else os.environ.get("EGP_NUM_GROUPS", 2))
+        self.noise_rate = 1.0
+        self.traj_cls = TrajBatch
+        self.logger_cls = LoggerRL
+        self.sample_modules = [policy_net]
+        self.update_modules = [policy_net, value_net]
+        self._rollout = None
+
+    # hooks kept for subclasses / API compatibility
+    def pre_episode(self):
+        return
+
+    def pre_sample(self):
+        return
+
+    def push_memory(self, memory, state, action, mask, next_state, reward, exp):
+        memory.push(state, action, mask, next_state, reward, exp)
+
+    def trans_policy(self, states):
+        return states
+
+    def trans_value(self, states):
+        return states
+
+    def set_noise_rate(self, noise_rate):
+        self.noise_rate = noise_rate
+
+    def _video_net(self):
+        raise NotImplementedError("the batched sampler is built for AgentEgo (video-context policy)")
+
+    def _get_rollout(self):
+        if self._rollout is None:
+            from .rollout import LockstepRollout
+            dev = torch.device(self.device)
+            if dev.type != "cuda":
+                raise RuntimeError("egopose_amd samples on an MI355X only: device=%s has no HIP path (no CPU fallback)" % (dev,))
+            idx = dev.index if dev.index is not None else torch.cuda.current_device()
+            reward_id = getattr(self.env.cfg, "reward_id", "quat_v3")
+            if self.custom_reward is not None and getattr(self.custom_reward, "egp_kernel", None) != "quat_v3":
+                raise NotImplementedError("only the quat_v3 reward has a HIP kernel (reward_id=%s)" % reward_id)
+            n_threads = None if self.num_threads in (None, 0) else int(self.num_threads)
+            sim = self.env.batched(self.num_envs, idx, n_threads=n_threads, n_groups=self.num_groups)
+            seed = int(getattr(self.env.cfg, "seed", 0)) * 1000 + D.rank()
+            self._rollout = LockstepRollout(sim, self.policy_net, self._video_net(), self.running_state, seed=seed)
+        return self._rollout
+
+    def sample(self, min_batch_size):
+        t0 = time.time()
+        self.pre_sample()
+        ro = self._get_rollout()
+        ro.noise_rate, ro.mean_action = self.noise_rate, self.mean_action
+        ro.sim.ctx.set_reward_weights(self.env.cfg.reward_weights)
+        with to_test(*self.sample_modules):
+            per_rank = int(math.ceil(min_batch_size / D.world_size()))
+            batch, log = ro.sample(per_rank, end_reward=float(self.env.end_reward))
+        if D.world_size() > 1:
+            log = D.merge_loggers(log, self.device)
+            if self.running_state is not None:
+                D.merge_running_state(self.running_state, ro.zf_delta_base, self.device)
+        log.sample_time = time.time() - t0
+        return batch, log
+
+
+class AgentPG(Agent):
+
+    def __init__(self, gamma=0.99, tau=0.95, optimizer_policy=None, optimizer_value=None, opt_num_epochs=1,
+                 value_opt_niter=1, **kwargs):
+        super().__init__(**kwargs)
+        self.gamma, self.tau = gamma, tau
+        self.optimizer_policy, self.optimizer_value = optimizer_policy, optimizer_value
+        self.opt_num_epochs, self.value_opt_niter = opt_num_epochs, value_opt_niter
+        self._grad_sync = None
+        self.update_stats = {}
+
+    # -- pieces shared by the A2C and PPO updates -------------------------------------------------
+    def _advantages(self, rewards, masks, values):
+        """K5 on device + standardisation with the GLOBAL mean / unbiased std (core/common.py:5-25)."""
+        ctx = self._kernel_ctx()
+        adv, ret, stats = ctx.gae(rewards.contiguous(), masks.contiguous(), values.reshape(-1).contiguous(), self.gamma, self.tau)
+        stats = D.merge_moments(stats)
+        ctx.gae_standardize(adv, stats)
+        return adv.unsqueeze(1), ret.unsqueeze(1)
+
+    def _kernel_ctx(self):
+        return self._get_rollout().sim.ctx
+
+    def _value_params(self):
+        return [p for g in self.optimizer_value.param_groups for p in g["params"]]
+
+    def _policy_params(self):
+        return [p for g in self.optimizer_policy.param_groups for p in g["params"]]
+
+    def _sync_grads(self):
+        if D.world_size() > 1:
+            if self._grad_sync is None:
+                self._grad_sync = D.FlatGradSync(self._value_params() + self._policy_params())
+            self._grad_sync.all_reduce()
+
+    def _value_backward(self, states, returns, n_global):
+        """MSE critic loss of the global batch (this rank's share) -> gradients, no optimizer step."""
+        if self.value_opt_niter != 1:
+            raise NotImplementedError("value_opt_niter != 1 is not on the ego_mimic path")
+        pred = self.value_net(self.trans_value(states))
+        loss = (pred - returns).pow(2).sum() / n_global
+        self.optimizer_value.zero_grad()
+        loss.backward()
+        return loss
+
+    def update_value(self, states, returns):
+        """update critic (agents/agent_pg.py:19-26)"""
+        loss = self._value_backward(states, returns, D.global_count(states.shape[0], states.device))
+        if D.world_size() > 1:
+            D.FlatGradSync(self._value_params()).all_reduce()
+        self.optimizer_value.step()
+        return loss
+
+    def update_policy(self, states, actions, returns, advantages, exps):
+        ind = exps.nonzero().squeeze(1)
+        n_val = D.global_count(states.shape[0], states.device)
+        n_exp = D.global_count(ind.shape[0], states.device)
+        for _ in range(self.opt_num_epochs):
+            self._value_backward(states, returns, n_val)
+            logp = self.policy_net.get_log_prob(self.trans_policy(states)[ind], actions[ind])
+            loss = -(logp * advantages[ind]).sum() / n_exp
+            self.optimizer_policy.zero_grad()
+            loss.backward()
+            self._sync_grads()
+            self.optimizer_value.step()
+            self.optimizer_policy.step()
+
+    def _load_batch(self, batch):
+        dev = torch.device(self.device)
+        cols = {k: _column(batch, k, self.dtype, dev) for k in ("states", "actions", "rewards", "masks", "exps")}
+        return cols
+
+    def update_params(self, batch):
+        t0 = time.time()
+        to_train(*self.update_modules)
+        c = self._load_batch(batch)
+        with to_test(*self.update_modules):
+            with torch.no_grad():
+                values = self.value_net(self.trans_value(c["states"]))
+        advantages, returns = self._advantages(c["rewards"], c["masks"], values)
+        self.update_policy(c["states"], c["actions"], returns, advantages, c["exps"])
+        return time.time() - t0
+
+
+class AgentPPO(AgentPG):
+
+    def __init__(self, clip_epsilon=0.2, opt_batch_size=64, use_mini_batch=False, policy_grad_clip=None, **kwargs):
+        super().__init__(**kwargs)
+        self.clip_epsilon, self.opt_batch_size = clip_epsilon, opt_batch_size
+        self.use_mini_batch, self.policy_grad_clip = use_mini_batch, policy_grad_clip
+
+    def clip_policy_grad(self):
+        if self.policy_grad_clip is not None:
+            for params, max_norm in self.policy_grad_clip:
+                torch.nn.utils.clip_grad_norm_(params, max_norm)
+
+    def ppo_loss(self, states, actions, advantages, fixed_log_probs, ind, n_exp=None):
+        n_exp = ind.shape[0] if n_exp is None else n_exp
+        logp = self.policy_net.get_log_prob(self.trans_policy(states)[ind], actions[ind])
+        ratio = torch.exp(logp - fixed_log_probs[ind])
+        adv = advantages[ind]
+        clipped = torch.clamp(ratio, 1.0 - self.clip_epsilon, 1.0 + self.clip_epsilon) * adv
+        return -torch.min(ratio * adv, clipped).sum() / n_exp
+
+    def update_policy(self, states, actions, returns, advantages, exps):
+        if self.use_mini_batch:
+            raise NotImplementedError("mini-batch PPO is not on the ego_mimic path (AgentEgo forces full batch)")
+        with to_test(*self.update_modules):
+            with torch.no_grad():
+                fixed_log_probs = self.policy_net.get_log_prob(self.trans_policy(states), actions)
+        ind = exps.nonzero().squeeze(1)
+        n_val = D.global_count(states.shape[0], states.device)
+        n_exp = D.global_count(ind.shape[0], states.device)
+        losses = []
+        for _ in range(self.opt_num_epochs):
+            # critic and actor have disjoint parameters: both backward passes run before the single
+            # gradient exchange; the value step precedes the policy step as in the reference
+            v_loss = self._value_backward(states, returns, n_val)
+            s_loss = self.ppo_loss(states, actions, advantages, fixed_log_probs, ind, n_exp)
+            self.optimizer_policy.zero_grad()
+            s_loss.backward()
+            self._sync_grads()
+            self.optimizer_value.step()
+            self.clip_policy_grad()
+            self.optimizer_policy.step()
+            losses.append((v_loss.detach(), s_loss.detach()))
+        self.update_stats = {"value_loss": [float(v) for v, _ in losses], "surr_loss": [float(s) for _, s in losses]}
+
+
+def _quat_v3_marker(fn):
+    fn.egp_kernel = "quat_v3"
+    return fn
+
+
+class AgentEgo(AgentPPO):
+
+    def __init__(self, policy_vs_net=None, value_vs_net=None, **kwargs):
+        super().__init__(use_mini_batch=False, **kwargs)
+        self.traj_cls = TrajBatchEgo
+        self.policy_vs_net, self.value_vs_net = policy_vs_net, value_vs_net
+        self.sample_modules.append(policy_vs_net)
+        self.update_modules += [policy_vs_net, value_vs_net]
+
+    def _video_net(self):
+        return self.policy_vs_net
+
+    def pre_sample(self):
+        self.policy_vs_net.set_mode("test")
+
+    def pre_episode(self):
+        self.policy_vs_net.initialize(torch.as_tensor(self.env.get_episode_cnn_feat()))
+
+    def push_memory(self, memory, state, action, mask, next_state, reward, exp):
+        memory.push(state, action, mask, next_state, reward, exp, np.array([self.env.expert_ind, self.env.start_ind]))
+
+    def trans_policy(self, states):
+        return self.policy_vs_net(states)
+
+    def trans_value(self, states):
+        return self.value_vs_net(states)
+
+    def update_params(self, batch):
+        t0 = time.time()
+        to_train(*self.update_modules)
+        c = self._load_batch(batch)
+        dev = c["states"].device
+        v_metas = batch.device_column("v_metas") if hasattr(batch, "device_column") else None
+        v_metas = v_metas.cpu().numpy() if v_metas is not None else batch.v_metas
+        if self._rollout is not None and self._rollout.experts is not None:
+            ex = self._rollout.experts
+            pdt = next(self.policy_vs_net.parameters()).dtype
+            for net in (self.policy_vs_net, self.value_vs_net):
+                net.attach_feature_table(ex.cnn_table(dev, pdt), ex.cnn_offset)
+        for net in (self.policy_vs_net, self.value_vs_net):
+            net.set_mode("train")
+            net.initialize((c["masks"], self.env.cnn_feat, v_metas))
+        with to_test(*self.update_modules):
+            with torch.no_grad():
+                values = self.value_net(self.trans_value(c["states"]))
+        advantages, returns = self._advantages(c["rewards"], c["masks"], values)
+        self.update_policy(c["states"], c["actions"], returns, advantages, c["exps"])
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        return time.time() - t0

@@ -246,6 +246,46 @@ __device__ __forceinline__ T half_wave_sum(T v) {
     return v;
 }
 
+// ---- per-lane feature helpers shared by the reward kernel (K2) and the feature kernel (K7)
+// body lane: orientation of one non-root body now and one step ago, and its finite-difference angular
+// velocity rotation_from_quaternion(q_t q_{t-1}^-1)/dt  (get_angvel_fd, utils/math.py:38-44)
+template <typename T>
+__device__ __forceinline__ void body_feature(const T *cq, const T *pq, int s, int nd, T dt, Q4<T> *qc, V3<T> *omega) {
+    const T c0 = nd > 0 ? cq[s] : T(0), c1 = nd > 1 ? cq[s + 1] : T(0), c2 = nd > 2 ? cq[s + 2] : T(0);
+    const T p0 = nd > 0 ? pq[s] : T(0), p1 = nd > 1 ? pq[s + 1] : T(0), p2 = nd > 2 ? pq[s + 2] : T(0);
+    *qc = q_from_euler_sxyz<T>(c0, c1, c2);
+    const Q4<T> qp = q_from_euler_sxyz<T>(p0, p1, p2);   // == env.prev_bquat (humanoid_v1.py:184,188)
+    const Q4<T> dv = qmul(*qc, qinv(qp));
+    V3<T> ax; T ang;
+    rot_axis_angle<T>(dv, &ax, &ang);
+    omega->x = ax.x * ang / dt; omega->y = ax.y * ang / dt; omega->z = ax.z * ang / dt;
+}
+
+// root lane: get_qvel_fd(prev, cur, dt) root part (utils/math.py:20-35): world-frame linear velocity `v`,
+// root-frame angular velocity `rv` (frame of the PREVIOUS root quaternion, angle wrapped to (-pi, pi])
+template <typename T>
+__device__ __forceinline__ void root_velocity(const T *cq, const T *pq, T dt, V3<T> *v, V3<T> *rv) {
+    const Q4<T> rc{cq[3], cq[4], cq[5], cq[6]};
+    const Q4<T> rp{pq[3], pq[4], pq[5], pq[6]};
+    v->x = (cq[0] - pq[0]) / dt; v->y = (cq[1] - pq[1]) / dt; v->z = (cq[2] - pq[2]) / dt;
+    const Q4<T> qrel = qmul(rc, qinv(rp));
+    V3<T> ax; T ang;
+    rot_axis_angle<T>(qrel, &ax, &ang);
+    const T pi = T(3.14159265358979323846);
+    if (ang > pi) ang -= T(2) * pi;
+    else if (ang < -pi) ang += T(2) * pi;
+    const V3<T> rvw{ax.x * ang / dt, ax.y * ang / dt, ax.z * ang / dt};
+    *rv = rotate_T(rp, rvw);
+}
+
+// end-effector lane: world position -> root-relative, heading frame (get_ee_pos, humanoid_v1.py:98-111)
+template <typename T>
+__device__ __forceinline__ V3<T> ee_local(const T *cq, const T *wp) {
+    const Q4<T> rc{cq[3], cq[4], cq[5], cq[6]};
+    const V3<T> rel{wp[0] - cq[0], wp[1] - cq[1], wp[2] - cq[2]};
+    return rotate_T(heading_q(rc), rel);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_reward_quat_v3(DevModel m, RewardW w, const T *__restrict__ expert_rows,
                                                         const T *__restrict__ cur_qpos, const T *__restrict__ prev_qpos,
@@ -278,22 +318,14 @@ __global__ __launch_bounds__(256) void k_reward_quat_v3(DevModel m, RewardW w, c
     T pose_sq = T(0), vel_acc = T(0), ee_sq = T(0);
     T rp_r = T(0), rv_r = T(0);
     if (l >= 1 && l < m.nbody) {
-        // body lanes: orientation + angular-velocity terms of one non-root body
-        const int s = s_start[l], nd = s_ndof[l];
-        const T c0 = nd > 0 ? cq[s] : T(0), c1 = nd > 1 ? cq[s + 1] : T(0), c2 = nd > 2 ? cq[s + 2] : T(0);
-        const T p0 = nd > 0 ? pq[s] : T(0), p1 = nd > 1 ? pq[s + 1] : T(0), p2 = nd > 2 ? pq[s + 2] : T(0);
-        const Q4<T> qc = q_from_euler_sxyz<T>(c0, c1, c2);
-        const Q4<T> qp = q_from_euler_sxyz<T>(p0, p1, p2);   // == env.prev_bquat (humanoid_v1.py:184,188)
+        Q4<T> qc; V3<T> om;
+        body_feature<T>(cq, pq, s_start[l], s_ndof[l], dt, &qc, &om);
         const T *eb = er + ER_BQ + 4 * (l - 1);
         const Q4<T> qe{eb[0], eb[1], eb[2], eb[3]};
-        const Q4<T> d = qmul(qc, qinv(qe));
-        const T pd = half_angle<T>(d) * (T)s_bw[l];
+        const T pd = half_angle<T>(qmul(qc, qinv(qe))) * (T)s_bw[l];
         pose_sq = pd * pd;
-        const Q4<T> dv = qmul(qc, qinv(qp));
-        V3<T> ax; T ang;
-        rot_axis_angle<T>(dv, &ax, &ang);
         const T *ev = er + ER_BAV + 3 * (l - 1);
-        const T dx = ax.x * ang / dt - ev[0], dy = ax.y * ang / dt - ev[1], dz = ax.z * ang / dt - ev[2];
+        const T dx = om.x - ev[0], dy = om.y - ev[1], dz = om.z - ev[2];
         if (w.v_ord == 2.0) {
             vel_acc = dx * dx + dy * dy + dz * dz;
         } else {
@@ -301,36 +333,24 @@ __global__ __launch_bounds__(256) void k_reward_quat_v3(DevModel m, RewardW w, c
             vel_acc = t_pow<T>(fabs(dx), p) + t_pow<T>(fabs(dy), p) + t_pow<T>(fabs(dz), p);
         }
     } else if (l == 0) {
-        // root lane: finite-difference root velocity (utils/math.py:20-35) + root pose
-        const Q4<T> rc{cq[3], cq[4], cq[5], cq[6]};
+        V3<T> v, rv;
+        root_velocity<T>(cq, pq, dt, &v, &rv);
         const Q4<T> rp{pq[3], pq[4], pq[5], pq[6]};
-        V3<T> v{(cq[0] - pq[0]) / dt, (cq[1] - pq[1]) / dt, (cq[2] - pq[2]) / dt};
-        const Q4<T> qrel = qmul(rc, qinv(rp));
-        V3<T> ax; T ang;
-        rot_axis_angle<T>(qrel, &ax, &ang);
-        const T pi = T(3.14159265358979323846);
-        if (ang > pi) ang -= T(2) * pi;
-        else if (ang < -pi) ang += T(2) * pi;
-        V3<T> rvw{ax.x * ang / dt, ax.y * ang / dt, ax.z * ang / dt};
-        const V3<T> rv = rotate_T(rp, rvw);                 // angular velocity in the (previous) root frame
-        const V3<T> vl = rotate_T(heading_q(rp), v);        // linear velocity in the (previous) heading frame
+        const V3<T> vl = rotate_T(heading_q(rp), v);        // learner: heading frame of the PREVIOUS root quat
         const T dl = (vl.x - er[ER_RLINV]) * (vl.x - er[ER_RLINV]) + (vl.y - er[ER_RLINV + 1]) * (vl.y - er[ER_RLINV + 1]) +
                      (vl.z - er[ER_RLINV + 2]) * (vl.z - er[ER_RLINV + 2]);
         const T da = (rv.x - er[ER_RANGV]) * (rv.x - er[ER_RANGV]) + (rv.y - er[ER_RANGV + 1]) * (rv.y - er[ER_RANGV + 1]) +
                      (rv.z - er[ER_RANGV + 2]) * (rv.z - er[ER_RANGV + 2]);
         rv_r = t_exp<T>(-(T)w.k_rl * dl - (T)w.k_ra * da);
+        const Q4<T> rc{cq[3], cq[4], cq[5], cq[6]};
         const Q4<T> rq = de_heading(rc);
         const Q4<T> erq{er[ER_RQ], er[ER_RQ + 1], er[ER_RQ + 2], er[ER_RQ + 3]};
         const T dq = half_angle<T>(qmul(rq, qinv(erq)));
         const T dh = cq[2] - er[ER_Z];
         rp_r = t_exp<T>(-(T)w.k_rh * dh * dh - (T)w.k_rq * dq * dq);
     } else if (l < m.nbody + 5) {
-        // end-effector lanes: root-relative position in the heading frame (humanoid_v1.py:98-111)
         const int k = l - m.nbody;
-        const Q4<T> rc{cq[3], cq[4], cq[5], cq[6]};
-        const T *wp = ee_wpos + env * 15 + 3 * k;
-        V3<T> rel{wp[0] - cq[0], wp[1] - cq[1], wp[2] - cq[2]};
-        const V3<T> o = rotate_T(heading_q(rc), rel);
+        const V3<T> o = ee_local<T>(cq, ee_wpos + env * 15 + 3 * k);
         const T *ee = er + ER_EE + 3 * k;
         ee_sq = (o.x - ee[0]) * (o.x - ee[0]) + (o.y - ee[1]) * (o.y - ee[1]) + (o.z - ee[2]) * (o.z - ee[2]);
     }
@@ -349,6 +369,65 @@ __global__ __launch_bounds__(256) void k_reward_quat_v3(DevModel m, RewardW w, c
         reward[env] = r;
         T *ci = cinfo + env * 5;
         ci[0] = pose_r; ci[1] = vel_r; ci[2] = ee_r; ci[3] = rp_r; ci[4] = rv_r;
+    }
+}
+
+// ============================================================================================ K7
+// Expert / learner pose features of one frame pair, reference formats (gen_expert.py:28-83 keys):
+//   qvel[nv] = get_qvel_fd(prev, cur, dt) (world-frame root lin-vel), rlinv_local[3], rangv[3], rq_rmh[4],
+//   ee_pos[15], bquat[4*nbody], bangvel[3*nbody].
+// expert_convention != 0: rlinv_local uses the heading of the CURRENT root quat (gen_expert.py:53);
+// otherwise the previous one (get_qvel_fd(..., 'heading') as in the reward, reward_function.py:19-21).
+template <typename T>
+__global__ __launch_bounds__(256) void k_pose_features(DevModel m, const T *__restrict__ cur_qpos,
+                                                       const T *__restrict__ prev_qpos, const T *__restrict__ ee_wpos,
+                                                       int n, int expert_convention, T *__restrict__ qvel,
+                                                       T *__restrict__ rlinv_local, T *__restrict__ rangv,
+                                                       T *__restrict__ rq_rmh, T *__restrict__ ee_pos,
+                                                       T *__restrict__ bquat, T *__restrict__ bangvel) {
+    __shared__ int s_start[EGP_MAX_BODY], s_ndof[EGP_MAX_BODY];
+    if (threadIdx.x < m.nbody) {
+        s_start[threadIdx.x] = m.body_qpos_start[threadIdx.x];
+        s_ndof[threadIdx.x] = m.body_ndof[threadIdx.x];
+    }
+    __syncthreads();
+    const long env = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int l = threadIdx.x & 31;
+    if (env >= n) return;
+    const T *cq = cur_qpos + env * m.nq;
+    const T *pq = prev_qpos + env * m.nq;
+    const T dt = (T)m.dt;
+    if (l >= 1 && l < m.nbody) {
+        Q4<T> qc; V3<T> om;
+        body_feature<T>(cq, pq, s_start[l], s_ndof[l], dt, &qc, &om);
+        T *bq = bquat + env * 4 * m.nbody + 4 * l;
+        bq[0] = qc.w; bq[1] = qc.x; bq[2] = qc.y; bq[3] = qc.z;
+        T *bv = bangvel + env * 3 * m.nbody + 3 * l;
+        bv[0] = om.x; bv[1] = om.y; bv[2] = om.z;
+        // hinge velocities of this body
+        for (int k = 0; k < s_ndof[l]; ++k) qvel[env * m.nv + s_start[l] - 1 + k] = (cq[s_start[l] + k] - pq[s_start[l] + k]) / dt;
+    } else if (l == 0) {
+        V3<T> v, rv;
+        root_velocity<T>(cq, pq, dt, &v, &rv);
+        const Q4<T> rc{cq[3], cq[4], cq[5], cq[6]};
+        const Q4<T> rp{pq[3], pq[4], pq[5], pq[6]};
+        T *qv = qvel + env * m.nv;
+        qv[0] = v.x; qv[1] = v.y; qv[2] = v.z; qv[3] = rv.x; qv[4] = rv.y; qv[5] = rv.z;
+        const V3<T> vl = rotate_T(heading_q(expert_convention ? rc : rp), v);
+        T *o = rlinv_local + env * 3; o[0] = vl.x; o[1] = vl.y; o[2] = vl.z;
+        o = rangv + env * 3; o[0] = rv.x; o[1] = rv.y; o[2] = rv.z;
+        const Q4<T> rq = de_heading(rc);
+        o = rq_rmh + env * 4; o[0] = rq.w; o[1] = rq.x; o[2] = rq.y; o[3] = rq.z;
+        // root entries of bquat / bangvel
+        o = bquat + env * 4 * m.nbody; o[0] = rc.w; o[1] = rc.x; o[2] = rc.y; o[3] = rc.z;
+        const Q4<T> dv = qmul(rc, qinv(rp));
+        V3<T> ax; T ang;
+        rot_axis_angle<T>(dv, &ax, &ang);
+        o = bangvel + env * 3 * m.nbody; o[0] = ax.x * ang / dt; o[1] = ax.y * ang / dt; o[2] = ax.z * ang / dt;
+    } else if (l < m.nbody + 5) {
+        const int k = l - m.nbody;
+        const V3<T> e = ee_local<T>(cq, ee_wpos + env * 15 + 3 * k);
+        T *o = ee_pos + env * 15 + 3 * k; o[0] = e.x; o[1] = e.y; o[2] = e.z;
     }
 }
 
@@ -788,6 +867,19 @@ static int launch_reward(egp_ctx *ctx, const T *expert_rows, const T *cur_qpos, 
     return after_launch("k_reward_quat_v3");
 }
 
+template <typename T>
+static int launch_features(egp_ctx *ctx, const T *cur, const T *prev, const T *ee_w, int n, int expert_conv, T *qvel, T *rlinv,
+                           T *rangv, T *rq, T *ee, T *bq, T *bav, void *stream) {
+    EGP_REQUIRE(ctx, "ctx is NULL");
+    EGP_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return EGP_OK;
+    EGP_REQUIRE(cur && prev && ee_w && qvel && rlinv && rangv && rq && ee && bq && bav, "NULL pointer");
+    const long threads = (long)n * 32;
+    k_pose_features<T><<<dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(ctx->dm, cur, prev, ee_w, n, expert_conv,
+                                                                                         qvel, rlinv, rangv, rq, ee, bq, bav);
+    return after_launch("k_pose_features");
+}
+
 static inline void zf_tiling(int n, int *rows_per_tile, int *n_tiles) {
     int tiles = (n + 63) / 64;
     if (tiles > 256) tiles = 256;
@@ -872,6 +964,15 @@ int egp_reward_quat_v3_f32(egp_ctx *c, const float *cq, const float *pq, const f
                            float *reward, float *cinfo, void *s) {
     EGP_REQUIRE(c, "ctx is NULL");
     return launch_reward<float>(c, c->expert_rows_f32, cq, pq, ee, t, frame, endf, active, end_reward, n, reward, cinfo, s);
+}
+
+int egp_pose_features_f64(egp_ctx *c, const double *cur, const double *prev, const double *ee_w, int32_t n, int32_t expert_conv,
+                          double *qvel, double *rlinv, double *rangv, double *rq, double *ee, double *bq, double *bav, void *s) {
+    return launch_features<double>(c, cur, prev, ee_w, n, expert_conv, qvel, rlinv, rangv, rq, ee, bq, bav, s);
+}
+int egp_pose_features_f32(egp_ctx *c, const float *cur, const float *prev, const float *ee_w, int32_t n, int32_t expert_conv,
+                          float *qvel, float *rlinv, float *rangv, float *rq, float *ee, float *bq, float *bav, void *s) {
+    return launch_features<float>(c, cur, prev, ee_w, n, expert_conv, qvel, rlinv, rangv, rq, ee, bq, bav, s);
 }
 
 int64_t egp_zfilter_workspace_bytes(int32_t n, int32_t dim) {

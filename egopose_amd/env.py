@@ -1,0 +1,174 @@
+"""HumanoidEnv: the reference's env object re-founded on a batch of lockstep envs.
+
+Drop-in surface of /root/reference/ego_pose/envs/humanoid_v1.py (``HumanoidEnv(cfg)``, ``seed``,
+``load_experts``, ``cnn_feat``, ``model.actuator_names``, ``observation_space/action_space``, ``dt``,
+``end_reward``, ``np_random``, ``set_fix_sampling`` ...) as far as the training driver touches it
+(ego_pose/ego_mimic.py:41-48,112). There is no per-env Python stepping on the hot path: the agent asks for
+``env.batched(n_env, device)`` and gets a ``BatchedSim`` bundling
+
+    EgpContext (skeleton + gains + reward weights + expert table in HBM)
+    physics backend (host)  +  RolloutEngine (worker threads, pinned staging, K1)
+
+MuJoCo is not loaded; the model tree comes from the MJCF named in the config when that file exists, else
+from the packaged skeleton asset. A single-env ``reset()/step()`` facade (batch of one, same kernels) is
+kept for callers such as eval scripts.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+import types
+
+import numpy as np
+
+from .skeleton import load_skeleton, DEFAULT_ASSET
+
+
+class _Space:
+    def __init__(self, dim):
+        self.shape = (int(dim),)
+        self.low = -np.inf * np.ones(dim)
+        self.high = np.inf * np.ones(dim)
+
+
+class BatchedSim:
+    """Everything device/host-resident that n_env lockstep envs share."""
+
+    def __init__(self, env, n_env, device_index=0, n_threads=None, n_groups=1, physics=None):
+        from .hip import EgpContext
+        from .physics import SurrogatePhysics, RolloutEngine
+        from .expert import ExpertSet
+        cfg = env.cfg
+        self.env = env
+        self.n_env = int(n_env)
+        self.ctx = EgpContext(env.skel, cfg.jkp, cfg.jkd, cfg.a_ref, cfg.a_scale, cfg.torque_lim, cfg.b_diffw,
+                              reward_weights=cfg.reward_weights, episode_len=cfg.env_episode_len,
+                              frame_skip=env.frame_skip, device=device_index)
+        self.physics = physics if physics is not None else SurrogatePhysics(env.skel, self.n_env)
+        self.engine = RolloutEngine(self.ctx, self.physics, self.n_env, n_threads=n_threads, n_groups=n_groups)
+        self.experts = None
+        if env.expert_arr is not None:
+            self.experts = ExpertSet(env.expert_arr, env.cnn_feat)
+            self.experts.upload(self.ctx)
+
+    def close(self):
+        self.engine.close()
+        self.physics.close()
+        self.ctx.close()
+
+
+class HumanoidEnv:
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.frame_skip = 15
+        path = getattr(cfg, "mujoco_model_file", None)
+        self.skel = load_skeleton(path if path and os.path.exists(path) else DEFAULT_ASSET)
+        sk = self.skel
+        self.model = types.SimpleNamespace(
+            actuator_names=tuple(sk.actuator_names), body_names=("world",) + tuple(sk.body_names),
+            nq=sk.nq, nv=sk.nv, nu=sk.nu, opt=types.SimpleNamespace(timestep=sk.timestep),
+            _body_name2id={n: i + 1 for i, n in enumerate(sk.body_names)})
+        self.body_qposaddr = sk.body_qposaddr()
+        self.obs_dim = sk.nq - 2 + sk.nv
+        self.observation_space = _Space(self.obs_dim)
+        self.action_space = _Space(sk.nu)
+        self.end_reward = 0.0
+        self.cur_t = 0
+        self.start_ind = 0
+        self.expert_ind = None
+        self.expert_id = None
+        self.expert_list = None
+        self.expert_arr = None
+        self.expert = None
+        self.cnn_feat = None
+        self.fix_expert_ind = self.fix_start_ind = self.fix_len = self.fix_start_state = None
+        self.fix_cnn_feat = self.fix_head_lb = None
+        self.np_random = None
+        self._sims = {}
+        self._single = None
+        self.seed()
+
+    # ------------------------------------------------------------------ reference API
+    @property
+    def dt(self):
+        return self.skel.timestep * self.frame_skip
+
+    def seed(self, seed=None):
+        self.np_random = np.random.RandomState(seed)
+        return [seed]
+
+    def load_experts(self, expert_list, expert_feat_file, cnn_feat_file):
+        self.expert_list = list(expert_list)
+        with open(expert_feat_file, "rb") as f:
+            expert_dict = pickle.load(f)
+        self.expert_arr = [expert_dict[name] for name in self.expert_list]
+        with open(cnn_feat_file, "rb") as f:
+            cnn_dict, _ = pickle.load(f)
+        self.cnn_feat = [cnn_dict[name] for name in self.expert_list]
+        self.set_expert(0)
+        for sim in self._sims.values():
+            sim.close()
+        self._sims.clear()
+
+    def set_experts(self, expert_list, expert_arr, cnn_feat):
+        """Same as load_experts for tables that are already in memory."""
+        self.expert_list, self.expert_arr, self.cnn_feat = list(expert_list), list(expert_arr), list(cnn_feat)
+        self.set_expert(0)
+
+    def set_expert(self, expert_ind):
+        self.expert_ind = expert_ind
+        self.expert_id = self.expert_list[expert_ind]
+        self.expert = self.expert_arr[expert_ind]
+
+    def set_fix_sampling(self, expert_ind=None, start_ind=None, len=None, start_state=None, cnn_feat=None):
+        self.fix_expert_ind, self.fix_start_ind, self.fix_len = expert_ind, start_ind, len
+        self.fix_start_state, self.fix_cnn_feat = start_state, cnn_feat
+
+    def set_fix_head_lb(self, fix_head_lb=None):
+        self.fix_head_lb = fix_head_lb
+
+    def get_expert_index(self, t):
+        return self.start_ind + t
+
+    def get_expert_attr(self, attr, ind):
+        return self.expert[attr][ind, :]
+
+    def get_episode_cnn_feat(self):
+        fm = self.cfg.fr_margin
+        n = self.cfg.env_episode_len if self.fix_len is None else self.fix_len
+        if self.fix_cnn_feat is not None:
+            return self.fix_cnn_feat
+        return self.cnn_feat[self.expert_ind][self.start_ind - fm: self.start_ind + n + fm, :]
+
+    # ------------------------------------------------------------------ batched access (the hot path)
+    def batched(self, n_env, device_index=0, n_threads=None, n_groups=1):
+        key = (int(n_env), int(device_index), n_threads, int(n_groups))
+        if key not in self._sims:
+            self._sims[key] = BatchedSim(self, n_env, device_index, n_threads, n_groups)
+        return self._sims[key]
+
+    def close(self):
+        for sim in self._sims.values():
+            sim.close()
+        self._sims.clear()
+
+    def sample_reset(self, n):
+        """Reset sampling of reset_model (humanoid_v1.py:206-216) for n envs at once:
+        expert take ~ randint(n_takes), start frame ~ randint(fr_margin, len - episode_len - fr_margin)."""
+        cfg = self.cfg
+        lens = np.array([int(e["len"]) for e in self.expert_arr])
+        if self.fix_expert_ind is None:
+            e_ind = self.np_random.randint(len(self.expert_arr), size=n)
+        else:
+            e_ind = np.full(n, self.fix_expert_ind)
+        if self.fix_start_ind is not None:
+            s_ind = np.full(n, self.fix_start_ind)
+        elif getattr(cfg, "env_start_first", False):
+            s_ind = np.zeros(n, dtype=np.int64)
+        else:
+            hi = lens[e_ind] - cfg.env_episode_len - cfg.fr_margin
+            if (hi <= cfg.fr_margin).any():
+                raise ValueError("expert take shorter than env_episode_len + 2*fr_margin")
+            s_ind = cfg.fr_margin + (self.np_random.random_sample(n) * (hi - cfg.fr_margin)).astype(np.int64)
+        return e_ind.astype(np.int64), s_ind.astype(np.int64)

@@ -199,6 +199,21 @@ class EgpContext:
                    _ptr(active), float(end_reward), n, _ptr(r), _ptr(ci), _stream()), "egp_reward_quat_v3")
         return r, ci
 
+    def pose_features(self, cur_qpos, prev_qpos, ee_wpos, expert_convention=False):
+        """-> dict(qvel, rlinv_local, rangv, rq_rmh, ee_pos, bquat, bangvel) device tensors (K7)."""
+        n, dt = cur_qpos.shape[0], cur_qpos.dtype
+        _need(cur_qpos, (n, self.nq), dt, "cur_qpos")
+        _need(prev_qpos, (n, self.nq), dt, "prev_qpos")
+        _need(ee_wpos, (n, 15), dt, "ee_wpos")
+        mk = lambda d: torch.empty(n, d, dtype=dt, device=cur_qpos.device)
+        out = dict(qvel=mk(self.nv), rlinv_local=mk(3), rangv=mk(3), rq_rmh=mk(4), ee_pos=mk(15),
+                   bquat=mk(4 * self.nbody), bangvel=mk(3 * self.nbody))
+        fn = getattr(self.lib, "egp_pose_features_" + self._sfx(cur_qpos))
+        L.check(fn(self.handle, _ptr(cur_qpos), _ptr(prev_qpos), _ptr(ee_wpos), n, 1 if expert_convention else 0,
+                   _ptr(out["qvel"]), _ptr(out["rlinv_local"]), _ptr(out["rangv"]), _ptr(out["rq_rmh"]), _ptr(out["ee_pos"]),
+                   _ptr(out["bquat"]), _ptr(out["bangvel"]), _stream()), "egp_pose_features")
+        return out
+
     def _workspace(self, key, nbytes, device):
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes or ws.device != device:

@@ -1,0 +1,266 @@
+"""Policy / value / video-context networks on PyTorch-ROCm (GEMMs on MFMA via rocBLAS/hipBLASLt/MIOpen).
+
+Parameter names and shapes are those of the reference so checkpoints stay drop-in
+(``net.affine_layers.i``, ``action_mean``, ``action_log_std``, ``value_head``, ``v_net.rnn_f/rnn_b``
+holding ``nn.LSTMCell`` parameters): models/mlp.py:5-25, models/rnn.py:5-61,
+models/video_state_net.py:7-70, core/policy.py:4-23, core/policy_gaussian.py:7-38, core/critic.py:5-18,
+core/distributions.py:6-25 of /root/reference.
+
+What differs is how they run: the temporal net consumes whole batches of windows -- (T, B, D) with B =
+all envs that reset this tick / all episodes of the PPO batch -- and the bi-LSTM is evaluated with one
+input-projection GEMM per direction plus a fused recurrent sweep (MIOpen ``lstm`` when the dtype allows,
+otherwise a cell loop over pre-projected gates) instead of 2*T LSTMCell calls at batch 1.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+_ACT = {"tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid}
+
+
+class MLP(nn.Module):
+    def __init__(self, input_dim, hidden_dims=(128, 128), activation="tanh"):
+        super().__init__()
+        self.activation = _ACT[activation]
+        dims = [input_dim] + list(hidden_dims)
+        self.out_dim = dims[-1]
+        self.affine_layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        for layer in self.affine_layers:
+            x = self.activation(layer(x))
+        return x
+
+
+class DiagGaussian(torch.distributions.Normal):
+    """Normal with summed log-prob and the reference's 'KL to a detached copy of itself'."""
+
+    def kl(self):
+        mu0, s0 = self.loc.detach(), self.scale.detach()
+        ls1 = self.scale.log()
+        out = ls1 - ls1.detach() + (s0.pow(2) + (mu0 - self.loc).pow(2)) / (2.0 * self.scale.pow(2)) - 0.5
+        return out.sum(1, keepdim=True)
+
+    def log_prob(self, value):
+        return super().log_prob(value).sum(1, keepdim=True)
+
+    def mean_sample(self):
+        return self.loc
+
+
+class Policy(nn.Module):
+    def select_action(self, x, mean_action=False):
+        dist = self.forward(x)
+        return dist.mean_sample() if mean_action else dist.sample()
+
+    def get_kl(self, x):
+        return self.forward(x).kl()
+
+    def get_log_prob(self, x, action):
+        return self.forward(x).log_prob(action)
+
+
+class PolicyGaussian(Policy):
+    def __init__(self, net, action_dim, net_out_dim=None, log_std=0, fix_std=False):
+        super().__init__()
+        self.type = "gaussian"
+        self.net = net
+        self.action_mean = nn.Linear(net.out_dim if net_out_dim is None else net_out_dim, action_dim)
+        with torch.no_grad():
+            self.action_mean.weight.mul_(0.1)
+            self.action_mean.bias.zero_()
+        self.action_log_std = nn.Parameter(torch.full((1, action_dim), float(log_std)), requires_grad=not fix_std)
+
+    def mean_std(self, x):
+        mean = self.action_mean(self.net(x))
+        return mean, torch.exp(self.action_log_std.expand_as(mean))
+
+    def forward(self, x):
+        return DiagGaussian(*self.mean_std(x))
+
+    def get_fim(self, x):
+        mean, _ = self.mean_std(x)
+        cov_inv = self.action_log_std.exp().pow(-2).squeeze(0).repeat(x.size(0))
+        offset, std_id, std_index = 0, 0, 0
+        for i, (name, p) in enumerate(self.named_parameters()):
+            if name == "action_log_std":
+                std_id, std_index = i, offset
+            offset += p.numel()
+        return cov_inv.detach(), mean, {"std_id": std_id, "std_index": std_index}
+
+
+class Value(nn.Module):
+    def __init__(self, net, net_out_dim=None):
+        super().__init__()
+        self.net = net
+        self.value_head = nn.Linear(net.out_dim if net_out_dim is None else net_out_dim, 1)
+        with torch.no_grad():
+            self.value_head.weight.mul_(0.1)
+            self.value_head.bias.zero_()
+
+    def forward(self, x):
+        return self.value_head(self.net(x))
+
+
+# ------------------------------------------------------------------------------------------------ temporal nets
+def _lstm_sweep(cell: nn.LSTMCell, x, reverse):
+    """(T,B,D) -> (T,B,H) for one direction; zero initial state."""
+    T, B, _ = x.shape
+    H = cell.hidden_size
+    fused_ok = x.is_cuda and x.dtype in (torch.float32, torch.float16, torch.bfloat16)
+    if fused_ok:
+        h0 = x.new_zeros(1, B, H)
+        xs = x.flip(0) if reverse else x
+        out, _, _ = torch._VF.lstm(xs, (h0, h0), [cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh],
+                                   True, 1, 0.0, cell.training, False, False)
+        return out.flip(0) if reverse else out
+    # generic path: one GEMM for every timestep's input projection, then the recurrence
+    gates_x = torch.addmm(cell.bias_ih + cell.bias_hh, x.reshape(T * B, -1), cell.weight_ih.t()).view(T, B, 4 * H)
+    w_hh_t = cell.weight_hh.t()
+    h = x.new_zeros(B, H)
+    c = x.new_zeros(B, H)
+    outs = [None] * T
+    for t in (range(T - 1, -1, -1) if reverse else range(T)):
+        g = torch.addmm(gates_x[t], h, w_hh_t)
+        i, f, gg, o = g.chunk(4, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        outs[t] = h
+    return torch.stack(outs, 0)
+
+
+class RNN(nn.Module):
+    def __init__(self, input_dim, out_dim, cell_type="lstm", bi_dir=False):
+        super().__init__()
+        self.input_dim, self.out_dim, self.cell_type, self.bi_dir = input_dim, out_dim, cell_type, bi_dir
+        self.mode = "batch"
+        make = nn.LSTMCell if cell_type == "lstm" else nn.GRUCell
+        hidden = out_dim // 2 if bi_dir else out_dim
+        self.rnn_f = make(input_dim, hidden)
+        if bi_dir:
+            self.rnn_b = make(input_dim, hidden)
+        self.hx = self.cx = None
+
+    def set_mode(self, mode):
+        self.mode = mode
+
+    def initialize(self, batch_size=1):
+        if self.mode == "step":
+            p = self.rnn_f.weight_hh
+            self.hx = p.new_zeros(batch_size, self.rnn_f.hidden_size)
+            self.cx = p.new_zeros(batch_size, self.rnn_f.hidden_size) if self.cell_type == "lstm" else None
+
+    def _sweep(self, cell, x, reverse):
+        if self.cell_type == "lstm":
+            return _lstm_sweep(cell, x, reverse)
+        h = x.new_zeros(x.size(1), cell.hidden_size)
+        outs = [None] * x.size(0)
+        for t in (range(x.size(0) - 1, -1, -1) if reverse else range(x.size(0))):
+            h = cell(x[t], h)
+            outs[t] = h
+        return torch.stack(outs, 0)
+
+    def forward(self, x):
+        if self.mode == "step":
+            self.hx = self.hx.to(x.device)
+            if self.cell_type == "lstm":
+                self.hx, self.cx = self.rnn_f(x, (self.hx, self.cx.to(x.device)))
+            else:
+                self.hx = self.rnn_f(x, self.hx)
+            return self.hx
+        out = self._sweep(self.rnn_f, x, False)
+        if self.bi_dir:
+            out = torch.cat((out, self._sweep(self.rnn_b, x, True)), 2)
+        return out
+
+
+class VideoStateNet(nn.Module):
+    """Temporal net over precomputed CNN features, concatenated in front of the state.
+
+    test mode: ``initialize(window)`` with window (T+2m, D) for ONE episode, or (T+2m, B, D) for a batch of
+    episodes (the lockstep rollout), keeps ``v_out`` = net(window)[m:-m]; ``forward(state)`` prepends
+    v_out[t] and advances t (single-episode form) -- the batched rollout indexes ``v_out`` itself.
+    train mode: ``initialize((masks, cnn_feat, v_metas))`` segments the flat batch into episodes and builds
+    the padded context (max_len+2m, n_ep, D) and flat gather indices; ``forward(states)`` runs the net over
+    the context and gathers one row per sample.
+    """
+
+    def __init__(self, cnn_feat_dim, v_hdim=128, v_margin=10, v_net_type="lstm", v_net_param=None, causal=False):
+        super().__init__()
+        if v_net_type != "lstm":
+            raise NotImplementedError("only the 'lstm' video net is on the hot path (tcn is out of scope)")
+        self.mode = "test"
+        self.cnn_feat_dim, self.v_hdim, self.v_margin, self.v_net_type = cnn_feat_dim, v_hdim, v_margin, v_net_type
+        self.v_net = RNN(cnn_feat_dim, v_hdim, v_net_type, bi_dir=not causal)
+        self.v_out = None
+        self.t = 0
+        self.indices = None
+        self.gather_indices = None
+        self.cnn_feat_ctx = None
+        self._cnn_table = None   # optional (device table, take offsets) installed by the env
+
+    def set_mode(self, mode):
+        self.mode = mode
+
+    def forward_v_net(self, x):
+        return self.v_net(x)
+
+    def attach_feature_table(self, table, take_offset):
+        """Device-resident concatenation of all takes' features (+ row offsets) for gather-built contexts."""
+        self._cnn_table = (table, torch.as_tensor(np.asarray(take_offset), dtype=torch.long, device=table.device))
+
+    def window_features(self, expert_ind, start_ind, length):
+        """Gather windows [start-m, start+length+m) of the given takes -> (length+2m, B, D) on device."""
+        table, off = self._cnn_table
+        m = self.v_margin
+        base = off[expert_ind.long()] + start_ind.long() - m
+        rows = base.unsqueeze(0) + torch.arange(length + 2 * m, device=table.device).unsqueeze(1)
+        return table[rows]
+
+    def initialize(self, x):
+        m = self.v_margin
+        if self.mode == "test":
+            p = next(self.parameters())
+            x = x.to(device=p.device, dtype=p.dtype)
+            single = x.dim() == 2
+            out = self.forward_v_net(x.unsqueeze(1) if single else x)[m:-m]
+            self.v_out = out.squeeze(1) if single else out
+            self.t = 0
+            return
+        masks, cnn_feat, v_metas = x
+        device, dtype = masks.device, masks.dtype
+        ends = torch.nonzero(masks == 0).flatten().cpu().numpy()
+        n = masks.shape[0]
+        starts = np.concatenate(([0], ends[:-1] + 1))
+        lens = ends - starts + 1
+        max_len = int(lens.max())
+        idx = np.arange(n)
+        ep_of = np.repeat(np.arange(len(ends)), lens)
+        covered = int(ends[-1]) + 1
+        idx[:covered] = ep_of * max_len + (np.arange(covered) - np.repeat(starts, lens))
+        self.indices = idx
+        meta = np.asarray(v_metas)[ends]
+        if self._cnn_table is not None and self._cnn_table[0].device == device:
+            e_ind = torch.as_tensor(meta[:, 0], device=device)
+            s_ind = torch.as_tensor(meta[:, 1], device=device)
+            self.cnn_feat_ctx = self.window_features(e_ind, s_ind, max_len).to(dtype)
+        else:
+            ctx = np.zeros((max_len + 2 * m, len(ends), self.cnn_feat_dim))
+            for e, (ei, si) in enumerate(meta):
+                ctx[:, e, :] = cnn_feat[int(ei)][int(si) - m: int(si) + max_len + m]
+            self.cnn_feat_ctx = torch.as_tensor(ctx, dtype=dtype, device=device)
+        self.gather_indices = torch.as_tensor(idx, dtype=torch.long, device=device)
+
+    def forward(self, x):
+        if self.mode == "test":
+            out = torch.cat((self.v_out[[self.t], :], x), dim=1)
+            self.t += 1
+            return out
+        m = self.v_margin
+        ctx = self.forward_v_net(self.cnn_feat_ctx)[m:-m]
+        ctx = ctx.transpose(0, 1).reshape(-1, self.v_hdim)
+        return torch.cat((ctx.index_select(0, self.gather_indices), x), dim=1)

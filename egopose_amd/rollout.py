@@ -1,0 +1,271 @@
+"""Lockstep batched rollout: the MI355X replacement of the multi-process sampler.
+
+The reference forks ``num_threads`` Python workers, each stepping ONE env with a batch-1 float64 policy
+(/root/reference/agents/agent.py:29-111 with the AgentEgo hooks, ego_pose/core/agent_ego.py:18-32). Here every
+env slot of the GPU is one such "worker": N slots advance in lockstep, and per tick
+
+    policy (torch, MFMA GEMMs)  ->  engine: 15 x {K1 stable-PD on GPU <-> physics on host threads}
+    -> K3 observation -> K6 batched ZFilter -> K2 imitation reward -> record -> in-batch resets
+
+Semantics kept from the reference: per-worker step quota ``floor(min_batch_size / n_workers)`` checked only at
+episode boundaries (episodes are never truncated), ``mask = 0`` on the last step of an episode,
+``exp = 1 - mean_action``, ``v_meta = (expert_ind, start_ind)``, reward computed on the state after the step,
+worker-ordered (here: slot-ordered), episode-contiguous batches, LoggerRL totals.
+Deviation (documented in DESIGN.md): the observation filter is updated with all slots' samples by block
+merges instead of sample-by-sample inside worker 0 only.
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import numpy as np
+import torch
+
+from .rl_core import LoggerRL, TrajBatchEgo
+
+
+class _PinnedRing:
+    """Small ring of pinned int32 staging buffers for per-tick host->device flag uploads."""
+
+    def __init__(self, rows, cols, device, slots=8):
+        self.bufs = [torch.empty(rows, cols, dtype=torch.int32).pin_memory() for _ in range(slots)]
+        self.events = [None] * slots
+        self.device = device
+        self.i = 0
+
+    def upload(self, arr):
+        k = self.i
+        self.i = (self.i + 1) % len(self.bufs)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        buf = self.bufs[k]
+        buf.numpy()[...] = arr
+        out = buf.to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        return out
+
+
+class LockstepRollout:
+
+    def __init__(self, sim, policy_net, policy_vs_net, running_state=None, noise_rate=1.0, mean_action=False,
+                 seed=0):
+        self.sim = sim
+        self.env = sim.env
+        self.cfg = sim.env.cfg
+        self.ctx, self.engine, self.experts = sim.ctx, sim.engine, sim.experts
+        if self.experts is None:
+            raise RuntimeError("LockstepRollout needs experts (env.load_experts) before sampling")
+        self.policy_net, self.policy_vs_net = policy_net, policy_vs_net
+        self.running_state = running_state
+        self.noise_rate, self.mean_action = noise_rate, mean_action
+        self.N = sim.n_env
+        self.dev = torch.device("cuda", self.ctx.device)
+        self.T_ep = int(self.cfg.env_episode_len)
+        self.margin = int(self.cfg.fr_margin)
+        self.gen = torch.Generator(device=self.dev)
+        self.gen.manual_seed(int(seed))
+        self.groups = [self.engine.group_range(g) for g in range(self.engine.n_groups)]
+        self.rings = [_PinnedRing(5, b - a, self.dev) for a, b in self.groups]
+        self.timing = {}
+        self._events = [None] * len(self.groups)
+
+    # ------------------------------------------------------------------ helpers
+    def _net_dtype(self):
+        return next(self.policy_net.parameters()).dtype
+
+    def _reset_slots(self, ids):
+        """reset_model for the given slots (sorted ids): sample take/start frame, set physics state."""
+        cfg, ex = self.cfg, self.experts
+        e_ind, s_ind = self.env.sample_reset(len(ids))
+        rows = ex.take_offset[e_ind] + s_ind
+        qpos = ex.qpos[rows].copy()
+        qvel = ex.qvel[rows].copy()
+        if cfg.env_init_noise > 0:
+            qpos[:, 7:] += self.env.np_random.normal(0.0, cfg.env_init_noise, size=(len(ids), qpos.shape[1] - 7))
+        self.engine.reset(ids, qpos, qvel)
+        self.e_ind[ids], self.s_ind[ids] = e_ind, s_ind
+        self.frame_base[ids] = rows
+        self.cur_t[ids] = 0
+        # policy video context of the new episodes: bi-LSTM over [start-m, start+T+m)
+        e_d = torch.as_tensor(e_ind, device=self.dev)
+        s_d = torch.as_tensor(s_ind, device=self.dev)
+        win = self.policy_vs_net.window_features(e_d, s_d, self.T_ep)
+        out = self.policy_vs_net.forward_v_net(win)[self.margin:-self.margin]      # (T, n, H)
+        self.v_out[torch.as_tensor(ids, device=self.dev)] = out.transpose(0, 1)
+
+    def _filter(self, obs, active_dev):
+        if self.zf_state is None:
+            return obs
+        new = torch.empty_like(self.zf_state)
+        y = self.ctx.zfilter(obs, self.zf_state, new, update=True, clip=self.zf_clip, active=active_dev)
+        self.zf_state = new
+        return y
+
+    # ------------------------------------------------------------------ one sampling pass
+    @torch.no_grad()
+    def sample(self, min_batch_size, end_reward=0.0):
+        t_start = time.time()
+        cfg, N, dev, T_ep = self.cfg, self.N, self.dev, self.T_ep
+        ctx, eng = self.ctx, self.engine
+        ndt = self._net_dtype()
+        quota = max(1, int(math.floor(min_batch_size / N)))
+        T_max = quota + T_ep
+        H = self.policy_vs_net.v_hdim
+        self.policy_vs_net.attach_feature_table(self.experts.cnn_table(dev, ndt), self.experts.cnn_offset)
+        od, nu = ctx.obs_dim, ctx.nu
+        f64 = torch.float64
+        rec = dict(
+            states=torch.empty(T_max, N, od, dtype=f64, device=dev), next_states=torch.empty(T_max, N, od, dtype=f64, device=dev),
+            actions=torch.empty(T_max, N, nu, dtype=f64, device=dev), rewards=torch.zeros(T_max, N, dtype=f64, device=dev),
+            cinfo=torch.zeros(T_max, N, 5, dtype=f64, device=dev), flags=torch.zeros(T_max, 5, N, dtype=torch.int32, device=dev),
+            exps=torch.ones(T_max, N, dtype=torch.int64, device=dev), e_ind=torch.zeros(T_max, N, dtype=torch.int64, device=dev),
+            s_ind=torch.zeros(T_max, N, dtype=torch.int64, device=dev))
+        self.v_out = torch.empty(N, T_ep, H, dtype=ndt, device=dev)
+        self.state = torch.empty(N, od, dtype=f64, device=dev)
+        self.prev_qpos = torch.empty(N, ctx.nq, dtype=f64, device=dev)
+        self.act_buf = torch.zeros(N, nu, dtype=f64, device=dev)
+        self.cur_t = np.zeros(N, np.int64)
+        self.e_ind = np.zeros(N, np.int64)
+        self.s_ind = np.zeros(N, np.int64)
+        self.frame_base = np.zeros(N, np.int64)
+        steps_done = np.zeros(N, np.int64)
+        active = np.ones(N, bool)
+        if self.running_state is not None:
+            rs = self.running_state.rs
+            self.zf_delta_base = (float(rs._n), np.array(rs._M, float).ravel().copy(), np.array(rs._S, float).ravel().copy())
+            self.zf_state = self.running_state.to_device_state(dev)
+            self.zf_clip = float(self.running_state.clip or 0.0)
+        else:
+            self.zf_state = None
+        lb = self.experts.head_height_lb
+        ep_lens = []
+        tick = [0] * len(self.groups)
+        tm = dict(policy=0.0, wait=0.0, post=0.0, reset=0.0)
+
+        # ---- initial reset of every slot
+        all_ids = np.arange(N)
+        self._reset_slots(all_ids)
+        ones = torch.ones(N, dtype=torch.int32, device=dev)
+        self.state.copy_(self._filter(ctx.obs(eng.qpos, eng.qvel), ones))
+
+        def pre_step(g):
+            a, b = self.groups[g]
+            t0 = time.time()
+            n = b - a
+            t_idx = torch.as_tensor(np.minimum(self.cur_t[a:b], T_ep - 1), device=dev)
+            vs = self.v_out[a:b][torch.arange(n, device=dev), t_idx]
+            x = torch.cat((vs, self.state[a:b].to(ndt)), dim=1)
+            if hasattr(self.policy_net, "mean_std"):
+                mean, std = self.policy_net.mean_std(x)
+            else:
+                dist = self.policy_net(x)
+                mean, std = dist.loc, dist.scale
+            if self.mean_action:
+                use_mean = torch.ones(n, dtype=torch.bool, device=dev)
+            elif self.noise_rate >= 1.0:
+                use_mean = torch.zeros(n, dtype=torch.bool, device=dev)
+            else:
+                use_mean = torch.rand(n, device=dev, generator=self.gen) >= self.noise_rate
+            noise = torch.randn(mean.shape, dtype=mean.dtype, device=dev, generator=self.gen)
+            action = torch.where(use_mean.unsqueeze(1), mean, mean + std * noise).to(f64)
+            self.act_buf[a:b] = action
+            k = tick[g]
+            rec["actions"][k, a:b] = action
+            rec["exps"][k, a:b] = (~use_mean).to(torch.int64)
+            rec["states"][k, a:b] = self.state[a:b]
+            self.prev_qpos[a:b] = eng.qpos[a:b]
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events[g] = ev          # must outlive the workers' hipStreamWaitEvent
+            eng.step_async(g, self.act_buf, active.astype(np.int32), ev)
+            tm["policy"] += time.time() - t0
+
+        def post_step(g):
+            a, b = self.groups[g]
+            t0 = time.time()
+            eng.wait(g)
+            t1 = time.time()
+            k = tick[g]
+            act_g = active[a:b]
+            self.cur_t[a:b] += act_g
+            head_z = eng.head_z[a:b]
+            if self.env.fix_head_lb is not None:
+                fail = head_z < self.env.fix_head_lb
+            else:
+                fail = head_z < lb[self.e_ind[a:b]] - 0.1
+            end = self.cur_t[a:b] >= (T_ep if self.env.fix_len is None else self.env.fix_len)
+            done = (fail | end) & act_g
+            flags = np.stack([self.cur_t[a:b], self.frame_base[a:b] + self.cur_t[a:b], end & act_g, act_g, done]).astype(np.int32)
+            fl = self.rings[g].upload(flags)
+            rec["flags"][k, :, a:b] = fl
+            obs = ctx.obs(eng.qpos[a:b], eng.qvel[a:b])
+            nxt = self._filter(obs, fl[3])
+            ctx.reward(eng.qpos[a:b], self.prev_qpos[a:b], eng.ee_wpos[a:b], fl[0], fl[1], fl[2], end_reward, active=fl[3],
+                       reward_out=rec["rewards"][k, a:b], cinfo_out=rec["cinfo"][k, a:b])
+            rec["next_states"][k, a:b] = nxt
+            rec["e_ind"][k, a:b] = torch.as_tensor(self.e_ind[a:b], device=dev)
+            rec["s_ind"][k, a:b] = torch.as_tensor(self.s_ind[a:b], device=dev)
+            self.state[a:b] = nxt
+            steps_done[a:b] += act_g
+            t2 = time.time()
+            if done.any():
+                ids = np.nonzero(done)[0] + a
+                ep_lens.extend(self.cur_t[ids].tolist())
+                finished = steps_done[ids] >= quota
+                active[ids[finished]] = False
+                again = ids[~finished]
+                if len(again):
+                    self._reset_slots(again)
+                    mask = np.zeros(b - a, np.int32)
+                    mask[again - a] = 1
+                    m_d = torch.as_tensor(mask, device=dev)
+                    fresh = self._filter(ctx.obs(eng.qpos[a:b], eng.qvel[a:b]), m_d)
+                    self.state[a:b] = torch.where(m_d.bool().unsqueeze(1), fresh, self.state[a:b])
+            tick[g] = k + 1
+            t3 = time.time()
+            tm["wait"] += t1 - t0
+            tm["post"] += t2 - t1
+            tm["reset"] += t3 - t2
+
+        for g in range(len(self.groups)):
+            pre_step(g)
+        live = [True] * len(self.groups)
+        while any(live):
+            for g, (a, b) in enumerate(self.groups):
+                if not live[g]:
+                    continue
+                post_step(g)
+                if active[a:b].any():
+                    if tick[g] >= T_max:
+                        raise RuntimeError("rollout exceeded its tick budget (quota %d + episode_len %d)" % (quota, T_ep))
+                    pre_step(g)
+                else:
+                    live[g] = False
+
+        # ---- episode-major batch: slot by slot, each slot's ticks in order
+        T_used = max(tick)
+        valid = rec["flags"][:T_used, 3, :].bool()                      # (T, N)
+        et = valid.t().nonzero()                                        # sorted by slot, then tick
+        flat = et[:, 1] * N + et[:, 0]
+        pick = lambda x: x[:T_used].reshape((T_used * N,) + tuple(x.shape[2:])).index_select(0, flat)
+        done_flag = rec["flags"][:T_used, 4, :].reshape(-1).index_select(0, flat)
+        batch = TrajBatchEgo.from_device(
+            states=pick(rec["states"]), actions=pick(rec["actions"]), masks=(1 - done_flag).to(torch.int64),
+            next_states=pick(rec["next_states"]), rewards=pick(rec["rewards"]), exps=pick(rec["exps"]),
+            v_metas=torch.stack((pick(rec["e_ind"]), pick(rec["s_ind"])), dim=1))
+        r = batch.device_column("rewards")
+        ci = pick(rec["cinfo"])
+        stats = torch.cat([r.sum().view(1), r.min().view(1), r.max().view(1), ci.sum(0)]).cpu().numpy()
+        n_steps = int(r.shape[0])
+        ep = np.asarray(ep_lens, float)
+        log = LoggerRL.from_totals(n_steps, len(ep), float(n_steps), ep.min(), ep.max(), stats[0], stats[1], stats[2], stats[3:])
+        if self.running_state is not None:
+            self.running_state.from_device_state(self.zf_state)
+        torch.cuda.synchronize(dev)
+        log.sample_time = time.time() - t_start
+        tm.update(ticks=T_used, quota=quota, **eng.timing())
+        self.timing = tm
+        return batch, log

@@ -1,0 +1,100 @@
+"""Running observation normaliser, host object + device-state bridge.
+
+API and pickled attribute names (``rs._n/_M/_S``, ``demean/destd/clip``) are those of
+/root/reference/utils/zfilter.py:7-74 so checkpoints holding a ``running_state`` stay loadable and
+``running_state.rs.mean/std/n`` keep working (ego_mimic_eval.py:67,126). The lockstep rollout does not
+call this object per sample: it moves the statistics to HBM (``to_device_state``), updates them with
+the batched Chan merge kernel (K6) and writes them back (``from_device_state``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class RunningStat:
+    def __init__(self, shape):
+        self._n = 0
+        self._M = np.zeros(shape)
+        self._S = np.zeros(shape)
+
+    def push(self, x):
+        """One Welford step (used by single-env callers such as the eval scripts)."""
+        x = np.asarray(x, dtype=float)
+        if x.shape != self._M.shape:
+            raise AssertionError("RunningStat.push: shape %s != %s" % (x.shape, self._M.shape))
+        self._n += 1
+        delta = x - self._M
+        if self._n == 1:
+            self._M = self._M + delta
+        else:
+            self._M = self._M + delta / self._n
+            self._S = self._S + delta * (x - self._M)
+
+    def merge(self, count, mean, m2):
+        """Chan merge of an already reduced block (count, mean, sum of squared deviations)."""
+        count = int(count)
+        if count == 0:
+            return
+        if self._n == 0:
+            self._n, self._M, self._S = count, np.array(mean, float), np.array(m2, float)
+            return
+        tot = self._n + count
+        d = np.asarray(mean, float) - self._M
+        self._S = self._S + np.asarray(m2, float) + d * d * (self._n * count / tot)
+        self._M = self._M + d * (count / tot)
+        self._n = tot
+
+    n = property(lambda self: self._n)
+    mean = property(lambda self: self._M)
+    shape = property(lambda self: self._M.shape)
+
+    @property
+    def var(self):
+        return self._S / (self._n - 1) if self._n > 1 else np.square(self._M)
+
+    @property
+    def std(self):
+        return np.sqrt(self.var)
+
+
+class ZFilter:
+    """y = clip((x - mean) / (std + 1e-8), +-clip) with running mean/std."""
+
+    def __init__(self, shape, demean=True, destd=True, clip=10.0):
+        self.demean, self.destd, self.clip = demean, destd, clip
+        self.rs = RunningStat(shape)
+
+    def __call__(self, x, update=True):
+        if update:
+            self.rs.push(x)
+        y = np.asarray(x, dtype=float)
+        if self.demean:
+            y = y - self.rs.mean
+        if self.destd:
+            y = y / (self.rs.std + 1e-8)
+        if self.clip:
+            y = np.clip(y, -self.clip, self.clip)
+        return y
+
+    def set_mean_std(self, mean, std, n):
+        # the reference stores `std` into S verbatim (utils/zfilter.py:69-74); kept for compatibility
+        self.rs._n = n
+        self.rs._M[...] = mean
+        self.rs._S[...] = std
+
+    # ------------------------------------------------------------------ device bridge (K6 state layout)
+    def to_device_state(self, device):
+        import torch
+        d = int(np.prod(self.rs.shape))
+        st = np.empty(1 + 2 * d)
+        st[0] = self.rs._n
+        st[1:1 + d] = np.asarray(self.rs._M, float).ravel()
+        st[1 + d:] = np.asarray(self.rs._S, float).ravel()
+        return torch.as_tensor(st, dtype=torch.float64, device=device)
+
+    def from_device_state(self, state):
+        st = state.detach().cpu().numpy()
+        d = int(np.prod(self.rs.shape))
+        self.rs._n = int(round(st[0]))
+        self.rs._M = st[1:1 + d].reshape(self.rs.shape).copy()
+        self.rs._S = st[1 + d:].reshape(self.rs.shape).copy()

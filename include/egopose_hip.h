@@ -134,6 +134,21 @@ int egp_reward_quat_v3_f32(egp_ctx *ctx, const float *cur_qpos, const float *pre
                            const int32_t *end, const int32_t *active, double end_reward, int32_t n,
                            float *reward, float *c_info, void *stream);
 
+/* ---------------------------------------------------------------------------------------- K7
+ * Pose features of a (previous, current) frame pair in the reference's expert formats
+ * (ego_pose/data_process/gen_expert.py:28-83; the learner side of reward_function.py:18-26):
+ *   qvel[n][nv]        get_qvel_fd(prev, cur, dt)            (utils/math.py:20-35, world-frame root lin-vel)
+ *   rlinv_local[n][3]  root lin-vel in the heading frame of the CURRENT root quat when expert_convention
+ *                      != 0 (gen_expert.py:53), of the PREVIOUS one otherwise (reward_function.py:19-21)
+ *   rangv[n][3], rq_rmh[n][4] (de_heading), ee_pos[n][15] (get_ee_pos 'heading'),
+ *   bquat[n][4*nbody] (get_body_quat), bangvel[n][3*nbody] (get_angvel_fd) */
+int egp_pose_features_f64(egp_ctx *ctx, const double *cur_qpos, const double *prev_qpos, const double *ee_wpos,
+                          int32_t n, int32_t expert_convention, double *qvel, double *rlinv_local, double *rangv,
+                          double *rq_rmh, double *ee_pos, double *bquat, double *bangvel, void *stream);
+int egp_pose_features_f32(egp_ctx *ctx, const float *cur_qpos, const float *prev_qpos, const float *ee_wpos,
+                          int32_t n, int32_t expert_convention, float *qvel, float *rlinv_local, float *rangv,
+                          float *rq_rmh, float *ee_pos, float *bquat, float *bangvel, void *stream);
+
 /* ---------------------------------------------------------------------------------------- K6
  * ZFilter / RunningStat (utils/zfilter.py:7-67), batched: Chan-merge the `active` rows of
  * x[n][dim] into the running state, then y = clip((x-mean)/(std+1e-8), +-clip) for all rows.

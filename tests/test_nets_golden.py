@@ -1,0 +1,77 @@
+"""Product nets (egopose_amd.nets) on CPU float64 against golden outputs of the reference modules:
+state_dict keys load strictly (checkpoint drop-in), forward values agree."""
+import numpy as np
+import torch
+
+from conftest import load_golden
+from egopose_amd.nets import MLP, PolicyGaussian, Value, VideoStateNet, RNN
+
+
+def _sd(g, prefix):
+    return {k[len(prefix):]: torch.as_tensor(g[k]) for k in g.files if k.startswith(prefix)}
+
+
+def test_policy_and_value_match_reference():
+    g = load_golden("policy_value.npz")
+    torch.set_default_dtype(torch.float64)
+    try:
+        pol = PolicyGaussian(MLP(13, [10, 6], "relu"), 4, log_std=-2.3, fix_std=True)
+        val = Value(MLP(13, [10, 6], "relu"))
+        pol.load_state_dict(_sd(g, "pol_"), strict=True)
+        val.load_state_dict(_sd(g, "val_"), strict=True)
+        assert not pol.action_log_std.requires_grad
+        x, a = torch.as_tensor(g["x"]), torch.as_tensor(g["a"])
+        with torch.no_grad():
+            d = pol(x)
+            np.testing.assert_allclose(d.loc.numpy(), g["mean"], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(d.scale.numpy(), g["std"], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(pol.get_log_prob(x, a).numpy(), g["logp"], rtol=1e-12, atol=1e-11)
+            np.testing.assert_allclose(val(x).numpy(), g["value"], rtol=1e-12, atol=1e-12)
+            np.testing.assert_array_equal(pol.select_action(x, True).numpy(), d.loc.numpy())
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def test_video_state_net_test_and_train_modes():
+    g = load_golden("video_state_net.npz")
+    torch.set_default_dtype(torch.float64)
+    try:
+        cdim, hdim, m = int(g["cdim"]), int(g["hdim"]), int(g["margin"])
+        vs = VideoStateNet(cdim, hdim, m, "lstm", None, False)
+        vs.load_state_dict(_sd(g, "sd_"), strict=True)
+        vs.set_mode("test")
+        with torch.no_grad():
+            vs.initialize(torch.as_tensor(g["win"]))
+            np.testing.assert_allclose(vs.v_out.numpy(), g["v_out"], rtol=1e-12, atol=1e-13)
+            st = torch.as_tensor(g["st"])
+            np.testing.assert_allclose(vs(st).numpy(), g["cat0"], rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(vs(st).numpy(), g["cat1"], rtol=1e-12, atol=1e-13)
+            # batched windows (what the lockstep rollout feeds): same numbers per column
+            win = torch.as_tensor(g["win"])
+            vs.initialize(torch.stack([win, win.flip(0)], dim=1))
+            np.testing.assert_allclose(vs.v_out[:, 0].numpy(), g["v_out"], rtol=1e-12, atol=1e-13)
+        vs.set_mode("train")
+        cnn = [g["cnn_feat0"], g["cnn_feat1"]]
+        vs.initialize((torch.as_tensor(g["masks"]), cnn, g["v_metas"]))
+        np.testing.assert_array_equal(vs.indices, g["indices"])
+        np.testing.assert_array_equal(vs.cnn_feat_ctx.numpy(), g["cnn_feat_ctx"])
+        with torch.no_grad():
+            np.testing.assert_allclose(vs(torch.as_tensor(g["states"])).numpy(), g["train_out"], rtol=1e-12, atol=1e-13)
+        # device-table gather builds the same context as the per-episode numpy slicing
+        table = torch.as_tensor(np.concatenate(cnn, 0))
+        vs.attach_feature_table(table, [0, cnn[0].shape[0]])
+        vs.initialize((torch.as_tensor(g["masks"]), cnn, g["v_metas"]))
+        np.testing.assert_array_equal(vs.cnn_feat_ctx.numpy(), g["cnn_feat_ctx"])
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def test_rnn_float32_generic_path_close_to_float64():
+    torch.manual_seed(0)
+    rnn = RNN(6, 8, "lstm", bi_dir=True).double()
+    x = torch.randn(9, 3, 6, dtype=torch.float64)
+    with torch.no_grad():
+        ref = rnn(x)
+        out32 = rnn.float()(x.float())
+    assert out32.shape == (9, 3, 8)
+    np.testing.assert_allclose(out32.numpy(), ref.numpy(), atol=2e-6)

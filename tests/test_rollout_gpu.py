@@ -1,0 +1,116 @@
+"""GPU integration: K7 features vs golden expert arrays, the lockstep rollout replayed step by step by the
+oracle's one-env CPU env (same physics backend), and one full PPO iteration."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def workspace(tmp_path_factory):
+    from egopose_amd.bench_support import write_synthetic_dataset
+    root = str(tmp_path_factory.mktemp("egp_ws"))
+    write_synthetic_dataset(root, "subject_03", n_takes=3, n_frames=300, seed=4)
+    return root
+
+
+def test_pose_features_match_reference_expert_arrays(skel):
+    """K7 on the golden take == the arrays the reference's gen_expert formulas produced."""
+    from egopose_amd.hip import EgpContext
+    c = load_golden("config_subject_03.npz")
+    g = load_golden("reward.npz")
+    ctx = EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"])
+    q = g["expert_qpos"]
+    ee_w = np.stack([skel.body_xpos(x)[skel.ee_body].ravel() for x in q])
+    cur = torch.as_tensor(q, device="cuda")
+    prev = torch.cat([cur[:1], cur[:-1]]).contiguous()
+    f = {k: v.cpu().numpy() for k, v in ctx.pose_features(cur, prev, torch.as_tensor(ee_w, device="cuda"), expert_convention=True).items()}
+    for k in ("rq_rmh", "ee_pos", "bquat"):
+        np.testing.assert_allclose(f[k], g["expert_" + k], rtol=1e-10, atol=1e-10, err_msg=k)
+    for k in ("qvel", "rlinv_local", "rangv", "bangvel"):       # frame 0 is a copy of frame 1 in the table
+        np.testing.assert_allclose(f[k][1:], g["expert_" + k][1:], rtol=1e-9, atol=1e-9, err_msg=k)
+    ctx.close()
+
+
+def _trainer(workspace, n_env, episode_len, **kw):
+    from egopose_amd.config import Config
+    from egopose_amd.train import Trainer
+    os.chdir(workspace)
+    cfg = Config("subject_03", create_dirs=False)
+    cfg.env_episode_len = episode_len
+    cfg.num_optim_epoch = 2
+    return Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=n_env, **kw), cfg
+
+
+@pytest.mark.parametrize("n_groups", [1, 2])
+def test_rollout_replayed_by_oracle_env(workspace, skel, n_groups):
+    from egopose_amd.physics import SurrogatePhysics
+    from oracle.cpu_env import OracleHumanoidEnv
+    tr, cfg = _trainer(workspace, 24, 15, num_threads=4, num_groups=n_groups)
+    tr.agent.running_state = None                      # raw observations so the replay can compare them
+    tr.env.end_reward = 0.37
+    batch, log = tr.agent.sample(24 * 20)
+    N = len(batch)
+    assert log.num_steps == N and N >= 480
+    masks = batch.masks
+    ends = np.where(masks == 0)[0]
+    assert ends[-1] == N - 1, "batch must end on an episode boundary (episodes are never truncated)"
+    assert log.num_episodes == len(ends)
+    starts = np.r_[0, ends[:-1] + 1]
+    lens = ends - starts + 1
+    assert lens.max() <= 15 and np.isclose(log.avg_episode_reward, lens.mean())
+    np.testing.assert_allclose(log.avg_c_reward, batch.rewards.mean(), rtol=1e-12)
+    assert batch.states.dtype == np.float64 and batch.v_metas.dtype == np.int64 and batch.exps.min() == 1
+    # replay every episode on the CPU with the oracle env and the recorded actions
+    ph = SurrogatePhysics(skel, 1)
+    env = OracleHumanoidEnv(skel, cfg, ph, tr.env.expert_arr, tr.env.cnn_feat)
+    env.end_reward = 0.37
+    for s, e in zip(starts[:12], ends[:12]):
+        ei, si = batch.v_metas[s]
+        assert (batch.v_metas[s:e + 1] == [ei, si]).all()
+        env.expert_ind, env.start_ind, env.cur_t = int(ei), int(si), 0
+        ex = tr.env.expert_arr[ei]
+        ph.reset(0, ex["qpos"][si], ex["qvel"][si])
+        env._drain(True)
+        from oracle import humanoid as H
+        env.bquat = H.body_quat(env.qpos, skel.body_qpos_start, skel.body_ndof)[0]
+        np.testing.assert_allclose(batch.states[s], env._obs(), rtol=1e-9, atol=1e-9)
+        for i in range(s, e + 1):
+            obs, _, done, info = env.step(batch.actions[i])
+            r, _ = env.reward(None, None, info)
+            np.testing.assert_allclose(batch.next_states[i], obs, rtol=1e-7, atol=1e-7, err_msg="obs @%d" % i)
+            np.testing.assert_allclose(batch.rewards[i], r, rtol=1e-7, atol=1e-7, err_msg="reward @%d" % i)
+            assert done == (masks[i] == 0)
+            if i < e:
+                np.testing.assert_allclose(batch.states[i + 1], obs, rtol=1e-7, atol=1e-7)
+    ph.close()
+    tr.close()
+
+
+def test_full_iteration_updates_parameters_and_filter(workspace):
+    tr, cfg = _trainer(workspace, 32, 12, num_threads=4, num_groups=2)
+    before = [p.detach().clone() for p in tr.policy_net.parameters()]
+    log, t_s, t_u, n = tr.iteration(0, 32 * 16)
+    assert n >= 512 and np.isfinite(log.avg_c_reward) and 0.0 <= log.min_c_reward <= log.max_c_reward
+    assert tr.running_state.rs.n >= n          # every sampled observation (+ resets) went through the filter
+    assert np.isfinite(tr.running_state.rs.std).all()
+    changed = [not torch.equal(a, b) for a, b in zip(before, tr.policy_net.parameters()) if b.requires_grad]
+    assert all(changed)
+    assert len(tr.agent.update_stats["surr_loss"]) == 2 and all(np.isfinite(tr.agent.update_stats["value_loss"]))
+    # checkpoint round trip in the reference's container (ego_mimic.py:133-139)
+    path = os.path.join(workspace, "cp.p")
+    tr.save(path)
+    cp = pickle.load(open(path, "rb"))
+    assert set(cp) == {"policy_dict", "policy_vs_dict", "value_dict", "value_vs_dict", "running_state"}
+    assert "v_net.rnn_f.weight_ih" in cp["policy_vs_dict"] and "action_log_std" in cp["policy_dict"]
+    tr.load(path)
+    # a second iteration reuses the engine and the end_reward bonus
+    log2, *_ = tr.iteration(1, 32 * 16)
+    assert tr.env.end_reward == pytest.approx(log2.avg_c_reward * cfg.gamma / (1 - cfg.gamma))
+    tr.close()
