@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--envs", type=int, default=1024, help="env slots per GPU")
     ap.add_argument("--threads", type=int, default=0, help="host physics threads per GPU (0 = auto)")
-    ap.add_argument("--groups", type=int, default=2)
+    ap.add_argument("--groups", type=int, default=4)
     ap.add_argument("--min-batch", type=int, default=0, help="env-steps per GPU per iteration (0 = config: 50000)")
     ap.add_argument("--cfg", default="subject_03")
     ap.add_argument("--cpu-steps", type=int, default=3000)
@@ -69,15 +69,15 @@ def main():
 
     from egopose_amd.bench_support import write_synthetic_dataset
     from egopose_amd.config import Config
-    from egopose_amd.physics import default_threads
     from egopose_amd.train import Trainer
 
     root = tempfile.mkdtemp(prefix="egp_bench_r%d_" % rank)
     write_synthetic_dataset(root, args.cfg, device_index=local)
     os.chdir(root)
     cfg = Config(args.cfg, create_dirs=False)
-    cores = default_threads()
-    n_threads = args.threads or max(args.groups, min(64, (os.cpu_count() or 8) // max(1, args.gpus)))
+    from egopose_amd.physics import available_cpus, default_threads
+    cores = available_cpus()
+    n_threads = args.threads or max(args.groups, default_threads(share=world))
     tr = Trainer(cfg, dev, torch.float32, num_envs=args.envs, num_threads=n_threads, num_groups=args.groups, seed_offset=rank)
     min_batch = (args.min_batch or cfg.min_batch_size) * world      # Agent.sample splits it evenly over ranks
 
@@ -131,7 +131,7 @@ def main():
         }
         if tim["k1_launches"] > 0:
             avg_s = tim["k1_ms"] * 1e-3 / tim["k1_launches"]
-            envs_per_launch = (args.envs / n_threads) / 2.0
+            envs_per_launch = args.envs / float(args.groups)
             achieved = K1_BYTES_PER_ENV * envs_per_launch / avg_s
             res["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "k_pd_torque_reg58<double>",

@@ -60,11 +60,12 @@ PHYS_RESET = C.CFUNCTYPE(C.c_int, vp, C.c_int32, c_dbl_p, c_dbl_p)
 PHYS_STEP = C.CFUNCTYPE(C.c_int, vp, C.c_int32, c_dbl_p)
 PHYS_DRAIN = C.CFUNCTYPE(C.c_int, vp, C.c_int32, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p)
 PHYS_DESTROY = C.CFUNCTYPE(None, vp)
+PHYS_EPOCH = C.CFUNCTYPE(C.c_int64, vp, C.c_int32)
 
 
 class PhysicsVtable(C.Structure):
     _fields_ = [("user", vp), ("reset", PHYS_RESET), ("step", PHYS_STEP), ("drain", PHYS_DRAIN),
-                ("destroy", PHYS_DESTROY), ("name", C.c_char_p)]
+                ("destroy", PHYS_DESTROY), ("name", C.c_char_p), ("inertia_epoch", PHYS_EPOCH)]
 
 
 # name -> (restype, argtypes); must list every symbol include/egopose_hip.h declares
@@ -111,6 +112,7 @@ SIGNATURES = {
     "egp_engine_wait": (C.c_int, [vp, _i32, vp]),
     "egp_engine_timing": (C.c_int, [vp, c_dbl_p, c_dbl_p, c_dbl_p, C.POINTER(_i64)]),
     "egp_engine_reset_timing": (C.c_int, [vp]),
+    "egp_engine_inertia_uploads": (_i64, [vp]),
     "egp_engine_set_profile": (C.c_int, [vp, C.c_int]),
     "egp_engine_layout": (C.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p]),
     "egp_engine_group_range": (C.c_int, [vp, _i32, c_int_p, c_int_p]),

@@ -24,7 +24,7 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-           "-Wno-unused-result", "-x", "hip"]
+           "-Wno-unused-result", "-Xarch_host", "-mavx2", "-Xarch_host", "-mfma", "-x", "hip"]
     cmd += [os.path.join(CSRC, f) for f in SOURCES]
     cmd += ["-o", LIB]
     if verbose:

@@ -2,20 +2,23 @@
 // (ego_pose/envs/humanoid_v1.py:158-177: 15 x {compute_torque; clip; data.ctrl = torque; sim.step()})
 // for all envs of a GPU at once.
 //
-//   * physics stays on the host (egp_physics vtable), run by a pool of worker threads; each worker owns
-//     a contiguous slice of envs, split into two half-slices that ping-pong so that one half's
-//     K1 launch + PCIe round trip overlaps the other half's physics;
-//   * per env and substep the drained MuJoCo fields travel as ONE packed row
-//     [qpos | qvel | qfrc_bias | qM | pad] (1088 doubles) from pinned host memory with hipMemcpyAsync
-//     on the half-slice's own stream; K1 reads the packed row in place and the clipped torque comes
-//     back with one D2H copy;
-//   * env groups (n_groups) can be stepped independently so the caller's GPU work for one group
-//     (reward / observation kernels, policy inference) overlaps the other group's physics.
+//   * envs are partitioned into `n_groups` contiguous groups; a group advances one env-step as 15 substeps of
+//        K1 over the whole group (ONE launch on the group's stream) -> one D2H copy of the clipped torques
+//        -> physics of the group's envs on the group's host threads (egp_physics vtable, env-parallel)
+//        -> ONE H2D copy of the group's state rows [qpos | qvel | qfrc_bias | pad] (176 doubles/env), plus
+//           ONE copy of its inertia rows qM (912 doubles/env) when the backend reports that some qM changed
+//     so the GPU sees a few large launches/copies per substep instead of many tiny ones (HIP streams beyond
+//     the handful of hardware queues serialise);
+//   * a group's threads meet at spin barriers inside the substep loop (phases are tens of microseconds);
+//     thread 0 of the group is its leader and owns every HIP call of the group;
+//   * different groups run independently: while one group's rows are on the PCIe link / in K1, another
+//     group's threads do physics, and the caller's GPU work for a finished group (reward / observation
+//     kernels, policy inference) overlaps the other groups' stepping.
 #include <hip/hip_runtime.h>
 
-#include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <atomic>
 #include <chrono>
@@ -24,6 +27,10 @@
 #include <thread>
 #include <vector>
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
 #include "egp_internal.hpp"
 
 namespace {
@@ -31,36 +38,55 @@ namespace {
 using clk = std::chrono::steady_clock;
 inline double secs(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
 
-struct Half {
-    int e0 = 0, e1 = 0;              // env range [e0, e1)
-    hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;       // recorded after the last H2D of an env-step
-    std::vector<hipEvent_t> k_beg, k_end;   // per substep, only when profiling K1
-};
+inline void cpu_relax() {
+#if defined(__x86_64__)
+    _mm_pause();
+#endif
+}
 
-struct Worker {
-    int group = 0;
-    Half half[2];
-    std::thread th;
-    // accumulated timing
-    double phys_s = 0.0, wait_s = 0.0;
-    double k1_ms = 0.0;
-    long k1_launches = 0;
-    int status = EGP_OK;
-    char err[256] = "";
+// sense-reversing spin barrier for the threads of one group
+struct SpinBarrier {
+    std::atomic<int> count{0};
+    std::atomic<int> phase{0};
+    int n = 1;
+    void wait() {
+        const int ph = phase.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) == n - 1) {
+            count.store(0, std::memory_order_relaxed);
+            phase.store(ph + 1, std::memory_order_release);
+        } else {
+            int spins = 0;
+            while (phase.load(std::memory_order_acquire) == ph) {
+                if (++spins < 4096) cpu_relax();
+                else { std::this_thread::yield(); }
+            }
+        }
+    }
 };
 
 struct Group {
+    int e0 = 0, e1 = 0;                       // env range [e0, e1)
+    int n_threads = 1;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;                // recorded after the last upload of an env-step
+    std::vector<hipEvent_t> k_beg, k_end;     // per substep, when profiling K1
+    SpinBarrier bar;
     std::mutex mu;
     std::condition_variable cv_go, cv_done;
-    long job = 0;                    // incremented per step request
-    int pending = 0;                 // workers still running the current job
+    long job = 0;
+    int pending = 0;                          // threads still inside the current job
     bool quit = false;
     const double *action = nullptr;
     hipEvent_t ready = nullptr;
-    std::vector<int> active;         // per env of the whole engine (copied from the caller)
+    std::vector<int> active;
     bool has_active = false;
-    std::vector<int> workers;
+    std::atomic<int> status{EGP_OK};
+    std::atomic<int> qM_dirty{0};             // some env of the group drained a new inertia this substep
+    char err[256] = "";
+    // timing (leader only)
+    double phys_s = 0.0, wait_s = 0.0, k1_ms = 0.0;
+    long k1_launches = 0, qM_uploads = 0;
+    std::vector<std::thread> threads;
 };
 
 }  // namespace
@@ -71,25 +97,30 @@ struct egp_engine {
     const egp_physics_vtable *vt = nullptr;
     int n_env = 0, n_threads = 0, n_groups = 0;
     int nq = 0, nv = 0, nu = 0, nM = 0, nbody = 0, frame_skip = 0;
-    int pack_ld = 0, off_qpos = 0, off_qvel = 0, off_bias = 0, off_qM = 0;
-    bool profile_k1 = false;
-    // device
-    double *d_pack = nullptr, *d_qpos = nullptr, *d_qvel = nullptr, *d_torque = nullptr, *d_ee = nullptr;
-    // pinned host
-    double *h_pack = nullptr, *h_qpos = nullptr, *h_qvel = nullptr, *h_torque = nullptr, *h_ee = nullptr,
+    int ld_s = 0, ld_m = 0, off_qpos = 0, off_qvel = 0, off_bias = 0;   // state / inertia row strides (doubles)
+    std::atomic<bool> profile_k1{false};
+    double *d_state = nullptr, *d_qM = nullptr, *d_qpos = nullptr, *d_qvel = nullptr, *d_torque = nullptr, *d_ee = nullptr;
+    double *h_state = nullptr, *h_qM = nullptr, *h_qpos = nullptr, *h_qvel = nullptr, *h_torque = nullptr, *h_ee = nullptr,
            *h_headz = nullptr, *h_xpos = nullptr;
-    std::vector<Worker> workers;
     std::vector<Group> groups;
+    std::vector<int64_t> epoch;               // last drained inertia epoch per env (-1 = never)
     std::vector<int> env_group;
 };
 
 namespace {
 
 int drain_env(egp_engine *E, int env, bool with_xpos) {
-    double *row = E->h_pack + (size_t)env * E->pack_ld;
+    double *row = E->h_state + (size_t)env * E->ld_s;
     double *xp = with_xpos ? E->h_xpos + (size_t)env * E->nbody * 3 : nullptr;
-    int rc = E->vt->drain(E->vt->user, env, row + E->off_qpos, row + E->off_qvel, row + E->off_qM, row + E->off_bias, xp);
+    double *qM = E->h_qM + (size_t)env * E->ld_m;
+    if (E->vt->inertia_epoch) {
+        const int64_t ep = E->vt->inertia_epoch(E->vt->user, env);
+        if (ep == E->epoch[env]) qM = nullptr;            // unchanged since the last drain: nothing to move
+        else E->epoch[env] = ep;
+    }
+    int rc = E->vt->drain(E->vt->user, env, row + E->off_qpos, row + E->off_qvel, qM, row + E->off_bias, xp);
     if (rc != 0) return EGP_E_PHYSICS;
+    if (qM) E->groups[E->env_group[env]].qM_dirty.store(1, std::memory_order_relaxed);
     if (with_xpos) {
         memcpy(E->h_qpos + (size_t)env * E->nq, row + E->off_qpos, E->nq * sizeof(double));
         memcpy(E->h_qvel + (size_t)env * E->nv, row + E->off_qvel, E->nv * sizeof(double));
@@ -102,97 +133,101 @@ int drain_env(egp_engine *E, int env, bool with_xpos) {
     return EGP_OK;
 }
 
-#define W_HIP(expr)                                                                                        \
-    do {                                                                                                   \
-        hipError_t _e = (expr);                                                                            \
-        if (_e != hipSuccess) {                                                                            \
-            snprintf(W.err, sizeof(W.err), "%s failed: %s", #expr, hipGetErrorString(_e));                 \
-            W.status = EGP_E_HIP;                                                                          \
-            return;                                                                                        \
-        }                                                                                                  \
-    } while (0)
-
-void enqueue_k1(egp_engine *E, Worker &W, Half &H, const double *action, int substep) {
-    const int m = H.e1 - H.e0;
-    if (m <= 0) return;
-    if (E->profile_k1) W_HIP(hipEventRecord(H.k_beg[substep], H.stream));
-    int rc = egp_launch_pd_torque_packed(E->ctx, E->d_pack + (size_t)H.e0 * E->pack_ld, E->pack_ld, E->off_qpos, E->off_qvel,
-                                         E->off_bias, E->off_qM, action + (size_t)H.e0 * E->nu, m,
-                                         E->d_torque + (size_t)H.e0 * E->nu, H.stream);
-    if (rc != EGP_OK) {
-        snprintf(W.err, sizeof(W.err), "K1 launch failed: %s", egp_last_error());
-        W.status = rc;
-        return;
-    }
-    if (E->profile_k1) W_HIP(hipEventRecord(H.k_end[substep], H.stream));
-    W_HIP(hipMemcpyAsync(E->h_torque + (size_t)H.e0 * E->nu, E->d_torque + (size_t)H.e0 * E->nu, (size_t)m * E->nu * sizeof(double),
-                         hipMemcpyDeviceToHost, H.stream));
+void fail(Group &G, int code, const char *what, const char *detail) {
+    int expect = EGP_OK;
+    if (G.status.compare_exchange_strong(expect, code)) snprintf(G.err, sizeof(G.err), "%s: %s", what, detail);
 }
 
-void run_step(egp_engine *E, Worker &W, Group &G) {
-    const double *action = G.action;
+#define G_HIP(expr)                                                          \
+    do {                                                                     \
+        hipError_t _e = (expr);                                              \
+        if (_e != hipSuccess) fail(G, EGP_E_HIP, #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// leader only: K1 over the whole group + torque download
+void enqueue_k1(egp_engine *E, Group &G, int substep) {
+    const int m = G.e1 - G.e0;
+    const bool prof = E->profile_k1.load(std::memory_order_relaxed) && !G.k_beg.empty();
+    if (prof) G_HIP(hipEventRecord(G.k_beg[substep], G.stream));
+    const double *st = E->d_state + (size_t)G.e0 * E->ld_s;
+    int rc = egp_launch_pd_torque_strided(E->ctx, st + E->off_qpos, E->ld_s, st + E->off_qvel, E->ld_s, st + E->off_bias, E->ld_s,
+                                          E->d_qM + (size_t)G.e0 * E->ld_m, E->ld_m, G.action + (size_t)G.e0 * E->nu, m,
+                                          E->d_torque + (size_t)G.e0 * E->nu, G.stream);
+    if (rc != EGP_OK) fail(G, rc, "K1 launch", egp_last_error());
+    if (prof) G_HIP(hipEventRecord(G.k_end[substep], G.stream));
+    G_HIP(hipMemcpyAsync(E->h_torque + (size_t)G.e0 * E->nu, E->d_torque + (size_t)G.e0 * E->nu, (size_t)m * E->nu * sizeof(double),
+                         hipMemcpyDeviceToHost, G.stream));
+}
+
+void run_step(egp_engine *E, Group &G, int tid) {
+    const bool leader = tid == 0;
     const int FS = E->frame_skip;
-    for (int h = 0; h < 2; ++h) {
-        Half &H = W.half[h];
-        if (H.e1 <= H.e0) continue;
-        if (G.ready) W_HIP(hipStreamWaitEvent(H.stream, G.ready, 0));
-        enqueue_k1(E, W, H, action, 0);
-        if (W.status != EGP_OK) return;
+    const int m = G.e1 - G.e0;
+    const int my0 = G.e0 + (int)((long)m * tid / G.n_threads), my1 = G.e0 + (int)((long)m * (tid + 1) / G.n_threads);
+    const bool prof = E->profile_k1.load(std::memory_order_relaxed) && !G.k_beg.empty();
+    if (leader) {
+        if (G.ready) G_HIP(hipStreamWaitEvent(G.stream, G.ready, 0));
+        enqueue_k1(E, G, 0);
     }
     for (int s = 0; s < FS; ++s) {
         const bool last = s == FS - 1;
-        for (int h = 0; h < 2; ++h) {
-            Half &H = W.half[h];
-            const int m = H.e1 - H.e0;
-            if (m <= 0) continue;
+        if (leader) {
             auto t0 = clk::now();
-            W_HIP(hipStreamSynchronize(H.stream));          // torque of substep s is on the host
-            auto t1 = clk::now();
-            for (int e = H.e0; e < H.e1; ++e) {
+            G_HIP(hipStreamSynchronize(G.stream));        // torques of substep s are on the host
+            G.wait_s += secs(t0, clk::now());
+        }
+        G.bar.wait();
+        auto t1 = clk::now();
+        if (G.status.load(std::memory_order_relaxed) == EGP_OK) {
+            for (int e = my0; e < my1; ++e) {
                 if (G.has_active && !G.active[e]) continue;
                 if (E->vt->step(E->vt->user, e, E->h_torque + (size_t)e * E->nu) != 0 || drain_env(E, e, last) != EGP_OK) {
-                    snprintf(W.err, sizeof(W.err), "physics backend failed on env %d", e);
-                    W.status = EGP_E_PHYSICS;
-                    return;
+                    char msg[64];
+                    snprintf(msg, sizeof(msg), "env %d", e);
+                    fail(G, EGP_E_PHYSICS, "physics backend failed", msg);
+                    break;
                 }
             }
-            auto t2 = clk::now();
-            W.wait_s += secs(t0, t1);
-            W.phys_s += secs(t1, t2);
-            W_HIP(hipMemcpyAsync(E->d_pack + (size_t)H.e0 * E->pack_ld, E->h_pack + (size_t)H.e0 * E->pack_ld,
-                                 (size_t)m * E->pack_ld * sizeof(double), hipMemcpyHostToDevice, H.stream));
-            if (!last) {
-                enqueue_k1(E, W, H, action, s + 1);
-                if (W.status != EGP_OK) return;
-            } else {
-                W_HIP(hipMemcpyAsync(E->d_qpos + (size_t)H.e0 * E->nq, E->h_qpos + (size_t)H.e0 * E->nq, (size_t)m * E->nq * sizeof(double),
-                                     hipMemcpyHostToDevice, H.stream));
-                W_HIP(hipMemcpyAsync(E->d_qvel + (size_t)H.e0 * E->nv, E->h_qvel + (size_t)H.e0 * E->nv, (size_t)m * E->nv * sizeof(double),
-                                     hipMemcpyHostToDevice, H.stream));
-                W_HIP(hipMemcpyAsync(E->d_ee + (size_t)H.e0 * 15, E->h_ee + (size_t)H.e0 * 15, (size_t)m * 15 * sizeof(double),
-                                     hipMemcpyHostToDevice, H.stream));
-                W_HIP(hipEventRecord(H.done, H.stream));
+        }
+        G.bar.wait();
+        if (leader) {
+            G.phys_s += secs(t1, clk::now());
+            if (G.status.load() == EGP_OK) {
+                G_HIP(hipMemcpyAsync(E->d_state + (size_t)G.e0 * E->ld_s, E->h_state + (size_t)G.e0 * E->ld_s,
+                                     (size_t)m * E->ld_s * sizeof(double), hipMemcpyHostToDevice, G.stream));
+                if (G.qM_dirty.exchange(0)) {
+                    G_HIP(hipMemcpyAsync(E->d_qM + (size_t)G.e0 * E->ld_m, E->h_qM + (size_t)G.e0 * E->ld_m,
+                                         (size_t)m * E->ld_m * sizeof(double), hipMemcpyHostToDevice, G.stream));
+                    G.qM_uploads += 1;
+                }
+                if (!last) {
+                    enqueue_k1(E, G, s + 1);
+                } else {
+                    G_HIP(hipMemcpyAsync(E->d_qpos + (size_t)G.e0 * E->nq, E->h_qpos + (size_t)G.e0 * E->nq, (size_t)m * E->nq * sizeof(double),
+                                         hipMemcpyHostToDevice, G.stream));
+                    G_HIP(hipMemcpyAsync(E->d_qvel + (size_t)G.e0 * E->nv, E->h_qvel + (size_t)G.e0 * E->nv, (size_t)m * E->nv * sizeof(double),
+                                         hipMemcpyHostToDevice, G.stream));
+                    G_HIP(hipMemcpyAsync(E->d_ee + (size_t)G.e0 * 15, E->h_ee + (size_t)G.e0 * 15, (size_t)m * 15 * sizeof(double),
+                                         hipMemcpyHostToDevice, G.stream));
+                    G_HIP(hipEventRecord(G.done, G.stream));
+                }
             }
         }
     }
-    if (E->profile_k1) {
-        for (int h = 0; h < 2; ++h) {
-            Half &H = W.half[h];
-            if (H.e1 <= H.e0) continue;
-            W_HIP(hipStreamSynchronize(H.stream));
-            for (int s = 0; s < FS; ++s) {
-                float ms = 0.f;
-                W_HIP(hipEventElapsedTime(&ms, H.k_beg[s], H.k_end[s]));
-                W.k1_ms += ms;
-                W.k1_launches += 1;
+    if (leader && prof && G.status.load() == EGP_OK) {
+        G_HIP(hipStreamSynchronize(G.stream));
+        for (int s = 0; s < FS; ++s) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, G.k_beg[s], G.k_end[s]) == hipSuccess) {
+                G.k1_ms += ms;
+                G.k1_launches += 1;
             }
         }
     }
 }
 
-void worker_main(egp_engine *E, int wi) {
-    Worker &W = E->workers[wi];
-    Group &G = E->groups[W.group];
+void thread_main(egp_engine *E, int gi, int tid) {
+    Group &G = E->groups[gi];
     (void)hipSetDevice(E->ctx->device);
     long seen = 0;
     for (;;) {
@@ -202,12 +237,25 @@ void worker_main(egp_engine *E, int wi) {
             if (G.quit) return;
             seen = G.job;
         }
-        if (W.status == EGP_OK) run_step(E, W, G);
+        run_step(E, G, tid);
         {
             std::lock_guard<std::mutex> lk(G.mu);
             if (--G.pending == 0) G.cv_done.notify_all();
         }
     }
+}
+
+int make_profile_events(egp_engine *E) {
+    for (auto &G : E->groups) {
+        if (!G.k_beg.empty()) continue;
+        G.k_beg.resize(E->frame_skip);
+        G.k_end.resize(E->frame_skip);
+        for (int s = 0; s < E->frame_skip; ++s) {
+            EGP_HIP_CHECK(hipEventCreate(&G.k_beg[s]));
+            EGP_HIP_CHECK(hipEventCreate(&G.k_end[s]));
+        }
+    }
+    return EGP_OK;
 }
 
 }  // namespace
@@ -217,7 +265,7 @@ extern "C" {
 int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d, egp_engine **out) {
     EGP_REQUIRE(ctx && phys && d && out, "NULL pointer");
     EGP_REQUIRE(d->n_env > 0 && d->n_threads > 0 && d->n_groups > 0, "n_env/n_threads/n_groups must be positive");
-    EGP_REQUIRE(d->n_groups <= d->n_threads && d->n_threads <= d->n_env, "need n_groups <= n_threads <= n_env");
+    EGP_REQUIRE(d->n_groups <= d->n_threads && d->n_groups <= d->n_env, "need n_groups <= n_threads and n_groups <= n_env");
     EGP_REQUIRE(egp_physics_n_env(phys) >= d->n_env, "physics backend has fewer envs than the engine");
     EGP_HIP_CHECK(hipSetDevice(ctx->device));
     egp_engine *E = new egp_engine();
@@ -225,62 +273,54 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     E->n_env = d->n_env; E->n_threads = d->n_threads; E->n_groups = d->n_groups;
     E->nq = ctx->dm.nq; E->nv = ctx->dm.nv; E->nu = ctx->dm.nu; E->nM = ctx->dm.nM; E->nbody = ctx->dm.nbody;
     E->frame_skip = ctx->frame_skip;
-    E->off_qpos = 0; E->off_qvel = E->nq; E->off_bias = E->nq + E->nv; E->off_qM = E->nq + 2 * E->nv;
-    E->pack_ld = ((E->off_qM + E->nM + 15) / 16) * 16;
-    const char *prof = getenv("EGP_PROFILE_K1");
-    E->profile_k1 = prof && atoi(prof) != 0;
+    E->off_qpos = 0; E->off_qvel = E->nq; E->off_bias = E->nq + E->nv;
+    E->ld_s = ((E->nq + 2 * E->nv + 15) / 16) * 16;
+    E->ld_m = ((E->nM + 15) / 16) * 16;
+    E->epoch.assign(d->n_env, -1);
+    E->env_group.assign(d->n_env, 0);
     const size_t N = (size_t)E->n_env;
 #define E_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { egp::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); egp_engine_destroy(E); return EGP_E_HIP; } } while (0)
-    E_TRY(hipMalloc((void **)&E->d_pack, N * E->pack_ld * sizeof(double)));
+    E_TRY(hipMalloc((void **)&E->d_state, N * E->ld_s * sizeof(double)));
+    E_TRY(hipMalloc((void **)&E->d_qM, N * E->ld_m * sizeof(double)));
     E_TRY(hipMalloc((void **)&E->d_qpos, N * E->nq * sizeof(double)));
     E_TRY(hipMalloc((void **)&E->d_qvel, N * E->nv * sizeof(double)));
     E_TRY(hipMalloc((void **)&E->d_torque, N * E->nu * sizeof(double)));
     E_TRY(hipMalloc((void **)&E->d_ee, N * 15 * sizeof(double)));
-    E_TRY(hipMemset(E->d_pack, 0, N * E->pack_ld * sizeof(double)));
-    E_TRY(hipHostMalloc((void **)&E->h_pack, N * E->pack_ld * sizeof(double), hipHostMallocDefault));
+    E_TRY(hipMemset(E->d_state, 0, N * E->ld_s * sizeof(double)));
+    E_TRY(hipMemset(E->d_qM, 0, N * E->ld_m * sizeof(double)));
+    E_TRY(hipHostMalloc((void **)&E->h_state, N * E->ld_s * sizeof(double), hipHostMallocDefault));
+    E_TRY(hipHostMalloc((void **)&E->h_qM, N * E->ld_m * sizeof(double), hipHostMallocDefault));
     E_TRY(hipHostMalloc((void **)&E->h_qpos, N * E->nq * sizeof(double), hipHostMallocDefault));
     E_TRY(hipHostMalloc((void **)&E->h_qvel, N * E->nv * sizeof(double), hipHostMallocDefault));
     E_TRY(hipHostMalloc((void **)&E->h_torque, N * E->nu * sizeof(double), hipHostMallocDefault));
     E_TRY(hipHostMalloc((void **)&E->h_ee, N * 15 * sizeof(double), hipHostMallocDefault));
     E_TRY(hipHostMalloc((void **)&E->h_headz, N * sizeof(double), hipHostMallocDefault));
     E_TRY(hipHostMalloc((void **)&E->h_xpos, N * E->nbody * 3 * sizeof(double), hipHostMallocDefault));
-    memset(E->h_pack, 0, N * E->pack_ld * sizeof(double));
+    memset(E->h_state, 0, N * E->ld_s * sizeof(double));
+    memset(E->h_qM, 0, N * E->ld_m * sizeof(double));
     memset(E->h_headz, 0, N * sizeof(double));
-    // partition: groups get contiguous env ranges; each group's range is split over its workers
-    E->workers.resize(E->n_threads);
     E->groups = std::vector<Group>(E->n_groups);
-    E->env_group.assign(E->n_env, 0);
-    int wi = 0;
     for (int g = 0; g < E->n_groups; ++g) {
-        const int ge0 = (int)((long)E->n_env * g / E->n_groups), ge1 = (int)((long)E->n_env * (g + 1) / E->n_groups);
+        Group &G = E->groups[g];
+        G.e0 = (int)((long)E->n_env * g / E->n_groups);
+        G.e1 = (int)((long)E->n_env * (g + 1) / E->n_groups);
         const int w0 = (int)((long)E->n_threads * g / E->n_groups), w1 = (int)((long)E->n_threads * (g + 1) / E->n_groups);
-        const int nw = w1 - w0;
-        for (int e = ge0; e < ge1; ++e) E->env_group[e] = g;
-        for (int k = 0; k < nw; ++k, ++wi) {
-            Worker &W = E->workers[wi];
-            W.group = g;
-            const int a = ge0 + (int)((long)(ge1 - ge0) * k / nw), b = ge0 + (int)((long)(ge1 - ge0) * (k + 1) / nw);
-            const int mid = a + (b - a + 1) / 2;
-            W.half[0].e0 = a; W.half[0].e1 = mid;
-            W.half[1].e0 = mid; W.half[1].e1 = b;
-            for (int h = 0; h < 2; ++h) {
-                E_TRY(hipStreamCreateWithFlags(&W.half[h].stream, hipStreamNonBlocking));
-                E_TRY(hipEventCreateWithFlags(&W.half[h].done, hipEventDisableTiming));
-                if (E->profile_k1) {
-                    W.half[h].k_beg.resize(E->frame_skip);
-                    W.half[h].k_end.resize(E->frame_skip);
-                    for (int s = 0; s < E->frame_skip; ++s) {
-                        E_TRY(hipEventCreate(&W.half[h].k_beg[s]));
-                        E_TRY(hipEventCreate(&W.half[h].k_end[s]));
-                    }
-                }
-            }
-            E->groups[g].workers.push_back(wi);
-        }
-        E->groups[g].active.assign(E->n_env, 1);
+        G.n_threads = std::max(1, std::min(w1 - w0, G.e1 - G.e0));
+        G.bar.n = G.n_threads;
+        G.active.assign(E->n_env, 1);
+        for (int e = G.e0; e < G.e1; ++e) E->env_group[e] = g;
+        E_TRY(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
+        E_TRY(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
     }
 #undef E_TRY
-    for (int i = 0; i < E->n_threads; ++i) E->workers[i].th = std::thread(worker_main, E, i);
+    const char *prof = getenv("EGP_PROFILE_K1");
+    if (prof && atoi(prof) != 0) {
+        int rc = make_profile_events(E);
+        if (rc != EGP_OK) { egp_engine_destroy(E); return rc; }
+        E->profile_k1 = true;
+    }
+    for (int g = 0; g < E->n_groups; ++g)
+        for (int t = 0; t < E->groups[g].n_threads; ++t) E->groups[g].threads.emplace_back(thread_main, E, g, t);
     *out = E;
     return EGP_OK;
 }
@@ -288,22 +328,21 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
 int egp_engine_destroy(egp_engine *E) {
     if (!E) return EGP_OK;
     for (auto &G : E->groups) {
-        std::lock_guard<std::mutex> lk(G.mu);
-        G.quit = true;
-        G.cv_go.notify_all();
-    }
-    for (auto &W : E->workers) {
-        if (W.th.joinable()) W.th.join();
-        for (int h = 0; h < 2; ++h) {
-            if (W.half[h].stream) (void)hipStreamDestroy(W.half[h].stream);
-            if (W.half[h].done) (void)hipEventDestroy(W.half[h].done);
-            for (auto ev : W.half[h].k_beg) (void)hipEventDestroy(ev);
-            for (auto ev : W.half[h].k_end) (void)hipEventDestroy(ev);
+        {
+            std::lock_guard<std::mutex> lk(G.mu);
+            G.quit = true;
+            G.cv_go.notify_all();
         }
+        for (auto &t : G.threads)
+            if (t.joinable()) t.join();
+        if (G.stream) (void)hipStreamDestroy(G.stream);
+        if (G.done) (void)hipEventDestroy(G.done);
+        for (auto ev : G.k_beg) (void)hipEventDestroy(ev);
+        for (auto ev : G.k_end) (void)hipEventDestroy(ev);
     }
-    void *dev[] = {E->d_pack, E->d_qpos, E->d_qvel, E->d_torque, E->d_ee};
+    void *dev[] = {E->d_state, E->d_qM, E->d_qpos, E->d_qvel, E->d_torque, E->d_ee};
     for (void *p : dev) if (p) (void)hipFree(p);
-    void *host[] = {E->h_pack, E->h_qpos, E->h_qvel, E->h_torque, E->h_ee, E->h_headz, E->h_xpos};
+    void *host[] = {E->h_state, E->h_qM, E->h_qpos, E->h_qvel, E->h_torque, E->h_ee, E->h_headz, E->h_xpos};
     for (void *p : host) if (p) (void)hipHostFree(p);
     delete E;
     return EGP_OK;
@@ -325,22 +364,33 @@ int egp_engine_reset(egp_engine *E, const int32_t *ids, int32_t n, const double 
     EGP_REQUIRE(E && (n == 0 || (ids && qpos && qvel)), "NULL pointer");
     EGP_HIP_CHECK(hipSetDevice(E->ctx->device));
     hipStream_t s = (hipStream_t)stream;
+    std::vector<char> new_qM(n, 0);
     for (int k = 0; k < n; ++k) {
         const int e = ids[k];
         EGP_REQUIRE(e >= 0 && e < E->n_env, "env id out of range");
         EGP_REQUIRE(k == 0 || ids[k] > ids[k - 1], "env ids must be strictly increasing");
+        Group &G = E->groups[E->env_group[e]];
+        {
+            std::lock_guard<std::mutex> lk(G.mu);
+            if (G.pending != 0) { egp::set_error("cannot reset env %d while its group is stepping", e); return EGP_E_STATE; }
+        }
+        const int64_t before = E->epoch[e];
         if (E->vt->reset(E->vt->user, e, qpos + (size_t)k * E->nq, qvel + (size_t)k * E->nv) != 0 || drain_env(E, e, true) != EGP_OK) {
             egp::set_error("physics backend failed to reset env %d", e);
             return EGP_E_PHYSICS;
         }
+        new_qM[k] = !E->vt->inertia_epoch || E->epoch[e] != before;
+        G.qM_dirty.store(0, std::memory_order_relaxed);   // the rows are uploaded right here
     }
-    // upload maximal runs of consecutive env ids
     int k = 0;
-    while (k < n) {
+    while (k < n) {                  // upload maximal runs of consecutive env ids
         int j = k;
-        while (j + 1 < n && ids[j + 1] == ids[j] + 1) ++j;
+        bool any_qM = new_qM[k];
+        while (j + 1 < n && ids[j + 1] == ids[j] + 1) { ++j; any_qM = any_qM || new_qM[j]; }
         const size_t e0 = ids[k], m = (size_t)(j - k + 1);
-        EGP_HIP_CHECK(hipMemcpyAsync(E->d_pack + e0 * E->pack_ld, E->h_pack + e0 * E->pack_ld, m * E->pack_ld * sizeof(double), hipMemcpyHostToDevice, s));
+        EGP_HIP_CHECK(hipMemcpyAsync(E->d_state + e0 * E->ld_s, E->h_state + e0 * E->ld_s, m * E->ld_s * sizeof(double), hipMemcpyHostToDevice, s));
+        if (any_qM)
+            EGP_HIP_CHECK(hipMemcpyAsync(E->d_qM + e0 * E->ld_m, E->h_qM + e0 * E->ld_m, m * E->ld_m * sizeof(double), hipMemcpyHostToDevice, s));
         EGP_HIP_CHECK(hipMemcpyAsync(E->d_qpos + e0 * E->nq, E->h_qpos + e0 * E->nq, m * E->nq * sizeof(double), hipMemcpyHostToDevice, s));
         EGP_HIP_CHECK(hipMemcpyAsync(E->d_qvel + e0 * E->nv, E->h_qvel + e0 * E->nv, m * E->nv * sizeof(double), hipMemcpyHostToDevice, s));
         EGP_HIP_CHECK(hipMemcpyAsync(E->d_ee + e0 * 15, E->h_ee + e0 * 15, m * 15 * sizeof(double), hipMemcpyHostToDevice, s));
@@ -355,11 +405,12 @@ int egp_engine_step_async(egp_engine *E, int32_t group, const double *action, co
     Group &G = E->groups[group];
     std::lock_guard<std::mutex> lk(G.mu);
     if (G.pending != 0) { egp::set_error("group %d is still stepping", group); return EGP_E_STATE; }
+    if (G.status.load() != EGP_OK) { egp::set_error("group %d failed earlier: %s", group, G.err); return G.status.load(); }
     G.action = action;
     G.ready = (hipEvent_t)ready_event;
     G.has_active = active_host != nullptr;
     if (active_host) memcpy(G.active.data(), active_host, E->n_env * sizeof(int));
-    G.pending = (int)G.workers.size();
+    G.pending = G.n_threads;
     G.job += 1;
     G.cv_go.notify_all();
     return EGP_OK;
@@ -373,23 +424,25 @@ int egp_engine_wait(egp_engine *E, int32_t group, void *stream) {
         std::unique_lock<std::mutex> lk(G.mu);
         G.cv_done.wait(lk, [&] { return G.pending == 0; });
     }
-    for (int wi : G.workers) {
-        Worker &W = E->workers[wi];
-        if (W.status != EGP_OK) {
-            egp::set_error("rollout worker %d: %s", wi, W.err);
-            return W.status;
-        }
-        for (int h = 0; h < 2; ++h)
-            if (W.half[h].e1 > W.half[h].e0) EGP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, W.half[h].done, 0));
+    if (G.status.load() != EGP_OK) {
+        egp::set_error("rollout group %d: %s", group, G.err);
+        return G.status.load();
     }
+    EGP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, G.done, 0));
     return EGP_OK;
+}
+
+int64_t egp_engine_inertia_uploads(egp_engine *E) {
+    long n = 0;
+    if (E) for (auto &G : E->groups) n += G.qM_uploads;
+    return n;
 }
 
 int egp_engine_timing(egp_engine *E, double *phys_s, double *gpu_wait_s, double *k1_ms, int64_t *k1_launches) {
     EGP_REQUIRE(E, "engine is NULL");
     double p = 0, w = 0, k = 0;
     long l = 0;
-    for (auto &W : E->workers) { p += W.phys_s; w += W.wait_s; k += W.k1_ms; l += W.k1_launches; }
+    for (auto &G : E->groups) { p += G.phys_s; w += G.wait_s; k += G.k1_ms; l += G.k1_launches; }
     if (phys_s) *phys_s = p;
     if (gpu_wait_s) *gpu_wait_s = w;
     if (k1_ms) *k1_ms = k;
@@ -399,18 +452,11 @@ int egp_engine_timing(egp_engine *E, double *phys_s, double *gpu_wait_s, double 
 
 int egp_engine_set_profile(egp_engine *E, int on) {
     EGP_REQUIRE(E, "engine is NULL");
-    EGP_REQUIRE(!on || !E->workers.empty(), "no workers");
-    if (on && E->workers[0].half[0].k_beg.empty()) {
+    for (auto &G : E->groups) EGP_REQUIRE(G.pending == 0, "cannot switch profiling while a group is stepping");
+    if (on) {
         EGP_HIP_CHECK(hipSetDevice(E->ctx->device));
-        for (auto &W : E->workers)
-            for (int h = 0; h < 2; ++h) {
-                W.half[h].k_beg.resize(E->frame_skip);
-                W.half[h].k_end.resize(E->frame_skip);
-                for (int s = 0; s < E->frame_skip; ++s) {
-                    EGP_HIP_CHECK(hipEventCreate(&W.half[h].k_beg[s]));
-                    EGP_HIP_CHECK(hipEventCreate(&W.half[h].k_end[s]));
-                }
-            }
+        int rc = make_profile_events(E);
+        if (rc != EGP_OK) return rc;
     }
     E->profile_k1 = on != 0;
     return EGP_OK;
@@ -418,13 +464,13 @@ int egp_engine_set_profile(egp_engine *E, int on) {
 
 int egp_engine_reset_timing(egp_engine *E) {
     EGP_REQUIRE(E, "engine is NULL");
-    for (auto &W : E->workers) { W.phys_s = 0; W.wait_s = 0; W.k1_ms = 0; W.k1_launches = 0; }
+    for (auto &G : E->groups) { G.phys_s = 0; G.wait_s = 0; G.k1_ms = 0; G.k1_launches = 0; }
     return EGP_OK;
 }
 
 int egp_engine_layout(egp_engine *E, int32_t *pack_ld, int32_t *n_env, int32_t *n_threads, int32_t *n_groups) {
     EGP_REQUIRE(E, "engine is NULL");
-    if (pack_ld) *pack_ld = E->pack_ld;
+    if (pack_ld) *pack_ld = E->ld_s + E->ld_m;
     if (n_env) *n_env = E->n_env;
     if (n_threads) *n_threads = E->n_threads;
     if (n_groups) *n_groups = E->n_groups;
@@ -434,8 +480,8 @@ int egp_engine_layout(egp_engine *E, int32_t *pack_ld, int32_t *n_env, int32_t *
 int egp_engine_group_range(egp_engine *E, int32_t group, int32_t *e0, int32_t *e1) {
     EGP_REQUIRE(E && e0 && e1, "NULL pointer");
     EGP_REQUIRE(group >= 0 && group < E->n_groups, "group out of range");
-    *e0 = (int)((long)E->n_env * group / E->n_groups);
-    *e1 = (int)((long)E->n_env * (group + 1) / E->n_groups);
+    *e0 = E->groups[group].e0;
+    *e1 = E->groups[group].e1;
     return EGP_OK;
 }
 

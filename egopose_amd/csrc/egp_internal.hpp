@@ -68,7 +68,8 @@ struct egp_ctx {
 };
 
 // launches used by the engine (same TU as the kernels)
-int egp_launch_pd_torque_packed(egp_ctx *ctx, const double *pack, long pack_ld, int off_qpos, int off_qvel, int off_bias,
-                                int off_qM, const double *action, int32_t n, double *torque, hipStream_t stream);
+int egp_launch_pd_torque_strided(egp_ctx *ctx, const double *qpos, long ld_qpos, const double *qvel, long ld_qvel,
+                                 const double *bias, long ld_bias, const double *qM, long ld_qM, const double *action,
+                                 int32_t n, double *torque, hipStream_t stream);
 const egp_physics_vtable *egp_physics_vt(const egp_physics *p);
 extern "C" int32_t egp_physics_n_env(const egp_physics *p);

@@ -844,12 +844,12 @@ static int launch_pd(egp_ctx *ctx, const PdLd &ld, const T *qpos, const T *qvel,
 
 static inline PdLd dense_ld(const egp_ctx *c) { return PdLd{c->dm.nq, c->dm.nv, c->dm.nu, c->dm.nM, c->dm.nv}; }
 
-// engine entry: all five inputs live in one packed row per env (row stride `pack_ld` doubles)
-int egp_launch_pd_torque_packed(egp_ctx *ctx, const double *pack, long pack_ld, int off_qpos, int off_qvel, int off_bias,
-                                int off_qM, const double *action, int32_t n, double *torque, hipStream_t stream) {
-    PdLd ld{pack_ld, pack_ld, ctx->dm.nu, pack_ld, pack_ld};
-    return launch_pd<double>(ctx, ld, pack + off_qpos, pack + off_qvel, action, pack + off_qM, pack + off_bias, n, torque,
-                             nullptr, stream);
+// engine entry: inputs live in the engine's staging layouts (row strides in doubles)
+int egp_launch_pd_torque_strided(egp_ctx *ctx, const double *qpos, long ld_qpos, const double *qvel, long ld_qvel,
+                                 const double *bias, long ld_bias, const double *qM, long ld_qM, const double *action,
+                                 int32_t n, double *torque, hipStream_t stream) {
+    PdLd ld{ld_qpos, ld_qvel, ctx->dm.nu, ld_qM, ld_bias};
+    return launch_pd<double>(ctx, ld, qpos, qvel, action, qM, bias, n, torque, nullptr, stream);
 }
 
 template <typename T>

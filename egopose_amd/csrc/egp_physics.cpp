@@ -129,11 +129,12 @@ int sur_step(void *user, int32_t env, const double *ctrl) {
     double f[EGP_MAX_NV], acc[EGP_MAX_NV];
     for (int i = 0; i < 6; ++i) f[i] = -C[i];
     for (int i = 6; i < nv; ++i) f[i] = ctrl[i - 6] - C[i];
-    for (int i = 0; i < nv; ++i) {
-        const double *row = &S.Minv0[(size_t)i * nv];
-        double s = 0.0;
-        for (int j = 0; j < nv; ++j) s += row[j] * f[j];
-        acc[i] = s;
+    // acc = Minv0 * f as nv axpys over contiguous rows (Minv0 is symmetric): vectorises without reassociation
+    for (int i = 0; i < nv; ++i) acc[i] = 0.0;
+    for (int j = 0; j < nv; ++j) {
+        const double *__restrict row = &S.Minv0[(size_t)j * nv];
+        const double fj = f[j];
+        for (int i = 0; i < nv; ++i) acc[i] += row[i] * fj;
     }
     for (int i = 0; i < nv; ++i) v[i] += S.dt * acc[i];
     for (int k = 0; k < 3; ++k) q[k] += S.dt * v[k];
@@ -162,6 +163,8 @@ int sur_drain(void *user, int32_t env, double *qpos, double *qvel, double *qM, d
     if (xpos) forward_kinematics(S, &S.qpos[(size_t)env * S.nq], xpos);
     return EGP_OK;
 }
+
+int64_t sur_epoch(void *, int32_t) { return 1; }   // M0 never changes
 
 void sur_destroy(void *user) { delete (Surrogate *)user; }
 
@@ -206,6 +209,7 @@ int egp_physics_create_surrogate(const egp_surrogate_desc *d, int32_t n_env, egp
     egp_physics_vtable vt{};
     vt.user = S; vt.reset = sur_reset; vt.step = sur_step; vt.drain = sur_drain; vt.destroy = sur_destroy;
     vt.name = "surrogate-euler-M0";
+    vt.inertia_epoch = sur_epoch;
     egp_physics *p = new egp_physics();
     p->vt = vt; p->n_env = n_env; p->owns_user = true;
     *out = p;

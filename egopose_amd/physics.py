@@ -86,13 +86,32 @@ class SurrogatePhysics:
             pass
 
 
-def default_threads():
+def available_cpus():
+    """CPUs this process may actually use: min(affinity mask, cgroup CPU quota)."""
     n = os.cpu_count() or 1
     try:
         n = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    return max(1, min(n, 32))
+    try:                                              # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:                                          # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
+def default_threads(share=1):
+    """Engine threads spin at barriers inside the substep loop: never oversubscribe the CPU budget and
+    leave room for the Python driver thread. ``share`` = processes splitting this host (ranks per node)."""
+    return max(1, min(available_cpus() // max(1, share) - 2, 64))
 
 
 class RolloutEngine:
@@ -157,6 +176,9 @@ class RolloutEngine:
 
     def reset_timing(self):
         L.check(self.lib.egp_engine_reset_timing(self.handle), "egp_engine_reset_timing")
+
+    def inertia_uploads(self):
+        return int(self.lib.egp_engine_inertia_uploads(self.handle))
 
     def timing(self):
         p, w, k = C.c_double(), C.c_double(), C.c_double()

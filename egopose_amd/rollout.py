@@ -71,15 +71,42 @@ class LockstepRollout:
         self.rings = [_PinnedRing(5, b - a, self.dev) for a, b in self.groups]
         self.timing = {}
         self._events = [None] * len(self.groups)
+        self.pool_batch = max(256, self.N // 2)
+        self._pool, self._pool_pos = None, 0
 
     # ------------------------------------------------------------------ helpers
     def _net_dtype(self):
         return next(self.policy_net.parameters()).dtype
 
+    def _draw_episodes(self, n):
+        """Next n (take, start frame) pairs of the reset-sampling stream + their policy video context
+        (bi-LSTM over [start-m, start+T+m)), computed ahead in large batches: one fused LSTM call per
+        ``pool_batch`` episodes instead of one launch-bound sweep per tick with resets."""
+        out_e, out_s, out_c = [], [], []
+        need = n
+        while need > 0:
+            if self._pool is None or self._pool_pos >= len(self._pool[0]):
+                m = max(need, self.pool_batch)
+                e_ind, s_ind = self.env.sample_reset(m)
+                e_d = torch.as_tensor(e_ind, device=self.dev)
+                s_d = torch.as_tensor(s_ind, device=self.dev)
+                win = self.policy_vs_net.window_features(e_d, s_d, self.T_ep)
+                ctx = self.policy_vs_net.forward_v_net(win)[self.margin:-self.margin].transpose(0, 1).contiguous()   # (m, T, H)
+                self._pool, self._pool_pos = (e_ind, s_ind, ctx), 0
+            e_ind, s_ind, ctx = self._pool
+            k = min(need, len(e_ind) - self._pool_pos)
+            sl = slice(self._pool_pos, self._pool_pos + k)
+            out_e.append(e_ind[sl]); out_s.append(s_ind[sl]); out_c.append(ctx[sl])
+            self._pool_pos += k
+            need -= k
+        if len(out_e) == 1:
+            return out_e[0], out_s[0], out_c[0]
+        return np.concatenate(out_e), np.concatenate(out_s), torch.cat(out_c, 0)
+
     def _reset_slots(self, ids):
         """reset_model for the given slots (sorted ids): sample take/start frame, set physics state."""
         cfg, ex = self.cfg, self.experts
-        e_ind, s_ind = self.env.sample_reset(len(ids))
+        e_ind, s_ind, ctx_rows = self._draw_episodes(len(ids))
         rows = ex.take_offset[e_ind] + s_ind
         qpos = ex.qpos[rows].copy()
         qvel = ex.qvel[rows].copy()
@@ -89,12 +116,7 @@ class LockstepRollout:
         self.e_ind[ids], self.s_ind[ids] = e_ind, s_ind
         self.frame_base[ids] = rows
         self.cur_t[ids] = 0
-        # policy video context of the new episodes: bi-LSTM over [start-m, start+T+m)
-        e_d = torch.as_tensor(e_ind, device=self.dev)
-        s_d = torch.as_tensor(s_ind, device=self.dev)
-        win = self.policy_vs_net.window_features(e_d, s_d, self.T_ep)
-        out = self.policy_vs_net.forward_v_net(win)[self.margin:-self.margin]      # (T, n, H)
-        self.v_out[torch.as_tensor(ids, device=self.dev)] = out.transpose(0, 1)
+        self.v_out[torch.as_tensor(ids, device=self.dev)] = ctx_rows
 
     def _filter(self, obs, active_dev):
         if self.zf_state is None:
@@ -115,6 +137,7 @@ class LockstepRollout:
         T_max = quota + T_ep
         H = self.policy_vs_net.v_hdim
         self.policy_vs_net.attach_feature_table(self.experts.cnn_table(dev, ndt), self.experts.cnn_offset)
+        self._pool, self._pool_pos = None, 0          # contexts depend on this iteration's weights
         od, nu = ctx.obs_dim, ctx.nu
         f64 = torch.float64
         rec = dict(

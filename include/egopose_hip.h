@@ -185,7 +185,7 @@ int egp_gae_standardize_f32(float *adv, int32_t n, const double *stats, void *st
  * env at a time; all buffers are HOST memory owned by the engine.
  *   reset(user, env, qpos[nq], qvel[nv])                      set_state + forward
  *   step (user, env, ctrl[nu])                                data.ctrl = ctrl; mj_step
- *   drain(user, env, qpos, qvel, qM[nM], qfrc_bias[nv], xpos[nbody*3])   copy out mjData fields
+ *   drain(user, env, qpos, qvel, qM[nM], qfrc_bias[nv], xpos[nbody*3])   copy out mjData fields (qM / xpos may be NULL)
  * A MuJoCo adapter fills this from mj_step / mjData; the built-in surrogate is egp_physics_create_surrogate. */
 typedef struct egp_physics_vtable {
     void *user;
@@ -195,6 +195,11 @@ typedef struct egp_physics_vtable {
                  double *xpos);
     void (*destroy)(void *user);
     const char *name;
+    /* optional (may be NULL): a counter that changes whenever env's qM changed since it was last drained.
+     * The engine re-uploads an env group's inertia rows only when some epoch in the group moved; a MuJoCo
+     * adapter returns a per-step counter (M depends on qpos), the surrogate a constant (its M0 is fixed).
+     * `drain` is then called with qM == NULL for unchanged envs. */
+    int64_t (*inertia_epoch)(void *user, int32_t env);
 } egp_physics_vtable;
 
 int egp_physics_register(const egp_physics_vtable *vt, int32_t n_env, egp_physics **out);
@@ -257,6 +262,7 @@ int egp_engine_wait(egp_engine *e, int32_t group, void *stream);
  * streams + number of K1 launches */
 int egp_engine_timing(egp_engine *e, double *phys_s, double *gpu_wait_s, double *k1_ms_events, int64_t *k1_launches);
 int egp_engine_reset_timing(egp_engine *e);
+int64_t egp_engine_inertia_uploads(egp_engine *e);   /* group-level qM uploads done inside step (not resets) */
 int egp_engine_set_profile(egp_engine *e, int on);   /* record HIP events around every K1 launch */
 int egp_engine_layout(egp_engine *e, int32_t *pack_ld, int32_t *n_env, int32_t *n_threads, int32_t *n_groups);
 int egp_engine_group_range(egp_engine *e, int32_t group, int32_t *env_begin, int32_t *env_end);
