@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--envs", type=int, default=1024, help="env slots per GPU")
     ap.add_argument("--threads", type=int, default=0, help="host physics threads per GPU (0 = auto)")
-    ap.add_argument("--groups", type=int, default=4)
+    ap.add_argument("--groups", type=int, default=2)
     ap.add_argument("--min-batch", type=int, default=0, help="env-steps per GPU per iteration (0 = config: 50000)")
     ap.add_argument("--cfg", default="subject_03")
     ap.add_argument("--cpu-steps", type=int, default=3000)
@@ -135,7 +135,7 @@ def main():
             achieved = K1_BYTES_PER_ENV * envs_per_launch / avg_s
             res["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "k_pd_torque_reg58<double>",
-                               "avg_launch_us": avg_s * 1e6, "launches": tim["k1_launches"], "envs_per_launch": envs_per_launch,
+                               "avg_launch_us": avg_s * 1e6, "event_pair_overhead_us_subtracted": tim["event_overhead_us"], "launches": tim["k1_launches"], "envs_per_launch": envs_per_launch,
                                "alg_bytes_per_env_substep": K1_BYTES_PER_ENV}
         else:
             res["roofline"] = None

@@ -84,7 +84,7 @@ struct Group {
     std::atomic<int> qM_dirty{0};             // some env of the group drained a new inertia this substep
     char err[256] = "";
     // timing (leader only)
-    double phys_s = 0.0, wait_s = 0.0, k1_ms = 0.0;
+    double phys_s = 0.0, wait_s = 0.0, k1_ms = 0.0, ev_overhead_ms = 0.0;
     long k1_launches = 0, qM_uploads = 0;
     std::vector<std::thread> threads;
 };
@@ -219,7 +219,7 @@ void run_step(egp_engine *E, Group &G, int tid) {
         for (int s = 0; s < FS; ++s) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, G.k_beg[s], G.k_end[s]) == hipSuccess) {
-                G.k1_ms += ms;
+                G.k1_ms += ms > G.ev_overhead_ms ? ms - G.ev_overhead_ms : 0.0;
                 G.k1_launches += 1;
             }
         }
@@ -254,6 +254,18 @@ int make_profile_events(egp_engine *E) {
             EGP_HIP_CHECK(hipEventCreate(&G.k_beg[s]));
             EGP_HIP_CHECK(hipEventCreate(&G.k_end[s]));
         }
+        // calibrate the cost of an empty begin/end event pair on this stream (subtracted from each K1 bracket)
+        double acc = 0.0;
+        const int reps = 32;
+        for (int r = 0; r < reps; ++r) {
+            EGP_HIP_CHECK(hipEventRecord(G.k_beg[0], G.stream));
+            EGP_HIP_CHECK(hipEventRecord(G.k_end[0], G.stream));
+            EGP_HIP_CHECK(hipStreamSynchronize(G.stream));
+            float ms = 0.f;
+            EGP_HIP_CHECK(hipEventElapsedTime(&ms, G.k_beg[0], G.k_end[0]));
+            acc += ms;
+        }
+        G.ev_overhead_ms = acc / reps;
     }
     return EGP_OK;
 }
@@ -430,6 +442,12 @@ int egp_engine_wait(egp_engine *E, int32_t group, void *stream) {
     }
     EGP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, G.done, 0));
     return EGP_OK;
+}
+
+double egp_engine_event_overhead_ms(egp_engine *E) {
+    double a = 0.0;
+    if (E && !E->groups.empty()) { for (auto &G : E->groups) a += G.ev_overhead_ms; a /= E->groups.size(); }
+    return a;
 }
 
 int64_t egp_engine_inertia_uploads(egp_engine *E) {

@@ -40,6 +40,14 @@ def global_count(n_local, device):
     return int(round(t.item()))
 
 
+def global_max(value, device="cpu"):
+    if not is_on():
+        return int(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_comm_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(round(t.item()))
+
+
 def chan_merge(parts):
     """Merge rows of (n, mean, M2) -- mean/M2 may be vectors -- in row order."""
     n, mean, m2 = 0.0, None, None

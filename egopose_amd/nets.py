@@ -19,6 +19,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import dist as _dist
+
 _ACT = {"tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid}
 
 
@@ -237,7 +239,9 @@ class VideoStateNet(nn.Module):
         n = masks.shape[0]
         starts = np.concatenate(([0], ends[:-1] + 1))
         lens = ends - starts + 1
-        max_len = int(lens.max())
+        # the padded window length is a batch-wide quantity in the reference (one process, one batch):
+        # keep it global when the batch is sharded over ranks
+        max_len = _dist.global_max(int(lens.max()), device)
         idx = np.arange(n)
         ep_of = np.repeat(np.arange(len(ends)), lens)
         covered = int(ends[-1]) + 1

@@ -184,7 +184,8 @@ class RolloutEngine:
         p, w, k = C.c_double(), C.c_double(), C.c_double()
         n = C.c_int64()
         L.check(self.lib.egp_engine_timing(self.handle, C.byref(p), C.byref(w), C.byref(k), C.byref(n)), "egp_engine_timing")
-        return dict(phys_s=p.value, gpu_wait_s=w.value, k1_ms=k.value, k1_launches=n.value)
+        return dict(phys_s=p.value, gpu_wait_s=w.value, k1_ms=k.value, k1_launches=n.value,
+                    event_overhead_us=float(self.lib.egp_engine_event_overhead_ms(self.handle)) * 1e3)
 
     def close(self):
         if getattr(self, "handle", None):

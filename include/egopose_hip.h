@@ -259,10 +259,11 @@ int egp_engine_step_async(egp_engine *e, int32_t group, const double *action, co
 int egp_engine_wait(egp_engine *e, int32_t group, void *stream);
 /* accumulated since creation / egp_engine_reset_timing, summed over workers: host physics seconds,
  * seconds blocked on the GPU round trip, and (when profiling) K1 time by HIP events on the launch
- * streams + number of K1 launches */
+ * streams (empty-bracket overhead subtracted) + number of K1 launches */
 int egp_engine_timing(egp_engine *e, double *phys_s, double *gpu_wait_s, double *k1_ms_events, int64_t *k1_launches);
 int egp_engine_reset_timing(egp_engine *e);
-int64_t egp_engine_inertia_uploads(egp_engine *e);   /* group-level qM uploads done inside step (not resets) */
+int64_t egp_engine_inertia_uploads(egp_engine *e);
+double egp_engine_event_overhead_ms(egp_engine *e);   /* calibrated cost of an empty begin/end event pair, already subtracted from k1_ms_events */   /* group-level qM uploads done inside step (not resets) */
 int egp_engine_set_profile(egp_engine *e, int on);   /* record HIP events around every K1 launch */
 int egp_engine_layout(egp_engine *e, int32_t *pack_ld, int32_t *n_env, int32_t *n_threads, int32_t *n_groups);
 int egp_engine_group_range(egp_engine *e, int32_t group, int32_t *env_begin, int32_t *env_end);

@@ -1,0 +1,195 @@
+"""Host-side logic on CPU: Config vs the reference's parsed arrays, the compat import surface the unmodified
+driver needs, ZFilter host object vs golden, synthetic motion generator, and the oracle CPU sampler
+(cpu_baseline leg) end to end on a tiny dataset."""
+import os
+import pickle
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import REPO, load_golden
+
+
+def _workspace(tmp_path, skel, n_takes=2, n_frames=90):
+    """A tiny dataset in the reference's formats built with ORACLE math (no GPU here)."""
+    from egopose_amd.config import _ASSET_CFG
+    from egopose_amd.physics import SurrogatePhysics
+    from egopose_amd.synthetic import synth_qpos_sequence
+    from oracle import humanoid as H, quat as Q
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "config", "egomimic"))
+    os.makedirs(os.path.join(root, "datasets", "meta"))
+    os.makedirs(os.path.join(root, "datasets", "features"))
+    import shutil
+    shutil.copy(os.path.join(_ASSET_CFG, "subject_03.yml"), os.path.join(root, "config", "egomimic", "subject_03.yml"))
+    rng = np.random.RandomState(3)
+    ph = SurrogatePhysics(skel, 1)
+    dt = skel.timestep * 15
+    experts, feats, names = {}, {}, ["t%d" % i for i in range(n_takes)]
+    for name in names:
+        q = synth_qpos_sequence(skel, rng, n_frames)
+        xpos = []
+        for row in q:
+            ph.reset(0, row, np.zeros(58))
+            xpos.append(ph.drain(0)[4])
+        xpos = np.stack(xpos)
+        bq = H.body_quat(q, skel.body_qpos_start, skel.body_ndof)
+        qv = H.qvel_fd(q[:-1], q[1:], dt)
+        qv = np.vstack([qv[:1], qv])
+        experts[name] = dict(
+            qpos=q, qvel=qv, rlinv_local=np.vstack([Q.transform_vec(qv[1:2, :3], q[1:2, 3:7], "heading"), Q.transform_vec(qv[1:, :3], q[1:, 3:7], "heading")]),
+            rangv=qv[:, 3:6].copy(), rq_rmh=Q.de_heading(q[:, 3:7]), ee_pos=H.ee_pos(q, xpos[:, skel.ee_body].reshape(len(q), 15)),
+            bquat=bq, bangvel=np.vstack([H.angvel_fd(bq[:1], bq[1:2], dt), H.angvel_fd(bq[:-1], bq[1:], dt)]),
+            head_pos=xpos[:, 6], len=len(q), height_lb=q[:, 2].min(), head_height_lb=xpos[:, 6, 2].min())
+        feats[name] = rng.normal(size=(n_frames, 16))
+    ph.close()
+    yaml.safe_dump({"train": names, "test": names[:1]}, open(os.path.join(root, "datasets", "meta", "meta_subject_03.yml"), "w"))
+    pickle.dump(experts, open(os.path.join(root, "datasets", "features", "expert_subject_03.p"), "wb"))
+    pickle.dump((feats, {}), open(os.path.join(root, "datasets", "features", "cnn_feat_subject_03.p"), "wb"))
+    return root
+
+
+def test_config_matches_reference_parse(tmp_path, skel, monkeypatch):
+    from egopose_amd.config import Config
+    root = _workspace(tmp_path, skel)
+    monkeypatch.chdir(root)
+    cfg = Config("subject_03", create_dirs=True)
+    g = load_golden("config_subject_03.npz")
+    for k in ("jkp", "jkd", "a_ref", "a_scale", "torque_lim", "b_diffw"):
+        np.testing.assert_array_equal(getattr(cfg, k), g[k])
+    for k in ("gamma", "tau", "clip_epsilon", "log_std", "min_batch_size", "num_optim_epoch", "env_episode_len", "fr_margin",
+              "policy_lr", "value_lr", "policy_v_hdim"):
+        assert getattr(cfg, k) == g[k]
+    assert bool(cfg.fix_std) == bool(g["fix_std"]) and list(cfg.policy_hsize) == list(g["policy_hsize"])
+    cfg.update_adaptive_params(0)
+    assert (cfg.adp_noise_rate, cfg.adp_log_std, cfg.adp_policy_lr) == (float(g["adp_noise_rate"]), float(g["adp_log_std"]), float(g["adp_policy_lr"]))
+    ws = dict(zip([str(x) for x in g["reward_keys"]], g["reward_vals"]))
+    assert {k: float(v) for k, v in cfg.reward_weights.items()} == {k: float(v) for k, v in ws.items()}
+    assert cfg.model_dir == "results/egomimic/subject_03/models" and os.path.isdir(cfg.log_dir)
+    assert cfg.expert_feat_file == "datasets/features/expert_subject_03.p" and cfg.takes["train"] == ["t0", "t1"]
+    # piecewise-linear schedules (egomimic_config.py:124-131)
+    cfg2 = Config("x", cfg_dict=dict(meta_id="meta_subject_03", mujoco_model="m", vis_model="v", adp_iter_cp=[0, 10, 30],
+                                     adp_noise_rate_cp=[1.0, 0.5], adp_log_std_cp=[-2.0, -3.0, -4.0]))
+    cfg2.update_adaptive_params(5)
+    assert cfg2.adp_noise_rate == pytest.approx(0.75) and cfg2.adp_log_std == pytest.approx(-2.5)
+    cfg2.update_adaptive_params(40)
+    assert cfg2.adp_noise_rate == pytest.approx(0.5) and cfg2.adp_log_std == pytest.approx(-4.0)
+    with pytest.raises(SystemExit):
+        Config("does_not_exist")
+
+
+def test_compat_packages_expose_the_driver_surface(tmp_path, skel):
+    """What ego_pose/ego_mimic.py:8-16,29-99 imports and calls, resolved through egopose_amd/compat."""
+    root = _workspace(tmp_path, skel)
+    code = r'''
+import os, sys
+from utils import *
+from core.policy_gaussian import PolicyGaussian
+from core.critic import Value
+from models.mlp import MLP
+from models.video_state_net import VideoStateNet
+from ego_pose.envs.humanoid_v1 import HumanoidEnv
+from ego_pose.core.agent_ego import AgentEgo
+from ego_pose.utils.egomimic_config import Config
+from ego_pose.core.reward_function import reward_func
+cfg = Config("subject_03", create_dirs=True)
+dtype = torch.float64
+torch.set_default_dtype(dtype)
+device = torch.device("cpu")
+np.random.seed(cfg.seed); torch.manual_seed(cfg.seed)
+tb_logger = Logger(cfg.tb_dir)
+logger = create_logger(os.path.join(cfg.log_dir, "log.txt"), file_handle=True)
+env = HumanoidEnv(cfg)
+env.seed(cfg.seed)
+env.load_experts(cfg.takes["train"], cfg.expert_feat_file, cfg.cnn_feat_file)
+cnn_feat_dim = env.cnn_feat[0].shape[-1]
+assert len(env.model.actuator_names) == 52
+state_dim, action_dim = env.observation_space.shape[0], env.action_space.shape[0]
+assert (state_dim, action_dim) == (115, 52)
+running_state = ZFilter((state_dim,), clip=5)
+policy_vs_net = VideoStateNet(cnn_feat_dim, cfg.policy_v_hdim, cfg.fr_margin, cfg.policy_v_net, cfg.policy_v_net_param, cfg.causal)
+value_vs_net = VideoStateNet(cnn_feat_dim, cfg.value_v_hdim, cfg.fr_margin, cfg.value_v_net, cfg.value_v_net_param, cfg.causal)
+policy_net = PolicyGaussian(MLP(state_dim + cfg.policy_v_hdim, cfg.policy_hsize, cfg.policy_htype), action_dim, log_std=cfg.log_std, fix_std=cfg.fix_std)
+value_net = Value(MLP(state_dim + cfg.value_v_hdim, cfg.value_hsize, cfg.value_htype))
+to_device(device, policy_net, value_net, policy_vs_net, value_vs_net)
+policy_params = list(policy_net.parameters()) + list(policy_vs_net.parameters())
+value_params = list(value_net.parameters()) + list(value_vs_net.parameters())
+optimizer_policy = torch.optim.Adam(policy_params, lr=cfg.policy_lr, weight_decay=cfg.policy_weightdecay)
+optimizer_value = torch.optim.Adam(value_params, lr=cfg.value_lr, weight_decay=cfg.value_weightdecay)
+agent = AgentEgo(env=env, dtype=dtype, device=device, running_state=running_state, custom_reward=reward_func[cfg.reward_id],
+                 mean_action=False, render=False, num_threads=2, policy_net=policy_net, policy_vs_net=policy_vs_net,
+                 value_net=value_net, value_vs_net=value_vs_net, optimizer_policy=optimizer_policy, optimizer_value=optimizer_value,
+                 opt_num_epochs=cfg.num_optim_epoch, gamma=cfg.gamma, tau=cfg.tau, clip_epsilon=cfg.clip_epsilon,
+                 policy_grad_clip=[(policy_params, 40)])
+cfg.update_adaptive_params(0)
+agent.set_noise_rate(cfg.adp_noise_rate)
+set_optimizer_lr(optimizer_policy, cfg.adp_policy_lr)
+policy_net.action_log_std.fill_(cfg.adp_log_std)
+tb_logger.scalar_summary("total_reward", 0.5, 0)
+with to_cpu(policy_net, value_net):
+    sd = policy_net.state_dict()
+assert "net.affine_layers.0.weight" in sd and "action_log_std" in sd
+try:
+    agent.sample(100)                      # no MI355X here: the product path must refuse, loudly
+except RuntimeError as e:
+    assert "no CPU fallback" in str(e)
+else:
+    raise SystemExit("sampling on CPU must fail")
+print("DRIVER_SURFACE_OK")
+'''
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.path.join(REPO, "egopose_amd", "compat"))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "DRIVER_SURFACE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    assert os.path.exists(os.path.join(root, "results/egomimic/subject_03/tb/scalars.jsonl"))
+
+
+def test_zfilter_host_object_and_device_bridge():
+    from egopose_amd.zfilter import ZFilter
+    g = load_golden("zfilter.npz")
+    zf = ZFilter((115,), clip=5)
+    Y = np.stack([zf(x) for x in g["X"]])
+    np.testing.assert_allclose(Y, g["Y"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(zf.rs.std, g["std"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(np.stack([zf(x, update=False) for x in g["X"][:16]]), g["Yfrozen"], rtol=1e-11, atol=1e-11)
+    st = zf.to_device_state("cpu")
+    assert st.shape == (231,) and st[0] == 300
+    z2 = ZFilter((115,), clip=5)
+    z2.from_device_state(st)
+    np.testing.assert_array_equal(z2.rs.mean, zf.rs.mean)
+    z3 = pickle.loads(pickle.dumps(zf))               # checkpoints carry the filter object
+    np.testing.assert_array_equal(z3.rs.std, zf.rs.std)
+    with pytest.raises(AssertionError):
+        zf.rs.push(np.zeros(3))
+
+
+def test_synthetic_motion_is_smooth_and_in_range(skel):
+    from egopose_amd.synthetic import synth_qpos_sequence
+    q = synth_qpos_sequence(skel, np.random.RandomState(0), 120)
+    assert q.shape == (120, 59)
+    np.testing.assert_allclose(np.linalg.norm(q[:, 3:7], axis=1), 1.0, atol=1e-12)
+    assert (q[:, 7:] >= skel.joint_range[:, 0] - 1e-12).all() and (q[:, 7:] <= skel.joint_range[:, 1] + 1e-12).all()
+    assert np.abs(np.diff(q[:, 7:], axis=0)).max() < 0.2 and (q[:, 32:35] == 0).all() and (q[:, 42:45] == 0).all()
+
+
+def test_oracle_cpu_sampler_runs_the_reference_structure(tmp_path, skel):
+    """bench.py's cpu_baseline leg: 2 forked workers, batch-1 float64 policy, numpy PD/reward, surrogate physics."""
+    root = _workspace(tmp_path, skel, n_takes=2, n_frames=80)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    # shrink the episode so the test takes seconds: patch the YAML copy
+    p = os.path.join(root, "config", "egomimic", "subject_03.yml")
+    cfg = yaml.safe_load(open(p))
+    cfg["env_episode_len"] = 8
+    cfg["fr_margin"] = 2
+    yaml.safe_dump(cfg, open(p, "w"))
+    out = subprocess.run([sys.executable, "-m", "oracle.cpu_env", "--dataset", root, "--threads", "2", "--steps", "30"],
+                         cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    import json
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["env_steps"] >= 30 and r["threads"] == 2 and r["episodes"] >= 4 and 0 < r["avg_c_reward"] < 5
+    assert r["physics"].startswith("surrogate")
