@@ -64,6 +64,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    local = local % max(1, torch.cuda.device_count())     # (several ranks may share a device in the gloo self-test)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -175,9 +175,10 @@ def init_from_env(device_index=None):
         return 0, 1, int(os.environ.get("LOCAL_RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not is_on():
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local if device_index is None else device_index)
+        backend = os.environ.get("EGP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            n_dev = max(1, torch.cuda.device_count())
+            torch.cuda.set_device((local if device_index is None else device_index) % n_dev)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend)
     return dist.get_rank(), dist.get_world_size(), local

@@ -58,18 +58,37 @@ def ee_pos(qpos, ee_wpos, transform="heading"):
     return out.reshape(qpos.shape[0], -1)
 
 
+_SPARSE_INDEX = {}
+
+
+def _sparse_index(dof_parentid, dof_Madr):
+    """(rows, cols) of every qM entry: dof i's chain i, parent(i), ... starts at dof_Madr[i]."""
+    key = (np.asarray(dof_parentid).tobytes(), np.asarray(dof_Madr).tobytes())
+    if key not in _SPARSE_INDEX:
+        rows, cols = [], []
+        for i in range(len(dof_parentid)):
+            adr, j = int(dof_Madr[i]), i
+            while j >= 0:
+                assert adr == len(rows), "dof_Madr is not the cumulative chain length"
+                rows.append(i)
+                cols.append(j)
+                adr += 1
+                j = int(dof_parentid[j])
+        _SPARSE_INDEX[key] = (np.array(rows), np.array(cols))
+    return _SPARSE_INDEX[key]
+
+
 def full_from_sparse(qM, dof_parentid, dof_Madr):
-    """mj_fullM: MuJoCo legacy sparse inertia (B,nM) -> dense symmetric (B,nv,nv)."""
+    """mj_fullM: MuJoCo legacy sparse inertia (B,nM) -> dense symmetric (B,nv,nv).
+
+    (The reference calls MuJoCo's C routine; the index walk is done once and cached so this port's
+    per-call cost is a scatter, not a Python loop.)"""
     qM = np.atleast_2d(np.asarray(qM, float))
+    rows, cols = _sparse_index(dof_parentid, dof_Madr)
     nv = len(dof_parentid)
     M = np.zeros((qM.shape[0], nv, nv))
-    for i in range(nv):
-        adr, j = int(dof_Madr[i]), i
-        while j >= 0:
-            M[:, i, j] = qM[:, adr]
-            M[:, j, i] = qM[:, adr]
-            adr += 1
-            j = int(dof_parentid[j])
+    M[:, rows, cols] = qM
+    M[:, cols, rows] = qM
     return M
 
 
