@@ -134,8 +134,16 @@ def main():
             avg_s = tim["k1_ms"] * 1e-3 / tim["k1_launches"]
             envs_per_launch = args.envs / float(args.groups)
             achieved = K1_BYTES_PER_ENV * envs_per_launch / avg_s
+            traffic, traffic_src = None, None
+            try:      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
+                pm = json.load(open(os.path.join(REPO, "profiles", "pmc_k1_traffic.json")))
+                traffic = pm["hbm_bytes_per_env_substep"] * envs_per_launch
+                traffic_src = pm["source"] + "; " + pm["correction"]
+            except Exception:
+                pass
             res["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "k_pd_torque_reg58<double>",
+                               "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes per launch",
+                               "traffic_source": traffic_src, "kernel": "k_pd_torque_reg58<double>",
                                "avg_launch_us": avg_s * 1e6, "event_pair_overhead_us_subtracted": tim["event_overhead_us"], "launches": tim["k1_launches"], "envs_per_launch": envs_per_launch,
                                "alg_bytes_per_env_substep": K1_BYTES_PER_ENV}
         else:
