@@ -64,7 +64,8 @@ struct egp_ctx {
     int n_takes = 0, n_frames = 0;
     double *expert_rows_f64 = nullptr; // [n_frames][EGP_EXPERT_ROW]
     float *expert_rows_f32 = nullptr;
-    int pd_variant = 0;                // 0 = register Gauss-Jordan (nv==58), 1 = generic LDS kernel
+    int pd_variant = 0;                // 0 = tree-ordered in-register elimination, 2 = dense in-register, 1 = LDS
+    bool tree58 = false;               // runtime dof tree == compiled-in humanoid tree
 };
 
 // launches used by the engine (same TU as the kernels)

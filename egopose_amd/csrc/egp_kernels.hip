@@ -188,6 +188,79 @@ __global__ __launch_bounds__(256) void k_pd_torque_reg58(DevModel m, PdLd ld, co
     pd_store<TIO>(m, env, row, lane < PD_NV, kp, kd, eq, qv, qacc, torque, torque_raw);
 }
 
+// Tree-ordered fast path (default for the humanoid): same lane-owns-row layout, but the dofs are eliminated
+// leaves -> root (descending index). When dof k is the pivot, every descendant column of row k has already
+// been zeroed, so row k is non-zero only on k's ANCESTOR columns: a pivot step updates |anc(k)| columns
+// instead of all remaining ones (852 + 58 row updates instead of 1711 + 58; MuJoCo's L^T D L sparsity,
+// no fill-in). The ancestor chains are compile-time tables (egp_tree58.inc, generated from the skeleton asset),
+// so every register index stays static; egp_create checks the runtime dof tree against them.
+#include <utility>
+#include "egp_tree58.inc"
+
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);          // v_rcp_f64 + two Newton steps: <= 1 ulp for normal x
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+
+template <int K, int... T>
+__device__ __forceinline__ void tree_pivot_update(double (&a)[PD_NV], double f, std::integer_sequence<int, T...>) {
+    if constexpr (sizeof...(T) > 0) {
+        // all broadcasts first (v_readlane -> SGPR pairs), then the FMAs: no SGPR-hazard nops in between
+        const double r[sizeof...(T)] = {readlane_f64(a[Tree58::ANC[K][T]], K)...};
+        ((a[Tree58::ANC[K][T]] = fma(-f, r[T], a[Tree58::ANC[K][T]])), ...);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void tree_eliminate(double (&a)[PD_NV], double &b, double &dinv, int row) {
+    const double pk = readlane_f64(a[K], K);
+    const double inv = fast_rcp(pk);
+    const bool me = row == K;
+    const double f = me ? 0.0 : a[K] * inv;
+    dinv = me ? inv : dinv;
+    tree_pivot_update<K>(a, f, std::make_integer_sequence<int, Tree58::NANC[K]>{});
+    const double bk = readlane_f64(b, K);
+    b = fma(-f, bk, b);
+    if constexpr (K > 0) tree_eliminate<K - 1>(a, b, dinv, row);
+}
+
+template <typename TIO>
+__global__ __launch_bounds__(256) void k_pd_torque_tree58(DevModel m, PdLd ld, const TIO *__restrict__ qpos,
+                                                          const TIO *__restrict__ qvel, const TIO *__restrict__ action,
+                                                          const TIO *__restrict__ qM, const TIO *__restrict__ C, int n,
+                                                          TIO *__restrict__ torque, TIO *__restrict__ torque_raw) {
+    __shared__ short s_map[PD_NV * PD_NV];
+    __shared__ double s_qM[4][PD_NM_MAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < PD_NV * PD_NV; i += 256) s_map[i] = m.m_map[i];
+    const long env = (long)blockIdx.x * 4 + wave;
+    const bool valid = env < n;
+    if (valid) {
+        const TIO *src = qM + env * ld.qM;
+        for (int i = lane; i < m.nM; i += 64) s_qM[wave][i] = (double)src[i];
+    }
+    __syncthreads();
+    if (!valid) return;
+    const int row = lane < PD_NV ? lane : PD_NV - 1;
+    double kp, kd, eq, qv, b;
+    pd_rhs<TIO>(m, ld, qpos, qvel, action, C, env, row, kp, kd, eq, qv, b);
+    const double kd_dt = kd * m.sub_dt;
+    double a[PD_NV];
+#pragma unroll
+    for (int j = 0; j < PD_NV; ++j) {
+        const int id = s_map[row * PD_NV + j];
+        double v = id >= 0 ? s_qM[wave][id] : 0.0;
+        a[j] = v + (j == row ? kd_dt : 0.0);
+    }
+    double dinv = 0.0;
+    tree_eliminate<PD_NV - 1>(a, b, dinv, row);
+    const double qacc = b * dinv;
+    pd_store<TIO>(m, env, row, lane < PD_NV, kp, kd, eq, qv, qacc, torque, torque_raw);
+}
+
 // Generic path (any nv <= 64): one wavefront per env, system in LDS.
 template <typename TIO>
 __global__ __launch_bounds__(64) void k_pd_torque_lds(DevModel m, PdLd ld, const TIO *__restrict__ qpos,
@@ -736,8 +809,17 @@ int egp_create(const egp_model_desc *d, int device, egp_ctx **out) {
     EGP_TRY(dev_copy<double>(ctx, d->torque_lim, d->nu, &m.torque_lim));
     EGP_TRY(dev_copy<double>(ctx, d->b_diffw, d->nbody - 1, &m.b_diffw));
 #undef EGP_TRY
+    // fast paths: 0 = tree-ordered elimination (needs the compiled-in humanoid dof tree), 2 = dense in-register
+    // Gauss-Jordan (any tree with nv == 58), 1 = generic LDS kernel
+    bool tree_ok = d->nv == Tree58::NV;
+    for (int i = 0; tree_ok && i < d->nv; ++i) tree_ok = d->dof_parentid[i] == Tree58::PARENT[i];
+    ctx->tree58 = tree_ok;
+    ctx->pd_variant = tree_ok ? 0 : (d->nv == PD_NV ? 2 : 1);
     const char *v = getenv("EGP_PD_VARIANT");
-    ctx->pd_variant = (v && atoi(v) == 1) || d->nv != PD_NV ? 1 : 0;
+    if (v) {
+        const int want = atoi(v);
+        if (want == 1 || (want == 2 && d->nv == PD_NV) || (want == 0 && tree_ok)) ctx->pd_variant = want;
+    }
     *out = ctx;
     return EGP_OK;
 }
@@ -756,7 +838,8 @@ int egp_set_reward_weights(egp_ctx *ctx, const egp_model_desc *d) {
 
 int egp_set_pd_variant(egp_ctx *ctx, int variant) {
     EGP_REQUIRE(ctx, "ctx is NULL");
-    EGP_REQUIRE(variant == 1 || (variant == 0 && ctx->dm.nv == PD_NV), "variant 0 needs nv == 58");
+    EGP_REQUIRE(variant == 1 || (variant == 2 && ctx->dm.nv == PD_NV) || (variant == 0 && ctx->tree58),
+                "variant 0 needs the humanoid_1205_v1 dof tree, variant 2 needs nv == 58");
     ctx->pd_variant = variant;
     return EGP_OK;
 }
@@ -833,6 +916,10 @@ static int launch_pd(egp_ctx *ctx, const PdLd &ld, const T *qpos, const T *qvel,
     if (n == 0) return EGP_OK;
     EGP_REQUIRE(qpos && qvel && action && qM && C && torque, "NULL pointer");
     if (ctx->pd_variant == 0) {
+        k_pd_torque_tree58<T><<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, C, n, torque, torque_raw);
+        return after_launch("k_pd_torque_tree58");
+    }
+    if (ctx->pd_variant == 2) {
         k_pd_torque_reg58<T><<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, C, n, torque, torque_raw);
         return after_launch("k_pd_torque_reg58");
     }

@@ -70,11 +70,11 @@ def main():
         ]
         for name, fn, bytes_per_unit, units_per_env in cases:
             if name == "K1_pd_torque":
-                for variant in (0, 1):
+                for variant in (0, 2, 1):
                     ctx.set_pd_variant(variant)
-                    s = timeit(fn, iters=20 if variant else 50)
+                    s = timeit(fn, iters=20 if variant == 1 else 50)
                     ab = bytes_per_unit * n
-                    print(json.dumps(dict(kernel=name + ("_reg58" if variant == 0 else "_lds"), n=n, us=s * 1e6, alg_bytes=ab,
+                    print(json.dumps(dict(kernel=name + {0: "_tree58", 2: "_reg58", 1: "_lds"}[variant], n=n, us=s * 1e6, alg_bytes=ab,
                                           GBps=ab / s / 1e9, frac_hbm=ab / s / HBM_PEAK)))
                 ctx.set_pd_variant(0)
                 continue
