@@ -96,6 +96,8 @@ SIGNATURES = {
     "egp_gae_f32": (C.c_int, [vp, vp, vp, _i32, _f64, _f64, vp, vp, vp, vp, vp]),
     "egp_gae_standardize_f64": (C.c_int, [vp, _i32, vp, vp]),
     "egp_gae_standardize_f32": (C.c_int, [vp, _i32, vp, vp]),
+    "egp_lstm_fwd_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp]),
+    "egp_lstm_bwd_f32": (C.c_int, [vp, vp, vp, vp, _i32, _i32, _i32, _i32, vp, vp]),
     "egp_physics_register": (C.c_int, [C.POINTER(PhysicsVtable), _i32, C.POINTER(vp)]),
     "egp_physics_create_surrogate": (C.c_int, [C.POINTER(SurrogateDesc), _i32, C.POINTER(vp)]),
     "egp_physics_destroy": (C.c_int, [vp]),

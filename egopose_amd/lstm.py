@@ -1,0 +1,79 @@
+"""One LSTM direction with the persistent HIP recurrence (csrc/egp_lstm.hip) behind torch autograd.
+
+Split of the work:
+  rocBLAS (MFMA):  the input projection  X W_ih^T + b  for all T*B rows at once, and in backward the three
+                   weight-gradient reductions  dW_ih = dPre^T X,  dW_hh = dPre^T H_prev,  db = sum dPre;
+  HIP kernels:     the sequential part -- T steps of h W_hh^T + gate non-linearities (forward) and the
+                   backward-through-time recurrence producing dPre.
+Parameters are those of ``nn.LSTMCell`` (weight_ih [4H,D], weight_hh [4H,H], bias_ih, bias_hh), hidden size 64,
+float32, zero initial state: exactly what ``RNN.batch_forward`` of the reference evaluates step by step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+HIDDEN = 64
+
+
+def available(x, cell):
+    return (x.is_cuda and x.dtype == torch.float32 and cell.hidden_size == HIDDEN
+            and cell.weight_hh.dtype == torch.float32 and cell.bias_ih is not None)
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class LstmDirection(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, reverse):
+        lib = L.load()
+        T, B, D = x.shape
+        x2 = x.reshape(T * B, D)
+        gx = torch.addmm(b_ih + b_hh, x2, w_ih.t()).view(T, B, 4 * HIDDEN)
+        h = torch.empty(T, B, HIDDEN, dtype=x.dtype, device=x.device)
+        train = any(ctx.needs_input_grad)
+        cells = torch.empty(T, B, HIDDEN, dtype=x.dtype, device=x.device) if train else None
+        w_hh_c = w_hh.contiguous()
+        # the activated gates overwrite the pre-activations in place (each workgroup reads its tile of gx[t]
+        # before the barrier that precedes the writes)
+        L.check(lib.egp_lstm_fwd_f32(_p(gx), _p(w_hh_c), T, B, HIDDEN, 1 if reverse else 0, _p(h),
+                                     _p(gx if train else None), _p(cells), _s()), "egp_lstm_fwd_f32")
+        if train:
+            ctx.save_for_backward(x2, w_ih, w_hh_c, h, gx, cells)
+            ctx.reverse = bool(reverse)
+            ctx.shape = (T, B, D)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        lib = L.load()
+        x2, w_ih, w_hh, h, gates, cells = ctx.saved_tensors
+        T, B, D = ctx.shape
+        dpre = torch.empty(T, B, 4 * HIDDEN, dtype=h.dtype, device=h.device)
+        L.check(lib.egp_lstm_bwd_f32(_p(dh.contiguous()), _p(gates), _p(cells), _p(w_hh), T, B, HIDDEN,
+                                     1 if ctx.reverse else 0, _p(dpre), _s()), "egp_lstm_bwd_f32")
+        zero = h.new_zeros(1, B, HIDDEN)
+        h_prev = torch.cat((h[1:], zero), 0) if ctx.reverse else torch.cat((zero, h[:-1]), 0)
+        # dW_ih | dW_hh | db in ONE batched GEMM over the time axis + a reduction: [dPre_t^T (x_t | h_prev_t | 1)]
+        # (a single (4H x T*B) @ (T*B x D) product runs 3x slower in rocBLAS than T independent ones)
+        xh1 = torch.cat((x2.view(T, B, D), h_prev, h.new_ones(T, B, 1)), 2)
+        dw = torch.bmm(dpre.transpose(1, 2), xh1).sum(0)                       # (4H, D + H + 1)
+        d_w_ih = dw[:, :D].contiguous() if ctx.needs_input_grad[1] else None
+        d_w_hh = dw[:, D:D + HIDDEN].contiguous() if ctx.needs_input_grad[2] else None
+        d_b = dw[:, D + HIDDEN].contiguous() if (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else None
+        d_x = dpre.view(T * B, 4 * HIDDEN).mm(w_ih).view(T, B, D) if ctx.needs_input_grad[0] else None
+        return d_x, d_w_ih, d_w_hh, d_b, d_b, None
+
+
+def lstm_direction(cell, x, reverse):
+    return LstmDirection.apply(x, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh, bool(reverse))

@@ -19,7 +19,12 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+import os
+
 from . import dist as _dist
+from . import lstm as _hip_lstm
+
+_LSTM_IMPL = os.environ.get("EGP_LSTM", "hip")      # "torch" forces the MIOpen / cell-loop paths (A/B runs)
 
 _ACT = {"tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid}
 
@@ -113,6 +118,8 @@ def _lstm_sweep(cell: nn.LSTMCell, x, reverse):
     """(T,B,D) -> (T,B,H) for one direction; zero initial state."""
     T, B, _ = x.shape
     H = cell.hidden_size
+    if _LSTM_IMPL != "torch" and _hip_lstm.available(x, cell):
+        return _hip_lstm.lstm_direction(cell, x.contiguous(), reverse)      # persistent HIP recurrence
     fused_ok = x.is_cuda and x.dtype in (torch.float32, torch.float16, torch.bfloat16)
     if fused_ok:
         h0 = x.new_zeros(1, B, H)

@@ -180,6 +180,18 @@ int egp_gae_f32(const float *rewards, const float *masks, const float *values, i
 int egp_gae_standardize_f64(double *adv, int32_t n, const double *stats, void *stream);
 int egp_gae_standardize_f32(float *adv, int32_t n, const double *stats, void *stream);
 
+/* ---------------------------------------------------------------------------------------- LSTM
+ * Recurrent sweep of ONE direction of the video-context LSTM (hidden size 64, float32, zero initial state):
+ * the t-loop of RNN.batch_forward (models/rnn.py:45-61) in one launch.
+ *   gates_x [T][B][256] = x_t W_ih^T + b_ih + b_hh (gate order i,f,g,o);  w_hh [256][64]
+ *   h_out [T][B][64];  gates_save [T][B][256] (may alias gates_x) / cells_save [T][B][64]: both NULL for inference */
+int egp_lstm_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t B, int32_t hidden, int32_t reverse,
+                     float *h_out, float *gates_save, float *cells_save, void *stream);
+/* backward-through-time of the same sweep: d_pre [T][B][256] = gradient w.r.t. the pre-activation gates; the
+ * caller forms dW_ih = d_pre^T X, dW_hh = d_pre^T H_prev, db = sum d_pre with library GEMMs */
+int egp_lstm_bwd_f32(const float *dh_out, const float *gates_save, const float *cells_save, const float *w_hh,
+                     int32_t T, int32_t B, int32_t hidden, int32_t reverse, float *d_pre, void *stream);
+
 /* ----------------------------------------------------------------------------------------
  * Host physics boundary (replaces mujoco_py's MjSim inside HumanoidEnv: envs/common/mujoco_env.py:84-105,
  * ego_pose/envs/humanoid_v1.py:158-177). A backend is a vtable of plain C callbacks working on one
