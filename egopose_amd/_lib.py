@@ -91,6 +91,8 @@ SIGNATURES = {
     "egp_zfilter_workspace_bytes": (_i64, [_i32, _i32]),
     "egp_zfilter_f64": (C.c_int, [vp, vp, _i32, _i32, vp, vp, _i32, _f64, vp, vp, vp]),
     "egp_zfilter_f32": (C.c_int, [vp, vp, _i32, _i32, vp, vp, _i32, _f64, vp, vp, vp]),
+    "egp_obs_zfilter_f64": (C.c_int, [vp, vp, vp, vp, _i32, vp, vp, _f64, vp, vp, _i32, vp, vp]),
+    "egp_obs_zfilter_f32": (C.c_int, [vp, vp, vp, vp, _i32, vp, vp, _f64, vp, vp, _i32, vp, vp]),
     "egp_gae_workspace_bytes": (_i64, [_i32]),
     "egp_gae_f64": (C.c_int, [vp, vp, vp, _i32, _f64, _f64, vp, vp, vp, vp, vp]),
     "egp_gae_f32": (C.c_int, [vp, vp, vp, _i32, _f64, _f64, vp, vp, vp, vp, vp]),
@@ -108,7 +110,7 @@ SIGNATURES = {
     "egp_physics_drain_host": (C.c_int, [vp, _i32, vp, vp, vp, vp, vp]),
     "egp_engine_create": (C.c_int, [vp, vp, C.POINTER(EngineDesc), C.POINTER(vp)]),
     "egp_engine_destroy": (C.c_int, [vp]),
-    "egp_engine_state": (C.c_int, [vp] + [C.POINTER(vp)] * 6),
+    "egp_engine_state": (C.c_int, [vp] + [C.POINTER(vp)] * 7),
     "egp_engine_reset": (C.c_int, [vp, vp, _i32, vp, vp, vp]),
     "egp_engine_step_async": (C.c_int, [vp, _i32, vp, vp, vp]),
     "egp_engine_wait": (C.c_int, [vp, _i32, vp]),

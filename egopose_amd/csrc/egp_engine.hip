@@ -99,7 +99,7 @@ struct egp_engine {
     int nq = 0, nv = 0, nu = 0, nM = 0, nbody = 0, frame_skip = 0;
     int ld_s = 0, ld_m = 0, off_qpos = 0, off_qvel = 0, off_bias = 0;   // state / inertia row strides (doubles)
     std::atomic<bool> profile_k1{false};
-    double *d_state = nullptr, *d_qM = nullptr, *d_qpos = nullptr, *d_qvel = nullptr, *d_torque = nullptr, *d_ee = nullptr;
+    double *d_state = nullptr, *d_qM = nullptr, *d_prev_qpos = nullptr, *d_qpos = nullptr, *d_qvel = nullptr, *d_torque = nullptr, *d_ee = nullptr;
     double *h_state = nullptr, *h_qM = nullptr, *h_qpos = nullptr, *h_qvel = nullptr, *h_torque = nullptr, *h_ee = nullptr,
            *h_headz = nullptr, *h_xpos = nullptr;
     std::vector<Group> groups;
@@ -167,6 +167,9 @@ void run_step(egp_engine *E, Group &G, int tid) {
     const bool prof = E->profile_k1.load(std::memory_order_relaxed) && !G.k_beg.empty();
     if (leader) {
         if (G.ready) G_HIP(hipStreamWaitEvent(G.stream, G.ready, 0));
+        // env.prev_qpos = data.qpos.copy() (humanoid_v1.py:182): kept on the device for the reward kernel
+        G_HIP(hipMemcpyAsync(E->d_prev_qpos + (size_t)G.e0 * E->nq, E->d_qpos + (size_t)G.e0 * E->nq, (size_t)m * E->nq * sizeof(double),
+                             hipMemcpyDeviceToDevice, G.stream));
         enqueue_k1(E, G, 0);
     }
     for (int s = 0; s < FS; ++s) {
@@ -295,6 +298,8 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     E_TRY(hipMalloc((void **)&E->d_state, N * E->ld_s * sizeof(double)));
     E_TRY(hipMalloc((void **)&E->d_qM, N * E->ld_m * sizeof(double)));
     E_TRY(hipMalloc((void **)&E->d_qpos, N * E->nq * sizeof(double)));
+    E_TRY(hipMalloc((void **)&E->d_prev_qpos, N * E->nq * sizeof(double)));
+    E_TRY(hipMemset(E->d_prev_qpos, 0, N * E->nq * sizeof(double)));
     E_TRY(hipMalloc((void **)&E->d_qvel, N * E->nv * sizeof(double)));
     E_TRY(hipMalloc((void **)&E->d_torque, N * E->nu * sizeof(double)));
     E_TRY(hipMalloc((void **)&E->d_ee, N * 15 * sizeof(double)));
@@ -352,7 +357,7 @@ int egp_engine_destroy(egp_engine *E) {
         for (auto ev : G.k_beg) (void)hipEventDestroy(ev);
         for (auto ev : G.k_end) (void)hipEventDestroy(ev);
     }
-    void *dev[] = {E->d_state, E->d_qM, E->d_qpos, E->d_qvel, E->d_torque, E->d_ee};
+    void *dev[] = {E->d_state, E->d_qM, E->d_prev_qpos, E->d_qpos, E->d_qvel, E->d_torque, E->d_ee};
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = {E->h_state, E->h_qM, E->h_qpos, E->h_qvel, E->h_torque, E->h_ee, E->h_headz, E->h_xpos};
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -361,8 +366,9 @@ int egp_engine_destroy(egp_engine *E) {
 }
 
 int egp_engine_state(egp_engine *E, double **qpos, double **qvel, double **ee_wpos, double **head_z_host,
-                     double **qpos_host, double **qvel_host) {
+                     double **qpos_host, double **qvel_host, double **prev_qpos) {
     EGP_REQUIRE(E, "engine is NULL");
+    if (prev_qpos) *prev_qpos = E->d_prev_qpos;
     if (qpos) *qpos = E->d_qpos;
     if (qvel) *qvel = E->d_qvel;
     if (ee_wpos) *ee_wpos = E->d_ee;

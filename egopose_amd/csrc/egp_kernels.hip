@@ -63,16 +63,10 @@ __global__ __launch_bounds__(256) void k_body_quat(DevModel m, const T *__restri
 // ============================================================================================ K3
 // get_full_obs (ego_pose/envs/humanoid_v1.py:73-96): obs = [qpos[2:] (root quat de-headed), qvel
 // (root linear velocity in the heading frame)]
+// one element of get_full_obs for env row (q, v): column c of [qpos[2:] (root quat de-headed), qvel (root
+// linear velocity in the heading frame)]
 template <typename T>
-__global__ __launch_bounds__(256) void k_obs(DevModel m, const T *__restrict__ qpos, const T *__restrict__ qvel,
-                                             int n, T *__restrict__ obs) {
-    const int od = m.nq - 2 + m.nv;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long)n * od) return;
-    const int env = gid / od, c = gid % od;
-    const T *q = qpos + (long)env * m.nq;
-    const T *v = qvel + (long)env * m.nv;
-    const int np = m.nq - 2;
+__device__ __forceinline__ T obs_element(const T *q, const T *v, int np, int c) {
     T out;
     if (c >= 1 && c <= 4) {
         Q4<T> r{q[3], q[4], q[5], q[6]};
@@ -89,7 +83,17 @@ __global__ __launch_bounds__(256) void k_obs(DevModel m, const T *__restrict__ q
     } else {
         out = v[c - np];
     }
-    obs[gid] = out;
+    return out;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_obs(DevModel m, const T *__restrict__ qpos, const T *__restrict__ qvel,
+                                             int n, T *__restrict__ obs) {
+    const int od = m.nq - 2 + m.nv;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)n * od) return;
+    const int env = gid / od, c = gid % od;
+    obs[gid] = obs_element<T>(qpos + (long)env * m.nq, qvel + (long)env * m.nv, m.nq - 2, c);
 }
 
 // ============================================================================================ K1
@@ -507,8 +511,18 @@ __global__ __launch_bounds__(256) void k_pose_features(DevModel m, const T *__re
 // ============================================================================================ K6
 // RunningStat / ZFilter (utils/zfilter.py:7-67), batched.
 // partial layout per tile p: ws[p*(1+2*dim)] = count, then mean[dim], then M2[dim]  (float64)
+// Source of the rows being filtered: a dense array x[n][dim], or (x == nullptr) the observation computed on the
+// fly from the drained state (K3 fused into K6: no intermediate raw-observation array)
 template <typename T>
-__global__ __launch_bounds__(128) void k_zf_partial(const T *__restrict__ x, const int *__restrict__ active, int n, int dim,
+struct ZfSrc {
+    const T *x; const T *qpos; const T *qvel; int nq, nv, dim;
+    __device__ __forceinline__ T at(long r, int c) const {
+        return x ? x[r * dim + c] : obs_element<T>(qpos + r * nq, qvel + r * nv, nq - 2, c);
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(128) void k_zf_partial(ZfSrc<T> src, const int *__restrict__ active, int n, int dim,
                                                     int rows_per_tile, double *__restrict__ ws) {
     const int p = blockIdx.x;
     const int r0 = p * rows_per_tile, r1 = min(n, r0 + rows_per_tile);
@@ -519,12 +533,12 @@ __global__ __launch_bounds__(128) void k_zf_partial(const T *__restrict__ x, con
     for (int c = threadIdx.x; c < dim; c += blockDim.x) {
         double s = 0.0;
         for (int r = r0; r < r1; ++r)
-            if (!active || active[r]) s += (double)x[(long)r * dim + c];
+            if (!active || active[r]) s += (double)src.at(r, c);
         const double mean = cnt > 0 ? s / cnt : 0.0;
         double m2 = 0.0;
         for (int r = r0; r < r1; ++r)
             if (!active || active[r]) {
-                const double d = (double)x[(long)r * dim + c] - mean;
+                const double d = (double)src.at(r, c) - mean;
                 m2 += d * d;
             }
         out[1 + c] = mean;
@@ -533,13 +547,15 @@ __global__ __launch_bounds__(128) void k_zf_partial(const T *__restrict__ x, con
 }
 
 template <typename T>
-__global__ __launch_bounds__(128) void k_zf_apply(const T *__restrict__ x, int n, int dim, int rows_per_tile, int n_tiles,
+__global__ __launch_bounds__(128) void k_zf_apply(ZfSrc<T> src, int n, int dim, int rows_per_tile, int n_tiles,
                                                   const double *__restrict__ ws, const double *__restrict__ st_in,
                                                   double *__restrict__ st_out, int update, double clip,
-                                                  T *__restrict__ y) {
+                                                  T *__restrict__ y, T *__restrict__ y2, const int *__restrict__ write_mask,
+                                                  int identity) {
     extern __shared__ double s_ms[];   // mean[dim], inv[dim]
     const int p = blockIdx.x;
     for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+        if (identity) { s_ms[c] = 0.0; s_ms[dim + c] = 1.0; continue; }
         double cnt = st_in[0], mean = st_in[1 + c], S = st_in[1 + dim + c];
         if (update) {
             for (int q = 0; q < n_tiles; ++q) {   // Chan merge, fixed order -> deterministic
@@ -572,9 +588,12 @@ __global__ __launch_bounds__(128) void k_zf_apply(const T *__restrict__ x, int n
     const long e0 = (long)r0 * dim, e1 = (long)r1 * dim;
     for (long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
         const int c = e % dim;
-        double v = ((double)x[e] - s_ms[c]) * s_ms[dim + c];
-        if (clip > 0.0) v = fmin(fmax(v, -clip), clip);
+        const long r = e / dim;
+        if (write_mask && !write_mask[r]) continue;
+        double v = ((double)src.at(r, c) - s_ms[c]) * s_ms[dim + c];
+        if (clip > 0.0 && !identity) v = fmin(fmax(v, -clip), clip);
         y[e] = (T)v;
+        if (y2) y2[e] = (T)v;
     }
 }
 
@@ -977,11 +996,13 @@ static inline void zf_tiling(int n, int *rows_per_tile, int *n_tiles) {
 }
 
 template <typename T>
-static int launch_zfilter(const T *x, const int *active, int n, int dim, const double *st_in, double *st_out, int update,
-                          double clip, T *y, void *ws, void *stream) {
-    EGP_REQUIRE(st_in && (n == 0 || (x && y)), "NULL pointer");
+static int launch_zfilter_src(const ZfSrc<T> &src, const int *active, int n, int dim, const double *st_in, double *st_out, int update,
+                              double clip, T *y, T *y2, const int *write_mask, void *ws, void *stream) {
+    const int identity = st_in == nullptr;
     EGP_REQUIRE(n >= 0 && dim > 0 && dim <= 4096, "bad n/dim");
-    EGP_REQUIRE(!update || (st_out && ws && st_out != st_in), "update needs workspace and a distinct state_out");
+    EGP_REQUIRE(n == 0 || y, "NULL output");
+    EGP_REQUIRE(identity || !update || (st_out && ws && st_out != st_in), "update needs workspace and a distinct state_out");
+    if (identity) update = 0;
     if (n == 0) {
         if (update) EGP_HIP_CHECK(hipMemcpyAsync(st_out, st_in, (1 + 2 * (size_t)dim) * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
         return EGP_OK;
@@ -989,13 +1010,32 @@ static int launch_zfilter(const T *x, const int *active, int n, int dim, const d
     int rpt, nt;
     zf_tiling(n, &rpt, &nt);
     if (update) {
-        k_zf_partial<T><<<dim3(nt), dim3(128), 0, (hipStream_t)stream>>>(x, active, n, dim, rpt, (double *)ws);
+        k_zf_partial<T><<<dim3(nt), dim3(128), 0, (hipStream_t)stream>>>(src, active, n, dim, rpt, (double *)ws);
         int rc = after_launch("k_zf_partial");
         if (rc != EGP_OK) return rc;
     }
     k_zf_apply<T><<<dim3(nt), dim3(128), 2 * dim * sizeof(double), (hipStream_t)stream>>>(
-        x, n, dim, rpt, nt, (const double *)ws, st_in, st_out, update, clip, y);
+        src, n, dim, rpt, nt, (const double *)ws, st_in, st_out, update, clip, y, y2, write_mask, identity);
     return after_launch("k_zf_apply");
+}
+
+template <typename T>
+static int launch_zfilter(const T *x, const int *active, int n, int dim, const double *st_in, double *st_out, int update,
+                          double clip, T *y, void *ws, void *stream) {
+    EGP_REQUIRE(st_in && (n == 0 || (x && y)), "NULL pointer");
+    ZfSrc<T> src{x, nullptr, nullptr, 0, 0, dim};
+    return launch_zfilter_src<T>(src, active, n, dim, st_in, st_out, update, clip, y, nullptr, nullptr, ws, stream);
+}
+
+template <typename T>
+static int launch_obs_zfilter(egp_ctx *ctx, const T *qpos, const T *qvel, const int *active, int n, const double *st_in, double *st_out,
+                              double clip, T *y, T *y2, int write_only_active, void *ws, void *stream) {
+    EGP_REQUIRE(ctx, "ctx is NULL");
+    EGP_REQUIRE(n == 0 || (qpos && qvel), "NULL pointer");
+    EGP_REQUIRE(!write_only_active || active, "write_only_active needs the active mask");
+    const int dim = ctx->dm.nq - 2 + ctx->dm.nv;
+    ZfSrc<T> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim};
+    return launch_zfilter_src<T>(src, active, n, dim, st_in, st_out, 1, clip, y, y2, write_only_active ? active : nullptr, ws, stream);
 }
 
 template <typename T>
@@ -1074,6 +1114,18 @@ int egp_zfilter_f64(const double *x, const int32_t *active, int32_t n, int32_t d
 int egp_zfilter_f32(const float *x, const int32_t *active, int32_t n, int32_t dim, const double *si, double *so,
                     int32_t update, double clip, float *y, void *ws, void *s) {
     return launch_zfilter<float>(x, active, n, dim, si, so, update, clip, y, ws, s);
+}
+
+/* K3+K6 fused: observations of the drained state (get_full_obs) pushed through the running filter in one call.
+ *   active [n] (optional): rows that update the statistics; write_only_active: only those rows are written.
+ *   state_in == NULL: no filter (raw observations). y2 (optional) receives a second copy of the output. */
+int egp_obs_zfilter_f64(egp_ctx *c, const double *qpos, const double *qvel, const int32_t *active, int32_t n, const double *si,
+                        double *so, double clip, double *y, double *y2, int32_t write_only_active, void *ws, void *s) {
+    return launch_obs_zfilter<double>(c, qpos, qvel, active, n, si, so, clip, y, y2, write_only_active, ws, s);
+}
+int egp_obs_zfilter_f32(egp_ctx *c, const float *qpos, const float *qvel, const int32_t *active, int32_t n, const double *si,
+                        double *so, double clip, float *y, float *y2, int32_t write_only_active, void *ws, void *s) {
+    return launch_obs_zfilter<float>(c, qpos, qvel, active, n, si, so, clip, y, y2, write_only_active, ws, s);
 }
 
 int64_t egp_gae_workspace_bytes(int32_t n) {

@@ -240,6 +240,26 @@ class EgpContext:
                    float(clip or 0.0), _ptr(y), _ptr(ws), _stream()), "egp_zfilter")
         return y
 
+    def obs_zfilter(self, qpos, qvel, state_in, state_out, clip, out, out2=None, active=None, write_only_active=False):
+        """K3+K6 fused: filtered observations of (qpos, qvel) written to ``out`` (and ``out2``); state_in None = raw."""
+        n, dt = qpos.shape[0], qpos.dtype
+        _need(qpos, (n, self.nq), dt, "qpos")
+        _need(qvel, (n, self.nv), dt, "qvel")
+        _need(out, (n, self.obs_dim), dt, "out")
+        if out2 is not None:
+            _need(out2, (n, self.obs_dim), dt, "out2")
+        if active is not None:
+            _need(active, (n,), torch.int32, "active")
+        ws = None
+        if state_in is not None:
+            _need(state_in, (1 + 2 * self.obs_dim,), torch.float64, "state_in")
+            _need(state_out, (1 + 2 * self.obs_dim,), torch.float64, "state_out")
+            ws = self._workspace("zf", self.lib.egp_zfilter_workspace_bytes(n, self.obs_dim), qpos.device)
+        fn = getattr(self.lib, "egp_obs_zfilter_" + self._sfx(qpos))
+        L.check(fn(self.handle, _ptr(qpos), _ptr(qvel), _ptr(active), n, _ptr(state_in), _ptr(state_out), float(clip or 0.0),
+                   _ptr(out), _ptr(out2), 1 if write_only_active else 0, _ptr(ws), _stream()), "egp_obs_zfilter")
+        return out
+
     def gae(self, rewards, masks, values, gamma, tau):
         """-> (adv_raw (n,), returns (n,), stats float64[3] = {n, mean, M2}) all on device."""
         n, dt = rewards.shape[0], rewards.dtype

@@ -129,7 +129,7 @@ class RolloutEngine:
         L.check(self.lib.egp_engine_create(ctx.handle, physics.handle, C.byref(d), C.byref(h)), "egp_engine_create")
         self.handle = h
         self.n_threads, self.n_groups = n_threads, int(n_groups)
-        ptrs = [C.c_void_p() for _ in range(6)]
+        ptrs = [C.c_void_p() for _ in range(7)]
         L.check(self.lib.egp_engine_state(self.handle, *[C.byref(p) for p in ptrs]), "egp_engine_state")
         dev = torch.device("cuda", ctx.device)
         self.qpos = _wrap_device(ptrs[0].value, (self.n_env, ctx.nq), dev)
@@ -138,6 +138,7 @@ class RolloutEngine:
         self.head_z = _wrap_host(ptrs[3].value, (self.n_env,))
         self.qpos_host = _wrap_host(ptrs[4].value, (self.n_env, ctx.nq))
         self.qvel_host = _wrap_host(ptrs[5].value, (self.n_env, ctx.nv))
+        self.prev_qpos = _wrap_device(ptrs[6].value, (self.n_env, ctx.nq), dev)
 
     def group_range(self, g):
         a, b = C.c_int32(), C.c_int32()

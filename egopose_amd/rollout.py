@@ -48,6 +48,34 @@ class _PinnedRing:
         return out
 
 
+class _Uploader:
+    """Non-blocking host->device uploads of small integer arrays through a ring of pinned buffers
+    (``torch.as_tensor(np_array, device=...)`` from pageable memory synchronises the stream)."""
+
+    def __init__(self, device, capacity, slots=32):
+        self.device, self.capacity = device, int(capacity)
+        self.bufs = [torch.empty(self.capacity, dtype=torch.int64).pin_memory() for _ in range(slots)]
+        self.events = [None] * slots
+        self.i = 0
+
+    def __call__(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.int64).ravel()
+        n = arr.shape[0]
+        if n > self.capacity:
+            return torch.as_tensor(arr, device=self.device)
+        k = self.i
+        self.i = (self.i + 1) % len(self.bufs)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        buf = self.bufs[k][:n]
+        buf.numpy()[...] = arr
+        out = buf.to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        return out
+
+
 class LockstepRollout:
 
     def __init__(self, sim, policy_net, policy_vs_net, running_state=None, noise_rate=1.0, mean_action=False,
@@ -68,9 +96,10 @@ class LockstepRollout:
         self.gen = torch.Generator(device=self.dev)
         self.gen.manual_seed(int(seed))
         self.groups = [self.engine.group_range(g) for g in range(self.engine.n_groups)]
-        self.rings = [_PinnedRing(5, b - a, self.dev) for a, b in self.groups]
+        self.rings = [_PinnedRing(4, b - a, self.dev) for a, b in self.groups]
         self.timing = {}
         self._events = [None] * len(self.groups)
+        self.up = _Uploader(self.dev, max(4096, self.N))
         self.pool_batch = max(256, self.N // 2)
         self._pool, self._pool_pos = None, 0
 
@@ -88,8 +117,7 @@ class LockstepRollout:
             if self._pool is None or self._pool_pos >= len(self._pool[0]):
                 m = max(need, self.pool_batch)
                 e_ind, s_ind = self.env.sample_reset(m)
-                e_d = torch.as_tensor(e_ind, device=self.dev)
-                s_d = torch.as_tensor(s_ind, device=self.dev)
+                e_d, s_d = self.up(e_ind), self.up(s_ind)
                 win = self.policy_vs_net.window_features(e_d, s_d, self.T_ep)
                 ctx = self.policy_vs_net.forward_v_net(win)[self.margin:-self.margin].transpose(0, 1).contiguous()   # (m, T, H)
                 self._pool, self._pool_pos = (e_ind, s_ind, ctx), 0
@@ -116,15 +144,18 @@ class LockstepRollout:
         self.e_ind[ids], self.s_ind[ids] = e_ind, s_ind
         self.frame_base[ids] = rows
         self.cur_t[ids] = 0
-        self.v_out[torch.as_tensor(ids, device=self.dev)] = ctx_rows
+        self.v_out[self.up(ids)] = ctx_rows
 
-    def _filter(self, obs, active_dev):
+    def _obs_filter(self, a, b, out, out2=None, active=None, write_only_active=False):
+        """K3+K6 fused for slots [a,b): filtered observation of the engine state -> out (and out2)."""
+        eng = self.engine
         if self.zf_state is None:
-            return obs
-        new = torch.empty_like(self.zf_state)
-        y = self.ctx.zfilter(obs, self.zf_state, new, update=True, clip=self.zf_clip, active=active_dev)
+            return self.ctx.obs_zfilter(eng.qpos[a:b], eng.qvel[a:b], None, None, 0.0, out, out2, active, write_only_active)
+        new = self._zf_bufs[self._zf_flip]
+        self._zf_flip ^= 1
+        self.ctx.obs_zfilter(eng.qpos[a:b], eng.qvel[a:b], self.zf_state, new, self.zf_clip, out, out2, active, write_only_active)
         self.zf_state = new
-        return y
+        return out
 
     # ------------------------------------------------------------------ one sampling pass
     @torch.no_grad()
@@ -140,16 +171,15 @@ class LockstepRollout:
         self._pool, self._pool_pos = None, 0          # contexts depend on this iteration's weights
         od, nu = ctx.obs_dim, ctx.nu
         f64 = torch.float64
+        # time-major record in HBM. rec["states"][k] IS the policy input of tick k: the filtered observation of
+        # tick k-1 is written straight into row k (and into next_states[k-1]) by the fused kernel.
         rec = dict(
-            states=torch.empty(T_max, N, od, dtype=f64, device=dev), next_states=torch.empty(T_max, N, od, dtype=f64, device=dev),
-            actions=torch.empty(T_max, N, nu, dtype=f64, device=dev), rewards=torch.zeros(T_max, N, dtype=f64, device=dev),
-            cinfo=torch.zeros(T_max, N, 5, dtype=f64, device=dev), flags=torch.zeros(T_max, 5, N, dtype=torch.int32, device=dev),
-            exps=torch.ones(T_max, N, dtype=torch.int64, device=dev), e_ind=torch.zeros(T_max, N, dtype=torch.int64, device=dev),
-            s_ind=torch.zeros(T_max, N, dtype=torch.int64, device=dev))
+            states=torch.empty(T_max + 1, N, od, dtype=f64, device=dev), next_states=torch.empty(T_max, N, od, dtype=f64, device=dev),
+            actions=torch.zeros(T_max, N, nu, dtype=f64, device=dev), rewards=torch.zeros(T_max, N, dtype=f64, device=dev),
+            cinfo=torch.zeros(T_max, N, 5, dtype=f64, device=dev), exps=torch.ones(T_max, N, dtype=torch.int64, device=dev))
+        host = dict(valid=np.zeros((T_max, N), bool), done=np.zeros((T_max, N), bool),
+                    e_ind=np.zeros((T_max, N), np.int64), s_ind=np.zeros((T_max, N), np.int64))
         self.v_out = torch.empty(N, T_ep, H, dtype=ndt, device=dev)
-        self.state = torch.empty(N, od, dtype=f64, device=dev)
-        self.prev_qpos = torch.empty(N, ctx.nq, dtype=f64, device=dev)
-        self.act_buf = torch.zeros(N, nu, dtype=f64, device=dev)
         self.cur_t = np.zeros(N, np.int64)
         self.e_ind = np.zeros(N, np.int64)
         self.s_ind = np.zeros(N, np.int64)
@@ -160,6 +190,8 @@ class LockstepRollout:
             rs = self.running_state.rs
             self.zf_delta_base = (float(rs._n), np.array(rs._M, float).ravel().copy(), np.array(rs._S, float).ravel().copy())
             self.zf_state = self.running_state.to_device_state(dev)
+            self._zf_bufs = [torch.empty_like(self.zf_state), torch.empty_like(self.zf_state)]
+            self._zf_flip = 0
             self.zf_clip = float(self.running_state.clip or 0.0)
         else:
             self.zf_state = None
@@ -167,43 +199,38 @@ class LockstepRollout:
         ep_lens = []
         tick = [0] * len(self.groups)
         tm = dict(policy=0.0, wait=0.0, post=0.0, reset=0.0)
+        ar = [torch.arange(b - a, device=dev) for a, b in self.groups]
 
-        # ---- initial reset of every slot
-        all_ids = np.arange(N)
-        self._reset_slots(all_ids)
-        ones = torch.ones(N, dtype=torch.int32, device=dev)
-        self.state.copy_(self._filter(ctx.obs(eng.qpos, eng.qvel), ones))
+        # ---- initial reset of every slot; group g's first state goes to rec["states"][0, a:b]
+        self._reset_slots(np.arange(N))
+        self._obs_filter(0, N, rec["states"][0])
 
         def pre_step(g):
             a, b = self.groups[g]
             t0 = time.time()
-            n = b - a
-            t_idx = torch.as_tensor(np.minimum(self.cur_t[a:b], T_ep - 1), device=dev)
-            vs = self.v_out[a:b][torch.arange(n, device=dev), t_idx]
-            x = torch.cat((vs, self.state[a:b].to(ndt)), dim=1)
+            k = tick[g]
+            t_idx = self.up(np.minimum(self.cur_t[a:b], T_ep - 1))
+            x = torch.cat((self.v_out[a:b][ar[g], t_idx], rec["states"][k, a:b].to(ndt)), dim=1)
             if hasattr(self.policy_net, "mean_std"):
                 mean, std = self.policy_net.mean_std(x)
             else:
                 dist = self.policy_net(x)
                 mean, std = dist.loc, dist.scale
             if self.mean_action:
-                use_mean = torch.ones(n, dtype=torch.bool, device=dev)
+                action = mean
+                rec["exps"][k, a:b] = 0
             elif self.noise_rate >= 1.0:
-                use_mean = torch.zeros(n, dtype=torch.bool, device=dev)
+                action = torch.addcmul(mean, std, torch.randn(mean.shape, dtype=mean.dtype, device=dev, generator=self.gen))
             else:
-                use_mean = torch.rand(n, device=dev, generator=self.gen) >= self.noise_rate
-            noise = torch.randn(mean.shape, dtype=mean.dtype, device=dev, generator=self.gen)
-            action = torch.where(use_mean.unsqueeze(1), mean, mean + std * noise).to(f64)
-            self.act_buf[a:b] = action
-            k = tick[g]
-            rec["actions"][k, a:b] = action
-            rec["exps"][k, a:b] = (~use_mean).to(torch.int64)
-            rec["states"][k, a:b] = self.state[a:b]
-            self.prev_qpos[a:b] = eng.qpos[a:b]
+                use_mean = torch.rand(b - a, device=dev, generator=self.gen) >= self.noise_rate
+                noise = torch.randn(mean.shape, dtype=mean.dtype, device=dev, generator=self.gen)
+                action = torch.where(use_mean.unsqueeze(1), mean, mean + std * noise)
+                rec["exps"][k, a:b] = (~use_mean).to(torch.int64)
+            rec["actions"][k, a:b] = action              # float64 copy the engine reads in place
             ev = torch.cuda.Event()
             ev.record()
             self._events[g] = ev          # must outlive the workers' hipStreamWaitEvent
-            eng.step_async(g, self.act_buf, active.astype(np.int32), ev)
+            eng.step_async(g, rec["actions"][k], active.astype(np.int32), ev)
             tm["policy"] += time.time() - t0
 
         def post_step(g):
@@ -221,17 +248,14 @@ class LockstepRollout:
                 fail = head_z < lb[self.e_ind[a:b]] - 0.1
             end = self.cur_t[a:b] >= (T_ep if self.env.fix_len is None else self.env.fix_len)
             done = (fail | end) & act_g
-            flags = np.stack([self.cur_t[a:b], self.frame_base[a:b] + self.cur_t[a:b], end & act_g, act_g, done]).astype(np.int32)
+            flags = np.stack([self.cur_t[a:b], self.frame_base[a:b] + self.cur_t[a:b], end & act_g, act_g]).astype(np.int32)
             fl = self.rings[g].upload(flags)
-            rec["flags"][k, :, a:b] = fl
-            obs = ctx.obs(eng.qpos[a:b], eng.qvel[a:b])
-            nxt = self._filter(obs, fl[3])
-            ctx.reward(eng.qpos[a:b], self.prev_qpos[a:b], eng.ee_wpos[a:b], fl[0], fl[1], fl[2], end_reward, active=fl[3],
+            host["valid"][k, a:b], host["done"][k, a:b] = act_g, done
+            host["e_ind"][k, a:b], host["s_ind"][k, a:b] = self.e_ind[a:b], self.s_ind[a:b]
+            # K3+K6: filtered next observation -> next_states[k] and the policy input of tick k+1;  K2: reward
+            self._obs_filter(a, b, rec["next_states"][k, a:b], rec["states"][k + 1, a:b], active=fl[3])
+            ctx.reward(eng.qpos[a:b], eng.prev_qpos[a:b], eng.ee_wpos[a:b], fl[0], fl[1], fl[2], end_reward, active=fl[3],
                        reward_out=rec["rewards"][k, a:b], cinfo_out=rec["cinfo"][k, a:b])
-            rec["next_states"][k, a:b] = nxt
-            rec["e_ind"][k, a:b] = torch.as_tensor(self.e_ind[a:b], device=dev)
-            rec["s_ind"][k, a:b] = torch.as_tensor(self.s_ind[a:b], device=dev)
-            self.state[a:b] = nxt
             steps_done[a:b] += act_g
             t2 = time.time()
             if done.any():
@@ -244,9 +268,8 @@ class LockstepRollout:
                     self._reset_slots(again)
                     mask = np.zeros(b - a, np.int32)
                     mask[again - a] = 1
-                    m_d = torch.as_tensor(mask, device=dev)
-                    fresh = self._filter(ctx.obs(eng.qpos[a:b], eng.qvel[a:b]), m_d)
-                    self.state[a:b] = torch.where(m_d.bool().unsqueeze(1), fresh, self.state[a:b])
+                    # fresh episodes: their first observation goes through the filter and replaces the policy input
+                    self._obs_filter(a, b, rec["states"][k + 1, a:b], active=self.up(mask).to(torch.int32), write_only_active=True)
             tick[g] = k + 1
             t3 = time.time()
             tm["wait"] += t1 - t0
@@ -270,15 +293,15 @@ class LockstepRollout:
 
         # ---- episode-major batch: slot by slot, each slot's ticks in order
         T_used = max(tick)
-        valid = rec["flags"][:T_used, 3, :].bool()                      # (T, N)
-        et = valid.t().nonzero()                                        # sorted by slot, then tick
-        flat = et[:, 1] * N + et[:, 0]
+        valid = host["valid"][:T_used]                                  # (T, N)
+        slot, tk = np.nonzero(valid.T)                                  # sorted by slot, then tick
+        flat = torch.as_tensor(tk * N + slot, device=dev)
         pick = lambda x: x[:T_used].reshape((T_used * N,) + tuple(x.shape[2:])).index_select(0, flat)
-        done_flag = rec["flags"][:T_used, 4, :].reshape(-1).index_select(0, flat)
+        hpick = lambda x, dt: torch.as_tensor(x[:T_used].reshape(T_used * N)[tk * N + slot].astype(dt), device=dev)
         batch = TrajBatchEgo.from_device(
-            states=pick(rec["states"]), actions=pick(rec["actions"]), masks=(1 - done_flag).to(torch.int64),
+            states=pick(rec["states"]), actions=pick(rec["actions"]), masks=hpick(~host["done"], np.int64),
             next_states=pick(rec["next_states"]), rewards=pick(rec["rewards"]), exps=pick(rec["exps"]),
-            v_metas=torch.stack((pick(rec["e_ind"]), pick(rec["s_ind"])), dim=1))
+            v_metas=torch.stack((hpick(host["e_ind"], np.int64), hpick(host["s_ind"], np.int64)), dim=1))
         r = batch.device_column("rewards")
         ci = pick(rec["cinfo"])
         stats = torch.cat([r.sum().view(1), r.min().view(1), r.max().view(1), ci.sum(0)]).cpu().numpy()

@@ -164,6 +164,17 @@ int egp_zfilter_f32(const float *x, const int32_t *active, int32_t n, int32_t di
                     const double *state_in, double *state_out, int32_t update, double clip,
                     float *y, void *workspace, void *stream);
 
+/* K3 + K6 fused (what the rollout calls every tick): get_full_obs of the drained state pushed through the
+ * running filter without an intermediate raw-observation array.
+ *   active [n] (optional): rows that update the statistics; write_only_active != 0: only those rows are written
+ *   state_in == NULL: no filter (y = raw observation);  y2 (optional): second copy of the output rows */
+int egp_obs_zfilter_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const int32_t *active, int32_t n,
+                        const double *state_in, double *state_out, double clip, double *y, double *y2,
+                        int32_t write_only_active, void *workspace, void *stream);
+int egp_obs_zfilter_f32(egp_ctx *ctx, const float *qpos, const float *qvel, const int32_t *active, int32_t n,
+                        const double *state_in, double *state_out, double clip, float *y, float *y2,
+                        int32_t write_only_active, void *workspace, void *stream);
+
 /* ---------------------------------------------------------------------------------------- K5
  * estimate_advantages (core/common.py:5-25) over the flat concatenated batch.
  *   rewards, masks, values [n] -> adv_raw [n] (before standardisation), returns [n]
@@ -255,9 +266,10 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *de
 int egp_engine_destroy(egp_engine *e);
 /* state of all envs after reset/wait, env-major float64. Device: qpos[n][nq], qvel[n][nv], ee_wpos[n][15]
  * (world positions of the 5 end effectors, data.body_xpos rows). Pinned host mirrors: head_z[n]
- * (get_body_com('Head')[2], humanoid_v1.py:191-196), qpos/qvel. Any out-pointer may be NULL. */
+ * (get_body_com('Head')[2], humanoid_v1.py:191-196), qpos/qvel. prev_qpos[n][nq] (device) is qpos as it was when the
+ * current/last env-step started (env.prev_qpos, humanoid_v1.py:182). Any out-pointer may be NULL. */
 int egp_engine_state(egp_engine *e, double **qpos, double **qvel, double **ee_wpos, double **head_z_host,
-                     double **qpos_host, double **qvel_host);
+                     double **qpos_host, double **qvel_host, double **prev_qpos);
 /* HumanoidEnv.reset_model's set_state (+ sim.forward) for the listed envs (strictly increasing ids):
  * rows qpos_host[k][nq], qvel_host[k][nv]; their drained state is uploaded on `stream`. */
 int egp_engine_reset(egp_engine *e, const int32_t *env_ids_host, int32_t n, const double *qpos_host,
