@@ -82,6 +82,11 @@ struct Group {
     bool has_active = false;
     std::atomic<int> status{EGP_OK};
     std::atomic<int> qM_dirty{0};             // some env of the group drained a new inertia this substep
+    unsigned *d_done = nullptr;               // K1 completion counter (HBM)
+    unsigned long long *h_flag = nullptr;     // K1 completion flag (pinned host), polled by the leader
+    unsigned long long *hd_flag = nullptr;
+    unsigned long long seq = 0;
+    bool polled = false;                      // the launch in flight publishes to h_flag
     char err[256] = "";
     // timing (leader only)
     double phys_s = 0.0, wait_s = 0.0, k1_ms = 0.0, ev_overhead_ms = 0.0;
@@ -99,6 +104,9 @@ struct egp_engine {
     int nq = 0, nv = 0, nu = 0, nM = 0, nbody = 0, frame_skip = 0;
     int ld_s = 0, ld_m = 0, off_qpos = 0, off_qvel = 0, off_bias = 0;   // state / inertia row strides (doubles)
     std::atomic<bool> profile_k1{false};
+    bool zero_copy = false;                   // K1 reads state rows / writes torques in pinned host memory directly
+    bool flag_poll = false;                   // leader polls a pinned completion flag instead of hipStreamSynchronize
+    double *hd_state = nullptr, *hd_torque = nullptr;   // device-side aliases of h_state / h_torque
     double *d_state = nullptr, *d_qM = nullptr, *d_prev_qpos = nullptr, *d_qpos = nullptr, *d_qvel = nullptr, *d_torque = nullptr, *d_ee = nullptr;
     double *h_state = nullptr, *h_qM = nullptr, *h_qpos = nullptr, *h_qvel = nullptr, *h_torque = nullptr, *h_ee = nullptr,
            *h_headz = nullptr, *h_xpos = nullptr;
@@ -149,14 +157,16 @@ void enqueue_k1(egp_engine *E, Group &G, int substep) {
     const int m = G.e1 - G.e0;
     const bool prof = E->profile_k1.load(std::memory_order_relaxed) && !G.k_beg.empty();
     if (prof) G_HIP(hipEventRecord(G.k_beg[substep], G.stream));
-    const double *st = E->d_state + (size_t)G.e0 * E->ld_s;
+    const double *st = (E->zero_copy ? E->hd_state : E->d_state) + (size_t)G.e0 * E->ld_s;
+    double *tq = (E->zero_copy ? E->hd_torque : E->d_torque) + (size_t)G.e0 * E->nu;
     int rc = egp_launch_pd_torque_strided(E->ctx, st + E->off_qpos, E->ld_s, st + E->off_qvel, E->ld_s, st + E->off_bias, E->ld_s,
-                                          E->d_qM + (size_t)G.e0 * E->ld_m, E->ld_m, G.action + (size_t)G.e0 * E->nu, m,
-                                          E->d_torque + (size_t)G.e0 * E->nu, G.stream);
+                                          E->d_qM + (size_t)G.e0 * E->ld_m, E->ld_m, G.action + (size_t)G.e0 * E->nu, m, tq, G.stream,
+                                          G.polled ? G.d_done : nullptr, G.hd_flag, G.polled ? ++G.seq : 0);
     if (rc != EGP_OK) fail(G, rc, "K1 launch", egp_last_error());
     if (prof) G_HIP(hipEventRecord(G.k_end[substep], G.stream));
-    G_HIP(hipMemcpyAsync(E->h_torque + (size_t)G.e0 * E->nu, E->d_torque + (size_t)G.e0 * E->nu, (size_t)m * E->nu * sizeof(double),
-                         hipMemcpyDeviceToHost, G.stream));
+    if (!E->zero_copy)
+        G_HIP(hipMemcpyAsync(E->h_torque + (size_t)G.e0 * E->nu, E->d_torque + (size_t)G.e0 * E->nu, (size_t)m * E->nu * sizeof(double),
+                             hipMemcpyDeviceToHost, G.stream));
 }
 
 void run_step(egp_engine *E, Group &G, int tid) {
@@ -166,6 +176,7 @@ void run_step(egp_engine *E, Group &G, int tid) {
     const int my0 = G.e0 + (int)((long)m * tid / G.n_threads), my1 = G.e0 + (int)((long)m * (tid + 1) / G.n_threads);
     const bool prof = E->profile_k1.load(std::memory_order_relaxed) && !G.k_beg.empty();
     if (leader) {
+        G.polled = E->flag_poll && E->zero_copy && !prof && E->ctx->pd_variant == 0;
         if (G.ready) G_HIP(hipStreamWaitEvent(G.stream, G.ready, 0));
         // env.prev_qpos = data.qpos.copy() (humanoid_v1.py:182): kept on the device for the reward kernel
         G_HIP(hipMemcpyAsync(E->d_prev_qpos + (size_t)G.e0 * E->nq, E->d_qpos + (size_t)G.e0 * E->nq, (size_t)m * E->nq * sizeof(double),
@@ -176,7 +187,18 @@ void run_step(egp_engine *E, Group &G, int tid) {
         const bool last = s == FS - 1;
         if (leader) {
             auto t0 = clk::now();
-            G_HIP(hipStreamSynchronize(G.stream));        // torques of substep s are on the host
+            bool synced = false;
+            if (G.polled) {                                // spin on the flag the last K1 block writes over PCIe
+                const unsigned long long want = G.seq;
+                const auto deadline = t0 + std::chrono::seconds(5);
+                long spins = 0;
+                while (__atomic_load_n(G.h_flag, __ATOMIC_ACQUIRE) != want) {
+                    cpu_relax();
+                    if ((++spins & 0xFFFF) == 0 && clk::now() > deadline) break;   // fall back to the runtime
+                }
+                synced = __atomic_load_n(G.h_flag, __ATOMIC_ACQUIRE) == want;
+            }
+            if (!synced) G_HIP(hipStreamSynchronize(G.stream));        // torques of substep s are on the host
             G.wait_s += secs(t0, clk::now());
         }
         G.bar.wait();
@@ -196,8 +218,9 @@ void run_step(egp_engine *E, Group &G, int tid) {
         if (leader) {
             G.phys_s += secs(t1, clk::now());
             if (G.status.load() == EGP_OK) {
-                G_HIP(hipMemcpyAsync(E->d_state + (size_t)G.e0 * E->ld_s, E->h_state + (size_t)G.e0 * E->ld_s,
-                                     (size_t)m * E->ld_s * sizeof(double), hipMemcpyHostToDevice, G.stream));
+                if (!E->zero_copy)
+                    G_HIP(hipMemcpyAsync(E->d_state + (size_t)G.e0 * E->ld_s, E->h_state + (size_t)G.e0 * E->ld_s,
+                                         (size_t)m * E->ld_s * sizeof(double), hipMemcpyHostToDevice, G.stream));
                 if (G.qM_dirty.exchange(0)) {
                     G_HIP(hipMemcpyAsync(E->d_qM + (size_t)G.e0 * E->ld_m, E->h_qM + (size_t)G.e0 * E->ld_m,
                                          (size_t)m * E->ld_m * sizeof(double), hipMemcpyHostToDevice, G.stream));
@@ -313,6 +336,20 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     E_TRY(hipHostMalloc((void **)&E->h_ee, N * 15 * sizeof(double), hipHostMallocDefault));
     E_TRY(hipHostMalloc((void **)&E->h_headz, N * sizeof(double), hipHostMallocDefault));
     E_TRY(hipHostMalloc((void **)&E->h_xpos, N * E->nbody * 3 * sizeof(double), hipHostMallocDefault));
+    {
+        const char *zc = getenv("EGP_ZERO_COPY");
+        E->zero_copy = !(zc && atoi(zc) == 0);
+        const char *fp = getenv("EGP_FLAG_POLL");
+        E->flag_poll = !(fp && atoi(fp) == 0);
+        void *p1 = nullptr, *p2 = nullptr;
+        if (E->zero_copy && hipHostGetDevicePointer(&p1, E->h_state, 0) == hipSuccess &&
+            hipHostGetDevicePointer(&p2, E->h_torque, 0) == hipSuccess) {
+            E->hd_state = (double *)p1;
+            E->hd_torque = (double *)p2;
+        } else {
+            E->zero_copy = false;
+        }
+    }
     memset(E->h_state, 0, N * E->ld_s * sizeof(double));
     memset(E->h_qM, 0, N * E->ld_m * sizeof(double));
     memset(E->h_headz, 0, N * sizeof(double));
@@ -328,6 +365,15 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
         for (int e = G.e0; e < G.e1; ++e) E->env_group[e] = g;
         E_TRY(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
         E_TRY(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
+        E_TRY(hipMalloc((void **)&G.d_done, sizeof(unsigned)));
+        E_TRY(hipMemset(G.d_done, 0, sizeof(unsigned)));
+        E_TRY(hipHostMalloc((void **)&G.h_flag, sizeof(unsigned long long), hipHostMallocDefault));
+        *G.h_flag = 0;
+        {
+            void *p = nullptr;
+            E_TRY(hipHostGetDevicePointer(&p, G.h_flag, 0));
+            G.hd_flag = (unsigned long long *)p;
+        }
     }
 #undef E_TRY
     const char *prof = getenv("EGP_PROFILE_K1");
@@ -352,6 +398,8 @@ int egp_engine_destroy(egp_engine *E) {
         }
         for (auto &t : G.threads)
             if (t.joinable()) t.join();
+        if (G.d_done) (void)hipFree(G.d_done);
+        if (G.h_flag) (void)hipHostFree(G.h_flag);
         if (G.stream) (void)hipStreamDestroy(G.stream);
         if (G.done) (void)hipEventDestroy(G.done);
         for (auto ev : G.k_beg) (void)hipEventDestroy(ev);

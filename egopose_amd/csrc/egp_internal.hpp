@@ -71,6 +71,7 @@ struct egp_ctx {
 // launches used by the engine (same TU as the kernels)
 int egp_launch_pd_torque_strided(egp_ctx *ctx, const double *qpos, long ld_qpos, const double *qvel, long ld_qvel,
                                  const double *bias, long ld_bias, const double *qM, long ld_qM, const double *action,
-                                 int32_t n, double *torque, hipStream_t stream);
+                                 int32_t n, double *torque, hipStream_t stream, unsigned *done_counter,
+                                 unsigned long long *host_flag, unsigned long long seq);
 const egp_physics_vtable *egp_physics_vt(const egp_physics *p);
 extern "C" int32_t egp_physics_n_env(const egp_physics *p);

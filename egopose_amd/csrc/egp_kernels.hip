@@ -107,6 +107,8 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // row strides (in elements) of the five K1 inputs: dense C-ABI arrays use (nq, nv, nu, nM, nv); the
 // rollout engine passes its packed per-env staging row instead
 struct PdLd { long qpos, qvel, action, qM, bias; };
+// optional completion signal of a K1 launch (counter in HBM, flag in pinned host memory)
+struct PdDone { unsigned *counter; unsigned long long *host_flag; unsigned long long seq; };
 
 template <typename TIO>
 __device__ __forceinline__ void pd_rhs(const DevModel &m, const PdLd &ld, const TIO *qpos, const TIO *qvel, const TIO *action,
@@ -235,7 +237,7 @@ template <typename TIO>
 __global__ __launch_bounds__(256) void k_pd_torque_tree58(DevModel m, PdLd ld, const TIO *__restrict__ qpos,
                                                           const TIO *__restrict__ qvel, const TIO *__restrict__ action,
                                                           const TIO *__restrict__ qM, const TIO *__restrict__ C, int n,
-                                                          TIO *__restrict__ torque, TIO *__restrict__ torque_raw) {
+                                                          TIO *__restrict__ torque, TIO *__restrict__ torque_raw, PdDone done) {
     __shared__ short s_map[PD_NV * PD_NV];
     __shared__ double s_qM[4][PD_NM_MAX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -247,22 +249,37 @@ __global__ __launch_bounds__(256) void k_pd_torque_tree58(DevModel m, PdLd ld, c
         for (int i = lane; i < m.nM; i += 64) s_qM[wave][i] = (double)src[i];
     }
     __syncthreads();
-    if (!valid) return;
-    const int row = lane < PD_NV ? lane : PD_NV - 1;
-    double kp, kd, eq, qv, b;
-    pd_rhs<TIO>(m, ld, qpos, qvel, action, C, env, row, kp, kd, eq, qv, b);
-    const double kd_dt = kd * m.sub_dt;
-    double a[PD_NV];
+    if (valid) {
+        const int row = lane < PD_NV ? lane : PD_NV - 1;
+        double kp, kd, eq, qv, b;
+        pd_rhs<TIO>(m, ld, qpos, qvel, action, C, env, row, kp, kd, eq, qv, b);
+        const double kd_dt = kd * m.sub_dt;
+        double a[PD_NV];
 #pragma unroll
-    for (int j = 0; j < PD_NV; ++j) {
-        const int id = s_map[row * PD_NV + j];
-        double v = id >= 0 ? s_qM[wave][id] : 0.0;
-        a[j] = v + (j == row ? kd_dt : 0.0);
+        for (int j = 0; j < PD_NV; ++j) {
+            const int id = s_map[row * PD_NV + j];
+            double v = id >= 0 ? s_qM[wave][id] : 0.0;
+            a[j] = v + (j == row ? kd_dt : 0.0);
+        }
+        double dinv = 0.0;
+        tree_eliminate<PD_NV - 1>(a, b, dinv, row);
+        const double qacc = b * dinv;
+        pd_store<TIO>(m, env, row, lane < PD_NV, kp, kd, eq, qv, qacc, torque, torque_raw);
     }
-    double dinv = 0.0;
-    tree_eliminate<PD_NV - 1>(a, b, dinv, row);
-    const double qacc = b * dinv;
-    pd_store<TIO>(m, env, row, lane < PD_NV, kp, kd, eq, qv, qacc, torque, torque_raw);
+    if (done.counter) {
+        // completion signal for a host that polls pinned memory instead of synchronising the stream: every block
+        // releases its torques system-wide and counts in; the last one publishes the launch's sequence number
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            const unsigned prev = atomicAdd(done.counter, 1u);
+            if (prev == gridDim.x - 1) {
+                *done.counter = 0u;
+                __threadfence_system();
+                __hip_atomic_store(done.host_flag, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // Generic path (any nv <= 64): one wavefront per env, system in LDS.
@@ -929,13 +946,13 @@ static int launch_obs(egp_ctx *ctx, const T *qpos, const T *qvel, int n, T *obs,
 
 template <typename T>
 static int launch_pd(egp_ctx *ctx, const PdLd &ld, const T *qpos, const T *qvel, const T *action, const T *qM, const T *C, int n,
-                     T *torque, T *torque_raw, hipStream_t stream) {
+                     T *torque, T *torque_raw, hipStream_t stream, PdDone done = PdDone{nullptr, nullptr, 0}) {
     EGP_REQUIRE(ctx, "ctx is NULL");
     EGP_REQUIRE(n >= 0, "n < 0");
     if (n == 0) return EGP_OK;
     EGP_REQUIRE(qpos && qvel && action && qM && C && torque, "NULL pointer");
     if (ctx->pd_variant == 0) {
-        k_pd_torque_tree58<T><<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, C, n, torque, torque_raw);
+        k_pd_torque_tree58<T><<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, C, n, torque, torque_raw, done);
         return after_launch("k_pd_torque_tree58");
     }
     if (ctx->pd_variant == 2) {
@@ -953,9 +970,11 @@ static inline PdLd dense_ld(const egp_ctx *c) { return PdLd{c->dm.nq, c->dm.nv, 
 // engine entry: inputs live in the engine's staging layouts (row strides in doubles)
 int egp_launch_pd_torque_strided(egp_ctx *ctx, const double *qpos, long ld_qpos, const double *qvel, long ld_qvel,
                                  const double *bias, long ld_bias, const double *qM, long ld_qM, const double *action,
-                                 int32_t n, double *torque, hipStream_t stream) {
+                                 int32_t n, double *torque, hipStream_t stream, unsigned *done_counter,
+                                 unsigned long long *host_flag, unsigned long long seq) {
     PdLd ld{ld_qpos, ld_qvel, ctx->dm.nu, ld_qM, ld_bias};
-    return launch_pd<double>(ctx, ld, qpos, qvel, action, qM, bias, n, torque, nullptr, stream);
+    PdDone done{ctx->pd_variant == 0 ? done_counter : nullptr, host_flag, seq};
+    return launch_pd<double>(ctx, ld, qpos, qvel, action, qM, bias, n, torque, nullptr, stream, done);
 }
 
 template <typename T>
