@@ -143,7 +143,7 @@ def main():
                 pass
             res["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes per launch",
-                               "traffic_source": traffic_src, "kernel": "k_pd_torque_reg58<double>",
+                               "traffic_source": traffic_src, "kernel": "k_pd_torque_tree58<double>",
                                "avg_launch_us": avg_s * 1e6, "event_pair_overhead_us_subtracted": tim["event_overhead_us"], "launches": tim["k1_launches"], "envs_per_launch": envs_per_launch,
                                "alg_bytes_per_env_substep": K1_BYTES_PER_ENV}
         else:

@@ -538,70 +538,90 @@ struct ZfSrc {
     }
 };
 
+// tile statistics: thread = column, rows of the tile in chunks of 8 (8 independent loads in flight, then an
+// exact two-pass mean / M2 of the chunk, Chan-merged into the running tile statistics)
 template <typename T>
 __global__ __launch_bounds__(128) void k_zf_partial(ZfSrc<T> src, const int *__restrict__ active, int n, int dim,
                                                     int rows_per_tile, double *__restrict__ ws) {
     const int p = blockIdx.x;
     const int r0 = p * rows_per_tile, r1 = min(n, r0 + rows_per_tile);
     double *out = ws + (long)p * (1 + 2 * dim);
-    int cnt = 0;
-    for (int r = r0; r < r1; ++r) cnt += (!active || active[r]) ? 1 : 0;
-    if (threadIdx.x == 0) out[0] = (double)cnt;
     for (int c = threadIdx.x; c < dim; c += blockDim.x) {
-        double s = 0.0;
-        for (int r = r0; r < r1; ++r)
-            if (!active || active[r]) s += (double)src.at(r, c);
-        const double mean = cnt > 0 ? s / cnt : 0.0;
-        double m2 = 0.0;
-        for (int r = r0; r < r1; ++r)
-            if (!active || active[r]) {
-                const double d = (double)src.at(r, c) - mean;
-                m2 += d * d;
+        double cnt = 0.0, mean = 0.0, m2 = 0.0;
+        for (int rb = r0; rb < r1; rb += 8) {
+            double v[8];
+            int on[8], k = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = rb + i;
+                on[i] = r < r1 && (!active || active[r]);
+                v[i] = on[i] ? (double)src.at(r, c) : 0.0;
+                k += on[i];
             }
+            if (k == 0) continue;
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+            const double mb = s / k;
+            double sb = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sb += on[i] ? (v[i] - mb) * (v[i] - mb) : 0.0;
+            if (cnt == 0.0) {
+                cnt = k; mean = mb; m2 = sb;
+            } else {
+                const double tot = cnt + k, d = mb - mean;
+                m2 += sb + d * d * (cnt * k / tot);
+                mean += d * (k / tot);
+                cnt = tot;
+            }
+        }
         out[1 + c] = mean;
         out[1 + dim + c] = m2;
+        if (c == 0) out[0] = cnt;
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(128) void k_zf_apply(ZfSrc<T> src, int n, int dim, int rows_per_tile, int n_tiles,
-                                                  const double *__restrict__ ws, const double *__restrict__ st_in,
-                                                  double *__restrict__ st_out, int update, double clip,
-                                                  T *__restrict__ y, T *__restrict__ y2, const int *__restrict__ write_mask,
-                                                  int identity) {
-    extern __shared__ double s_ms[];   // mean[dim], inv[dim]
-    const int p = blockIdx.x;
+// one block: Chan-merge the tile partials into the running state, fixed order (deterministic)
+__global__ __launch_bounds__(128) void k_zf_merge(int dim, int n_tiles, const double *__restrict__ ws,
+                                                  const double *__restrict__ st_in, double *__restrict__ st_out) {
     for (int c = threadIdx.x; c < dim; c += blockDim.x) {
-        if (identity) { s_ms[c] = 0.0; s_ms[dim + c] = 1.0; continue; }
         double cnt = st_in[0], mean = st_in[1 + c], S = st_in[1 + dim + c];
-        if (update) {
-            for (int q = 0; q < n_tiles; ++q) {   // Chan merge, fixed order -> deterministic
-                const double *pp = ws + (long)q * (1 + 2 * dim);
-                const double nb = pp[0];
-                if (nb > 0.0) {
-                    const double mb = pp[1 + c], Sb = pp[1 + dim + c];
-                    if (cnt == 0.0) {
-                        cnt = nb; mean = mb; S = Sb;
-                    } else {
-                        const double d = mb - mean, tot = cnt + nb;
-                        S = S + Sb + d * d * (cnt * nb / tot);
-                        mean = mean + d * (nb / tot);
-                        cnt = tot;
-                    }
+        for (int q = 0; q < n_tiles; ++q) {
+            const double *pp = ws + (long)q * (1 + 2 * dim);
+            const double nb = pp[0];
+            if (nb > 0.0) {
+                const double mb = pp[1 + c], Sb = pp[1 + dim + c];
+                if (cnt == 0.0) {
+                    cnt = nb; mean = mb; S = Sb;
+                } else {
+                    const double d = mb - mean, tot = cnt + nb;
+                    S = S + Sb + d * d * (cnt * nb / tot);
+                    mean = mean + d * (nb / tot);
+                    cnt = tot;
                 }
             }
-            if (p == 0) {
-                st_out[1 + c] = mean;
-                st_out[1 + dim + c] = S;
-                if (c == 0) st_out[0] = cnt;
-            }
         }
+        st_out[1 + c] = mean;
+        st_out[1 + dim + c] = S;
+        if (c == 0) st_out[0] = cnt;
+    }
+}
+
+// y = clip((x - mean) / (std + 1e-8)) with the statistics in `st` (identity: raw copy)
+template <typename T>
+__global__ __launch_bounds__(128) void k_zf_apply(ZfSrc<T> src, int n, int dim, int rows_per_block, const double *__restrict__ st,
+                                                  double clip, T *__restrict__ y, T *__restrict__ y2,
+                                                  const int *__restrict__ write_mask, int identity) {
+    extern __shared__ double s_ms[];   // mean[dim], inv[dim]
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+        if (identity) { s_ms[c] = 0.0; s_ms[dim + c] = 1.0; continue; }
+        const double cnt = st[0], mean = st[1 + c], S = st[1 + dim + c];
         const double var = cnt > 1.0 ? S / (cnt - 1.0) : mean * mean;
         s_ms[c] = mean;
         s_ms[dim + c] = 1.0 / (sqrt(var) + 1e-8);
     }
     __syncthreads();
-    const int r0 = p * rows_per_tile, r1 = min(n, r0 + rows_per_tile);
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
     const long e0 = (long)r0 * dim, e1 = (long)r1 * dim;
     for (long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
         const int c = e % dim;
@@ -1005,13 +1025,12 @@ static int launch_features(egp_ctx *ctx, const T *cur, const T *prev, const T *e
     return after_launch("k_pose_features");
 }
 
+// 8-row tiles while that gives <= 512 partials (the merge is one block walking them in order), larger tiles beyond
 static inline void zf_tiling(int n, int *rows_per_tile, int *n_tiles) {
-    int tiles = (n + 63) / 64;
-    if (tiles > 256) tiles = 256;
-    if (tiles < 1) tiles = 1;
-    *rows_per_tile = (n + tiles - 1) / tiles;
-    *n_tiles = (n + *rows_per_tile - 1) / *rows_per_tile;
-    if (*n_tiles < 1) *n_tiles = 1;
+    int rpt = 8;
+    while ((n + rpt - 1) / rpt > 512) rpt *= 2;
+    *rows_per_tile = rpt;
+    *n_tiles = n > 0 ? (n + rpt - 1) / rpt : 1;
 }
 
 template <typename T>
@@ -1030,11 +1049,13 @@ static int launch_zfilter_src(const ZfSrc<T> &src, const int *active, int n, int
     zf_tiling(n, &rpt, &nt);
     if (update) {
         k_zf_partial<T><<<dim3(nt), dim3(128), 0, (hipStream_t)stream>>>(src, active, n, dim, rpt, (double *)ws);
-        int rc = after_launch("k_zf_partial");
+        k_zf_merge<<<dim3(1), dim3(128), 0, (hipStream_t)stream>>>(dim, nt, (const double *)ws, st_in, st_out);
+        int rc = after_launch("k_zf_partial/merge");
         if (rc != EGP_OK) return rc;
     }
-    k_zf_apply<T><<<dim3(nt), dim3(128), 2 * dim * sizeof(double), (hipStream_t)stream>>>(
-        src, n, dim, rpt, nt, (const double *)ws, st_in, st_out, update, clip, y, y2, write_mask, identity);
+    const int rows_per_block = 16;
+    k_zf_apply<T><<<dim3((n + rows_per_block - 1) / rows_per_block), dim3(128), 2 * dim * sizeof(double), (hipStream_t)stream>>>(
+        src, n, dim, rows_per_block, update ? st_out : st_in, clip, y, y2, write_mask, identity);
     return after_launch("k_zf_apply");
 }
 
