@@ -586,18 +586,27 @@ __global__ __launch_bounds__(128) void k_zf_merge(int dim, int n_tiles, const do
                                                   const double *__restrict__ st_in, double *__restrict__ st_out) {
     for (int c = threadIdx.x; c < dim; c += blockDim.x) {
         double cnt = st_in[0], mean = st_in[1 + c], S = st_in[1 + dim + c];
-        for (int q = 0; q < n_tiles; ++q) {
-            const double *pp = ws + (long)q * (1 + 2 * dim);
-            const double nb = pp[0];
-            if (nb > 0.0) {
-                const double mb = pp[1 + c], Sb = pp[1 + dim + c];
-                if (cnt == 0.0) {
-                    cnt = nb; mean = mb; S = Sb;
-                } else {
-                    const double d = mb - mean, tot = cnt + nb;
-                    S = S + Sb + d * d * (cnt * nb / tot);
-                    mean = mean + d * (nb / tot);
-                    cnt = tot;
+        for (int q0 = 0; q0 < n_tiles; q0 += 8) {
+            double nb[8], mb[8], Sb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {          // 24 independent loads in flight, then the ordered merge
+                const int q = q0 + i;
+                const double *pp = ws + (long)(q < n_tiles ? q : 0) * (1 + 2 * dim);
+                nb[i] = q < n_tiles ? pp[0] : 0.0;
+                mb[i] = pp[1 + c];
+                Sb[i] = pp[1 + dim + c];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (nb[i] > 0.0) {
+                    if (cnt == 0.0) {
+                        cnt = nb[i]; mean = mb[i]; S = Sb[i];
+                    } else {
+                        const double d = mb[i] - mean, tot = cnt + nb[i];
+                        S = S + Sb[i] + d * d * (cnt * nb[i] / tot);
+                        mean = mean + d * (nb[i] / tot);
+                        cnt = tot;
+                    }
                 }
             }
         }
@@ -1053,7 +1062,7 @@ static int launch_zfilter_src(const ZfSrc<T> &src, const int *active, int n, int
         int rc = after_launch("k_zf_partial/merge");
         if (rc != EGP_OK) return rc;
     }
-    const int rows_per_block = 16;
+    const int rows_per_block = n <= 8192 ? 2 : 16;     // small batches: enough blocks to cover the latency
     k_zf_apply<T><<<dim3((n + rows_per_block - 1) / rows_per_block), dim3(128), 2 * dim * sizeof(double), (hipStream_t)stream>>>(
         src, n, dim, rows_per_block, update ? st_out : st_in, clip, y, y2, write_mask, identity);
     return after_launch("k_zf_apply");
