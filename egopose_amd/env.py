@@ -152,6 +152,87 @@ class HumanoidEnv:
         for sim in self._sims.values():
             sim.close()
         self._sims.clear()
+        if self._single is not None:
+            self._single.close()
+            self._single = None
+
+    # ------------------------------------------------------------------ single-env facade (batch of one, same kernels)
+    def _one(self):
+        if self._single is None:
+            self._single = BatchedSim(self, 1, 0, n_threads=1, n_groups=1)
+        return self._single
+
+    @property
+    def data(self):
+        """mjData-like view of the single env: qpos / qvel (host copies of the drained state)."""
+        eng = self._one().engine
+        return types.SimpleNamespace(qpos=eng.qpos_host[0].copy(), qvel=eng.qvel_host[0].copy())
+
+    def reset(self):
+        """MujocoEnv.reset + HumanoidEnv.reset_model (envs/common/mujoco_env.py:84-93, humanoid_v1.py:201-231)."""
+        import torch
+        sim = self._one()
+        if self.fix_start_state is not None:
+            qpos, qvel = self.fix_start_state[:self.skel.nq], self.fix_start_state[self.skel.nq:]
+        else:
+            e_ind, s_ind = self.sample_reset(1)
+            self.set_expert(int(e_ind[0]))
+            self.start_ind = int(s_ind[0])
+            qpos = self.expert["qpos"][self.start_ind].copy()
+            qvel = self.expert["qvel"][self.start_ind].copy()
+            if self.cfg.env_init_noise > 0:
+                qpos[7:] += self.np_random.normal(0.0, self.cfg.env_init_noise, size=self.skel.nq - 7)
+        self.cur_t = 0
+        sim.engine.reset(np.array([0]), qpos[None], qvel[None])
+        torch.cuda.synchronize()
+        self.prev_qpos = None
+        self.bquat = self.get_body_quat()
+        return self.get_obs()
+
+    def step(self, a):
+        """HumanoidEnv.step (humanoid_v1.py:179-199) through the engine: 15 x {K1 <-> physics}."""
+        import torch
+        sim = self._one()
+        eng = sim.engine
+        self.prev_qpos = eng.qpos_host[0].copy()
+        self.prev_qvel = eng.qvel_host[0].copy()
+        self.prev_bquat = self.bquat.copy()
+        act = torch.as_tensor(np.asarray(a, dtype=np.float64).reshape(1, -1), device=eng.qpos.device)
+        eng.step_async(0, act)
+        eng.wait(0)
+        torch.cuda.synchronize()
+        self.cur_t += 1
+        self.bquat = self.get_body_quat()
+        self.data_qpos = eng.qpos_host[0].copy()
+        self.ee_wpos = eng.ee_wpos.cpu().numpy()[0]
+        head_z = float(eng.head_z[0])
+        if self.fix_head_lb is not None:
+            fail = head_z < self.fix_head_lb
+        else:
+            fail = self.expert is not None and head_z < self.expert["head_height_lb"] - 0.1
+        end = self.cur_t >= (self.cfg.env_episode_len if self.fix_len is None else self.fix_len)
+        return self.get_obs(), 1.0, bool(fail or end), {"fail": bool(fail), "end": bool(end)}
+
+    def get_obs(self):
+        sim = self._one()
+        return sim.ctx.obs(sim.engine.qpos, sim.engine.qvel).cpu().numpy()[0]
+
+    get_full_obs = get_obs
+
+    def get_body_quat(self):
+        sim = self._one()
+        return sim.ctx.body_quat(sim.engine.qpos).cpu().numpy()[0]
+
+    def get_ee_pos(self, transform):
+        """World end-effector positions, or root-relative in the heading frame (humanoid_v1.py:98-111)."""
+        sim = self._one()
+        eng = sim.engine
+        if transform is None:
+            return eng.ee_wpos.cpu().numpy()[0]
+        if transform != "heading":
+            raise AssertionError("only the 'heading' transform is on the hot path")
+        f = sim.ctx.pose_features(eng.qpos, eng.qpos, eng.ee_wpos)
+        return f["ee_pos"].cpu().numpy()[0]
 
     def sample_reset(self, n):
         """Reset sampling of reset_model (humanoid_v1.py:206-216) for n envs at once:

@@ -10,7 +10,7 @@ import numpy as np
 
 
 def quat_space_reward_v3(env, state, action, info):
-    sim = env.batched(1)
+    sim = env._one()
     import torch
     dev = torch.device("cuda", sim.ctx.device)
     sim.ctx.set_reward_weights(env.cfg.reward_weights)

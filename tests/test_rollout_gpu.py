@@ -114,3 +114,47 @@ def test_full_iteration_updates_parameters_and_filter(workspace):
     log2, *_ = tr.iteration(1, 32 * 16)
     assert tr.env.end_reward == pytest.approx(log2.avg_c_reward * cfg.gamma / (1 - cfg.gamma))
     tr.close()
+
+
+def test_single_env_facade_matches_oracle_env(workspace, skel):
+    """HumanoidEnv.reset/step + reward_func['quat_v3'] on a batch of one == the oracle's CPU env (eval-style use)."""
+    from egopose_amd.config import Config
+    from egopose_amd.env import HumanoidEnv
+    from egopose_amd.physics import SurrogatePhysics
+    from egopose_amd.reward import reward_func
+    from oracle.cpu_env import OracleHumanoidEnv
+    from oracle import humanoid as H
+    os.chdir(workspace)
+    cfg = Config("subject_03", create_dirs=False)
+    cfg.env_episode_len = 6
+    env = HumanoidEnv(cfg)
+    env.seed(3)
+    env.load_experts(cfg.takes["train"], cfg.expert_feat_file, cfg.cnn_feat_file)
+    env.end_reward = 0.25
+    obs = env.reset()
+    ph = SurrogatePhysics(skel, 1)
+    ref = OracleHumanoidEnv(skel, cfg, ph, env.expert_arr, env.cnn_feat)
+    ref.end_reward = 0.25
+    ref.expert_ind, ref.start_ind, ref.cur_t = env.expert_ind, env.start_ind, 0
+    ph.reset(0, env.expert["qpos"][env.start_ind], env.expert["qvel"][env.start_ind])
+    ref._drain(True)
+    ref.bquat = H.body_quat(ref.qpos, skel.body_qpos_start, skel.body_ndof)[0]
+    np.testing.assert_allclose(obs, ref._obs(), rtol=1e-10, atol=1e-10)
+    assert env.get_episode_cnn_feat().shape == (6 + 2 * cfg.fr_margin, 128)
+    rng = np.random.RandomState(0)
+    done = False
+    while not done:
+        a = rng.normal(size=52) * 0.2
+        o1, r1, done, info = env.step(a)
+        o2, r2, d2, info2 = ref.step(a)
+        assert (r1, done, info) == (r2, d2, info2)
+        np.testing.assert_allclose(o1, o2, rtol=1e-8, atol=1e-8)
+        c1, ci1 = reward_func[cfg.reward_id](env, None, a, info)
+        c2, ci2 = ref.reward(None, a, info2)
+        np.testing.assert_allclose(c1, c2, rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(ci1, ci2, rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(env.get_ee_pos("heading"), H.ee_pos(ref.qpos, ref.xpos[skel.ee_body].ravel())[0], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(env.data.qpos, ref.qpos, rtol=1e-9, atol=1e-9)
+    assert env.cur_t <= 6
+    ph.close()
+    env.close()
