@@ -51,9 +51,10 @@ def main():
     ap.add_argument("--groups", type=int, default=2)
     ap.add_argument("--min-batch", type=int, default=0, help="env-steps per GPU per iteration (0 = config: 50000)")
     ap.add_argument("--cfg", default="subject_03")
-    ap.add_argument("--cpu-steps", type=int, default=3000)
+    ap.add_argument("--cpu-steps", type=int, default=24000, help="env-steps of the CPU baseline sample (~15 s on 2 cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-k1-events", action="store_true")
+    ap.add_argument("--k1-event-every", type=int, default=8, help="bracket K1 with HIP events on every Nth env-step")
     args = ap.parse_args()
 
     import numpy as np
@@ -93,7 +94,7 @@ def main():
         it += 1
     eng = tr.agent._get_rollout().engine
     if not args.no_k1_events:
-        eng.set_profile(True)
+        eng.set_profile(True, every=args.k1_event_every)
     eng.reset_timing()
     barrier()
     t0 = time.time()
@@ -144,7 +145,7 @@ def main():
             res["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes per launch",
                                "traffic_source": traffic_src, "kernel": "k_pd_torque_tree58<double>",
-                               "avg_launch_us": avg_s * 1e6, "event_pair_overhead_us_subtracted": tim["event_overhead_us"], "launches": tim["k1_launches"], "envs_per_launch": envs_per_launch,
+                               "avg_launch_us": avg_s * 1e6, "event_pair_overhead_us_subtracted": tim["event_overhead_us"], "launches_timed": tim["k1_launches"], "event_sampling": "every %d-th env-step of each group inside the timed region" % args.k1_event_every, "envs_per_launch": envs_per_launch,
                                "alg_bytes_per_env_substep": K1_BYTES_PER_ENV}
         else:
             res["roofline"] = None

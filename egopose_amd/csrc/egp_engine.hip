@@ -87,6 +87,7 @@ struct Group {
     unsigned long long *hd_flag = nullptr;
     unsigned long long seq = 0;
     bool polled = false;                      // the launch in flight publishes to h_flag
+    bool prof_now = false;                    // this env-step brackets its K1 launches with events
     char err[256] = "";
     // timing (leader only)
     double phys_s = 0.0, wait_s = 0.0, k1_ms = 0.0, ev_overhead_ms = 0.0;
@@ -104,6 +105,7 @@ struct egp_engine {
     int nq = 0, nv = 0, nu = 0, nM = 0, nbody = 0, frame_skip = 0;
     int ld_s = 0, ld_m = 0, off_qpos = 0, off_qvel = 0, off_bias = 0;   // state / inertia row strides (doubles)
     std::atomic<bool> profile_k1{false};
+    int profile_every = 1;                    // bracket K1 with events on every Nth env-step of a group
     bool zero_copy = false;                   // K1 reads state rows / writes torques in pinned host memory directly
     bool flag_poll = false;                   // leader polls a pinned completion flag instead of hipStreamSynchronize
     double *hd_state = nullptr, *hd_torque = nullptr;   // device-side aliases of h_state / h_torque
@@ -155,7 +157,7 @@ void fail(Group &G, int code, const char *what, const char *detail) {
 // leader only: K1 over the whole group + torque download
 void enqueue_k1(egp_engine *E, Group &G, int substep) {
     const int m = G.e1 - G.e0;
-    const bool prof = E->profile_k1.load(std::memory_order_relaxed) && !G.k_beg.empty();
+    const bool prof = G.prof_now;
     if (prof) G_HIP(hipEventRecord(G.k_beg[substep], G.stream));
     const double *st = (E->zero_copy ? E->hd_state : E->d_state) + (size_t)G.e0 * E->ld_s;
     double *tq = (E->zero_copy ? E->hd_torque : E->d_torque) + (size_t)G.e0 * E->nu;
@@ -174,9 +176,9 @@ void run_step(egp_engine *E, Group &G, int tid) {
     const int FS = E->frame_skip;
     const int m = G.e1 - G.e0;
     const int my0 = G.e0 + (int)((long)m * tid / G.n_threads), my1 = G.e0 + (int)((long)m * (tid + 1) / G.n_threads);
-    const bool prof = E->profile_k1.load(std::memory_order_relaxed) && !G.k_beg.empty();
     if (leader) {
-        G.polled = E->flag_poll && E->zero_copy && !prof && E->ctx->pd_variant == 0;
+        G.prof_now = E->profile_k1.load(std::memory_order_relaxed) && !G.k_beg.empty() && (G.job % E->profile_every == 0);
+        G.polled = E->flag_poll && E->zero_copy && E->ctx->pd_variant == 0;
         if (G.ready) G_HIP(hipStreamWaitEvent(G.stream, G.ready, 0));
         // env.prev_qpos = data.qpos.copy() (humanoid_v1.py:182): kept on the device for the reward kernel
         G_HIP(hipMemcpyAsync(E->d_prev_qpos + (size_t)G.e0 * E->nq, E->d_qpos + (size_t)G.e0 * E->nq, (size_t)m * E->nq * sizeof(double),
@@ -240,7 +242,7 @@ void run_step(egp_engine *E, Group &G, int tid) {
             }
         }
     }
-    if (leader && prof && G.status.load() == EGP_OK) {
+    if (leader && G.prof_now && G.status.load() == EGP_OK) {
         G_HIP(hipStreamSynchronize(G.stream));
         for (int s = 0; s < FS; ++s) {
             float ms = 0.f;
@@ -524,6 +526,7 @@ int egp_engine_timing(egp_engine *E, double *phys_s, double *gpu_wait_s, double 
 
 int egp_engine_set_profile(egp_engine *E, int on) {
     EGP_REQUIRE(E, "engine is NULL");
+    E->profile_every = on > 1 ? on : 1;            // on = N > 1: sample every Nth env-step of each group
     for (auto &G : E->groups) EGP_REQUIRE(G.pending == 0, "cannot switch profiling while a group is stepping");
     if (on) {
         EGP_HIP_CHECK(hipSetDevice(E->ctx->device));

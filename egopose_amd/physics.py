@@ -172,8 +172,9 @@ class RolloutEngine:
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         L.check(self.lib.egp_engine_wait(self.handle, int(group), s), "egp_engine_wait")
 
-    def set_profile(self, on=True):
-        L.check(self.lib.egp_engine_set_profile(self.handle, 1 if on else 0), "egp_engine_set_profile")
+    def set_profile(self, on=True, every=1):
+        """K1 timing by HIP events on the launch streams; ``every`` = N samples every Nth env-step."""
+        L.check(self.lib.egp_engine_set_profile(self.handle, (max(1, int(every)) if on else 0)), "egp_engine_set_profile")
 
     def reset_timing(self):
         L.check(self.lib.egp_engine_reset_timing(self.handle), "egp_engine_reset_timing")

@@ -289,7 +289,7 @@ int egp_engine_timing(egp_engine *e, double *phys_s, double *gpu_wait_s, double 
 int egp_engine_reset_timing(egp_engine *e);
 int64_t egp_engine_inertia_uploads(egp_engine *e);
 double egp_engine_event_overhead_ms(egp_engine *e);   /* calibrated cost of an empty begin/end event pair, already subtracted from k1_ms_events */   /* group-level qM uploads done inside step (not resets) */
-int egp_engine_set_profile(egp_engine *e, int on);   /* record HIP events around every K1 launch */
+int egp_engine_set_profile(egp_engine *e, int on);   /* 0 off; 1: HIP events around every K1 launch; N>1: on every Nth env-step */
 int egp_engine_layout(egp_engine *e, int32_t *pack_ld, int32_t *n_env, int32_t *n_threads, int32_t *n_groups);
 int egp_engine_group_range(egp_engine *e, int32_t group, int32_t *env_begin, int32_t *env_end);
 int32_t egp_physics_n_env(const egp_physics *p);
