@@ -17,6 +17,7 @@ merges instead of sample-by-sample inside worker 0 only.
 from __future__ import annotations
 
 import math
+import os
 import time
 
 import numpy as np
@@ -95,11 +96,16 @@ class LockstepRollout:
         self.margin = int(self.cfg.fr_margin)
         self.gen = torch.Generator(device=self.dev)
         self.gen.manual_seed(int(seed))
+        with torch.cuda.device(self.dev):
+            torch.cuda.manual_seed(int(seed) + 7919)     # default generator feeds the (graph-captured) action noise
         self.groups = [self.engine.group_range(g) for g in range(self.engine.n_groups)]
         self.rings = [_PinnedRing(4, b - a, self.dev) for a, b in self.groups]
         self.timing = {}
         self._events = [None] * len(self.groups)
         self.up = _Uploader(self.dev, max(4096, self.N))
+        self.use_graphs = os.environ.get("EGP_POLICY_GRAPH", "1") != "0"
+        self._graphs = None                 # per group: captured hipGraph of the policy step
+        self._graph_key = None
         self.pool_batch = max(256, self.N // 2)
         self._pool, self._pool_pos = None, 0
 
@@ -157,6 +163,58 @@ class LockstepRollout:
         self.zf_state = new
         return out
 
+    # ------------------------------------------------------------------ policy step (eager or captured in a hipGraph)
+    def _mean_std(self, x):
+        if hasattr(self.policy_net, "mean_std"):
+            return self.policy_net.mean_std(x)
+        dist = self.policy_net(x)
+        return dist.loc, dist.scale
+
+    def _policy_body(self, g):
+        """action = mean + std * N(0,1) for group g, reading / writing only static buffers (graph-capturable)."""
+        a, b = self.groups[g]
+        x = torch.cat((self.v_out[a:b][self._ar[g], self._g_tidx[g]], self._g_state[g].to(self.v_out.dtype)), dim=1)
+        mean, std = self._mean_std(x)
+        self._g_act[g].copy_(torch.addcmul(mean, std, torch.randn_like(mean)))
+
+    def _ensure_static(self, ndt):
+        """Persistent buffers (and, when possible, one captured hipGraph per group) for the per-tick policy step:
+        ~13 launch-bound torch ops become one graph launch."""
+        # the captured graph holds raw pointers to the policy weights: moving the module (e.g. the reference's
+        # `with to_cpu(...)` around checkpoint saving) re-allocates them, so the key includes their addresses
+        key = (ndt, self.policy_vs_net.v_hdim) + tuple(p.data_ptr() for p in self.policy_net.parameters())
+        if self._graph_key == key:
+            return
+        dev, f64 = self.dev, torch.float64
+        self.v_out = torch.zeros(self.N, self.T_ep, self.policy_vs_net.v_hdim, dtype=ndt, device=dev)
+        self._ar = [torch.arange(b - a, device=dev) for a, b in self.groups]
+        self._g_tidx = [torch.zeros(b - a, dtype=torch.int64, device=dev) for a, b in self.groups]
+        self._g_state = [torch.zeros(b - a, self.ctx.obs_dim, dtype=f64, device=dev) for a, b in self.groups]
+        self._g_act = [torch.zeros(b - a, self.ctx.nu, dtype=f64, device=dev) for a, b in self.groups]
+        self._graph_key = key
+        self._graphs = None
+        if not self.use_graphs:
+            return
+        try:
+            cur = torch.cuda.current_stream(dev)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    for g in range(len(self.groups)):
+                        self._policy_body(g)
+            cur.wait_stream(side)
+            graphs = []
+            for g in range(len(self.groups)):
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    self._policy_body(g)
+                graphs.append(gr)
+            self._graphs = graphs
+        except Exception as e:                       # capture is an optimisation: the eager path is the same arithmetic
+            self._graphs = None
+            self.graph_error = repr(e)
+
     # ------------------------------------------------------------------ one sampling pass
     @torch.no_grad()
     def sample(self, min_batch_size, end_reward=0.0):
@@ -179,7 +237,7 @@ class LockstepRollout:
             cinfo=torch.zeros(T_max, N, 5, dtype=f64, device=dev), exps=torch.ones(T_max, N, dtype=torch.int64, device=dev))
         host = dict(valid=np.zeros((T_max, N), bool), done=np.zeros((T_max, N), bool),
                     e_ind=np.zeros((T_max, N), np.int64), s_ind=np.zeros((T_max, N), np.int64))
-        self.v_out = torch.empty(N, T_ep, H, dtype=ndt, device=dev)
+        self._ensure_static(ndt)
         self.cur_t = np.zeros(N, np.int64)
         self.e_ind = np.zeros(N, np.int64)
         self.s_ind = np.zeros(N, np.int64)
@@ -199,34 +257,39 @@ class LockstepRollout:
         ep_lens = []
         tick = [0] * len(self.groups)
         tm = dict(policy=0.0, wait=0.0, post=0.0, reset=0.0)
-        ar = [torch.arange(b - a, device=dev) for a, b in self.groups]
 
         # ---- initial reset of every slot; group g's first state goes to rec["states"][0, a:b]
         self._reset_slots(np.arange(N))
         self._obs_filter(0, N, rec["states"][0])
+
+        plain_noise = (not self.mean_action) and self.noise_rate >= 1.0
 
         def pre_step(g):
             a, b = self.groups[g]
             t0 = time.time()
             k = tick[g]
             t_idx = self.up(np.minimum(self.cur_t[a:b], T_ep - 1))
-            x = torch.cat((self.v_out[a:b][ar[g], t_idx], rec["states"][k, a:b].to(ndt)), dim=1)
-            if hasattr(self.policy_net, "mean_std"):
-                mean, std = self.policy_net.mean_std(x)
+            if plain_noise:
+                # static-buffer form (one hipGraph launch when captured)
+                self._g_tidx[g].copy_(t_idx)
+                self._g_state[g].copy_(rec["states"][k, a:b])
+                if self._graphs is not None:
+                    self._graphs[g].replay()
+                else:
+                    self._policy_body(g)
+                rec["actions"][k, a:b] = self._g_act[g]
             else:
-                dist = self.policy_net(x)
-                mean, std = dist.loc, dist.scale
-            if self.mean_action:
-                action = mean
-                rec["exps"][k, a:b] = 0
-            elif self.noise_rate >= 1.0:
-                action = torch.addcmul(mean, std, torch.randn(mean.shape, dtype=mean.dtype, device=dev, generator=self.gen))
-            else:
-                use_mean = torch.rand(b - a, device=dev, generator=self.gen) >= self.noise_rate
-                noise = torch.randn(mean.shape, dtype=mean.dtype, device=dev, generator=self.gen)
-                action = torch.where(use_mean.unsqueeze(1), mean, mean + std * noise)
-                rec["exps"][k, a:b] = (~use_mean).to(torch.int64)
-            rec["actions"][k, a:b] = action              # float64 copy the engine reads in place
+                x = torch.cat((self.v_out[a:b][self._ar[g], t_idx], rec["states"][k, a:b].to(ndt)), dim=1)
+                mean, std = self._mean_std(x)
+                if self.mean_action:
+                    action = mean
+                    rec["exps"][k, a:b] = 0
+                else:
+                    use_mean = torch.rand(b - a, device=dev, generator=self.gen) >= self.noise_rate
+                    noise = torch.randn(mean.shape, dtype=mean.dtype, device=dev, generator=self.gen)
+                    action = torch.where(use_mean.unsqueeze(1), mean, mean + std * noise)
+                    rec["exps"][k, a:b] = (~use_mean).to(torch.int64)
+                rec["actions"][k, a:b] = action          # float64 copy the engine reads in place
             ev = torch.cuda.Event()
             ev.record()
             self._events[g] = ev          # must outlive the workers' hipStreamWaitEvent
@@ -312,6 +375,6 @@ class LockstepRollout:
             self.running_state.from_device_state(self.zf_state)
         torch.cuda.synchronize(dev)
         log.sample_time = time.time() - t_start
-        tm.update(ticks=T_used, quota=quota, **eng.timing())
+        tm.update(ticks=T_used, quota=quota, policy_graph=self._graphs is not None, **eng.timing())
         self.timing = tm
         return batch, log
