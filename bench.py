@@ -133,7 +133,7 @@ def main():
         }
         if tim["k1_launches"] > 0:
             avg_s = tim["k1_ms"] * 1e-3 / tim["k1_launches"]
-            envs_per_launch = args.envs / float(args.groups)
+            envs_per_launch = args.envs / float(args.groups) / max(1, eng.launches_per_substep)
             achieved = K1_BYTES_PER_ENV * envs_per_launch / avg_s
             traffic, traffic_src = None, None
             try:      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)

@@ -121,6 +121,7 @@ SIGNATURES = {
     "egp_engine_set_profile": (C.c_int, [vp, C.c_int]),
     "egp_engine_layout": (C.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p]),
     "egp_engine_group_range": (C.c_int, [vp, _i32, c_int_p, c_int_p]),
+    "egp_engine_launches_per_substep": (C.c_int, [vp]),
 }
 
 _lib = None

@@ -23,6 +23,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -64,8 +65,23 @@ struct SpinBarrier {
     }
 };
 
+// A slice of a group with its own K1 launch, completion counter and pinned completion flag (pipelined mode)
+struct Chunk {
+    int e0 = 0, e1 = 0;
+    unsigned *d_done = nullptr;
+    unsigned long long *h_flag = nullptr, *hd_flag = nullptr;
+    hipStream_t stream = nullptr;             // own launch stream (EGP_CHUNK_STREAMS=1) or the group's
+    bool own_stream = false;
+    unsigned long long seq = 0;               // sequence number of the last launch
+    unsigned long long base = 0;              // seq when the current env-step was posted
+    alignas(64) std::atomic<long> phys_done{0};   // worker completions of this env-step (cumulative over substeps)
+    std::atomic<int> qM_dirty{0};
+};
+
 struct Group {
     int e0 = 0, e1 = 0;                       // env range [e0, e1)
+    std::unique_ptr<Chunk[]> chunks;          // pipelined mode: n_chunks >= 2 slices, else unused
+    int n_chunks = 0;
     int n_threads = 1;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;                // recorded after the last upload of an env-step
@@ -88,6 +104,7 @@ struct Group {
     unsigned long long seq = 0;
     bool polled = false;                      // the launch in flight publishes to h_flag
     bool prof_now = false;                    // this env-step brackets its K1 launches with events
+    bool pipelined_job = false;               // mode of the env-step in flight (fixed when it is posted)
     char err[256] = "";
     // timing (leader only)
     double phys_s = 0.0, wait_s = 0.0, k1_ms = 0.0, ev_overhead_ms = 0.0;
@@ -114,7 +131,7 @@ struct egp_engine {
            *h_headz = nullptr, *h_xpos = nullptr;
     std::vector<Group> groups;
     std::vector<int64_t> epoch;               // last drained inertia epoch per env (-1 = never)
-    std::vector<int> env_group;
+    std::vector<int> env_group, env_chunk;
 };
 
 namespace {
@@ -130,7 +147,11 @@ int drain_env(egp_engine *E, int env, bool with_xpos) {
     }
     int rc = E->vt->drain(E->vt->user, env, row + E->off_qpos, row + E->off_qvel, qM, row + E->off_bias, xp);
     if (rc != 0) return EGP_E_PHYSICS;
-    if (qM) E->groups[E->env_group[env]].qM_dirty.store(1, std::memory_order_relaxed);
+    if (qM) {
+        Group &G = E->groups[E->env_group[env]];
+        G.qM_dirty.store(1, std::memory_order_relaxed);
+        if (G.n_chunks) G.chunks[E->env_chunk[env]].qM_dirty.store(1, std::memory_order_relaxed);
+    }
     if (with_xpos) {
         memcpy(E->h_qpos + (size_t)env * E->nq, row + E->off_qpos, E->nq * sizeof(double));
         memcpy(E->h_qvel + (size_t)env * E->nv, row + E->off_qvel, E->nv * sizeof(double));
@@ -224,6 +245,7 @@ void run_step(egp_engine *E, Group &G, int tid) {
                     G_HIP(hipMemcpyAsync(E->d_state + (size_t)G.e0 * E->ld_s, E->h_state + (size_t)G.e0 * E->ld_s,
                                          (size_t)m * E->ld_s * sizeof(double), hipMemcpyHostToDevice, G.stream));
                 if (G.qM_dirty.exchange(0)) {
+                    for (int c = 0; c < G.n_chunks; ++c) G.chunks[c].qM_dirty.store(0, std::memory_order_relaxed);
                     G_HIP(hipMemcpyAsync(E->d_qM + (size_t)G.e0 * E->ld_m, E->h_qM + (size_t)G.e0 * E->ld_m,
                                          (size_t)m * E->ld_m * sizeof(double), hipMemcpyHostToDevice, G.stream));
                     G.qM_uploads += 1;
@@ -254,6 +276,134 @@ void run_step(egp_engine *E, Group &G, int tid) {
     }
 }
 
+inline bool pipelined_mode(const egp_engine *E, const Group &G) {
+    return G.n_chunks >= 2 && G.n_threads >= 3 && E->flag_poll && E->zero_copy && E->ctx->pd_variant == 0;
+}
+
+// Pipelined env-step: the group is cut into chunks, each with its own K1 launch and completion flag.
+//   leader (tid 0): owns the stream. Launches K1(chunk, s+1) as soon as every worker has finished the physics of
+//                   (chunk, s) -- no physics of its own, so a launch never waits behind a slice of envs.
+//   workers:        walk the chunks in order; for (chunk, s) spin on the chunk's pinned flag until the torques of
+//                   substep s have landed, advance their slice of the chunk, bump the chunk's counter.
+// While K1 of one chunk is in flight (launch + PCIe reads + solve + flag write, ~30 us whatever the size) the
+// workers are inside the other chunks, so the fixed K1 latency is hidden behind physics instead of added to it.
+void run_step_pipelined(egp_engine *E, Group &G, int tid) {
+    const int FS = E->frame_skip;
+    const int NC = G.n_chunks;
+    const int W = G.n_threads - 1;
+    auto launch = [&](Chunk &C, int substep, int ci) {
+        const bool prof = G.prof_now;
+        const int ev = substep * NC + ci;
+        if (prof) G_HIP(hipEventRecord(G.k_beg[ev], C.stream));
+        const double *st = E->hd_state + (size_t)C.e0 * E->ld_s;
+        int rc = egp_launch_pd_torque_strided(E->ctx, st + E->off_qpos, E->ld_s, st + E->off_qvel, E->ld_s, st + E->off_bias, E->ld_s,
+                                              E->d_qM + (size_t)C.e0 * E->ld_m, E->ld_m, G.action + (size_t)C.e0 * E->nu, C.e1 - C.e0,
+                                              E->hd_torque + (size_t)C.e0 * E->nu, C.stream, C.d_done, C.hd_flag, ++C.seq);
+        if (rc != EGP_OK) fail(G, rc, "K1 launch", egp_last_error());
+        if (prof) G_HIP(hipEventRecord(G.k_end[ev], C.stream));
+    };
+    if (tid == 0) {
+        G.prof_now = E->profile_k1.load(std::memory_order_relaxed) && (int)G.k_beg.size() >= FS * NC && (G.job % E->profile_every == 0);
+        if (G.ready) G_HIP(hipStreamWaitEvent(G.stream, G.ready, 0));
+        G_HIP(hipMemcpyAsync(E->d_prev_qpos + (size_t)G.e0 * E->nq, E->d_qpos + (size_t)G.e0 * E->nq,
+                             (size_t)(G.e1 - G.e0) * E->nq * sizeof(double), hipMemcpyDeviceToDevice, G.stream));
+        for (int c = 0; c < NC; ++c) {
+            if (G.chunks[c].own_stream && G.ready) G_HIP(hipStreamWaitEvent(G.chunks[c].stream, G.ready, 0));
+            launch(G.chunks[c], 0, c);
+        }
+        for (int s = 0; s < FS; ++s) {
+            const bool last = s == FS - 1;
+            for (int c = 0; c < NC; ++c) {
+                Chunk &C = G.chunks[c];
+                const long want = (long)W * (s + 1);
+                int spins = 0;
+                while (C.phys_done.load(std::memory_order_acquire) < want) {
+                    if (++spins < 4096) cpu_relax();
+                    else std::this_thread::yield();
+                }
+                if (G.status.load(std::memory_order_relaxed) != EGP_OK) continue;
+                if (C.qM_dirty.exchange(0)) {
+                    G_HIP(hipMemcpyAsync(E->d_qM + (size_t)C.e0 * E->ld_m, E->h_qM + (size_t)C.e0 * E->ld_m,
+                                         (size_t)(C.e1 - C.e0) * E->ld_m * sizeof(double), hipMemcpyHostToDevice, C.stream));
+                    G.qM_uploads += 1;
+                }
+                if (!last) launch(C, s + 1, c);
+            }
+        }
+        G.qM_dirty.store(0, std::memory_order_relaxed);
+        if (G.status.load() == EGP_OK) {
+            const int m = G.e1 - G.e0;
+            G_HIP(hipMemcpyAsync(E->d_qpos + (size_t)G.e0 * E->nq, E->h_qpos + (size_t)G.e0 * E->nq, (size_t)m * E->nq * sizeof(double),
+                                 hipMemcpyHostToDevice, G.stream));
+            G_HIP(hipMemcpyAsync(E->d_qvel + (size_t)G.e0 * E->nv, E->h_qvel + (size_t)G.e0 * E->nv, (size_t)m * E->nv * sizeof(double),
+                                 hipMemcpyHostToDevice, G.stream));
+            G_HIP(hipMemcpyAsync(E->d_ee + (size_t)G.e0 * 15, E->h_ee + (size_t)G.e0 * 15, (size_t)m * 15 * sizeof(double),
+                                 hipMemcpyHostToDevice, G.stream));
+            G_HIP(hipEventRecord(G.done, G.stream));
+        }
+        if (G.prof_now && G.status.load() == EGP_OK) {
+            G_HIP(hipStreamSynchronize(G.stream));
+            for (int c = 0; c < NC; ++c)
+                if (G.chunks[c].own_stream) G_HIP(hipStreamSynchronize(G.chunks[c].stream));
+            for (int i = 0; i < FS * NC; ++i) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, G.k_beg[i], G.k_end[i]) == hipSuccess) {
+                    G.k1_ms += ms > G.ev_overhead_ms ? ms - G.ev_overhead_ms : 0.0;
+                    G.k1_launches += 1;
+                }
+            }
+        }
+        return;
+    }
+    const int w = tid - 1;
+    const bool timekeeper = w == 0;
+    double t_wait = 0.0, t_phys = 0.0;
+    for (int s = 0; s < FS; ++s) {
+        const bool last = s == FS - 1;
+        for (int c = 0; c < NC; ++c) {
+            Chunk &C = G.chunks[c];
+            const unsigned long long want = C.base + (unsigned long long)s + 1ull;
+            auto t0 = clk::now();
+            {
+                const auto deadline = t0 + std::chrono::seconds(5);
+                long spins = 0;
+                while (__atomic_load_n(C.h_flag, __ATOMIC_ACQUIRE) < want) {
+                    cpu_relax();
+                    if ((++spins & 0x3FFF) == 0) {
+                        if (G.status.load(std::memory_order_relaxed) != EGP_OK) break;
+                        if (clk::now() > deadline) {       // ask the runtime; a flag that is still behind is an error
+                            (void)hipStreamSynchronize(C.stream);
+                            if (__atomic_load_n(C.h_flag, __ATOMIC_ACQUIRE) < want) fail(G, EGP_E_HIP, "K1 completion flag", "timed out");
+                            break;
+                        }
+                    }
+                }
+            }
+            auto t1 = clk::now();
+            if (G.status.load(std::memory_order_relaxed) == EGP_OK) {
+                const int mc = C.e1 - C.e0;
+                const int my0 = C.e0 + (int)((long)mc * w / W), my1 = C.e0 + (int)((long)mc * (w + 1) / W);
+                for (int e = my0; e < my1; ++e) {
+                    if (G.has_active && !G.active[e]) continue;
+                    if (E->vt->step(E->vt->user, e, E->h_torque + (size_t)e * E->nu) != 0 || drain_env(E, e, last) != EGP_OK) {
+                        char msg[64];
+                        snprintf(msg, sizeof(msg), "env %d", e);
+                        fail(G, EGP_E_PHYSICS, "physics backend failed", msg);
+                        break;
+                    }
+                }
+            }
+            C.phys_done.fetch_add(1, std::memory_order_acq_rel);
+            if (timekeeper) {
+                auto t2 = clk::now();
+                t_wait += secs(t0, t1);
+                t_phys += secs(t1, t2);
+            }
+        }
+    }
+    if (timekeeper) { G.wait_s += t_wait; G.phys_s += t_phys; }
+}
+
 void thread_main(egp_engine *E, int gi, int tid) {
     Group &G = E->groups[gi];
     (void)hipSetDevice(E->ctx->device);
@@ -265,7 +415,8 @@ void thread_main(egp_engine *E, int gi, int tid) {
             if (G.quit) return;
             seen = G.job;
         }
-        run_step(E, G, tid);
+        if (G.pipelined_job) run_step_pipelined(E, G, tid);
+        else run_step(E, G, tid);
         {
             std::lock_guard<std::mutex> lk(G.mu);
             if (--G.pending == 0) G.cv_done.notify_all();
@@ -276,9 +427,10 @@ void thread_main(egp_engine *E, int gi, int tid) {
 int make_profile_events(egp_engine *E) {
     for (auto &G : E->groups) {
         if (!G.k_beg.empty()) continue;
-        G.k_beg.resize(E->frame_skip);
-        G.k_end.resize(E->frame_skip);
-        for (int s = 0; s < E->frame_skip; ++s) {
+        const int n_ev = E->frame_skip * std::max(1, G.n_chunks);
+        G.k_beg.resize(n_ev);
+        G.k_end.resize(n_ev);
+        for (int s = 0; s < n_ev; ++s) {
             EGP_HIP_CHECK(hipEventCreate(&G.k_beg[s]));
             EGP_HIP_CHECK(hipEventCreate(&G.k_end[s]));
         }
@@ -318,6 +470,7 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     E->ld_m = ((E->nM + 15) / 16) * 16;
     E->epoch.assign(d->n_env, -1);
     E->env_group.assign(d->n_env, 0);
+    E->env_chunk.assign(d->n_env, 0);
     const size_t N = (size_t)E->n_env;
 #define E_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { egp::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); egp_engine_destroy(E); return EGP_E_HIP; } } while (0)
     E_TRY(hipMalloc((void **)&E->d_state, N * E->ld_s * sizeof(double)));
@@ -376,6 +529,34 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
             E_TRY(hipHostGetDevicePointer(&p, G.h_flag, 0));
             G.hd_flag = (unsigned long long *)p;
         }
+        // pipelined mode: cut the group into chunks (EGP_CHUNKS, default 2; every chunk keeps >= 8 envs)
+        int want_chunks = 2;
+        if (const char *ck = getenv("EGP_CHUNKS")) want_chunks = atoi(ck);
+        const int m = G.e1 - G.e0;
+        const int nc = std::min(want_chunks, m / 8);
+        if (nc >= 2 && G.n_threads >= 3) {
+            G.n_chunks = nc;
+            G.chunks.reset(new Chunk[nc]);
+            for (int c = 0; c < nc; ++c) {
+                Chunk &C = G.chunks[c];
+                C.e0 = G.e0 + (int)((long)m * c / nc);
+                C.e1 = G.e0 + (int)((long)m * (c + 1) / nc);
+                for (int e = C.e0; e < C.e1; ++e) E->env_chunk[e] = c;
+                E_TRY(hipMalloc((void **)&C.d_done, sizeof(unsigned)));
+                E_TRY(hipMemset(C.d_done, 0, sizeof(unsigned)));
+                E_TRY(hipHostMalloc((void **)&C.h_flag, sizeof(unsigned long long), hipHostMallocDefault));
+                *C.h_flag = 0;
+                void *p = nullptr;
+                E_TRY(hipHostGetDevicePointer(&p, C.h_flag, 0));
+                C.hd_flag = (unsigned long long *)p;
+                C.stream = G.stream;
+                const char *cs = getenv("EGP_CHUNK_STREAMS");
+                if (cs && atoi(cs) != 0 && c > 0) {
+                    E_TRY(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
+                    C.own_stream = true;
+                }
+            }
+        }
     }
 #undef E_TRY
     const char *prof = getenv("EGP_PROFILE_K1");
@@ -400,6 +581,11 @@ int egp_engine_destroy(egp_engine *E) {
         }
         for (auto &t : G.threads)
             if (t.joinable()) t.join();
+        for (int c = 0; c < G.n_chunks; ++c) {
+            if (G.chunks[c].d_done) (void)hipFree(G.chunks[c].d_done);
+            if (G.chunks[c].h_flag) (void)hipHostFree(G.chunks[c].h_flag);
+            if (G.chunks[c].own_stream) (void)hipStreamDestroy(G.chunks[c].stream);
+        }
         if (G.d_done) (void)hipFree(G.d_done);
         if (G.h_flag) (void)hipHostFree(G.h_flag);
         if (G.stream) (void)hipStreamDestroy(G.stream);
@@ -449,6 +635,7 @@ int egp_engine_reset(egp_engine *E, const int32_t *ids, int32_t n, const double 
         }
         new_qM[k] = !E->vt->inertia_epoch || E->epoch[e] != before;
         G.qM_dirty.store(0, std::memory_order_relaxed);   // the rows are uploaded right here
+        if (G.n_chunks) G.chunks[E->env_chunk[e]].qM_dirty.store(0, std::memory_order_relaxed);
     }
     int k = 0;
     while (k < n) {                  // upload maximal runs of consecutive env ids
@@ -478,6 +665,12 @@ int egp_engine_step_async(egp_engine *E, int32_t group, const double *action, co
     G.ready = (hipEvent_t)ready_event;
     G.has_active = active_host != nullptr;
     if (active_host) memcpy(G.active.data(), active_host, E->n_env * sizeof(int));
+    G.pipelined_job = pipelined_mode(E, G);
+    if (G.pipelined_job)
+        for (int c = 0; c < G.n_chunks; ++c) {
+            G.chunks[c].base = G.chunks[c].seq;
+            G.chunks[c].phys_done.store(0, std::memory_order_relaxed);
+        }
     G.pending = G.n_threads;
     G.job += 1;
     G.cv_go.notify_all();
@@ -550,6 +743,12 @@ int egp_engine_layout(egp_engine *E, int32_t *pack_ld, int32_t *n_env, int32_t *
     if (n_threads) *n_threads = E->n_threads;
     if (n_groups) *n_groups = E->n_groups;
     return EGP_OK;
+}
+
+int egp_engine_launches_per_substep(egp_engine *E) {
+    if (!E || E->groups.empty()) return 0;
+    const Group &G = E->groups[0];
+    return pipelined_mode(E, G) ? G.n_chunks : 1;
 }
 
 int egp_engine_group_range(egp_engine *E, int32_t group, int32_t *e0, int32_t *e1) {

@@ -241,18 +241,58 @@ __global__ __launch_bounds__(256) void k_pd_torque_tree58(DevModel m, PdLd ld, c
     __shared__ short s_map[PD_NV * PD_NV];
     __shared__ double s_qM[4][PD_NM_MAX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < PD_NV * PD_NV; i += 256) s_map[i] = m.m_map[i];
     const long env = (long)blockIdx.x * 4 + wave;
     const bool valid = env < n;
+    const int row = lane < PD_NV ? lane : PD_NV - 1;
+    // the state row may live in pinned host memory (zero-copy engine): issue those loads first so the PCIe round
+    // trip overlaps the LDS fills below
+    const int act = row >= 6 ? row - 6 : 0;
+    TIO r_q = TIO(0), r_v = TIO(0), r_c = TIO(0), r_a = TIO(0);
     if (valid) {
-        const TIO *src = qM + env * ld.qM;
-        for (int i = lane; i < m.nM; i += 64) s_qM[wave][i] = (double)src[i];
+        r_q = qpos[env * ld.qpos + 7 + act];
+        r_v = qvel[env * ld.qvel + row];
+        r_c = C[env * ld.bias + row];
+        r_a = action[env * ld.action + act];
+    }
+    // per-dof constants, also up front (each dependent global load costs a full memory round trip at 2 waves/CU)
+    const double c_kp = m.jkp[act], c_kd = m.jkd[act], c_ref = m.a_ref[act], c_scale = m.a_scale[act], c_lim = m.torque_lim[act];
+    // LDS fills with every load of a thread in flight at once (the rolled loops waited for each load in turn)
+    {
+        constexpr int MAP_IT = (PD_NV * PD_NV + 255) / 256;
+        short t_map[MAP_IT];
+#pragma unroll
+        for (int k = 0; k < MAP_IT; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            t_map[k] = i < PD_NV * PD_NV ? m.m_map[i] : (short)0;
+        }
+        constexpr int QM_IT = PD_NM_MAX / 64;
+        TIO t_qM[QM_IT];
+        const TIO *src = qM + (valid ? env : 0) * ld.qM;
+#pragma unroll
+        for (int k = 0; k < QM_IT; ++k) {
+            const int i = lane + 64 * k;
+            t_qM[k] = (valid && i < m.nM) ? src[i] : TIO(0);
+        }
+#pragma unroll
+        for (int k = 0; k < MAP_IT; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < PD_NV * PD_NV) s_map[i] = t_map[k];
+        }
+#pragma unroll
+        for (int k = 0; k < QM_IT; ++k) s_qM[wave][lane + 64 * k] = (double)t_qM[k];
     }
     __syncthreads();
     if (valid) {
-        const int row = lane < PD_NV ? lane : PD_NV - 1;
-        double kp, kd, eq, qv, b;
-        pd_rhs<TIO>(m, ld, qpos, qvel, action, C, env, row, kp, kd, eq, qv, b);
+        // same arithmetic as pd_rhs / pd_store
+        double kp = 0.0, kd = 0.0, eq = 0.0;
+        if (row >= 6) {
+            kp = c_kp;
+            kd = c_kd;
+            const double target = c_ref + (double)r_a * c_scale;
+            eq = (double)r_q - target;
+        }
+        const double qv = (double)r_v;
+        double b = -(double)r_c - kp * eq - kd * qv;
         const double kd_dt = kd * m.sub_dt;
         double a[PD_NV];
 #pragma unroll
@@ -264,7 +304,13 @@ __global__ __launch_bounds__(256) void k_pd_torque_tree58(DevModel m, PdLd ld, c
         double dinv = 0.0;
         tree_eliminate<PD_NV - 1>(a, b, dinv, row);
         const double qacc = b * dinv;
-        pd_store<TIO>(m, env, row, lane < PD_NV, kp, kd, eq, qv, qacc, torque, torque_raw);
+        if (lane < PD_NV && row >= 6) {
+            const double ev = qv + qacc * m.sub_dt;
+            const double tau = -kp * eq - kd * ev;
+            const double tc = fmin(fmax(tau, -c_lim), c_lim);
+            torque[env * m.nu + act] = (TIO)tc;
+            if (torque_raw) torque_raw[env * m.nu + act] = (TIO)tau;
+        }
     }
     if (done.counter) {
         // completion signal for a host that polls pinned memory instead of synchronising the stream: every block

@@ -145,6 +145,11 @@ class RolloutEngine:
         L.check(self.lib.egp_engine_group_range(self.handle, int(g), C.byref(a), C.byref(b)), "egp_engine_group_range")
         return a.value, b.value
 
+    @property
+    def launches_per_substep(self):
+        """K1 launches per group per substep (number of chunks when the group runs pipelined, else 1)."""
+        return int(self.lib.egp_engine_launches_per_substep(self.handle))
+
     def reset(self, env_ids, qpos, qvel):
         import torch
         ids = _np_i32(env_ids)

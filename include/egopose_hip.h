@@ -292,6 +292,9 @@ double egp_engine_event_overhead_ms(egp_engine *e);   /* calibrated cost of an e
 int egp_engine_set_profile(egp_engine *e, int on);   /* 0 off; 1: HIP events around every K1 launch; N>1: on every Nth env-step */
 int egp_engine_layout(egp_engine *e, int32_t *pack_ld, int32_t *n_env, int32_t *n_threads, int32_t *n_groups);
 int egp_engine_group_range(egp_engine *e, int32_t group, int32_t *env_begin, int32_t *env_end);
+/* K1 launches a group issues per substep: 1, or the number of chunks when the group runs pipelined
+ * (>= 3 threads, >= 16 envs, polled zero-copy mode; EGP_CHUNKS, default 2) */
+int egp_engine_launches_per_substep(egp_engine *e);
 int32_t egp_physics_n_env(const egp_physics *p);
 
 #ifdef __cplusplus
