@@ -134,17 +134,20 @@ def main():
         if tim["k1_launches"] > 0:
             avg_s = tim["k1_ms"] * 1e-3 / tim["k1_launches"]
             envs_per_launch = args.envs / float(args.groups) / max(1, eng.launches_per_substep)
-            achieved = K1_BYTES_PER_ENV * envs_per_launch / avg_s
+            sub_per_launch = max(1, eng.substeps_per_launch)       # 15 when the resident K1 serves a whole env-step
+            achieved = K1_BYTES_PER_ENV * envs_per_launch * sub_per_launch / avg_s
             traffic, traffic_src = None, None
             try:      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
                 pm = json.load(open(os.path.join(REPO, "profiles", "pmc_k1_traffic.json")))
-                traffic = pm["hbm_bytes_per_env_substep"] * envs_per_launch
+                traffic = pm["hbm_bytes_per_env_substep"] * envs_per_launch * sub_per_launch
                 traffic_src = pm["source"] + "; " + pm["correction"]
             except Exception:
                 pass
             res["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes per launch",
-                               "traffic_source": traffic_src, "kernel": "k_pd_torque_tree58<double>",
+                               "traffic_source": traffic_src,
+                               "kernel": "k_pd_server_tree58 (resident: one launch = 15 substeps, duration includes the waits for host physics)" if sub_per_launch > 1 else "k_pd_torque_tree58<double>",
+                               "substeps_per_launch": sub_per_launch,
                                "avg_launch_us": avg_s * 1e6, "event_pair_overhead_us_subtracted": tim["event_overhead_us"], "launches_timed": tim["k1_launches"], "event_sampling": "every %d-th env-step of each group inside the timed region" % args.k1_event_every, "envs_per_launch": envs_per_launch,
                                "alg_bytes_per_env_substep": K1_BYTES_PER_ENV}
         else:

@@ -122,6 +122,8 @@ SIGNATURES = {
     "egp_engine_layout": (C.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p]),
     "egp_engine_group_range": (C.c_int, [vp, _i32, c_int_p, c_int_p]),
     "egp_engine_launches_per_substep": (C.c_int, [vp]),
+    "egp_engine_substeps_per_launch": (C.c_int, [vp]),
+    "egp_engine_server_trace": (C.c_int, [vp, _i32, vp, vp]),
 }
 
 _lib = None

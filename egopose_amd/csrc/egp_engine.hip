@@ -78,8 +78,23 @@ struct Chunk {
     std::atomic<int> qM_dirty{0};
 };
 
+// Resident-K1 mode: the group's envs as a few slices per host thread (whole 4-env blocks each), each with the `go`
+// word its owner raises after a substep of physics; torques come back through sentinel-filled pinned rows
+struct Server {
+    int n_slices = 0, n_blocks = 0, per_thread = 0;
+    std::vector<int> e0, e1;                  // env range of each slice
+    int *d_block_slice = nullptr;
+    unsigned long long *h_go = nullptr, *hd_go = nullptr;   // [n_slices * 8]
+    int *h_err = nullptr, *hd_err = nullptr;
+    unsigned long long seq = 1, base = 0;     // next free sequence number / first substep of the env-step in flight
+    std::unique_ptr<std::atomic<int>[]> dirty;   // some qM row of the slice changed since the kernel last read it
+    long long *d_trace = nullptr;             // EGP_SERVER_TRACE=1: device stamps of block 0 + host stamps of slice 0
+    std::vector<double> host_trace;           // [frame_skip * 4] us since the job started: wait start, torques seen, go written
+};
+
 struct Group {
     int e0 = 0, e1 = 0;                       // env range [e0, e1)
+    Server srv;
     std::unique_ptr<Chunk[]> chunks;          // pipelined mode: n_chunks >= 2 slices, else unused
     int n_chunks = 0;
     int n_threads = 1;
@@ -105,6 +120,7 @@ struct Group {
     bool polled = false;                      // the launch in flight publishes to h_flag
     bool prof_now = false;                    // this env-step brackets its K1 launches with events
     bool pipelined_job = false;               // mode of the env-step in flight (fixed when it is posted)
+    bool server_job = false;
     char err[256] = "";
     // timing (leader only)
     double phys_s = 0.0, wait_s = 0.0, k1_ms = 0.0, ev_overhead_ms = 0.0;
@@ -125,18 +141,21 @@ struct egp_engine {
     int profile_every = 1;                    // bracket K1 with events on every Nth env-step of a group
     bool zero_copy = false;                   // K1 reads state rows / writes torques in pinned host memory directly
     bool flag_poll = false;                   // leader polls a pinned completion flag instead of hipStreamSynchronize
-    double *hd_state = nullptr, *hd_torque = nullptr;   // device-side aliases of h_state / h_torque
+    double *hd_state = nullptr, *hd_torque = nullptr, *hd_qM = nullptr;   // device-side aliases of h_state / h_torque / h_qM
+    bool server_ok = false;                   // resident-K1 mode allowed (EGP_SERVER, block budget)
     double *d_state = nullptr, *d_qM = nullptr, *d_prev_qpos = nullptr, *d_qpos = nullptr, *d_qvel = nullptr, *d_torque = nullptr, *d_ee = nullptr;
     double *h_state = nullptr, *h_qM = nullptr, *h_qpos = nullptr, *h_qvel = nullptr, *h_torque = nullptr, *h_ee = nullptr,
            *h_headz = nullptr, *h_xpos = nullptr;
     std::vector<Group> groups;
     std::vector<int64_t> epoch;               // last drained inertia epoch per env (-1 = never)
-    std::vector<int> env_group, env_chunk;
+    std::vector<int> env_group, env_chunk, env_slice;
 };
 
 namespace {
 
-int drain_env(egp_engine *E, int env, bool with_xpos) {
+// mark_dirty: flag the env's group / chunk / slice for an inertia upload (the substep loop); egp_engine_reset
+// uploads the rows it drained itself and must leave the flags of its neighbours alone
+int drain_env(egp_engine *E, int env, bool with_xpos, bool mark_dirty = true) {
     double *row = E->h_state + (size_t)env * E->ld_s;
     double *xp = with_xpos ? E->h_xpos + (size_t)env * E->nbody * 3 : nullptr;
     double *qM = E->h_qM + (size_t)env * E->ld_m;
@@ -147,10 +166,11 @@ int drain_env(egp_engine *E, int env, bool with_xpos) {
     }
     int rc = E->vt->drain(E->vt->user, env, row + E->off_qpos, row + E->off_qvel, qM, row + E->off_bias, xp);
     if (rc != 0) return EGP_E_PHYSICS;
-    if (qM) {
+    if (qM && mark_dirty) {
         Group &G = E->groups[E->env_group[env]];
         G.qM_dirty.store(1, std::memory_order_relaxed);
         if (G.n_chunks) G.chunks[E->env_chunk[env]].qM_dirty.store(1, std::memory_order_relaxed);
+        if (G.srv.n_slices) G.srv.dirty[E->env_slice[env]].store(1, std::memory_order_relaxed);
     }
     if (with_xpos) {
         memcpy(E->h_qpos + (size_t)env * E->nq, row + E->off_qpos, E->nq * sizeof(double));
@@ -272,6 +292,131 @@ void run_step(egp_engine *E, Group &G, int tid) {
                 G.k1_ms += ms > G.ev_overhead_ms ? ms - G.ev_overhead_ms : 0.0;
                 G.k1_launches += 1;
             }
+        }
+    }
+}
+
+inline bool server_mode(const egp_engine *E, const Group &G) {
+    return E->server_ok && G.srv.n_slices > 0 && E->flag_poll && E->zero_copy && E->ctx->pd_variant == 0 && E->ctx->tree58;
+}
+
+// Resident-K1 env-step: one launch of k_pd_server_tree58 serves all substeps. Every host thread owns a few slices
+// and walks them round-robin -- while the GPU turns one slice's new state into torques (PCIe read, solve, PCIe
+// write), the thread advances the next -- so no thread ever waits for another one inside the env-step, and an env
+// is stepped the moment its own torque row has fully arrived.
+inline bool row_arrived(const double *row, int nu) {
+    const unsigned long long *u = reinterpret_cast<const unsigned long long *>(row);
+    bool ok = true;
+    for (int i = 0; i < nu; ++i) ok &= __atomic_load_n(u + i, __ATOMIC_RELAXED) != EGP_TORQUE_SENTINEL;
+    return ok;
+}
+
+inline void fill_sentinel(double *rows, size_t count) {
+    unsigned long long *u = reinterpret_cast<unsigned long long *>(rows);
+    for (size_t i = 0; i < count; ++i) u[i] = EGP_TORQUE_SENTINEL;
+}
+
+void run_step_server(egp_engine *E, Group &G, int tid) {
+    Server &S = G.srv;
+    const int FS = E->frame_skip, nu = E->nu, K = S.per_thread;
+    const unsigned long long base = S.base;
+    const unsigned long long drain_all = 0x7FFFFFFFFFFFFFFFull << 1;
+    const auto t_job = clk::now();
+    // own slices: sentinel rows first, then the go word of substep 0 (the kernel writes torques only after it saw go)
+    for (int h = 0; h < K; ++h) {
+        const int sl = K * tid + h;
+        fill_sentinel(E->h_torque + (size_t)S.e0[sl] * nu, (size_t)(S.e1[sl] - S.e0[sl]) * nu);
+        __atomic_store_n(S.h_go + sl * 8, (base << 1) | (unsigned long long)S.dirty[sl].exchange(0), __ATOMIC_RELEASE);
+    }
+    if (tid == 0) {
+        G.prof_now = E->profile_k1.load(std::memory_order_relaxed) && !G.k_beg.empty() && (G.job % E->profile_every == 0);
+        const int m = G.e1 - G.e0;
+        if (G.ready) G_HIP(hipStreamWaitEvent(G.stream, G.ready, 0));
+        G_HIP(hipMemcpyAsync(E->d_prev_qpos + (size_t)G.e0 * E->nq, E->d_qpos + (size_t)G.e0 * E->nq, (size_t)m * E->nq * sizeof(double),
+                             hipMemcpyDeviceToDevice, G.stream));
+        if (G.prof_now) G_HIP(hipEventRecord(G.k_beg[0], G.stream));
+        const double *st = E->hd_state + (size_t)G.e0 * E->ld_s;
+        int rc = egp_launch_pd_server(E->ctx, st + E->off_qpos, E->ld_s, st + E->off_qvel, E->ld_s, st + E->off_bias, E->ld_s,
+                                      E->d_qM + (size_t)G.e0 * E->ld_m, E->ld_m, E->hd_qM + (size_t)G.e0 * E->ld_m,
+                                      G.action + (size_t)G.e0 * nu, m, E->hd_torque + (size_t)G.e0 * nu, G.stream, S.d_block_slice,
+                                      S.hd_go, base, FS, S.hd_err, 2.0, S.d_trace);
+        if (rc != EGP_OK) fail(G, rc, "K1 server launch", egp_last_error());
+        if (G.prof_now) G_HIP(hipEventRecord(G.k_end[0], G.stream));
+    }
+    const bool timekeeper = tid == (G.n_threads > 1 ? 1 : 0);
+    double t_wait = 0.0, t_phys = 0.0;
+    for (int s = 0; s < FS; ++s) {
+        const bool last = s == FS - 1;
+        for (int h = 0; h < K; ++h) {
+            const int sl = K * tid + h;
+            const bool tr = sl == 0 && !S.host_trace.empty();
+            auto t0 = clk::now();
+            if (tr) S.host_trace[s * 4 + 0] = secs(t_job, t0) * 1e6;
+            double waited = 0.0;
+            bool first = true;
+            for (int e = S.e0[sl]; e < S.e1[sl] && G.status.load(std::memory_order_relaxed) == EGP_OK; ++e) {
+                if (G.has_active && !G.active[e]) continue;
+                const double *row = E->h_torque + (size_t)e * nu;
+                if (!row_arrived(row, nu)) {
+                    auto w0 = clk::now();
+                    const auto deadline = w0 + std::chrono::seconds(5);
+                    long spins = 0;
+                    while (!row_arrived(row, nu)) {
+                        cpu_relax();
+                        if ((++spins & 0xFFF) == 0) {
+                            if (G.status.load(std::memory_order_relaxed) != EGP_OK) break;
+                            if (__atomic_load_n(S.h_err, __ATOMIC_ACQUIRE) != 0) { fail(G, EGP_E_HIP, "K1 server", "kernel-side wait timed out"); break; }
+                            if (clk::now() > deadline) { fail(G, EGP_E_HIP, "K1 server", "no torques within 5 s"); break; }
+                        }
+                    }
+                    waited += secs(w0, clk::now());
+                    if (G.status.load(std::memory_order_relaxed) != EGP_OK) break;
+                }
+                if (tr && first) { S.host_trace[s * 4 + 1] = secs(t_job, clk::now()) * 1e6; first = false; }
+                if (E->vt->step(E->vt->user, e, row) != 0 || drain_env(E, e, last) != EGP_OK) {
+                    char msg[64];
+                    snprintf(msg, sizeof(msg), "env %d", e);
+                    fail(G, EGP_E_PHYSICS, "physics backend failed", msg);
+                    break;
+                }
+            }
+            if (G.status.load(std::memory_order_relaxed) != EGP_OK) {
+                __atomic_store_n(S.h_go + sl * 8, drain_all, __ATOMIC_RELEASE);       // let the kernel run out
+            } else if (!last) {
+                fill_sentinel(E->h_torque + (size_t)S.e0[sl] * nu, (size_t)(S.e1[sl] - S.e0[sl]) * nu);
+                __atomic_store_n(S.h_go + sl * 8, ((base + (unsigned long long)s + 1ull) << 1) | (unsigned long long)S.dirty[sl].exchange(0),
+                                 __ATOMIC_RELEASE);
+            }
+            if (tr) S.host_trace[s * 4 + 2] = secs(t_job, clk::now()) * 1e6;
+            if (timekeeper) {
+                t_wait += waited;
+                t_phys += secs(t0, clk::now()) - waited;
+            }
+        }
+    }
+    if (timekeeper) { G.wait_s += t_wait; G.phys_s += t_phys; }
+    G.bar.wait();
+    if (tid != 0) return;
+    if (G.status.load() != EGP_OK) {
+        for (int sl = 0; sl < S.n_slices; ++sl) __atomic_store_n(S.h_go + sl * 8, drain_all, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(G.stream);
+        return;
+    }
+    G.qM_dirty.store(0, std::memory_order_relaxed);
+    for (int c = 0; c < G.n_chunks; ++c) G.chunks[c].qM_dirty.store(0, std::memory_order_relaxed);
+    const int m = G.e1 - G.e0;
+    G_HIP(hipMemcpyAsync(E->d_qpos + (size_t)G.e0 * E->nq, E->h_qpos + (size_t)G.e0 * E->nq, (size_t)m * E->nq * sizeof(double),
+                         hipMemcpyHostToDevice, G.stream));
+    G_HIP(hipMemcpyAsync(E->d_qvel + (size_t)G.e0 * E->nv, E->h_qvel + (size_t)G.e0 * E->nv, (size_t)m * E->nv * sizeof(double),
+                         hipMemcpyHostToDevice, G.stream));
+    G_HIP(hipMemcpyAsync(E->d_ee + (size_t)G.e0 * 15, E->h_ee + (size_t)G.e0 * 15, (size_t)m * 15 * sizeof(double), hipMemcpyHostToDevice, G.stream));
+    G_HIP(hipEventRecord(G.done, G.stream));
+    if (G.prof_now) {
+        G_HIP(hipStreamSynchronize(G.stream));
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, G.k_beg[0], G.k_end[0]) == hipSuccess) {
+            G.k1_ms += ms > G.ev_overhead_ms ? ms - G.ev_overhead_ms : 0.0;
+            G.k1_launches += 1;
         }
     }
 }
@@ -415,7 +560,8 @@ void thread_main(egp_engine *E, int gi, int tid) {
             if (G.quit) return;
             seen = G.job;
         }
-        if (G.pipelined_job) run_step_pipelined(E, G, tid);
+        if (G.server_job) run_step_server(E, G, tid);
+        else if (G.pipelined_job) run_step_pipelined(E, G, tid);
         else run_step(E, G, tid);
         {
             std::lock_guard<std::mutex> lk(G.mu);
@@ -471,6 +617,7 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     E->epoch.assign(d->n_env, -1);
     E->env_group.assign(d->n_env, 0);
     E->env_chunk.assign(d->n_env, 0);
+    E->env_slice.assign(d->n_env, 0);
     const size_t N = (size_t)E->n_env;
 #define E_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { egp::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); egp_engine_destroy(E); return EGP_E_HIP; } } while (0)
     E_TRY(hipMalloc((void **)&E->d_state, N * E->ld_s * sizeof(double)));
@@ -501,6 +648,8 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
             hipHostGetDevicePointer(&p2, E->h_torque, 0) == hipSuccess) {
             E->hd_state = (double *)p1;
             E->hd_torque = (double *)p2;
+            void *p3 = nullptr;
+            if (hipHostGetDevicePointer(&p3, E->h_qM, 0) == hipSuccess) E->hd_qM = (double *)p3;
         } else {
             E->zero_copy = false;
         }
@@ -509,6 +658,8 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     memset(E->h_qM, 0, N * E->ld_m * sizeof(double));
     memset(E->h_headz, 0, N * sizeof(double));
     E->groups = std::vector<Group>(E->n_groups);
+    int total_server_blocks = 0;
+    bool all_groups_sliced = true;
     for (int g = 0; g < E->n_groups; ++g) {
         Group &G = E->groups[g];
         G.e0 = (int)((long)E->n_env * g / E->n_groups);
@@ -557,6 +708,59 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
                 }
             }
         }
+        // resident-K1 mode: EGP_SERVER_SLICES (default 8) slices per thread, whole 4-env blocks each
+        {
+            Server &S = G.srv;
+            const int m = G.e1 - G.e0;
+            const int nb = (m + 3) / 4;
+            int per_thread = 8;
+            if (const char *sp = getenv("EGP_SERVER_SLICES")) per_thread = std::max(1, atoi(sp));
+            while (per_thread > 1 && nb < per_thread * G.n_threads) per_thread /= 2;
+            const int ns = per_thread * G.n_threads;
+            if (nb >= ns && E->hd_qM) {
+                S.n_slices = ns;
+                S.n_blocks = nb;
+                S.per_thread = per_thread;
+                S.e0.resize(ns);
+                S.e1.resize(ns);
+                S.dirty.reset(new std::atomic<int>[ns]);
+                std::vector<int> block_slice(nb);
+                for (int sl = 0; sl < ns; ++sl) {
+                    const int b0 = (int)((long)nb * sl / ns), b1 = (int)((long)nb * (sl + 1) / ns);
+                    S.e0[sl] = G.e0 + 4 * b0;
+                    S.e1[sl] = std::min(G.e1, G.e0 + 4 * b1);
+                    S.dirty[sl].store(0);
+                    for (int b = b0; b < b1; ++b) block_slice[b] = sl;
+                    for (int e = S.e0[sl]; e < S.e1[sl]; ++e) E->env_slice[e] = sl;
+                }
+                E_TRY(hipMalloc((void **)&S.d_block_slice, nb * sizeof(int)));
+                E_TRY(hipMemcpy(S.d_block_slice, block_slice.data(), nb * sizeof(int), hipMemcpyHostToDevice));
+                E_TRY(hipHostMalloc((void **)&S.h_go, (size_t)ns * 8 * sizeof(unsigned long long), hipHostMallocDefault));
+                E_TRY(hipHostMalloc((void **)&S.h_err, 64, hipHostMallocDefault));
+                memset(S.h_go, 0, (size_t)ns * 8 * sizeof(unsigned long long));
+                *S.h_err = 0;
+                void *p = nullptr;
+                E_TRY(hipHostGetDevicePointer(&p, S.h_go, 0));   S.hd_go = (unsigned long long *)p;
+                E_TRY(hipHostGetDevicePointer(&p, S.h_err, 0));  S.hd_err = (int *)p;
+                if (const char *tr = getenv("EGP_SERVER_TRACE")) {
+                    if (atoi(tr) != 0) {
+                        E_TRY(hipMalloc((void **)&S.d_trace, (size_t)E->frame_skip * 8 * sizeof(long long)));
+                        E_TRY(hipMemset(S.d_trace, 0, (size_t)E->frame_skip * 8 * sizeof(long long)));
+                        S.host_trace.assign((size_t)E->frame_skip * 4, 0.0);
+                    }
+                }
+                total_server_blocks += nb;
+            } else {
+                all_groups_sliced = false;
+            }
+        }
+    }
+    {
+        // the resident kernel's blocks wait on the host, so all of them (every group's) must fit on the chip at once
+        int max_blocks = 512;
+        if (const char *mb = getenv("EGP_SERVER_MAX_BLOCKS")) max_blocks = atoi(mb);
+        const char *sv = getenv("EGP_SERVER");
+        E->server_ok = all_groups_sliced && total_server_blocks <= max_blocks && !(sv && atoi(sv) == 0);
     }
 #undef E_TRY
     const char *prof = getenv("EGP_PROFILE_K1");
@@ -585,6 +789,13 @@ int egp_engine_destroy(egp_engine *E) {
             if (G.chunks[c].d_done) (void)hipFree(G.chunks[c].d_done);
             if (G.chunks[c].h_flag) (void)hipHostFree(G.chunks[c].h_flag);
             if (G.chunks[c].own_stream) (void)hipStreamDestroy(G.chunks[c].stream);
+        }
+        {
+            Server &S = G.srv;
+            void *dv[] = {S.d_block_slice, S.d_trace};
+            for (void *p : dv) if (p) (void)hipFree(p);
+            void *hv[] = {S.h_go, S.h_err};
+            for (void *p : hv) if (p) (void)hipHostFree(p);
         }
         if (G.d_done) (void)hipFree(G.d_done);
         if (G.h_flag) (void)hipHostFree(G.h_flag);
@@ -619,6 +830,18 @@ int egp_engine_reset(egp_engine *E, const int32_t *ids, int32_t n, const double 
     EGP_HIP_CHECK(hipSetDevice(E->ctx->device));
     hipStream_t s = (hipStream_t)stream;
     std::vector<char> new_qM(n, 0);
+    // the last env-step's uploads read the pinned rows when the copy engine gets to them, which can be after
+    // egp_engine_wait returned: let them finish before a reset overwrites those rows
+    {
+        int last_group = -1;
+        for (int k = 0; k < n; ++k) {
+            if (ids[k] < 0 || ids[k] >= E->n_env) continue;
+            const int g = E->env_group[ids[k]];
+            if (g == last_group) continue;
+            last_group = g;
+            EGP_HIP_CHECK(hipEventSynchronize(E->groups[g].done));
+        }
+    }
     for (int k = 0; k < n; ++k) {
         const int e = ids[k];
         EGP_REQUIRE(e >= 0 && e < E->n_env, "env id out of range");
@@ -629,13 +852,11 @@ int egp_engine_reset(egp_engine *E, const int32_t *ids, int32_t n, const double 
             if (G.pending != 0) { egp::set_error("cannot reset env %d while its group is stepping", e); return EGP_E_STATE; }
         }
         const int64_t before = E->epoch[e];
-        if (E->vt->reset(E->vt->user, e, qpos + (size_t)k * E->nq, qvel + (size_t)k * E->nv) != 0 || drain_env(E, e, true) != EGP_OK) {
+        if (E->vt->reset(E->vt->user, e, qpos + (size_t)k * E->nq, qvel + (size_t)k * E->nv) != 0 || drain_env(E, e, true, false) != EGP_OK) {
             egp::set_error("physics backend failed to reset env %d", e);
             return EGP_E_PHYSICS;
         }
         new_qM[k] = !E->vt->inertia_epoch || E->epoch[e] != before;
-        G.qM_dirty.store(0, std::memory_order_relaxed);   // the rows are uploaded right here
-        if (G.n_chunks) G.chunks[E->env_chunk[e]].qM_dirty.store(0, std::memory_order_relaxed);
     }
     int k = 0;
     while (k < n) {                  // upload maximal runs of consecutive env ids
@@ -665,7 +886,12 @@ int egp_engine_step_async(egp_engine *E, int32_t group, const double *action, co
     G.ready = (hipEvent_t)ready_event;
     G.has_active = active_host != nullptr;
     if (active_host) memcpy(G.active.data(), active_host, E->n_env * sizeof(int));
-    G.pipelined_job = pipelined_mode(E, G);
+    G.server_job = server_mode(E, G);
+    if (G.server_job) {
+        G.srv.base = G.srv.seq;
+        G.srv.seq += (unsigned long long)E->frame_skip + 1ull;
+    }
+    G.pipelined_job = !G.server_job && pipelined_mode(E, G);
     if (G.pipelined_job)
         for (int c = 0; c < G.n_chunks; ++c) {
             G.chunks[c].base = G.chunks[c].seq;
@@ -748,7 +974,23 @@ int egp_engine_layout(egp_engine *E, int32_t *pack_ld, int32_t *n_env, int32_t *
 int egp_engine_launches_per_substep(egp_engine *E) {
     if (!E || E->groups.empty()) return 0;
     const Group &G = E->groups[0];
+    if (server_mode(E, G)) return 1;
     return pipelined_mode(E, G) ? G.n_chunks : 1;
+}
+
+int egp_engine_server_trace(egp_engine *E, int32_t group, int64_t *device_ticks, double *host_us) {
+    EGP_REQUIRE(E && device_ticks && host_us, "NULL pointer");
+    EGP_REQUIRE(group >= 0 && group < E->n_groups, "group out of range");
+    Server &S = E->groups[group].srv;
+    if (!S.d_trace) { egp::set_error("engine was created without EGP_SERVER_TRACE=1"); return EGP_E_STATE; }
+    EGP_HIP_CHECK(hipMemcpy(device_ticks, S.d_trace, (size_t)E->frame_skip * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    memcpy(host_us, S.host_trace.data(), S.host_trace.size() * sizeof(double));
+    return EGP_OK;
+}
+
+int egp_engine_substeps_per_launch(egp_engine *E) {
+    if (!E || E->groups.empty()) return 0;
+    return server_mode(E, E->groups[0]) ? E->frame_skip : 1;
 }
 
 int egp_engine_group_range(egp_engine *E, int32_t group, int32_t *e0, int32_t *e1) {

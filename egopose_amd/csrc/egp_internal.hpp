@@ -73,5 +73,11 @@ int egp_launch_pd_torque_strided(egp_ctx *ctx, const double *qpos, long ld_qpos,
                                  const double *bias, long ld_bias, const double *qM, long ld_qM, const double *action,
                                  int32_t n, double *torque, hipStream_t stream, unsigned *done_counter,
                                  unsigned long long *host_flag, unsigned long long seq);
+int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const double *qvel, long ld_qvel, const double *bias,
+                         long ld_bias, const double *qM, long ld_qM, const double *qM_host, const double *action, int32_t n,
+                         double *torque, hipStream_t stream, const int *block_slice, const unsigned long long *go,
+                         unsigned long long base, int n_sub, int *err, double timeout_s, long long *trace);
+// bit pattern the engine pre-fills pinned torque rows with in resident-K1 mode (a quiet NaN no clipped torque can equal)
+constexpr unsigned long long EGP_TORQUE_SENTINEL = 0x7FF8DEADBEEF0001ull;
 const egp_physics_vtable *egp_physics_vt(const egp_physics *p);
 extern "C" int32_t egp_physics_n_env(const egp_physics *p);

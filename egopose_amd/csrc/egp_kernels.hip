@@ -313,8 +313,9 @@ __global__ __launch_bounds__(256) void k_pd_torque_tree58(DevModel m, PdLd ld, c
         }
     }
     if (done.counter) {
-        // completion signal for a host that polls pinned memory instead of synchronising the stream: every block
-        // releases its torques system-wide and counts in; the last one publishes the launch's sequence number
+        // completion signal for a host that polls pinned memory instead of synchronising the stream: every wave
+        // releases its torques system-wide, the block counts in; the last one publishes the launch's sequence number
+        __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) {
             __threadfence_system();
@@ -324,6 +325,146 @@ __global__ __launch_bounds__(256) void k_pd_torque_tree58(DevModel m, PdLd ld, c
                 __threadfence_system();
                 __hip_atomic_store(done.host_flag, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+        }
+    }
+}
+
+// Resident form of the tree kernel for the rollout engine ("K1 server"): ONE launch covers all frame_skip
+// substeps of an env-step. The launch is cut into slices of whole blocks, each owned by one host physics thread.
+// For every substep a block waits until its slice's `go` word (pinned host memory, written by the owner after it
+// advanced the slice's envs) reaches the substep, reads the fresh state rows over PCIe, solves and writes the
+// clipped torques straight into the pinned torque rows. There is no completion signal: the owner pre-fills the
+// rows with a NaN sentinel before it raises `go` and steps an env as soon as its row holds no sentinel any more
+// (clipped torques are never NaN), so the device side needs no fence, no counter and no flag write.
+// What stays on the chip across substeps: the dof map, the gains, the action and the sparse inertia rows in LDS
+// (re-read from the host rows only when the owner flags that some qM of the slice changed).
+// No kernel launch, no stream sync and no group-wide barrier is left on the substep path.
+struct PdServe {
+    const int *block_slice;               // [gridDim.x]
+    const unsigned long long *go;         // [n_slices * 8]  host; value = (substep sequence << 1) | refresh_qM
+    unsigned long long base;              // sequence of substep 0 of this env-step
+    int n_sub;
+    const double *qM_host;                // device alias of the pinned inertia rows (same row stride as qM)
+    double *qM_dev;                       // HBM inertia rows, refreshed together with LDS
+    int *err;                             // host: set when a wait timed out
+    long long timeout_ticks;              // wall_clock64 ticks (100 MHz)
+    long long *trace;                     // optional [n_sub * 8] wall_clock64 stamps of block 0 (diagnostics)
+};
+
+__device__ __forceinline__ double sys_load_f64(const double *p) {
+    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return __longlong_as_double((long long)u);
+}
+
+__global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, const double *qpos, const double *qvel,
+                                                          const double *__restrict__ action, const double *qM, const double *C,
+                                                          int n, double *torque, PdServe sv) {
+    __shared__ short s_map[PD_NV * PD_NV];
+    __shared__ double s_qM[4][PD_NM_MAX];
+    __shared__ unsigned long long s_go[2];
+    __shared__ int s_abort;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long env = (long)blockIdx.x * 4 + wave;
+    const bool valid = env < n;
+    const int row = lane < PD_NV ? lane : PD_NV - 1;
+    const int act = row >= 6 ? row - 6 : 0;
+    const int slice = sv.block_slice[blockIdx.x];
+    const double r_a = valid ? action[env * ld.action + act] : 0.0;
+    const double c_kp = row >= 6 ? m.jkp[act] : 0.0, c_kd = row >= 6 ? m.jkd[act] : 0.0;
+    const double c_ref = m.a_ref[act], c_scale = m.a_scale[act], c_lim = m.torque_lim[act];
+    constexpr int QM_IT = PD_NM_MAX / 64;
+    {
+        constexpr int MAP_IT = (PD_NV * PD_NV + 255) / 256;
+        short t_map[MAP_IT];
+#pragma unroll
+        for (int k = 0; k < MAP_IT; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            t_map[k] = i < PD_NV * PD_NV ? m.m_map[i] : (short)0;
+        }
+        double t_qM[QM_IT];
+        const double *src = qM + (valid ? env : 0) * ld.qM;
+#pragma unroll
+        for (int k = 0; k < QM_IT; ++k) {
+            const int i = lane + 64 * k;
+            t_qM[k] = (valid && i < m.nM) ? src[i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < MAP_IT; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < PD_NV * PD_NV) s_map[i] = t_map[k];
+        }
+#pragma unroll
+        for (int k = 0; k < QM_IT; ++k) s_qM[wave][lane + 64 * k] = t_qM[k];
+    }
+    if (threadIdx.x == 0) s_abort = 0;
+    const double target = c_ref + r_a * c_scale;
+    const bool tracer = sv.trace && blockIdx.x == 0 && threadIdx.x == 0;
+    for (int sub = 0; sub < sv.n_sub; ++sub) {
+        if (threadIdx.x == 0) {
+            const unsigned long long want = sv.base + (unsigned long long)sub;
+            const long long t0 = wall_clock64();
+            unsigned long long v;
+            for (;;) {
+                v = __hip_atomic_load(sv.go + slice * 8, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((v >> 1) >= want) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t0 > sv.timeout_ticks) { s_abort = 1; break; }
+            }
+            s_go[sub & 1] = v;            // double-buffered: one barrier per substep is enough
+            if (tracer) { sv.trace[sub * 8 + 0] = t0; sv.trace[sub * 8 + 1] = wall_clock64(); }
+        }
+        __syncthreads();
+        if (s_abort) {
+            if (threadIdx.x == 0) __hip_atomic_store(sv.err, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        const bool refresh = (s_go[sub & 1] & 1ull) != 0ull;
+        if (valid) {
+            const double r_q = sys_load_f64(qpos + env * ld.qpos + 7 + act);
+            const double r_v = sys_load_f64(qvel + env * ld.qvel + row);
+            const double r_c = sys_load_f64(C + env * ld.bias + row);
+            if (refresh) {                      // this wave's inertia row changed on the host: LDS and HBM copies
+                const double *src = sv.qM_host + env * ld.qM;
+                double *dst = sv.qM_dev + env * ld.qM;
+                double t_qM[QM_IT];
+#pragma unroll
+                for (int k = 0; k < QM_IT; ++k) {
+                    const int i = lane + 64 * k;
+                    t_qM[k] = i < m.nM ? sys_load_f64(src + i) : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < QM_IT; ++k) {
+                    const int i = lane + 64 * k;
+                    s_qM[wave][i] = t_qM[k];
+                    if (i < m.nM) dst[i] = t_qM[k];
+                }
+            }
+            const double kp = c_kp, kd = c_kd;
+            const double eq = row >= 6 ? r_q - target : 0.0;
+            const double qv = r_v;
+            double b = -r_c - kp * eq - kd * qv;
+            if (tracer) sv.trace[sub * 8 + 2] = b != 12345.678 ? wall_clock64() : 0;
+            const double kd_dt = kd * m.sub_dt;
+            double a[PD_NV];
+#pragma unroll
+            for (int j = 0; j < PD_NV; ++j) {
+                const int id = s_map[row * PD_NV + j];
+                double v = id >= 0 ? s_qM[wave][id] : 0.0;
+                a[j] = v + (j == row ? kd_dt : 0.0);
+            }
+            double dinv = 0.0;
+            tree_eliminate<PD_NV - 1>(a, b, dinv, row);
+            const double qacc = b * dinv;
+            if (tracer) sv.trace[sub * 8 + 3] = qacc != 12345.678 ? wall_clock64() : 0;
+            if (lane < PD_NV && row >= 6) {
+                const double ev = qv + qacc * m.sub_dt;
+                const double tau = -kp * eq - kd * ev;
+                // system-scope store: straight to the pinned row, nothing lingers in a device cache
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(torque + env * m.nu + act),
+                                   (unsigned long long)__double_as_longlong(fmin(fmax(tau, -c_lim), c_lim)), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            if (tracer) sv.trace[sub * 8 + 4] = wall_clock64();
         }
     }
 }
@@ -1050,6 +1191,20 @@ int egp_launch_pd_torque_strided(egp_ctx *ctx, const double *qpos, long ld_qpos,
     PdLd ld{ld_qpos, ld_qvel, ctx->dm.nu, ld_qM, ld_bias};
     PdDone done{ctx->pd_variant == 0 ? done_counter : nullptr, host_flag, seq};
     return launch_pd<double>(ctx, ld, qpos, qvel, action, qM, bias, n, torque, nullptr, stream, done);
+}
+
+// engine entry for the resident K1 (see k_pd_server_tree58); all flag arrays are device-visible addresses
+int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const double *qvel, long ld_qvel, const double *bias,
+                         long ld_bias, const double *qM, long ld_qM, const double *qM_host, const double *action, int32_t n,
+                         double *torque, hipStream_t stream, const int *block_slice, const unsigned long long *go,
+                         unsigned long long base, int n_sub, int *err, double timeout_s, long long *trace) {
+    EGP_REQUIRE(ctx && ctx->tree58 && ctx->pd_variant == 0, "the K1 server needs the humanoid tree kernel");
+    EGP_REQUIRE(qpos && qvel && bias && qM && qM_host && action && torque && block_slice && go && err, "NULL pointer");
+    EGP_REQUIRE(n > 0 && n_sub > 0, "n and n_sub must be positive");
+    PdLd ld{ld_qpos, ld_qvel, ctx->dm.nu, ld_qM, ld_bias};
+    PdServe sv{block_slice, go, base, n_sub, qM_host, const_cast<double *>(qM), err, (long long)(timeout_s * 100.0e6), trace};
+    k_pd_server_tree58<<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, bias, n, torque, sv);
+    return after_launch("k_pd_server_tree58");
 }
 
 template <typename T>

@@ -86,6 +86,56 @@ class SurrogatePhysics:
             pass
 
 
+class CallbackPhysics:
+    """egp_physics_register with Python callables: the route for a backend that lives in Python (a `mujoco`-bindings
+    adapter, a test double). The callables get NumPy views of the engine's host buffers and are invoked from the
+    engine's worker threads (ctypes takes the GIL for each call), so this is for bring-up and tests, not speed.
+
+        reset(env, qpos[nq], qvel[nv])      step(env, ctrl[nu])
+        drain(env, qpos, qvel, qM or None, qfrc_bias, xpos or None)     fill the arrays in place
+        inertia_epoch(env) -> int           optional, see egp_physics_vtable
+    """
+
+    def __init__(self, skel: Skeleton, n_env: int, reset, step, drain, inertia_epoch=None, name="python-callbacks"):
+        self.lib = L.load()
+        self.skel, self.n_env = skel, int(n_env)
+        nq, nv, nu, nM, nb = skel.nq, skel.nv, skel.nu, skel.nM, len(skel.body_names)
+        arr = lambda p, n: np.ctypeslib.as_array(p, shape=(n,)) if p else None
+        self.errors = []
+
+        def guard(fn):
+            def call(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception as exc:           # a raising callback must not unwind through C
+                    self.errors.append(exc)
+                    return 1
+            return call
+
+        self._reset = L.PHYS_RESET(lambda u, e, qp, qv: guard(reset)(e, arr(qp, nq), arr(qv, nv)))
+        self._step = L.PHYS_STEP(lambda u, e, c: guard(step)(e, arr(c, nu)))
+        self._drain = L.PHYS_DRAIN(lambda u, e, qp, qv, qM, b, xp: guard(drain)(
+            e, arr(qp, nq), arr(qv, nv), arr(qM, nM), arr(b, nv), arr(xp, nb * 3).reshape(nb, 3) if xp else None))
+        self._destroy = L.PHYS_DESTROY(lambda u: None)
+        self._epoch = L.PHYS_EPOCH(lambda u, e: int(inertia_epoch(e))) if inertia_epoch is not None else L.PHYS_EPOCH()
+        self._name = name.encode()
+        vt = L.PhysicsVtable(None, self._reset, self._step, self._drain, self._destroy, self._name, self._epoch)
+        self._vt = vt
+        h = C.c_void_p()
+        L.check(self.lib.egp_physics_register(C.byref(vt), self.n_env, C.byref(h)), "egp_physics_register")
+        self.handle = h
+
+    @property
+    def name(self):
+        return self.lib.egp_physics_name(self.handle).decode()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.egp_physics_destroy(self.handle)
+            self.handle = None
+
+
 def available_cpus():
     """CPUs this process may actually use: min(affinity mask, cgroup CPU quota)."""
     n = os.cpu_count() or 1
@@ -149,6 +199,11 @@ class RolloutEngine:
     def launches_per_substep(self):
         """K1 launches per group per substep (number of chunks when the group runs pipelined, else 1)."""
         return int(self.lib.egp_engine_launches_per_substep(self.handle))
+
+    @property
+    def substeps_per_launch(self):
+        """frame_skip when the resident K1 serves a whole env-step per launch, else 1."""
+        return int(self.lib.egp_engine_substeps_per_launch(self.handle))
 
     def reset(self, env_ids, qpos, qvel):
         import torch

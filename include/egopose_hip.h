@@ -295,6 +295,14 @@ int egp_engine_group_range(egp_engine *e, int32_t group, int32_t *env_begin, int
 /* K1 launches a group issues per substep: 1, or the number of chunks when the group runs pipelined
  * (>= 3 threads, >= 16 envs, polled zero-copy mode; EGP_CHUNKS, default 2) */
 int egp_engine_launches_per_substep(egp_engine *e);
+/* substeps one K1 launch serves: frame_skip when the engine runs the resident K1 (one launch per env-step that
+ * trades go/done words with the physics threads through pinned memory; EGP_SERVER=0 turns it off), else 1 */
+int egp_engine_substeps_per_launch(egp_engine *e);
+/* diagnostics (engine created with EGP_SERVER_TRACE=1): the last env-step of `group` as seen by block 0 of the
+ * resident K1 -- device_ticks[frame_skip*8], 100 MHz wall_clock64 stamps per substep: poll start, go seen, state
+ * loaded, solved, torques stored -- and by the owner of slice 0 -- host_us[frame_skip*4], microseconds since the
+ * step was posted: wait start, first torque row in, go written */
+int egp_engine_server_trace(egp_engine *e, int32_t group, int64_t *device_ticks, double *host_us);
 int32_t egp_physics_n_env(const egp_physics *p);
 
 #ifdef __cplusplus

@@ -93,3 +93,29 @@ def test_surrogate_step_is_deterministic_and_stale_bias(skel):
     with pytest.raises(ValueError):
         ph.step(5, ctrl)
     ph.close()
+
+
+def test_callback_backend_round_trip(skel):
+    """egp_physics_register with Python callables: reset/step/drain reach the callables with views of the caller's
+    buffers, the epoch callback is wired, and a raising callable turns into an error code instead of unwinding."""
+    from conftest import VaryingInertiaBackend
+    from egopose_amd import _lib as L
+    g = load_golden("body_quat_obs.npz")
+    be = VaryingInertiaBackend(skel, 2)
+    lib = L.load()
+    q0, v0 = np.ascontiguousarray(g["qpos"][0]), np.ascontiguousarray(g["qvel"][0] * 0.1)
+    L.check(lib.egp_physics_reset_host(be.handle, 1, q0.ctypes.data, v0.ctypes.data), "reset")
+    assert be.physics.name == "varying-inertia" and lib.egp_physics_n_env(be.handle) == 2
+    ctrl = np.linspace(-1, 1, skel.nu)
+    for k in range(3):
+        L.check(lib.egp_physics_step_host(be.handle, 1, ctrl.ctypes.data), "step")
+    assert len(be.torques[1]) == 3 and np.array_equal(be.torques[1][0], ctrl) and be.k[1] == 3
+    qpos, qvel, qM, bias = np.empty(skel.nq), np.empty(skel.nv), np.empty(skel.nM), np.empty(skel.nv)
+    L.check(lib.egp_physics_drain_host(be.handle, 1, qpos.ctypes.data, qvel.ctypes.data, qM.ctypes.data, bias.ctypes.data, None), "drain")
+    rq, rv, rM, rb, _ = be.inner.drain(1, want_xpos=False)
+    np.testing.assert_array_equal(qpos, rq)
+    np.testing.assert_array_equal(qM, rM * be.scale(1, 3))
+    # a callable that raises -> nonzero status, exception kept on the wrapper
+    rc = lib.egp_physics_step_host(be.handle, 7, ctrl.ctypes.data)      # env 7 does not exist in the inner backend
+    assert rc != 0
+    be.close()

@@ -243,10 +243,22 @@ def test_gae_sizes_vs_oracle(ctx):
 
 
 # ------------------------------------------------------------------------------------------------ engine
-def test_engine_step_matches_host_loop(ctx, skel):
+ENGINE_MODES = {                     # env switches read by egp_engine_create -> (launches/substep, substeps/launch)
+    "resident": ({}, None),
+    "pipelined": ({"EGP_SERVER": "0", "EGP_CHUNKS": "2"}, None),
+    "barrier": ({"EGP_SERVER": "0", "EGP_CHUNKS": "1"}, (1, 1)),
+    "copies": ({"EGP_SERVER": "0", "EGP_ZERO_COPY": "0"}, (1, 1)),
+}
+
+
+@pytest.mark.parametrize("mode", list(ENGINE_MODES))
+def test_engine_step_matches_host_loop(ctx, skel, mode, monkeypatch):
     """15 substeps of {K1 on GPU <-> surrogate physics on host threads} == the same loop done
-    env by env with the oracle's stable-PD on the CPU (do_simulation, humanoid_v1.py:158-177)."""
+    env by env with the oracle's stable-PD on the CPU (do_simulation, humanoid_v1.py:158-177),
+    in every mode the engine can run the substep loop in."""
     from egopose_amd.physics import SurrogatePhysics, RolloutEngine
+    for k, v in ENGINE_MODES[mode][0].items():
+        monkeypatch.setenv(k, v)
     c = load_golden("config_subject_03.npz")
     g = load_golden("body_quat_obs.npz")
     n = 37
@@ -256,6 +268,10 @@ def test_engine_step_matches_host_loop(ctx, skel):
     for n_groups, n_threads in [(1, 3), (2, 4)]:
         ph = SurrogatePhysics(skel, n)
         eng = RolloutEngine(ctx, ph, n, n_threads=n_threads, n_groups=n_groups)
+        if mode == "resident":
+            assert (eng.launches_per_substep, eng.substeps_per_launch) == (1, 15)
+        elif ENGINE_MODES[mode][1]:
+            assert (eng.launches_per_substep, eng.substeps_per_launch) == ENGINE_MODES[mode][1]
         eng.reset(np.arange(n), qpos0, qvel0)
         act_d = dev(action)
         torch.cuda.synchronize()
@@ -283,3 +299,61 @@ def test_engine_step_matches_host_loop(ctx, skel):
             np.testing.assert_allclose(got_ee[e], xpos[skel.ee_body].ravel(), rtol=1e-9, atol=1e-9)
             np.testing.assert_allclose(head_z[e], xpos[6, 2], rtol=1e-9, atol=1e-9)
         ref.close()
+
+
+@pytest.mark.parametrize("mode", ["resident", "pipelined", "barrier"])
+def test_engine_follows_changing_inertia(ctx, skel, mode, monkeypatch):
+    """A backend whose qM changes on every step (what a MuJoCo adapter looks like): every torque row the engine
+    hands to step() must come from the inertia drained just before it, over two env-steps and a partial reset."""
+    from conftest import VaryingInertiaBackend
+    from egopose_amd.physics import RolloutEngine
+    for k, v in ENGINE_MODES[mode][0].items():
+        monkeypatch.setenv(k, v)
+    c = load_golden("config_subject_03.npz")
+    g = load_golden("body_quat_obs.npz")
+    n = 26
+    rng = np.random.RandomState(4)
+    qpos0, qvel0 = g["qpos"][:n], g["qvel"][:n] * 0.2
+    be = VaryingInertiaBackend(skel, n)
+    eng = RolloutEngine(ctx, be, n, n_threads=3, n_groups=1)
+    eng.reset(np.arange(n), qpos0, qvel0)
+    actions = []
+    for step in range(2):
+        a = rng.normal(size=(n, 52)) * 0.2
+        actions.append(a)
+        act_d = dev(a)
+        torch.cuda.synchronize()
+        eng.step_async(0, act_d)
+        eng.wait(0)
+        torch.cuda.synchronize()
+        if step == 0:                                  # re-seat a few envs between the two env-steps
+            ids = np.array([3, 4, 17])
+            eng.reset(ids, qpos0[ids], qvel0[ids])
+            torch.cuda.synchronize()
+    assert not be.physics.errors
+    got_q = eng.qpos.cpu().numpy()
+    logged = [np.array(t) for t in be.torques]
+    eng.close()
+    # replay on the host with the oracle's stable PD and the same per-step inertia
+    from egopose_amd.physics import SurrogatePhysics
+    ref = SurrogatePhysics(skel, 1)
+    for e in range(n):
+        ref.reset(0, qpos0[e], qvel0[e])
+        k = 0
+        row = 0
+        for step in range(2):
+            if step == 1 and e in (3, 4, 17):
+                ref.reset(0, qpos0[e], qvel0[e])
+                k = 0
+            for s in range(15):
+                q, v, qM, bias, _ = ref.drain(0, want_xpos=False)
+                M = H.full_from_sparse(qM * be.scale(e, k), skel.dof_parentid, skel.dof_Madr)
+                _, tc = H.pd_torque(q, v, actions[step][e], M, bias, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], skel.timestep)
+                np.testing.assert_allclose(logged[e][row], tc[0], rtol=1e-8, atol=1e-8, err_msg="env %d step %d substep %d" % (e, step, s))
+                ref.step(0, tc[0])
+                k += 1
+                row += 1
+        q, *_ = ref.drain(0, want_xpos=False)
+        np.testing.assert_allclose(got_q[e], q, rtol=1e-8, atol=1e-8)
+    ref.close()
+    be.close()

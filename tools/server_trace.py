@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Timeline of one env-step in resident-K1 mode (EGP_SERVER_TRACE=1): block 0's device stamps and the host stamps of
+the thread that owns slice 0, per substep. Usage: python tools/server_trace.py [n_env] [n_groups]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+os.environ["EGP_SERVER_TRACE"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from egopose_amd import _lib as L
+from egopose_amd.hip import EgpContext
+from egopose_amd.physics import SurrogatePhysics, RolloutEngine, default_threads
+from egopose_amd.presets import subject_03_params
+from egopose_amd.skeleton import load_skeleton
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    groups = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    sk = load_skeleton()
+    p = subject_03_params()
+    ctx = EgpContext(sk, p["jkp"], p["jkd"], p["a_ref"], p["a_scale"], p["torque_lim"], p["b_diffw"], p["reward_weights"])
+    ph = SurrogatePhysics(sk, n)
+    eng = RolloutEngine(ctx, ph, n, n_threads=default_threads(), n_groups=groups)
+    rng = np.random.RandomState(0)
+    q0 = np.tile(sk.default_qpos() if hasattr(sk, "default_qpos") else np.r_[0, 0, 1.0, 1, 0, 0, 0, np.zeros(52)], (n, 1))
+    eng.reset(np.arange(n), q0, np.zeros((n, 58)))
+    act = torch.as_tensor(rng.normal(size=(n, 52)) * 0.1, device="cuda")
+    torch.cuda.synchronize()
+    for it in range(20):
+        for g in range(groups):
+            eng.step_async(g, act)
+        for g in range(groups):
+            eng.wait(g)
+    torch.cuda.synchronize()
+    fs = 15
+    dev = np.zeros(fs * 8, np.int64)
+    host = np.zeros(fs * 4)
+    L.check(eng.lib.egp_engine_server_trace(eng.handle, 0, dev.ctypes.data, host.ctypes.data), "trace")
+    dev = dev.reshape(fs, 8).astype(float) / 100.0        # us
+    host = host.reshape(fs, 4)
+    t0 = dev[0, 0]
+    print("device (block 0), us since kernel start:  poll | go seen | loaded | solved | stored")
+    for s in range(fs):
+        r = dev[s] - t0
+        print("  sub %2d  %8.2f %8.2f %8.2f %8.2f %8.2f   | wait %.2f load %.2f solve %.2f store %.2f" % (
+            s, r[0], r[1], r[2], r[3], r[4], r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3]))
+    print("host (owner of slice 0), us since the step was posted:  wait start | first row in | go written")
+    for s in range(fs):
+        print("  sub %2d  %8.2f %8.2f %8.2f   | waited %.2f physics %.2f" % (s, host[s, 0], host[s, 1], host[s, 2], host[s, 1] - host[s, 0], host[s, 2] - host[s, 1]))
+    print("threads", eng.n_threads if hasattr(eng, "n_threads") else "?", "timing", eng.timing())
+    eng.close(); ph.close(); ctx.close()
+
+
+if __name__ == "__main__":
+    main()
