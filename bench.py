@@ -41,6 +41,15 @@ def cpu_baseline(dataset, steps, threads):
                       % (threads, r["env_steps"], r["seconds"], r["physics"])}
 
 
+def cgroup_throttle():
+    """(nr_throttled, throttled_usec) of this container's CPU cgroup, or None."""
+    try:
+        st = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(st.get("nr_throttled", 0)), int(st.get("throttled_usec", 0))
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +105,7 @@ def main():
     if not args.no_k1_events:
         eng.set_profile(True, every=args.k1_event_every)
     eng.reset_timing()
+    thr0 = cgroup_throttle()
     barrier()
     t0 = time.time()
     steps_local, t_sample, t_update = 0, 0.0, 0.0
@@ -107,6 +117,7 @@ def main():
         it += 1
     barrier()
     elapsed = time.time() - t0
+    thr1 = cgroup_throttle()
     tim = eng.timing()
     tot = torch.tensor([float(steps_local), elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -129,7 +140,8 @@ def main():
                        "host_threads_per_gpu": n_threads, "env_groups": args.groups, "host_cores_seen": cores,
                        "parallelism": "dp%d" % world},
             "env_steps": total_steps, "rollout_only_env_steps_per_s": steps_local / max(t_sample, 1e-9) * world,
-            "t_sample_s": t_sample, "t_update_s": t_update, "rollout_timing": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ro.timing.items()},
+            "t_sample_s": t_sample, "t_update_s": t_update,
+            "host_cgroup_throttled": None if not (thr0 and thr1) else {"events": thr1[0] - thr0[0], "usec_all_threads": thr1[1] - thr0[1]}, "rollout_timing": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ro.timing.items()},
         }
         if tim["k1_launches"] > 0:
             avg_s = tim["k1_ms"] * 1e-3 / tim["k1_launches"]

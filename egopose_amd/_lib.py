@@ -52,6 +52,10 @@ class SurrogateDesc(C.Structure):
     ]
 
 
+class MlpLayer(C.Structure):
+    _fields_ = [("wt", vp), ("bias", vp), ("in_dim", C.c_int32), ("out_dim", C.c_int32)]
+
+
 class EngineDesc(C.Structure):
     _fields_ = [("n_env", C.c_int32), ("n_threads", C.c_int32), ("n_groups", C.c_int32)]
 
@@ -100,6 +104,7 @@ SIGNATURES = {
     "egp_gae_standardize_f32": (C.c_int, [vp, _i32, vp, vp]),
     "egp_lstm_fwd_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp]),
     "egp_lstm_bwd_f32": (C.c_int, [vp, vp, vp, vp, _i32, _i32, _i32, _i32, vp, vp]),
+    "egp_policy_gaussian_f32": (C.c_int, [vp, C.c_int64, _i32, vp, vp, _i32, _i32, C.POINTER(MlpLayer), _i32, _i32, vp, vp, vp, vp, vp]),
     "egp_physics_register": (C.c_int, [C.POINTER(PhysicsVtable), _i32, C.POINTER(vp)]),
     "egp_physics_create_surrogate": (C.c_int, [C.POINTER(SurrogateDesc), _i32, C.POINTER(vp)]),
     "egp_physics_destroy": (C.c_int, [vp]),
@@ -163,3 +168,15 @@ def check(rc, what=""):
     if rc == -1:
         raise ValueError(text)
     raise EgpError(text)
+
+
+def current_stream(device_index=None):
+    """c_void_p of torch's current HIP stream on `device_index` (default: current device). Goes through the raw
+    accessor (no Stream object is built); falls back to torch.cuda.current_stream."""
+    import torch
+    try:
+        if device_index is None:
+            device_index = torch._C._cuda_getDevice()
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(device_index))
+    except AttributeError:
+        return C.c_void_p(torch.cuda.current_stream(device_index).cuda_stream)

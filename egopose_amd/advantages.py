@@ -21,7 +21,7 @@ def estimate_advantages(rewards, masks, values, gamma, tau):
     adv, ret = torch.empty_like(r), torch.empty_like(r)
     stats = torch.empty(3, dtype=torch.float64, device=r.device)
     ws = torch.empty(int(lib.egp_gae_workspace_bytes(n)), dtype=torch.uint8, device=r.device)
-    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    s = L.current_stream()
     p = lambda t: C.c_void_p(t.data_ptr())
     L.check(getattr(lib, "egp_gae_" + sfx)(p(r), p(m), p(v), n, float(gamma), float(tau), p(adv), p(ret), p(stats), p(ws), s), "egp_gae")
     L.check(getattr(lib, "egp_gae_standardize_" + sfx)(p(adv), n, p(stats), s), "egp_gae_standardize")

@@ -106,6 +106,8 @@ struct Group {
     std::condition_variable cv_go, cv_done;
     long job = 0;
     int pending = 0;                          // threads still inside the current job
+    std::atomic<long> job_pub{0};             // == job, published for threads that spin between env-steps
+    std::atomic<int> pending_pub{0};          // == pending, published for a caller that spins in egp_engine_wait
     bool quit = false;
     const double *action = nullptr;
     hipEvent_t ready = nullptr;
@@ -141,8 +143,9 @@ struct egp_engine {
     int profile_every = 1;                    // bracket K1 with events on every Nth env-step of a group
     bool zero_copy = false;                   // K1 reads state rows / writes torques in pinned host memory directly
     bool flag_poll = false;                   // leader polls a pinned completion flag instead of hipStreamSynchronize
-    double *hd_state = nullptr, *hd_torque = nullptr, *hd_qM = nullptr;   // device-side aliases of h_state / h_torque / h_qM
+    double *hd_state = nullptr, *hd_torque = nullptr, *hd_qM = nullptr, *hd_ee = nullptr;   // device-side aliases of h_state / h_torque / h_qM
     bool server_ok = false;                   // resident-K1 mode allowed (EGP_SERVER, block budget)
+    int spin_us = 0;                          // EGP_SPIN_US: poll this long for the next env-step before sleeping (off: measured no gain)
     double *d_state = nullptr, *d_qM = nullptr, *d_prev_qpos = nullptr, *d_qpos = nullptr, *d_qvel = nullptr, *d_torque = nullptr, *d_ee = nullptr;
     double *h_state = nullptr, *h_qM = nullptr, *h_qpos = nullptr, *h_qvel = nullptr, *h_torque = nullptr, *h_ee = nullptr,
            *h_headz = nullptr, *h_xpos = nullptr;
@@ -155,6 +158,26 @@ namespace {
 
 // mark_dirty: flag the env's group / chunk / slice for an inertia upload (the substep loop); egp_engine_reset
 // uploads the rows it drained itself and must leave the flags of its neighbours alone
+// End of a resident-K1 env-step: prev_qpos <- qpos, then qpos | qvel | ee_wpos <- the pinned rows the physics
+// threads drained (read over PCIe inside the kernel). One launch instead of a D2D and three H2D copy-engine calls.
+__global__ __launch_bounds__(256) void k_engine_gather(const double *__restrict__ h_state, int ld_s, int off_qpos, int off_qvel,
+                                                       const double *__restrict__ h_ee, int nq, int nv, int n, double *qpos,
+                                                       double *prev_qpos, double *qvel, double *ee) {
+    const int per_env = nq + nv + 15;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n * per_env) return;
+    const int e = (int)(i / per_env), c = (int)(i % per_env);
+    if (c < nq) {
+        const long d = (long)e * nq + c;
+        prev_qpos[d] = qpos[d];
+        qpos[d] = h_state[(long)e * ld_s + off_qpos + c];
+    } else if (c < nq + nv) {
+        qvel[(long)e * nv + (c - nq)] = h_state[(long)e * ld_s + off_qvel + (c - nq)];
+    } else {
+        ee[(long)e * 15 + (c - nq - nv)] = h_ee[(long)e * 15 + (c - nq - nv)];
+    }
+}
+
 int drain_env(egp_engine *E, int env, bool with_xpos, bool mark_dirty = true) {
     double *row = E->h_state + (size_t)env * E->ld_s;
     double *xp = with_xpos ? E->h_xpos + (size_t)env * E->nbody * 3 : nullptr;
@@ -332,8 +355,6 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
         G.prof_now = E->profile_k1.load(std::memory_order_relaxed) && !G.k_beg.empty() && (G.job % E->profile_every == 0);
         const int m = G.e1 - G.e0;
         if (G.ready) G_HIP(hipStreamWaitEvent(G.stream, G.ready, 0));
-        G_HIP(hipMemcpyAsync(E->d_prev_qpos + (size_t)G.e0 * E->nq, E->d_qpos + (size_t)G.e0 * E->nq, (size_t)m * E->nq * sizeof(double),
-                             hipMemcpyDeviceToDevice, G.stream));
         if (G.prof_now) G_HIP(hipEventRecord(G.k_beg[0], G.stream));
         const double *st = E->hd_state + (size_t)G.e0 * E->ld_s;
         int rc = egp_launch_pd_server(E->ctx, st + E->off_qpos, E->ld_s, st + E->off_qvel, E->ld_s, st + E->off_bias, E->ld_s,
@@ -405,11 +426,14 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
     G.qM_dirty.store(0, std::memory_order_relaxed);
     for (int c = 0; c < G.n_chunks; ++c) G.chunks[c].qM_dirty.store(0, std::memory_order_relaxed);
     const int m = G.e1 - G.e0;
-    G_HIP(hipMemcpyAsync(E->d_qpos + (size_t)G.e0 * E->nq, E->h_qpos + (size_t)G.e0 * E->nq, (size_t)m * E->nq * sizeof(double),
-                         hipMemcpyHostToDevice, G.stream));
-    G_HIP(hipMemcpyAsync(E->d_qvel + (size_t)G.e0 * E->nv, E->h_qvel + (size_t)G.e0 * E->nv, (size_t)m * E->nv * sizeof(double),
-                         hipMemcpyHostToDevice, G.stream));
-    G_HIP(hipMemcpyAsync(E->d_ee + (size_t)G.e0 * 15, E->h_ee + (size_t)G.e0 * 15, (size_t)m * 15 * sizeof(double), hipMemcpyHostToDevice, G.stream));
+    {
+        const long total = (long)m * (E->nq + E->nv + 15);
+        k_engine_gather<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, G.stream>>>(
+            E->hd_state + (size_t)G.e0 * E->ld_s, E->ld_s, E->off_qpos, E->off_qvel, E->hd_ee + (size_t)G.e0 * 15, E->nq, E->nv, m,
+            E->d_qpos + (size_t)G.e0 * E->nq, E->d_prev_qpos + (size_t)G.e0 * E->nq, E->d_qvel + (size_t)G.e0 * E->nv,
+            E->d_ee + (size_t)G.e0 * 15);
+        G_HIP(hipGetLastError());
+    }
     G_HIP(hipEventRecord(G.done, G.stream));
     if (G.prof_now) {
         G_HIP(hipStreamSynchronize(G.stream));
@@ -554,7 +578,20 @@ void thread_main(egp_engine *E, int gi, int tid) {
     (void)hipSetDevice(E->ctx->device);
     long seen = 0;
     for (;;) {
-        {
+        // the next env-step of a group usually arrives within a few hundred microseconds (the caller's reward /
+        // observation / policy launches): spin that long before going to sleep on the condition variable
+        bool got = false;
+        if (E->spin_us > 0) {
+            const auto until = clk::now() + std::chrono::microseconds(E->spin_us);
+            int n = 0;
+            while (!(got = G.job_pub.load(std::memory_order_acquire) != seen)) {
+                cpu_relax();
+                if ((++n & 63) == 0 && clk::now() > until) break;
+            }
+        }
+        if (got) {
+            seen = G.job_pub.load(std::memory_order_acquire);
+        } else {
             std::unique_lock<std::mutex> lk(G.mu);
             G.cv_go.wait(lk, [&] { return G.quit || G.job != seen; });
             if (G.quit) return;
@@ -565,7 +602,10 @@ void thread_main(egp_engine *E, int gi, int tid) {
         else run_step(E, G, tid);
         {
             std::lock_guard<std::mutex> lk(G.mu);
-            if (--G.pending == 0) G.cv_done.notify_all();
+            if (--G.pending == 0) {
+                G.pending_pub.store(0, std::memory_order_release);
+                G.cv_done.notify_all();
+            }
         }
     }
 }
@@ -641,6 +681,7 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     {
         const char *zc = getenv("EGP_ZERO_COPY");
         E->zero_copy = !(zc && atoi(zc) == 0);
+        if (const char *su = getenv("EGP_SPIN_US")) E->spin_us = atoi(su);
         const char *fp = getenv("EGP_FLAG_POLL");
         E->flag_poll = !(fp && atoi(fp) == 0);
         void *p1 = nullptr, *p2 = nullptr;
@@ -650,6 +691,8 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
             E->hd_torque = (double *)p2;
             void *p3 = nullptr;
             if (hipHostGetDevicePointer(&p3, E->h_qM, 0) == hipSuccess) E->hd_qM = (double *)p3;
+            void *p4 = nullptr;
+            if (hipHostGetDevicePointer(&p4, E->h_ee, 0) == hipSuccess) E->hd_ee = (double *)p4;
         } else {
             E->zero_copy = false;
         }
@@ -717,7 +760,7 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
             if (const char *sp = getenv("EGP_SERVER_SLICES")) per_thread = std::max(1, atoi(sp));
             while (per_thread > 1 && nb < per_thread * G.n_threads) per_thread /= 2;
             const int ns = per_thread * G.n_threads;
-            if (nb >= ns && E->hd_qM) {
+            if (nb >= ns && E->hd_qM && E->hd_ee) {
                 S.n_slices = ns;
                 S.n_blocks = nb;
                 S.per_thread = per_thread;
@@ -898,7 +941,9 @@ int egp_engine_step_async(egp_engine *E, int32_t group, const double *action, co
             G.chunks[c].phys_done.store(0, std::memory_order_relaxed);
         }
     G.pending = G.n_threads;
+    G.pending_pub.store(G.n_threads, std::memory_order_relaxed);
     G.job += 1;
+    G.job_pub.store(G.job, std::memory_order_release);
     G.cv_go.notify_all();
     return EGP_OK;
 }
@@ -907,7 +952,16 @@ int egp_engine_wait(egp_engine *E, int32_t group, void *stream) {
     EGP_REQUIRE(E, "engine is NULL");
     EGP_REQUIRE(group >= 0 && group < E->n_groups, "group out of range");
     Group &G = E->groups[group];
-    {
+    bool done = false;
+    if (E->spin_us > 0) {               // an env-step takes a few hundred microseconds: poll before sleeping
+        const auto until = clk::now() + std::chrono::microseconds(4 * E->spin_us);
+        int n = 0;
+        while (!(done = G.pending_pub.load(std::memory_order_acquire) == 0)) {
+            cpu_relax();
+            if ((++n & 63) == 0 && clk::now() > until) break;
+        }
+    }
+    if (!done) {
         std::unique_lock<std::mutex> lk(G.mu);
         G.cv_done.wait(lk, [&] { return G.pending == 0; });
     }

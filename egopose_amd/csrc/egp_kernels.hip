@@ -216,7 +216,9 @@ __device__ __forceinline__ void tree_pivot_update(double (&a)[PD_NV], double f, 
     if constexpr (sizeof...(T) > 0) {
         // all broadcasts first (v_readlane -> SGPR pairs), then the FMAs: no SGPR-hazard nops in between
         const double r[sizeof...(T)] = {readlane_f64(a[Tree58::ANC[K][T]], K)...};
+        __builtin_amdgcn_sched_barrier(0);
         ((a[Tree58::ANC[K][T]] = fma(-f, r[T], a[Tree58::ANC[K][T]])), ...);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 

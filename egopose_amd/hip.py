@@ -17,7 +17,7 @@ _DT = {torch.float64: "f64", torch.float32: "f32"}
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return L.current_stream()
 
 
 def _ptr(t: Optional[torch.Tensor]):

@@ -25,7 +25,7 @@ def available(x, cell):
 
 
 def _s():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return L.current_stream()
 
 
 def _p(t):

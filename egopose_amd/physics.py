@@ -211,7 +211,7 @@ class RolloutEngine:
         qpos, qvel = _np_f64(qpos), _np_f64(qvel)
         if qpos.shape != (ids.shape[0], self.ctx.nq) or qvel.shape != (ids.shape[0], self.ctx.nv):
             raise ValueError("reset rows must be (n, nq) / (n, nv)")
-        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        s = L.current_stream()
         L.check(self.lib.egp_engine_reset(self.handle, ids.ctypes.data, ids.shape[0], qpos.ctypes.data, qvel.ctypes.data, s),
                 "egp_engine_reset")
 
@@ -229,7 +229,7 @@ class RolloutEngine:
 
     def wait(self, group):
         import torch
-        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        s = L.current_stream()
         L.check(self.lib.egp_engine_wait(self.handle, int(group), s), "egp_engine_wait")
 
     def set_profile(self, on=True, every=1):

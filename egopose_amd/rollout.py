@@ -23,6 +23,7 @@ import time
 import numpy as np
 import torch
 
+from . import policy_step
 from .rl_core import LoggerRL, TrajBatchEgo
 
 
@@ -104,6 +105,8 @@ class LockstepRollout:
         self._events = [None] * len(self.groups)
         self.up = _Uploader(self.dev, max(4096, self.N))
         self.use_graphs = os.environ.get("EGP_POLICY_GRAPH", "1") != "0"
+        self.use_fused = os.environ.get("EGP_POLICY_FUSED", "1") != "0"     # HIP policy step (float32 PolicyGaussian over an MLP)
+        self._fused = None
         self._graphs = None                 # per group: captured hipGraph of the policy step
         self._graph_key = None
         self.pool_batch = max(256, self.N // 2)
@@ -173,6 +176,10 @@ class LockstepRollout:
     def _policy_body(self, g):
         """action = mean + std * N(0,1) for group g, reading / writing only static buffers (graph-capturable)."""
         a, b = self.groups[g]
+        if self._fused is not None:              # one HIP launch: concat + MLP + Gaussian head
+            self._g_noise[g].normal_()                # default generator: graph-safe philox offsets
+            self._fused(self.v_out[a:b], self._g_tidx[g], self._g_state[g], self._g_act[g], noise=self._g_noise[g])
+            return
         x = torch.cat((self.v_out[a:b][self._ar[g], self._g_tidx[g]], self._g_state[g].to(self.v_out.dtype)), dim=1)
         mean, std = self._mean_std(x)
         self._g_act[g].copy_(torch.addcmul(mean, std, torch.randn_like(mean)))
@@ -184,6 +191,8 @@ class LockstepRollout:
         # `with to_cpu(...)` around checkpoint saving) re-allocates them, so the key includes their addresses
         key = (ndt, self.policy_vs_net.v_hdim) + tuple(p.data_ptr() for p in self.policy_net.parameters())
         if self._graph_key == key:
+            if self._fused is not None:
+                self._fused.refresh()            # same buffers, this iteration's weights
             return
         dev, f64 = self.dev, torch.float64
         self.v_out = torch.zeros(self.N, self.T_ep, self.policy_vs_net.v_hdim, dtype=ndt, device=dev)
@@ -191,6 +200,10 @@ class LockstepRollout:
         self._g_tidx = [torch.zeros(b - a, dtype=torch.int64, device=dev) for a, b in self.groups]
         self._g_state = [torch.zeros(b - a, self.ctx.obs_dim, dtype=f64, device=dev) for a, b in self.groups]
         self._g_act = [torch.zeros(b - a, self.ctx.nu, dtype=f64, device=dev) for a, b in self.groups]
+        self._g_noise = [torch.zeros(b - a, self.ctx.nu, dtype=torch.float32, device=dev) for a, b in self.groups]
+        self._fused = None
+        if self.use_fused and ndt == torch.float32 and policy_step.supported(self.policy_net):
+            self._fused = policy_step.FusedGaussianPolicy(self.policy_net, dev)
         self._graph_key = key
         self._graphs = None
         if not self.use_graphs:

@@ -204,6 +204,24 @@ int egp_lstm_bwd_f32(const float *dh_out, const float *gates_save, const float *
                      int32_t T, int32_t B, int32_t hidden, int32_t reverse, float *d_pre, void *stream);
 
 /* ----------------------------------------------------------------------------------------
+ * Rollout-time policy step in one launch (replaces, for all envs of a group at once, the chain
+ * VideoStateNet.forward concat (models/video_state_net.py:37-43) -> MLP (models/mlp.py:5-25) ->
+ * PolicyGaussian.forward / select_action (models/policy_gaussian.py:19-27, core/agent.py:38-44)):
+ *   x[r] = [ctx_rows[r*ctx_row_stride + t_idx[r]*ctx_dim ...] (float32) | state[r] (float64 -> float32)]
+ *   hidden layers with `activation` (0 tanh, 1 relu, 2 sigmoid), last layer = action_mean (no activation)
+ *   action[r] = mean + exp(log_std) * noise[r]   (noise == NULL: action = mean), float32 arithmetic, stored float64
+ * `layers[l].wt` is the TRANSPOSED weight, [in_dim][out_dim] row-major. mean_out (float32) may be NULL. */
+typedef struct egp_mlp_layer {
+    const float *wt;
+    const float *bias;
+    int32_t in_dim, out_dim;
+} egp_mlp_layer;
+int egp_policy_gaussian_f32(const float *ctx_rows, int64_t ctx_row_stride, int32_t ctx_dim, const int64_t *t_idx,
+                            const double *state, int32_t state_dim, int32_t n, const egp_mlp_layer *layers,
+                            int32_t n_layers, int32_t activation, const float *log_std, const float *noise,
+                            double *action, float *mean_out, void *stream);
+
+/* ----------------------------------------------------------------------------------------
  * Host physics boundary (replaces mujoco_py's MjSim inside HumanoidEnv: envs/common/mujoco_env.py:84-105,
  * ego_pose/envs/humanoid_v1.py:158-177). A backend is a vtable of plain C callbacks working on one
  * env at a time; all buffers are HOST memory owned by the engine.

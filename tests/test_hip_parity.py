@@ -357,3 +357,44 @@ def test_engine_follows_changing_inertia(ctx, skel, mode, monkeypatch):
         np.testing.assert_allclose(got_q[e], q, rtol=1e-8, atol=1e-8)
     ref.close()
     be.close()
+
+
+# ------------------------------------------------------------------------------------------------ fused policy step
+@pytest.mark.parametrize("act,hidden,n", [("relu", (300, 200), 517), ("tanh", (64,), 3), ("sigmoid", (130, 70, 33), 64)])
+def test_fused_policy_step_matches_torch(act, hidden, n):
+    """egp_policy_gaussian_f32 == cat(v_out[t], state) -> MLP -> action_mean -> mean + exp(log_std) * noise in torch
+    (float32; tolerance 2e-5 relative to the output scale: different summation order only)."""
+    from egopose_amd.nets import MLP, PolicyGaussian
+    from egopose_amd import policy_step
+    torch.manual_seed(3)
+    H, S, T, nu = 128, 115, 9, 52
+    pol = PolicyGaussian(MLP(H + S, hidden, act), nu, log_std=-0.7).cuda()
+    with torch.no_grad():
+        pol.action_mean.weight.mul_(10.0)
+        pol.action_mean.bias.normal_()
+        pol.action_log_std.normal_(std=0.3)
+    assert policy_step.supported(pol)
+    fp = policy_step.FusedGaussianPolicy(pol, torch.device("cuda"))
+    v_out = torch.randn(n, T, H, device="cuda")
+    t_idx = torch.randint(0, T, (n,), device="cuda")
+    state = torch.randn(n, S, dtype=torch.float64, device="cuda") * 2
+    noise = torch.randn(n, nu, device="cuda")
+    act_out = torch.empty(n, nu, dtype=torch.float64, device="cuda")
+    mean_out = torch.empty(n, nu, device="cuda")
+    fp(v_out, t_idx, state, act_out, noise=noise, mean_out=mean_out)
+    with torch.no_grad():
+        x = torch.cat((v_out[torch.arange(n, device="cuda"), t_idx], state.float()), 1)
+        mean, std = pol.mean_std(x)
+        ref = (mean + std * noise).double()
+    scale = float(ref.abs().max())
+    assert float((mean_out - mean).abs().max()) <= 2e-5 * max(1.0, float(mean.abs().max()))
+    assert float((act_out - ref).abs().max()) <= 2e-5 * max(1.0, scale)
+    # mean action (noise None) and a parameter refresh
+    with torch.no_grad():
+        pol.net.affine_layers[0].weight.add_(0.01)
+    fp.refresh()
+    fp(v_out, t_idx, state, act_out)
+    with torch.no_grad():
+        mean2, _ = pol.mean_std(x)
+    assert float((act_out - mean2.double()).abs().max()) <= 2e-5 * max(1.0, float(mean2.abs().max()))
+    assert float((mean2 - mean).abs().max()) > 1e-4
