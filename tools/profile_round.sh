@@ -1,0 +1,50 @@
+#!/bin/bash
+# Round profile set (run on the GPU box through gpurun): writes gpurun_out/profiles_round/
+#   bench_kernel_stats.csv      rocprofv3 --kernel-trace --stats over the default `python bench.py`
+#   bench_line_under_rocprof.json   the JSON line that run printed
+#   pmc_bench_fetch_write.csv   FETCH_SIZE / WRITE_SIZE per egp kernel (separate --pmc passes, kernel-trace only)
+#   pmc_k1_traffic.json         HBM bytes per env-substep of the dominant kernel from those passes
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_round
+rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -o b -- python bench.py > $OUT/bench.log 2>&1
+grep '^{' $OUT/bench.log | tail -1 > $OUT/bench_line_under_rocprof.json
+cp "$(find $OUT/raw -name '*kernel_stats.csv' | head -1)" $OUT/bench_kernel_stats.csv
+rm -rf $OUT/raw
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o b -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-k1-events > $OUT/$c.log 2>&1
+done
+python - <<PY
+import csv, glob, collections, json
+OUT = "$OUT"
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for path in glob.glob(OUT + "/%s/**/*counter_collection.csv" % c, recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r.get("Counter_Name") != c or "egp::" not in r["Kernel_Name"]: continue
+            k = r["Kernel_Name"][:64] + "|grid=" + r.get("Grid_Size", "?")
+            acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
+    res[c] = acc
+rows = ["kernel|grid,launches,FETCH_SIZE_KiB_avg,WRITE_SIZE_KiB_avg"]
+k1 = None
+for k in sorted(set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"])):
+    f, nf = res["FETCH_SIZE"].get(k, [0, 0]); w, nw = res["WRITE_SIZE"].get(k, [0, 0])
+    rows.append("%s,%d,%.2f,%.2f" % (k, max(nf, nw), f / max(nf, 1), w / max(nw, 1)))
+    if "k_pd_server_tree58" in k and (k1 is None or max(nf, nw) > k1[1]):
+        k1 = (k, max(nf, nw), f / max(nf, 1), w / max(nw, 1))
+open(OUT + "/pmc_bench_fetch_write.csv", "w").write("\n".join(rows) + "\n")
+if k1:
+    grid = int(k1[0].split("grid=")[1])
+    envs = grid // 256 * 4
+    d = {"kernel": "k_pd_server_tree58 (resident K1: one launch = 15 substeps of a %d-env group)" % envs,
+         "source": "profiles/r01_pmc_bench_n1_fetch_write.csv (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 1 --warmup 0, %d launches)" % k1[1],
+         "fetch_kib_per_launch": k1[2], "write_kib_per_launch": k1[3], "envs_per_launch": envs, "substeps_per_launch": 15,
+         "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads -> bytes = (2*FETCH + WRITE) * 1024; the counters also see the state rows / torques in pinned host memory (zero-copy) and the go-word polls",
+         "hbm_bytes_per_env_substep": (2 * k1[2] + k1[3]) * 1024 / (envs * 15)}
+    json.dump(d, open(OUT + "/pmc_k1_traffic.json", "w"), indent=1)
+print("\n".join(rows))
+PY
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
+head -12 $OUT/bench_kernel_stats.csv | cut -c1-160
+cat $OUT/pmc_k1_traffic.json
