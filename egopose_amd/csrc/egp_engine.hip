@@ -152,32 +152,36 @@ struct egp_engine {
     std::vector<Group> groups;
     std::vector<int64_t> epoch;               // last drained inertia epoch per env (-1 = never)
     std::vector<int> env_group, env_chunk, env_slice;
+    int *h_reset_list = nullptr, *hd_reset_list = nullptr;   // pinned (env, qM_changed) pairs of the reset in flight
+    hipEvent_t reset_done = nullptr;                          // recorded behind the scatter kernel of the last reset
+    bool reset_pending = false;
 };
 
 namespace {
 
-// mark_dirty: flag the env's group / chunk / slice for an inertia upload (the substep loop); egp_engine_reset
-// uploads the rows it drained itself and must leave the flags of its neighbours alone
-// End of a resident-K1 env-step: prev_qpos <- qpos, then qpos | qvel | ee_wpos <- the pinned rows the physics
-// threads drained (read over PCIe inside the kernel). One launch instead of a D2D and three H2D copy-engine calls.
-__global__ __launch_bounds__(256) void k_engine_gather(const double *__restrict__ h_state, int ld_s, int off_qpos, int off_qvel,
-                                                       const double *__restrict__ h_ee, int nq, int nv, int n, double *qpos,
-                                                       double *prev_qpos, double *qvel, double *ee) {
-    const int per_env = nq + nv + 15;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)n * per_env) return;
-    const int e = (int)(i / per_env), c = (int)(i % per_env);
-    if (c < nq) {
-        const long d = (long)e * nq + c;
-        prev_qpos[d] = qpos[d];
-        qpos[d] = h_state[(long)e * ld_s + off_qpos + c];
-    } else if (c < nq + nv) {
-        qvel[(long)e * nv + (c - nq)] = h_state[(long)e * ld_s + off_qvel + (c - nq)];
-    } else {
-        ee[(long)e * 15 + (c - nq - nv)] = h_ee[(long)e * 15 + (c - nq - nv)];
+// egp_engine_reset on a zero-copy engine: ONE launch moves the freshly drained pinned rows of the listed envs to
+// their HBM mirrors (block per env; the list holds (env, qM_changed) pairs in pinned memory) instead of five
+// copy-engine calls per run of consecutive env ids.
+__global__ __launch_bounds__(256) void k_engine_reset_scatter(const int *__restrict__ list, const double *__restrict__ h_state, int ld_s,
+                                                              int off_qpos, int off_qvel, const double *__restrict__ h_ee,
+                                                              const double *__restrict__ h_qM, int ld_m, int nM, int nq, int nv,
+                                                              double *d_state, double *d_qpos, double *d_qvel, double *d_ee,
+                                                              double *d_qM) {
+    const int e = list[2 * blockIdx.x], new_qM = list[2 * blockIdx.x + 1];
+    const double *row = h_state + (long)e * ld_s;
+    for (int c = threadIdx.x; c < ld_s; c += blockDim.x) {
+        const double v = row[c];
+        d_state[(long)e * ld_s + c] = v;
+        if (c >= off_qpos && c < off_qpos + nq) d_qpos[(long)e * nq + (c - off_qpos)] = v;
+        if (c >= off_qvel && c < off_qvel + nv) d_qvel[(long)e * nv + (c - off_qvel)] = v;
     }
+    if (threadIdx.x < 15) d_ee[(long)e * 15 + threadIdx.x] = h_ee[(long)e * 15 + threadIdx.x];
+    if (new_qM)
+        for (int c = threadIdx.x; c < nM; c += blockDim.x) d_qM[(long)e * ld_m + c] = h_qM[(long)e * ld_m + c];
 }
 
+// mark_dirty: flag the env's group / chunk / slice for an inertia upload (the substep loop); egp_engine_reset
+// uploads the rows it drained itself and must leave the flags of its neighbours alone
 int drain_env(egp_engine *E, int env, bool with_xpos, bool mark_dirty = true) {
     double *row = E->h_state + (size_t)env * E->ld_s;
     double *xp = with_xpos ? E->h_xpos + (size_t)env * E->nbody * 3 : nullptr;
@@ -360,9 +364,12 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
         int rc = egp_launch_pd_server(E->ctx, st + E->off_qpos, E->ld_s, st + E->off_qvel, E->ld_s, st + E->off_bias, E->ld_s,
                                       E->d_qM + (size_t)G.e0 * E->ld_m, E->ld_m, E->hd_qM + (size_t)G.e0 * E->ld_m,
                                       G.action + (size_t)G.e0 * nu, m, E->hd_torque + (size_t)G.e0 * nu, G.stream, S.d_block_slice,
-                                      S.hd_go, base, FS, S.hd_err, 2.0, S.d_trace);
+                                      S.hd_go, base, FS, S.hd_err, 2.0, S.d_trace, E->hd_ee + (size_t)G.e0 * 15,
+                                      E->d_qpos + (size_t)G.e0 * E->nq, E->d_prev_qpos + (size_t)G.e0 * E->nq,
+                                      E->d_qvel + (size_t)G.e0 * E->nv, E->d_ee + (size_t)G.e0 * 15);
         if (rc != EGP_OK) fail(G, rc, "K1 server launch", egp_last_error());
         if (G.prof_now) G_HIP(hipEventRecord(G.k_end[0], G.stream));
+        G_HIP(hipEventRecord(G.done, G.stream));      // the kernel's epilogue moves the final state to HBM
     }
     const bool timekeeper = tid == (G.n_threads > 1 ? 1 : 0);
     double t_wait = 0.0, t_phys = 0.0;
@@ -407,6 +414,10 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
                 fill_sentinel(E->h_torque + (size_t)S.e0[sl] * nu, (size_t)(S.e1[sl] - S.e0[sl]) * nu);
                 __atomic_store_n(S.h_go + sl * 8, ((base + (unsigned long long)s + 1ull) << 1) | (unsigned long long)S.dirty[sl].exchange(0),
                                  __ATOMIC_RELEASE);
+            } else {
+                // final state of the slice is drained: let the kernel's epilogue move it to HBM (a pending qM refresh
+                // stays flagged for the next env-step)
+                __atomic_store_n(S.h_go + sl * 8, (base + (unsigned long long)FS) << 1, __ATOMIC_RELEASE);
             }
             if (tr) S.host_trace[s * 4 + 2] = secs(t_job, clk::now()) * 1e6;
             if (timekeeper) {
@@ -425,16 +436,6 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
     }
     G.qM_dirty.store(0, std::memory_order_relaxed);
     for (int c = 0; c < G.n_chunks; ++c) G.chunks[c].qM_dirty.store(0, std::memory_order_relaxed);
-    const int m = G.e1 - G.e0;
-    {
-        const long total = (long)m * (E->nq + E->nv + 15);
-        k_engine_gather<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, G.stream>>>(
-            E->hd_state + (size_t)G.e0 * E->ld_s, E->ld_s, E->off_qpos, E->off_qvel, E->hd_ee + (size_t)G.e0 * 15, E->nq, E->nv, m,
-            E->d_qpos + (size_t)G.e0 * E->nq, E->d_prev_qpos + (size_t)G.e0 * E->nq, E->d_qvel + (size_t)G.e0 * E->nv,
-            E->d_ee + (size_t)G.e0 * 15);
-        G_HIP(hipGetLastError());
-    }
-    G_HIP(hipEventRecord(G.done, G.stream));
     if (G.prof_now) {
         G_HIP(hipStreamSynchronize(G.stream));
         float ms = 0.f;
@@ -697,6 +698,13 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
             E->zero_copy = false;
         }
     }
+    if (E->zero_copy && E->hd_qM && E->hd_ee) {
+        void *p = nullptr;
+        if (hipHostMalloc((void **)&E->h_reset_list, N * 2 * sizeof(int), hipHostMallocDefault) == hipSuccess &&
+            hipHostGetDevicePointer(&p, E->h_reset_list, 0) == hipSuccess &&
+            hipEventCreateWithFlags(&E->reset_done, hipEventDisableTiming) == hipSuccess)
+            E->hd_reset_list = (int *)p;
+    }
     memset(E->h_state, 0, N * E->ld_s * sizeof(double));
     memset(E->h_qM, 0, N * E->ld_m * sizeof(double));
     memset(E->h_headz, 0, N * sizeof(double));
@@ -849,7 +857,8 @@ int egp_engine_destroy(egp_engine *E) {
     }
     void *dev[] = {E->d_state, E->d_qM, E->d_prev_qpos, E->d_qpos, E->d_qvel, E->d_torque, E->d_ee};
     for (void *p : dev) if (p) (void)hipFree(p);
-    void *host[] = {E->h_state, E->h_qM, E->h_qpos, E->h_qvel, E->h_torque, E->h_ee, E->h_headz, E->h_xpos};
+    if (E->reset_done) (void)hipEventDestroy(E->reset_done);
+    void *host[] = {E->h_state, E->h_qM, E->h_qpos, E->h_qvel, E->h_torque, E->h_ee, E->h_headz, E->h_xpos, E->h_reset_list};
     for (void *p : host) if (p) (void)hipHostFree(p);
     delete E;
     return EGP_OK;
@@ -885,6 +894,10 @@ int egp_engine_reset(egp_engine *E, const int32_t *ids, int32_t n, const double 
             EGP_HIP_CHECK(hipEventSynchronize(E->groups[g].done));
         }
     }
+    if (E->reset_pending) {              // the previous reset's kernel reads the pinned rows and the env list
+        EGP_HIP_CHECK(hipEventSynchronize(E->reset_done));
+        E->reset_pending = false;
+    }
     for (int k = 0; k < n; ++k) {
         const int e = ids[k];
         EGP_REQUIRE(e >= 0 && e < E->n_env, "env id out of range");
@@ -900,6 +913,16 @@ int egp_engine_reset(egp_engine *E, const int32_t *ids, int32_t n, const double 
             return EGP_E_PHYSICS;
         }
         new_qM[k] = !E->vt->inertia_epoch || E->epoch[e] != before;
+    }
+    if (E->hd_reset_list && n > 0) {
+        for (int k = 0; k < n; ++k) { E->h_reset_list[2 * k] = ids[k]; E->h_reset_list[2 * k + 1] = new_qM[k]; }
+        k_engine_reset_scatter<<<dim3(n), dim3(256), 0, s>>>(E->hd_reset_list, E->hd_state, E->ld_s, E->off_qpos, E->off_qvel, E->hd_ee,
+                                                              E->hd_qM, E->ld_m, E->nM, E->nq, E->nv, E->d_state, E->d_qpos, E->d_qvel,
+                                                              E->d_ee, E->d_qM);
+        EGP_HIP_CHECK(hipGetLastError());
+        EGP_HIP_CHECK(hipEventRecord(E->reset_done, s));
+        E->reset_pending = true;
+        return EGP_OK;
     }
     int k = 0;
     while (k < n) {                  // upload maximal runs of consecutive env ids

@@ -76,7 +76,8 @@ int egp_launch_pd_torque_strided(egp_ctx *ctx, const double *qpos, long ld_qpos,
 int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const double *qvel, long ld_qvel, const double *bias,
                          long ld_bias, const double *qM, long ld_qM, const double *qM_host, const double *action, int32_t n,
                          double *torque, hipStream_t stream, const int *block_slice, const unsigned long long *go,
-                         unsigned long long base, int n_sub, int *err, double timeout_s, long long *trace);
+                         unsigned long long base, int n_sub, int *err, double timeout_s, long long *trace, const double *ee_host,
+                         double *out_qpos, double *out_prev_qpos, double *out_qvel, double *out_ee);
 // bit pattern the engine pre-fills pinned torque rows with in resident-K1 mode (a quiet NaN no clipped torque can equal)
 constexpr unsigned long long EGP_TORQUE_SENTINEL = 0x7FF8DEADBEEF0001ull;
 const egp_physics_vtable *egp_physics_vt(const egp_physics *p);

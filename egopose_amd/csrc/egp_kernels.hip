@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "egp_internal.hpp"
@@ -351,7 +352,22 @@ struct PdServe {
     int *err;                             // host: set when a wait timed out
     long long timeout_ticks;              // wall_clock64 ticks (100 MHz)
     long long *trace;                     // optional [n_sub * 8] wall_clock64 stamps of block 0 (diagnostics)
+    // epilogue (go word reaches base + n_sub: the slice's last physics step is drained): final state -> HBM
+    const double *ee_host;                // [n][15] pinned end-effector rows (device alias)
+    double *out_qpos, *out_prev_qpos, *out_qvel, *out_ee;   // HBM [n][nq] / [n][nq] / [n][nv] / [n][15]
+    int nq, nv;
+    int poll_sleep;                       // s_sleep(1) (64 clocks) repeats between two polls of a go word
 };
+
+// Poll a word of pinned host memory through the SCALAR memory path (s_load ... glc = always fetch from beyond the
+// scalar cache). A vector load that is out on PCIe for ~2 us sits in the CU's in-order vector-memory return queue,
+// and with a polling block on every CU that stalled the loads of every other kernel on the chip (a 17 us policy
+// kernel took 160 us next to the polling engine); scalar loads do not go through that queue.
+__device__ __forceinline__ unsigned long long scalar_poll_u64(const unsigned long long *p) {
+    unsigned long long v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
 
 __device__ __forceinline__ double sys_load_f64(const double *p) {
     const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -407,9 +423,9 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
             const long long t0 = wall_clock64();
             unsigned long long v;
             for (;;) {
-                v = __hip_atomic_load(sv.go + slice * 8, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                v = scalar_poll_u64(sv.go + slice * 8);
                 if ((v >> 1) >= want) break;
-                __builtin_amdgcn_s_sleep(2);
+                for (int z = 0; z < sv.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
                 if (wall_clock64() - t0 > sv.timeout_ticks) { s_abort = 1; break; }
             }
             s_go[sub & 1] = v;            // double-buffered: one barrier per substep is enough
@@ -467,6 +483,40 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
                                    __HIP_MEMORY_SCOPE_SYSTEM);
             }
             if (tracer) sv.trace[sub * 8 + 4] = wall_clock64();
+        }
+    }
+    // epilogue: prev_qpos <- qpos; qpos | qvel | ee_wpos <- the rows the owner drained after the last substep.
+    // Runs slice by slice as the physics threads finish, so the env-step ends one PCIe round trip after the last
+    // physics call instead of a barrier + a copy launch later.
+    {
+        const int slot = sv.n_sub & 1;
+        if (threadIdx.x == 0) {
+            const unsigned long long want = sv.base + (unsigned long long)sv.n_sub;
+            const long long t0 = wall_clock64();
+            unsigned long long v;
+            for (;;) {
+                v = scalar_poll_u64(sv.go + slice * 8);
+                if ((v >> 1) >= want) break;
+                for (int z = 0; z < sv.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > sv.timeout_ticks) { s_abort = 1; break; }
+            }
+            s_go[slot] = v;
+        }
+        __syncthreads();
+        if (s_abort) {
+            if (threadIdx.x == 0) __hip_atomic_store(sv.err, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        if (valid) {
+            // the row base of qpos: `qpos` points at the state rows' qpos column (offset 0 of the row)
+            if (lane < sv.nq) {
+                const long d = env * sv.nq + lane;
+                const double q = sys_load_f64(qpos + env * ld.qpos + lane);
+                sv.out_prev_qpos[d] = sv.out_qpos[d];
+                sv.out_qpos[d] = q;
+            }
+            if (lane < sv.nv) sv.out_qvel[env * sv.nv + lane] = sys_load_f64(qvel + env * ld.qvel + lane);
+            if (lane < 15) sv.out_ee[env * 15 + lane] = sys_load_f64(sv.ee_host + env * 15 + lane);
         }
     }
 }
@@ -1199,12 +1249,17 @@ int egp_launch_pd_torque_strided(egp_ctx *ctx, const double *qpos, long ld_qpos,
 int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const double *qvel, long ld_qvel, const double *bias,
                          long ld_bias, const double *qM, long ld_qM, const double *qM_host, const double *action, int32_t n,
                          double *torque, hipStream_t stream, const int *block_slice, const unsigned long long *go,
-                         unsigned long long base, int n_sub, int *err, double timeout_s, long long *trace) {
+                         unsigned long long base, int n_sub, int *err, double timeout_s, long long *trace, const double *ee_host,
+                         double *out_qpos, double *out_prev_qpos, double *out_qvel, double *out_ee) {
     EGP_REQUIRE(ctx && ctx->tree58 && ctx->pd_variant == 0, "the K1 server needs the humanoid tree kernel");
+    EGP_REQUIRE(ee_host && out_qpos && out_prev_qpos && out_qvel && out_ee, "NULL epilogue pointer");
+    EGP_REQUIRE(ctx->dm.nq <= 64 && ctx->dm.nv <= 64, "the epilogue moves one state row per wavefront");
     EGP_REQUIRE(qpos && qvel && bias && qM && qM_host && action && torque && block_slice && go && err, "NULL pointer");
     EGP_REQUIRE(n > 0 && n_sub > 0, "n and n_sub must be positive");
     PdLd ld{ld_qpos, ld_qvel, ctx->dm.nu, ld_qM, ld_bias};
-    PdServe sv{block_slice, go, base, n_sub, qM_host, const_cast<double *>(qM), err, (long long)(timeout_s * 100.0e6), trace};
+    static const int poll_sleep = [] { const char *e = getenv("EGP_SERVER_POLL_SLEEP"); return e ? atoi(e) : 2; }();
+    PdServe sv{block_slice, go, base, n_sub, qM_host, const_cast<double *>(qM), err, (long long)(timeout_s * 100.0e6), trace,
+               ee_host, out_qpos, out_prev_qpos, out_qvel, out_ee, ctx->dm.nq, ctx->dm.nv, poll_sleep};
     k_pd_server_tree58<<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, bias, n, torque, sv);
     return after_launch("k_pd_server_tree58");
 }

@@ -17,7 +17,7 @@ constexpr int POL_ROWS = 4;          // rows per workgroup
 constexpr int POL_MAX_LAYERS = 8;
 
 struct PolLayers {
-    const float *wt[POL_MAX_LAYERS];     // W^T, [in][out] row-major
+    const float *wt[POL_MAX_LAYERS];     // W^T, [in][round_up(out, 4)] row-major, 16-byte aligned
     const float *bias[POL_MAX_LAYERS];
     int in_dim[POL_MAX_LAYERS], out_dim[POL_MAX_LAYERS];
     int n;                                // hidden layers + the output layer
@@ -29,12 +29,14 @@ __device__ __forceinline__ float pol_act(float v, int kind) {
     return tanhf(v);                                      // tanh
 }
 
+// Thread t of a layer pass owns 4 consecutive outputs (one 16-byte weight load per input feature) for one slice of
+// the input features; the slices' partial sums meet in LDS. With 320 threads: 300 outputs -> 75 columns x 4 slices.
 __global__ void k_policy_gaussian(const float *__restrict__ ctx_rows, long ctx_row_stride, int ctx_dim,
                                   const long long *__restrict__ t_idx, const double *__restrict__ state, int state_dim, int n,
-                                  PolLayers L, int act_kind, int kmax, const float *__restrict__ log_std,
+                                  PolLayers L, int act_kind, int kmax, int part_elems, const float *__restrict__ log_std,
                                   const float *__restrict__ noise, double *__restrict__ action, float *__restrict__ mean_out) {
-    extern __shared__ float4 s_act[];     // two buffers of kmax float4 (one float per row of the tile)
-    float4 *cur = s_act, *nxt = s_act + kmax;
+    extern __shared__ float4 s_act[];     // cur[kmax] | nxt[kmax] | part[part_elems]   (one float per row of the tile)
+    float4 *cur = s_act, *nxt = s_act + kmax, *part = s_act + 2 * kmax;
     const int r0 = blockIdx.x * POL_ROWS;
     const int in0 = ctx_dim + state_dim;
     for (int k = threadIdx.x; k < in0; k += blockDim.x) {
@@ -51,30 +53,53 @@ __global__ void k_policy_gaussian(const float *__restrict__ ctx_rows, long ctx_r
     __syncthreads();
     for (int l = 0; l < L.n; ++l) {
         const int in = L.in_dim[l], out = L.out_dim[l];
-        const float *__restrict__ wt = L.wt[l];
+        const int ldw = (out + 3) & ~3;                      // weight rows are padded to 4 floats
+        const int ncol = ldw >> 2;
+        const float4 *__restrict__ wt = reinterpret_cast<const float4 *>(L.wt[l]);
         const bool last = l == L.n - 1;
+        const int cols = ncol < (int)blockDim.x ? ncol : (int)blockDim.x;
+        const int G = blockDim.x / cols;                     // input-feature slices
+        const int kc = (in + G - 1) / G;
+        const int col_l = threadIdx.x % cols, grp = threadIdx.x / cols;
+        for (int c0 = 0; c0 < ncol; c0 += cols) {
+            const int col = c0 + col_l;
+            if (grp < G && col < ncol) {
+                float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;      // a_o = output o of the column, .xyzw = rows
+                const int k0 = grp * kc, k1 = min(in, k0 + kc);
+                int k = k0;
+                for (; k + 4 <= k1; k += 4) {
+                    const float4 w0 = wt[(long)(k + 0) * ncol + col], w1 = wt[(long)(k + 1) * ncol + col];
+                    const float4 w2 = wt[(long)(k + 2) * ncol + col], w3 = wt[(long)(k + 3) * ncol + col];
+                    const float4 x0 = cur[k], x1 = cur[k + 1], x2 = cur[k + 2], x3 = cur[k + 3];
+#define POL_FMA(W, X)                                                                                                     \
+    a0.x = fmaf(W.x, X.x, a0.x); a0.y = fmaf(W.x, X.y, a0.y); a0.z = fmaf(W.x, X.z, a0.z); a0.w = fmaf(W.x, X.w, a0.w);   \
+    a1.x = fmaf(W.y, X.x, a1.x); a1.y = fmaf(W.y, X.y, a1.y); a1.z = fmaf(W.y, X.z, a1.z); a1.w = fmaf(W.y, X.w, a1.w);   \
+    a2.x = fmaf(W.z, X.x, a2.x); a2.y = fmaf(W.z, X.y, a2.y); a2.z = fmaf(W.z, X.z, a2.z); a2.w = fmaf(W.z, X.w, a2.w);   \
+    a3.x = fmaf(W.w, X.x, a3.x); a3.y = fmaf(W.w, X.y, a3.y); a3.z = fmaf(W.w, X.z, a3.z); a3.w = fmaf(W.w, X.w, a3.w);
+                    POL_FMA(w0, x0) POL_FMA(w1, x1) POL_FMA(w2, x2) POL_FMA(w3, x3)
+                }
+                for (; k < k1; ++k) {
+                    const float4 w = wt[(long)k * ncol + col];
+                    const float4 x = cur[k];
+                    POL_FMA(w, x)
+                }
+#undef POL_FMA
+                float4 *pp = part + ((long)grp * ncol + col) * 4;
+                pp[0] = a0; pp[1] = a1; pp[2] = a2; pp[3] = a3;
+            }
+        }
+        __syncthreads();
         for (int j = threadIdx.x; j < out; j += blockDim.x) {
             const float b = L.bias[l][j];
-            float a0 = b, a1 = b, a2 = b, a3 = b;
-            int k = 0;
-            for (; k + 4 <= in; k += 4) {           // 4 weight loads in flight per thread
-                const float w0 = wt[(long)(k + 0) * out + j], w1 = wt[(long)(k + 1) * out + j];
-                const float w2 = wt[(long)(k + 2) * out + j], w3 = wt[(long)(k + 3) * out + j];
-                const float4 x0 = cur[k], x1 = cur[k + 1], x2 = cur[k + 2], x3 = cur[k + 3];
-                a0 = fmaf(w0, x0.x, a0); a1 = fmaf(w0, x0.y, a1); a2 = fmaf(w0, x0.z, a2); a3 = fmaf(w0, x0.w, a3);
-                a0 = fmaf(w1, x1.x, a0); a1 = fmaf(w1, x1.y, a1); a2 = fmaf(w1, x1.z, a2); a3 = fmaf(w1, x1.w, a3);
-                a0 = fmaf(w2, x2.x, a0); a1 = fmaf(w2, x2.y, a1); a2 = fmaf(w2, x2.z, a2); a3 = fmaf(w2, x2.w, a3);
-                a0 = fmaf(w3, x3.x, a0); a1 = fmaf(w3, x3.y, a1); a2 = fmaf(w3, x3.z, a2); a3 = fmaf(w3, x3.w, a3);
-            }
-            for (; k < in; ++k) {
-                const float w = wt[(long)k * out + j];
-                const float4 x = cur[k];
-                a0 = fmaf(w, x.x, a0); a1 = fmaf(w, x.y, a1); a2 = fmaf(w, x.z, a2); a3 = fmaf(w, x.w, a3);
+            float4 acc = make_float4(b, b, b, b);
+            for (int g = 0; g < G; ++g) {                   // fixed order: deterministic
+                const float4 p = part[((long)g * ncol + (j >> 2)) * 4 + (j & 3)];
+                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
             }
             if (!last) {
-                nxt[j] = make_float4(pol_act(a0, act_kind), pol_act(a1, act_kind), pol_act(a2, act_kind), pol_act(a3, act_kind));
+                nxt[j] = make_float4(pol_act(acc.x, act_kind), pol_act(acc.y, act_kind), pol_act(acc.z, act_kind), pol_act(acc.w, act_kind));
             } else {
-                const float m[POL_ROWS] = {a0, a1, a2, a3};
+                const float m[POL_ROWS] = {acc.x, acc.y, acc.z, acc.w};
                 const float sd = noise ? expf(log_std[j]) : 0.0f;
 #pragma unroll
                 for (int r = 0; r < POL_ROWS; ++r) {
@@ -116,14 +141,20 @@ extern "C" int egp_policy_gaussian_f32(const float *ctx_rows, int64_t ctx_row_st
     }
     L.n = n_layers;
     EGP_REQUIRE(kmax <= 2048, "layer wider than 2048");
-    int widest = 64;
-    for (int l = 0; l < n_layers; ++l) widest = layers[l].out_dim > widest ? layers[l].out_dim : widest;
-    int threads = ((widest + 63) / 64) * 64;
-    if (threads > 512) threads = 512;
-    const size_t lds = (size_t)2 * kmax * sizeof(float4);
+    const int threads = 320;
+    int part_elems = 0;                 // float4 slots for the partial sums: slices x padded outputs
+    for (int l = 0; l < n_layers; ++l) {
+        const int ncol = (layers[l].out_dim + 3) / 4;
+        const int cols = ncol < threads ? ncol : threads;
+        const int G = threads / cols;
+        const int e = G * ncol * 4;
+        if (e > part_elems) part_elems = e;
+    }
+    const size_t lds = ((size_t)2 * kmax + part_elems) * sizeof(float4);
+    EGP_REQUIRE(lds <= 150 * 1024, "layers too wide for the LDS tile");
     k_policy_gaussian<<<dim3((n + POL_ROWS - 1) / POL_ROWS), dim3(threads), lds, (hipStream_t)stream>>>(
-        ctx_rows, (long)ctx_row_stride, ctx_dim, (const long long *)t_idx, state, state_dim, n, L, activation, kmax, log_std, noise,
-        action, mean_out);
+        ctx_rows, (long)ctx_row_stride, ctx_dim, (const long long *)t_idx, state, state_dim, n, L, activation, kmax, part_elems,
+        log_std, noise, action, mean_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { egp::set_error("k_policy_gaussian launch failed: %s", hipGetErrorString(e)); return EGP_E_HIP; }
     return EGP_OK;

@@ -31,7 +31,8 @@ class FusedGaussianPolicy:
         self.net = policy_net
         self.layers = list(policy_net.net.affine_layers) + [policy_net.action_mean]
         self.act = _ACT_CODE[policy_net.net.activation]
-        self.wt = [torch.empty(l.in_features, l.out_features, dtype=torch.float32, device=device) for l in self.layers]
+        pad4 = lambda v: (v + 3) // 4 * 4          # the kernel reads weight rows as float4
+        self.wt = [torch.zeros(l.in_features, pad4(l.out_features), dtype=torch.float32, device=device) for l in self.layers]
         self.bias = [torch.empty(l.out_features, dtype=torch.float32, device=device) for l in self.layers]
         self.log_std = torch.empty(self.layers[-1].out_features, dtype=torch.float32, device=device)
         self.desc = (L.MlpLayer * len(self.layers))()
@@ -47,7 +48,7 @@ class FusedGaussianPolicy:
     def refresh(self):
         """Copy the live parameters into the transposed buffers (call once per rollout, after the optimiser step)."""
         for l, wt, b in zip(self.layers, self.wt, self.bias):
-            wt.copy_(l.weight.t())
+            wt[:, :l.out_features].copy_(l.weight.t())
             b.copy_(l.bias)
         self.log_std.copy_(self.net.action_log_std.reshape(-1))
 

@@ -210,7 +210,8 @@ int egp_lstm_bwd_f32(const float *dh_out, const float *gates_save, const float *
  *   x[r] = [ctx_rows[r*ctx_row_stride + t_idx[r]*ctx_dim ...] (float32) | state[r] (float64 -> float32)]
  *   hidden layers with `activation` (0 tanh, 1 relu, 2 sigmoid), last layer = action_mean (no activation)
  *   action[r] = mean + exp(log_std) * noise[r]   (noise == NULL: action = mean), float32 arithmetic, stored float64
- * `layers[l].wt` is the TRANSPOSED weight, [in_dim][out_dim] row-major. mean_out (float32) may be NULL. */
+ * `layers[l].wt` is the TRANSPOSED weight, [in_dim][round_up(out_dim, 4)] row-major (zero padded, 16-byte aligned).
+ * mean_out (float32) may be NULL. */
 typedef struct egp_mlp_layer {
     const float *wt;
     const float *bias;
