@@ -189,6 +189,16 @@ class HumanoidEnv:
         self.bquat = self.get_body_quat()
         return self.get_obs()
 
+    def set_state(self, qpos, qvel):
+        """MujocoEnv.set_state (envs/common/mujoco_env.py:95-101): overwrite the single env's state + forward."""
+        import torch
+        qpos, qvel = np.asarray(qpos, dtype=np.float64), np.asarray(qvel, dtype=np.float64)
+        assert qpos.shape == (self.skel.nq,) and qvel.shape == (self.skel.nv,)
+        sim = self._one()
+        sim.engine.reset(np.array([0]), qpos[None], qvel[None])
+        torch.cuda.synchronize()
+        self.bquat = self.get_body_quat()
+
     def step(self, a):
         """HumanoidEnv.step (humanoid_v1.py:179-199) through the engine: 15 x {K1 <-> physics}."""
         import torch

@@ -1,0 +1,196 @@
+"""Evaluation driver of the ego_mimic policy: one env, deterministic policy, state-regressor resets.
+
+Mirrors /root/reference/ego_pose/ego_mimic_eval.py:93-197 (reset_env_state, eval_expert and the per-take loop that
+writes `(results, meta)`), on top of the single-env facade of `HumanoidEnv` (batch of one through the same engine and
+kernels as training) and the host-side metrics of `egopose_amd.metrics` (ego_pose/eval_pose.py:31-69).
+
+Per take: roll the policy over the whole clip (`fix_len = len - 2*fr_margin`) with the mean action; whenever the
+fail-safe fires -- 'valuefs': the value estimate drops below 0.6 x its running mean, 'naivefs': the env reports a
+fall -- re-seat the humanoid on the state regressor's prediction for the next frame, aligned to where the
+character stands (utils/tools.py:71-75). Rendering (`env_vis`, `--render`) is out of scope.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from . import metrics
+from .reward import reward_func
+from .zfilter import RunningStat
+
+
+class Evaluator:
+
+    def __init__(self, cfg, env, policy_net, policy_vs_net, value_net, value_vs_net, state_net, state_net_mean, state_net_std,
+                 running_state=None, fail_safe="valuefs", causal=False, show_noise=False, sync=False, logger=None,
+                 keep_trace=False):
+        if fail_safe not in ("valuefs", "naivefs", "none"):
+            raise ValueError("fail_safe must be 'valuefs', 'naivefs' or 'none'")
+        self.cfg, self.env = cfg, env
+        self.policy_net, self.policy_vs_net = policy_net, policy_vs_net
+        self.value_net, self.value_vs_net = value_net, value_vs_net
+        self.state_net = state_net
+        self.state_net_mean, self.state_net_std = np.asarray(state_net_mean, float), np.asarray(state_net_std, float)
+        self.running_state = running_state
+        self.fail_safe, self.causal, self.show_noise, self.sync = fail_safe, causal, show_noise, sync
+        self.value_stat = RunningStat(1)
+        self.logger = logger
+        self.trace = {} if keep_trace else None      # per take: actions, values, reset frames, regressor states
+        for net in (policy_net, policy_vs_net, value_net, value_vs_net, state_net):
+            net.eval()
+        for net in (policy_vs_net, value_vs_net):
+            net.set_mode("test")
+        p = next(policy_net.parameters())
+        self.device, self.dtype = p.device, p.dtype
+
+    # ------------------------------------------------------------------ ego_mimic_eval.py:93-100
+    def reset_env_state(self, state, ref_qpos):
+        env = self.env
+        qpos = np.array(ref_qpos, float, copy=True)
+        qpos[2:] = state[:qpos.size - 2]
+        qvel = np.array(state[qpos.size - 2:], float, copy=True)
+        metrics.align_human_state(qpos, qvel, ref_qpos)
+        env.set_state(qpos, qvel)
+        return env.get_obs()
+
+    def _filter(self, state):
+        return self.running_state(state, update=False) if self.running_state is not None else state
+
+    # ------------------------------------------------------------------ ego_mimic_eval.py:103-175
+    @torch.no_grad()
+    def eval_expert(self, expert_ind):
+        env, cfg = self.env, self.cfg
+        m = cfg.fr_margin
+        data_len = env.cnn_feat[expert_ind].shape[0]
+        test_len = data_len - 2 * m
+        env.set_fix_sampling(expert_ind, m, test_len)
+        traj_pred, traj_orig, vel_pred = [], [], []
+        num_reset, reward_episode = 0, 0.0
+
+        state = env.reset()
+        cnn_feat = torch.as_tensor(env.get_episode_cnn_feat(), dtype=self.dtype, device=self.device)
+        self.policy_vs_net.initialize(cnn_feat)
+        self.value_vs_net.initialize(cnn_feat)
+        sp = next(self.state_net.parameters())
+        state_pred = self.state_net(cnn_feat.to(device=sp.device, dtype=sp.dtype).unsqueeze(1))[m:-m].double().cpu().numpy()
+        state_pred = state_pred * self.state_net_std[None, :] + self.state_net_mean[None, :]
+
+        state = self._filter(self.reset_env_state(state_pred[0], env.data.qpos))
+        tr = None
+        if self.trace is not None:
+            tr = self.trace[env.expert_list[expert_ind]] = dict(actions=[], values=[], resets=[], state_pred=state_pred)
+        for t in range(test_len):
+            ind = env.get_expert_index(t)
+            epos = env.get_expert_attr("qpos", ind).copy()
+            data = env.data
+            traj_pred.append(data.qpos.copy())
+            traj_orig.append(epos.copy())
+            vel_pred.append(data.qvel.copy())
+            if self.causal:
+                self.policy_vs_net.initialize(cnn_feat[:t + 2 * m + 1])
+                self.policy_vs_net.t = t
+            state_var = torch.as_tensor(state, dtype=self.dtype, device=self.device).unsqueeze(0)
+            policy_in = self.policy_vs_net(state_var)
+            value = float(self.value_net(self.value_vs_net(state_var)).item())
+            self.value_stat.push(np.array([value]))
+            action = self.policy_net.select_action(policy_in, mean_action=not self.show_noise)[0].double().cpu().numpy()
+            if tr is not None:
+                tr["actions"].append(action.copy())
+                tr["values"].append(value)
+            next_state, _, done, info = env.step(action)
+            next_state = self._filter(next_state)
+            reward, _ = reward_func[cfg.reward_id](env, state, action, info)
+            reward_episode += reward
+            if info["end"]:
+                break
+            if (self.fail_safe == "valuefs" and value < 0.6 * self.value_stat.mean[0]) or (self.fail_safe == "naivefs" and info["fail"]):
+                if self.logger is not None:
+                    self.logger.info("reset state!")
+                num_reset += 1
+                if tr is not None:
+                    tr["resets"].append(t)
+                state = self._filter(self.reset_env_state(state_pred[t + 1], env.data.qpos))
+            else:
+                state = next_state
+        self.last_reward = reward_episode
+        return np.vstack(traj_pred), np.vstack(traj_orig), np.vstack(vel_pred), num_reset
+
+    # ------------------------------------------------------------------ ego_mimic_eval.py:183-197
+    def run(self, takes=None):
+        """Evaluate every take of the env's expert list -> (results, meta) in the reference's pickle layout."""
+        traj_pred, traj_orig, vel_pred, num_reset = {}, {}, {}, 0
+        for i, take in enumerate(self.env.expert_list):
+            if takes is not None and take not in takes:
+                continue
+            traj_pred[take], traj_orig[take], vel_pred[take], n = self.eval_expert(i)
+            num_reset += n
+        results = {"traj_pred": traj_pred, "traj_orig": traj_orig, "vel_pred": vel_pred}
+        meta = {"algo": "ego_mimic", "num_reset": num_reset}
+        return results, meta
+
+    def save(self, results, meta, it, data="test"):
+        fs_tag = "" if self.fail_safe == "valuefs" else "_" + self.fail_safe
+        c_tag = "_causal" if self.causal else ""
+        path = "%s/iter_%04d_%s%s%s.p" % (self.cfg.result_dir, it, data, fs_tag, c_tag)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "wb") as f:
+            pickle.dump((results, meta), f)
+        return path
+
+
+def compute_metrics(results, dt=1.0 / 30.0, algo="ego_mimic", verbose=False):
+    return metrics.compute_metrics(results, dt, algo, verbose)
+
+
+def main(argv=None):
+    """`python -m egopose_amd.evaluate --cfg subject_03 --iter 3000 --data test [--fail-safe naivefs] [--causal]`:
+    the non-rendering part of ego_pose/ego_mimic_eval.py (checkpoint + state-net loading: :60-80) followed by the
+    statistics of ego_pose/eval_pose.py (--mode stats)."""
+    import argparse
+    from .config import Config
+    from .env import HumanoidEnv
+    from .nets import MLP, PolicyGaussian, Value, VideoRegNet, VideoStateNet
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg", default="subject_03")
+    ap.add_argument("--iter", type=int, default=0)
+    ap.add_argument("--data", default="test")
+    ap.add_argument("--fail-safe", default="valuefs")
+    ap.add_argument("--causal", action="store_true")
+    ap.add_argument("--show-noise", action="store_true")
+    ap.add_argument("--gpu-index", type=int, default=0)
+    args = ap.parse_args(argv)
+    cfg = Config(args.cfg, create_dirs=False)
+    dev, dtype = torch.device("cuda", args.gpu_index), torch.float32
+    env = HumanoidEnv(cfg)
+    env.seed(cfg.seed)
+    env.load_experts(cfg.takes[args.data], cfg.expert_feat_file, cfg.cnn_feat_file)
+    cnn_dim = env.cnn_feat[0].shape[-1]
+    sd, ad = env.observation_space.shape[0], env.action_space.shape[0]
+    mk = lambda hdim, kind, param: VideoStateNet(cnn_dim, hdim, cfg.fr_margin, kind, param, cfg.causal)
+    policy_vs, value_vs = mk(cfg.policy_v_hdim, cfg.policy_v_net, cfg.policy_v_net_param), mk(cfg.value_v_hdim, cfg.value_v_net, cfg.value_v_net_param)
+    policy = PolicyGaussian(MLP(sd + cfg.policy_v_hdim, cfg.policy_hsize, cfg.policy_htype), ad, log_std=cfg.log_std, fix_std=cfg.fix_std)
+    value = Value(MLP(sd + cfg.value_v_hdim, cfg.value_hsize, cfg.value_htype))
+    cp = pickle.load(open("%s/iter_%04d.p" % (cfg.model_dir, args.iter), "rb"))
+    policy.load_state_dict(cp["policy_dict"]); policy_vs.load_state_dict(cp["policy_vs_dict"])
+    value.load_state_dict(cp["value_dict"]); value_vs.load_state_dict(cp["value_vs_dict"])
+    sn_cp, meta = pickle.load(open(cfg.state_net_model, "rb"))
+    sn_cfg = meta["cfg"]
+    state_net = VideoRegNet(meta["mean"].size, sn_cfg.v_hdim, cnn_dim, no_cnn=True, cnn_type=sn_cfg.cnn_type, mlp_dim=sn_cfg.mlp_dim,
+                            v_net_type=sn_cfg.v_net, v_net_param=sn_cfg.v_net_param, causal=sn_cfg.causal)
+    state_net.load_state_dict(sn_cp["state_net_dict"])
+    for net in (policy, policy_vs, value, value_vs, state_net):
+        net.to(dev, dtype)
+    ev = Evaluator(cfg, env, policy, policy_vs, value, value_vs, state_net, meta["mean"], meta["std"], running_state=cp["running_state"],
+                   fail_safe=args.fail_safe, causal=args.causal, show_noise=args.show_noise)
+    results, rmeta = ev.run()
+    path = ev.save(results, rmeta, args.iter, args.data)
+    print("num reset: %d, saved results to %s" % (rmeta["num_reset"], path))
+    compute_metrics(results, verbose=True)
+    env.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -275,3 +275,31 @@ class VideoStateNet(nn.Module):
         ctx = self.forward_v_net(self.cnn_feat_ctx)[m:-m]
         ctx = ctx.transpose(0, 1).reshape(-1, self.v_hdim)
         return torch.cat((ctx.index_select(0, self.gather_indices), x), dim=1)
+
+
+class VideoRegNet(nn.Module):
+    """State regressor over precomputed CNN features -- the `no_cnn=True` form of models/video_reg_net.py:10-59 that
+    the evaluation drivers load (ego_pose/ego_mimic_eval.py:71-80): temporal net -> MLP (relu) -> Linear.
+    x: (T, B, cnn_fdim) -> (T*B, out_dim). The image encoder (ResNet-18 / MobileNet, `no_cnn=False`) belongs to the
+    state_reg training path, which is outside this build."""
+
+    def __init__(self, out_dim, v_hdim, cnn_fdim, no_cnn=True, frame_shape=(3, 224, 224), mlp_dim=(300, 200),
+                 cnn_type="resnet", v_net_type="lstm", v_net_param=None, causal=False):
+        super().__init__()
+        if not no_cnn:
+            raise NotImplementedError("the image encoder of VideoRegNet is not part of this build (use no_cnn=True)")
+        if v_net_type != "lstm":
+            raise NotImplementedError("only the 'lstm' video net is implemented (tcn is out of scope)")
+        self.out_dim, self.cnn_fdim, self.v_hdim, self.no_cnn = out_dim, cnn_fdim, v_hdim, True
+        self.cnn = None
+        self.v_net_type = v_net_type
+        self.v_net = RNN(cnn_fdim, v_hdim, v_net_type, bi_dir=not causal)
+        self.mlp = MLP(v_hdim, mlp_dim, "relu")
+        self.linear = nn.Linear(self.mlp.out_dim, out_dim)
+
+    def forward_v_net(self, x):
+        return self.v_net(x)
+
+    def forward(self, x):
+        x = self.forward_v_net(x).reshape(-1, self.v_hdim)
+        return self.linear(self.mlp(x))

@@ -158,3 +158,81 @@ def test_single_env_facade_matches_oracle_env(workspace, skel):
     assert env.cur_t <= 6
     ph.close()
     env.close()
+
+
+@pytest.mark.parametrize("fail_safe", ["naivefs", "valuefs"])
+def test_eval_driver_replayed_by_oracle_env(workspace, skel, fail_safe):
+    """Evaluator.eval_expert (ego_mimic_eval.py:103-175 on the single-env facade): every frame of traj_pred, every
+    fail-safe re-seat and the reported expert frames are reproduced by the oracle's CPU env driven with the logged
+    actions; the metrics of the result pickle are the product-side eval_pose numbers."""
+    from egopose_amd.evaluate import Evaluator, compute_metrics
+    from egopose_amd import metrics as M
+    from egopose_amd.nets import VideoRegNet
+    from egopose_amd.physics import SurrogatePhysics
+    from oracle.cpu_env import OracleHumanoidEnv
+    from oracle import humanoid as H
+    tr, cfg = _trainer(workspace, 8, 15, num_threads=2, num_groups=1)
+    cfg.env_init_noise = 0.0
+    env = tr.env
+    m = cfg.fr_margin
+    torch.manual_seed(11)
+    state_net = VideoRegNet(115, 128, env.cnn_feat[0].shape[-1]).cuda()
+    ex = env.expert_arr[0]
+    obs_like = np.concatenate([ex["qpos"][m:, 2:], ex["qvel"][m:]], 1)
+    mean, std = obs_like.mean(0), np.full(115, 0.02)
+    if fail_safe == "valuefs":                               # make the value drop now and then so that resets happen
+        with torch.no_grad():
+            tr.value_net.value_head.weight.mul_(30.0)
+            tr.value_net.value_head.bias.fill_(1.0)
+    ev = Evaluator(cfg, env, tr.policy_net, tr.policy_vs_net, tr.value_net, tr.value_vs_net, state_net, mean, std,
+                   running_state=tr.running_state, fail_safe=fail_safe, keep_trace=True)
+    take = env.expert_list[0]
+    results, meta = ev.run(takes=[take])
+    pred, orig, vel = results["traj_pred"][take], results["traj_orig"][take], results["vel_pred"][take]
+    T = pred.shape[0]
+    test_len = env.cnn_feat[0].shape[0] - 2 * m
+    assert T == test_len and orig.shape == (T, 59) and vel.shape == (T, 58)
+    np.testing.assert_array_equal(orig, ex["qpos"][m:m + T])
+    trc = ev.trace[take]
+    assert meta == {"algo": "ego_mimic", "num_reset": len(trc["resets"])}
+    if fail_safe == "valuefs":
+        assert len(trc["resets"]) > 0, "the test is meant to exercise the re-seat path"
+    # --- oracle replay
+    cfg.env_episode_len = test_len
+    ph = SurrogatePhysics(skel, 1)
+    ref = OracleHumanoidEnv(skel, cfg, ph, env.expert_arr, env.cnn_feat)
+    ref.expert_ind, ref.start_ind, ref.cur_t = 0, m, 0
+
+    def seat(state, ref_qpos):
+        qpos = ref_qpos.copy()
+        qpos[2:] = state[:57]
+        qvel = state[57:].copy()
+        M.align_human_state(qpos, qvel, ref_qpos)
+        ph.reset(0, qpos, qvel)
+        ref._drain(True)
+        ref.bquat = H.body_quat(ref.qpos, skel.body_qpos_start, skel.body_ndof)[0]
+
+    seat(trc["state_pred"][0], ex["qpos"][m])
+    resets = set(trc["resets"])
+    for t in range(T):
+        np.testing.assert_allclose(pred[t], ref.qpos, rtol=1e-7, atol=1e-7, err_msg="frame %d" % t)
+        np.testing.assert_allclose(vel[t], ref.qvel, rtol=1e-6, atol=1e-6, err_msg="frame %d" % t)
+        _, _, _, info = ref.step(trc["actions"][t])
+        if info["end"]:
+            assert t == T - 1
+            break
+        if fail_safe == "naivefs":
+            assert info["fail"] == (t in resets)
+        if t in resets:
+            seat(trc["state_pred"][t + 1], ref.qpos)
+    ph.close()
+    # --- metrics of the result pickle + the reference's file layout
+    out = compute_metrics(results)
+    assert np.isfinite([out["pose_dist"], out["vel_dist"], out["accels"]]).all() and out["pose_dist"] > 0
+    np.testing.assert_allclose(out["per_take"][take][0], M.get_mean_dist(M.get_joint_angles(pred), M.get_joint_angles(orig)))
+    cfg.result_dir = os.path.join(workspace, "results_eval")
+    path = ev.save(results, meta, 7, data="test")
+    assert path.endswith("iter_0007_test%s.p" % ("" if fail_safe == "valuefs" else "_naivefs"))
+    r2, m2 = pickle.load(open(path, "rb"))
+    assert m2 == meta and set(r2) == {"traj_pred", "traj_orig", "vel_pred"}
+    tr.close()

@@ -525,6 +525,26 @@ def main():
     np.savez(os.path.join(OUT, "metrics.npz"), traj=traj, traj2=traj2, angles=ja, vels=jv, accels=jacc, dt=dt,
              mean_dist=rmetrics.get_mean_dist(ja, ja2), mean_abs=rmetrics.get_mean_abs(jacc))
 
+    # ------------------------------------------------------------------ G16 eval-path helpers
+    from utils.tools import align_human_state
+    from models.video_reg_net import VideoRegNet
+    rng2 = np.random.RandomState(77)
+    n_al = 6
+    al_qpos = synth_qpos(rng2, sk, n_al)
+    al_qvel = rng2.normal(size=(n_al, 58))
+    al_ref = synth_qpos(rng2, sk, n_al)
+    out_q, out_v = al_qpos.copy(), al_qvel.copy()
+    for i in range(n_al):
+        align_human_state(out_q[i], out_v[i], al_ref[i])
+    torch.manual_seed(5)
+    sn = VideoRegNet(9, 32, 16, no_cnn=True, mlp_dim=(24, 12), v_net_type='lstm')
+    sn.eval()
+    sn_x = torch.tensor(rng2.normal(size=(12, 1, 16)))
+    with torch.no_grad():
+        sn_y = sn(sn_x).numpy()
+    np.savez(os.path.join(OUT, "eval_tools.npz"), qpos=al_qpos, qvel=al_qvel, ref_qpos=al_ref, out_qpos=out_q, out_qvel=out_v,
+             sn_x=sn_x.numpy(), sn_y=sn_y, **{"sn_" + k: v.numpy() for k, v in sn.state_dict().items()})
+
     os.chdir(REPO)
     shutil.rmtree(wd, ignore_errors=True)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
