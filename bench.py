@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--groups", type=int, default=2)
     ap.add_argument("--min-batch", type=int, default=0, help="env-steps per GPU per iteration (0 = config: 50000)")
     ap.add_argument("--cfg", default="subject_03")
+    ap.add_argument("--task", choices=["egomimic", "egoforecast"], default="egomimic",
+                    help="egoforecast = BASELINE config 5's nets (VideoForecastNet, 90-step episodes, decayed reward)")
     ap.add_argument("--cpu-steps", type=int, default=24000, help="env-steps of the CPU baseline sample (~15 s on 2 cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-k1-events", action="store_true")
@@ -79,13 +81,13 @@ def main():
     dev = torch.device("cuda", local)
 
     from egopose_amd.bench_support import write_synthetic_dataset
-    from egopose_amd.config import Config
+    from egopose_amd.config import Config, ForecastConfig
     from egopose_amd.train import Trainer
 
     root = tempfile.mkdtemp(prefix="egp_bench_r%d_" % rank)
     write_synthetic_dataset(root, args.cfg, device_index=local)
     os.chdir(root)
-    cfg = Config(args.cfg, create_dirs=False)
+    cfg = (ForecastConfig if args.task == "egoforecast" else Config)(args.cfg, create_dirs=False)
     from egopose_amd.physics import available_cpus, default_threads
     cores = available_cpus()
     n_threads = args.threads or max(args.groups, default_threads(share=world))
@@ -134,8 +136,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(1, args.steps) * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 (rollout kernels K1-K6, physics state) + f32 (policy/value nets)", "data": "synthetic",
-            "config": {"workload": "ego_mimic %s, %d lockstep env slots per MI355X, precomputed (synthetic) CNN features, "
-                                   "MLP policy/value + bi-LSTM video context, PPO 10 full-batch epochs" % (args.cfg, args.envs),
+            "config": {"workload": ("ego_mimic %s, %d lockstep env slots per MI355X, precomputed (synthetic) CNN features, "
+                                    "MLP policy/value + bi-LSTM video context, PPO 10 full-batch epochs" % (args.cfg, args.envs))
+                       if args.task == "egomimic" else
+                       ("ego_forecast %s, %d lockstep env slots per MI355X, precomputed (synthetic) CNN features, MLP policy/value + "
+                        "causal video LSTM over the past %d frames + per-step state LSTM, %d-step episodes, decayed reward, "
+                        "PPO 10 full-batch epochs" % (args.cfg, args.envs, cfg.fr_margin, cfg.env_episode_len)),
                        "envs_per_gpu": args.envs, "min_batch_per_gpu": min_batch // world, "physics": ro.sim.physics.name,
                        "host_threads_per_gpu": n_threads, "env_groups": args.groups, "host_cores_seen": cores,
                        "parallelism": "dp%d" % world},

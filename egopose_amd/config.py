@@ -15,7 +15,8 @@ import shutil
 import numpy as np
 import yaml
 
-_ASSET_CFG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "config", "egomimic")
+_ASSET_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "config")
+_ASSET_CFG = os.path.join(_ASSET_ROOT, "egomimic")
 
 # attribute -> (yaml key, default); attributes whose default depends on another value are handled below
 _SCALARS = [
@@ -33,6 +34,16 @@ _SCALARS = [
     ("env_start_first", False), ("env_init_noise", 0.0), ("env_episode_len", 200), ("obs_type", "full"),
     ("obs_coord", "heading"), ("obs_heading", False), ("obs_vel", "full"), ("root_deheading", True),
     ("sync_exp_interval", 100), ("action_type", "position"),
+]
+
+
+# ego_forecast (ego_pose/utils/egoforecast_config.py:9-131): same table minus the state-net / causal entries, plus the
+# ego_mimic warm start, the per-step state nets of VideoForecastNet and a few env switches; other defaults differ
+_FORECAST_SCALARS = [(a, d) for a, d in _SCALARS if a not in ("state_net_cfg", "state_net_iter", "causal", "fr_margin")] + [
+    ("fr_margin", 10), ("ego_mimic_cfg", None), ("ego_mimic_iter", None),
+    ("policy_s_net", "id"), ("policy_s_hdim", None), ("policy_dyn_v", False),
+    ("value_s_net", "id"), ("value_s_hdim", None), ("value_dyn_v", False),
+    ("end_reward", True), ("obs_phase", False), ("random_cur_t", False),
 ]
 
 
@@ -71,13 +82,16 @@ def packaged_config(cfg_id):
 
 
 class Config:
+    task = "egomimic"
+    scalars = _SCALARS
+    schedules = ("noise_rate", "log_std", "policy_lr")
 
     def __init__(self, cfg_id=None, create_dirs=False, cfg_dict=None):
         self.id = cfg_id
         if cfg_dict is None:
-            path = "config/egomimic/%s.yml" % cfg_id
+            path = "config/%s/%s.yml" % (self.task, cfg_id)
             if not os.path.exists(path):
-                packaged = os.path.join(_ASSET_CFG, "%s.yml" % cfg_id)
+                packaged = os.path.join(_ASSET_ROOT, self.task, "%s.yml" % cfg_id)
                 if not os.path.exists(packaged):
                     print("Config file doesn't exist: %s" % path)
                     raise SystemExit(0)
@@ -88,7 +102,7 @@ class Config:
 
         # results layout
         self.base_dir = "results"
-        self.cfg_dir = "%s/egomimic/%s" % (self.base_dir, cfg_id)
+        self.cfg_dir = "%s/%s/%s" % (self.base_dir, self.task, cfg_id)
         for name in ("model", "result", "log", "tb"):
             setattr(self, name + "_dir", "%s/%s" % (self.cfg_dir, {"model": "models", "result": "results"}.get(name, name)))
         os.makedirs(self.model_dir, exist_ok=True)
@@ -106,9 +120,9 @@ class Config:
         self.expert_feat_file = feat % ("expert", cfg["expert_feat"]) if "expert_feat" in cfg else None
         self.cnn_feat_file = feat % ("cnn_feat", cfg["cnn_feat"]) if "cnn_feat" in cfg else None
 
-        for attr, default in _SCALARS:
+        for attr, default in self.scalars:
             setattr(self, attr, cfg.get(attr, default))
-        if self.state_net_cfg is not None:
+        if getattr(self, "state_net_cfg", None) is not None:
             self.state_net_model = "%s/statereg/%s/models/iter_%04d_inf.p" % (self.base_dir, self.state_net_cfg, self.state_net_iter)
 
         # adaptive schedules: control points at iterations adp_iter_cp, linear in between
@@ -118,6 +132,9 @@ class Config:
         self.adp_log_std_cp = _schedule(cfg.get("adp_log_std_cp"), n_cp, self.log_std)
         self.adp_policy_lr_cp = _schedule(cfg.get("adp_policy_lr_cp"), n_cp, self.policy_lr)
         self.adp_noise_rate = self.adp_log_std = self.adp_policy_lr = None
+        if "init_noise" in self.schedules:
+            self.adp_init_noise_cp = _schedule(cfg.get("adp_init_noise_cp"), n_cp, 0.0)
+            self.adp_init_noise = None
 
         # environment / model files
         cwd = os.getcwd()
@@ -132,6 +149,15 @@ class Config:
         lo = int(np.where(i_iter >= cp)[0][-1])
         hi = lo + int(lo < len(cp) - 1)
         w = (i_iter - cp[lo]) / (cp[hi] - cp[lo]) if hi > lo else 0.0
-        for name in ("noise_rate", "log_std", "policy_lr"):
+        for name in self.schedules:
             pts = getattr(self, "adp_%s_cp" % name)
             setattr(self, "adp_" + name, pts[lo] * (1 - w) + pts[hi] * w)
+
+
+class ForecastConfig(Config):
+    """Drop-in for ``ego_pose.utils.egoforecast_config.Config`` (egoforecast_config.py:9-140): results under
+    ``results/egoforecast/<id>``, the ego_mimic warm-start ids, the state-net switches of VideoForecastNet, ``end_reward``
+    and the extra adaptive schedule ``adp_init_noise`` (:88-95, :131-140)."""
+    task = "egoforecast"
+    scalars = _FORECAST_SCALARS
+    schedules = ("noise_rate", "log_std", "policy_lr", "init_noise")

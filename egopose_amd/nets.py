@@ -303,3 +303,123 @@ class VideoRegNet(nn.Module):
     def forward(self, x):
         x = self.forward_v_net(x).reshape(-1, self.v_hdim)
         return self.linear(self.mlp(x))
+
+
+class VideoForecastNet(nn.Module):
+    """Policy/value front end of ego_forecast (models/video_forecast_net.py:7-111): the video net sees only the
+    `v_margin` frames BEFORE the episode (causal LSTM, last output kept for the whole episode), the state goes through
+    its own LSTM (`s_net_type='lstm'`, stepped one env-step at a time while sampling) or through unchanged ('id').
+
+    test mode   ``initialize(window)``: window (>= v_margin, D) of ONE episode, or (v_margin, B, D) for a batch of
+                episodes (the lockstep rollout); ``forward(state)`` -> cat(v_out, s_net(state)). The batched rollout
+                steps the state LSTM itself through ``s_step``.
+    train mode  ``initialize((masks, cnn_feat, v_metas))`` segments the flat batch into episodes;
+                ``forward(states)`` scatters the states into a padded (max_len, n_ep, state_dim) block, runs both
+                nets and gathers one row per sample.
+    """
+
+    def __init__(self, cnn_feat_dim, state_dim, v_hdim=128, v_margin=10, v_net_type="lstm", v_net_param=None,
+                 s_hdim=None, s_net_type="id", dynamic_v=False):
+        super().__init__()
+        if v_net_type != "lstm":
+            raise NotImplementedError("only the 'lstm' video net is implemented (tcn is out of scope)")
+        if s_net_type not in ("id", "lstm"):
+            raise ValueError("s_net_type must be 'id' or 'lstm'")
+        s_hdim = state_dim if s_hdim is None else s_hdim
+        self.cnn_feat_dim, self.state_dim, self.v_hdim, self.v_margin = cnn_feat_dim, state_dim, v_hdim, v_margin
+        self.v_net_type, self.s_net_type, self.s_hdim, self.dynamic_v = v_net_type, s_net_type, s_hdim, dynamic_v
+        self.out_dim = v_hdim + s_hdim
+        self.v_net = RNN(cnn_feat_dim, v_hdim, v_net_type, bi_dir=False)
+        if s_net_type == "lstm":
+            self.s_net = RNN(state_dim, s_hdim, s_net_type, bi_dir=False)
+        self.v_out = None
+        self.t = 0
+        self.indices = self.gather_indices = self.cnn_feat_ctx = None
+        self.num_episode = self.max_episode_len = None
+        self._cnn_table = None
+        self.set_mode("test")
+
+    def set_mode(self, mode):
+        self.mode = mode
+        if self.s_net_type == "lstm":
+            self.s_net.set_mode("batch" if mode == "train" else "step")
+
+    def forward_v_net(self, x):
+        return self.v_net(x)
+
+    def attach_feature_table(self, table, take_offset):
+        self._cnn_table = (table, torch.as_tensor(np.asarray(take_offset), dtype=torch.long, device=table.device))
+
+    def window_features(self, expert_ind, start_ind, length=0):
+        """Rows [start - v_margin, start + length) of the given takes -> (v_margin + length, B, D) on device."""
+        table, off = self._cnn_table
+        base = off[expert_ind.long()] + start_ind.long() - self.v_margin
+        rows = base.unsqueeze(0) + torch.arange(self.v_margin + length, device=table.device).unsqueeze(1)
+        return table[rows]
+
+    def context(self, window):
+        """(v_margin, B, D) -> the per-episode video context (B, v_hdim): last output of the causal net."""
+        return self.forward_v_net(window[:self.v_margin])[-1]
+
+    def s_step(self, state, hc):
+        """One step of the state net for a batch of envs: state (B, state_dim), hc = (h, c) or None -> (out, (h, c))."""
+        if self.s_net_type != "lstm":
+            return state, hc
+        h, c = self.s_net.rnn_f(state, hc)
+        return h, (h, c)
+
+    def initialize(self, x):
+        if self.mode == "test":
+            p = next(self.parameters())
+            x = x.to(device=p.device, dtype=p.dtype)
+            self.v_out = self.context(x.unsqueeze(1) if x.dim() == 2 else x)
+            if self.s_net_type == "lstm":
+                self.s_net.initialize(self.v_out.shape[0])
+            self.t = 0
+            return
+        masks, cnn_feat, v_metas = x
+        device, dtype = masks.device, masks.dtype
+        m = self.v_margin
+        ends = torch.nonzero(masks == 0).flatten().cpu().numpy()
+        n = masks.shape[0]
+        starts = np.concatenate(([0], ends[:-1] + 1))
+        lens = ends - starts + 1
+        max_len = _dist.global_max(int(lens.max()), device)       # batch-wide in the reference; global when sharded
+        self.num_episode, self.max_episode_len = len(ends), max_len
+        idx = np.arange(n)
+        covered = int(ends[-1]) + 1
+        idx[:covered] = np.repeat(np.arange(len(ends)), lens) * max_len + (np.arange(covered) - np.repeat(starts, lens))
+        self.indices = idx
+        meta = np.asarray(v_metas)[ends]
+        T_ctx = m + max_len if self.dynamic_v else m
+        if self._cnn_table is not None and self._cnn_table[0].device == device:
+            win = self.window_features(torch.as_tensor(meta[:, 0], device=device), torch.as_tensor(meta[:, 1], device=device)).to(dtype)
+            ctx = win.new_zeros(T_ctx, len(ends), self.cnn_feat_dim)
+            ctx[:m] = win
+        else:
+            ctx = np.zeros((T_ctx, len(ends), self.cnn_feat_dim))
+            for e, (ei, si) in enumerate(meta):
+                ctx[:m, e, :] = cnn_feat[int(ei)][int(si) - m: int(si)]
+            ctx = torch.as_tensor(ctx, dtype=dtype, device=device)
+        self.cnn_feat_ctx = ctx
+        self.gather_indices = torch.as_tensor(idx, dtype=torch.long, device=device)
+
+    def forward(self, x):
+        if self.mode == "test":
+            if self.s_net_type == "lstm":
+                x = self.s_net(x)
+            self.t += 1
+            return torch.cat((self.v_out, x), dim=1)
+        if self.dynamic_v:
+            v_ctx = self.forward_v_net(self.cnn_feat_ctx)[self.v_margin:]
+        else:
+            v_ctx = self.forward_v_net(self.cnn_feat_ctx)[[-1]].expand(self.max_episode_len, -1, -1)
+        v_out = v_ctx.transpose(0, 1).reshape(-1, self.v_hdim).index_select(0, self.gather_indices)
+        if self.s_net_type == "lstm":
+            s_ctx = x.new_zeros(self.num_episode * self.max_episode_len, self.state_dim)
+            s_ctx = s_ctx.index_copy(0, self.gather_indices, x)
+            s_ctx = s_ctx.view(self.num_episode, self.max_episode_len, self.state_dim).transpose(0, 1).contiguous()
+            s_out = self.s_net(s_ctx).transpose(0, 1).reshape(-1, self.s_hdim).index_select(0, self.gather_indices)
+        else:
+            s_out = x
+        return torch.cat((v_out, s_out), dim=1)

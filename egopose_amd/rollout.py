@@ -95,6 +95,11 @@ class LockstepRollout:
         self.dev = torch.device("cuda", self.ctx.device)
         self.T_ep = int(self.cfg.env_episode_len)
         self.margin = int(self.cfg.fr_margin)
+        # ego_forecast front end (VideoForecastNet): one video context per episode + a state LSTM stepped per tick
+        self.forecast = hasattr(policy_vs_net, "s_step")
+        self.ctx_T = 1 if self.forecast else self.T_ep          # context rows per episode kept in v_out
+        if getattr(self.cfg, "obs_phase", False) or getattr(self.cfg, "random_cur_t", False):
+            raise NotImplementedError("obs_phase / random_cur_t are not implemented in the lockstep rollout")
         self.gen = torch.Generator(device=self.dev)
         self.gen.manual_seed(int(seed))
         with torch.cuda.device(self.dev):
@@ -107,6 +112,7 @@ class LockstepRollout:
         self.use_graphs = os.environ.get("EGP_POLICY_GRAPH", "1") != "0"
         self.use_fused = os.environ.get("EGP_POLICY_FUSED", "1") != "0"     # HIP policy step (float32 PolicyGaussian over an MLP)
         self._fused = None
+        self._s_hc = None
         self._graphs = None                 # per group: captured hipGraph of the policy step
         self._graph_key = None
         self.pool_batch = max(256, self.N // 2)
@@ -127,8 +133,11 @@ class LockstepRollout:
                 m = max(need, self.pool_batch)
                 e_ind, s_ind = self.env.sample_reset(m)
                 e_d, s_d = self.up(e_ind), self.up(s_ind)
-                win = self.policy_vs_net.window_features(e_d, s_d, self.T_ep)
-                ctx = self.policy_vs_net.forward_v_net(win)[self.margin:-self.margin].transpose(0, 1).contiguous()   # (m, T, H)
+                if self.forecast:        # causal net over the v_margin frames before the episode, last output
+                    ctx = self.policy_vs_net.context(self.policy_vs_net.window_features(e_d, s_d)).unsqueeze(1)      # (m, 1, H)
+                else:
+                    win = self.policy_vs_net.window_features(e_d, s_d, self.T_ep)
+                    ctx = self.policy_vs_net.forward_v_net(win)[self.margin:-self.margin].transpose(0, 1).contiguous()   # (m, T, H)
                 self._pool, self._pool_pos = (e_ind, s_ind, ctx), 0
             e_ind, s_ind, ctx = self._pool
             k = min(need, len(e_ind) - self._pool_pos)
@@ -153,7 +162,11 @@ class LockstepRollout:
         self.e_ind[ids], self.s_ind[ids] = e_ind, s_ind
         self.frame_base[ids] = rows
         self.cur_t[ids] = 0
-        self.v_out[self.up(ids)] = ctx_rows
+        ids_d = self.up(ids)
+        self.v_out[ids_d] = ctx_rows
+        if self._s_hc is not None:               # fresh episodes start the state LSTM from zero
+            self._s_hc[0][ids_d] = 0
+            self._s_hc[1][ids_d] = 0
 
     def _obs_filter(self, a, b, out, out2=None, active=None, write_only_active=False):
         """K3+K6 fused for slots [a,b): filtered observation of the engine state -> out (and out2)."""
@@ -173,6 +186,19 @@ class LockstepRollout:
         dist = self.policy_net(x)
         return dist.loc, dist.scale
 
+    def _policy_input(self, g, t_idx, state):
+        """cat(video context of each slot's episode, state features) for group g (torch path)."""
+        a, b = self.groups[g]
+        ctx = self.v_out[a:b][self._ar[g], t_idx]
+        st = state.to(self.v_out.dtype)
+        if self.forecast:
+            hc = None if self._s_hc is None else (self._s_hc[0][a:b], self._s_hc[1][a:b])
+            st, hc = self.policy_vs_net.s_step(st, hc)
+            if hc is not None:
+                self._s_hc[0][a:b].copy_(hc[0])
+                self._s_hc[1][a:b].copy_(hc[1])
+        return torch.cat((ctx, st), dim=1)
+
     def _policy_body(self, g):
         """action = mean + std * N(0,1) for group g, reading / writing only static buffers (graph-capturable)."""
         a, b = self.groups[g]
@@ -180,8 +206,7 @@ class LockstepRollout:
             self._g_noise[g].normal_()                # default generator: graph-safe philox offsets
             self._fused(self.v_out[a:b], self._g_tidx[g], self._g_state[g], self._g_act[g], noise=self._g_noise[g])
             return
-        x = torch.cat((self.v_out[a:b][self._ar[g], self._g_tidx[g]], self._g_state[g].to(self.v_out.dtype)), dim=1)
-        mean, std = self._mean_std(x)
+        mean, std = self._mean_std(self._policy_input(g, self._g_tidx[g], self._g_state[g]))
         self._g_act[g].copy_(torch.addcmul(mean, std, torch.randn_like(mean)))
 
     def _ensure_static(self, ndt):
@@ -190,19 +215,25 @@ class LockstepRollout:
         # the captured graph holds raw pointers to the policy weights: moving the module (e.g. the reference's
         # `with to_cpu(...)` around checkpoint saving) re-allocates them, so the key includes their addresses
         key = (ndt, self.policy_vs_net.v_hdim) + tuple(p.data_ptr() for p in self.policy_net.parameters())
+        if self.forecast:                # the captured policy step also runs the state LSTM cell of the vs net
+            key += tuple(p.data_ptr() for p in self.policy_vs_net.parameters())
         if self._graph_key == key:
             if self._fused is not None:
                 self._fused.refresh()            # same buffers, this iteration's weights
             return
         dev, f64 = self.dev, torch.float64
-        self.v_out = torch.zeros(self.N, self.T_ep, self.policy_vs_net.v_hdim, dtype=ndt, device=dev)
+        self.v_out = torch.zeros(self.N, self.ctx_T, self.policy_vs_net.v_hdim, dtype=ndt, device=dev)
+        self._s_hc = None
+        if self.forecast and self.policy_vs_net.s_net_type == "lstm":
+            self._s_hc = (torch.zeros(self.N, self.policy_vs_net.s_hdim, dtype=ndt, device=dev),
+                          torch.zeros(self.N, self.policy_vs_net.s_hdim, dtype=ndt, device=dev))
         self._ar = [torch.arange(b - a, device=dev) for a, b in self.groups]
         self._g_tidx = [torch.zeros(b - a, dtype=torch.int64, device=dev) for a, b in self.groups]
         self._g_state = [torch.zeros(b - a, self.ctx.obs_dim, dtype=f64, device=dev) for a, b in self.groups]
         self._g_act = [torch.zeros(b - a, self.ctx.nu, dtype=f64, device=dev) for a, b in self.groups]
         self._g_noise = [torch.zeros(b - a, self.ctx.nu, dtype=torch.float32, device=dev) for a, b in self.groups]
         self._fused = None
-        if self.use_fused and ndt == torch.float32 and policy_step.supported(self.policy_net):
+        if self.use_fused and not self.forecast and ndt == torch.float32 and policy_step.supported(self.policy_net):
             self._fused = policy_step.FusedGaussianPolicy(self.policy_net, dev)
         self._graph_key = key
         self._graphs = None
@@ -281,7 +312,7 @@ class LockstepRollout:
             a, b = self.groups[g]
             t0 = time.time()
             k = tick[g]
-            t_idx = self.up(np.minimum(self.cur_t[a:b], T_ep - 1))
+            t_idx = self.up(np.minimum(self.cur_t[a:b], self.ctx_T - 1))
             if plain_noise:
                 # static-buffer form (one hipGraph launch when captured)
                 self._g_tidx[g].copy_(t_idx)
@@ -292,8 +323,7 @@ class LockstepRollout:
                     self._policy_body(g)
                 rec["actions"][k, a:b] = self._g_act[g]
             else:
-                x = torch.cat((self.v_out[a:b][self._ar[g], t_idx], rec["states"][k, a:b].to(ndt)), dim=1)
-                mean, std = self._mean_std(x)
+                mean, std = self._mean_std(self._policy_input(g, t_idx, rec["states"][k, a:b]))
                 if self.mean_action:
                     action = mean
                     rec["exps"][k, a:b] = 0

@@ -18,10 +18,10 @@ import torch
 
 from . import dist as D
 from .agent import AgentEgo
-from .config import Config
+from .config import Config, ForecastConfig
 from .env import HumanoidEnv
 from .logging_utils import Logger, create_logger
-from .nets import MLP, PolicyGaussian, Value, VideoStateNet
+from .nets import MLP, PolicyGaussian, Value, VideoForecastNet, VideoStateNet
 from .reward import reward_func
 from .torch_utils import set_optimizer_lr, to_cpu, to_device
 from .zfilter import ZFilter
@@ -41,12 +41,21 @@ class Trainer:
         cnn_dim = env.cnn_feat[0].shape[-1]
         state_dim, action_dim = env.observation_space.shape[0], env.action_space.shape[0]
         self.running_state = ZFilter((state_dim,), clip=5)
-        mk_vs = lambda hdim, kind, param: VideoStateNet(cnn_dim, hdim, cfg.fr_margin, kind, param, cfg.causal)
-        self.policy_vs_net = mk_vs(cfg.policy_v_hdim, cfg.policy_v_net, cfg.policy_v_net_param)
-        self.value_vs_net = mk_vs(cfg.value_v_hdim, cfg.value_v_net, cfg.value_v_net_param)
-        self.policy_net = PolicyGaussian(MLP(state_dim + cfg.policy_v_hdim, cfg.policy_hsize, cfg.policy_htype), action_dim,
+        self.forecast = getattr(cfg, "task", "egomimic") == "egoforecast"
+        if self.forecast:        # ego_pose/ego_forecast.py:53-59: causal video net over the past + per-step state net
+            mk_vs = lambda p: VideoForecastNet(cnn_dim, state_dim, getattr(cfg, p + "_v_hdim"), cfg.fr_margin, getattr(cfg, p + "_v_net"),
+                                               getattr(cfg, p + "_v_net_param"), getattr(cfg, p + "_s_hdim"), getattr(cfg, p + "_s_net"),
+                                               getattr(cfg, p + "_dyn_v"))
+            self.policy_vs_net, self.value_vs_net = mk_vs("policy"), mk_vs("value")
+            p_in, v_in = self.policy_vs_net.out_dim, self.value_vs_net.out_dim
+        else:
+            mk_vs = lambda hdim, kind, param: VideoStateNet(cnn_dim, hdim, cfg.fr_margin, kind, param, cfg.causal)
+            self.policy_vs_net = mk_vs(cfg.policy_v_hdim, cfg.policy_v_net, cfg.policy_v_net_param)
+            self.value_vs_net = mk_vs(cfg.value_v_hdim, cfg.value_v_net, cfg.value_v_net_param)
+            p_in, v_in = state_dim + cfg.policy_v_hdim, state_dim + cfg.value_v_hdim
+        self.policy_net = PolicyGaussian(MLP(p_in, cfg.policy_hsize, cfg.policy_htype), action_dim,
                                          log_std=cfg.log_std, fix_std=cfg.fix_std)
-        self.value_net = Value(MLP(state_dim + cfg.value_v_hdim, cfg.value_hsize, cfg.value_htype))
+        self.value_net = Value(MLP(v_in, cfg.value_hsize, cfg.value_htype))
         self.nets = dict(policy_dict=self.policy_net, policy_vs_dict=self.policy_vs_net, value_dict=self.value_net,
                          value_vs_dict=self.value_vs_net)
         for net in self.nets.values():
@@ -73,6 +82,8 @@ class Trainer:
     def pre_iter_update(self, i_iter):
         cfg = self.cfg
         cfg.update_adaptive_params(i_iter)
+        if self.forecast:
+            cfg.env_init_noise = cfg.adp_init_noise           # ego_forecast.py:108
         self.agent.set_noise_rate(cfg.adp_noise_rate)
         set_optimizer_lr(self.optimizer_policy, cfg.adp_policy_lr)
         if cfg.fix_std:
@@ -83,7 +94,8 @@ class Trainer:
         cfg = self.cfg
         self.pre_iter_update(i_iter)
         batch, log = self.agent.sample(cfg.min_batch_size if min_batch_size is None else min_batch_size)
-        self.env.end_reward = log.avg_c_reward * cfg.gamma / (1 - cfg.gamma)
+        if getattr(cfg, "end_reward", True):                  # ego_forecast.py:126-127 makes the bonus optional
+            self.env.end_reward = log.avg_c_reward * cfg.gamma / (1 - cfg.gamma)
         t0 = time.time()
         self.agent.update_params(batch)
         return log, log.sample_time, time.time() - t0, len(batch)
@@ -103,6 +115,21 @@ class Trainer:
         self.running_state = cp["running_state"]
         self.agent.running_state = self.running_state
 
+    def warm_start(self, path, em_cfg=None):
+        """ego_forecast.py:60-68: start the policy / value MLPs from an ego_mimic checkpoint; the first affine layer is
+        dropped when its input width differs (state LSTM, phase observation or another video width)."""
+        from .torch_utils import filter_state_dict
+        with open(path, "rb") as f:
+            cp = pickle.load(f)
+        cfg = self.cfg
+        differs = getattr(cfg, "obs_phase", False) or getattr(cfg, "policy_s_net", "id") != "id" or \
+            (em_cfg is not None and cfg.policy_v_hdim != em_cfg.policy_v_hdim)
+        if differs:
+            filter_state_dict(cp["policy_dict"], {"net.affine_layers.0"})
+            filter_state_dict(cp["value_dict"], {"net.affine_layers.0"})
+        self.policy_net.load_state_dict(cp["policy_dict"], strict=False)
+        self.value_net.load_state_dict(cp["value_dict"], strict=False)
+
     def close(self):
         self.env.close()
 
@@ -118,6 +145,7 @@ def main():
     ap.add_argument("--iter", type=int, default=0)
     ap.add_argument("--max-iter", type=int, default=None)
     ap.add_argument("--dtype", choices=["float32", "float64"], default="float32")
+    ap.add_argument("--task", choices=["egomimic", "egoforecast"], default="egomimic")
     args = ap.parse_args()
     rank, world, local = D.init_from_env(args.gpu_index)
     gpu = local if args.gpu_index is None else args.gpu_index
@@ -129,13 +157,21 @@ def main():
         write_synthetic_dataset(".", args.cfg, device_index=gpu)
     if world > 1:
         torch.distributed.barrier()
-    cfg = Config(args.cfg, create_dirs=(rank == 0 and args.iter == 0))
+    cfg = (ForecastConfig if args.task == "egoforecast" else Config)(args.cfg, create_dirs=(rank == 0 and args.iter == 0))
     tr = Trainer(cfg, torch.device("cuda", gpu), getattr(torch, args.dtype), num_envs=args.num_envs,
                  num_threads=args.num_threads or None, seed_offset=rank)
     logger = create_logger(os.path.join(cfg.log_dir, "log.txt"), file_handle=rank == 0)
     tb = Logger(cfg.tb_dir) if rank == 0 else None
     if args.iter > 0:
         tr.load("%s/iter_%04d.p" % (cfg.model_dir, args.iter))
+    elif args.task == "egoforecast" and cfg.ego_mimic_cfg is not None:
+        em_cfg = Config(cfg.ego_mimic_cfg, create_dirs=False)
+        cp_path = "%s/iter_%04d.p" % (em_cfg.model_dir, cfg.ego_mimic_iter)
+        if os.path.exists(cp_path):
+            logger.info("loading model from ego mimic checkpoint: %s" % cp_path)
+            tr.warm_start(cp_path, em_cfg)
+        else:
+            logger.info("no ego mimic checkpoint at %s: training the forecast nets from scratch" % cp_path)
     for i_iter in range(args.iter, args.max_iter or cfg.max_iter_num):
         log, t_s, t_u, _ = tr.iteration(i_iter, cfg.min_batch_size)
         if rank == 0:

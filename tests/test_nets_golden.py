@@ -75,3 +75,56 @@ def test_rnn_float32_generic_path_close_to_float64():
         out32 = rnn.float()(x.float())
     assert out32.shape == (9, 3, 8)
     np.testing.assert_allclose(out32.numpy(), ref.numpy(), atol=2e-6)
+
+
+def test_forecast_config_and_net_match_reference():
+    """ForecastConfig schedules == egoforecast_config.py; VideoForecastNet test / train mode == models/video_forecast_net.py."""
+    import os, tempfile, yaml
+    from egopose_amd.config import ForecastConfig
+    from egopose_amd.nets import VideoForecastNet
+    g = load_golden("forecast.npz")
+    cwd = os.getcwd()
+    d = tempfile.mkdtemp()
+    try:
+        os.chdir(d)
+        os.makedirs("datasets/meta")
+        yaml.safe_dump({"train": ["a"], "test": ["b"]}, open("datasets/meta/meta_subject_03.yml", "w"))
+        cfg = ForecastConfig("subject_03")
+        assert (cfg.fr_margin, cfg.env_episode_len, cfg.end_reward, cfg.policy_s_hdim) == (int(g["fr_margin"]), int(g["env_episode_len"]), bool(g["end_reward"]), int(g["policy_s_hdim"]))
+        assert cfg.cfg_dir == "results/egoforecast/subject_03" and cfg.reward_weights["decay"] is True
+        np.testing.assert_allclose(cfg.jkp, g["jkp"])
+        np.testing.assert_allclose(cfg.a_ref, g["a_ref"])
+        for it, nr, ls, lr, init in g["adp"]:
+            cfg.update_adaptive_params(int(it))
+            np.testing.assert_allclose([cfg.adp_noise_rate, cfg.adp_log_std, cfg.adp_policy_lr, cfg.adp_init_noise], [nr, ls, lr, init], rtol=1e-12)
+    finally:
+        os.chdir(cwd)
+    cdim, sdim, vh, sh, margin = (int(v) for v in g["dims"])
+    net = VideoForecastNet(cdim, sdim, vh, margin, "lstm", None, sh, "lstm", False).double()
+    net.load_state_dict({k[3:]: torch.as_tensor(g[k]) for k in g.files if k.startswith("sd_")})
+    assert net.out_dim == vh + sh
+    with torch.no_grad():
+        net.set_mode("test")
+        net.initialize(torch.as_tensor(g["win"]))
+        np.testing.assert_allclose(net.v_out.numpy(), g["v_out"], rtol=1e-10, atol=1e-12)
+        outs = np.stack([net(torch.as_tensor(g["st_seq"][k])).numpy()[0] for k in range(g["st_seq"].shape[0])])
+        np.testing.assert_allclose(outs, g["test_out"], rtol=1e-10, atol=1e-12)
+        # batched test mode + explicit state-net stepping (what the lockstep rollout uses)
+        win_b = torch.as_tensor(np.stack([g["win"][:margin], g["win"][:margin] * 0.5], 1))
+        ctx = net.context(win_b)
+        np.testing.assert_allclose(ctx[0].numpy(), g["v_out"][0], rtol=1e-10, atol=1e-12)
+        hc = None
+        for k in range(g["st_seq"].shape[0]):
+            st = torch.as_tensor(np.repeat(g["st_seq"][k], 2, 0))
+            out, hc = net.s_step(st, hc)
+            np.testing.assert_allclose(out[0].numpy(), g["test_out"][k][vh:], rtol=1e-10, atol=1e-12)
+        net.set_mode("train")
+        masks = torch.as_tensor(g["masks"])
+        net.initialize((masks, [g["cnn_feat0"], g["cnn_feat1"]], g["v_metas"]))
+        np.testing.assert_array_equal(net.indices, g["indices"])
+        np.testing.assert_allclose(net(torch.as_tensor(g["states"])).numpy(), g["train_out"], rtol=1e-10, atol=1e-12)
+        # gather-built contexts from a device-style table give the same result
+        table = torch.as_tensor(np.concatenate([g["cnn_feat0"], g["cnn_feat1"]]))
+        net.attach_feature_table(table, [0, g["cnn_feat0"].shape[0]])
+        net.initialize((masks, None, g["v_metas"]))
+        np.testing.assert_allclose(net(torch.as_tensor(g["states"])).numpy(), g["train_out"], rtol=1e-10, atol=1e-12)

@@ -236,3 +236,91 @@ def test_eval_driver_replayed_by_oracle_env(workspace, skel, fail_safe):
     r2, m2 = pickle.load(open(path, "rb"))
     assert m2 == meta and set(r2) == {"traj_pred", "traj_orig", "vel_pred"}
     tr.close()
+
+
+def _forecast_trainer(workspace, n_env, episode_len, **kw):
+    from egopose_amd.config import ForecastConfig
+    from egopose_amd.train import Trainer
+    os.chdir(workspace)
+    cfg = ForecastConfig("subject_03", create_dirs=False)
+    cfg.env_episode_len = episode_len
+    cfg.num_optim_epoch = 2
+    return Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=n_env, **kw), cfg
+
+
+def test_forecast_rollout_matches_train_mode_nets_and_oracle_env(workspace, skel):
+    """ego_forecast front end in the lockstep rollout: with the mean action, every recorded action equals the policy
+    head over VideoForecastNet's TRAIN-mode forward of the batch (the form pinned to the reference's golden vectors),
+    i.e. the per-slot video context and the per-tick state-LSTM stepping (reset at episode starts) are right; physics,
+    observations and the decayed reward are replayed by the oracle's CPU env."""
+    from egopose_amd.physics import SurrogatePhysics
+    from oracle.cpu_env import OracleHumanoidEnv
+    from oracle import humanoid as H
+    tr, cfg = _forecast_trainer(workspace, 16, 12, num_threads=4, num_groups=2)
+    assert tr.forecast and cfg.reward_weights["decay"] and cfg.fr_margin == 30 and not cfg.end_reward
+    tr.pre_iter_update(0)
+    tr.agent.mean_action = True
+    ro = tr.agent._get_rollout()
+    ro.mean_action = True
+    batch, log = tr.agent.sample(16 * 30)
+    N = len(batch)
+    assert N >= 480 and batch.exps.max() == 0
+    ends = np.where(batch.masks == 0)[0]
+    starts = np.r_[0, ends[:-1] + 1]
+    assert (ends - starts + 1).max() <= 12
+    # --- actions == policy head over the train-mode nets on the same (filtered) states
+    dev = torch.device("cuda", 0)
+    vs, pol = tr.policy_vs_net, tr.policy_net
+    with torch.no_grad():
+        vs.set_mode("train")
+        vs.attach_feature_table(ro.experts.cnn_table(dev, torch.float32), ro.experts.cnn_offset)
+        masks = torch.as_tensor(batch.masks.astype(np.float32), device=dev)
+        vs.initialize((masks, tr.env.cnn_feat, batch.v_metas))
+        x = vs(torch.as_tensor(batch.states, dtype=torch.float32, device=dev))
+        mean, _ = pol.mean_std(x)
+        vs.set_mode("test")
+    np.testing.assert_allclose(batch.actions, mean.double().cpu().numpy(), rtol=2e-4, atol=2e-4)
+    # --- physics / observation / decayed reward replay (raw observations need the filter state: compare rewards + masks)
+    ph = SurrogatePhysics(skel, 1)
+    env = OracleHumanoidEnv(skel, cfg, ph, tr.env.expert_arr, tr.env.cnn_feat)
+    for s, e in zip(starts[:6], ends[:6]):
+        ei, si = batch.v_metas[s]
+        env.expert_ind, env.start_ind, env.cur_t = int(ei), int(si), 0
+        ex = tr.env.expert_arr[ei]
+        ph.reset(0, ex["qpos"][si], ex["qvel"][si])
+        env._drain(True)
+        env.bquat = H.body_quat(env.qpos, skel.body_qpos_start, skel.body_ndof)[0]
+        for i in range(s, e + 1):
+            _, _, done, info = env.step(batch.actions[i])
+            r, _ = env.reward(None, None, info)
+            np.testing.assert_allclose(batch.rewards[i], r, rtol=1e-7, atol=1e-7, err_msg="reward @%d" % i)
+            assert done == (batch.masks[i] == 0)
+    ph.close()
+    tr.close()
+
+
+def test_forecast_full_iteration(workspace):
+    tr, cfg = _forecast_trainer(workspace, 32, 10, num_threads=4, num_groups=2)
+    before = [p.detach().clone() for p in list(tr.policy_net.parameters()) + list(tr.policy_vs_net.parameters())]
+    log, t_s, t_u, n = tr.iteration(0, 32 * 12)
+    assert n >= 384 and np.isfinite(log.avg_c_reward)
+    assert tr.env.end_reward == 0.0                     # end_reward: false in the egoforecast configs
+    assert cfg.env_init_noise == cfg.adp_init_noise
+    after = list(tr.policy_net.parameters()) + list(tr.policy_vs_net.parameters())
+    changed = [not torch.equal(a, b) for a, b in zip(before, after) if b.requires_grad]
+    assert all(changed), "policy MLP, video LSTM and state LSTM must all receive gradients"
+    assert all(np.isfinite(tr.agent.update_stats["value_loss"]))
+    path = os.path.join(workspace, "cp_forecast.p")
+    tr.save(path)
+    cp = pickle.load(open(path, "rb"))
+    assert "s_net.rnn_f.weight_ih" in cp["policy_vs_dict"] and "v_net.rnn_f.weight_hh" in cp["value_vs_dict"]
+    # warm start from an ego_mimic-shaped checkpoint drops the first affine layer (input width differs)
+    mim, mcfg = _trainer(workspace, 8, 10, num_threads=2, num_groups=1)
+    mpath = os.path.join(workspace, "cp_mimic.p")
+    mim.save(mpath)
+    w_before = tr.policy_net.net.affine_layers[0].weight.detach().clone()
+    tr.warm_start(mpath, mcfg)
+    assert torch.equal(tr.policy_net.net.affine_layers[0].weight, w_before)
+    assert torch.equal(tr.policy_net.net.affine_layers[1].weight.cpu(), mim.policy_net.net.affine_layers[1].weight.cpu())
+    mim.close()
+    tr.close()

@@ -545,6 +545,47 @@ def main():
     np.savez(os.path.join(OUT, "eval_tools.npz"), qpos=al_qpos, qvel=al_qvel, ref_qpos=al_ref, out_qpos=out_q, out_qvel=out_v,
              sn_x=sn_x.numpy(), sn_y=sn_y, **{"sn_" + k: v.numpy() for k, v in sn.state_dict().items()})
 
+    # ------------------------------------------------------------------ G17 ego_forecast: config schedules + VideoForecastNet
+    from ego_pose.utils.egoforecast_config import Config as FConfig
+    from models.video_forecast_net import VideoForecastNet
+    fcfg = FConfig("subject_03", create_dirs=False)
+    adp = []
+    for it in (0, 40, 250, 1000, 2999):
+        fcfg.update_adaptive_params(it)
+        adp.append([it, fcfg.adp_noise_rate, fcfg.adp_log_std, fcfg.adp_policy_lr, fcfg.adp_init_noise])
+    rng3 = np.random.RandomState(91)
+    torch.manual_seed(13)
+    cdim, sdim, vh, sh, margin = 6, 5, 8, 7, 4
+    fn = VideoForecastNet(cdim, sdim, vh, margin, 'lstm', None, sh, 'lstm', False)
+    fsd = {k: v.numpy().copy() for k, v in fn.state_dict().items()}
+    win = rng3.normal(size=(margin + 9 + margin, cdim))
+    fn.set_mode('test')
+    st_seq = rng3.normal(size=(4, 1, sdim))
+    with torch.no_grad():
+        fn.initialize(torch.tensor(win))
+        f_vout = fn.v_out.numpy().copy()
+        test_out = np.stack([fn(torch.tensor(st_seq[k])).numpy()[0] for k in range(4)])
+    cnn_feat_f = [rng3.normal(size=(40, cdim)), rng3.normal(size=(35, cdim))]
+    masks_f, v_metas_f = [], []
+    for L_ep in [5, 2, 7, 1, 4]:
+        e_ind = int(rng3.randint(2))
+        s_ind = int(rng3.randint(margin, cnn_feat_f[e_ind].shape[0] - 9 - margin))
+        for k in range(L_ep):
+            masks_f.append(0.0 if k == L_ep - 1 else 1.0)
+            v_metas_f.append([e_ind, s_ind])
+    masks_f = torch.tensor(masks_f)
+    v_metas_f = np.array(v_metas_f)
+    fn.set_mode('train')
+    fn.initialize((masks_f, cnn_feat_f, v_metas_f))
+    states_f = torch.tensor(rng3.normal(size=(len(masks_f), sdim)))
+    with torch.no_grad():
+        f_train_out = fn(states_f).numpy().copy()
+    np.savez(os.path.join(OUT, "forecast.npz"), adp=np.array(adp, float), fr_margin=fcfg.fr_margin, env_episode_len=fcfg.env_episode_len,
+             end_reward=fcfg.end_reward, jkp=fcfg.jkp, a_ref=fcfg.a_ref, policy_s_hdim=fcfg.policy_s_hdim,
+             win=win, v_out=f_vout, st_seq=st_seq, test_out=test_out, cnn_feat0=cnn_feat_f[0], cnn_feat1=cnn_feat_f[1],
+             masks=masks_f.numpy(), v_metas=v_metas_f, states=states_f.numpy(), train_out=f_train_out, indices=fn.indices,
+             dims=np.array([cdim, sdim, vh, sh, margin]), **{"sd_" + k: v for k, v in fsd.items()})
+
     os.chdir(REPO)
     shutil.rmtree(wd, ignore_errors=True)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
