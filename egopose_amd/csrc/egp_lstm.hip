@@ -1,4 +1,5 @@
-// Persistent recurrent kernels for the video-context LSTM (hidden 64 per direction, float32).
+// Persistent recurrent kernels for the LSTMs of the video / state front ends (float32; hidden 64 = one direction of
+// ego_mimic's bi-LSTM, hidden 128 = the causal video net and the state net of ego_forecast).
 //
 // The reference evaluates the bi-LSTM with 2*T nn.LSTMCell calls (models/rnn.py:45-61) and every PPO epoch
 // re-runs it forward+backward over the padded episode contexts (models/video_state_net.py:65-69), which on
@@ -21,19 +22,20 @@
 
 namespace egp {
 
-constexpr int LH = 64;          // hidden units per direction
-constexpr int LG = 4 * LH;      // gate columns
+constexpr int KC = 64;          // hidden-state columns multiplied per register chunk
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each): ~1e-7 relative, far inside the float32 parity budget
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
-// TILE sequences per 256-thread workgroup (8 fills the chip at B ~ 2k, 16 amortises W_hh better for large B).
-template <int TILE>
-__global__ __launch_bounds__(256) void k_lstm_fwd(const float *__restrict__ gx, const float *__restrict__ w_hh, int T, int B,
-                                                  int reverse, float *__restrict__ h_out, float *__restrict__ gates_out,
-                                                  float *__restrict__ c_out) {
-    constexpr int NP = TILE * LH / 256;             // (row, unit) pairs per thread in the pointwise phase
+// TILE sequences per workgroup of 4*LH threads (thread c = gate column c); small tiles put several workgroups on a CU.
+template <int TILE, int LH>
+__global__ __launch_bounds__(4 * LH) void k_lstm_fwd(const float *__restrict__ gx, const float *__restrict__ w_hh, int T, int B,
+                                                     int reverse, float *__restrict__ h_out, float *__restrict__ gates_out,
+                                                     float *__restrict__ c_out) {
+    constexpr int LG = 4 * LH, NT = 4 * LH;
+    constexpr int NP = TILE * LH / NT;              // (row, unit) pairs per thread in the pointwise phase
+    static_assert(NP >= 1 && LH % KC == 0, "tile / hidden size");
     __shared__ __attribute__((aligned(16))) float s_h[2][TILE][LH];   // ping-pong: written for step+1 while step reads
     __shared__ float s_g[2][TILE][LG + 1];
     const int c = threadIdx.x;
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void k_lstm_fwd(const float *__restrict__ gx, 
     float cst[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) cst[q] = 0.f;
-    for (int i = threadIdx.x; i < 2 * TILE * LH; i += 256) (&s_h[0][0][0])[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * TILE * LH; i += NT) (&s_h[0][0][0])[i] = 0.f;
     // software prefetch: the input-projection tile of the NEXT step is in flight while this step computes
     float nxt[TILE];
     {
@@ -65,20 +67,23 @@ __global__ __launch_bounds__(256) void k_lstm_fwd(const float *__restrict__ gx, 
 #pragma unroll
             for (int r = 0; r < TILE; ++r) nxt[r] = (r0 + r < B) ? gn[(long)r * LG + c] : 0.f;
         }
-        // h W_hh^T row by row: the 16 broadcast ds_read_b128 of a row are issued back to back into distinct
-        // registers (one exposed LDS latency per row, not per read) and feed 4 independent FMA chains
+        // h W_hh^T row by row: the 16 broadcast ds_read_b128 of a 64-column chunk are issued back to back into distinct
+        // registers (one exposed LDS latency per chunk, not per read) and feed 4 independent FMA chains
 #pragma unroll
         for (int r = 0; r < TILE; ++r) {
-            float4 hv[LH / 4];
-#pragma unroll
-            for (int k4 = 0; k4 < LH / 4; ++k4) hv[k4] = reinterpret_cast<const float4 *>(&s_h[step & 1][r][0])[k4];
             float a0 = acc[r], a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-            for (int k4 = 0; k4 < LH / 4; ++k4) {
-                a0 = fmaf(w[4 * k4 + 0], hv[k4].x, a0);
-                a1 = fmaf(w[4 * k4 + 1], hv[k4].y, a1);
-                a2 = fmaf(w[4 * k4 + 2], hv[k4].z, a2);
-                a3 = fmaf(w[4 * k4 + 3], hv[k4].w, a3);
+            for (int kc = 0; kc < LH; kc += KC) {
+                float4 hv[KC / 4];
+#pragma unroll
+                for (int k4 = 0; k4 < KC / 4; ++k4) hv[k4] = reinterpret_cast<const float4 *>(&s_h[step & 1][r][kc])[k4];
+#pragma unroll
+                for (int k4 = 0; k4 < KC / 4; ++k4) {
+                    a0 = fmaf(w[kc + 4 * k4 + 0], hv[k4].x, a0);
+                    a1 = fmaf(w[kc + 4 * k4 + 1], hv[k4].y, a1);
+                    a2 = fmaf(w[kc + 4 * k4 + 2], hv[k4].z, a2);
+                    a3 = fmaf(w[kc + 4 * k4 + 3], hv[k4].w, a3);
+                }
             }
             acc[r] = (a0 + a1) + (a2 + a3);
         }
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256) void k_lstm_fwd(const float *__restrict__ gx, 
         __syncthreads();       // gate pre-activations of every column are in s_g[step&1]
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            const int p = threadIdx.x + 256 * q, r = p >> 6, j = p & 63;
+            const int p = threadIdx.x + NT * q, r = p / LH, j = p % LH;
             const float *sg = &s_g[step & 1][r][0];
             const float ig = sigmoidf_(sg[j]), fg = sigmoidf_(sg[LH + j]);
             const float gg = tanhf_(sg[2 * LH + j]), og = sigmoidf_(sg[3 * LH + j]);
@@ -109,16 +114,17 @@ __global__ __launch_bounds__(256) void k_lstm_fwd(const float *__restrict__ gx, 
     }
 }
 
-// backward through time for one direction. Thread (q = tid/64, k = tid%64) keeps W_hh[q*64 .. q*64+63][k]
+// backward through time for one direction. Thread (q = tid/LH, k = tid%LH) keeps W_hh[q*LH .. q*LH+LH-1][k]
 // so that dh_rec[r][k] = sum_c dpre[r][c] W_hh[c][k] is a 4-way partial sum reduced through LDS.
-template <int TILE>
-__global__ __launch_bounds__(256) void k_lstm_bwd(const float *__restrict__ dh_out, const float *__restrict__ gates,
+template <int TILE, int LH>
+__global__ __launch_bounds__(4 * LH) void k_lstm_bwd(const float *__restrict__ dh_out, const float *__restrict__ gates,
                                                   const float *__restrict__ cells, const float *__restrict__ w_hh, int T, int B,
                                                   int reverse, float *__restrict__ dpre) {
-    constexpr int NP = TILE * LH / 256;
+    constexpr int LG = 4 * LH, NT = 4 * LH;
+    constexpr int NP = TILE * LH / NT;
     __shared__ __attribute__((aligned(16))) float s_d[TILE][LG];        // d(pre-activation gates) of this step
     __shared__ float s_part[4][TILE][LH + 1];
-    const int q = threadIdx.x >> 6, k = threadIdx.x & 63;
+    const int q = threadIdx.x / LH, k = threadIdx.x % LH;
     const int r0 = blockIdx.x * TILE;
     float w[LH];
 #pragma unroll
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(const float *__restrict__ dh_o
         const int f_t = reverse ? T - 1 - (STEP) : (STEP);                                           \
         const int f_tp = reverse ? f_t + 1 : f_t - 1;                                                \
         _Pragma("unroll") for (int qq = 0; qq < NP; ++qq) {                                          \
-            const int p = threadIdx.x + 256 * qq, r = p >> 6, j = p & 63;                            \
+            const int p = threadIdx.x + NT * qq, r = p / LH, j = p % LH;                             \
             if (r0 + r < B) {                                                                        \
                 const long row = (long)f_t * B + r0 + r;                                             \
                 const float *g = gates + row * LG;                                                   \
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(const float *__restrict__ dh_o
         const int t = reverse ? T - 1 - step : step;
 #pragma unroll
         for (int qq = 0; qq < NP; ++qq) {
-            const int p = threadIdx.x + 256 * qq, r = p >> 6, j = p & 63;
+            const int p = threadIdx.x + NT * qq, r = p / LH, j = p % LH;
             const float ig = pg[qq][0], fg = pg[qq][1], gg = pg[qq][2], og = pg[qq][3];
             const float tc = tanhf_(pc[qq]);
             const float dh = pdh[qq] + dh_rec[qq];
@@ -175,16 +181,19 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(const float *__restrict__ dh_o
         float acc[TILE];
 #pragma unroll
         for (int r = 0; r < TILE; ++r) {
-            float4 dv[LH / 4];
-#pragma unroll
-            for (int c4 = 0; c4 < LH / 4; ++c4) dv[c4] = reinterpret_cast<const float4 *>(&s_d[r][q * LH])[c4];
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-            for (int c4 = 0; c4 < LH / 4; ++c4) {
-                a0 = fmaf(w[4 * c4 + 0], dv[c4].x, a0);
-                a1 = fmaf(w[4 * c4 + 1], dv[c4].y, a1);
-                a2 = fmaf(w[4 * c4 + 2], dv[c4].z, a2);
-                a3 = fmaf(w[4 * c4 + 3], dv[c4].w, a3);
+            for (int kc = 0; kc < LH; kc += KC) {
+                float4 dv[KC / 4];
+#pragma unroll
+                for (int c4 = 0; c4 < KC / 4; ++c4) dv[c4] = reinterpret_cast<const float4 *>(&s_d[r][q * LH + kc])[c4];
+#pragma unroll
+                for (int c4 = 0; c4 < KC / 4; ++c4) {
+                    a0 = fmaf(w[kc + 4 * c4 + 0], dv[c4].x, a0);
+                    a1 = fmaf(w[kc + 4 * c4 + 1], dv[c4].y, a1);
+                    a2 = fmaf(w[kc + 4 * c4 + 2], dv[c4].z, a2);
+                    a3 = fmaf(w[kc + 4 * c4 + 3], dv[c4].w, a3);
+                }
             }
             acc[r] = (a0 + a1) + (a2 + a3);
         }
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(const float *__restrict__ dh_o
         __syncthreads();
 #pragma unroll
         for (int qq = 0; qq < NP; ++qq) {
-            const int p = threadIdx.x + 256 * qq, r = p >> 6, j = p & 63;
+            const int p = threadIdx.x + NT * qq, r = p / LH, j = p % LH;
             dh_rec[qq] = s_part[0][r][j] + s_part[1][r][j] + s_part[2][r][j] + s_part[3][r][j];
         }
         __syncthreads();
@@ -221,40 +230,52 @@ static int lstm_launch_check(const char *what) {
     return EGP_OK;
 }
 
+template <int LH>
+static void launch_fwd(int tile, const float *gates_x, const float *w_hh, int T, int B, int reverse, float *h_out, float *gates_save,
+                       float *cells_save, hipStream_t s) {
+    if (tile == 16)
+        k_lstm_fwd<16, LH><<<dim3((B + 15) / 16), dim3(4 * LH), 0, s>>>(gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save);
+    else if (tile == 8)
+        k_lstm_fwd<8, LH><<<dim3((B + 7) / 8), dim3(4 * LH), 0, s>>>(gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save);
+    else
+        k_lstm_fwd<4, LH><<<dim3((B + 3) / 4), dim3(4 * LH), 0, s>>>(gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save);
+}
+
+template <int LH>
+static void launch_bwd(int tile, const float *dh_out, const float *gates_save, const float *cells_save, const float *w_hh, int T, int B,
+                       int reverse, float *d_pre, hipStream_t s) {
+    if (tile == 16)
+        k_lstm_bwd<16, LH><<<dim3((B + 15) / 16), dim3(4 * LH), 0, s>>>(dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre);
+    else if (tile == 8)
+        k_lstm_bwd<8, LH><<<dim3((B + 7) / 8), dim3(4 * LH), 0, s>>>(dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre);
+    else
+        k_lstm_bwd<4, LH><<<dim3((B + 3) / 4), dim3(4 * LH), 0, s>>>(dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre);
+}
+
 extern "C" {
 
 int egp_lstm_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t B, int32_t hidden, int32_t reverse,
                      float *h_out, float *gates_save, float *cells_save, void *stream) {
-    EGP_REQUIRE(hidden == LH, "egp_lstm kernels are specialised for hidden size 64");
+    EGP_REQUIRE(hidden == 64 || hidden == 128, "egp_lstm kernels are built for hidden size 64 and 128");
     EGP_REQUIRE(T >= 0 && B >= 0, "negative size");
     if (T == 0 || B == 0) return EGP_OK;
     EGP_REQUIRE(gates_x && w_hh && h_out, "NULL pointer");
     EGP_REQUIRE((gates_save == nullptr) == (cells_save == nullptr), "gates_save and cells_save go together");
     hipStream_t s = (hipStream_t)stream;
-    const int tile = lstm_tile(B);
-    if (tile == 16)
-        k_lstm_fwd<16><<<dim3((B + 15) / 16), dim3(256), 0, s>>>(gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save);
-    else if (tile == 8)
-        k_lstm_fwd<8><<<dim3((B + 7) / 8), dim3(256), 0, s>>>(gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save);
-    else
-        k_lstm_fwd<4><<<dim3((B + 3) / 4), dim3(256), 0, s>>>(gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save);
+    if (hidden == 64) launch_fwd<64>(lstm_tile(B), gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
+    else launch_fwd<128>(4, gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
     return lstm_launch_check("k_lstm_fwd");
 }
 
 int egp_lstm_bwd_f32(const float *dh_out, const float *gates_save, const float *cells_save, const float *w_hh, int32_t T, int32_t B,
                      int32_t hidden, int32_t reverse, float *d_pre, void *stream) {
-    EGP_REQUIRE(hidden == LH, "egp_lstm kernels are specialised for hidden size 64");
+    EGP_REQUIRE(hidden == 64 || hidden == 128, "egp_lstm kernels are built for hidden size 64 and 128");
     EGP_REQUIRE(T >= 0 && B >= 0, "negative size");
     if (T == 0 || B == 0) return EGP_OK;
     EGP_REQUIRE(dh_out && gates_save && cells_save && w_hh && d_pre, "NULL pointer");
     hipStream_t s = (hipStream_t)stream;
-    const int tile = lstm_tile(B);
-    if (tile == 16)
-        k_lstm_bwd<16><<<dim3((B + 15) / 16), dim3(256), 0, s>>>(dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre);
-    else if (tile == 8)
-        k_lstm_bwd<8><<<dim3((B + 7) / 8), dim3(256), 0, s>>>(dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre);
-    else
-        k_lstm_bwd<4><<<dim3((B + 3) / 4), dim3(256), 0, s>>>(dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre);
+    if (hidden == 64) launch_bwd<64>(lstm_tile(B), dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
+    else launch_bwd<128>(4, dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
     return lstm_launch_check("k_lstm_bwd");
 }
 

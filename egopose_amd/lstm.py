@@ -16,11 +16,11 @@ import torch
 
 from . import _lib as L
 
-HIDDEN = 64
+HIDDEN_SIZES = (64, 128)      # hidden sizes the HIP kernels are built for
 
 
 def available(x, cell):
-    return (x.is_cuda and x.dtype == torch.float32 and cell.hidden_size == HIDDEN
+    return (x.is_cuda and x.dtype == torch.float32 and cell.hidden_size in HIDDEN_SIZES
             and cell.weight_hh.dtype == torch.float32 and cell.bias_ih is not None)
 
 
@@ -38,6 +38,7 @@ class LstmDirection(torch.autograd.Function):
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, reverse):
         lib = L.load()
         T, B, D = x.shape
+        HIDDEN = w_hh.shape[1]
         x2 = x.reshape(T * B, D)
         gx = torch.addmm(b_ih + b_hh, x2, w_ih.t()).view(T, B, 4 * HIDDEN)
         h = torch.empty(T, B, HIDDEN, dtype=x.dtype, device=x.device)
@@ -59,6 +60,7 @@ class LstmDirection(torch.autograd.Function):
         lib = L.load()
         x2, w_ih, w_hh, h, gates, cells = ctx.saved_tensors
         T, B, D = ctx.shape
+        HIDDEN = w_hh.shape[1]
         dpre = torch.empty(T, B, 4 * HIDDEN, dtype=h.dtype, device=h.device)
         L.check(lib.egp_lstm_bwd_f32(_p(dh.contiguous()), _p(gates), _p(cells), _p(w_hh), T, B, HIDDEN,
                                      1 if ctx.reverse else 0, _p(dpre), _s()), "egp_lstm_bwd_f32")

@@ -50,3 +50,32 @@ def test_hip_lstm_matches_miopen_path(monkeypatch):
         monkeypatch.setattr(nets, "_LSTM_IMPL", "torch")
         b = rnn(x)
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("T,B,D", [(30, 45, 128), (90, 19, 115), (5, 3, 128)])
+def test_hip_lstm_hidden128_matches_lstmcell_loop(T, B, D):
+    """The hidden-128 instantiation (ego_forecast's causal video net / state net: uni-directional RNN(D, 128)) vs
+    torch's float64 nn.LSTMCell loop on the CPU (models/rnn.py:45-61): outputs and all parameter gradients."""
+    import egopose_amd.lstm as lstm_mod
+    from egopose_amd.nets import RNN
+    torch.manual_seed(T + B)
+    rnn = RNN(D, 128, "lstm", bi_dir=False)
+    x, dy = torch.randn(T, B, D), torch.randn(T, B, 128)
+    ref_cell = torch.nn.LSTMCell(D, 128).double()
+    ref_cell.load_state_dict({k: v.double() for k, v in rnn.rnn_f.state_dict().items()})
+    h = c = torch.zeros(B, 128, dtype=torch.float64)
+    outs = []
+    for t in range(T):
+        h, c = ref_cell(x[t].double(), (h, c))
+        outs.append(h)
+    ref = torch.stack(outs)
+    (ref * dy.double()).sum().backward()
+    rnn = rnn.cuda()
+    assert lstm_mod.available(x.cuda(), rnn.rnn_f)
+    out = rnn(x.cuda())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=3e-5)
+    (out * dy.cuda()).sum().backward()
+    for name, p in rnn.rnn_f.named_parameters():
+        g = getattr(ref_cell, name).grad.numpy()
+        scale = max(1.0, np.abs(g).max())
+        np.testing.assert_allclose(p.grad.cpu().numpy() / scale, g / scale, rtol=0, atol=5e-5, err_msg=name)
