@@ -29,8 +29,9 @@ class VaryingInertiaBackend:
     every step (qM = qM0 * (1 + 0.03 * ((step + env) % 4))) and so does its epoch -- the shape of a MuJoCo adapter,
     whose M depends on qpos. `torques` logs every ctrl row the engine handed to step()."""
 
-    def __init__(self, skel, n_env):
+    def __init__(self, skel, n_env, fail_at=None):
         from egopose_amd.physics import SurrogatePhysics, CallbackPhysics
+        self.fail_at = fail_at                      # (env, step count): step() raises there (failure-path tests)
         self.inner = SurrogatePhysics(skel, n_env)
         self.k = np.zeros(n_env, np.int64)
         self.resets = np.zeros(n_env, np.int64)
@@ -48,6 +49,8 @@ class VaryingInertiaBackend:
         self.resets[env] += 1
 
     def _step(self, env, ctrl):
+        if self.fail_at is not None and (env, int(self.k[env])) == tuple(self.fail_at):
+            raise RuntimeError("contact solver diverged (injected)")
         self.torques[env].append(ctrl.copy())
         self.inner.step(env, ctrl.copy())
         self.k[env] += 1

@@ -398,3 +398,36 @@ def test_fused_policy_step_matches_torch(act, hidden, n):
         mean2, _ = pol.mean_std(x)
     assert float((act_out - mean2.double()).abs().max()) <= 2e-5 * max(1.0, float(mean2.abs().max()))
     assert float((mean2 - mean).abs().max()) > 1e-4
+
+
+@pytest.mark.parametrize("mode", ["resident", "pipelined", "barrier"])
+def test_engine_reports_backend_failure_instead_of_hanging(ctx, skel, mode, monkeypatch):
+    """A physics callback that fails in the middle of an env-step: every engine mode must come back with an error
+    (the resident K1 is drained through its go words, nothing is left spinning on the GPU), stay failed for further
+    steps, and leave the device usable."""
+    import time
+    from conftest import VaryingInertiaBackend
+    from egopose_amd.physics import RolloutEngine
+    for k, v in ENGINE_MODES[mode][0].items():
+        monkeypatch.setenv(k, v)
+    g = load_golden("body_quat_obs.npz")
+    n = 26
+    be = VaryingInertiaBackend(skel, n, fail_at=(9, 3))
+    eng = RolloutEngine(ctx, be, n, n_threads=3, n_groups=1)
+    try:
+        eng.reset(np.arange(n), g["qpos"][:n], g["qvel"][:n] * 0.2)
+        act = dev(np.zeros((n, 52)))
+        torch.cuda.synchronize()
+        t0 = time.time()
+        eng.step_async(0, act)
+        with pytest.raises(RuntimeError, match="physics backend failed"):
+            eng.wait(0)
+        assert time.time() - t0 < 4.0, "a failure must not have to wait for a timeout"
+        with pytest.raises(RuntimeError):
+            eng.step_async(0, act)                 # the group stays failed
+        torch.cuda.synchronize()                   # nothing is left running on the device
+        assert float((dev(np.ones(4)) * 2).sum().item()) == 8.0
+        assert any("injected" in str(e) for e in be.physics.errors)
+    finally:
+        eng.close()
+        be.close()
