@@ -52,6 +52,12 @@ class SurrogateDesc(C.Structure):
     ]
 
 
+class DynamicsDesc(C.Structure):
+    _fields_ = [("nbody", C.c_int32), ("njoint", C.c_int32), ("body_parent", c_int_p), ("body_pos", c_dbl_p), ("body_com", c_dbl_p),
+                ("body_inertia", c_dbl_p), ("body_mass", c_dbl_p), ("body_ndof", c_int_p), ("joint_axis", c_dbl_p),
+                ("joint_anchor", c_dbl_p), ("armature", C.c_double), ("gravity", C.c_double * 3)]
+
+
 class MlpLayer(C.Structure):
     _fields_ = [("wt", vp), ("bias", vp), ("in_dim", C.c_int32), ("out_dim", C.c_int32)]
 
@@ -104,6 +110,8 @@ SIGNATURES = {
     "egp_gae_standardize_f32": (C.c_int, [vp, _i32, vp, vp]),
     "egp_lstm_fwd_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp]),
     "egp_lstm_bwd_f32": (C.c_int, [vp, vp, vp, vp, _i32, _i32, _i32, _i32, vp, vp]),
+    "egp_set_dynamics_model": (C.c_int, [vp, C.POINTER(DynamicsDesc)]),
+    "egp_dynamics_f64": (C.c_int, [vp, vp, vp, _i32, vp, C.c_int64, vp, vp, vp]),
     "egp_policy_gaussian_f32": (C.c_int, [vp, C.c_int64, _i32, vp, vp, _i32, _i32, C.POINTER(MlpLayer), _i32, _i32, vp, vp, vp, vp, vp]),
     "egp_physics_register": (C.c_int, [C.POINTER(PhysicsVtable), _i32, C.POINTER(vp)]),
     "egp_physics_create_surrogate": (C.c_int, [C.POINTER(SurrogateDesc), _i32, C.POINTER(vp)]),

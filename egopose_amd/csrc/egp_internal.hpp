@@ -66,6 +66,7 @@ struct egp_ctx {
     float *expert_rows_f32 = nullptr;
     int pd_variant = 0;                // 0 = tree-ordered in-register elimination, 2 = dense in-register, 1 = LDS
     bool tree58 = false;               // runtime dof tree == compiled-in humanoid tree
+    void *dyn_tables = nullptr;        // device copy of the dynamics tree (egp_set_dynamics_model), owned through allocs
 };
 
 // launches used by the engine (same TU as the kernels)

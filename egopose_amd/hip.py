@@ -199,6 +199,53 @@ class EgpContext:
                    _ptr(active), float(end_reward), n, _ptr(r), _ptr(ci), _stream()), "egp_reward_quat_v3")
         return r, ci
 
+    # ------------------------------------------------------------------ K8: dynamics terms on the GPU
+    def set_dynamics_model(self, skel=None, gravity=(0.0, 0.0, -9.81)):
+        """Upload the inertial tree (masses, COMs, inertias, hinge axes / anchors at the zero pose) for `dynamics`."""
+        sk = skel if skel is not None else self.skel
+        keep = dict(parent=np.ascontiguousarray(sk.body_parent, np.int32), pos=np.ascontiguousarray(sk.body_pos, np.float64),
+                    com=np.ascontiguousarray(sk.body_com, np.float64), inertia=np.ascontiguousarray(sk.body_inertia, np.float64),
+                    mass=np.ascontiguousarray(sk.body_mass, np.float64), ndof=np.ascontiguousarray(sk.body_ndof, np.int32),
+                    axis=np.ascontiguousarray(sk.joint_axis, np.float64), anchor=np.ascontiguousarray(sk.joint_anchor, np.float64))
+        d = L.DynamicsDesc()
+        d.nbody, d.njoint = len(sk.body_names), len(sk.joint_names)
+        d.body_parent = keep["parent"].ctypes.data_as(L.c_int_p)
+        d.body_pos = keep["pos"].ctypes.data_as(L.c_dbl_p)
+        d.body_com = keep["com"].ctypes.data_as(L.c_dbl_p)
+        d.body_inertia = keep["inertia"].ctypes.data_as(L.c_dbl_p)
+        d.body_mass = keep["mass"].ctypes.data_as(L.c_dbl_p)
+        d.body_ndof = keep["ndof"].ctypes.data_as(L.c_int_p)
+        d.joint_axis = keep["axis"].ctypes.data_as(L.c_dbl_p)
+        d.joint_anchor = keep["anchor"].ctypes.data_as(L.c_dbl_p)
+        d.armature = float(sk.armature)
+        for i in range(3):
+            d.gravity[i] = float(gravity[i])
+        L.check(self.lib.egp_set_dynamics_model(self.handle, C.byref(d)), "egp_set_dynamics_model")
+        self._has_dynamics = True
+
+    def dynamics(self, qpos, qvel, want_qM=True, want_bias=True, want_xpos=False, qM_out=None):
+        """(qpos, qvel) float64 [n] -> dict(qM [n][nM] legacy sparse, bias [n][nv], xpos [n][nbody][3]) on the GPU."""
+        if not getattr(self, "_has_dynamics", False):
+            self.set_dynamics_model()
+        n = qpos.shape[0]
+        _need(qpos, (n, self.nq), torch.float64, "qpos")
+        _need(qvel, (n, self.nv), torch.float64, "qvel")
+        dev = qpos.device
+        out = {}
+        ld = self.nM
+        if qM_out is not None:
+            assert qM_out.dtype == torch.float64 and qM_out.shape[0] == n and qM_out.stride(1) == 1 and qM_out.shape[1] >= self.nM
+            out["qM"], ld = qM_out, qM_out.stride(0)
+        elif want_qM:
+            out["qM"] = torch.empty(n, self.nM, dtype=torch.float64, device=dev)
+        if want_bias:
+            out["bias"] = torch.empty(n, self.nv, dtype=torch.float64, device=dev)
+        if want_xpos:
+            out["xpos"] = torch.empty(n, self.nbody, 3, dtype=torch.float64, device=dev)
+        L.check(self.lib.egp_dynamics_f64(self.handle, _ptr(qpos), _ptr(qvel), n, _ptr(out.get("qM")), int(ld), _ptr(out.get("bias")),
+                                          _ptr(out.get("xpos")), _stream()), "egp_dynamics_f64")
+        return out
+
     def pose_features(self, cur_qpos, prev_qpos, ee_wpos, expert_convention=False):
         """-> dict(qvel, rlinv_local, rangv, rq_rmh, ee_pos, bquat, bangvel) device tensors (K7)."""
         n, dt = cur_qpos.shape[0], cur_qpos.dtype

@@ -204,6 +204,30 @@ int egp_lstm_bwd_f32(const float *dh_out, const float *gates_save, const float *
                      int32_t T, int32_t B, int32_t hidden, int32_t reverse, float *d_pre, void *stream);
 
 /* ----------------------------------------------------------------------------------------
+ * K8: dynamics terms on the GPU. From (qpos, qvel) per env: body frame positions (mjData.xpos[1:]),
+ * the joint-space inertia in MuJoCo's legacy sparse order (mjData.qM, what mj_fullM expands) and the bias force
+ * (mjData.qfrc_bias) -- the mjData fields compute_torque / get_ee_pos read (ego_pose/envs/humanoid_v1.py:98-111,130-144).
+ * Conventions are MuJoCo's (root angular velocity in the body frame, MJCF coordinate="global", armature on the hinge
+ * diagonal). Tables are HOST arrays describing the zero pose in global coordinates; bodies parents-first, body 0 = root.
+ * qM / qfrc_bias / xpos may each be NULL. MuJoCo is not available to pin against: see oracle/dynamics.py. */
+typedef struct egp_dynamics_desc {
+    int32_t nbody, njoint;
+    const int32_t *body_parent;   /* [nbody], -1 for the root */
+    const double *body_pos;       /* [nbody*3] */
+    const double *body_com;       /* [nbody*3] */
+    const double *body_inertia;   /* [nbody*9] about the COM, global axes */
+    const double *body_mass;      /* [nbody] */
+    const int32_t *body_ndof;     /* [nbody] hinges per body (entry 0 ignored: free joint) */
+    const double *joint_axis;     /* [njoint*3] */
+    const double *joint_anchor;   /* [njoint*3] */
+    double armature;
+    double gravity[3];
+} egp_dynamics_desc;
+int egp_set_dynamics_model(egp_ctx *ctx, const egp_dynamics_desc *desc);
+int egp_dynamics_f64(egp_ctx *ctx, const double *qpos, const double *qvel, int32_t n, double *qM, int64_t ld_m,
+                     double *qfrc_bias, double *xpos, void *stream);
+
+/* ----------------------------------------------------------------------------------------
  * Rollout-time policy step in one launch (replaces, for all envs of a group at once, the chain
  * VideoStateNet.forward concat (models/video_state_net.py:37-43) -> MLP (models/mlp.py:5-25) ->
  * PolicyGaussian.forward / select_action (models/policy_gaussian.py:19-27, core/agent.py:38-44)):

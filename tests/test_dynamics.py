@@ -1,0 +1,102 @@
+"""K8 (csrc/egp_dynamics.hip): forward kinematics, joint-space inertia (MuJoCo legacy sparse qM) and bias force on the
+GPU. MuJoCo is not available, so the oracle (oracle/dynamics.py) is first pinned to first principles on the CPU
+(kinetic energy and Newton-Euler from finite differences of the forward kinematics, the zero-pose inertia the
+surrogate backend already uses), then the kernel is compared with it."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dynamics as D
+from oracle import humanoid as H
+
+
+@pytest.fixture(scope="module")
+def ctx(skel):
+    from conftest import load_golden
+    from egopose_amd.hip import EgpContext
+    c = load_golden("config_subject_03.npz")
+    cx = EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"])
+    yield cx
+    cx.close()
+
+
+def _rand_state(skel, rng, n, joint_scale=0.5, vel_scale=1.0):
+    q = np.zeros((n, skel.nq))
+    q[:, :3] = rng.normal(size=(n, 3))
+    quat = rng.normal(size=(n, 4))
+    q[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    q[:, 7:] = rng.normal(size=(n, skel.nq - 7)) * joint_scale
+    return q, rng.normal(size=(n, skel.nv)) * vel_scale
+
+
+def test_oracle_dynamics_first_principles(skel):
+    rng = np.random.RandomState(3)
+    q0 = np.zeros(skel.nq)
+    q0[2], q0[3] = 1.0, 1.0
+    np.testing.assert_allclose(D.inertia_matrix(skel, q0), skel.zero_pose_inertia(), atol=1e-12)
+    q, v = _rand_state(skel, rng, 3)
+    for i in range(3):
+        np.testing.assert_allclose(D.fk(skel, q[i])[1], skel.body_xpos(q[i]), atol=1e-12)
+        M = D.inertia_matrix(skel, q[i])
+        assert np.linalg.eigvalsh(M).min() > 0 and np.abs(M - M.T).max() == 0
+        ke = 0.5 * v[i] @ M @ v[i] - 0.5 * skel.armature * (v[i, 6:] @ v[i, 6:])
+        assert ke == pytest.approx(D.kinetic_energy_fd(skel, q[i], v[i]), rel=1e-7)
+        # tree sparsity: dofs on different branches do not couple
+        rows, cols = skel.sparse_index()
+        mask = np.zeros_like(M, bool)
+        mask[rows, cols] = mask[cols, rows] = True
+        assert np.abs(M[~mask]).max() < 1e-12
+        # the spatial-vector formulation (the kernel's) against the Jacobian sum and the finite-difference Newton-Euler
+        Ms, Cs, _ = D.crba_rne_spatial(skel, q[i], v[i])
+        np.testing.assert_allclose(Ms, M, atol=1e-11)
+        C = D.bias_force(skel, q[i], v[i])
+        np.testing.assert_allclose(Cs, C, rtol=0, atol=2e-5 * max(1.0, np.abs(C).max()))
+    # at rest the bias is pure gravity: root force = total weight, straight up against g
+    q1, _ = _rand_state(skel, rng, 1)
+    C0 = D.bias_force(skel, q1[0], np.zeros(skel.nv))
+    np.testing.assert_allclose(C0[:3], [0, 0, 9.81 * skel.body_mass.sum()], atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 5, 64, 131])
+def test_dynamics_kernel_matches_oracle(ctx, skel, n):
+    rng = np.random.RandomState(n)
+    q, v = _rand_state(skel, rng, n)
+    dev = torch.device("cuda")
+    out = ctx.dynamics(torch.as_tensor(q, device=dev), torch.as_tensor(v, device=dev), want_xpos=True)
+    qM, bias, xpos = (out[k].cpu().numpy() for k in ("qM", "bias", "xpos"))
+    assert qM.shape == (n, skel.nM) and bias.shape == (n, skel.nv) and xpos.shape == (n, len(skel.body_names), 3)
+    for i in range(min(n, 12)):
+        np.testing.assert_allclose(xpos[i], skel.body_xpos(q[i]), rtol=0, atol=1e-12)
+        Ms, Cs, _ = D.crba_rne_spatial(skel, q[i], v[i])
+        np.testing.assert_allclose(skel.full_from_sparse(qM[i]), Ms, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(bias[i], Cs, rtol=0, atol=1e-9 * max(1.0, np.abs(Cs).max()))
+    # independent formulations on a couple of envs (Jacobian sum; finite-difference Newton-Euler)
+    for i in range(min(n, 2)):
+        np.testing.assert_allclose(skel.full_from_sparse(qM[i]), D.inertia_matrix(skel, q[i]), rtol=0, atol=1e-10)
+        C = D.bias_force(skel, q[i], v[i])
+        np.testing.assert_allclose(bias[i], C, rtol=0, atol=2e-5 * max(1.0, np.abs(C).max()))
+
+
+@pytest.mark.gpu
+def test_dynamics_feeds_stable_pd(ctx, skel):
+    """K8 -> K1 on the device: torques from GPU-computed (qM, qfrc_bias) == the oracle's stable PD on the oracle's M, C."""
+    from conftest import load_golden
+    c = load_golden("config_subject_03.npz")
+    rng = np.random.RandomState(8)
+    n = 9
+    q, v = _rand_state(skel, rng, n, joint_scale=0.3, vel_scale=0.5)
+    a = rng.normal(size=(n, skel.nu)) * 0.2
+    dev = torch.device("cuda")
+    qd, vd = torch.as_tensor(q, device=dev), torch.as_tensor(v, device=dev)
+    dyn = ctx.dynamics(qd, vd)
+    tq = ctx.pd_torque(qd, vd, torch.as_tensor(a, device=dev), dyn["qM"], dyn["bias"]).cpu().numpy()
+    for i in range(n):
+        M, C, _ = D.crba_rne_spatial(skel, q[i], v[i])
+        _, ref = H.pd_torque(q[i], v[i], a[i], M, C, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], skel.timestep)
+        np.testing.assert_allclose(tq[i], ref[0], rtol=1e-8, atol=1e-8)
+    # strided qM output (the engine's 912-double rows) and partial outputs
+    rows = torch.zeros(n, 912, dtype=torch.float64, device=dev)
+    only = ctx.dynamics(qd, vd, want_bias=False, qM_out=rows)
+    assert "bias" not in only and torch.equal(rows[:, :skel.nM], dyn["qM"]) and float(rows[:, skel.nM:].abs().max()) == 0.0
+    assert ctx.dynamics(qd[:0], vd[:0])["qM"].shape == (0, skel.nM)
