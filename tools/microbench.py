@@ -57,6 +57,7 @@ def main():
         frame = torch.randint(0, F, (n,), dtype=torch.int32, device="cuda")
         end = torch.zeros(n, dtype=torch.int32, device="cuda")
         obs = g(n, 115)
+        qM_dyn = torch.empty(n, sk.nM, dtype=dt, device="cuda")
         st0 = torch.zeros(231, dtype=dt, device="cuda")
         st1 = torch.empty_like(st0)
         rew, msk, val = torch.rand(n * 200 // 8, dtype=dt, device="cuda"), torch.ones(n * 200 // 8, dtype=dt, device="cuda"), g(n * 200 // 8)
@@ -67,6 +68,8 @@ def main():
             ("K4_body_quat", lambda: ctx.body_quat(qpos), (59 + 84) * W, 1),
             ("K6_zfilter", lambda: ctx.zfilter(obs, st0, st1, update=True), (115 + 115) * W, 1),
             ("K5_gae", lambda: ctx.gae(rew, msk, val, 0.95, 0.95), 5 * W, rew.shape[0] / n),
+            # K8: reads qpos 59 + qvel 58, writes qM 910 + bias 58 + xpos 63
+            ("K8_dynamics", lambda: ctx.dynamics(qpos, qvel, want_xpos=True, qM_out=qM_dyn), (59 + 58 + 910 + 58 + 63) * W, 1),
         ]
         for name, fn, bytes_per_unit, units_per_env in cases:
             if name == "K1_pd_torque":
