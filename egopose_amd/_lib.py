@@ -63,7 +63,7 @@ class MlpLayer(C.Structure):
 
 
 class EngineDesc(C.Structure):
-    _fields_ = [("n_env", C.c_int32), ("n_threads", C.c_int32), ("n_groups", C.c_int32)]
+    _fields_ = [("n_env", C.c_int32), ("n_threads", C.c_int32), ("n_groups", C.c_int32), ("device_dynamics", C.c_int32)]
 
 
 PHYS_RESET = C.CFUNCTYPE(C.c_int, vp, C.c_int32, c_dbl_p, c_dbl_p)

@@ -127,8 +127,8 @@ __device__ __forceinline__ void st_v3(double *p, V3 v) { p[0] = v.x; p[1] = v.y;
 //   E  lane = body : composite inertia / subtree force = sum over the body's contiguous (depth-first) subtree range
 //   F  lane = dof  : column of M up the ancestor chain, bias entry
 __global__ __launch_bounds__(256) void k_dynamics(const DynTables *__restrict__ tab_g, const double *__restrict__ qpos,
-                                                  const double *__restrict__ qvel, int n, int nq, double *__restrict__ qM, long ld_m,
-                                                  double *__restrict__ bias, double *__restrict__ xpos) {
+                                                  const double *__restrict__ qvel, int n, long ld_q, long ld_v, double *__restrict__ qM,
+                                                  long ld_m, double *__restrict__ bias, long ld_b, double *__restrict__ xpos) {
     __shared__ DynTables tb;
     extern __shared__ double s_env[];            // 4 x DY_ENV_DOUBLES
     {
@@ -149,8 +149,8 @@ __global__ __launch_bounds__(256) void k_dynamics(const DynTables *__restrict__ 
     double *sSq = sS + DY_MAXV * 6;                      // [nv][6]   S_d * qvel_d
     double *sIb = sSq + DY_MAXV * 6;                     // [nb][10]  own spatial inertia about the world origin
     double *sF = sIb + DY_MAXB * 10;                     // [nb][6]   body force
-    const double *q = qpos + e * nq;
-    const double *qd = qvel + e * (nq - 1);
+    const double *q = qpos + e * ld_q;
+    const double *qd = qvel + e * ld_v;
     __syncthreads();
     const int nb = tb.nb, nv = tb.nv;
     const int b = lane;
@@ -286,11 +286,23 @@ __global__ __launch_bounds__(256) void k_dynamics(const DynTables *__restrict__ 
                 i = tb.dof_parent[i];
             }
         }
-        if (bias) bias[env * nv + d] = sdot(S, fc);
+        if (bias) bias[env * ld_b + d] = sdot(S, fc);
     }
 }
 
 }  // namespace
+
+// engine entry: state rows / outputs with arbitrary row strides (doubles)
+int egp_launch_dynamics_strided(egp_ctx *ctx, const double *qpos, long ld_q, const double *qvel, long ld_v, int32_t n, double *qM,
+                                long ld_m, double *bias, long ld_b, double *xpos, hipStream_t stream) {
+    if (!ctx->dyn_tables) { egp::set_error("egp_set_dynamics_model must be called before egp_dynamics"); return EGP_E_STATE; }
+    const size_t lds = (size_t)4 * DY_ENV_DOUBLES * sizeof(double);
+    k_dynamics<<<dim3((n + 3) / 4), dim3(256), lds, stream>>>((const DynTables *)ctx->dyn_tables, qpos, qvel, n, ld_q, ld_v, qM, ld_m, bias,
+                                                              ld_b, xpos);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { egp::set_error("k_dynamics launch failed: %s", hipGetErrorString(e)); return EGP_E_HIP; }
+    return EGP_OK;
+}
 
 extern "C" {
 
@@ -377,11 +389,8 @@ int egp_dynamics_f64(egp_ctx *ctx, const double *qpos, const double *qvel, int32
     if (n == 0) return EGP_OK;
     EGP_REQUIRE(qpos && qvel, "NULL pointer");
     EGP_REQUIRE(!qM || ld_m >= ctx->dm.nM, "ld_m smaller than nM");
-    const size_t lds = (size_t)4 * DY_ENV_DOUBLES * sizeof(double);
-    k_dynamics<<<dim3((n + 3) / 4), dim3(256), lds, (hipStream_t)stream>>>((const DynTables *)ctx->dyn_tables, qpos, qvel, n, ctx->dm.nq, qM, (long)ld_m, qfrc_bias, xpos);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { egp::set_error("k_dynamics launch failed: %s", hipGetErrorString(e)); return EGP_E_HIP; }
-    return EGP_OK;
+    return egp_launch_dynamics_strided(ctx, qpos, ctx->dm.nq, qvel, ctx->dm.nv, n, qM, ld_m, qfrc_bias, ctx->dm.nv, xpos,
+                                       (hipStream_t)stream);
 }
 
 }  // extern "C"

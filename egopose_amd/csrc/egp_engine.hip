@@ -145,6 +145,8 @@ struct egp_engine {
     bool flag_poll = false;                   // leader polls a pinned completion flag instead of hipStreamSynchronize
     double *hd_state = nullptr, *hd_torque = nullptr, *hd_qM = nullptr, *hd_ee = nullptr;   // device-side aliases of h_state / h_torque / h_qM
     bool server_ok = false;                   // resident-K1 mode allowed (EGP_SERVER, block budget)
+    bool device_dynamics = false;             // K8 supplies qM / qfrc_bias from the drained (qpos, qvel) each substep
+    double *d_bias = nullptr;                 // [n_env][nv] K8's bias (device-dynamics mode)
     int spin_us = 0;                          // EGP_SPIN_US: poll this long for the next env-step before sleeping (off: measured no gain)
     double *d_state = nullptr, *d_qM = nullptr, *d_prev_qpos = nullptr, *d_qpos = nullptr, *d_qvel = nullptr, *d_torque = nullptr, *d_ee = nullptr;
     double *h_state = nullptr, *h_qM = nullptr, *h_qpos = nullptr, *h_qvel = nullptr, *h_torque = nullptr, *h_ee = nullptr,
@@ -185,8 +187,8 @@ __global__ __launch_bounds__(256) void k_engine_reset_scatter(const int *__restr
 int drain_env(egp_engine *E, int env, bool with_xpos, bool mark_dirty = true) {
     double *row = E->h_state + (size_t)env * E->ld_s;
     double *xp = with_xpos ? E->h_xpos + (size_t)env * E->nbody * 3 : nullptr;
-    double *qM = E->h_qM + (size_t)env * E->ld_m;
-    if (E->vt->inertia_epoch) {
+    double *qM = E->device_dynamics ? nullptr : E->h_qM + (size_t)env * E->ld_m;
+    if (qM && E->vt->inertia_epoch) {
         const int64_t ep = E->vt->inertia_epoch(E->vt->user, env);
         if (ep == E->epoch[env]) qM = nullptr;            // unchanged since the last drain: nothing to move
         else E->epoch[env] = ep;
@@ -229,7 +231,17 @@ void enqueue_k1(egp_engine *E, Group &G, int substep) {
     if (prof) G_HIP(hipEventRecord(G.k_beg[substep], G.stream));
     const double *st = (E->zero_copy ? E->hd_state : E->d_state) + (size_t)G.e0 * E->ld_s;
     double *tq = (E->zero_copy ? E->hd_torque : E->d_torque) + (size_t)G.e0 * E->nu;
-    int rc = egp_launch_pd_torque_strided(E->ctx, st + E->off_qpos, E->ld_s, st + E->off_qvel, E->ld_s, st + E->off_bias, E->ld_s,
+    const double *bias = st + E->off_bias;
+    long ld_bias = E->ld_s;
+    if (E->device_dynamics) {        // K8: inertia and bias force of the state just drained, straight into HBM
+        double *db = E->d_bias + (size_t)G.e0 * E->nv;
+        int rd = egp_launch_dynamics_strided(E->ctx, st + E->off_qpos, E->ld_s, st + E->off_qvel, E->ld_s, m,
+                                             E->d_qM + (size_t)G.e0 * E->ld_m, E->ld_m, db, E->nv, nullptr, G.stream);
+        if (rd != EGP_OK) fail(G, rd, "K8 launch", egp_last_error());
+        bias = db;
+        ld_bias = E->nv;
+    }
+    int rc = egp_launch_pd_torque_strided(E->ctx, st + E->off_qpos, E->ld_s, st + E->off_qvel, E->ld_s, bias, ld_bias,
                                           E->d_qM + (size_t)G.e0 * E->ld_m, E->ld_m, G.action + (size_t)G.e0 * E->nu, m, tq, G.stream,
                                           G.polled ? G.d_done : nullptr, G.hd_flag, G.polled ? ++G.seq : 0);
     if (rc != EGP_OK) fail(G, rc, "K1 launch", egp_last_error());
@@ -324,7 +336,7 @@ void run_step(egp_engine *E, Group &G, int tid) {
 }
 
 inline bool server_mode(const egp_engine *E, const Group &G) {
-    return E->server_ok && G.srv.n_slices > 0 && E->flag_poll && E->zero_copy && E->ctx->pd_variant == 0 && E->ctx->tree58;
+    return !E->device_dynamics && E->server_ok && G.srv.n_slices > 0 && E->flag_poll && E->zero_copy && E->ctx->pd_variant == 0 && E->ctx->tree58;
 }
 
 // Resident-K1 env-step: one launch of k_pd_server_tree58 serves all substeps. Every host thread owns a few slices
@@ -447,7 +459,7 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
 }
 
 inline bool pipelined_mode(const egp_engine *E, const Group &G) {
-    return G.n_chunks >= 2 && G.n_threads >= 3 && E->flag_poll && E->zero_copy && E->ctx->pd_variant == 0;
+    return !E->device_dynamics && G.n_chunks >= 2 && G.n_threads >= 3 && E->flag_poll && E->zero_copy && E->ctx->pd_variant == 0;
 }
 
 // Pipelined env-step: the group is cut into chunks, each with its own K1 launch and completion flag.
@@ -652,6 +664,12 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     E->n_env = d->n_env; E->n_threads = d->n_threads; E->n_groups = d->n_groups;
     E->nq = ctx->dm.nq; E->nv = ctx->dm.nv; E->nu = ctx->dm.nu; E->nM = ctx->dm.nM; E->nbody = ctx->dm.nbody;
     E->frame_skip = ctx->frame_skip;
+    E->device_dynamics = d->device_dynamics != 0;
+    if (E->device_dynamics && !ctx->dyn_tables) {
+        egp::set_error("device_dynamics needs egp_set_dynamics_model on the context first");
+        delete E;
+        return EGP_E_STATE;
+    }
     E->off_qpos = 0; E->off_qvel = E->nq; E->off_bias = E->nq + E->nv;
     E->ld_s = ((E->nq + 2 * E->nv + 15) / 16) * 16;
     E->ld_m = ((E->nM + 15) / 16) * 16;
@@ -669,6 +687,7 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     E_TRY(hipMalloc((void **)&E->d_qvel, N * E->nv * sizeof(double)));
     E_TRY(hipMalloc((void **)&E->d_torque, N * E->nu * sizeof(double)));
     E_TRY(hipMalloc((void **)&E->d_ee, N * 15 * sizeof(double)));
+    if (E->device_dynamics) E_TRY(hipMalloc((void **)&E->d_bias, N * E->nv * sizeof(double)));
     E_TRY(hipMemset(E->d_state, 0, N * E->ld_s * sizeof(double)));
     E_TRY(hipMemset(E->d_qM, 0, N * E->ld_m * sizeof(double)));
     E_TRY(hipHostMalloc((void **)&E->h_state, N * E->ld_s * sizeof(double), hipHostMallocDefault));
@@ -855,7 +874,7 @@ int egp_engine_destroy(egp_engine *E) {
         for (auto ev : G.k_beg) (void)hipEventDestroy(ev);
         for (auto ev : G.k_end) (void)hipEventDestroy(ev);
     }
-    void *dev[] = {E->d_state, E->d_qM, E->d_prev_qpos, E->d_qpos, E->d_qvel, E->d_torque, E->d_ee};
+    void *dev[] = {E->d_state, E->d_qM, E->d_prev_qpos, E->d_qpos, E->d_qvel, E->d_torque, E->d_ee, E->d_bias};
     for (void *p : dev) if (p) (void)hipFree(p);
     if (E->reset_done) (void)hipEventDestroy(E->reset_done);
     void *host[] = {E->h_state, E->h_qM, E->h_qpos, E->h_qvel, E->h_torque, E->h_ee, E->h_headz, E->h_xpos, E->h_reset_list};

@@ -45,7 +45,9 @@ class BatchedSim:
                               reward_weights=cfg.reward_weights, episode_len=cfg.env_episode_len,
                               frame_skip=env.frame_skip, device=device_index)
         self.physics = physics if physics is not None else SurrogatePhysics(env.skel, self.n_env)
-        self.engine = RolloutEngine(self.ctx, self.physics, self.n_env, n_threads=n_threads, n_groups=n_groups)
+        # EGP_DEVICE_DYNAMICS=1: qM / qfrc_bias of every substep from K8 on the GPU instead of the backend's drain
+        self.engine = RolloutEngine(self.ctx, self.physics, self.n_env, n_threads=n_threads, n_groups=n_groups,
+                                    device_dynamics=os.environ.get("EGP_DEVICE_DYNAMICS", "0") == "1")
         self.experts = None
         if env.expert_arr is not None:
             self.experts = ExpertSet(env.expert_arr, env.cnn_feat)

@@ -167,14 +167,17 @@ def default_threads(share=1):
 class RolloutEngine:
     """egp_engine: n_env envs advance one env-step per step_async/wait pair."""
 
-    def __init__(self, ctx, physics, n_env: int, n_threads: Optional[int] = None, n_groups: int = 1):
+    def __init__(self, ctx, physics, n_env: int, n_threads: Optional[int] = None, n_groups: int = 1, device_dynamics: bool = False):
         import torch
         self.lib = L.load()
         self.ctx, self.physics = ctx, physics
         self.n_env = int(n_env)
         n_threads = default_threads() if n_threads is None else int(n_threads)
         n_threads = max(int(n_groups), min(n_threads, self.n_env))
-        d = L.EngineDesc(self.n_env, n_threads, int(n_groups))
+        if device_dynamics and not getattr(ctx, "_has_dynamics", False):
+            ctx.set_dynamics_model()
+        d = L.EngineDesc(self.n_env, n_threads, int(n_groups), 1 if device_dynamics else 0)
+        self.device_dynamics = bool(device_dynamics)
         h = C.c_void_p()
         L.check(self.lib.egp_engine_create(ctx.handle, physics.handle, C.byref(d), C.byref(h)), "egp_engine_create")
         self.handle = h

@@ -303,6 +303,9 @@ typedef struct egp_engine_desc {
     int32_t n_env;
     int32_t n_threads;       /* host physics worker threads (reference: --num-threads samplers) */
     int32_t n_groups;        /* env groups that can be stepped independently (policy/physics overlap) */
+    int32_t device_dynamics; /* 1: qM and qfrc_bias of every substep come from K8 (egp_set_dynamics_model must have been
+                              * called) instead of the backend's drain -- `drain` is then always called with qM == NULL and its
+                              * qfrc_bias is ignored; M and C belong to the CURRENT state (mj_step's are one step stale) */
 } egp_engine_desc;
 
 int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *desc, egp_engine **out);
