@@ -277,21 +277,21 @@ class VideoStateNet(nn.Module):
         return torch.cat((ctx.index_select(0, self.gather_indices), x), dim=1)
 
 
-class VideoRegNet(nn.Module):
-    """State regressor over precomputed CNN features -- the `no_cnn=True` form of models/video_reg_net.py:10-59 that
-    the evaluation drivers load (ego_pose/ego_mimic_eval.py:71-80): temporal net -> MLP (relu) -> Linear.
-    x: (T, B, cnn_fdim) -> (T*B, out_dim). The image encoder (ResNet-18 / MobileNet, `no_cnn=False`) belongs to the
-    state_reg training path, which is outside this build."""
+class VideoRegNet(nn.Module):          # (ResNet is defined further down; resolved at construction time)
+    """State regressor of models/video_reg_net.py:10-59: [ResNet-18 per frame ->] temporal net -> MLP (relu) -> Linear.
+    `no_cnn=True` (what the evaluation drivers load, ego_pose/ego_mimic_eval.py:71-80) takes precomputed features
+    x: (T, B, cnn_fdim); with the encoder x: (T, B, 3, H, W). Output (T*B, out_dim)."""
 
     def __init__(self, out_dim, v_hdim, cnn_fdim, no_cnn=True, frame_shape=(3, 224, 224), mlp_dim=(300, 200),
                  cnn_type="resnet", v_net_type="lstm", v_net_param=None, causal=False):
         super().__init__()
-        if not no_cnn:
-            raise NotImplementedError("the image encoder of VideoRegNet is not part of this build (use no_cnn=True)")
+        if not no_cnn and cnn_type != "resnet":
+            raise NotImplementedError("only the 'resnet' image encoder is implemented (mobile net is out of scope)")
         if v_net_type != "lstm":
             raise NotImplementedError("only the 'lstm' video net is implemented (tcn is out of scope)")
-        self.out_dim, self.cnn_fdim, self.v_hdim, self.no_cnn = out_dim, cnn_fdim, v_hdim, True
-        self.cnn = None
+        self.out_dim, self.cnn_fdim, self.v_hdim, self.no_cnn = out_dim, cnn_fdim, v_hdim, no_cnn
+        self.frame_shape = tuple(frame_shape)
+        self.cnn = None if no_cnn else ResNet(cnn_fdim)
         self.v_net_type = v_net_type
         self.v_net = RNN(cnn_fdim, v_hdim, v_net_type, bi_dir=not causal)
         self.mlp = MLP(v_hdim, mlp_dim, "relu")
@@ -301,8 +301,13 @@ class VideoRegNet(nn.Module):
         return self.v_net(x)
 
     def forward(self, x):
+        if self.cnn is not None:        # x: (T, B, 3, H, W) optical-flow frames -> per-frame features
+            x = self.cnn(x.reshape((-1,) + self.frame_shape)).view(-1, x.size(1), self.cnn_fdim)
         x = self.forward_v_net(x).reshape(-1, self.v_hdim)
         return self.linear(self.mlp(x))
+
+    def get_cnn_feature(self, x):
+        return self.cnn(x.reshape((-1,) + self.frame_shape))
 
 
 class VideoForecastNet(nn.Module):
@@ -423,3 +428,62 @@ class VideoForecastNet(nn.Module):
         else:
             s_out = x
         return torch.cat((v_out, s_out), dim=1)
+
+
+# ---------------------------------------------------------------------- image encoder of the state regressor
+class _BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = torch.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return torch.relu(out + idt)
+
+
+class ResNet18(nn.Module):
+    """The published ResNet-18 (He et al. 2016; basic blocks [2, 2, 2, 2], 64-128-256-512 channels) with the module and
+    parameter names of torchvision's `resnet18`, so a torchvision state dict loads unchanged; `fc` -> out_dim as
+    models/resnet.py:12-17 does. torchvision is not in this image, so no pretrained weights are fetched here."""
+
+    def __init__(self, out_dim):
+        super().__init__()
+        self.out_dim = out_dim
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        chans, layers, cin = (64, 128, 256, 512), [], 64
+        for i, c in enumerate(chans):
+            layers.append(nn.Sequential(_BasicBlock(cin, c, 1 if i == 0 else 2), _BasicBlock(c, c, 1)))
+            cin = c
+        self.layer1, self.layer2, self.layer3, self.layer4 = layers
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512, out_dim)
+
+    def forward(self, x):
+        x = self.maxpool(torch.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+class ResNet(nn.Module):
+    """models/resnet.py:6-18: `self.resnet` = ResNet-18 whose fc maps to `out_dim`."""
+
+    def __init__(self, out_dim, fix_params=False):
+        super().__init__()
+        self.out_dim = out_dim
+        self.resnet = ResNet18(out_dim)
+        if fix_params:
+            for name, p in self.resnet.named_parameters():
+                p.requires_grad = name.startswith("fc.")
+
+    def forward(self, x):
+        return self.resnet(x)

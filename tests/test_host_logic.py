@@ -228,4 +228,69 @@ def test_eval_metrics_and_helpers_match_reference():
         y = net(torch.as_tensor(e["sn_x"])).numpy()
     np.testing.assert_allclose(y, e["sn_y"], rtol=1e-10, atol=1e-12)
     with pytest.raises(NotImplementedError):
-        VideoRegNet(9, 32, 16, no_cnn=False)
+        VideoRegNet(9, 32, 16, no_cnn=False, cnn_type="mobile")
+
+
+def test_statereg_dataset_config_and_nets(tmp_path, monkeypatch):
+    """state_reg data path == ego_pose/utils/statereg_dataset.py on the same files (normalised trajectories, chunking with
+    overlap, take order, frame offsets); config loads; ResNet-18 has torchvision's parameter set; one CPU training step."""
+    from egopose_amd import statereg as SR
+    from egopose_amd.nets import ResNet18
+    g = load_golden("statereg_dataset.npz")
+    monkeypatch.chdir(tmp_path)
+    names = ["tk_a", "tk_b", "tk_c"]
+    for d in ("datasets/traj", "datasets/fpv_of", "datasets/meta"):
+        os.makedirs(d)
+    msync = {n: [int(v) for v in g["msync"][i]] for i, n in enumerate(names)}
+    for i, n in enumerate(names):
+        tr = g["traj_" + n]
+        with open("datasets/traj/%s_traj.p" % n, "wb") as f:
+            np.save(f, tr)
+        os.makedirs("datasets/fpv_of/%s" % n)
+        for k in range(tr.shape[0] + msync[n][0] + 2):
+            np.save("datasets/fpv_of/%s/%05d.npy" % (n, k), np.full((2, 2, 2), float(k) + 1000 * i))
+    yaml.safe_dump({"train": ["tk_a", "tk_b"], "test": ["tk_c"], "video_mocap_sync": msync, "capture": {"fps": 30}},
+                   open("datasets/meta/meta_sr_test.yml", "w"))
+    ds = SR.Dataset("meta_sr_test", "train", 16, "iter", False, 6, 100)
+    assert ds.traj_dim == int(g["traj_dim"]) and ds.len == int(g["length"])
+    np.testing.assert_allclose(ds.mean, g["mean"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(ds.std, g["std"], rtol=1e-10, atol=1e-12)
+    of_ids, norm, orig, lens = [], [], [], []
+    for of, nt, ot in ds:
+        of_ids.append(of[:, 0, 0, 0]); norm.append(nt); orig.append(ot); lens.append(len(of))
+    assert lens == list(g["chunk_len"]) and len(lens) == int(g["n_chunks"])
+    np.testing.assert_array_equal(np.concatenate(of_ids), g["of_ids"])
+    # (columns with ~zero spread -- the zeroed wrist joints -- divide rounding noise by std + 1e-8)
+    np.testing.assert_allclose(np.vstack(norm), g["norm"], rtol=1e-9, atol=1e-6)
+    np.testing.assert_array_equal(np.vstack(orig), g["orig"])
+    dt_ = SR.Dataset("meta_sr_test", "test", 16, "iter", False, 6, 100)
+    dt_.set_mean_std(ds.mean, ds.std)
+    np.testing.assert_allclose(np.vstack([nt for _, nt, _ in dt_]), g["test_norm"], rtol=1e-9, atol=1e-6)
+    # the packaged config and the published parameter count of ResNet-18 without its classifier
+    cfg = SR.StateRegConfig("subject_03")
+    assert (cfg.fr_num, cfg.v_hdim, cfg.cnn_fdim, cfg.fr_margin, cfg.cnn_type) == (120, 128, 128, 10, "resnet")
+    rn = ResNet18(128)
+    assert sum(p.numel() for n_, p in rn.named_parameters() if not n_.startswith("fc.")) == 11176512
+    assert {"conv1.weight", "layer1.0.conv1.weight", "layer2.0.downsample.0.weight", "layer4.1.bn2.bias", "fc.weight"} <= set(dict(rn.named_parameters()))
+    # integrating a regressor output that equals the ground truth reproduces height, joints and (to first order) the path
+    traj = ds.orig_trajs[0][3:40]
+    sp = ds.trajs[0][3:40]
+    rec = SR.get_traj_from_state_pred(sp, traj[0, :2], SR.M._heading_q(traj[0, 3:7]), ds.dt, ds.traj_dim)
+    np.testing.assert_allclose(rec[:, 2], traj[:, 2], atol=1e-12)
+    np.testing.assert_allclose(rec[:, 7:], traj[:, 7:], atol=1e-12)
+    assert np.abs(rec[:, :2] - traj[:, :2]).max() < 0.02 and np.abs(np.abs((rec[:, 3:7] * traj[:, 3:7]).sum(1)) - 1).max() < 1e-3
+    # one optimisation step on the CPU with a tiny frame size
+    cfg.fr_margin, cfg.mlp_dim, cfg.v_hdim, cfg.cnn_fdim = 3, [16, 8], 16, 8
+    for n in names[:2]:
+        for k in range(g["traj_" + n].shape[0] + msync[n][0] + 2):
+            np.save("datasets/fpv_of/%s/%05d.npy" % (n, k), np.random.RandomState(k).normal(size=(32, 32, 2)))
+    ds2 = SR.Dataset("meta_sr_test", "train", 16, "iter", False, 6, 100)
+    tr = SR.StateRegTrainer(cfg, ds2, "cpu", torch.float32, frame_shape=(3, 32, 32))
+    before = tr.net.cnn.resnet.conv1.weight.detach().clone()
+    loss, n_s, _ = tr.train_epoch()
+    assert np.isfinite(loss) and n_s > 0 and not torch.equal(before, tr.net.cnn.resnet.conv1.weight)
+    res, meta = tr.test()
+    assert set(res["traj_pred"]) == {"tk_a", "tk_b"} and res["traj_pred"]["tk_a"].shape[1] == 59 and meta["algo"] == "state_reg"
+    tr.save(str(tmp_path / "inf.p"), inference=True)
+    cp, m2 = pickle.load(open(tmp_path / "inf.p", "rb"))
+    assert "cfg" in m2 and not any(k.startswith("cnn.") for k in cp["state_net_dict"])

@@ -79,3 +79,29 @@ def test_hip_lstm_hidden128_matches_lstmcell_loop(T, B, D):
         g = getattr(ref_cell, name).grad.numpy()
         scale = max(1.0, np.abs(g).max())
         np.testing.assert_allclose(p.grad.cpu().numpy() / scale, g / scale, rtol=0, atol=5e-5, err_msg=name)
+
+
+def test_statereg_training_step_on_gpu():
+    """VideoRegNet with the ResNet-18 encoder: one fp32 and one bf16-autocast optimisation step on the device (MIOpen
+    convolutions + the persistent HIP LSTM), losses finite, every parameter group moves."""
+    from egopose_amd.nets import VideoRegNet
+    torch.manual_seed(2)
+    for ac in (None, torch.bfloat16):
+        net = VideoRegNet(115, 128, 128, no_cnn=False, frame_shape=(3, 64, 64)).cuda()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        x = torch.randn(24, 1, 3, 64, 64, device="cuda")
+        gt = torch.randn(24, 115, device="cuda")
+        probes = {n: p.detach().clone() for n, p in net.named_parameters() if n in ("cnn.resnet.conv1.weight", "v_net.rnn_f.weight_hh", "linear.weight")}
+        if ac is None:
+            pred = net(x)
+        else:
+            with torch.autocast("cuda", dtype=ac):
+                pred = net(x).float()
+        loss = (gt - pred).pow(2).sum(1).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        assert pred.shape == (24, 115) and np.isfinite(float(loss))
+        for n, p in net.named_parameters():
+            if n in probes:
+                assert not torch.equal(p, probes[n]), n

@@ -586,6 +586,39 @@ def main():
              masks=masks_f.numpy(), v_metas=v_metas_f, states=states_f.numpy(), train_out=f_train_out, indices=fn.indices,
              dims=np.array([cdim, sdim, vh, sh, margin]), **{"sd_" + k: v for k, v in fsd.items()})
 
+    # ------------------------------------------------------------------ G18 state_reg dataset (normalised trajectories, iteration order)
+    from ego_pose.utils.statereg_dataset import Dataset as RDataset
+    rng4 = np.random.RandomState(123)
+    os.makedirs("datasets/traj", exist_ok=True)
+    os.makedirs("datasets/fpv_of", exist_ok=True)
+    takes = {"tk_a": 46, "tk_b": 38, "tk_c": 33}
+    msync = {}
+    sr_traj = {}
+    for name, L in takes.items():
+        tr = synth_qpos(rng4, sk, L, joint_scale=0.2)
+        tr[:, :3] = np.cumsum(rng4.normal(size=(L, 3)) * 0.01, axis=0) + [0, 0, 0.9]
+        with open("datasets/traj/%s_traj.p" % name, "wb") as f:
+            np.save(f, tr)
+        sr_traj[name] = tr
+        off = int(rng4.randint(0, 4))
+        msync[name] = [off, 2, L - 1]
+        os.makedirs("datasets/fpv_of/%s" % name, exist_ok=True)
+        for i in range(L + off + 2):
+            np.save("datasets/fpv_of/%s/%05d.npy" % (name, i), np.full((2, 2, 2), float(i) + 1000 * list(takes).index(name)))
+    with open("datasets/meta/meta_sr_test.yml", "w") as f:
+        yaml.safe_dump({"train": ["tk_a", "tk_b"], "test": ["tk_c"], "video_mocap_sync": msync, "capture": {"fps": 30}}, f)
+    ds = RDataset("meta_sr_test", "train", 16, "iter", False, 2 * 3, 100)
+    it_of, it_nt, it_ot = [], [], []
+    for of, nt, ot in ds:
+        it_of.append(of[:, 0, 0, 0].copy()); it_nt.append(nt.copy()); it_ot.append(ot.copy())
+    ds_t = RDataset("meta_sr_test", "test", 16, "iter", False, 6, 100)
+    ds_t.set_mean_std(ds.mean, ds.std)
+    t_nt = [nt.copy() for _, nt, _ in ds_t]
+    np.savez(os.path.join(OUT, "statereg_dataset.npz"), mean=ds.mean, std=ds.std, traj_dim=ds.traj_dim, length=ds.len,
+             n_chunks=len(it_of), of_ids=np.concatenate(it_of), chunk_len=np.array([len(x) for x in it_of]),
+             norm=np.vstack(it_nt), orig=np.vstack(it_ot), test_norm=np.vstack(t_nt),
+             msync=np.array([msync[k] for k in takes]), **{"traj_" + k: v for k, v in sr_traj.items()})
+
     os.chdir(REPO)
     shutil.rmtree(wd, ignore_errors=True)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Re-serialise the reference's egomimic / egoforecast YAML configs (data, not code) into egopose_amd/assets/config/.
+"""Re-serialise the reference's egomimic / egoforecast / statereg YAML configs (data, not code) into egopose_amd/assets/config/.
 Run in the build container only."""
 import os, sys, yaml
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for task in ("egomimic", "egoforecast"):
+for task in ("egomimic", "egoforecast", "statereg"):
     src = "/root/reference/config/%s" % task
     dst = os.path.join(REPO, "egopose_amd", "assets", "config", task)
     os.makedirs(dst, exist_ok=True)
