@@ -24,6 +24,11 @@ import os
 from . import dist as _dist
 from . import lstm as _hip_lstm
 
+# Length buckets of the train-mode forward LSTM (1 = off, the default: measured SLOWER on the MI355X -- the persistent
+# LSTM kernel is bound by its per-timestep latency, not by the batch, so four short launches in a row cost more than
+# one long one; kept for throughput-bound shapes). Running the two directions on two HIP streams was also tried: no
+# gain in the update, and an intermittent stall next to the resident K1 streams -- removed.
+_FWD_BUCKETS = int(os.environ.get("EGP_FWD_BUCKETS", "1"))
 _LSTM_IMPL = os.environ.get("EGP_LSTM", "hip")      # "torch" forces the MIOpen / cell-loop paths (A/B runs)
 
 _ACT = {"tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid}
@@ -210,6 +215,7 @@ class VideoStateNet(nn.Module):
         self.indices = None
         self.gather_indices = None
         self.cnn_feat_ctx = None
+        self._buckets = None
         self._cnn_table = None   # optional (device table, take offsets) installed by the env
 
     def set_mode(self, mode):
@@ -265,6 +271,35 @@ class VideoStateNet(nn.Module):
                 ctx[:, e, :] = cnn_feat[int(ei)][int(si) - m: int(si) + max_len + m]
             self.cnn_feat_ctx = torch.as_tensor(ctx, dtype=dtype, device=device)
         self.gather_indices = torch.as_tensor(idx, dtype=torch.long, device=device)
+        # Length buckets for the forward direction: its output at frame t only depends on frames <= t and only frames
+        # [m, m + len_e) of an episode are ever gathered, so episodes sorted by length let the forward LSTM stop early
+        # (the backward direction starts at the end of the padded window and must run it all, as in the reference).
+        self._buckets = None
+        n_ep = len(ends)
+        if _FWD_BUCKETS > 1 and n_ep >= 4 * _FWD_BUCKETS and self.v_net_type == "lstm":
+            order = np.argsort(-lens, kind="stable")
+            rank = np.empty(n_ep, np.int64)
+            rank[order] = np.arange(n_ep)
+            idx_s = np.arange(n)
+            idx_s[:covered] = rank[ep_of] * max_len + (np.arange(covered) - np.repeat(starts, lens))
+            self._gather_sorted = torch.as_tensor(idx_s, dtype=torch.long, device=device)
+            self._ctx_sorted = self.cnn_feat_ctx.index_select(1, torch.as_tensor(order, device=device))
+            cuts = [n_ep * k // _FWD_BUCKETS for k in range(_FWD_BUCKETS + 1)]
+            lens_sorted = lens[order]
+            self._buckets = [(cuts[k], cuts[k + 1], int(m + lens_sorted[cuts[k]])) for k in range(_FWD_BUCKETS)]
+
+    def _bucketed_context(self):
+        """(T - 2m, n_ep sorted by length, v_hdim): backward direction over the full window, forward direction per length bucket."""
+        ctx, rnn = self._ctx_sorted, self.v_net
+        T, B, _ = ctx.shape
+        Hd = rnn.rnn_f.hidden_size
+        out_f = ctx.new_zeros(T, B, Hd)
+        for i0, i1, Tb in self._buckets:
+            Tb = min(Tb, T)
+            out_f[:Tb, i0:i1] = rnn._sweep(rnn.rnn_f, ctx[:Tb, i0:i1], False)
+        if not rnn.bi_dir:
+            return out_f
+        return torch.cat((out_f, rnn._sweep(rnn.rnn_b, ctx, True)), 2)
 
     def forward(self, x):
         if self.mode == "test":
@@ -272,6 +307,9 @@ class VideoStateNet(nn.Module):
             self.t += 1
             return out
         m = self.v_margin
+        if self._buckets is not None:
+            ctx = self._bucketed_context()[m:-m].transpose(0, 1).reshape(-1, self.v_hdim)
+            return torch.cat((ctx.index_select(0, self._gather_sorted), x), dim=1)
         ctx = self.forward_v_net(self.cnn_feat_ctx)[m:-m]
         ctx = ctx.transpose(0, 1).reshape(-1, self.v_hdim)
         return torch.cat((ctx.index_select(0, self.gather_indices), x), dim=1)

@@ -128,3 +128,39 @@ def test_forecast_config_and_net_match_reference():
         net.attach_feature_table(table, [0, g["cnn_feat0"].shape[0]])
         net.initialize((masks, None, g["v_metas"]))
         np.testing.assert_allclose(net(torch.as_tensor(g["states"])).numpy(), g["train_out"], rtol=1e-10, atol=1e-12)
+
+
+def test_length_bucketed_forward_lstm_is_exact(monkeypatch):
+    """Train-mode VideoStateNet with the forward direction run per length bucket == the plain full-window forward:
+    outputs and all parameter gradients (float64, CPU)."""
+    import egopose_amd.nets as nets
+    from egopose_amd.nets import VideoStateNet
+    rng = np.random.RandomState(5)
+    torch.manual_seed(5)
+    cdim, hdim, margin, T_ep = 6, 8, 3, 14
+    cnn_feat = [rng.normal(size=(70, cdim)), rng.normal(size=(55, cdim))]
+    lens = [14, 2, 9, 14, 1, 7, 3, 3, 11, 5, 14, 6, 2, 8, 1, 4, 12, 10, 2, 13]
+    masks, metas = [], []
+    for L in lens:
+        e = int(rng.randint(2))
+        s = int(rng.randint(margin, cnn_feat[e].shape[0] - T_ep - margin))
+        masks += [1.0] * (L - 1) + [0.0]
+        metas += [[e, s]] * L
+    masks, metas = torch.tensor(masks, dtype=torch.float64), np.array(metas)
+    states = torch.tensor(rng.normal(size=(len(masks), 5)))
+    w = torch.tensor(rng.normal(size=(len(masks), hdim + 5)))
+    outs, grads = [], []
+    for buckets in (1, 4):
+        monkeypatch.setattr(nets, "_FWD_BUCKETS", buckets)
+        torch.manual_seed(9)
+        vs = VideoStateNet(cdim, hdim, margin, "lstm", None, False).double()
+        vs.set_mode("train")
+        vs.initialize((masks, cnn_feat, metas))
+        assert (vs._buckets is not None) == (buckets > 1)
+        out = vs(states)
+        (out * w).sum().backward()
+        outs.append(out.detach().numpy())
+        grads.append({n: p.grad.numpy().copy() for n, p in vs.named_parameters()})
+    np.testing.assert_allclose(outs[1], outs[0], rtol=1e-12, atol=1e-13)
+    for n in grads[0]:
+        np.testing.assert_allclose(grads[1][n], grads[0][n], rtol=1e-10, atol=1e-12, err_msg=n)
