@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egopose_amd.nets import VideoRegNet
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+# (torch.backends.cudnn.benchmark = True -- MIOpen's exhaustive search -- was tried: six minutes of tuning, same step time)
 dev = torch.device("cuda")
 torch.manual_seed(0)
 for name, ac in (("fp32", None), ("bf16 autocast", torch.bfloat16)):
