@@ -34,8 +34,8 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd(const float *__restrict__ g
                                                      int reverse, float *__restrict__ h_out, float *__restrict__ gates_out,
                                                      float *__restrict__ c_out) {
     constexpr int LG = 4 * LH, NT = 4 * LH;
-    constexpr int NP = TILE * LH / NT;              // (row, unit) pairs per thread in the pointwise phase
-    static_assert(NP >= 1 && LH % KC == 0, "tile / hidden size");
+    constexpr int NP = (TILE * LH + NT - 1) / NT;   // (row, unit) pairs per thread in the pointwise phase
+    static_assert(LH % KC == 0, "hidden size");
     __shared__ __attribute__((aligned(16))) float s_h[2][TILE][LH];   // ping-pong: written for step+1 while step reads
     __shared__ float s_g[2][TILE][LG + 1];
     const int c = threadIdx.x;
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd(const float *__restrict__ g
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int p = threadIdx.x + NT * q, r = p / LH, j = p % LH;
+            if (TILE * LH < NT && p >= TILE * LH) continue;          // tiles smaller than the workgroup (TILE < 4)
             const float *sg = &s_g[step & 1][r][0];
             const float ig = sigmoidf_(sg[j]), fg = sigmoidf_(sg[LH + j]);
             const float gg = tanhf_(sg[2 * LH + j]), og = sigmoidf_(sg[3 * LH + j]);
@@ -121,7 +122,8 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd(const float *__restrict__ d
                                                   const float *__restrict__ cells, const float *__restrict__ w_hh, int T, int B,
                                                   int reverse, float *__restrict__ dpre) {
     constexpr int LG = 4 * LH, NT = 4 * LH;
-    constexpr int NP = TILE * LH / NT;
+    constexpr int NP = (TILE * LH + NT - 1) / NT;
+    constexpr bool PARTIAL = TILE * LH < NT;        // fewer (row, unit) pairs than threads
     __shared__ __attribute__((aligned(16))) float s_d[TILE][LG];        // d(pre-activation gates) of this step
     __shared__ float s_part[4][TILE][LH + 1];
     const int q = threadIdx.x / LH, k = threadIdx.x % LH;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd(const float *__restrict__ d
         const int f_tp = reverse ? f_t + 1 : f_t - 1;                                                \
         _Pragma("unroll") for (int qq = 0; qq < NP; ++qq) {                                          \
             const int p = threadIdx.x + NT * qq, r = p / LH, j = p % LH;                             \
-            if (r0 + r < B) {                                                                        \
+            if ((!PARTIAL || p < TILE * LH) && r0 + r < B) {                                         \
                 const long row = (long)f_t * B + r0 + r;                                             \
                 const float *g = gates + row * LG;                                                   \
                 pg[qq][0] = g[j]; pg[qq][1] = g[LH + j]; pg[qq][2] = g[2 * LH + j]; pg[qq][3] = g[3 * LH + j]; \
@@ -161,6 +163,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd(const float *__restrict__ d
 #pragma unroll
         for (int qq = 0; qq < NP; ++qq) {
             const int p = threadIdx.x + NT * qq, r = p / LH, j = p % LH;
+            if (PARTIAL && p >= TILE * LH) continue;
             const float ig = pg[qq][0], fg = pg[qq][1], gg = pg[qq][2], og = pg[qq][3];
             const float tc = tanhf_(pc[qq]);
             const float dh = pdh[qq] + dh_rec[qq];
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd(const float *__restrict__ d
 #pragma unroll
         for (int qq = 0; qq < NP; ++qq) {
             const int p = threadIdx.x + NT * qq, r = p / LH, j = p % LH;
+            if (PARTIAL && p >= TILE * LH) continue;
             dh_rec[qq] = s_part[0][r][j] + s_part[1][r][j] + s_part[2][r][j] + s_part[3][r][j];
         }
         __syncthreads();
@@ -217,7 +221,7 @@ using namespace egp;
 // sequences per workgroup: small tiles put several workgroups on a CU so their LDS / barrier latencies overlap
 static int lstm_tile(int B) {
     const char *e = getenv("EGP_LSTM_TILE");
-    if (e) { const int t = atoi(e); if (t == 4 || t == 8 || t == 16) return t; }
+    if (e) { const int t = atoi(e); if (t == 2 || t == 4 || t == 8 || t == 16) return t; }
     return B >= 16384 ? 16 : (B >= 8192 ? 8 : 4);
 }
 
@@ -237,8 +241,10 @@ static void launch_fwd(int tile, const float *gates_x, const float *w_hh, int T,
         k_lstm_fwd<16, LH><<<dim3((B + 15) / 16), dim3(4 * LH), 0, s>>>(gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save);
     else if (tile == 8)
         k_lstm_fwd<8, LH><<<dim3((B + 7) / 8), dim3(4 * LH), 0, s>>>(gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save);
-    else
+    else if (tile == 4)
         k_lstm_fwd<4, LH><<<dim3((B + 3) / 4), dim3(4 * LH), 0, s>>>(gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save);
+    else
+        k_lstm_fwd<2, LH><<<dim3((B + 1) / 2), dim3(4 * LH), 0, s>>>(gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save);
 }
 
 template <int LH>
@@ -248,8 +254,10 @@ static void launch_bwd(int tile, const float *dh_out, const float *gates_save, c
         k_lstm_bwd<16, LH><<<dim3((B + 15) / 16), dim3(4 * LH), 0, s>>>(dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre);
     else if (tile == 8)
         k_lstm_bwd<8, LH><<<dim3((B + 7) / 8), dim3(4 * LH), 0, s>>>(dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre);
-    else
+    else if (tile == 4)
         k_lstm_bwd<4, LH><<<dim3((B + 3) / 4), dim3(4 * LH), 0, s>>>(dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre);
+    else
+        k_lstm_bwd<2, LH><<<dim3((B + 1) / 2), dim3(4 * LH), 0, s>>>(dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre);
 }
 
 extern "C" {
