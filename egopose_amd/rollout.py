@@ -17,12 +17,14 @@ merges instead of sample-by-sample inside worker 0 only.
 from __future__ import annotations
 
 import math
+import ctypes
 import os
 import time
 
 import numpy as np
 import torch
 
+from . import _lib
 from . import policy_step
 from .rl_core import LoggerRL, TrajBatchEgo
 
@@ -113,6 +115,7 @@ class LockstepRollout:
         self.use_fused = os.environ.get("EGP_POLICY_FUSED", "1") != "0"     # HIP policy step (float32 PolicyGaussian over an MLP)
         self._fused = None
         self._s_hc = None
+        self._fast_bufs = None              # pinned per-tick flag / index slots of the fast tick path
         self._graphs = None                 # per group: captured hipGraph of the policy step
         self._graph_key = None
         self.pool_batch = max(256, self.N // 2)
@@ -382,6 +385,125 @@ class LockstepRollout:
             tm["post"] += t2 - t1
             tm["reset"] += t3 - t2
 
+        # ---- fast tick: the same per-tick work with no torch views, no uploads and one ctypes call per kernel.
+        # The integer flags / context row indices of a tick live in pinned buffers the kernels read in place (two slots
+        # per group: a slot is reused two ticks later, after the env-step that was ordered behind its readers), every
+        # tensor argument is a precomputed address, and the fused policy kernel reads rec.states[k] / writes
+        # rec.actions[k] directly.
+        fast = (self._fused is not None and plain_noise and not self.forecast and os.environ.get("EGP_FAST_TICK", "1") != "0")
+        if fast:
+            lib, hnd = ctx.lib, ctx.handle
+            vp = ctypes.c_void_p
+            P = {k: v.data_ptr() for k, v in rec.items()}
+            qpos_p, qvel_p, prev_p, ee_p = eng.qpos.data_ptr(), eng.qvel.data_ptr(), eng.prev_qpos.data_ptr(), eng.ee_wpos.data_ptr()
+            zf_p = [b_.data_ptr() for b_ in self._zf_bufs] if self.zf_state is not None else None
+            ws = ctx._workspace("zf", ctx.lib.egp_zfilter_workspace_bytes(max(b - a for a, b in self.groups), od), dev)
+            ws_p = ws.data_ptr()
+            v_out_p, v_stride = self.v_out.data_ptr(), self.v_out.stride(0)
+            fz = self._fused
+            if self._fast_bufs is None or self._fast_bufs[0].shape[2] != max(b - a for a, b in self.groups):
+                nmax = max(b - a for a, b in self.groups)
+                self._fast_bufs = (torch.zeros(len(self.groups), 2, nmax * 4, dtype=torch.int32).pin_memory(),
+                                   torch.zeros(len(self.groups), 2, nmax, dtype=torch.int64).pin_memory(),
+                                   [torch.zeros(b - a, nu, dtype=torch.float32, device=dev) for a, b in self.groups])
+            fl_t, ti_t, noise_t = self._fast_bufs
+            fl_np, ti_np = fl_t.numpy(), ti_t.numpy()
+            fl_p, ti_p = fl_t.data_ptr(), ti_t.data_ptr()          # pinned memory: same address on the device (unified addressing)
+            end_r = float(end_reward)
+            zclip = float(self.zf_clip) if self.zf_state is not None else 0.0
+            act_i32 = np.ones(N, np.int32)
+
+        def pre_fast(g):
+            a, b = self.groups[g]
+            n = b - a
+            t0 = time.time()
+            k = tick[g]
+            slot = k & 1
+            ti = ti_np[g, slot, :n]
+            np.minimum(self.cur_t[a:b], self.ctx_T - 1, out=ti)
+            nz = noise_t[g]
+            nz.normal_()
+            rc = lib.egp_policy_gaussian_f32(v_out_p + a * v_stride * 4, v_stride, H, ti_p + ((g * 2 + slot) * ti_np.shape[2]) * 8,
+                                             P["states"] + (k * N + a) * od * 8, od, n, fz.desc, len(fz.layers), fz.act,
+                                             fz.log_std.data_ptr(), nz.data_ptr(), P["actions"] + (k * N + a) * nu * 8, None,
+                                             _lib.current_stream())
+            if rc != 0:
+                _lib.check(rc, "egp_policy_gaussian_f32")
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events[g] = ev
+            np.copyto(act_i32, active, casting="unsafe")
+            rc = eng.lib.egp_engine_step_async(eng.handle, g, P["actions"] + k * N * nu * 8, act_i32.ctypes.data, ev.cuda_event)
+            if rc != 0:
+                _lib.check(rc, "egp_engine_step_async")
+            tm["policy"] += time.time() - t0
+
+        def post_fast(g):
+            a, b = self.groups[g]
+            n = b - a
+            t0 = time.time()
+            rc = eng.lib.egp_engine_wait(eng.handle, g, _lib.current_stream())
+            if rc != 0:
+                _lib.check(rc, "egp_engine_wait")
+            t1 = time.time()
+            k = tick[g]
+            slot = k & 1
+            act_g = active[a:b]
+            self.cur_t[a:b] += act_g
+            ct = self.cur_t[a:b]
+            head_z = eng.head_z[a:b]
+            if self.env.fix_head_lb is not None:
+                fail = head_z < self.env.fix_head_lb
+            else:
+                fail = head_z < lb[self.e_ind[a:b]] - 0.1
+            end = ct >= (T_ep if self.env.fix_len is None else self.env.fix_len)
+            done = (fail | end) & act_g
+            fl = fl_np[g, slot, :4 * n].reshape(4, n)
+            fl[0] = ct
+            fl[1] = self.frame_base[a:b] + ct
+            fl[2] = end & act_g
+            fl[3] = act_g
+            host["valid"][k, a:b], host["done"][k, a:b] = act_g, done
+            host["e_ind"][k, a:b], host["s_ind"][k, a:b] = self.e_ind[a:b], self.s_ind[a:b]
+            fbase = fl_p + ((g * 2 + slot) * fl_np.shape[2]) * 4
+            if zf_p is not None:                 # same ping-pong as _obs_filter
+                new_t, new, cur = self._zf_bufs[self._zf_flip], zf_p[self._zf_flip], self.zf_state.data_ptr()
+                self._zf_flip ^= 1
+            else:                                # raw observations (no running_state)
+                new_t, new, cur = None, None, None
+            rc = lib.egp_obs_zfilter_f64(hnd, qpos_p + a * ctx.nq * 8, qvel_p + a * ctx.nv * 8, fbase + 3 * n * 4, n, cur, new, zclip,
+                                         P["next_states"] + (k * N + a) * od * 8, P["states"] + ((k + 1) * N + a) * od * 8, 0, ws_p,
+                                         _lib.current_stream())
+            if rc != 0:
+                _lib.check(rc, "egp_obs_zfilter")
+            if new_t is not None:
+                self.zf_state = new_t
+            rc = lib.egp_reward_quat_v3_f64(hnd, qpos_p + a * ctx.nq * 8, prev_p + a * ctx.nq * 8, ee_p + a * 15 * 8, fbase, fbase + n * 4,
+                                            fbase + 2 * n * 4, fbase + 3 * n * 4, end_r, n, P["rewards"] + (k * N + a) * 8,
+                                            P["cinfo"] + (k * N + a) * 5 * 8, _lib.current_stream())
+            if rc != 0:
+                _lib.check(rc, "egp_reward_quat_v3")
+            steps_done[a:b] += act_g
+            t2 = time.time()
+            if done.any():
+                ids = np.nonzero(done)[0] + a
+                ep_lens.extend(self.cur_t[ids].tolist())
+                finished = steps_done[ids] >= quota
+                active[ids[finished]] = False
+                again = ids[~finished]
+                if len(again):
+                    self._reset_slots(again)
+                    mask = np.zeros(b - a, np.int32)
+                    mask[again - a] = 1
+                    self._obs_filter(a, b, rec["states"][k + 1, a:b], active=self.up(mask).to(torch.int32), write_only_active=True)
+            tick[g] = k + 1
+            t3 = time.time()
+            tm["wait"] += t1 - t0
+            tm["post"] += t2 - t1
+            tm["reset"] += t3 - t2
+
+        if fast:
+            pre_step, post_step = pre_fast, post_fast
         for g in range(len(self.groups)):
             pre_step(g)
         live = [True] * len(self.groups)

@@ -324,3 +324,29 @@ def test_forecast_full_iteration(workspace):
     assert torch.equal(tr.policy_net.net.affine_layers[1].weight.cpu(), mim.policy_net.net.affine_layers[1].weight.cpu())
     mim.close()
     tr.close()
+
+
+def test_fast_tick_path_is_bit_identical_to_the_torch_path(workspace, monkeypatch):
+    """The pointer-level tick (pinned flag slots read in place, one ctypes call per kernel) against the torch-tensor tick
+    with the same seeds: identical batches, filter statistics and logger totals."""
+    outs = []
+    for fast in ("0", "1"):
+        monkeypatch.setenv("EGP_FAST_TICK", fast)
+        monkeypatch.setenv("EGP_POLICY_GRAPH", "0")          # eager noise draws in both runs (same generator stream)
+        torch.manual_seed(123)
+        np.random.seed(5)
+        tr, cfg = _trainer(workspace, 48, 14, num_threads=4, num_groups=2)
+        tr.env.seed(77)
+        tr.pre_iter_update(0)
+        tr.env.end_reward = 0.21
+        torch.cuda.manual_seed(999)
+        batch, log = tr.agent.sample(48 * 25)
+        rs = tr.running_state.rs
+        outs.append(dict(states=batch.states.copy(), actions=batch.actions.copy(), rewards=batch.rewards.copy(), masks=batch.masks.copy(),
+                         next_states=batch.next_states.copy(), v_metas=batch.v_metas.copy(), n=rs.n, mean=np.array(rs.mean).copy(),
+                         std=np.array(rs.std).copy(), steps=log.num_steps, eps=log.num_episodes, r=log.avg_c_reward))
+        tr.close()
+    a, b = outs
+    assert a["steps"] == b["steps"] and a["eps"] == b["eps"] and a["n"] == b["n"] and a["r"] == b["r"]
+    for k in ("states", "actions", "rewards", "masks", "next_states", "v_metas", "mean", "std"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
