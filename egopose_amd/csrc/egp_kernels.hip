@@ -620,12 +620,12 @@ __device__ __forceinline__ V3<T> ee_local(const T *cq, const T *wp) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_reward_quat_v3(DevModel m, RewardW w, const T *__restrict__ expert_rows,
-                                                        const T *__restrict__ cur_qpos, const T *__restrict__ prev_qpos,
-                                                        const T *__restrict__ ee_wpos, const int *__restrict__ tcur,
-                                                        const int *__restrict__ frame, const int *__restrict__ endf,
-                                                        const int *__restrict__ active, T end_reward, int n,
-                                                        T *__restrict__ reward, T *__restrict__ cinfo) {
+__device__ __forceinline__ void reward_body(const DevModel &m, const RewardW &w, const T *__restrict__ expert_rows,
+                                            const T *__restrict__ cur_qpos, const T *__restrict__ prev_qpos,
+                                            const T *__restrict__ ee_wpos, const int *__restrict__ tcur,
+                                            const int *__restrict__ frame, const int *__restrict__ endf,
+                                            const int *__restrict__ active, T end_reward, int n,
+                                            T *__restrict__ reward, T *__restrict__ cinfo, int block_id) {
     __shared__ int s_start[EGP_MAX_BODY], s_ndof[EGP_MAX_BODY];
     __shared__ double s_bw[EGP_MAX_BODY];
     if (threadIdx.x < m.nbody) {
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void k_reward_quat_v3(DevModel m, RewardW w, c
         s_bw[threadIdx.x] = threadIdx.x > 0 ? m.b_diffw[threadIdx.x - 1] : 0.0;
     }
     __syncthreads();
-    const long env = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const long env = ((long)block_id * blockDim.x + threadIdx.x) >> 5;
     const int l = threadIdx.x & 31;
     if (env >= n) return;
     if (active && !active[env]) {
@@ -703,6 +703,16 @@ __global__ __launch_bounds__(256) void k_reward_quat_v3(DevModel m, RewardW w, c
         T *ci = cinfo + env * 5;
         ci[0] = pose_r; ci[1] = vel_r; ci[2] = ee_r; ci[3] = rp_r; ci[4] = rv_r;
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_reward_quat_v3(DevModel m, RewardW w, const T *__restrict__ expert_rows,
+                                                        const T *__restrict__ cur_qpos, const T *__restrict__ prev_qpos,
+                                                        const T *__restrict__ ee_wpos, const int *__restrict__ tcur,
+                                                        const int *__restrict__ frame, const int *__restrict__ endf,
+                                                        const int *__restrict__ active, T end_reward, int n,
+                                                        T *__restrict__ reward, T *__restrict__ cinfo) {
+    reward_body<T>(m, w, expert_rows, cur_qpos, prev_qpos, ee_wpos, tcur, frame, endf, active, end_reward, n, reward, cinfo, blockIdx.x);
 }
 
 // ============================================================================================ K7
@@ -780,9 +790,8 @@ struct ZfSrc {
 // tile statistics: thread = column, rows of the tile in chunks of 8 (8 independent loads in flight, then an
 // exact two-pass mean / M2 of the chunk, Chan-merged into the running tile statistics)
 template <typename T>
-__global__ __launch_bounds__(128) void k_zf_partial(ZfSrc<T> src, const int *__restrict__ active, int n, int dim,
-                                                    int rows_per_tile, double *__restrict__ ws) {
-    const int p = blockIdx.x;
+__device__ __forceinline__ void zf_partial_body(const ZfSrc<T> &src, const int *__restrict__ active, int n, int dim,
+                                                int rows_per_tile, double *__restrict__ ws, int p) {
     const int r0 = p * rows_per_tile, r1 = min(n, r0 + rows_per_tile);
     double *out = ws + (long)p * (1 + 2 * dim);
     for (int c = threadIdx.x; c < dim; c += blockDim.x) {
@@ -818,6 +827,29 @@ __global__ __launch_bounds__(128) void k_zf_partial(ZfSrc<T> src, const int *__r
         out[1 + dim + c] = m2;
         if (c == 0) out[0] = cnt;
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void k_zf_partial(ZfSrc<T> src, const int *__restrict__ active, int n, int dim,
+                                                    int rows_per_tile, double *__restrict__ ws) {
+    zf_partial_body<T>(src, active, n, dim, rows_per_tile, ws, blockIdx.x);
+}
+
+// One launch for the two independent halves of a rollout tick's post-step: blocks [0, n_tiles) compute the observation
+// filter's tile statistics (K6, first pass), the remaining blocks the imitation reward (K2). The reward then costs no
+// launch and no time of its own on the tick's critical path (filter -> policy -> next env-step).
+template <typename T>
+__global__ __launch_bounds__(256) void k_post_step(ZfSrc<T> src, const int *__restrict__ zf_active, int n, int dim, int rows_per_tile,
+                                                   double *__restrict__ ws, int n_tiles, DevModel m, RewardW w,
+                                                   const T *__restrict__ expert_rows, const T *__restrict__ prev_qpos,
+                                                   const T *__restrict__ ee_wpos, const int *__restrict__ tcur,
+                                                   const int *__restrict__ frame, const int *__restrict__ endf, T end_reward,
+                                                   T *__restrict__ reward, T *__restrict__ cinfo) {
+    if ((int)blockIdx.x < n_tiles)
+        zf_partial_body<T>(src, zf_active, n, dim, rows_per_tile, ws, blockIdx.x);
+    else
+        reward_body<T>(m, w, expert_rows, src.qpos, prev_qpos, ee_wpos, tcur, frame, endf, zf_active, end_reward, n, reward, cinfo,
+                       (int)blockIdx.x - n_tiles);
 }
 
 // one block: Chan-merge the tile partials into the running state, fixed order (deterministic)
@@ -1345,6 +1377,34 @@ static int launch_obs_zfilter(egp_ctx *ctx, const T *qpos, const T *qvel, const 
     return launch_zfilter_src<T>(src, active, n, dim, st_in, st_out, 1, clip, y, y2, write_only_active ? active : nullptr, ws, stream);
 }
 
+// K3+K6 (filtered observation -> y, y2; statistics updated) and K2 (reward) of one rollout tick in three launches
+static int launch_post_step(egp_ctx *ctx, const double *qpos, const double *qvel, const double *prev_qpos, const double *ee_wpos,
+                            const int *tcur, const int *frame, const int *endf, const int *active, int n, const double *st_in,
+                            double *st_out, double clip, double *y, double *y2, void *ws, double end_reward, double *reward,
+                            double *cinfo, void *stream) {
+    EGP_REQUIRE(ctx, "ctx is NULL");
+    EGP_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return EGP_OK;
+    EGP_REQUIRE(qpos && qvel && prev_qpos && ee_wpos && tcur && frame && endf && y && reward && cinfo, "NULL pointer");
+    if (!ctx->expert_rows_f64) { set_error("egp_upload_experts must be called before the reward kernel"); return EGP_E_STATE; }
+    const int dim = ctx->dm.nq - 2 + ctx->dm.nv;
+    ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim};
+    const int identity = st_in == nullptr;
+    EGP_REQUIRE(identity || (st_out && ws && st_out != st_in), "the filter update needs workspace and a distinct state_out");
+    hipStream_t s = (hipStream_t)stream;
+    int rpt = 0, nt = 0;
+    if (!identity) zf_tiling(n, &rpt, &nt);
+    const int reward_blocks = (int)(((long)n * 32 + 255) / 256);
+    k_post_step<double><<<dim3(nt + reward_blocks), dim3(256), 0, s>>>(src, active, n, dim, rpt, (double *)ws, nt, ctx->dm, ctx->rw,
+                                                                       ctx->expert_rows_f64, prev_qpos, ee_wpos, tcur, frame, endf,
+                                                                       end_reward, reward, cinfo);
+    if (!identity) k_zf_merge<<<dim3(1), dim3(128), 0, s>>>(dim, nt, (const double *)ws, st_in, st_out);
+    const int rows_per_block = n <= 8192 ? 2 : 16;
+    k_zf_apply<double><<<dim3((n + rows_per_block - 1) / rows_per_block), dim3(128), 2 * dim * sizeof(double), s>>>(
+        src, n, dim, rows_per_block, identity ? st_in : st_out, clip, y, y2, nullptr, identity);
+    return after_launch("k_post_step / k_zf_merge / k_zf_apply");
+}
+
 template <typename T>
 static int launch_gae(const T *r, const T *mk, const T *v, int n, double gamma, double tau, T *adv, T *ret, double *stats,
                       void *ws, void *stream) {
@@ -1433,6 +1493,14 @@ int egp_obs_zfilter_f64(egp_ctx *c, const double *qpos, const double *qvel, cons
 int egp_obs_zfilter_f32(egp_ctx *c, const float *qpos, const float *qvel, const int32_t *active, int32_t n, const double *si,
                         double *so, double clip, float *y, float *y2, int32_t write_only_active, void *ws, void *s) {
     return launch_obs_zfilter<float>(c, qpos, qvel, active, n, si, so, clip, y, y2, write_only_active, ws, s);
+}
+
+int egp_post_step_f64(egp_ctx *c, const double *qpos, const double *qvel, const double *prev_qpos, const double *ee_wpos,
+                      const int32_t *t, const int32_t *frame, const int32_t *end, const int32_t *active, int32_t n, const double *si,
+                      double *so, double clip, double *y, double *y2, void *ws, double end_reward, double *reward, double *cinfo,
+                      void *s) {
+    return launch_post_step(c, qpos, qvel, prev_qpos, ee_wpos, t, frame, end, active, n, si, so, clip, y, y2, ws, end_reward, reward,
+                            cinfo, s);
 }
 
 int64_t egp_gae_workspace_bytes(int32_t n) {

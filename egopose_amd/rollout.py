@@ -412,6 +412,9 @@ class LockstepRollout:
             end_r = float(end_reward)
             zclip = float(self.zf_clip) if self.zf_state is not None else 0.0
             act_i32 = np.ones(N, np.int32)
+            # egp_post_step (reward workgroups riding in the filter's first launch) is bit-identical but measured no faster
+            # than the two separate calls (the merge still waits for the slower half): opt-in
+            post_fused = os.environ.get("EGP_POST_FUSED", "0") == "1"
 
         def pre_fast(g):
             a, b = self.groups[g]
@@ -471,18 +474,24 @@ class LockstepRollout:
                 self._zf_flip ^= 1
             else:                                # raw observations (no running_state)
                 new_t, new, cur = None, None, None
-            rc = lib.egp_obs_zfilter_f64(hnd, qpos_p + a * ctx.nq * 8, qvel_p + a * ctx.nv * 8, fbase + 3 * n * 4, n, cur, new, zclip,
-                                         P["next_states"] + (k * N + a) * od * 8, P["states"] + ((k + 1) * N + a) * od * 8, 0, ws_p,
-                                         _lib.current_stream())
+            # K3+K6 (-> next_states[k] and states[k+1]) and K2 (-> rewards[k], cinfo[k]): three launches, one call
+            if not post_fused:
+                rc = lib.egp_obs_zfilter_f64(hnd, qpos_p + a * ctx.nq * 8, qvel_p + a * ctx.nv * 8, fbase + 3 * n * 4, n, cur, new, zclip,
+                                             P["next_states"] + (k * N + a) * od * 8, P["states"] + ((k + 1) * N + a) * od * 8, 0, ws_p,
+                                             _lib.current_stream())
+                if rc == 0:
+                    rc = lib.egp_reward_quat_v3_f64(hnd, qpos_p + a * ctx.nq * 8, prev_p + a * ctx.nq * 8, ee_p + a * 15 * 8, fbase,
+                                                    fbase + n * 4, fbase + 2 * n * 4, fbase + 3 * n * 4, end_r, n,
+                                                    P["rewards"] + (k * N + a) * 8, P["cinfo"] + (k * N + a) * 5 * 8, _lib.current_stream())
+            else:
+              rc = lib.egp_post_step_f64(hnd, qpos_p + a * ctx.nq * 8, qvel_p + a * ctx.nv * 8, prev_p + a * ctx.nq * 8, ee_p + a * 15 * 8,
+                                       fbase, fbase + n * 4, fbase + 2 * n * 4, fbase + 3 * n * 4, n, cur, new, zclip,
+                                       P["next_states"] + (k * N + a) * od * 8, P["states"] + ((k + 1) * N + a) * od * 8, ws_p, end_r,
+                                       P["rewards"] + (k * N + a) * 8, P["cinfo"] + (k * N + a) * 5 * 8, _lib.current_stream())
             if rc != 0:
-                _lib.check(rc, "egp_obs_zfilter")
+                _lib.check(rc, "egp_post_step")
             if new_t is not None:
                 self.zf_state = new_t
-            rc = lib.egp_reward_quat_v3_f64(hnd, qpos_p + a * ctx.nq * 8, prev_p + a * ctx.nq * 8, ee_p + a * 15 * 8, fbase, fbase + n * 4,
-                                            fbase + 2 * n * 4, fbase + 3 * n * 4, end_r, n, P["rewards"] + (k * N + a) * 8,
-                                            P["cinfo"] + (k * N + a) * 5 * 8, _lib.current_stream())
-            if rc != 0:
-                _lib.check(rc, "egp_reward_quat_v3")
             steps_done[a:b] += act_g
             t2 = time.time()
             if done.any():

@@ -174,6 +174,13 @@ int egp_obs_zfilter_f64(egp_ctx *ctx, const double *qpos, const double *qvel, co
 int egp_obs_zfilter_f32(egp_ctx *ctx, const float *qpos, const float *qvel, const int32_t *active, int32_t n,
                         const double *state_in, double *state_out, double clip, float *y, float *y2,
                         int32_t write_only_active, void *workspace, void *stream);
+/* One rollout tick's post-step in three launches: egp_obs_zfilter (all rows written to y / y2, rows with active != 0 update
+ * the statistics; state_in == NULL: raw observations) + egp_reward_quat_v3 with the same mask; the reward's workgroups
+ * ride in the launch of the filter's first pass. Same arithmetic as the two separate calls (bit-identical, tested). */
+int egp_post_step_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const double *prev_qpos, const double *ee_wpos,
+                      const int32_t *t, const int32_t *frame, const int32_t *end, const int32_t *active, int32_t n,
+                      const double *state_in, double *state_out, double clip, double *y, double *y2, void *workspace,
+                      double end_reward, double *reward, double *cinfo, void *stream);
 
 /* ---------------------------------------------------------------------------------------- K5
  * estimate_advantages (core/common.py:5-25) over the flat concatenated batch.
