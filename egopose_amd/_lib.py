@@ -110,6 +110,7 @@ SIGNATURES = {
     "egp_gae_standardize_f32": (C.c_int, [vp, _i32, vp, vp]),
     "egp_lstm_fwd_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp]),
     "egp_lstm_bwd_f32": (C.c_int, [vp, vp, vp, vp, _i32, _i32, _i32, _i32, vp, vp]),
+    "egp_upload_async": (C.c_int, [vp, vp, C.c_int64, vp]),
     "egp_post_step_f64": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, _i32, vp, vp, _f64, vp, vp, vp, _f64, vp, vp, vp]),
     "egp_set_dynamics_model": (C.c_int, [vp, C.POINTER(DynamicsDesc)]),
     "egp_dynamics_f64": (C.c_int, [vp, vp, vp, _i32, vp, C.c_int64, vp, vp, vp]),

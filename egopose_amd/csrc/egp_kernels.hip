@@ -1522,6 +1522,13 @@ int egp_obs_zfilter_f32(egp_ctx *c, const float *qpos, const float *qvel, const 
     return launch_obs_zfilter<float>(c, qpos, qvel, active, n, si, so, clip, y, y2, write_only_active, ws, s);
 }
 
+int egp_upload_async(void *dst_device, const void *src_pinned, int64_t bytes, void *stream) {
+    EGP_REQUIRE(bytes >= 0 && (bytes == 0 || (dst_device && src_pinned)), "bad upload");
+    if (bytes == 0) return EGP_OK;
+    EGP_HIP_CHECK(hipMemcpyAsync(dst_device, src_pinned, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return EGP_OK;
+}
+
 int egp_post_step_f64(egp_ctx *c, const double *qpos, const double *qvel, const double *prev_qpos, const double *ee_wpos,
                       const int32_t *t, const int32_t *frame, const int32_t *end, const int32_t *active, int32_t n, const double *si,
                       double *so, double clip, double *y, double *y2, void *ws, double end_reward, double *reward, double *cinfo,

@@ -405,10 +405,16 @@ class LockstepRollout:
                 nmax = max(b - a for a, b in self.groups)
                 self._fast_bufs = (torch.zeros(len(self.groups), 2, nmax * 4, dtype=torch.int32).pin_memory(),
                                    torch.zeros(len(self.groups), 2, nmax, dtype=torch.int64).pin_memory(),
-                                   [torch.zeros(b - a, nu, dtype=torch.float32, device=dev) for a, b in self.groups])
-            fl_t, ti_t, noise_t = self._fast_bufs
+                                   [torch.zeros(b - a, nu, dtype=torch.float32, device=dev) for a, b in self.groups],
+                                   torch.zeros(len(self.groups), 2, nmax * 4, dtype=torch.int32, device=dev),
+                                   torch.zeros(len(self.groups), 2, nmax, dtype=torch.int64, device=dev))
+            fl_t, ti_t, noise_t, fl_d, ti_d = self._fast_bufs
             fl_np, ti_np = fl_t.numpy(), ti_t.numpy()
-            fl_p, ti_p = fl_t.data_ptr(), ti_t.data_ptr()          # pinned memory: same address on the device (unified addressing)
+            fl_h, ti_h = fl_t.data_ptr(), ti_t.data_ptr()          # pinned staging slots ...
+            fl_p, ti_p = fl_d.data_ptr(), ti_d.data_ptr()          # ... and their device mirrors (one async copy per use)
+            flags_upload = os.environ.get("EGP_TICK_FLAGS", "upload") != "zerocopy"
+            if not flags_upload:       # kernels read the pinned slots in place (same address on the device): every access is a PCIe read
+                fl_p, ti_p = fl_h, ti_h
             end_r = float(end_reward)
             zclip = float(self.zf_clip) if self.zf_state is not None else 0.0
             act_i32 = np.ones(N, np.int32)
@@ -424,9 +430,12 @@ class LockstepRollout:
             slot = k & 1
             ti = ti_np[g, slot, :n]
             np.minimum(self.cur_t[a:b], self.ctx_T - 1, out=ti)
+            toff = ((g * 2 + slot) * ti_np.shape[2]) * 8
+            if flags_upload:
+                lib.egp_upload_async(ti_p + toff, ti_h + toff, n * 8, _lib.current_stream())
             nz = noise_t[g]
             nz.normal_()
-            rc = lib.egp_policy_gaussian_f32(v_out_p + a * v_stride * 4, v_stride, H, ti_p + ((g * 2 + slot) * ti_np.shape[2]) * 8,
+            rc = lib.egp_policy_gaussian_f32(v_out_p + a * v_stride * 4, v_stride, H, ti_p + toff,
                                              P["states"] + (k * N + a) * od * 8, od, n, fz.desc, len(fz.layers), fz.act,
                                              fz.log_std.data_ptr(), nz.data_ptr(), P["actions"] + (k * N + a) * nu * 8, None,
                                              _lib.current_stream())
@@ -468,7 +477,10 @@ class LockstepRollout:
             fl[3] = act_g
             host["valid"][k, a:b], host["done"][k, a:b] = act_g, done
             host["e_ind"][k, a:b], host["s_ind"][k, a:b] = self.e_ind[a:b], self.s_ind[a:b]
-            fbase = fl_p + ((g * 2 + slot) * fl_np.shape[2]) * 4
+            foff = ((g * 2 + slot) * fl_np.shape[2]) * 4
+            if flags_upload:
+                lib.egp_upload_async(fl_p + foff, fl_h + foff, 4 * n * 4, _lib.current_stream())
+            fbase = fl_p + foff
             if zf_p is not None:                 # same ping-pong as _obs_filter
                 new_t, new, cur = self._zf_bufs[self._zf_flip], zf_p[self._zf_flip], self.zf_state.data_ptr()
                 self._zf_flip ^= 1

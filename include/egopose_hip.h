@@ -174,6 +174,9 @@ int egp_obs_zfilter_f64(egp_ctx *ctx, const double *qpos, const double *qvel, co
 int egp_obs_zfilter_f32(egp_ctx *ctx, const float *qpos, const float *qvel, const int32_t *active, int32_t n,
                         const double *state_in, double *state_out, double clip, float *y, float *y2,
                         int32_t write_only_active, void *workspace, void *stream);
+/* hipMemcpyAsync host (pinned) -> device on `stream`: the per-tick integer flags of the rollout driver (kernels that
+ * re-read a flag array must not read it from pinned memory: every access would cross PCIe) */
+int egp_upload_async(void *dst_device, const void *src_pinned, int64_t bytes, void *stream);
 /* One rollout tick's post-step in three launches: egp_obs_zfilter (all rows written to y / y2, rows with active != 0 update
  * the statistics; state_in == NULL: raw observations) + egp_reward_quat_v3 with the same mask; the reward's workgroups
  * ride in the launch of the filter's first pass. Same arithmetic as the two separate calls (bit-identical, tested). */
