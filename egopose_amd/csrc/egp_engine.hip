@@ -111,7 +111,8 @@ struct Group {
     bool quit = false;
     const double *action = nullptr;
     hipEvent_t ready = nullptr;
-    std::vector<int> active;
+    int *active = nullptr;                    // [n_env] pinned (the resident K1 reads its group's part in place)
+    int *hd_active = nullptr;
     bool has_active = false;
     std::atomic<int> status{EGP_OK};
     std::atomic<int> qM_dirty{0};             // some env of the group drained a new inertia this substep
@@ -343,28 +344,38 @@ inline bool server_mode(const egp_engine *E, const Group &G) {
 // and walks them round-robin -- while the GPU turns one slice's new state into torques (PCIe read, solve, PCIe
 // write), the thread advances the next -- so no thread ever waits for another one inside the env-step, and an env
 // is stepped the moment its own torque row has fully arrived.
-inline bool row_arrived(const double *row, int nu) {
+// A torque row is nu doubles; the GPU writes it in pieces of at least one 32-byte sector (4 doubles), each of which
+// lands atomically. Rows start sector-aligned when nu % 4 == 0 (52 for the humanoid), so ONE sentinel word per sector
+// is enough both to arm a row and to see that all of it has arrived; otherwise every word is used.
+inline int sentinel_stride(int nu) { return nu % 4 == 0 ? 4 : 1; }
+
+inline bool row_arrived(const double *row, int nu, int stride) {
     const unsigned long long *u = reinterpret_cast<const unsigned long long *>(row);
     bool ok = true;
-    for (int i = 0; i < nu; ++i) ok &= __atomic_load_n(u + i, __ATOMIC_RELAXED) != EGP_TORQUE_SENTINEL;
+    for (int i = 0; i < nu; i += stride) ok &= __atomic_load_n(u + i, __ATOMIC_RELAXED) != EGP_TORQUE_SENTINEL;
     return ok;
 }
 
-inline void fill_sentinel(double *rows, size_t count) {
-    unsigned long long *u = reinterpret_cast<unsigned long long *>(rows);
-    for (size_t i = 0; i < count; ++i) u[i] = EGP_TORQUE_SENTINEL;
+// arm the rows of the slice's envs that will be stepped (inactive envs are never read: their rows stay as they are)
+inline void arm_slice(egp_engine *E, const Group &G, int e0, int e1, int nu, int stride) {
+    for (int e = e0; e < e1; ++e) {
+        if (G.has_active && !G.active[e]) continue;
+        unsigned long long *u = reinterpret_cast<unsigned long long *>(E->h_torque + (size_t)e * nu);
+        for (int i = 0; i < nu; i += stride) u[i] = EGP_TORQUE_SENTINEL;
+    }
 }
 
 void run_step_server(egp_engine *E, Group &G, int tid) {
     Server &S = G.srv;
     const int FS = E->frame_skip, nu = E->nu, K = S.per_thread;
+    const int sstride = sentinel_stride(nu);
     const unsigned long long base = S.base;
     const unsigned long long drain_all = 0x7FFFFFFFFFFFFFFFull << 1;
     const auto t_job = clk::now();
     // own slices: sentinel rows first, then the go word of substep 0 (the kernel writes torques only after it saw go)
     for (int h = 0; h < K; ++h) {
         const int sl = K * tid + h;
-        fill_sentinel(E->h_torque + (size_t)S.e0[sl] * nu, (size_t)(S.e1[sl] - S.e0[sl]) * nu);
+        arm_slice(E, G, S.e0[sl], S.e1[sl], nu, sstride);
         __atomic_store_n(S.h_go + sl * 8, (base << 1) | (unsigned long long)S.dirty[sl].exchange(0), __ATOMIC_RELEASE);
     }
     if (tid == 0) {
@@ -378,10 +389,12 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
                                       G.action + (size_t)G.e0 * nu, m, E->hd_torque + (size_t)G.e0 * nu, G.stream, S.d_block_slice,
                                       S.hd_go, base, FS, S.hd_err, 2.0, S.d_trace, E->hd_ee + (size_t)G.e0 * 15,
                                       E->d_qpos + (size_t)G.e0 * E->nq, E->d_prev_qpos + (size_t)G.e0 * E->nq,
-                                      E->d_qvel + (size_t)G.e0 * E->nv, E->d_ee + (size_t)G.e0 * 15);
+                                      E->d_qvel + (size_t)G.e0 * E->nv, E->d_ee + (size_t)G.e0 * 15,
+                                      G.has_active ? G.hd_active + G.e0 : nullptr);
         if (rc != EGP_OK) fail(G, rc, "K1 server launch", egp_last_error());
         if (G.prof_now) G_HIP(hipEventRecord(G.k_end[0], G.stream));
         G_HIP(hipEventRecord(G.done, G.stream));      // the kernel's epilogue moves the final state to HBM
+        if (!S.host_trace.empty()) S.host_trace[0 * 4 + 3] = secs(t_job, clk::now()) * 1e6;     // launch issued
     }
     const bool timekeeper = tid == (G.n_threads > 1 ? 1 : 0);
     double t_wait = 0.0, t_phys = 0.0;
@@ -397,11 +410,11 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
             for (int e = S.e0[sl]; e < S.e1[sl] && G.status.load(std::memory_order_relaxed) == EGP_OK; ++e) {
                 if (G.has_active && !G.active[e]) continue;
                 const double *row = E->h_torque + (size_t)e * nu;
-                if (!row_arrived(row, nu)) {
+                if (!row_arrived(row, nu, sstride)) {
                     auto w0 = clk::now();
                     const auto deadline = w0 + std::chrono::seconds(5);
                     long spins = 0;
-                    while (!row_arrived(row, nu)) {
+                    while (!row_arrived(row, nu, sstride)) {
                         cpu_relax();
                         if ((++spins & 0xFFF) == 0) {
                             if (G.status.load(std::memory_order_relaxed) != EGP_OK) break;
@@ -423,7 +436,7 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
             if (G.status.load(std::memory_order_relaxed) != EGP_OK) {
                 __atomic_store_n(S.h_go + sl * 8, drain_all, __ATOMIC_RELEASE);       // let the kernel run out
             } else if (!last) {
-                fill_sentinel(E->h_torque + (size_t)S.e0[sl] * nu, (size_t)(S.e1[sl] - S.e0[sl]) * nu);
+                arm_slice(E, G, S.e0[sl], S.e1[sl], nu, sstride);
                 __atomic_store_n(S.h_go + sl * 8, ((base + (unsigned long long)s + 1ull) << 1) | (unsigned long long)S.dirty[sl].exchange(0),
                                  __ATOMIC_RELEASE);
             } else {
@@ -439,8 +452,15 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
         }
     }
     if (timekeeper) { G.wait_s += t_wait; G.phys_s += t_phys; }
+    if (tid == 0 && !S.host_trace.empty()) S.host_trace[1 * 4 + 3] = secs(t_job, clk::now()) * 1e6;      // own substeps done
+    if (!S.host_trace.empty() && 4 + tid < FS) S.host_trace[(4 + tid) * 4 + 3] = secs(t_job, clk::now()) * 1e6;   // per thread
     G.bar.wait();
     if (tid != 0) return;
+    if (!S.host_trace.empty()) {
+        S.host_trace[2 * 4 + 3] = secs(t_job, clk::now()) * 1e6;                                       // every thread done
+        (void)hipEventSynchronize(G.done);
+        S.host_trace[3 * 4 + 3] = secs(t_job, clk::now()) * 1e6;                                       // kernel (epilogue) done
+    }
     if (G.status.load() != EGP_OK) {
         for (int sl = 0; sl < S.n_slices; ++sl) __atomic_store_n(S.h_go + sl * 8, drain_all, __ATOMIC_RELEASE);
         (void)hipStreamSynchronize(G.stream);
@@ -737,7 +757,13 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
         const int w0 = (int)((long)E->n_threads * g / E->n_groups), w1 = (int)((long)E->n_threads * (g + 1) / E->n_groups);
         G.n_threads = std::max(1, std::min(w1 - w0, G.e1 - G.e0));
         G.bar.n = G.n_threads;
-        G.active.assign(E->n_env, 1);
+        E_TRY(hipHostMalloc((void **)&G.active, (size_t)E->n_env * sizeof(int), hipHostMallocDefault));
+        for (int e = 0; e < E->n_env; ++e) G.active[e] = 1;
+        {
+            void *p = nullptr;
+            E_TRY(hipHostGetDevicePointer(&p, G.active, 0));
+            G.hd_active = (int *)p;
+        }
         for (int e = G.e0; e < G.e1; ++e) E->env_group[e] = g;
         E_TRY(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
         E_TRY(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
@@ -867,6 +893,7 @@ int egp_engine_destroy(egp_engine *E) {
             void *hv[] = {S.h_go, S.h_err};
             for (void *p : hv) if (p) (void)hipHostFree(p);
         }
+        if (G.active) (void)hipHostFree(G.active);
         if (G.d_done) (void)hipFree(G.d_done);
         if (G.h_flag) (void)hipHostFree(G.h_flag);
         if (G.stream) (void)hipStreamDestroy(G.stream);
@@ -970,7 +997,7 @@ int egp_engine_step_async(egp_engine *E, int32_t group, const double *action, co
     G.action = action;
     G.ready = (hipEvent_t)ready_event;
     G.has_active = active_host != nullptr;
-    if (active_host) memcpy(G.active.data(), active_host, E->n_env * sizeof(int));
+    if (active_host) memcpy(G.active, active_host, E->n_env * sizeof(int));
     G.server_job = server_mode(E, G);
     if (G.server_job) {
         G.srv.base = G.srv.seq;

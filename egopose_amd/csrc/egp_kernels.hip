@@ -379,6 +379,8 @@ struct PdServe {
     double *out_qpos, *out_prev_qpos, *out_qvel, *out_ee;   // HBM [n][nq] / [n][nq] / [n][nv] / [n][15]
     int nq, nv;
     int poll_sleep;                       // s_sleep(1) (64 clocks) repeats between two polls of a go word
+    const int *active;                    // optional [n] (pinned host): envs with 0 are not stepped this env-step -- their waves
+                                          // move no state, torque or epilogue rows (in a rollout's tail that is most of the PCIe traffic)
 };
 
 // Poll a word of pinned host memory through the SCALAR memory path (s_load ... glc = always fetch from beyond the
@@ -409,6 +411,7 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
     const int row = lane < PD_NV ? lane : PD_NV - 1;
     const int act = row >= 6 ? row - 6 : 0;
     const int slice = sv.block_slice[blockIdx.x];
+    const bool live = valid && (!sv.active || sv.active[env] != 0);
     const double r_a = valid ? action[env * ld.action + act] : 0.0;
     const double c_kp = row >= 6 ? m.jkp[act] : 0.0, c_kd = row >= 6 ? m.jkd[act] : 0.0;
     const double c_ref = m.a_ref[act], c_scale = m.a_scale[act], c_lim = m.torque_lim[act];
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
             return;
         }
         const bool refresh = (s_go[sub & 1] & 1ull) != 0ull;
-        if (valid) {
+        if (live) {
             const double r_q = sys_load_f64(qpos + env * ld.qpos + 7 + act);
             const double r_v = sys_load_f64(qvel + env * ld.qvel + row);
             const double r_c = sys_load_f64(C + env * ld.bias + row);
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
             if (threadIdx.x == 0) __hip_atomic_store(sv.err, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
-        if (valid) {
+        if (live) {
             // the row base of qpos: `qpos` points at the state rows' qpos column (offset 0 of the row)
             if (lane < sv.nq) {
                 const long d = env * sv.nq + lane;
@@ -1309,7 +1312,7 @@ int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const d
                          long ld_bias, const double *qM, long ld_qM, const double *qM_host, const double *action, int32_t n,
                          double *torque, hipStream_t stream, const int *block_slice, const unsigned long long *go,
                          unsigned long long base, int n_sub, int *err, double timeout_s, long long *trace, const double *ee_host,
-                         double *out_qpos, double *out_prev_qpos, double *out_qvel, double *out_ee) {
+                         double *out_qpos, double *out_prev_qpos, double *out_qvel, double *out_ee, const int *active) {
     EGP_REQUIRE(ctx && ctx->tree58 && ctx->pd_variant == 0, "the K1 server needs the humanoid tree kernel");
     EGP_REQUIRE(ee_host && out_qpos && out_prev_qpos && out_qvel && out_ee, "NULL epilogue pointer");
     EGP_REQUIRE(ctx->dm.nq <= 64 && ctx->dm.nv <= 64, "the epilogue moves one state row per wavefront");
@@ -1318,7 +1321,7 @@ int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const d
     PdLd ld{ld_qpos, ld_qvel, ctx->dm.nu, ld_qM, ld_bias};
     static const int poll_sleep = [] { const char *e = getenv("EGP_SERVER_POLL_SLEEP"); return e ? atoi(e) : 2; }();
     PdServe sv{block_slice, go, base, n_sub, qM_host, const_cast<double *>(qM), err, (long long)(timeout_s * 100.0e6), trace,
-               ee_host, out_qpos, out_prev_qpos, out_qvel, out_ee, ctx->dm.nq, ctx->dm.nv, poll_sleep};
+               ee_host, out_qpos, out_prev_qpos, out_qvel, out_ee, ctx->dm.nq, ctx->dm.nv, poll_sleep, active};
     k_pd_server_tree58<<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, bias, n, torque, sv);
     return after_launch("k_pd_server_tree58");
 }

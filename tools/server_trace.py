@@ -20,6 +20,7 @@ from egopose_amd.skeleton import load_skeleton
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     groups = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    n_active = int(sys.argv[3]) if len(sys.argv) > 3 else n          # env 0 (block 0 / slice 0, the traced ones) stays active
     sk = load_skeleton()
     p = subject_03_params()
     ctx = EgpContext(sk, p["jkp"], p["jkd"], p["a_ref"], p["a_scale"], p["torque_lim"], p["b_diffw"], p["reward_weights"])
@@ -30,12 +31,22 @@ def main():
     eng.reset(np.arange(n), q0, np.zeros((n, 58)))
     act = torch.as_tensor(rng.normal(size=(n, 52)) * 0.1, device="cuda")
     torch.cuda.synchronize()
+    mask = None
+    if n_active < n:
+        mask = np.zeros(n, np.int32)
+        mask[0] = 1
+        mask[np.random.RandomState(1).choice(np.arange(1, n), max(0, n_active - 1), replace=False)] = 1
+    import time
+    t_steps = []
     for it in range(20):
+        t0 = time.perf_counter()
         for g in range(groups):
-            eng.step_async(g, act)
+            eng.step_async(g, act, mask)
         for g in range(groups):
             eng.wait(g)
+        t_steps.append((time.perf_counter() - t0) * 1e6)
     torch.cuda.synchronize()
+    print("env-step wall time (us), last 5:", [round(t) for t in t_steps[-5:]])
     fs = 15
     dev = np.zeros(fs * 8, np.int64)
     host = np.zeros(fs * 4)
@@ -51,6 +62,8 @@ def main():
     print("host (owner of slice 0), us since the step was posted:  wait start | first row in | go written")
     for s in range(fs):
         print("  sub %2d  %8.2f %8.2f %8.2f   | waited %.2f physics %.2f" % (s, host[s, 0], host[s, 1], host[s, 2], host[s, 1] - host[s, 0], host[s, 2] - host[s, 1]))
+    print("leader, us since the step was posted: launch issued %.1f | own substeps done %.1f | all threads done %.1f | kernel done %.1f" % tuple(host[:4, 3]))
+    print("per-thread finish (us since posted; each thread's own clock start):", [round(x) for x in host[4:, 3] if x > 0])
     print("threads", eng.n_threads if hasattr(eng, "n_threads") else "?", "timing", eng.timing())
     eng.close(); ph.close(); ctx.close()
 
