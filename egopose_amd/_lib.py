@@ -136,6 +136,7 @@ SIGNATURES = {
     "egp_engine_set_profile": (C.c_int, [vp, C.c_int]),
     "egp_engine_layout": (C.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p]),
     "egp_engine_group_range": (C.c_int, [vp, _i32, c_int_p, c_int_p]),
+    "egp_engine_set_reward_job": (C.c_int, [vp, _i32, vp, vp, vp, vp, _f64, vp, vp]),
     "egp_engine_launches_per_substep": (C.c_int, [vp]),
     "egp_engine_substeps_per_launch": (C.c_int, [vp]),
     "egp_engine_server_trace": (C.c_int, [vp, _i32, vp, vp]),

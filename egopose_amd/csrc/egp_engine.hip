@@ -111,6 +111,13 @@ struct Group {
     bool quit = false;
     const double *action = nullptr;
     hipEvent_t ready = nullptr;
+    // reward job of the env-step in flight (egp_engine_set_reward_job): launched on the group's stream right behind K1
+    struct RewardJob {
+        bool armed = false;
+        const int32_t *t = nullptr, *frame = nullptr, *end = nullptr, *active = nullptr;
+        double end_reward = 0.0;
+        double *reward = nullptr, *cinfo = nullptr;
+    } rjob;
     int *active = nullptr;                    // [n_env] pinned (the resident K1 reads its group's part in place)
     int *hd_active = nullptr;
     bool has_active = false;
@@ -394,6 +401,16 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
         if (rc != EGP_OK) fail(G, rc, "K1 server launch", egp_last_error());
         if (G.prof_now) G_HIP(hipEventRecord(G.k_end[0], G.stream));
         G_HIP(hipEventRecord(G.done, G.stream));      // the kernel's epilogue moves the final state to HBM
+        if (G.rjob.armed) {
+            // K2 of this env-step, stream-ordered behind the epilogue and ahead of the next env-step's kernel: off the
+            // caller's critical path (filter -> policy -> next step), and its inputs cannot be overwritten under it
+            const int m2 = G.e1 - G.e0;
+            int rr = egp_reward_quat_v3_f64(E->ctx, E->d_qpos + (size_t)G.e0 * E->nq, E->d_prev_qpos + (size_t)G.e0 * E->nq,
+                                            E->d_ee + (size_t)G.e0 * 15, G.rjob.t, G.rjob.frame, G.rjob.end, G.rjob.active,
+                                            G.rjob.end_reward, m2, G.rjob.reward, G.rjob.cinfo, G.stream);
+            if (rr != EGP_OK) fail(G, rr, "reward launch", egp_last_error());
+            G.rjob.armed = false;
+        }
         if (!S.host_trace.empty()) S.host_trace[0 * 4 + 3] = secs(t_job, clk::now()) * 1e6;     // launch issued
     }
     const bool timekeeper = tid == (G.n_threads > 1 ? 1 : 0);
@@ -1014,6 +1031,20 @@ int egp_engine_step_async(egp_engine *E, int32_t group, const double *action, co
     G.job += 1;
     G.job_pub.store(G.job, std::memory_order_release);
     G.cv_go.notify_all();
+    return EGP_OK;
+}
+
+int egp_engine_set_reward_job(egp_engine *E, int32_t group, const int32_t *t, const int32_t *frame, const int32_t *end,
+                              const int32_t *active, double end_reward, double *reward, double *cinfo) {
+    EGP_REQUIRE(E && t && frame && end && reward && cinfo, "NULL pointer");
+    EGP_REQUIRE(group >= 0 && group < E->n_groups, "group out of range");
+    Group &G = E->groups[group];
+    std::lock_guard<std::mutex> lk(G.mu);
+    if (G.pending != 0) { egp::set_error("group %d is still stepping", group); return EGP_E_STATE; }
+    if (!server_mode(E, G)) { egp::set_error("the reward job rides behind the resident K1 only"); return EGP_E_STATE; }
+    G.rjob.t = t; G.rjob.frame = frame; G.rjob.end = end; G.rjob.active = active;
+    G.rjob.end_reward = end_reward; G.rjob.reward = reward; G.rjob.cinfo = cinfo;
+    G.rjob.armed = true;
     return EGP_OK;
 }
 

@@ -401,26 +401,28 @@ class LockstepRollout:
             ws_p = ws.data_ptr()
             v_out_p, v_stride = self.v_out.data_ptr(), self.v_out.stride(0)
             fz = self._fused
-            if self._fast_bufs is None or self._fast_bufs[0].shape[2] != max(b - a for a, b in self.groups):
-                nmax = max(b - a for a, b in self.groups)
-                self._fast_bufs = (torch.zeros(len(self.groups), 2, nmax * 4, dtype=torch.int32).pin_memory(),
-                                   torch.zeros(len(self.groups), 2, nmax, dtype=torch.int64).pin_memory(),
-                                   [torch.zeros(b - a, nu, dtype=torch.float32, device=dev) for a, b in self.groups],
-                                   torch.zeros(len(self.groups), 2, nmax * 4, dtype=torch.int32, device=dev),
-                                   torch.zeros(len(self.groups), 2, nmax, dtype=torch.int64, device=dev))
-            fl_t, ti_t, noise_t, fl_d, ti_d = self._fast_bufs
-            fl_np, ti_np = fl_t.numpy(), ti_t.numpy()
-            fl_h, ti_h = fl_t.data_ptr(), ti_t.data_ptr()          # pinned staging slots ...
-            fl_p, ti_p = fl_d.data_ptr(), ti_d.data_ptr()          # ... and their device mirrors (one async copy per use)
+            nmax = max(b - a for a, b in self.groups)
+            if self._fast_bufs is None or self._fast_bufs[3] != nmax:
+                # per (group, slot) one 24*nmax-byte slab: 4 x nmax int32 flags (t | frame | end | active), then nmax int64 context rows
+                self._fast_bufs = (torch.zeros(len(self.groups), 2, 24 * nmax, dtype=torch.uint8).pin_memory(),
+                                   torch.zeros(len(self.groups), 2, 24 * nmax, dtype=torch.uint8, device=dev),
+                                   [torch.zeros(b - a, nu, dtype=torch.float32, device=dev) for a, b in self.groups], nmax)
+            slab_h, slab_d, noise_t, _ = self._fast_bufs
+            slab_np = slab_h.numpy()
+            fl_np = slab_np[:, :, :16 * nmax].view(np.int32)            # (G, 2, 4*nmax)
+            ti_np = slab_np[:, :, 16 * nmax:].view(np.int64)            # (G, 2, nmax)
+            slab_hp, slab_dp = slab_h.data_ptr(), slab_d.data_ptr()
             flags_upload = os.environ.get("EGP_TICK_FLAGS", "upload") != "zerocopy"
-            if not flags_upload:       # kernels read the pinned slots in place (same address on the device): every access is a PCIe read
-                fl_p, ti_p = fl_h, ti_h
+            if not flags_upload:       # kernels read the pinned slab in place (same address on the device): every access is a PCIe read
+                slab_dp = slab_hp
+            reward_job = eng.substeps_per_launch > 1 and os.environ.get("EGP_REWARD_JOB", "1") != "0"
+            T_eff = T_ep if self.env.fix_len is None else self.env.fix_len
             end_r = float(end_reward)
             zclip = float(self.zf_clip) if self.zf_state is not None else 0.0
             act_i32 = np.ones(N, np.int32)
             # egp_post_step (reward workgroups riding in the filter's first launch) is bit-identical but measured no faster
             # than the two separate calls (the merge still waits for the slower half): opt-in
-            post_fused = os.environ.get("EGP_POST_FUSED", "0") == "1"
+            post_fused = os.environ.get("EGP_POST_FUSED", "0") == "1" and not reward_job
 
         def pre_fast(g):
             a, b = self.groups[g]
@@ -428,14 +430,22 @@ class LockstepRollout:
             t0 = time.time()
             k = tick[g]
             slot = k & 1
-            ti = ti_np[g, slot, :n]
-            np.minimum(self.cur_t[a:b], self.ctx_T - 1, out=ti)
-            toff = ((g * 2 + slot) * ti_np.shape[2]) * 8
+            # flags of the state this env-step will produce (they do not depend on its outcome) + context rows of this tick
+            act_g = active[a:b]
+            fl = fl_np[g, slot].reshape(4, nmax)
+            t_next = self.cur_t[a:b] + act_g
+            fl[0, :n] = t_next
+            fl[1, :n] = self.frame_base[a:b] + t_next
+            fl[2, :n] = (t_next >= T_eff) & act_g
+            fl[3, :n] = act_g
+            np.minimum(self.cur_t[a:b], self.ctx_T - 1, out=ti_np[g, slot, :n])
+            soff = (g * 2 + slot) * 24 * nmax
             if flags_upload:
-                lib.egp_upload_async(ti_p + toff, ti_h + toff, n * 8, _lib.current_stream())
+                lib.egp_upload_async(slab_dp + soff, slab_hp + soff, 24 * nmax, _lib.current_stream())
+            fbase = slab_dp + soff
             nz = noise_t[g]
             nz.normal_()
-            rc = lib.egp_policy_gaussian_f32(v_out_p + a * v_stride * 4, v_stride, H, ti_p + toff,
+            rc = lib.egp_policy_gaussian_f32(v_out_p + a * v_stride * 4, v_stride, H, fbase + 16 * nmax,
                                              P["states"] + (k * N + a) * od * 8, od, n, fz.desc, len(fz.layers), fz.act,
                                              fz.log_std.data_ptr(), nz.data_ptr(), P["actions"] + (k * N + a) * nu * 8, None,
                                              _lib.current_stream())
@@ -444,6 +454,11 @@ class LockstepRollout:
             ev = torch.cuda.Event()
             ev.record()
             self._events[g] = ev
+            if reward_job:      # K2 rides behind this env-step's kernel on the engine's stream
+                rc = eng.lib.egp_engine_set_reward_job(eng.handle, g, fbase, fbase + 4 * nmax, fbase + 8 * nmax, fbase + 12 * nmax, end_r,
+                                                       P["rewards"] + (k * N + a) * 8, P["cinfo"] + (k * N + a) * 5 * 8)
+                if rc != 0:
+                    _lib.check(rc, "egp_engine_set_reward_job")
             np.copyto(act_i32, active, casting="unsafe")
             rc = eng.lib.egp_engine_step_async(eng.handle, g, P["actions"] + k * N * nu * 8, act_i32.ctypes.data, ev.cuda_event)
             if rc != 0:
@@ -470,17 +485,9 @@ class LockstepRollout:
                 fail = head_z < lb[self.e_ind[a:b]] - 0.1
             end = ct >= (T_ep if self.env.fix_len is None else self.env.fix_len)
             done = (fail | end) & act_g
-            fl = fl_np[g, slot, :4 * n].reshape(4, n)
-            fl[0] = ct
-            fl[1] = self.frame_base[a:b] + ct
-            fl[2] = end & act_g
-            fl[3] = act_g
             host["valid"][k, a:b], host["done"][k, a:b] = act_g, done
             host["e_ind"][k, a:b], host["s_ind"][k, a:b] = self.e_ind[a:b], self.s_ind[a:b]
-            foff = ((g * 2 + slot) * fl_np.shape[2]) * 4
-            if flags_upload:
-                lib.egp_upload_async(fl_p + foff, fl_h + foff, 4 * n * 4, _lib.current_stream())
-            fbase = fl_p + foff
+            fbase = slab_dp + (g * 2 + slot) * 24 * nmax          # the flags pre_fast staged for this env-step
             if zf_p is not None:                 # same ping-pong as _obs_filter
                 new_t, new, cur = self._zf_bufs[self._zf_flip], zf_p[self._zf_flip], self.zf_state.data_ptr()
                 self._zf_flip ^= 1
@@ -488,16 +495,16 @@ class LockstepRollout:
                 new_t, new, cur = None, None, None
             # K3+K6 (-> next_states[k] and states[k+1]) and K2 (-> rewards[k], cinfo[k]): three launches, one call
             if not post_fused:
-                rc = lib.egp_obs_zfilter_f64(hnd, qpos_p + a * ctx.nq * 8, qvel_p + a * ctx.nv * 8, fbase + 3 * n * 4, n, cur, new, zclip,
+                rc = lib.egp_obs_zfilter_f64(hnd, qpos_p + a * ctx.nq * 8, qvel_p + a * ctx.nv * 8, fbase + 12 * nmax, n, cur, new, zclip,
                                              P["next_states"] + (k * N + a) * od * 8, P["states"] + ((k + 1) * N + a) * od * 8, 0, ws_p,
                                              _lib.current_stream())
-                if rc == 0:
+                if rc == 0 and not reward_job:
                     rc = lib.egp_reward_quat_v3_f64(hnd, qpos_p + a * ctx.nq * 8, prev_p + a * ctx.nq * 8, ee_p + a * 15 * 8, fbase,
-                                                    fbase + n * 4, fbase + 2 * n * 4, fbase + 3 * n * 4, end_r, n,
+                                                    fbase + 4 * nmax, fbase + 8 * nmax, fbase + 12 * nmax, end_r, n,
                                                     P["rewards"] + (k * N + a) * 8, P["cinfo"] + (k * N + a) * 5 * 8, _lib.current_stream())
             else:
               rc = lib.egp_post_step_f64(hnd, qpos_p + a * ctx.nq * 8, qvel_p + a * ctx.nv * 8, prev_p + a * ctx.nq * 8, ee_p + a * 15 * 8,
-                                       fbase, fbase + n * 4, fbase + 2 * n * 4, fbase + 3 * n * 4, n, cur, new, zclip,
+                                       fbase, fbase + 4 * nmax, fbase + 8 * nmax, fbase + 12 * nmax, n, cur, new, zclip,
                                        P["next_states"] + (k * N + a) * od * 8, P["states"] + ((k + 1) * N + a) * od * 8, ws_p, end_r,
                                        P["rewards"] + (k * N + a) * 8, P["cinfo"] + (k * N + a) * 5 * 8, _lib.current_stream())
             if rc != 0:
@@ -541,6 +548,7 @@ class LockstepRollout:
                     live[g] = False
 
         # ---- episode-major batch: slot by slot, each slot's ticks in order
+        torch.cuda.synchronize(dev)              # reward launches of the last env-steps live on the engine's streams
         T_used = max(tick)
         valid = host["valid"][:T_used]                                  # (T, N)
         slot, tk = np.nonzero(valid.T)                                  # sorted by slot, then tick

@@ -350,6 +350,13 @@ int egp_engine_layout(egp_engine *e, int32_t *pack_ld, int32_t *n_env, int32_t *
 int egp_engine_group_range(egp_engine *e, int32_t group, int32_t *env_begin, int32_t *env_end);
 /* K1 launches a group issues per substep: 1, or the number of chunks when the group runs pipelined
  * (>= 3 threads, >= 16 envs, polled zero-copy mode; EGP_CHUNKS, default 2) */
+/* Resident-K1 mode only: hand the NEXT egp_engine_step_async of `group` its reward launch. The flag arrays (device
+ * memory, group-local: t / frame / end / active of the state the step will produce) must be ready by the step's
+ * ready_event; the engine launches egp_reward_quat_v3_f64 on the group's stream right behind the env-step's kernel (inputs:
+ * its own qpos / prev_qpos / ee_wpos rows), i.e. ordered before the next env-step and off the caller's stream. The caller
+ * must synchronise with the device before reading `reward` / `cinfo`. */
+int egp_engine_set_reward_job(egp_engine *e, int32_t group, const int32_t *t, const int32_t *frame, const int32_t *end,
+                              const int32_t *active, double end_reward, double *reward, double *cinfo);
 int egp_engine_launches_per_substep(egp_engine *e);
 /* substeps one K1 launch serves: frame_skip when the engine runs the resident K1 (one launch per env-step that
  * trades go/done words with the physics threads through pinned memory; EGP_SERVER=0 turns it off), else 1 */
