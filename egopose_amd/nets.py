@@ -22,6 +22,7 @@ import torch.nn as nn
 import os
 
 from . import dist as _dist
+from . import gemm_tuning as _tuning
 from . import lstm as _hip_lstm
 
 # Length buckets of the train-mode forward LSTM (1 = off, the default: measured SLOWER on the MI355X -- the persistent
@@ -32,6 +33,16 @@ _FWD_BUCKETS = int(os.environ.get("EGP_FWD_BUCKETS", "1"))
 _LSTM_IMPL = os.environ.get("EGP_LSTM", "hip")      # "torch" forces the MIOpen / cell-loop paths (A/B runs)
 
 _ACT = {"tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid}
+
+
+def bucket_rows(x):
+    """Zero-pad a big (N, D) batch to the next row bucket so its GEMM shapes come from a small tuned set
+    (gemm_tuning.py). Returns (x_padded, N) or (x, None)."""
+    if _tuning.enabled() and x.is_cuda and x.dim() == 2 and x.shape[0] >= 4 * _tuning.ROW_BUCKET:
+        pad = _tuning.pad_to(x.shape[0], _tuning.ROW_BUCKET)
+        if pad:
+            return nn.functional.pad(x, (0, 0, 0, pad)), x.shape[0]
+    return x, None
 
 
 class MLP(nn.Module):
@@ -88,7 +99,10 @@ class PolicyGaussian(Policy):
         self.action_log_std = nn.Parameter(torch.full((1, action_dim), float(log_std)), requires_grad=not fix_std)
 
     def mean_std(self, x):
+        x, n = bucket_rows(x)
         mean = self.action_mean(self.net(x))
+        if n is not None:
+            mean = mean[:n]
         return mean, torch.exp(self.action_log_std.expand_as(mean))
 
     def forward(self, x):
@@ -115,7 +129,9 @@ class Value(nn.Module):
             self.value_head.bias.zero_()
 
     def forward(self, x):
-        return self.value_head(self.net(x))
+        x, n = bucket_rows(x)
+        out = self.value_head(self.net(x))
+        return out if n is None else out[:n]
 
 
 # ------------------------------------------------------------------------------------------------ temporal nets
@@ -262,6 +278,11 @@ class VideoStateNet(nn.Module):
         self.indices = idx
         meta = np.asarray(v_metas)[ends]
         if self._cnn_table is not None and self._cnn_table[0].device == device:
+            # episode count rounded up to a bucket (gemm_tuning.py): the extra windows repeat episode 0, nothing
+            # gathers from them, so their gradient contribution is exactly zero
+            pad = _tuning.pad_to(len(ends), _tuning.EPISODE_BUCKET) if _tuning.enabled() and len(ends) >= 4 * _tuning.EPISODE_BUCKET else 0
+            if pad:
+                meta = np.concatenate((meta, np.repeat(meta[:1], pad, axis=0)), 0)
             e_ind = torch.as_tensor(meta[:, 0], device=device)
             s_ind = torch.as_tensor(meta[:, 1], device=device)
             self.cnn_feat_ctx = self.window_features(e_ind, s_ind, max_len).to(dtype)
@@ -436,8 +457,13 @@ class VideoForecastNet(nn.Module):
         meta = np.asarray(v_metas)[ends]
         T_ctx = m + max_len if self.dynamic_v else m
         if self._cnn_table is not None and self._cnn_table[0].device == device:
+            # episode count rounded up to a bucket (gemm_tuning.py); nothing gathers from the extra columns
+            pad = _tuning.pad_to(len(ends), _tuning.EPISODE_BUCKET) if _tuning.enabled() and len(ends) >= 4 * _tuning.EPISODE_BUCKET else 0
+            if pad:
+                meta = np.concatenate((meta, np.repeat(meta[:1], pad, axis=0)), 0)
+                self.num_episode = meta.shape[0]
             win = self.window_features(torch.as_tensor(meta[:, 0], device=device), torch.as_tensor(meta[:, 1], device=device)).to(dtype)
-            ctx = win.new_zeros(T_ctx, len(ends), self.cnn_feat_dim)
+            ctx = win.new_zeros(T_ctx, meta.shape[0], self.cnn_feat_dim)
             ctx[:m] = win
         else:
             ctx = np.zeros((T_ctx, len(ends), self.cnn_feat_dim))

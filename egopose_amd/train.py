@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import dist as D
+from . import gemm_tuning
 from .agent import AgentEgo
 from .config import Config, ForecastConfig
 from .env import HumanoidEnv
@@ -32,6 +33,8 @@ class Trainer:
 
     def __init__(self, cfg, device, dtype=torch.float32, num_envs=1024, num_threads=None, num_groups=2, seed_offset=0):
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        if self.device.type == "cuda" and dtype == torch.float32 and not gemm_tuning.enabled():
+            gemm_tuning.enable()                         # bucketed update shapes + pre-tuned rocBLAS/hipBLASLt picks
         np.random.seed(cfg.seed + seed_offset)
         torch.manual_seed(cfg.seed)                      # identical initial weights on every rank
         env = HumanoidEnv(cfg)

@@ -1,0 +1,115 @@
+"""Shape buckets of the PPO update (egopose_amd/gemm_tuning.py): padding rows / episodes must not change any
+result, and the shipped TunableOp picks must load on the MI355X image they were tuned on."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from egopose_amd import gemm_tuning
+from egopose_amd.nets import MLP, PolicyGaussian, Value, VideoStateNet, bucket_rows
+
+
+def test_shipped_picks_file_is_well_formed():
+    path = gemm_tuning.tuned_file()
+    assert os.path.exists(path)
+    lines = open(path).read().strip().splitlines()
+    kinds = {l.split(",")[0] for l in lines}
+    assert "Validator" in kinds and any(k.startswith("Gemm") for k in kinds)
+    # every MLP layer of the ego_mimic nets has a forward entry for at least one row bucket
+    for k, m in ((243, 300), (300, 200), (200, 52)):
+        assert any(l.startswith("GemmAndBiasTunableOp_float_TN,tn_%d_" % m) and ("_%d_ld_" % k) in l for l in lines), (k, m)
+    rows = [int(l.split(",")[1].split("_")[2]) for l in lines if l.startswith("GemmAndBiasTunableOp_float_TN,tn_300_")]
+    assert rows and all(r % gemm_tuning.ROW_BUCKET == 0 for r in rows)
+
+
+def test_bucket_rows_is_a_no_op_when_disabled_or_on_cpu():
+    assert not gemm_tuning.enabled()
+    x = torch.randn(5 * gemm_tuning.ROW_BUCKET + 3, 4)
+    y, n = bucket_rows(x)
+    assert y is x and n is None
+    assert gemm_tuning.pad_to(8192, 8192) == 0 and gemm_tuning.pad_to(8193, 8192) == 8191
+
+
+@pytest.fixture
+def tuned():
+    if not gemm_tuning.enable():
+        pytest.fail("the shipped TunableOp picks did not load (library versions differ from the tuned image?)")
+    yield
+    gemm_tuning.disable()
+
+
+def _policy_value(dev):
+    torch.manual_seed(3)
+    pol = PolicyGaussian(MLP(243, (300, 200), "relu"), 52, log_std=-2.3, fix_std=True).to(dev)
+    val = Value(MLP(243, (300, 200), "relu")).to(dev)
+    return pol, val
+
+
+@pytest.mark.gpu
+def test_padded_mlp_matches_unpadded(tuned):
+    dev = torch.device("cuda", 0)
+    pol, val = _policy_value(dev)
+    n = 4 * gemm_tuning.ROW_BUCKET + 1234
+    x = torch.randn(n, 243, device=dev)
+    a = torch.randn(n, 52, device=dev)
+    w = torch.randn(n, 1, device=dev)
+
+    def run():
+        for p in list(pol.parameters()) + list(val.parameters()):
+            p.grad = None
+        xx = x.clone().requires_grad_(True)
+        lp, v = pol.get_log_prob(xx, a), val(xx)
+        assert lp.shape == (n, 1) and v.shape == (n, 1)
+        ((lp + v) * w).sum().backward()
+        return lp.detach(), v.detach(), xx.grad, [p.grad.clone() for p in list(pol.parameters()) + list(val.parameters()) if p.grad is not None]
+
+    got = run()
+    assert bucket_rows(x)[1] == n
+    gemm_tuning.disable()
+    ref = run()
+    assert bucket_rows(x)[1] is None
+    for g, r in zip(got[:3], ref[:3]):
+        torch.testing.assert_close(g, r, rtol=2e-4, atol=2e-4)
+    for g, r in zip(got[3], ref[3]):        # sums over 34 k rows in another order
+        torch.testing.assert_close(g, r, rtol=2e-3, atol=2e-2 * float(r.abs().max()) + 1e-6)
+
+
+@pytest.mark.gpu
+def test_padded_episode_batch_matches_unpadded(tuned):
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(2)
+    cdim, hdim, margin, T_ep = 128, 128, 10, 30
+    cnn = [rng.normal(size=(400, cdim)), rng.normal(size=(300, cdim))]
+    n_ep = 4 * gemm_tuning.EPISODE_BUCKET + 5
+    lens = rng.randint(1, T_ep + 1, size=n_ep)
+    lens[0] = T_ep
+    masks, metas = [], []
+    for L in lens:
+        e = int(rng.randint(2))
+        s = int(rng.randint(margin, cnn[e].shape[0] - T_ep - margin))
+        masks += [1.0] * (L - 1) + [0.0]
+        metas += [[e, s]] * int(L)
+    masks = torch.tensor(masks, dtype=torch.float32, device=dev)
+    metas = np.array(metas)
+    table = torch.tensor(np.concatenate(cnn, 0), dtype=torch.float32, device=dev)
+    offs = np.array([0, cnn[0].shape[0]])
+    states = torch.randn(len(masks), 7, device=dev)
+    w = torch.randn(len(masks), hdim + 7, device=dev)
+    outs = []
+    for on in (True, False):
+        if not on:
+            gemm_tuning.disable()
+        torch.manual_seed(4)
+        vs = VideoStateNet(cdim, hdim, margin, "lstm", None, False).to(dev)
+        vs.attach_feature_table(table, offs)
+        vs.set_mode("train")
+        vs.initialize((masks, cnn, metas))
+        assert vs.cnn_feat_ctx.shape[1] == (n_ep + gemm_tuning.pad_to(n_ep, gemm_tuning.EPISODE_BUCKET) if on else n_ep)
+        out = vs(states)
+        (out * w).sum().backward()
+        outs.append((out.detach(), {k: p.grad.clone() for k, p in vs.named_parameters()}))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-4)
+    for k in outs[1][1]:
+        r = outs[1][1][k]
+        torch.testing.assert_close(outs[0][1][k], r, rtol=1e-3, atol=1e-3 * float(r.abs().max()) + 1e-6, msg=lambda m, k=k: k + ": " + m)
