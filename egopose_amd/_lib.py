@@ -108,6 +108,7 @@ SIGNATURES = {
     "egp_gae_f32": (C.c_int, [vp, vp, vp, _i32, _f64, _f64, vp, vp, vp, vp, vp]),
     "egp_gae_standardize_f64": (C.c_int, [vp, _i32, vp, vp]),
     "egp_gae_standardize_f32": (C.c_int, [vp, _i32, vp, vp]),
+    "egp_lstm_gate_layout": (_i32, []),
     "egp_lstm_fwd_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp]),
     "egp_lstm_bwd_f32": (C.c_int, [vp, vp, vp, vp, _i32, _i32, _i32, _i32, vp, vp]),
     "egp_upload_async": (C.c_int, [vp, vp, C.c_int64, vp]),

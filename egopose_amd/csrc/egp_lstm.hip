@@ -214,6 +214,277 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd(const float *__restrict__ d
 #undef EGP_LSTM_FETCH
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// MFMA recurrences. The FMA kernels above read the hidden tile with broadcast ds_read_b128 -- every lane receives
+// the same 16 bytes, and the LDS->VGPR return path (128 B/clk per CU) delivers 1 KiB per read: 4 waves x 16 reads x
+// TILE rows x 8 clk = 2-4 k clk per timestep, more than the FMAs themselves (measured 1.76 us per step at B = 1 280).
+// v_mfma_f32_4x4x1_16b_f32 takes the same product from per-lane operands instead: 16 independent 4x4 outer products
+// per instruction, block b = lanes 4b..4b+3; A[i] and B[j] come from lane 4b+i / 4b+j, D[i][j] lands in register i of
+// lane 4b+j. Exact f32 (an fmaf chain), 8 clk per instruction.
+//
+//   forward : block b of wave w = hidden unit u = 16w + b; A[i] = W_hh[gate i][u][k], B[j] = h[row j][k]; after the k
+//             loop lane (b, j) holds the four gate pre-activations of (row j, unit u) in its four accumulator
+//             registers, so the pointwise cell update stays in registers (no gate tile in LDS, one barrier per step).
+//   backward: wave (q, uh) multiplies a quarter of the d-gate columns with its 64 units' slice of W_hh:
+//             A[i] = W_hh[col c][64uh + 4b + i], B[j] = dpre[row j][col c]; the four partial sums meet in LDS.
+//
+// Gate layout (EGP_LSTM_GATES_UNIT_MAJOR): gates_x, the saved gates and d_pre are [T][B][unit][gate] -- the four gates
+// of a unit are one 16-byte access of the lane that owns them (1 load + 3 stores per step instead of 4 + 6; the stores
+// were a third of the step). The caller permutes the rows of W_ih / its bias once (256 x D) and un-permutes dW.
+// What bounds a step now (ablations on the MI355X, one workgroup per CU): LDS latency of the hidden-tile reads and the
+// barrier ~0.25 us, stores ~0.1 us, the 64 MFMAs hide behind both. NQ = row quads per workgroup.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// FULL = every row of every workgroup exists (B % ROWS == 0), TRAIN = gates / cells are saved. Both are template
+// parameters so that the timestep body is straight-line code: with a branch around any load or store the compiler's
+// s_waitcnt pass no longer knows how many memory operations are outstanding and waits for ALL of them (vmcnt(0))
+// before touching a prefetched register -- i.e. for the acknowledgement of the stores it has just issued, every step.
+template <int NQ, int LH, bool FULL, bool TRAIN>
+__global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restrict__ gx, const float *__restrict__ w_hh, int T, int B,
+                                                          int reverse, float *__restrict__ h_out, float *__restrict__ gates_out,
+                                                          float *__restrict__ c_out) {
+    constexpr int LG = 4 * LH, ROWS = 4 * NQ;
+    constexpr int PD = LH == 128 ? 2 : (NQ == 1 ? 8 : 4);   // steps per unrolled iteration = input-projection tiles in flight (even)
+    __shared__ __attribute__((aligned(16))) float s_h[2][ROWS][LH + 4];     // +4: the 4 rows of a read hit distinct banks
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = 16 * wave + (lane >> 2), sub = lane & 3;                   // sub = gate index as A, row-in-quad as B / D
+    const int r0 = blockIdx.x * ROWS;
+    float w[LH];
+#pragma unroll
+    for (int k = 0; k < LH; ++k) w[k] = w_hh[(long)(sub * LH + u) * LH + k];
+    float cst[NQ];
+    f32x4 pre[PD][NQ];
+    bool live[NQ];
+    int rowc[NQ];               // row to read: a missing row of a ragged last tile reads the last real row instead
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        cst[q] = 0.f;
+        live[q] = FULL || r0 + 4 * q + sub < B;
+        rowc[q] = live[q] ? r0 + 4 * q + sub : B - 1;
+    }
+    for (int i = threadIdx.x; i < 2 * ROWS * (LH + 4); i += 4 * LH) (&s_h[0][0][0])[i] = 0.f;
+
+#define EGP_LSTM_FETCH_GX(STEP, DST)                                                                 \
+    {                                                                                                \
+        const int f_s = (STEP) < T ? (STEP) : T - 1;                                                 \
+        const int f_t = reverse ? T - 1 - f_s : f_s;                                                 \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                               \
+            DST[q] = *reinterpret_cast<const f32x4 *>(gx + ((long)f_t * B + rowc[q]) * LG + 4 * u);  \
+    }
+
+    // one timestep: products, cell update in registers, stores, barrier
+    auto do_step = [&](const int step, const int par, const f32x4 (&init)[NQ]) {
+        const int t = reverse ? T - 1 - step : step;
+        // the whole hidden tile of this lane's rows first (16 reads per quad in flight, one exposed LDS latency) ...
+        // (64 hidden columns at a time: with LH = 128 the registers do not hold the whole row next to W_hh)
+        f32x4 acc[NQ], acc2[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { acc[q] = init[q]; acc2[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kc = 0; kc < LH; kc += 64) {
+            float4 hv[NQ][16];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int k4 = 0; k4 < 16; ++k4) hv[q][k4] = *reinterpret_cast<const float4 *>(&s_h[par][4 * q + sub][kc + 4 * k4]);
+            __builtin_amdgcn_sched_barrier(0);
+            // ... then the products; two accumulator chains per quad cover the dependent-issue latency (four: no gain)
+#pragma unroll
+            for (int k4 = 0; k4 < 16; ++k4)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[kc + 4 * k4 + 0], hv[q][k4].x, acc[q], 0, 0, 0);
+                    acc2[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[kc + 4 * k4 + 1], hv[q][k4].y, acc2[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[kc + 4 * k4 + 2], hv[q][k4].z, acc[q], 0, 0, 0);
+                    acc2[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[kc + 4 * k4 + 3], hv[q][k4].w, acc2[q], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const f32x4 a = acc[q] + acc2[q];
+            const float ig = sigmoidf_(a[0]), fg = sigmoidf_(a[1]), gg = tanhf_(a[2]), og = sigmoidf_(a[3]);
+            const float cn = fg * cst[q] + ig * gg;
+            const float hn = og * tanhf_(cn);
+            cst[q] = cn;
+            s_h[par ^ 1][4 * q + sub][u] = hn;
+            if (FULL || live[q]) {
+                const long row = (long)t * B + r0 + 4 * q + sub;
+                h_out[row * LH + u] = hn;
+                if (TRAIN) {
+                    *reinterpret_cast<f32x4 *>(gates_out + row * LG + 4 * u) = f32x4{ig, fg, gg, og};
+                    c_out[row * LH + u] = cn;
+                }
+            }
+        }
+        __syncthreads();       // the whole new hidden tile before the next step's products (s_h is double-buffered)
+    };
+
+#pragma unroll
+    for (int d = 0; d < PD; ++d) EGP_LSTM_FETCH_GX(d, pre[d])
+    __syncthreads();
+    int s0 = 0;
+    for (; s0 + PD <= T; s0 += PD) {
+        // this iteration's tiles move to `cur`, then ALL loads of the next iteration are issued before the first step:
+        // when they are needed (next iteration) only operations issued after them -- this iteration's stores -- may
+        // still be outstanding, so the in-order vmcnt wait never stalls on a young load or store. No exit from the
+        // middle of the iteration either (the remainder of T / PD runs in the plain loop below): every path into the
+        // wait must have issued the same operations.
+        f32x4 cur[PD][NQ];
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) cur[d][q] = pre[d][q];
+#pragma unroll
+        for (int d = 0; d < PD; ++d) EGP_LSTM_FETCH_GX(s0 + PD + d, pre[d])
+        // (past the end the fetch repeats the last step: the count of loads per iteration stays fixed.
+        //  In training gx doubles as gates_out: a lane re-reads only what it wrote itself, or has not reached yet)
+#pragma unroll
+        for (int d = 0; d < PD; ++d) do_step(s0 + d, d & 1, cur[d]);
+    }
+    for (int d = 0; s0 + d < T; ++d) {          // T % PD last steps: their tiles are pre[0..] (fetched, not clamped)
+        f32x4 last[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) last[q] = d == 0 ? pre[0][q] : d == 1 ? pre[1 % PD][q] : d == 2 ? pre[2 % PD][q] : d == 3 ? pre[3 % PD][q]
+                                             : d == 4 ? pre[4 % PD][q] : d == 5 ? pre[5 % PD][q] : pre[6 % PD][q];
+        do_step(s0 + d, d & 1, last);
+    }
+#undef EGP_LSTM_FETCH_GX
+}
+
+template <int NQ, int LH, bool FULL>
+__global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restrict__ dh_out, const float *__restrict__ gates,
+                                                          const float *__restrict__ cells, const float *__restrict__ w_hh, int T, int B,
+                                                          int reverse, float *__restrict__ dpre) {
+    constexpr int LG = 4 * LH, NT = 4 * LH, ROWS = 4 * NQ, UH = LH / 64;
+    constexpr int NP = (ROWS * LH + NT - 1) / NT;     // = NQ: (row, unit) pairs per thread in the pointwise phase
+    constexpr int PD = (NQ == 1 && LH == 64) ? 4 : 2;   // steps per unrolled iteration = operand sets in flight
+    __shared__ __attribute__((aligned(16))) float s_d[ROWS][LG + 4];     // d-gates of the step, [row][unit][gate]
+    __shared__ float s_part[4][ROWS][LH + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = wave / UH, uh = wave % UH, sub = lane & 3;
+    const int r0 = blockIdx.x * ROWS;
+    // wave (q, uh): d-gate columns [q*LH, (q+1)*LH) of the unit-major layout = units q*LH/4 .. , all four gates;
+    // column n = 4*unit + gate is row gate*LH + unit of W_hh
+    float w[LH];
+#pragma unroll
+    for (int cc = 0; cc < LH; ++cc) {
+        const int n = q * LH + cc;
+        w[cc] = w_hh[(long)((n & 3) * LH + (n >> 2)) * LH + 64 * uh + lane];
+    }
+    float dc_next[NP], dh_rec[NP];
+    f32x4 pg[PD][NP];
+    float pc[PD][NP], pdh[PD][NP];     // activated gates, cell state, dh of the staged steps
+    bool live[NP];
+    int rowc[NP];
+#pragma unroll
+    for (int qq = 0; qq < NP; ++qq) {
+        dc_next[qq] = 0.f; dh_rec[qq] = 0.f;
+        const int r = (threadIdx.x + NT * qq) / LH;
+        live[qq] = FULL || r0 + r < B;
+        rowc[qq] = live[qq] ? r0 + r : B - 1;
+    }
+
+#define EGP_LSTM_FETCH(STEP, D)                                                                      \
+    {                                                                                                \
+        const int f_s = (STEP) > 0 ? (STEP) : 0;                                                     \
+        const int f_t = reverse ? T - 1 - f_s : f_s;                                                 \
+        _Pragma("unroll") for (int qq = 0; qq < NP; ++qq) {                                          \
+            const int j = (threadIdx.x + NT * qq) % LH;                                              \
+            const long row = (long)f_t * B + rowc[qq];                                               \
+            pg[D][qq] = *reinterpret_cast<const f32x4 *>(gates + row * LG + 4 * j);                  \
+            pc[D][qq] = cells[row * LH + j];                                                         \
+            pdh[D][qq] = dh_out[row * LH + j];                                                       \
+        }                                                                                            \
+    }
+
+    // one timestep: d-gates of the step (pointwise), then the recurrent product dgates W_hh through the matrix cores
+    auto do_step = [&](const int step, const f32x4 (&g4)[NP], const float (&cc_)[NP], const float (&cdh)[NP], const float (&cprev)[NP]) {
+        const int t = reverse ? T - 1 - step : step;
+#pragma unroll
+        for (int qq = 0; qq < NP; ++qq) {
+            const int p = threadIdx.x + NT * qq, r = p / LH, j = p % LH;
+            const float ig = g4[qq][0], fg = g4[qq][1], gg = g4[qq][2], og = g4[qq][3];
+            const float c_prev = step > 0 ? cprev[qq] : 0.f;
+            const float tc = tanhf_(cc_[qq]);
+            const float dh = (FULL || live[qq] ? cdh[qq] : 0.f) + dh_rec[qq];
+            const float dc = dh * og * (1.f - tc * tc) + dc_next[qq];
+            const float d_o = dh * tc * og * (1.f - og);
+            const float di = dc * gg * ig * (1.f - ig);
+            const float df = dc * c_prev * fg * (1.f - fg);
+            const float dg = dc * ig * (1.f - gg * gg);
+            dc_next[qq] = dc * fg;
+            const f32x4 d4 = f32x4{di, df, dg, d_o};
+            if (FULL || live[qq]) *reinterpret_cast<f32x4 *>(dpre + ((long)t * B + r0 + r) * LG + 4 * j) = d4;
+            *reinterpret_cast<f32x4 *>(&s_d[r][4 * j]) = d4;
+        }
+        __syncthreads();
+        f32x4 acc[NQ], acc2[NQ];
+#pragma unroll
+        for (int qd = 0; qd < NQ; ++qd) acc[qd] = acc2[qd] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < LH; kc += 64) {
+            float4 dv[NQ][16];
+#pragma unroll
+            for (int qd = 0; qd < NQ; ++qd)
+#pragma unroll
+                for (int c4 = 0; c4 < 16; ++c4) dv[qd][c4] = *reinterpret_cast<const float4 *>(&s_d[4 * qd + sub][q * LH + kc + 4 * c4]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c4 = 0; c4 < 16; ++c4)
+#pragma unroll
+                for (int qd = 0; qd < NQ; ++qd) {
+                    acc[qd] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[kc + 4 * c4 + 0], dv[qd][c4].x, acc[qd], 0, 0, 0);
+                    acc2[qd] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[kc + 4 * c4 + 1], dv[qd][c4].y, acc2[qd], 0, 0, 0);
+                    acc[qd] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[kc + 4 * c4 + 2], dv[qd][c4].z, acc[qd], 0, 0, 0);
+                    acc2[qd] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[kc + 4 * c4 + 3], dv[qd][c4].w, acc2[qd], 0, 0, 0);
+                }
+        }
+        // D register i of lane (b, j) = partial dh_rec of (row j, unit 64uh + 4b + i)
+#pragma unroll
+        for (int qd = 0; qd < NQ; ++qd) {
+            const f32x4 a = acc[qd] + acc2[qd];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_part[q][4 * qd + sub][64 * uh + (lane & ~3) + i] = a[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qq = 0; qq < NP; ++qq) {
+            const int p = threadIdx.x + NT * qq, r = p / LH, j = p % LH;
+            dh_rec[qq] = s_part[0][r][j] + s_part[1][r][j] + s_part[2][r][j] + s_part[3][r][j];
+        }
+        // no third barrier: s_d is rewritten only after every wave passed the barrier above (its reads are done),
+        // s_part only after the next step's first barrier, which a wave reaches after these reads
+    };
+
+#pragma unroll
+    for (int d = 0; d < PD; ++d) EGP_LSTM_FETCH(T - 1 - d, d)
+    int s0 = T - 1;
+    for (; s0 - PD + 1 >= 0; s0 -= PD) {
+        // as in the forward kernel: this iteration's operands move to `c*`, all loads of the next iteration go out
+        // first, and nothing leaves the iteration half way
+        f32x4 cg[PD][NP];
+        float cc_[PD][NP], cdh[PD][NP];
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+#pragma unroll
+            for (int qq = 0; qq < NP; ++qq) {
+                cg[d][qq] = pg[d][qq];
+                cc_[d][qq] = pc[d][qq];
+                cdh[d][qq] = pdh[d][qq];
+            }
+#pragma unroll
+        for (int d = 0; d < PD; ++d) EGP_LSTM_FETCH(s0 - PD - d, d)      // (clamped at step 0: unused, fixed load count)
+#pragma unroll
+        for (int d = 0; d < PD; ++d)      // cell state of step - 1: the next stage of this iteration, or the first of the next
+            do_step(s0 - d, cg[d], cc_[d], cdh[d], d + 1 < PD ? cc_[d + 1 < PD ? d + 1 : 0] : pc[0]);
+    }
+#pragma unroll
+    for (int d = 0; d < PD - 1; ++d)      // T % PD last steps, staged in p*[0..]
+        if (s0 - d >= 0) do_step(s0 - d, pg[d], pc[d], pdh[d], pc[d + 1]);
+#undef EGP_LSTM_FETCH
+}
+
 }  // namespace egp
 
 using namespace egp;
@@ -223,6 +494,17 @@ static int lstm_tile(int B) {
     const char *e = getenv("EGP_LSTM_TILE");
     if (e) { const int t = atoi(e); if (t == 2 || t == 4 || t == 8 || t == 16) return t; }
     return B >= 16384 ? 16 : (B >= 8192 ? 8 : 4);
+}
+
+// EGP_LSTM_MFMA=0 selects the FMA kernels (A/B runs); the MFMA kernels take row quads: TILE 4, 8 or 16
+static bool lstm_mfma() {
+    static const bool on = [] { const char *e = getenv("EGP_LSTM_MFMA"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+static int lstm_quads(int B) {
+    const char *e = getenv("EGP_LSTM_TILE");
+    if (e) { const int t = atoi(e); if (t == 4 || t == 8) return t / 4; }
+    return B >= 4096 ? 2 : 1;
 }
 
 static int lstm_launch_check(const char *what) {
@@ -260,7 +542,39 @@ static void launch_bwd(int tile, const float *dh_out, const float *gates_save, c
         k_lstm_bwd<2, LH><<<dim3((B + 1) / 2), dim3(4 * LH), 0, s>>>(dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre);
 }
 
+template <int NQ, int LH>
+static void launch_fwd_mfma_t(bool full, bool train, const float *gx, const float *w_hh, int T, int B, int reverse, float *h_out, float *gates_save,
+                              float *cells_save, hipStream_t s) {
+    const dim3 grid((B + 4 * NQ - 1) / (4 * NQ)), block(4 * LH);
+    if (full && train) k_lstm_fwd_mfma<NQ, LH, true, true><<<grid, block, 0, s>>>(gx, w_hh, T, B, reverse, h_out, gates_save, cells_save);
+    else if (full) k_lstm_fwd_mfma<NQ, LH, true, false><<<grid, block, 0, s>>>(gx, w_hh, T, B, reverse, h_out, gates_save, cells_save);
+    else if (train) k_lstm_fwd_mfma<NQ, LH, false, true><<<grid, block, 0, s>>>(gx, w_hh, T, B, reverse, h_out, gates_save, cells_save);
+    else k_lstm_fwd_mfma<NQ, LH, false, false><<<grid, block, 0, s>>>(gx, w_hh, T, B, reverse, h_out, gates_save, cells_save);
+}
+static void launch_fwd_mfma(int hidden, int nq, bool full, bool train, const float *gx, const float *w_hh, int T, int B, int reverse, float *h_out,
+                            float *gates_save, float *cells_save, hipStream_t s) {
+    if (hidden == 128) launch_fwd_mfma_t<1, 128>(full, train, gx, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
+    else if (nq >= 2) launch_fwd_mfma_t<2, 64>(full, train, gx, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
+    else launch_fwd_mfma_t<1, 64>(full, train, gx, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
+}
+
+template <int NQ, int LH>
+static void launch_bwd_mfma_t(bool full, const float *dh_out, const float *gates_save, const float *cells_save, const float *w_hh, int T, int B,
+                              int reverse, float *d_pre, hipStream_t s) {
+    const dim3 grid((B + 4 * NQ - 1) / (4 * NQ)), block(4 * LH);
+    if (full) k_lstm_bwd_mfma<NQ, LH, true><<<grid, block, 0, s>>>(dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre);
+    else k_lstm_bwd_mfma<NQ, LH, false><<<grid, block, 0, s>>>(dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre);
+}
+static void launch_bwd_mfma(int hidden, int nq, bool full, const float *dh_out, const float *gates_save, const float *cells_save, const float *w_hh,
+                            int T, int B, int reverse, float *d_pre, hipStream_t s) {
+    if (hidden == 128) launch_bwd_mfma_t<1, 128>(full, dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
+    else if (nq >= 2) launch_bwd_mfma_t<2, 64>(full, dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
+    else launch_bwd_mfma_t<1, 64>(full, dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
+}
+
 extern "C" {
+
+int32_t egp_lstm_gate_layout(void) { return lstm_mfma() ? EGP_LSTM_GATES_UNIT_MAJOR : EGP_LSTM_GATES_TORCH; }
 
 int egp_lstm_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t B, int32_t hidden, int32_t reverse,
                      float *h_out, float *gates_save, float *cells_save, void *stream) {
@@ -270,7 +584,10 @@ int egp_lstm_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t
     EGP_REQUIRE(gates_x && w_hh && h_out, "NULL pointer");
     EGP_REQUIRE((gates_save == nullptr) == (cells_save == nullptr), "gates_save and cells_save go together");
     hipStream_t s = (hipStream_t)stream;
-    if (hidden == 64) launch_fwd<64>(lstm_tile(B), gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
+    if (lstm_mfma()) {
+        const int nq = hidden == 64 ? lstm_quads(B) : 1;
+        launch_fwd_mfma(hidden, nq, B % (4 * nq) == 0, gates_save != nullptr, gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
+    } else if (hidden == 64) launch_fwd<64>(lstm_tile(B), gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
     else launch_fwd<128>(4, gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
     return lstm_launch_check("k_lstm_fwd");
 }
@@ -282,7 +599,10 @@ int egp_lstm_bwd_f32(const float *dh_out, const float *gates_save, const float *
     if (T == 0 || B == 0) return EGP_OK;
     EGP_REQUIRE(dh_out && gates_save && cells_save && w_hh && d_pre, "NULL pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (hidden == 64) launch_bwd<64>(lstm_tile(B), dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
+    if (lstm_mfma()) {
+        const int nq = hidden == 64 ? lstm_quads(B) : 1;
+        launch_bwd_mfma(hidden, nq, B % (4 * nq) == 0, dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
+    } else if (hidden == 64) launch_bwd<64>(lstm_tile(B), dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
     else launch_bwd<128>(4, dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
     return lstm_launch_check("k_lstm_bwd");
 }

@@ -32,6 +32,22 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+_PERM = {}
+
+
+def _gate_perm(hidden, device):
+    """Row permutation W_ih -> the kernels' gate layout (include/egopose_hip.h): unit-major column n = 4*u + g
+    takes torch row g*H + u; None when the build uses torch's own order."""
+    if L.load().egp_lstm_gate_layout() == 0:
+        return None
+    key = (hidden, str(device))
+    if key not in _PERM:
+        n = torch.arange(4 * hidden, device=device)
+        perm = (n % 4) * hidden + n // 4
+        _PERM[key] = (perm, torch.argsort(perm))
+    return _PERM[key]
+
+
 class LstmDirection(torch.autograd.Function):
 
     @staticmethod
@@ -40,17 +56,22 @@ class LstmDirection(torch.autograd.Function):
         T, B, D = x.shape
         HIDDEN = w_hh.shape[1]
         x2 = x.reshape(T * B, D)
-        gx = torch.addmm(b_ih + b_hh, x2, w_ih.t()).view(T, B, 4 * HIDDEN)
+        pp = _gate_perm(HIDDEN, x.device)
+        bias = b_ih + b_hh
+        w_in = w_ih
+        if pp is not None:
+            w_in, bias = w_ih.index_select(0, pp[0]), bias.index_select(0, pp[0])
+        gx = torch.addmm(bias, x2, w_in.t()).view(T, B, 4 * HIDDEN)
         h = torch.empty(T, B, HIDDEN, dtype=x.dtype, device=x.device)
         train = any(ctx.needs_input_grad)
         cells = torch.empty(T, B, HIDDEN, dtype=x.dtype, device=x.device) if train else None
         w_hh_c = w_hh.contiguous()
-        # the activated gates overwrite the pre-activations in place (each workgroup reads its tile of gx[t]
-        # before the barrier that precedes the writes)
+        # the activated gates overwrite the pre-activations in place (a thread reads its part of gx[t] before it
+        # writes the same addresses)
         L.check(lib.egp_lstm_fwd_f32(_p(gx), _p(w_hh_c), T, B, HIDDEN, 1 if reverse else 0, _p(h),
                                      _p(gx if train else None), _p(cells), _s()), "egp_lstm_fwd_f32")
         if train:
-            ctx.save_for_backward(x2, w_ih, w_hh_c, h, gx, cells)
+            ctx.save_for_backward(x2, w_in, w_hh_c, h, gx, cells)
             ctx.reverse = bool(reverse)
             ctx.shape = (T, B, D)
         return h
@@ -58,7 +79,7 @@ class LstmDirection(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh):
         lib = L.load()
-        x2, w_ih, w_hh, h, gates, cells = ctx.saved_tensors
+        x2, w_in, w_hh, h, gates, cells = ctx.saved_tensors
         T, B, D = ctx.shape
         HIDDEN = w_hh.shape[1]
         dpre = torch.empty(T, B, 4 * HIDDEN, dtype=h.dtype, device=h.device)
@@ -69,11 +90,14 @@ class LstmDirection(torch.autograd.Function):
         # dW_ih | dW_hh | db in ONE batched GEMM over the time axis + a reduction: [dPre_t^T (x_t | h_prev_t | 1)]
         # (a single (4H x T*B) @ (T*B x D) product runs 3x slower in rocBLAS than T independent ones)
         xh1 = torch.cat((x2.view(T, B, D), h_prev, h.new_ones(T, B, 1)), 2)
-        dw = torch.bmm(dpre.transpose(1, 2), xh1).sum(0)                       # (4H, D + H + 1)
+        dw = torch.bmm(dpre.transpose(1, 2), xh1).sum(0)                       # (4H, D + H + 1), rows in the kernels' gate layout
+        pp = _gate_perm(HIDDEN, h.device)
+        if pp is not None:
+            dw = dw.index_select(0, pp[1])
         d_w_ih = dw[:, :D].contiguous() if ctx.needs_input_grad[1] else None
         d_w_hh = dw[:, D:D + HIDDEN].contiguous() if ctx.needs_input_grad[2] else None
         d_b = dw[:, D + HIDDEN].contiguous() if (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else None
-        d_x = dpre.view(T * B, 4 * HIDDEN).mm(w_ih).view(T, B, D) if ctx.needs_input_grad[0] else None
+        d_x = dpre.view(T * B, 4 * HIDDEN).mm(w_in).view(T, B, D) if ctx.needs_input_grad[0] else None
         return d_x, d_w_ih, d_w_hh, d_b, d_b, None
 
 

@@ -202,10 +202,17 @@ int egp_gae_standardize_f64(double *adv, int32_t n, const double *stats, void *s
 int egp_gae_standardize_f32(float *adv, int32_t n, const double *stats, void *stream);
 
 /* ---------------------------------------------------------------------------------------- LSTM
- * Recurrent sweep of ONE direction of the video-context LSTM (hidden size 64, float32, zero initial state):
+ * Recurrent sweep of ONE direction of the video-context LSTM (hidden size 64 or 128, float32, zero initial state):
  * the t-loop of RNN.batch_forward (models/rnn.py:45-61) in one launch.
- *   gates_x [T][B][256] = x_t W_ih^T + b_ih + b_hh (gate order i,f,g,o);  w_hh [256][64]
- *   h_out [T][B][64];  gates_save [T][B][256] (may alias gates_x) / cells_save [T][B][64]: both NULL for inference */
+ *   gates_x [T][B][4H] = x_t W_ih^T + b_ih + b_hh;  w_hh [4H][H] (torch.nn.LSTMCell order: rows i, f, g, o)
+ *   h_out [T][B][H];  gates_save [T][B][4H] (may alias gates_x) / cells_save [T][B][H]: both NULL for inference
+ * gates_x, gates_save and d_pre use the layout egp_lstm_gate_layout() reports: EGP_LSTM_GATES_TORCH = [gate][unit] as
+ * torch (column g*H + u), EGP_LSTM_GATES_UNIT_MAJOR = [unit][gate] (column 4*u + g; what the matrix-core kernels use:
+ * the four gates of a unit are one 16-byte access). The caller permutes the rows of W_ih and of the bias accordingly
+ * (4H x D, once per call) and un-permutes the rows of the weight gradient it forms from d_pre. */
+#define EGP_LSTM_GATES_TORCH 0
+#define EGP_LSTM_GATES_UNIT_MAJOR 1
+int32_t egp_lstm_gate_layout(void);
 int egp_lstm_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t B, int32_t hidden, int32_t reverse,
                      float *h_out, float *gates_save, float *cells_save, void *stream);
 /* backward-through-time of the same sweep: d_pre [T][B][256] = gradient w.r.t. the pre-activation gates; the

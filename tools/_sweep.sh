@@ -6,5 +6,5 @@ for l in sys.stdin:
         d=json.loads(l); print('$label', round(d['value']), 'tsample', round(d['t_sample_s'],3), 'tupdate', round(d['t_update_s'],3))
 "
 }
-for i in 1 2; do ENVV="EGP_TUNED_GEMMS=0" run fc_default --task egoforecast; ENVV="EGP_X=1" run fc_tuned --task egoforecast; done
-ENVV="EGP_X=1" run mimic_tuned
+for i in 1 2; do ENVV="EGP_LSTM_MFMA=0" run fma; ENVV="EGP_LSTM_MFMA=1" run mfma; ENVV="EGP_UPDATE_OVERLAP=1" run mfma_overlap; done
+ENVV="EGP_X=1" run forecast --task egoforecast
