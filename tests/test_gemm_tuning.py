@@ -20,7 +20,8 @@ def test_shipped_picks_file_is_well_formed():
     for k, m in ((243, 300), (300, 200), (200, 52)):
         assert any(l.startswith("GemmAndBiasTunableOp_float_TN,tn_%d_" % m) and ("_%d_ld_" % k) in l for l in lines), (k, m)
     rows = [int(l.split(",")[1].split("_")[2]) for l in lines if l.startswith("GemmAndBiasTunableOp_float_TN,tn_300_")]
-    assert rows and all(r % gemm_tuning.ROW_BUCKET == 0 for r in rows)
+    big = [r for r in rows if r >= 4 * gemm_tuning.ROW_BUCKET]       # (small entries: per-tick batches of the rollout)
+    assert big and all(r % gemm_tuning.ROW_BUCKET == 0 for r in big)
 
 
 def test_bucket_rows_is_a_no_op_when_disabled_or_on_cpu():
