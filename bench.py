@@ -14,12 +14,17 @@ Prints ONE JSON line (rank 0) with the driver's fields plus
                bounded sample, same physics backend (rank 0, N=1 only)
 """
 import argparse
+import faulthandler
 import json
 import os
 import subprocess
 import sys
 import tempfile
 import time
+
+import signal
+
+faulthandler.register(signal.SIGUSR1, all_threads=True)       # `kill -USR1 <pid>`: where is a stuck run waiting?
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)

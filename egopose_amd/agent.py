@@ -221,7 +221,7 @@ class AgentPPO(AgentPG):
         n_val = D.global_count(states.shape[0], states.device)
         n_exp = D.global_count(ind.shape[0], states.device)
         losses = []
-        overlap = states.is_cuda and os.environ.get("EGP_UPDATE_OVERLAP", "1") != "0"
+        overlap = states.is_cuda and os.environ.get("EGP_UPDATE_OVERLAP", "0") != "0"
         if overlap:
             if getattr(self, "_streams", None) is None:
                 self._streams = (torch.cuda.Stream(device=states.device), torch.cuda.Stream(device=states.device))

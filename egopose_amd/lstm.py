@@ -62,7 +62,11 @@ class LstmDirection(torch.autograd.Function):
         if pp is not None:
             w_in, bias = w_ih.index_select(0, pp[0]), bias.index_select(0, pp[0])
         gx = torch.addmm(bias, x2, w_in.t()).view(T, B, 4 * HIDDEN)
-        h = torch.empty(T, B, HIDDEN, dtype=x.dtype, device=x.device)
+        # T + 1 time slots with a zero one in front (behind, for the reverse direction): h and the h_prev the weight
+        # gradient needs are two views of the same buffer
+        h_buf = torch.empty(T + 1, B, HIDDEN, dtype=x.dtype, device=x.device)
+        h_buf[T if reverse else 0].zero_()
+        h = h_buf[:T] if reverse else h_buf[1:]
         train = any(ctx.needs_input_grad)
         cells = torch.empty(T, B, HIDDEN, dtype=x.dtype, device=x.device) if train else None
         w_hh_c = w_hh.contiguous()
@@ -71,7 +75,7 @@ class LstmDirection(torch.autograd.Function):
         L.check(lib.egp_lstm_fwd_f32(_p(gx), _p(w_hh_c), T, B, HIDDEN, 1 if reverse else 0, _p(h),
                                      _p(gx if train else None), _p(cells), _s()), "egp_lstm_fwd_f32")
         if train:
-            ctx.save_for_backward(x2, w_in, w_hh_c, h, gx, cells)
+            ctx.save_for_backward(x2, w_in, w_hh_c, h_buf, gx, cells)
             ctx.reverse = bool(reverse)
             ctx.shape = (T, B, D)
         return h
@@ -79,16 +83,17 @@ class LstmDirection(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh):
         lib = L.load()
-        x2, w_in, w_hh, h, gates, cells = ctx.saved_tensors
+        x2, w_in, w_hh, h_buf, gates, cells = ctx.saved_tensors
         T, B, D = ctx.shape
         HIDDEN = w_hh.shape[1]
+        h = h_buf
         dpre = torch.empty(T, B, 4 * HIDDEN, dtype=h.dtype, device=h.device)
         L.check(lib.egp_lstm_bwd_f32(_p(dh.contiguous()), _p(gates), _p(cells), _p(w_hh), T, B, HIDDEN,
                                      1 if ctx.reverse else 0, _p(dpre), _s()), "egp_lstm_bwd_f32")
-        zero = h.new_zeros(1, B, HIDDEN)
-        h_prev = torch.cat((h[1:], zero), 0) if ctx.reverse else torch.cat((zero, h[:-1]), 0)
+        h_prev = h_buf[1:] if ctx.reverse else h_buf[:T]
         # dW_ih | dW_hh | db in ONE batched GEMM over the time axis + a reduction: [dPre_t^T (x_t | h_prev_t | 1)]
-        # (a single (4H x T*B) @ (T*B x D) product runs 3x slower in rocBLAS than T independent ones)
+        # (a single (4H x T*B) @ (T*B x D) product runs 3x slower in rocBLAS than T independent ones; separate
+        # products per operand would read dPre three times)
         xh1 = torch.cat((x2.view(T, B, D), h_prev, h.new_ones(T, B, 1)), 2)
         dw = torch.bmm(dpre.transpose(1, 2), xh1).sum(0)                       # (4H, D + H + 1), rows in the kernels' gate layout
         pp = _gate_perm(HIDDEN, h.device)
