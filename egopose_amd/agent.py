@@ -198,6 +198,10 @@ class AgentPPO(AgentPG):
         self.clip_epsilon, self.opt_batch_size = clip_epsilon, opt_batch_size
         self.use_mini_batch, self.policy_grad_clip = use_mini_batch, policy_grad_clip
 
+    def _group_contexts(self):
+        """Hook: prepare the critic's and the actor's state transforms together (AgentEgo). False = nothing prepared."""
+        return False
+
     def clip_policy_grad(self):
         if self.policy_grad_clip is not None:
             for params, max_norm in self.policy_grad_clip:
@@ -242,6 +246,17 @@ class AgentPPO(AgentPG):
                     s_loss.backward()
                 main.wait_stream(s_v)
                 main.wait_stream(s_p)
+            elif self._group_contexts():
+                # both video nets' recurrences in one grouped launch each way; disjoint parameters, so one backward
+                # over the sum of the two losses yields exactly the two separate gradients
+                if self.value_opt_niter != 1:
+                    raise NotImplementedError("value_opt_niter != 1 is not on the ego_mimic path")
+                pred = self.value_net(self.trans_value(states))
+                v_loss = (pred - returns).pow(2).sum() / n_val
+                s_loss = self.ppo_loss(states, actions, advantages, fixed_log_probs, ind, n_exp)
+                self.optimizer_value.zero_grad()
+                self.optimizer_policy.zero_grad()
+                (v_loss + s_loss).backward()
             else:
                 v_loss = self._value_backward(states, returns, n_val)
                 s_loss = self.ppo_loss(states, actions, advantages, fixed_log_probs, ind, n_exp)
@@ -280,6 +295,10 @@ class AgentEgo(AgentPPO):
 
     def push_memory(self, memory, state, action, mask, next_state, reward, exp):
         memory.push(state, action, mask, next_state, reward, exp, np.array([self.env.expert_ind, self.env.start_ind]))
+
+    def _group_contexts(self):
+        from .nets import grouped_video_context
+        return grouped_video_context([self.value_vs_net, self.policy_vs_net])
 
     def trans_policy(self, states):
         return self.policy_vs_net(states)

@@ -236,15 +236,31 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd(const float *__restrict__ d
 // barrier ~0.25 us, stores ~0.1 us, the 64 MFMAs hide behind both. NQ = row quads per workgroup.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Several sweeps over the same (T, B) in one launch (blockIdx.y = problem): the directions of a bi-LSTM, or the LSTMs of
+// the critic's and the actor's video nets -- a sweep is latency-bound and 320 workgroups leave 64 CUs with double
+// duty; 4 x 320 = 5 per CU. Problems share one gate buffer [T*B][P*4H] (columns p*4H.. belong to problem p: what ONE
+// input-projection GEMM against the stacked W_ih produces) and differ in W_hh, direction and output slabs.
+struct LstmGroup {
+    int ld_g;               // row stride of gates_x / gates_save / d_pre (floats): P * 4H
+    int rev_mask;           // bit p: problem p runs t = T-1 .. 0
+    long h_stride;          // floats between the h_out (fwd) slabs of consecutive problems
+    long c_stride;          // ... cells_save slabs
+    const float *dh[4];     // backward: d h_out per problem ([T][B][H] each)
+    float *db;              // backward, optional: [P][4H] accumulates sum_t,b d_pre (atomics; zeroed by the caller)
+};
+
 // FULL = every row of every workgroup exists (B % ROWS == 0), TRAIN = gates / cells are saved. Both are template
 // parameters so that the timestep body is straight-line code: with a branch around any load or store the compiler's
 // s_waitcnt pass no longer knows how many memory operations are outstanding and waits for ALL of them (vmcnt(0))
 // before touching a prefetched register -- i.e. for the acknowledgement of the stores it has just issued, every step.
 template <int NQ, int LH, bool FULL, bool TRAIN>
 __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restrict__ gx, const float *__restrict__ w_hh, int T, int B,
-                                                          int reverse, float *__restrict__ h_out, float *__restrict__ gates_out,
+                                                          LstmGroup grp, float *__restrict__ h_out, float *__restrict__ gates_out,
                                                           float *__restrict__ c_out) {
     constexpr int LG = 4 * LH, ROWS = 4 * NQ;
+    const int prob = blockIdx.y, reverse = (grp.rev_mask >> prob) & 1, ld = grp.ld_g;
+    gx += prob * LG; w_hh += (long)prob * LG * LH; h_out += prob * grp.h_stride;
+    if (TRAIN) { gates_out += prob * LG; c_out += prob * grp.c_stride; }
     constexpr int PD = LH == 128 ? 2 : (NQ == 1 ? 8 : 4);   // steps per unrolled iteration = input-projection tiles in flight (even)
     __shared__ __attribute__((aligned(16))) float s_h[2][ROWS][LH + 4];     // +4: the 4 rows of a read hit distinct banks
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
         const int f_s = (STEP) < T ? (STEP) : T - 1;                                                 \
         const int f_t = reverse ? T - 1 - f_s : f_s;                                                 \
         _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                               \
-            DST[q] = *reinterpret_cast<const f32x4 *>(gx + ((long)f_t * B + rowc[q]) * LG + 4 * u);  \
+            DST[q] = *reinterpret_cast<const f32x4 *>(gx + ((long)f_t * B + rowc[q]) * ld + 4 * u);  \
     }
 
     // one timestep: products, cell update in registers, stores, barrier
@@ -312,7 +328,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
                 const long row = (long)t * B + r0 + 4 * q + sub;
                 h_out[row * LH + u] = hn;
                 if (TRAIN) {
-                    *reinterpret_cast<f32x4 *>(gates_out + row * LG + 4 * u) = f32x4{ig, fg, gg, og};
+                    *reinterpret_cast<f32x4 *>(gates_out + row * ld + 4 * u) = f32x4{ig, fg, gg, og};
                     c_out[row * LH + u] = cn;
                 }
             }
@@ -353,10 +369,13 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
 }
 
 template <int NQ, int LH, bool FULL>
-__global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restrict__ dh_out, const float *__restrict__ gates,
-                                                          const float *__restrict__ cells, const float *__restrict__ w_hh, int T, int B,
-                                                          int reverse, float *__restrict__ dpre) {
+__global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restrict__ gates, const float *__restrict__ cells,
+                                                          const float *__restrict__ w_hh, int T, int B, LstmGroup grp,
+                                                          float *__restrict__ dpre) {
     constexpr int LG = 4 * LH, NT = 4 * LH, ROWS = 4 * NQ, UH = LH / 64;
+    const int prob = blockIdx.y, reverse = (grp.rev_mask >> prob) & 1, ld = grp.ld_g;
+    const float *__restrict__ dh_out = grp.dh[prob];
+    gates += prob * LG; dpre += prob * LG; cells += prob * grp.c_stride; w_hh += (long)prob * LG * LH;
     constexpr int NP = (ROWS * LH + NT - 1) / NT;     // = NQ: (row, unit) pairs per thread in the pointwise phase
     constexpr int PD = (NQ == 1 && LH == 64) ? 4 : 2;   // steps per unrolled iteration = operand sets in flight
     __shared__ __attribute__((aligned(16))) float s_d[ROWS][LG + 4];     // d-gates of the step, [row][unit][gate]
@@ -373,13 +392,14 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
         w[cc] = w_hh[(long)((n & 3) * LH + (n >> 2)) * LH + 64 * uh + lane];
     }
     float dc_next[NP], dh_rec[NP];
+    f32x4 dsum[NP];                    // sum over time of this thread's d-gates: the bias gradient, reduced at the end
     f32x4 pg[PD][NP];
     float pc[PD][NP], pdh[PD][NP];     // activated gates, cell state, dh of the staged steps
     bool live[NP];
     int rowc[NP];
 #pragma unroll
     for (int qq = 0; qq < NP; ++qq) {
-        dc_next[qq] = 0.f; dh_rec[qq] = 0.f;
+        dc_next[qq] = 0.f; dh_rec[qq] = 0.f; dsum[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int r = (threadIdx.x + NT * qq) / LH;
         live[qq] = FULL || r0 + r < B;
         rowc[qq] = live[qq] ? r0 + r : B - 1;
@@ -392,7 +412,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
         _Pragma("unroll") for (int qq = 0; qq < NP; ++qq) {                                          \
             const int j = (threadIdx.x + NT * qq) % LH;                                              \
             const long row = (long)f_t * B + rowc[qq];                                               \
-            pg[D][qq] = *reinterpret_cast<const f32x4 *>(gates + row * LG + 4 * j);                  \
+            pg[D][qq] = *reinterpret_cast<const f32x4 *>(gates + row * ld + 4 * j);                  \
             pc[D][qq] = cells[row * LH + j];                                                         \
             pdh[D][qq] = dh_out[row * LH + j];                                                       \
         }                                                                                            \
@@ -415,7 +435,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
             const float dg = dc * ig * (1.f - gg * gg);
             dc_next[qq] = dc * fg;
             const f32x4 d4 = f32x4{di, df, dg, d_o};
-            if (FULL || live[qq]) *reinterpret_cast<f32x4 *>(dpre + ((long)t * B + r0 + r) * LG + 4 * j) = d4;
+            if (FULL || live[qq]) { *reinterpret_cast<f32x4 *>(dpre + ((long)t * B + r0 + r) * ld + 4 * j) = d4; dsum[qq] += d4; }
             *reinterpret_cast<f32x4 *>(&s_d[r][4 * j]) = d4;
         }
         __syncthreads();
@@ -483,6 +503,21 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
     for (int d = 0; d < PD - 1; ++d)      // T % PD last steps, staged in p*[0..]
         if (s0 - d >= 0) do_step(s0 - d, pg[d], pc[d], pdh[d], pc[d + 1]);
 #undef EGP_LSTM_FETCH
+    if (grp.db) {                         // db[4*unit + gate] += sum over this workgroup's rows (s_d is free again)
+        __syncthreads();
+#pragma unroll
+        for (int qq = 0; qq < NP; ++qq) {
+            const int p = threadIdx.x + NT * qq;
+            *reinterpret_cast<f32x4 *>(&s_d[p / LH][4 * (p % LH)]) = dsum[qq];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < LG; c += NT) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) a += s_d[r][c];
+            atomicAdd(grp.db + prob * LG + c, a);
+        }
+    }
 }
 
 }  // namespace egp
@@ -543,33 +578,37 @@ static void launch_bwd(int tile, const float *dh_out, const float *gates_save, c
 }
 
 template <int NQ, int LH>
-static void launch_fwd_mfma_t(bool full, bool train, const float *gx, const float *w_hh, int T, int B, int reverse, float *h_out, float *gates_save,
-                              float *cells_save, hipStream_t s) {
-    const dim3 grid((B + 4 * NQ - 1) / (4 * NQ)), block(4 * LH);
-    if (full && train) k_lstm_fwd_mfma<NQ, LH, true, true><<<grid, block, 0, s>>>(gx, w_hh, T, B, reverse, h_out, gates_save, cells_save);
-    else if (full) k_lstm_fwd_mfma<NQ, LH, true, false><<<grid, block, 0, s>>>(gx, w_hh, T, B, reverse, h_out, gates_save, cells_save);
-    else if (train) k_lstm_fwd_mfma<NQ, LH, false, true><<<grid, block, 0, s>>>(gx, w_hh, T, B, reverse, h_out, gates_save, cells_save);
-    else k_lstm_fwd_mfma<NQ, LH, false, false><<<grid, block, 0, s>>>(gx, w_hh, T, B, reverse, h_out, gates_save, cells_save);
+static void launch_fwd_mfma_t(bool full, bool train, int P, const float *gx, const float *w_hh, int T, int B, const LstmGroup &g, float *h_out,
+                              float *gates_save, float *cells_save, hipStream_t s) {
+    const dim3 grid((B + 4 * NQ - 1) / (4 * NQ), P), block(4 * LH);
+    if (full && train) k_lstm_fwd_mfma<NQ, LH, true, true><<<grid, block, 0, s>>>(gx, w_hh, T, B, g, h_out, gates_save, cells_save);
+    else if (full) k_lstm_fwd_mfma<NQ, LH, true, false><<<grid, block, 0, s>>>(gx, w_hh, T, B, g, h_out, gates_save, cells_save);
+    else if (train) k_lstm_fwd_mfma<NQ, LH, false, true><<<grid, block, 0, s>>>(gx, w_hh, T, B, g, h_out, gates_save, cells_save);
+    else k_lstm_fwd_mfma<NQ, LH, false, false><<<grid, block, 0, s>>>(gx, w_hh, T, B, g, h_out, gates_save, cells_save);
 }
-static void launch_fwd_mfma(int hidden, int nq, bool full, bool train, const float *gx, const float *w_hh, int T, int B, int reverse, float *h_out,
+static void launch_fwd_mfma(int hidden, int P, const float *gx, const float *w_hh, int T, int B, const LstmGroup &g, float *h_out,
                             float *gates_save, float *cells_save, hipStream_t s) {
-    if (hidden == 128) launch_fwd_mfma_t<1, 128>(full, train, gx, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
-    else if (nq >= 2) launch_fwd_mfma_t<2, 64>(full, train, gx, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
-    else launch_fwd_mfma_t<1, 64>(full, train, gx, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
+    const int nq = hidden == 64 ? lstm_quads(B) : 1;      // (4-row workgroups also win for grouped launches: measured)
+    const bool full = B % (4 * nq) == 0, train = gates_save != nullptr;
+    if (hidden == 128) launch_fwd_mfma_t<1, 128>(full, train, P, gx, w_hh, T, B, g, h_out, gates_save, cells_save, s);
+    else if (nq >= 2) launch_fwd_mfma_t<2, 64>(full, train, P, gx, w_hh, T, B, g, h_out, gates_save, cells_save, s);
+    else launch_fwd_mfma_t<1, 64>(full, train, P, gx, w_hh, T, B, g, h_out, gates_save, cells_save, s);
 }
 
 template <int NQ, int LH>
-static void launch_bwd_mfma_t(bool full, const float *dh_out, const float *gates_save, const float *cells_save, const float *w_hh, int T, int B,
-                              int reverse, float *d_pre, hipStream_t s) {
-    const dim3 grid((B + 4 * NQ - 1) / (4 * NQ)), block(4 * LH);
-    if (full) k_lstm_bwd_mfma<NQ, LH, true><<<grid, block, 0, s>>>(dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre);
-    else k_lstm_bwd_mfma<NQ, LH, false><<<grid, block, 0, s>>>(dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre);
+static void launch_bwd_mfma_t(bool full, int P, const float *gates_save, const float *cells_save, const float *w_hh, int T, int B,
+                              const LstmGroup &g, float *d_pre, hipStream_t s) {
+    const dim3 grid((B + 4 * NQ - 1) / (4 * NQ), P), block(4 * LH);
+    if (full) k_lstm_bwd_mfma<NQ, LH, true><<<grid, block, 0, s>>>(gates_save, cells_save, w_hh, T, B, g, d_pre);
+    else k_lstm_bwd_mfma<NQ, LH, false><<<grid, block, 0, s>>>(gates_save, cells_save, w_hh, T, B, g, d_pre);
 }
-static void launch_bwd_mfma(int hidden, int nq, bool full, const float *dh_out, const float *gates_save, const float *cells_save, const float *w_hh,
-                            int T, int B, int reverse, float *d_pre, hipStream_t s) {
-    if (hidden == 128) launch_bwd_mfma_t<1, 128>(full, dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
-    else if (nq >= 2) launch_bwd_mfma_t<2, 64>(full, dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
-    else launch_bwd_mfma_t<1, 64>(full, dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
+static void launch_bwd_mfma(int hidden, int P, const float *gates_save, const float *cells_save, const float *w_hh, int T, int B,
+                            const LstmGroup &g, float *d_pre, hipStream_t s) {
+    const int nq = hidden == 64 ? lstm_quads(B) : 1;      // (4-row workgroups also win for grouped launches: measured)
+    const bool full = B % (4 * nq) == 0;
+    if (hidden == 128) launch_bwd_mfma_t<1, 128>(full, P, gates_save, cells_save, w_hh, T, B, g, d_pre, s);
+    else if (nq >= 2) launch_bwd_mfma_t<2, 64>(full, P, gates_save, cells_save, w_hh, T, B, g, d_pre, s);
+    else launch_bwd_mfma_t<1, 64>(full, P, gates_save, cells_save, w_hh, T, B, g, d_pre, s);
 }
 
 extern "C" {
@@ -585,8 +624,9 @@ int egp_lstm_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t
     EGP_REQUIRE((gates_save == nullptr) == (cells_save == nullptr), "gates_save and cells_save go together");
     hipStream_t s = (hipStream_t)stream;
     if (lstm_mfma()) {
-        const int nq = hidden == 64 ? lstm_quads(B) : 1;
-        launch_fwd_mfma(hidden, nq, B % (4 * nq) == 0, gates_save != nullptr, gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
+        LstmGroup g = {};
+        g.ld_g = 4 * hidden; g.rev_mask = reverse ? 1 : 0;
+        launch_fwd_mfma(hidden, 1, gates_x, w_hh, T, B, g, h_out, gates_save, cells_save, s);
     } else if (hidden == 64) launch_fwd<64>(lstm_tile(B), gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
     else launch_fwd<128>(4, gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
     return lstm_launch_check("k_lstm_fwd");
@@ -600,11 +640,45 @@ int egp_lstm_bwd_f32(const float *dh_out, const float *gates_save, const float *
     EGP_REQUIRE(dh_out && gates_save && cells_save && w_hh && d_pre, "NULL pointer");
     hipStream_t s = (hipStream_t)stream;
     if (lstm_mfma()) {
-        const int nq = hidden == 64 ? lstm_quads(B) : 1;
-        launch_bwd_mfma(hidden, nq, B % (4 * nq) == 0, dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
+        LstmGroup g = {};
+        g.ld_g = 4 * hidden; g.rev_mask = reverse ? 1 : 0; g.dh[0] = dh_out;
+        launch_bwd_mfma(hidden, 1, gates_save, cells_save, w_hh, T, B, g, d_pre, s);
     } else if (hidden == 64) launch_bwd<64>(lstm_tile(B), dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
     else launch_bwd<128>(4, dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
     return lstm_launch_check("k_lstm_bwd");
+}
+
+int egp_lstm_group_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t B, int32_t hidden, int32_t n_problems,
+                           int32_t reverse_mask, float *h_out, int64_t h_stride, float *gates_save, float *cells_save, void *stream) {
+    EGP_REQUIRE(lstm_mfma(), "grouped LSTM sweeps need the matrix-core kernels (EGP_LSTM_MFMA=0 is set)");
+    EGP_REQUIRE(hidden == 64 || hidden == 128, "egp_lstm kernels are built for hidden size 64 and 128");
+    EGP_REQUIRE(n_problems >= 1 && n_problems <= 4, "1..4 problems per group");
+    EGP_REQUIRE(T >= 0 && B >= 0, "negative size");
+    if (T == 0 || B == 0) return EGP_OK;
+    EGP_REQUIRE(gates_x && w_hh && h_out, "NULL pointer");
+    EGP_REQUIRE((gates_save == nullptr) == (cells_save == nullptr), "gates_save and cells_save go together");
+    LstmGroup g = {};
+    g.ld_g = 4 * hidden * n_problems; g.rev_mask = reverse_mask; g.h_stride = h_stride; g.c_stride = (long)T * B * hidden;
+    launch_fwd_mfma(hidden, n_problems, gates_x, w_hh, T, B, g, h_out, gates_save, cells_save, (hipStream_t)stream);
+    return lstm_launch_check("k_lstm_fwd_mfma (group)");
+}
+
+int egp_lstm_group_bwd_f32(const float *const *dh_out, const float *gates_save, const float *cells_save, const float *w_hh, int32_t T,
+                           int32_t B, int32_t hidden, int32_t n_problems, int32_t reverse_mask, float *d_pre, float *d_bias, void *stream) {
+    EGP_REQUIRE(lstm_mfma(), "grouped LSTM sweeps need the matrix-core kernels (EGP_LSTM_MFMA=0 is set)");
+    EGP_REQUIRE(hidden == 64 || hidden == 128, "egp_lstm kernels are built for hidden size 64 and 128");
+    EGP_REQUIRE(n_problems >= 1 && n_problems <= 4, "1..4 problems per group");
+    EGP_REQUIRE(T >= 0 && B >= 0, "negative size");
+    if (T == 0 || B == 0) return EGP_OK;
+    EGP_REQUIRE(dh_out && gates_save && cells_save && w_hh && d_pre, "NULL pointer");
+    LstmGroup g = {};
+    g.ld_g = 4 * hidden * n_problems; g.rev_mask = reverse_mask; g.c_stride = (long)T * B * hidden; g.db = d_bias;
+    for (int p = 0; p < n_problems; ++p) {
+        EGP_REQUIRE(dh_out[p], "NULL d h_out");
+        g.dh[p] = dh_out[p];
+    }
+    launch_bwd_mfma(hidden, n_problems, gates_save, cells_save, w_hh, T, B, g, d_pre, (hipStream_t)stream);
+    return lstm_launch_check("k_lstm_bwd_mfma (group)");
 }
 
 }  // extern "C"

@@ -106,5 +106,79 @@ class LstmDirection(torch.autograd.Function):
         return d_x, d_w_ih, d_w_hh, d_b, d_b, None
 
 
+class LstmGroup(torch.autograd.Function):
+    """P sweeps (cells, directions) over the same input x in one grouped launch each way:
+    apply(x, reverse_mask, P, w_ih_0, w_hh_0, b_ih_0, b_hh_0, w_ih_1, ...) -> (h_0, ..., h_{P-1}).
+    One projection GEMM against the stacked W_ih; in backward the bias gradient comes out of the kernel, dW_ih of all
+    problems is one batched GEMM against x, dW_hh one per problem against its own h_prev (no concatenated operands)."""
+
+    @staticmethod
+    def forward(ctx, x, reverse_mask, P, *params):
+        lib = L.load()
+        T, B, D = x.shape
+        w_ih, w_hh, b_ih, b_hh = params[0::4], params[1::4], params[2::4], params[3::4]
+        H = w_hh[0].shape[1]
+        perm, inv = _gate_perm(H, x.device)
+        x2 = x.reshape(T * B, D)
+        w_in = torch.cat([w.index_select(0, perm) for w in w_ih], 0)                       # (P*4H, D)
+        bias = torch.cat([(bi + bh).index_select(0, perm) for bi, bh in zip(b_ih, b_hh)], 0)
+        gx = torch.addmm(bias, x2, w_in.t())                                                # (T*B, P*4H)
+        w_hh_all = torch.stack([w.contiguous() for w in w_hh], 0)
+        # per problem T + 2 time slots, zero | h_0 .. h_{T-1} | zero: h_prev is the same buffer shifted by one slot
+        # (down for a forward sweep, up for a reversed one), and every problem's h starts at slot 1
+        h_buf = torch.empty(P, T + 2, B, H, dtype=x.dtype, device=x.device)
+        h_buf[:, 0].zero_()
+        h_buf[:, T + 1].zero_()
+        train = any(ctx.needs_input_grad)
+        cells = torch.empty(P, T, B, H, dtype=x.dtype, device=x.device) if train else None
+        L.check(lib.egp_lstm_group_fwd_f32(_p(gx), _p(w_hh_all), T, B, H, P, reverse_mask, _p(h_buf[0, 1]), (T + 2) * B * H,
+                                           _p(gx if train else None), _p(cells), _s()), "egp_lstm_group_fwd_f32")
+        hs = tuple(h_buf[p, 1:T + 1] for p in range(P))
+        if train:
+            ctx.save_for_backward(x2, w_in, w_hh_all, h_buf, gx, cells)
+            ctx.meta = (T, B, D, H, P, reverse_mask)
+        return hs
+
+    @staticmethod
+    def backward(ctx, *dhs):
+        lib = L.load()
+        x2, w_in, w_hh_all, h_buf, gates, cells = ctx.saved_tensors
+        T, B, D, H, P, reverse_mask = ctx.meta
+        perm, inv = _gate_perm(H, x2.device)
+        dhs = [dh.contiguous() if dh is not None else h_buf.new_zeros(T, B, H) for dh in dhs]
+        ptrs = (C.c_void_p * P)(*[dh.data_ptr() for dh in dhs])
+        dpre = torch.empty(T * B, P * 4 * H, dtype=x2.dtype, device=x2.device)
+        db = torch.zeros(P, 4 * H, dtype=x2.dtype, device=x2.device)
+        L.check(lib.egp_lstm_group_bwd_f32(ptrs, _p(gates), _p(cells), _p(w_hh_all), T, B, H, P, reverse_mask, _p(dpre), _p(db), _s()),
+                "egp_lstm_group_bwd_f32")
+        d3 = dpre.view(T, B, P * 4 * H)
+        dw_ih_all = torch.bmm(d3.transpose(1, 2), x2.view(T, B, D)).sum(0)                 # (P*4H, D), kernel gate order
+        grads = []
+        for p in range(P):
+            rev = (reverse_mask >> p) & 1
+            h_prev = h_buf[p, 2:] if rev else h_buf[p, :T]
+            dw_hh = torch.bmm(d3[:, :, p * 4 * H:(p + 1) * 4 * H].transpose(1, 2), h_prev).sum(0).index_select(0, inv)
+            dw_ih = dw_ih_all[p * 4 * H:(p + 1) * 4 * H].index_select(0, inv)
+            d_b = db[p].index_select(0, inv)
+            grads += [dw_ih, dw_hh, d_b, d_b]
+        d_x = dpre.mm(w_in).view(T, B, D) if ctx.needs_input_grad[0] else None
+        return (d_x, None, None, *grads)
+
+
+def group_available(x, cells):
+    """Grouped sweeps need the matrix-core kernels, at most four problems and identical cell shapes."""
+    if not cells or len(cells) > 4 or L.load().egp_lstm_gate_layout() == 0:
+        return False
+    c0 = cells[0]
+    return all(available(x, c) and c.hidden_size == c0.hidden_size and c.input_size == c0.input_size for c in cells)
+
+
+def lstm_group(x, cells, reverses):
+    """[(T,B,H)] * P for P (cell, reverse) pairs over the same x (T,B,D), one grouped launch each way."""
+    mask = sum(1 << i for i, r in enumerate(reverses) if r)
+    params = [t for c in cells for t in (c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh)]
+    return list(LstmGroup.apply(x.contiguous(), mask, len(cells), *params))
+
+
 def lstm_direction(cell, x, reverse):
     return LstmDirection.apply(x, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh, bool(reverse))

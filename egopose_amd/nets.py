@@ -232,6 +232,8 @@ class VideoStateNet(nn.Module):
         self.gather_indices = None
         self.cnn_feat_ctx = None
         self._buckets = None
+        self._v_ctx = None
+        self._ctx_key = None
         self._cnn_table = None   # optional (device table, take offsets) installed by the env
 
     def set_mode(self, mode):
@@ -292,6 +294,7 @@ class VideoStateNet(nn.Module):
                 ctx[:, e, :] = cnn_feat[int(ei)][int(si) - m: int(si) + max_len + m]
             self.cnn_feat_ctx = torch.as_tensor(ctx, dtype=dtype, device=device)
         self.gather_indices = torch.as_tensor(idx, dtype=torch.long, device=device)
+        self._ctx_key = (int(max_len), meta.shape[0], hash(meta.tobytes()))       # which windows cnn_feat_ctx holds
         # Length buckets for the forward direction: its output at frame t only depends on frames <= t and only frames
         # [m, m + len_e) of an episode are ever gathered, so episodes sorted by length let the forward LSTM stop early
         # (the backward direction starts at the end of the padded window and must run it all, as in the reference).
@@ -331,8 +334,11 @@ class VideoStateNet(nn.Module):
         if self._buckets is not None:
             ctx = self._bucketed_context()[m:-m].transpose(0, 1).reshape(-1, self.v_hdim)
             return torch.cat((ctx.index_select(0, self._gather_sorted), x), dim=1)
-        ctx = self.forward_v_net(self.cnn_feat_ctx)[m:-m]
-        ctx = ctx.transpose(0, 1).reshape(-1, self.v_hdim)
+        if self._v_ctx is not None:          # computed together with another net's (grouped_video_context)
+            ctx, self._v_ctx = self._v_ctx, None
+        else:
+            ctx = self.forward_v_net(self.cnn_feat_ctx)
+        ctx = ctx[m:-m].transpose(0, 1).reshape(-1, self.v_hdim)
         return torch.cat((ctx.index_select(0, self.gather_indices), x), dim=1)
 
 
@@ -492,6 +498,34 @@ class VideoForecastNet(nn.Module):
         else:
             s_out = x
         return torch.cat((v_out, s_out), dim=1)
+
+
+def grouped_video_context(nets):
+    """Train-mode video contexts of several VideoStateNets (the critic's and the actor's) in ONE grouped recurrent
+    launch each way (lstm.LstmGroup): their bi-LSTMs read the same windows with different weights, and a single sweep
+    leaves most of the chip idle. Each net's next forward() consumes its context. Returns False (nothing done) when the
+    nets do not qualify; the nets then compute their contexts one by one as usual."""
+    if os.environ.get("EGP_LSTM_GROUP", "1") == "0" or _LSTM_IMPL == "torch" or len(nets) < 1:
+        return False
+    n0 = nets[0]
+    for n in nets:
+        if not (isinstance(n, VideoStateNet) and n.mode == "train" and n._buckets is None and n.v_net.cell_type == "lstm"
+                and n.cnn_feat_ctx is not None and n.cnn_feat_ctx.shape == n0.cnn_feat_ctx.shape and n._ctx_key == n0._ctx_key
+                and n.cnn_feat_ctx.dtype == n0.cnn_feat_ctx.dtype and n.v_net.bi_dir == n0.v_net.bi_dir):
+            return False
+    cells, revs = [], []
+    for n in nets:
+        cells.append(n.v_net.rnn_f); revs.append(False)
+        if n.v_net.bi_dir:
+            cells.append(n.v_net.rnn_b); revs.append(True)
+    x = n0.cnn_feat_ctx                      # same episodes, same windows for every net (initialize() of the same batch)
+    if not _hip_lstm.group_available(x, cells):
+        return False
+    hs = _hip_lstm.lstm_group(x, cells, revs)
+    k = 2 if n0.v_net.bi_dir else 1
+    for i, n in enumerate(nets):
+        n._v_ctx = torch.cat(hs[k * i:k * i + k], 2) if k == 2 else hs[k * i]
+    return True
 
 
 # ---------------------------------------------------------------------- image encoder of the state regressor

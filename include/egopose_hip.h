@@ -219,6 +219,18 @@ int egp_lstm_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t
  * caller forms dW_ih = d_pre^T X, dW_hh = d_pre^T H_prev, db = sum d_pre with library GEMMs */
 int egp_lstm_bwd_f32(const float *dh_out, const float *gates_save, const float *cells_save, const float *w_hh,
                      int32_t T, int32_t B, int32_t hidden, int32_t reverse, float *d_pre, void *stream);
+/* n_problems (1..4) sweeps over the same (T, B) in ONE launch -- the two directions of a bi-LSTM and/or the LSTMs of several
+ * nets reading the same windows (a sweep is latency-bound: grouped problems fill the CUs a single one leaves idle).
+ * Needs the unit-major layout (egp_lstm_gate_layout() == EGP_LSTM_GATES_UNIT_MAJOR).
+ *   gates_x / gates_save / d_pre [T*B][n_problems*4H]: columns p*4H .. (p+1)*4H-1 belong to problem p (what one
+ *   projection GEMM against the row-stacked W_ih of all problems produces);  w_hh [n_problems][4H][H];
+ *   reverse_mask bit p: problem p runs backwards in time;  h_out + p*h_stride -> [T][B][H] of problem p;
+ *   cells_save [n_problems][T][B][H];  dh_out[p] -> [T][B][H];  d_bias (optional) [n_problems][4H], zeroed by the
+ *   caller, receives sum over (t, b) of d_pre (float atomics). */
+int egp_lstm_group_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t B, int32_t hidden, int32_t n_problems,
+                           int32_t reverse_mask, float *h_out, int64_t h_stride, float *gates_save, float *cells_save, void *stream);
+int egp_lstm_group_bwd_f32(const float *const *dh_out, const float *gates_save, const float *cells_save, const float *w_hh, int32_t T,
+                           int32_t B, int32_t hidden, int32_t n_problems, int32_t reverse_mask, float *d_pre, float *d_bias, void *stream);
 
 /* ----------------------------------------------------------------------------------------
  * K8: dynamics terms on the GPU. From (qpos, qvel) per env: body frame positions (mjData.xpos[1:]),

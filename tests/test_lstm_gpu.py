@@ -105,3 +105,75 @@ def test_statereg_training_step_on_gpu():
         for n, p in net.named_parameters():
             if n in probes:
                 assert not torch.equal(p, probes[n]), n
+
+
+@pytest.mark.gpu
+def test_grouped_sweeps_match_separate_ones():
+    """lstm.LstmGroup (one grouped launch each way for 4 cells over the same input) == four lstm_direction calls:
+    outputs, d_x and every parameter gradient."""
+    from egopose_amd import lstm as hl
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(11)
+    T, B, D, H = 37, 70, 24, 64          # ragged tile (70 % 4 != 0), T % 8 != 0
+    cells = [torch.nn.LSTMCell(D, H).to(dev) for _ in range(4)]
+    revs = [False, True, False, True]
+    x = torch.randn(T, B, D, device=dev)
+    ws = [torch.randn(T, B, H, device=dev) for _ in range(4)]
+    assert hl.group_available(x, cells)
+
+    def run(grouped):
+        for c in cells:
+            c.zero_grad()
+        xx = x.clone().requires_grad_(True)
+        hs = hl.lstm_group(xx, cells, revs) if grouped else [hl.lstm_direction(c, xx, r) for c, r in zip(cells, revs)]
+        sum((h * w).sum() for h, w in zip(hs, ws)).backward()
+        return [h.detach().clone() for h in hs], xx.grad.clone(), [[p.grad.clone() for p in c.parameters()] for c in cells]
+
+    h_g, dx_g, g_g = run(True)
+    h_s, dx_s, g_s = run(False)
+    for a, b in zip(h_g, h_s):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dx_g, dx_s, rtol=1e-4, atol=1e-4)
+    for ga, gb in zip(g_g, g_s):
+        for a, b in zip(ga, gb):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()) + 1e-6)
+
+
+@pytest.mark.gpu
+def test_grouped_video_contexts_match_per_net_contexts():
+    """nets.grouped_video_context for (value_vs_net, policy_vs_net) == each net computing its own context."""
+    import numpy as np
+    from egopose_amd.nets import VideoStateNet, grouped_video_context
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(3)
+    cdim, hdim, margin, T_ep = 128, 128, 10, 25
+    cnn = [rng.normal(size=(300, cdim))]
+    lens = rng.randint(1, T_ep + 1, size=40); lens[0] = T_ep
+    masks, metas = [], []
+    for Lk in lens:
+        s0 = int(rng.randint(margin, cnn[0].shape[0] - T_ep - margin))
+        masks += [1.0] * (Lk - 1) + [0.0]
+        metas += [[0, s0]] * int(Lk)
+    masks = torch.tensor(masks, dtype=torch.float32, device=dev)
+    metas = np.array(metas)
+    table = torch.tensor(cnn[0], dtype=torch.float32, device=dev)
+    states = torch.randn(len(masks), 9, device=dev)
+    w = torch.randn(len(masks), hdim + 9, device=dev)
+    torch.manual_seed(5)
+    nets = [VideoStateNet(cdim, hdim, margin, "lstm", None, False).to(dev) for _ in range(2)]
+    res = []
+    for grouped in (True, False):
+        for n in nets:
+            n.zero_grad()
+            n.attach_feature_table(table, np.array([0]))
+            n.set_mode("train")
+            n.initialize((masks, cnn, metas))
+        if grouped:
+            assert grouped_video_context(nets)
+        ys = [n(states) for n in nets]
+        sum((y * w).sum() for y in ys).backward()          # one backward over both nets, as the PPO update does
+        res.append([(y.detach().clone(), [p.grad.clone() for p in n.parameters()]) for y, n in zip(ys, nets)])
+    for (oa, ga), (ob, gb) in zip(*res):
+        torch.testing.assert_close(oa, ob, rtol=1e-5, atol=1e-5)
+        for a, b in zip(ga, gb):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()) + 1e-6)
