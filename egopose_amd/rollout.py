@@ -424,6 +424,9 @@ class LockstepRollout:
             # than the two separate calls (the merge still waits for the slower half): opt-in
             post_fused = os.environ.get("EGP_POST_FUSED", "0") == "1" and not reward_job
 
+        cur_stream = _lib.current_stream()           # the rollout stays on one torch stream
+        ev_ring = [[torch.cuda.Event(), torch.cuda.Event()] for _ in self.groups]
+
         def pre_fast(g):
             a, b = self.groups[g]
             n = b - a
@@ -441,17 +444,17 @@ class LockstepRollout:
             np.minimum(self.cur_t[a:b], self.ctx_T - 1, out=ti_np[g, slot, :n])
             soff = (g * 2 + slot) * 24 * nmax
             if flags_upload:
-                lib.egp_upload_async(slab_dp + soff, slab_hp + soff, 24 * nmax, _lib.current_stream())
+                lib.egp_upload_async(slab_dp + soff, slab_hp + soff, 24 * nmax, cur_stream)
             fbase = slab_dp + soff
             nz = noise_t[g]
             nz.normal_()
             rc = lib.egp_policy_gaussian_f32(v_out_p + a * v_stride * 4, v_stride, H, fbase + 16 * nmax,
                                              P["states"] + (k * N + a) * od * 8, od, n, fz.desc, len(fz.layers), fz.act,
                                              fz.log_std.data_ptr(), nz.data_ptr(), P["actions"] + (k * N + a) * nu * 8, None,
-                                             _lib.current_stream())
+                                             cur_stream)
             if rc != 0:
                 _lib.check(rc, "egp_policy_gaussian_f32")
-            ev = torch.cuda.Event()
+            ev = ev_ring[g][slot]           # the env-step that waited on it two ticks ago has long finished
             ev.record()
             self._events[g] = ev
             if reward_job:      # K2 rides behind this env-step's kernel on the engine's stream
@@ -469,12 +472,38 @@ class LockstepRollout:
             a, b = self.groups[g]
             n = b - a
             t0 = time.time()
-            rc = eng.lib.egp_engine_wait(eng.handle, g, _lib.current_stream())
+            rc = eng.lib.egp_engine_wait(eng.handle, g, cur_stream)
             if rc != 0:
                 _lib.check(rc, "egp_engine_wait")
             t1 = time.time()
             k = tick[g]
             slot = k & 1
+            # the filter -> policy chain of the next tick starts here: launch K3+K6 (and K2) before the host bookkeeping;
+            # everything they read was staged before the env-step (flags) or is on the device (state, ping-pong filter)
+            fbase = slab_dp + (g * 2 + slot) * 24 * nmax          # the flags pre_fast staged for this env-step
+            if zf_p is not None:                 # same ping-pong as _obs_filter
+                new_t, new, cur = self._zf_bufs[self._zf_flip], zf_p[self._zf_flip], self.zf_state.data_ptr()
+                self._zf_flip ^= 1
+            else:                                # raw observations (no running_state)
+                new_t, new, cur = None, None, None
+            # K3+K6 (-> next_states[k] and states[k+1]) and K2 (-> rewards[k], cinfo[k]): three launches, one call
+            if not post_fused:
+                rc = lib.egp_obs_zfilter_f64(hnd, qpos_p + a * ctx.nq * 8, qvel_p + a * ctx.nv * 8, fbase + 12 * nmax, n, cur, new, zclip,
+                                             P["next_states"] + (k * N + a) * od * 8, P["states"] + ((k + 1) * N + a) * od * 8, 0, ws_p,
+                                             cur_stream)
+                if rc == 0 and not reward_job:
+                    rc = lib.egp_reward_quat_v3_f64(hnd, qpos_p + a * ctx.nq * 8, prev_p + a * ctx.nq * 8, ee_p + a * 15 * 8, fbase,
+                                                    fbase + 4 * nmax, fbase + 8 * nmax, fbase + 12 * nmax, end_r, n,
+                                                    P["rewards"] + (k * N + a) * 8, P["cinfo"] + (k * N + a) * 5 * 8, cur_stream)
+            else:
+                rc = lib.egp_post_step_f64(hnd, qpos_p + a * ctx.nq * 8, qvel_p + a * ctx.nv * 8, prev_p + a * ctx.nq * 8, ee_p + a * 15 * 8,
+                                           fbase, fbase + 4 * nmax, fbase + 8 * nmax, fbase + 12 * nmax, n, cur, new, zclip,
+                                           P["next_states"] + (k * N + a) * od * 8, P["states"] + ((k + 1) * N + a) * od * 8, ws_p, end_r,
+                                           P["rewards"] + (k * N + a) * 8, P["cinfo"] + (k * N + a) * 5 * 8, cur_stream)
+            if rc != 0:
+                _lib.check(rc, "egp_post_step")
+            if new_t is not None:
+                self.zf_state = new_t
             act_g = active[a:b]
             self.cur_t[a:b] += act_g
             ct = self.cur_t[a:b]
@@ -487,30 +516,6 @@ class LockstepRollout:
             done = (fail | end) & act_g
             host["valid"][k, a:b], host["done"][k, a:b] = act_g, done
             host["e_ind"][k, a:b], host["s_ind"][k, a:b] = self.e_ind[a:b], self.s_ind[a:b]
-            fbase = slab_dp + (g * 2 + slot) * 24 * nmax          # the flags pre_fast staged for this env-step
-            if zf_p is not None:                 # same ping-pong as _obs_filter
-                new_t, new, cur = self._zf_bufs[self._zf_flip], zf_p[self._zf_flip], self.zf_state.data_ptr()
-                self._zf_flip ^= 1
-            else:                                # raw observations (no running_state)
-                new_t, new, cur = None, None, None
-            # K3+K6 (-> next_states[k] and states[k+1]) and K2 (-> rewards[k], cinfo[k]): three launches, one call
-            if not post_fused:
-                rc = lib.egp_obs_zfilter_f64(hnd, qpos_p + a * ctx.nq * 8, qvel_p + a * ctx.nv * 8, fbase + 12 * nmax, n, cur, new, zclip,
-                                             P["next_states"] + (k * N + a) * od * 8, P["states"] + ((k + 1) * N + a) * od * 8, 0, ws_p,
-                                             _lib.current_stream())
-                if rc == 0 and not reward_job:
-                    rc = lib.egp_reward_quat_v3_f64(hnd, qpos_p + a * ctx.nq * 8, prev_p + a * ctx.nq * 8, ee_p + a * 15 * 8, fbase,
-                                                    fbase + 4 * nmax, fbase + 8 * nmax, fbase + 12 * nmax, end_r, n,
-                                                    P["rewards"] + (k * N + a) * 8, P["cinfo"] + (k * N + a) * 5 * 8, _lib.current_stream())
-            else:
-              rc = lib.egp_post_step_f64(hnd, qpos_p + a * ctx.nq * 8, qvel_p + a * ctx.nv * 8, prev_p + a * ctx.nq * 8, ee_p + a * 15 * 8,
-                                       fbase, fbase + 4 * nmax, fbase + 8 * nmax, fbase + 12 * nmax, n, cur, new, zclip,
-                                       P["next_states"] + (k * N + a) * od * 8, P["states"] + ((k + 1) * N + a) * od * 8, ws_p, end_r,
-                                       P["rewards"] + (k * N + a) * 8, P["cinfo"] + (k * N + a) * 5 * 8, _lib.current_stream())
-            if rc != 0:
-                _lib.check(rc, "egp_post_step")
-            if new_t is not None:
-                self.zf_state = new_t
             steps_done[a:b] += act_g
             t2 = time.time()
             if done.any():

@@ -1,9 +1,9 @@
 """Time the update's MLP GEMM shapes (fp32) with the default BLAS pick vs torch TunableOp. Usage: gemm_probe.py [rows]"""
 import sys, time, os
 import torch
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 134000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 139264
 dev = "cuda"
-dims = [(243, 300), (300, 200), (200, 52)]
+dims = [(243, 300), (256, 300), (300, 200), (304, 200), (300, 208), (200, 52), (200, 1)]
 
 
 def bench(f, reps=20):
@@ -39,5 +39,3 @@ tn.set_max_tuning_duration(30); tn.set_max_tuning_iterations(20)
 tn.set_filename(os.environ.get("TUNE_OUT", "/tmp/tunable.csv"))
 t0 = time.time(); run("tuning  "); print("tuning took", round(time.time() - t0, 1), "s")
 run("tuned   ")
-tn.write_file()
-print(open(tn.get_filename()).read()[:3000])
