@@ -304,6 +304,7 @@ class LockstepRollout:
         ep_lens = []
         tick = [0] * len(self.groups)
         tm = dict(policy=0.0, wait=0.0, post=0.0, reset=0.0)
+        trace = [] if os.environ.get("EGP_TICK_TRACE") else None
 
         # ---- initial reset of every slot; group g's first state goes to rec["states"][0, a:b]
         self._reset_slots(np.arange(N))
@@ -534,6 +535,8 @@ class LockstepRollout:
             tm["wait"] += t1 - t0
             tm["post"] += t2 - t1
             tm["reset"] += t3 - t2
+            if trace is not None:           # EGP_TICK_TRACE: (group, tick, stepped envs, wait, post, reset) per env-step
+                trace.append((g, k, int(act_g.sum()), t1 - t0, t2 - t1, t3 - t2))
 
         if fast:
             pre_step, post_step = pre_fast, post_fast
@@ -576,4 +579,5 @@ class LockstepRollout:
         log.sample_time = time.time() - t_start
         tm.update(ticks=T_used, quota=quota, policy_graph=self._graphs is not None, **eng.timing())
         self.timing = tm
+        self.tick_trace = trace
         return batch, log
