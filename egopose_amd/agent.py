@@ -225,28 +225,11 @@ class AgentPPO(AgentPG):
         n_val = D.global_count(states.shape[0], states.device)
         n_exp = D.global_count(ind.shape[0], states.device)
         losses = []
-        overlap = states.is_cuda and os.environ.get("EGP_UPDATE_OVERLAP", "0") != "0"
-        if overlap:
-            if getattr(self, "_streams", None) is None:
-                self._streams = (torch.cuda.Stream(device=states.device), torch.cuda.Stream(device=states.device))
-            s_v, s_p = self._streams
-            main = torch.cuda.current_stream(states.device)
         for _ in range(self.opt_num_epochs):
             # critic and actor have disjoint parameters: both backward passes run before the single gradient
-            # exchange (on two HIP streams: the per-timestep LSTM kernels of one net are latency-bound and
-            # leave most CUs idle); the value step precedes the policy step as in the reference
-            if overlap:
-                s_v.wait_stream(main)
-                s_p.wait_stream(main)
-                with torch.cuda.stream(s_v):
-                    v_loss = self._value_backward(states, returns, n_val)
-                with torch.cuda.stream(s_p):
-                    s_loss = self.ppo_loss(states, actions, advantages, fixed_log_probs, ind, n_exp)
-                    self.optimizer_policy.zero_grad()
-                    s_loss.backward()
-                main.wait_stream(s_v)
-                main.wait_stream(s_p)
-            elif self._group_contexts():
+            # exchange; the value step precedes the policy step as in the reference. (Running the two passes on two
+            # HIP streams was faster and hung the GPU intermittently -- concurrent library GEMMs)
+            if self._group_contexts():
                 # both video nets' recurrences in one grouped launch each way; disjoint parameters, so one backward
                 # over the sum of the two losses yields exactly the two separate gradients
                 if self.value_opt_niter != 1:

@@ -882,11 +882,11 @@ __global__ __launch_bounds__(256) void k_post_step(ZfSrc<T> src, const int *__re
                        (int)blockIdx.x - n_tiles);
 }
 
-// Chan-merge of the tile partials of column c into the running state, fixed order (deterministic)
-__device__ __forceinline__ void zf_merge_column(int c, int dim, int n_tiles, const double *__restrict__ ws,
-                                                const double *__restrict__ st_in, double &cnt, double &mean, double &S) {
-    {
-        cnt = st_in[0]; mean = st_in[1 + c]; S = st_in[1 + dim + c];
+// one block: Chan-merge the tile partials into the running state, fixed order (deterministic)
+__global__ __launch_bounds__(128) void k_zf_merge(int dim, int n_tiles, const double *__restrict__ ws,
+                                                  const double *__restrict__ st_in, double *__restrict__ st_out) {
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+        double cnt = st_in[0], mean = st_in[1 + c], S = st_in[1 + dim + c];
         for (int q0 = 0; q0 < n_tiles; q0 += 8) {
             double nb[8], mb[8], Sb[8];
 #pragma unroll
@@ -911,15 +911,6 @@ __device__ __forceinline__ void zf_merge_column(int c, int dim, int n_tiles, con
                 }
             }
         }
-    }
-}
-
-// one block: the merged state
-__global__ __launch_bounds__(128) void k_zf_merge(int dim, int n_tiles, const double *__restrict__ ws,
-                                                  const double *__restrict__ st_in, double *__restrict__ st_out) {
-    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
-        double cnt, mean, S;
-        zf_merge_column(c, dim, n_tiles, ws, st_in, cnt, mean, S);
         st_out[1 + c] = mean;
         st_out[1 + dim + c] = S;
         if (c == 0) st_out[0] = cnt;
@@ -927,28 +918,14 @@ __global__ __launch_bounds__(128) void k_zf_merge(int dim, int n_tiles, const do
 }
 
 // y = clip((x - mean) / (std + 1e-8)) with the statistics in `st` (identity: raw copy)
-// merge_tiles > 0: `st` is the state BEFORE this batch and every block first merges the batch's tile partials itself
-// (the same ordered merge in every block -> identical statistics; block 0 stores them to st_out): the separate
-// one-block merge launch, and its place on the rollout tick's critical chain, disappear.
 template <typename T>
 __global__ __launch_bounds__(128) void k_zf_apply(ZfSrc<T> src, int n, int dim, int rows_per_block, const double *__restrict__ st,
                                                   double clip, T *__restrict__ y, T *__restrict__ y2,
-                                                  const int *__restrict__ write_mask, int identity, int merge_tiles,
-                                                  const double *__restrict__ ws, double *__restrict__ st_out) {
+                                                  const int *__restrict__ write_mask, int identity) {
     extern __shared__ double s_ms[];   // mean[dim], inv[dim]
     for (int c = threadIdx.x; c < dim; c += blockDim.x) {
         if (identity) { s_ms[c] = 0.0; s_ms[dim + c] = 1.0; continue; }
-        double cnt, mean, S;
-        if (merge_tiles > 0) {
-            zf_merge_column(c, dim, merge_tiles, ws, st, cnt, mean, S);
-            if (blockIdx.x == 0) {
-                st_out[1 + c] = mean;
-                st_out[1 + dim + c] = S;
-                if (c == 0) st_out[0] = cnt;
-            }
-        } else {
-            cnt = st[0]; mean = st[1 + c]; S = st[1 + dim + c];
-        }
+        const double cnt = st[0], mean = st[1 + c], S = st[1 + dim + c];
         const double var = cnt > 1.0 ? S / (cnt - 1.0) : mean * mean;
         s_ms[c] = mean;
         s_ms[dim + c] = 1.0 / (sqrt(var) + 1e-8);
@@ -1399,19 +1376,15 @@ static int launch_zfilter_src(const ZfSrc<T> &src, const int *active, int n, int
     }
     int rpt, nt;
     zf_tiling(n, &rpt, &nt);
-    // small batches (a rollout tick): the apply blocks merge the partials themselves -> two launches instead of three
-    static const bool allow_merge_in_apply = [] { const char *e = getenv("EGP_ZF_MERGE_IN_APPLY"); return e && atoi(e) != 0; }();   // measured: no gain over the separate merge launch, so opt-in
-    const bool merge_in_apply = update && nt <= 128 && allow_merge_in_apply;
     if (update) {
         k_zf_partial<T><<<dim3(nt), dim3(128), 0, (hipStream_t)stream>>>(src, active, n, dim, rpt, (double *)ws);
-        if (!merge_in_apply) k_zf_merge<<<dim3(1), dim3(128), 0, (hipStream_t)stream>>>(dim, nt, (const double *)ws, st_in, st_out);
+        k_zf_merge<<<dim3(1), dim3(128), 0, (hipStream_t)stream>>>(dim, nt, (const double *)ws, st_in, st_out);
         int rc = after_launch("k_zf_partial/merge");
         if (rc != EGP_OK) return rc;
     }
     const int rows_per_block = n <= 8192 ? 2 : 16;     // small batches: enough blocks to cover the latency
     k_zf_apply<T><<<dim3((n + rows_per_block - 1) / rows_per_block), dim3(128), 2 * dim * sizeof(double), (hipStream_t)stream>>>(
-        src, n, dim, rows_per_block, (update && !merge_in_apply) ? st_out : st_in, clip, y, y2, write_mask, identity,
-        merge_in_apply ? nt : 0, (const double *)ws, st_out);
+        src, n, dim, rows_per_block, update ? st_out : st_in, clip, y, y2, write_mask, identity);
     return after_launch("k_zf_apply");
 }
 
@@ -1458,7 +1431,7 @@ static int launch_post_step(egp_ctx *ctx, const double *qpos, const double *qvel
     if (!identity) k_zf_merge<<<dim3(1), dim3(128), 0, s>>>(dim, nt, (const double *)ws, st_in, st_out);
     const int rows_per_block = n <= 8192 ? 2 : 16;
     k_zf_apply<double><<<dim3((n + rows_per_block - 1) / rows_per_block), dim3(128), 2 * dim * sizeof(double), s>>>(
-        src, n, dim, rows_per_block, identity ? st_in : st_out, clip, y, y2, nullptr, identity, 0, nullptr, nullptr);
+        src, n, dim, rows_per_block, identity ? st_in : st_out, clip, y, y2, nullptr, identity);
     return after_launch("k_post_step / k_zf_merge / k_zf_apply");
 }
 
