@@ -208,10 +208,17 @@ class AgentPPO(AgentPG):
                 torch.nn.utils.clip_grad_norm_(params, max_norm)
 
     def ppo_loss(self, states, actions, advantages, fixed_log_probs, ind, n_exp=None):
-        n_exp = ind.shape[0] if n_exp is None else n_exp
-        logp = self.policy_net.get_log_prob(self.trans_policy(states)[ind], actions[ind])
-        ratio = torch.exp(logp - fixed_log_probs[ind])
-        adv = advantages[ind]
+        """`ind` = rows with exps == 1 (agents/agent_ppo.py:45-51), or None when that is every row (no gather copies)."""
+        if ind is None:
+            n_exp = states.shape[0] if n_exp is None else n_exp
+            logp = self.policy_net.get_log_prob(self.trans_policy(states), actions)
+            ratio = torch.exp(logp - fixed_log_probs)
+            adv = advantages
+        else:
+            n_exp = ind.shape[0] if n_exp is None else n_exp
+            logp = self.policy_net.get_log_prob(self.trans_policy(states)[ind], actions[ind])
+            ratio = torch.exp(logp - fixed_log_probs[ind])
+            adv = advantages[ind]
         clipped = torch.clamp(ratio, 1.0 - self.clip_epsilon, 1.0 + self.clip_epsilon) * adv
         return -torch.min(ratio * adv, clipped).sum() / n_exp
 
@@ -224,6 +231,8 @@ class AgentPPO(AgentPG):
         ind = exps.nonzero().squeeze(1)
         n_val = D.global_count(states.shape[0], states.device)
         n_exp = D.global_count(ind.shape[0], states.device)
+        if ind.shape[0] == states.shape[0]:
+            ind = None                       # every sample is an exploration sample: nothing to select
         losses = []
         for _ in range(self.opt_num_epochs):
             # critic and actor have disjoint parameters: both backward passes run before the single gradient
@@ -306,6 +315,7 @@ class AgentEgo(AgentPPO):
             net.initialize((c["masks"], self.env.cnn_feat, v_metas))
         with to_test(*self.update_modules):
             with torch.no_grad():
+                self._group_contexts()       # the policy net's context is consumed by update_policy's first pass
                 values = self.value_net(self.trans_value(c["states"]))
         advantages, returns = self._advantages(c["rewards"], c["masks"], values)
         self.update_policy(c["states"], c["actions"], returns, advantages, c["exps"])

@@ -230,6 +230,7 @@ class VideoStateNet(nn.Module):
         self.t = 0
         self.indices = None
         self.gather_indices = None
+        self._gather_tm = None
         self.cnn_feat_ctx = None
         self._buckets = None
         self._v_ctx = None
@@ -294,6 +295,9 @@ class VideoStateNet(nn.Module):
                 ctx[:, e, :] = cnn_feat[int(ei)][int(si) - m: int(si) + max_len + m]
             self.cnn_feat_ctx = torch.as_tensor(ctx, dtype=dtype, device=device)
         self.gather_indices = torch.as_tensor(idx, dtype=torch.long, device=device)
+        # the same rows addressed in the net's own (time, episode) order: forward() gathers straight from the LSTM output
+        # instead of slicing off the margins, transposing and copying it first
+        self._gather_tm = torch.as_tensor(((idx % max_len) + m) * self.cnn_feat_ctx.shape[1] + idx // max_len, dtype=torch.long, device=device)
         self._ctx_key = (int(max_len), meta.shape[0], hash(meta.tobytes()))       # which windows cnn_feat_ctx holds
         # Length buckets for the forward direction: its output at frame t only depends on frames <= t and only frames
         # [m, m + len_e) of an episode are ever gathered, so episodes sorted by length let the forward LSTM stop early
@@ -334,12 +338,14 @@ class VideoStateNet(nn.Module):
         if self._buckets is not None:
             ctx = self._bucketed_context()[m:-m].transpose(0, 1).reshape(-1, self.v_hdim)
             return torch.cat((ctx.index_select(0, self._gather_sorted), x), dim=1)
+        ctx = None
         if self._v_ctx is not None:          # computed together with another net's (grouped_video_context)
-            ctx, self._v_ctx = self._v_ctx, None
-        else:
+            (ctx, with_grad), self._v_ctx = self._v_ctx, None
+            if with_grad != torch.is_grad_enabled():
+                ctx = None                   # left over from a pass in the other autograd mode: never reuse it
+        if ctx is None:
             ctx = self.forward_v_net(self.cnn_feat_ctx)
-        ctx = ctx[m:-m].transpose(0, 1).reshape(-1, self.v_hdim)
-        return torch.cat((ctx.index_select(0, self.gather_indices), x), dim=1)
+        return torch.cat((ctx.reshape(-1, self.v_hdim).index_select(0, self._gather_tm), x), dim=1)
 
 
 class VideoRegNet(nn.Module):          # (ResNet is defined further down; resolved at construction time)
@@ -524,7 +530,7 @@ def grouped_video_context(nets):
     hs = _hip_lstm.lstm_group(x, cells, revs)
     k = 2 if n0.v_net.bi_dir else 1
     for i, n in enumerate(nets):
-        n._v_ctx = torch.cat(hs[k * i:k * i + k], 2) if k == 2 else hs[k * i]
+        n._v_ctx = (torch.cat(hs[k * i:k * i + k], 2) if k == 2 else hs[k * i], torch.is_grad_enabled())
     return True
 
 
