@@ -243,9 +243,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct LstmGroup {
     int ld_g;               // row stride of gates_x / gates_save / d_pre (floats): P * 4H
     int rev_mask;           // bit p: problem p runs t = T-1 .. 0
-    long h_stride;          // floats between the h_out (fwd) slabs of consecutive problems
-    long c_stride;          // ... cells_save slabs
-    const float *dh[4];     // backward: d h_out per problem ([T][B][H] each)
+    int ld_h;               // row stride of h_out (floats): H, or 2H when two directions share one [T][B][2H] buffer
+    int ld_dh;              // ... of d h_out
+    long c_stride;          // floats between the cells_save slabs of consecutive problems
+    float *h[4];            // forward: h_out per problem (row (t, b) at h[p] + (t*B + b) * ld_h)
+    const float *dh[4];     // backward: d h_out per problem
     float *db;              // backward, optional: [P][4H] accumulates sum_t,b d_pre (atomics; zeroed by the caller)
 };
 
@@ -255,11 +257,11 @@ struct LstmGroup {
 // before touching a prefetched register -- i.e. for the acknowledgement of the stores it has just issued, every step.
 template <int NQ, int LH, bool FULL, bool TRAIN>
 __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restrict__ gx, const float *__restrict__ w_hh, int T, int B,
-                                                          LstmGroup grp, float *__restrict__ h_out, float *__restrict__ gates_out,
-                                                          float *__restrict__ c_out) {
+                                                          LstmGroup grp, float *__restrict__ gates_out, float *__restrict__ c_out) {
     constexpr int LG = 4 * LH, ROWS = 4 * NQ;
-    const int prob = blockIdx.y, reverse = (grp.rev_mask >> prob) & 1, ld = grp.ld_g;
-    gx += prob * LG; w_hh += (long)prob * LG * LH; h_out += prob * grp.h_stride;
+    const int prob = blockIdx.y, reverse = (grp.rev_mask >> prob) & 1, ld = grp.ld_g, ld_h = grp.ld_h;
+    float *__restrict__ h_out = grp.h[prob];
+    gx += prob * LG; w_hh += (long)prob * LG * LH;
     if (TRAIN) { gates_out += prob * LG; c_out += prob * grp.c_stride; }
     constexpr int PD = LH == 128 ? 2 : (NQ == 1 ? 8 : 4);   // steps per unrolled iteration = input-projection tiles in flight (even)
     __shared__ __attribute__((aligned(16))) float s_h[2][ROWS][LH + 4];     // +4: the 4 rows of a read hit distinct banks
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
             s_h[par ^ 1][4 * q + sub][u] = hn;
             if (FULL || live[q]) {
                 const long row = (long)t * B + r0 + 4 * q + sub;
-                h_out[row * LH + u] = hn;
+                h_out[row * ld_h + u] = hn;
                 if (TRAIN) {
                     *reinterpret_cast<f32x4 *>(gates_out + row * ld + 4 * u) = f32x4{ig, fg, gg, og};
                     c_out[row * LH + u] = cn;
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
                                                           const float *__restrict__ w_hh, int T, int B, LstmGroup grp,
                                                           float *__restrict__ dpre) {
     constexpr int LG = 4 * LH, NT = 4 * LH, ROWS = 4 * NQ, UH = LH / 64;
-    const int prob = blockIdx.y, reverse = (grp.rev_mask >> prob) & 1, ld = grp.ld_g;
+    const int prob = blockIdx.y, reverse = (grp.rev_mask >> prob) & 1, ld = grp.ld_g, ld_dh = grp.ld_dh;
     const float *__restrict__ dh_out = grp.dh[prob];
     gates += prob * LG; dpre += prob * LG; cells += prob * grp.c_stride; w_hh += (long)prob * LG * LH;
     constexpr int NP = (ROWS * LH + NT - 1) / NT;     // = NQ: (row, unit) pairs per thread in the pointwise phase
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
             const long row = (long)f_t * B + rowc[qq];                                               \
             pg[D][qq] = *reinterpret_cast<const f32x4 *>(gates + row * ld + 4 * j);                  \
             pc[D][qq] = cells[row * LH + j];                                                         \
-            pdh[D][qq] = dh_out[row * LH + j];                                                       \
+            pdh[D][qq] = dh_out[row * ld_dh + j];                                                    \
         }                                                                                            \
     }
 
@@ -578,21 +580,21 @@ static void launch_bwd(int tile, const float *dh_out, const float *gates_save, c
 }
 
 template <int NQ, int LH>
-static void launch_fwd_mfma_t(bool full, bool train, int P, const float *gx, const float *w_hh, int T, int B, const LstmGroup &g, float *h_out,
+static void launch_fwd_mfma_t(bool full, bool train, int P, const float *gx, const float *w_hh, int T, int B, const LstmGroup &g,
                               float *gates_save, float *cells_save, hipStream_t s) {
     const dim3 grid((B + 4 * NQ - 1) / (4 * NQ), P), block(4 * LH);
-    if (full && train) k_lstm_fwd_mfma<NQ, LH, true, true><<<grid, block, 0, s>>>(gx, w_hh, T, B, g, h_out, gates_save, cells_save);
-    else if (full) k_lstm_fwd_mfma<NQ, LH, true, false><<<grid, block, 0, s>>>(gx, w_hh, T, B, g, h_out, gates_save, cells_save);
-    else if (train) k_lstm_fwd_mfma<NQ, LH, false, true><<<grid, block, 0, s>>>(gx, w_hh, T, B, g, h_out, gates_save, cells_save);
-    else k_lstm_fwd_mfma<NQ, LH, false, false><<<grid, block, 0, s>>>(gx, w_hh, T, B, g, h_out, gates_save, cells_save);
+    if (full && train) k_lstm_fwd_mfma<NQ, LH, true, true><<<grid, block, 0, s>>>(gx, w_hh, T, B, g, gates_save, cells_save);
+    else if (full) k_lstm_fwd_mfma<NQ, LH, true, false><<<grid, block, 0, s>>>(gx, w_hh, T, B, g, gates_save, cells_save);
+    else if (train) k_lstm_fwd_mfma<NQ, LH, false, true><<<grid, block, 0, s>>>(gx, w_hh, T, B, g, gates_save, cells_save);
+    else k_lstm_fwd_mfma<NQ, LH, false, false><<<grid, block, 0, s>>>(gx, w_hh, T, B, g, gates_save, cells_save);
 }
-static void launch_fwd_mfma(int hidden, int P, const float *gx, const float *w_hh, int T, int B, const LstmGroup &g, float *h_out,
+static void launch_fwd_mfma(int hidden, int P, const float *gx, const float *w_hh, int T, int B, const LstmGroup &g,
                             float *gates_save, float *cells_save, hipStream_t s) {
     const int nq = hidden == 64 ? lstm_quads(B) : 1;      // (4-row workgroups also win for grouped launches: measured)
     const bool full = B % (4 * nq) == 0, train = gates_save != nullptr;
-    if (hidden == 128) launch_fwd_mfma_t<1, 128>(full, train, P, gx, w_hh, T, B, g, h_out, gates_save, cells_save, s);
-    else if (nq >= 2) launch_fwd_mfma_t<2, 64>(full, train, P, gx, w_hh, T, B, g, h_out, gates_save, cells_save, s);
-    else launch_fwd_mfma_t<1, 64>(full, train, P, gx, w_hh, T, B, g, h_out, gates_save, cells_save, s);
+    if (hidden == 128) launch_fwd_mfma_t<1, 128>(full, train, P, gx, w_hh, T, B, g, gates_save, cells_save, s);
+    else if (nq >= 2) launch_fwd_mfma_t<2, 64>(full, train, P, gx, w_hh, T, B, g, gates_save, cells_save, s);
+    else launch_fwd_mfma_t<1, 64>(full, train, P, gx, w_hh, T, B, g, gates_save, cells_save, s);
 }
 
 template <int NQ, int LH>
@@ -625,8 +627,8 @@ int egp_lstm_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t
     hipStream_t s = (hipStream_t)stream;
     if (lstm_mfma()) {
         LstmGroup g = {};
-        g.ld_g = 4 * hidden; g.rev_mask = reverse ? 1 : 0;
-        launch_fwd_mfma(hidden, 1, gates_x, w_hh, T, B, g, h_out, gates_save, cells_save, s);
+        g.ld_g = 4 * hidden; g.rev_mask = reverse ? 1 : 0; g.ld_h = hidden; g.h[0] = h_out;
+        launch_fwd_mfma(hidden, 1, gates_x, w_hh, T, B, g, gates_save, cells_save, s);
     } else if (hidden == 64) launch_fwd<64>(lstm_tile(B), gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
     else launch_fwd<128>(4, gates_x, w_hh, T, B, reverse, h_out, gates_save, cells_save, s);
     return lstm_launch_check("k_lstm_fwd");
@@ -641,7 +643,7 @@ int egp_lstm_bwd_f32(const float *dh_out, const float *gates_save, const float *
     hipStream_t s = (hipStream_t)stream;
     if (lstm_mfma()) {
         LstmGroup g = {};
-        g.ld_g = 4 * hidden; g.rev_mask = reverse ? 1 : 0; g.dh[0] = dh_out;
+        g.ld_g = 4 * hidden; g.rev_mask = reverse ? 1 : 0; g.ld_dh = hidden; g.dh[0] = dh_out;
         launch_bwd_mfma(hidden, 1, gates_save, cells_save, w_hh, T, B, g, d_pre, s);
     } else if (hidden == 64) launch_bwd<64>(lstm_tile(B), dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
     else launch_bwd<128>(4, dh_out, gates_save, cells_save, w_hh, T, B, reverse, d_pre, s);
@@ -649,30 +651,35 @@ int egp_lstm_bwd_f32(const float *dh_out, const float *gates_save, const float *
 }
 
 int egp_lstm_group_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t B, int32_t hidden, int32_t n_problems,
-                           int32_t reverse_mask, float *h_out, int64_t h_stride, float *gates_save, float *cells_save, void *stream) {
+                           int32_t reverse_mask, float *const *h_out, int32_t ld_h, float *gates_save, float *cells_save, void *stream) {
     EGP_REQUIRE(lstm_mfma(), "grouped LSTM sweeps need the matrix-core kernels (EGP_LSTM_MFMA=0 is set)");
     EGP_REQUIRE(hidden == 64 || hidden == 128, "egp_lstm kernels are built for hidden size 64 and 128");
     EGP_REQUIRE(n_problems >= 1 && n_problems <= 4, "1..4 problems per group");
     EGP_REQUIRE(T >= 0 && B >= 0, "negative size");
     if (T == 0 || B == 0) return EGP_OK;
-    EGP_REQUIRE(gates_x && w_hh && h_out, "NULL pointer");
+    EGP_REQUIRE(gates_x && w_hh && h_out && ld_h >= hidden, "NULL pointer / h_out row stride below the hidden size");
     EGP_REQUIRE((gates_save == nullptr) == (cells_save == nullptr), "gates_save and cells_save go together");
     LstmGroup g = {};
-    g.ld_g = 4 * hidden * n_problems; g.rev_mask = reverse_mask; g.h_stride = h_stride; g.c_stride = (long)T * B * hidden;
-    launch_fwd_mfma(hidden, n_problems, gates_x, w_hh, T, B, g, h_out, gates_save, cells_save, (hipStream_t)stream);
+    g.ld_g = 4 * hidden * n_problems; g.rev_mask = reverse_mask; g.ld_h = ld_h; g.c_stride = (long)T * B * hidden;
+    for (int p = 0; p < n_problems; ++p) {
+        EGP_REQUIRE(h_out[p], "NULL h_out");
+        g.h[p] = h_out[p];
+    }
+    launch_fwd_mfma(hidden, n_problems, gates_x, w_hh, T, B, g, gates_save, cells_save, (hipStream_t)stream);
     return lstm_launch_check("k_lstm_fwd_mfma (group)");
 }
 
-int egp_lstm_group_bwd_f32(const float *const *dh_out, const float *gates_save, const float *cells_save, const float *w_hh, int32_t T,
-                           int32_t B, int32_t hidden, int32_t n_problems, int32_t reverse_mask, float *d_pre, float *d_bias, void *stream) {
+int egp_lstm_group_bwd_f32(const float *const *dh_out, int32_t ld_dh, const float *gates_save, const float *cells_save, const float *w_hh,
+                           int32_t T, int32_t B, int32_t hidden, int32_t n_problems, int32_t reverse_mask, float *d_pre, float *d_bias,
+                           void *stream) {
     EGP_REQUIRE(lstm_mfma(), "grouped LSTM sweeps need the matrix-core kernels (EGP_LSTM_MFMA=0 is set)");
     EGP_REQUIRE(hidden == 64 || hidden == 128, "egp_lstm kernels are built for hidden size 64 and 128");
     EGP_REQUIRE(n_problems >= 1 && n_problems <= 4, "1..4 problems per group");
     EGP_REQUIRE(T >= 0 && B >= 0, "negative size");
     if (T == 0 || B == 0) return EGP_OK;
-    EGP_REQUIRE(dh_out && gates_save && cells_save && w_hh && d_pre, "NULL pointer");
+    EGP_REQUIRE(dh_out && gates_save && cells_save && w_hh && d_pre && ld_dh >= hidden, "NULL pointer / d h_out row stride below the hidden size");
     LstmGroup g = {};
-    g.ld_g = 4 * hidden * n_problems; g.rev_mask = reverse_mask; g.c_stride = (long)T * B * hidden; g.db = d_bias;
+    g.ld_g = 4 * hidden * n_problems; g.rev_mask = reverse_mask; g.ld_dh = ld_dh; g.c_stride = (long)T * B * hidden; g.db = d_bias;
     for (int p = 0; p < n_problems; ++p) {
         EGP_REQUIRE(dh_out[p], "NULL d h_out");
         g.dh[p] = dh_out[p];

@@ -108,12 +108,14 @@ class LstmDirection(torch.autograd.Function):
 
 class LstmGroup(torch.autograd.Function):
     """P sweeps (cells, directions) over the same input x in one grouped launch each way:
-    apply(x, reverse_mask, P, w_ih_0, w_hh_0, b_ih_0, b_hh_0, w_ih_1, ...) -> (h_0, ..., h_{P-1}).
+    apply(x, reverse_mask, P, width, w_ih_0, w_hh_0, b_ih_0, b_hh_0, w_ih_1, ...).
+    width = 1 -> P outputs (T,B,H);  width = 2 -> P/2 outputs (T,B,2H): problems 2i and 2i+1 (the two directions of a
+    bi-LSTM) write the halves of one buffer, so no concatenation afterwards and no split of its gradient.
     One projection GEMM against the stacked W_ih; in backward the bias gradient comes out of the kernel, dW_ih of all
     problems is one batched GEMM against x, dW_hh one per problem against its own h_prev (no concatenated operands)."""
 
     @staticmethod
-    def forward(ctx, x, reverse_mask, P, *params):
+    def forward(ctx, x, reverse_mask, P, width, *params):
         lib = L.load()
         T, B, D = x.shape
         w_ih, w_hh, b_ih, b_hh = params[0::4], params[1::4], params[2::4], params[3::4]
@@ -124,45 +126,51 @@ class LstmGroup(torch.autograd.Function):
         bias = torch.cat([(bi + bh).index_select(0, perm) for bi, bh in zip(b_ih, b_hh)], 0)
         gx = torch.addmm(bias, x2, w_in.t())                                                # (T*B, P*4H)
         w_hh_all = torch.stack([w.contiguous() for w in w_hh], 0)
-        # per problem T + 2 time slots, zero | h_0 .. h_{T-1} | zero: h_prev is the same buffer shifted by one slot
-        # (down for a forward sweep, up for a reversed one), and every problem's h starts at slot 1
-        h_buf = torch.empty(P, T + 2, B, H, dtype=x.dtype, device=x.device)
+        # per output T + 2 time slots, zero | h_0 .. h_{T-1} | zero: h_prev is the same buffer shifted by one slot
+        # (down for a forward sweep, up for a reversed one)
+        n_out, W = P // width, width * H
+        h_buf = torch.empty(n_out, T + 2, B, W, dtype=x.dtype, device=x.device)
         h_buf[:, 0].zero_()
         h_buf[:, T + 1].zero_()
         train = any(ctx.needs_input_grad)
         cells = torch.empty(P, T, B, H, dtype=x.dtype, device=x.device) if train else None
-        L.check(lib.egp_lstm_group_fwd_f32(_p(gx), _p(w_hh_all), T, B, H, P, reverse_mask, _p(h_buf[0, 1]), (T + 2) * B * H,
+        base, esz = h_buf.data_ptr(), h_buf.element_size()
+        ptrs = (C.c_void_p * P)(*[base + esz * (((p // width) * (T + 2) + 1) * B * W + (p % width) * H) for p in range(P)])
+        L.check(lib.egp_lstm_group_fwd_f32(_p(gx), _p(w_hh_all), T, B, H, P, reverse_mask, ptrs, W,
                                            _p(gx if train else None), _p(cells), _s()), "egp_lstm_group_fwd_f32")
-        hs = tuple(h_buf[p, 1:T + 1] for p in range(P))
+        outs = tuple(h_buf[i, 1:T + 1] for i in range(n_out))
         if train:
             ctx.save_for_backward(x2, w_in, w_hh_all, h_buf, gx, cells)
-            ctx.meta = (T, B, D, H, P, reverse_mask)
-        return hs
+            ctx.meta = (T, B, D, H, P, width, reverse_mask)
+        return outs
 
     @staticmethod
-    def backward(ctx, *dhs):
+    def backward(ctx, *douts):
         lib = L.load()
         x2, w_in, w_hh_all, h_buf, gates, cells = ctx.saved_tensors
-        T, B, D, H, P, reverse_mask = ctx.meta
+        T, B, D, H, P, width, reverse_mask = ctx.meta
+        W = width * H
         perm, inv = _gate_perm(H, x2.device)
-        dhs = [dh.contiguous() if dh is not None else h_buf.new_zeros(T, B, H) for dh in dhs]
-        ptrs = (C.c_void_p * P)(*[dh.data_ptr() for dh in dhs])
+        douts = [d.contiguous() if d is not None else h_buf.new_zeros(T, B, W) for d in douts]
+        esz = h_buf.element_size()
+        ptrs = (C.c_void_p * P)(*[douts[p // width].data_ptr() + esz * (p % width) * H for p in range(P)])
         dpre = torch.empty(T * B, P * 4 * H, dtype=x2.dtype, device=x2.device)
         db = torch.zeros(P, 4 * H, dtype=x2.dtype, device=x2.device)
-        L.check(lib.egp_lstm_group_bwd_f32(ptrs, _p(gates), _p(cells), _p(w_hh_all), T, B, H, P, reverse_mask, _p(dpre), _p(db), _s()),
+        L.check(lib.egp_lstm_group_bwd_f32(ptrs, W, _p(gates), _p(cells), _p(w_hh_all), T, B, H, P, reverse_mask, _p(dpre), _p(db), _s()),
                 "egp_lstm_group_bwd_f32")
         d3 = dpre.view(T, B, P * 4 * H)
         dw_ih_all = torch.bmm(d3.transpose(1, 2), x2.view(T, B, D)).sum(0)                 # (P*4H, D), kernel gate order
         grads = []
         for p in range(P):
             rev = (reverse_mask >> p) & 1
-            h_prev = h_buf[p, 2:] if rev else h_buf[p, :T]
+            slab = h_buf[p // width, 2:] if rev else h_buf[p // width, :T]
+            h_prev = slab[:, :, (p % width) * H:(p % width + 1) * H]
             dw_hh = torch.bmm(d3[:, :, p * 4 * H:(p + 1) * 4 * H].transpose(1, 2), h_prev).sum(0).index_select(0, inv)
             dw_ih = dw_ih_all[p * 4 * H:(p + 1) * 4 * H].index_select(0, inv)
             d_b = db[p].index_select(0, inv)
             grads += [dw_ih, dw_hh, d_b, d_b]
         d_x = dpre.mm(w_in).view(T, B, D) if ctx.needs_input_grad[0] else None
-        return (d_x, None, None, *grads)
+        return (d_x, None, None, None, *grads)
 
 
 def group_available(x, cells):
@@ -173,11 +181,12 @@ def group_available(x, cells):
     return all(available(x, c) and c.hidden_size == c0.hidden_size and c.input_size == c0.input_size for c in cells)
 
 
-def lstm_group(x, cells, reverses):
-    """[(T,B,H)] * P for P (cell, reverse) pairs over the same x (T,B,D), one grouped launch each way."""
+def lstm_group(x, cells, reverses, pairs=False):
+    """P (cell, reverse) pairs over the same x (T,B,D), one grouped launch each way. Returns [(T,B,H)] * P, or with
+    pairs=True [(T,B,2H)] * P/2 where problems 2i and 2i+1 fill the two halves of output i."""
     mask = sum(1 << i for i, r in enumerate(reverses) if r)
     params = [t for c in cells for t in (c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh)]
-    return list(LstmGroup.apply(x.contiguous(), mask, len(cells), *params))
+    return list(LstmGroup.apply(x.contiguous(), mask, len(cells), 2 if pairs else 1, *params))
 
 
 def lstm_direction(cell, x, reverse):

@@ -527,10 +527,9 @@ def grouped_video_context(nets):
     x = n0.cnn_feat_ctx                      # same episodes, same windows for every net (initialize() of the same batch)
     if not _hip_lstm.group_available(x, cells):
         return False
-    hs = _hip_lstm.lstm_group(x, cells, revs)
-    k = 2 if n0.v_net.bi_dir else 1
+    hs = _hip_lstm.lstm_group(x, cells, revs, pairs=n0.v_net.bi_dir)     # bi-directional: (T, B, 2H) per net, no concatenation
     for i, n in enumerate(nets):
-        n._v_ctx = (torch.cat(hs[k * i:k * i + k], 2) if k == 2 else hs[k * i], torch.is_grad_enabled())
+        n._v_ctx = (hs[i], torch.is_grad_enabled())
     return True
 
 

@@ -224,13 +224,15 @@ int egp_lstm_bwd_f32(const float *dh_out, const float *gates_save, const float *
  * Needs the unit-major layout (egp_lstm_gate_layout() == EGP_LSTM_GATES_UNIT_MAJOR).
  *   gates_x / gates_save / d_pre [T*B][n_problems*4H]: columns p*4H .. (p+1)*4H-1 belong to problem p (what one
  *   projection GEMM against the row-stacked W_ih of all problems produces);  w_hh [n_problems][4H][H];
- *   reverse_mask bit p: problem p runs backwards in time;  h_out + p*h_stride -> [T][B][H] of problem p;
- *   cells_save [n_problems][T][B][H];  dh_out[p] -> [T][B][H];  d_bias (optional) [n_problems][4H], zeroed by the
- *   caller, receives sum over (t, b) of d_pre (float atomics). */
+ *   reverse_mask bit p: problem p runs backwards in time;  h_out[p] -> problem p's hidden states, row (t, b) at
+ *   h_out[p] + (t*B + b)*ld_h (ld_h = H for a dense [T][B][H]; 2H when the two directions of a bi-LSTM fill the halves of
+ *   one [T][B][2H] buffer);  cells_save [n_problems][T][B][H];  dh_out[p] / ld_dh likewise;  d_bias (optional)
+ *   [n_problems][4H], zeroed by the caller, receives sum over (t, b) of d_pre (float atomics). */
 int egp_lstm_group_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t B, int32_t hidden, int32_t n_problems,
-                           int32_t reverse_mask, float *h_out, int64_t h_stride, float *gates_save, float *cells_save, void *stream);
-int egp_lstm_group_bwd_f32(const float *const *dh_out, const float *gates_save, const float *cells_save, const float *w_hh, int32_t T,
-                           int32_t B, int32_t hidden, int32_t n_problems, int32_t reverse_mask, float *d_pre, float *d_bias, void *stream);
+                           int32_t reverse_mask, float *const *h_out, int32_t ld_h, float *gates_save, float *cells_save, void *stream);
+int egp_lstm_group_bwd_f32(const float *const *dh_out, int32_t ld_dh, const float *gates_save, const float *cells_save, const float *w_hh,
+                           int32_t T, int32_t B, int32_t hidden, int32_t n_problems, int32_t reverse_mask, float *d_pre, float *d_bias,
+                           void *stream);
 
 /* ----------------------------------------------------------------------------------------
  * K8: dynamics terms on the GPU. From (qpos, qvel) per env: body frame positions (mjData.xpos[1:]),

@@ -131,6 +131,19 @@ def test_grouped_sweeps_match_separate_ones():
 
     h_g, dx_g, g_g = run(True)
     h_s, dx_s, g_s = run(False)
+    # paired form: the two directions of a cell pair fill the halves of one (T, B, 2H) buffer
+    for c in cells:
+        c.zero_grad()
+    xx = x.clone().requires_grad_(True)
+    hp = hl.lstm_group(xx, cells, revs, pairs=True)
+    assert len(hp) == 2 and hp[0].shape == (T, B, 2 * H)
+    sum((h * torch.cat(ws[2 * i:2 * i + 2], 2)).sum() for i, h in enumerate(hp)).backward()
+    for i, h in enumerate(hp):
+        torch.testing.assert_close(h.detach(), torch.cat(h_s[2 * i:2 * i + 2], 2), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(xx.grad, dx_s, rtol=1e-4, atol=1e-4)
+    for c, gb in zip(cells, g_s):
+        for a, b in zip([p.grad for p in c.parameters()], gb):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()) + 1e-6)
     for a, b in zip(h_g, h_s):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(dx_g, dx_s, rtol=1e-4, atol=1e-4)
