@@ -1,0 +1,257 @@
+// Device side of K8 (see egp_dynamics.hip): the per-env dynamics pass as a wave-level function, shared by the stand-alone
+// kernel k_dynamics and the resident stable-PD kernel (egp_kernels.hip: k_pd_server_tree58<true>), which runs it on the
+// state rows it has just read instead of taking qM / qfrc_bias from the host.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace egp_dyn {
+
+constexpr int DY_MAXB = 24;      // bodies
+constexpr int DY_MAXJ = 64;      // hinges
+constexpr int DY_MAXC = 4;       // children per body
+constexpr int DY_MAXV = 64;      // dofs
+
+struct DynTables {               // device copy of the tree, laid out as the kernel stages it
+    int nb, nj, nv, max_level;
+    int parent[DY_MAXB], level[DY_MAXB], nchild[DY_MAXB], child[DY_MAXB][DY_MAXC], first_j[DY_MAXB], ndof[DY_MAXB];
+    int dof_parent[DY_MAXV], dof_madr[DY_MAXV], dof_body[DY_MAXV];
+    int last_dof[DY_MAXB];       // deepest dof of the body's chain (its own last hinge, or the nearest ancestor's)
+    int subtree_end[DY_MAXB];    // bodies [b, subtree_end[b]) form b's subtree (depth-first body order)
+    double off[DY_MAXB][3];      // body_pos - body_pos[parent]   (zero pose, global)
+    double com_l[DY_MAXB][3];    // body_com - body_pos
+    double I_l[DY_MAXB][6];      // inertia about the COM, axes of the zero pose: xx, yy, zz, xy, xz, yz
+    double mass[DY_MAXB];
+    double axis[DY_MAXJ][3], anc[DY_MAXJ][3];   // hinge axis, anchor - body_pos[body]
+    double armature, g[3];
+};
+
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+struct M3 { double m[9]; };      // row major
+__device__ __forceinline__ V3 mul(const M3 &R, V3 v) {
+    return {R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z, R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z, R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z};
+}
+__device__ __forceinline__ M3 mul(const M3 &A, const M3 &B) {
+    M3 C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+    return C;
+}
+// Rodrigues: I + sin K + (1 - cos) K^2
+__device__ __forceinline__ M3 axis_angle(V3 a, double ang) {
+    const double s = sin(ang), c1 = 1.0 - cos(ang);
+    M3 R;
+    R.m[0] = 1.0 + c1 * (-a.y * a.y - a.z * a.z); R.m[1] = -s * a.z + c1 * a.x * a.y;          R.m[2] = s * a.y + c1 * a.x * a.z;
+    R.m[3] = s * a.z + c1 * a.x * a.y;           R.m[4] = 1.0 + c1 * (-a.x * a.x - a.z * a.z); R.m[5] = -s * a.x + c1 * a.y * a.z;
+    R.m[6] = -s * a.y + c1 * a.x * a.z;          R.m[7] = s * a.x + c1 * a.y * a.z;           R.m[8] = 1.0 + c1 * (-a.x * a.x - a.y * a.y);
+    return R;
+}
+
+// spatial vectors: [angular; linear-at-origin] motion, [moment-about-origin; force] force
+struct Sp { V3 w, v; };
+__device__ __forceinline__ Sp operator+(Sp a, Sp b) { return {a.w + b.w, a.v + b.v}; }
+__device__ __forceinline__ Sp operator*(double s, Sp a) { return {s * a.w, s * a.v}; }
+__device__ __forceinline__ Sp cross_m(Sp a, Sp b) { return {cross(a.w, b.w), cross(a.w, b.v) + cross(a.v, b.w)}; }
+__device__ __forceinline__ Sp cross_f(Sp a, Sp f) { return {cross(a.w, f.w) + cross(a.v, f.v), cross(a.w, f.v)}; }
+__device__ __forceinline__ double sdot(Sp a, Sp f) { return dot(a.w, f.w) + dot(a.v, f.v); }
+// spatial inertia about the world origin: mass, first moment h = m c, rotational inertia I (xx, yy, zz, xy, xz, yz)
+__device__ __forceinline__ Sp inertia_apply(const double *in10, Sp s) {
+    const double m = in10[0];
+    const V3 h = {in10[1], in10[2], in10[3]};
+    const double *I = in10 + 4;
+    const V3 Iw = {I[0] * s.w.x + I[3] * s.w.y + I[4] * s.w.z, I[3] * s.w.x + I[1] * s.w.y + I[5] * s.w.z, I[4] * s.w.x + I[5] * s.w.y + I[2] * s.w.z};
+    return {Iw + cross(h, s.v), m * s.v + cross(s.w, h)};
+}
+
+__device__ __forceinline__ void st_sp(double *p, Sp s) { p[0] = s.w.x; p[1] = s.w.y; p[2] = s.w.z; p[3] = s.v.x; p[4] = s.v.y; p[5] = s.v.z; }
+__device__ __forceinline__ Sp ld_sp(const double *p) { return {{p[0], p[1], p[2]}, {p[3], p[4], p[5]}}; }
+
+// per-env LDS (doubles): local chain transforms, world frames, joint motion vectors, inertias, velocities, forces
+constexpr int DY_ENV_DOUBLES = DY_MAXB * 12 * 2 + DY_MAXJ * 6 + DY_MAXV * 6 * 2 + DY_MAXB * 10 + DY_MAXB * 6;
+
+// Every env is owned by ONE wavefront, so the phases only need the wave's own LDS writes to have landed before its
+// next reads: LDS operations of a wave complete in order; the fences keep the compiler from moving accesses across.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void ld_m3(const double *p, M3 &R) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R.m[i] = p[i];
+}
+__device__ __forceinline__ void st_m3(double *p, const M3 &R) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p[i] = R.m[i];
+}
+__device__ __forceinline__ V3 ld_v3(const double *p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st_v3(double *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+
+// No level-by-level sweep: every lane walks its own (short) ancestor chain, so the tree costs four wave-local
+// synchronisations instead of two per depth level, and no lane waits for lanes of other levels.
+//   A  lane = body : chain of the body's own hinges in the PARENT frame -> local transform (Rl, tl) and the hinges' local
+//                    axis / anchor (parent-frame coordinates)
+//   B  lane = body : world frame = root frame o local transforms along the ancestor path (walked upwards)
+//   C  lane = dof  : joint motion vector S_d in world coordinates, and S_d * qvel_d
+//   D  lane = body : spatial velocity and bias acceleration from the dof chain (walked upwards with suffix sums), own
+//                    spatial inertia, body force
+//   E  lane = body : composite inertia / subtree force = sum over the body's contiguous (depth-first) subtree range
+//   F  lane = dof  : column of M up the ancestor chain, bias entry
+// `tb`: the tree tables (LDS copy); `base`: DY_ENV_DOUBLES doubles of wave-private LDS; q / qd: the env's qpos / qvel (any
+// memory the wave can read); outputs may be NULL: qM_out = the env's sparse inertia row (MuJoCo order), bias_out [nv],
+// xpos_out [nb][3]. `valid` = false makes the wave compute on its inputs and write nothing.
+__device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base, const double *q, const double *qd, int lane, bool valid,
+                                              double *qM_out, double *bias_out, double *xpos_out) {
+    double *sLoc = base;                                 // [nb][12]  local transform in the parent frame: Rl (9), tl (3)
+    double *sW = sLoc + DY_MAXB * 12;                    // [nb][12]  world frame: R (9), p (3)
+    double *sJl = sW + DY_MAXB * 12;                     // [nj][6]   hinge axis (3) and anchor (3) in the parent frame of its body
+    double *sS = sJl + DY_MAXJ * 6;                      // [nv][6]   joint motion vectors (world)
+    double *sSq = sS + DY_MAXV * 6;                      // [nv][6]   S_d * qvel_d
+    double *sIb = sSq + DY_MAXV * 6;                     // [nb][10]  own spatial inertia about the world origin
+    double *sF = sIb + DY_MAXB * 10;                     // [nb][6]   body force
+    const int nb = tb.nb, nv = tb.nv;
+    const int b = lane;
+    // ---- A: own hinge chain in the parent frame
+    if (b < nb) {
+        M3 Rl;
+        V3 tl;
+        if (b == 0) {
+            double qw = q[3], qx = q[4], qy = q[5], qz = q[6];
+            const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+            qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+            Rl.m[0] = 1 - 2 * (qy * qy + qz * qz); Rl.m[1] = 2 * (qx * qy - qz * qw);     Rl.m[2] = 2 * (qx * qz + qy * qw);
+            Rl.m[3] = 2 * (qx * qy + qz * qw);     Rl.m[4] = 1 - 2 * (qx * qx + qz * qz); Rl.m[5] = 2 * (qy * qz - qx * qw);
+            Rl.m[6] = 2 * (qx * qz - qy * qw);     Rl.m[7] = 2 * (qy * qz + qx * qw);     Rl.m[8] = 1 - 2 * (qx * qx + qy * qy);
+            tl = {q[0], q[1], q[2]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rl.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
+            tl = {tb.off[b][0], tb.off[b][1], tb.off[b][2]};
+            const int j0 = tb.first_j[b];
+            for (int k = 0; k < tb.ndof[b]; ++k) {
+                const int j = j0 + k;
+                const V3 a_loc = {tb.axis[j][0], tb.axis[j][1], tb.axis[j][2]};
+                const V3 anc_loc = {tb.anc[j][0], tb.anc[j][1], tb.anc[j][2]};
+                const V3 a_p = mul(Rl, a_loc);                   // axis / anchor before this hinge turns, parent-frame coordinates
+                const V3 r_p = tl + mul(Rl, anc_loc);
+                st_v3(sJl + j * 6, a_p);
+                st_v3(sJl + j * 6 + 3, r_p);
+                Rl = mul(Rl, axis_angle(a_loc, q[7 + j]));
+                tl = r_p - mul(Rl, anc_loc);
+            }
+        }
+        st_m3(sLoc + b * 12, Rl);
+        st_v3(sLoc + b * 12 + 9, tl);
+    }
+    wave_sync();
+    // ---- B: world frames (compose upwards: T_world = T_root o ... o T_parent o T_b)
+    if (b < nb) {
+        M3 R;
+        ld_m3(sLoc + b * 12, R);
+        V3 t = ld_v3(sLoc + b * 12 + 9);
+        for (int c = tb.parent[b]; c >= 0; c = tb.parent[c]) {
+            M3 Rc;
+            ld_m3(sLoc + c * 12, Rc);
+            t = ld_v3(sLoc + c * 12 + 9) + mul(Rc, t);
+            R = mul(Rc, R);
+        }
+        st_m3(sW + b * 12, R);
+        st_v3(sW + b * 12 + 9, t);
+        if (valid && xpos_out) st_v3(xpos_out + b * 3, t);
+    }
+    wave_sync();
+    // ---- C: joint motion vectors
+    if (lane < nv) {
+        const int d = lane;
+        Sp S;
+        if (d < 3) {
+            S = {{0, 0, 0}, {d == 0 ? 1.0 : 0.0, d == 1 ? 1.0 : 0.0, d == 2 ? 1.0 : 0.0}};
+        } else if (d < 6) {      // rotation about the root's own axis d-3 through the root origin
+            const V3 a = {sW[d - 3], sW[3 + d - 3], sW[6 + d - 3]};
+            S = {a, cross(ld_v3(sW + 9), a)};
+        } else {
+            const int j = d - 6, par = tb.parent[tb.dof_body[d]];
+            M3 Rp;
+            ld_m3(sW + par * 12, Rp);
+            const V3 a_w = mul(Rp, ld_v3(sJl + j * 6));
+            const V3 r_w = ld_v3(sW + par * 12 + 9) + mul(Rp, ld_v3(sJl + j * 6 + 3));
+            S = {a_w, cross(r_w, a_w)};
+        }
+        st_sp(sS + d * 6, S);
+        st_sp(sSq + d * 6, qd[d] * S);
+    }
+    wave_sync();
+    // ---- D: velocity, bias acceleration, own inertia, body force
+    if (b < nb) {
+        // a = a0 + sum over dof pairs d' < d of the chain of (S_d' qd_d') x (S_d qd_d), except pairs inside the root's three
+        // rotational dofs (their axes ride on the root itself: d/dt S = v_root x S, whose rot-rot part cancels).
+        Sp suffix = {{0, 0, 0}, {0, 0, 0}};          // sum of S_d qd_d over the dofs visited so far (below the current one)
+        Sp hinge_suffix = suffix;                     // the same without the root's rotational dofs
+        Sp a = {{0, 0, 0}, {-tb.g[0], -tb.g[1], -tb.g[2]}};
+        for (int d = tb.last_dof[b]; d >= 0; d = tb.dof_parent[d]) {
+            const Sp sq = ld_sp(sSq + d * 6);
+            const bool root_rot = d >= 3 && d < 6;
+            a = a + cross_m(sq, root_rot ? hinge_suffix : suffix);
+            suffix = suffix + sq;
+            if (!root_rot) hinge_suffix = hinge_suffix + sq;
+        }
+        const Sp v = suffix;
+        M3 R;
+        ld_m3(sW + b * 12, R);
+        const V3 p = ld_v3(sW + b * 12 + 9);
+        const V3 c = p + mul(R, V3{tb.com_l[b][0], tb.com_l[b][1], tb.com_l[b][2]});
+        const double *Il = tb.I_l[b];
+        M3 I0;
+        I0.m[0] = Il[0]; I0.m[1] = Il[3]; I0.m[2] = Il[4];
+        I0.m[3] = Il[3]; I0.m[4] = Il[1]; I0.m[5] = Il[5];
+        I0.m[6] = Il[4]; I0.m[7] = Il[5]; I0.m[8] = Il[2];
+        M3 Rt;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) Rt.m[3 * i + jj] = R.m[3 * jj + i];
+        const M3 Iw = mul(mul(R, I0), Rt);
+        const double m = tb.mass[b], cc = dot(c, c);
+        double in10[10];
+        in10[0] = m; in10[1] = m * c.x; in10[2] = m * c.y; in10[3] = m * c.z;
+        in10[4] = Iw.m[0] + m * (cc - c.x * c.x); in10[5] = Iw.m[4] + m * (cc - c.y * c.y); in10[6] = Iw.m[8] + m * (cc - c.z * c.z);
+        in10[7] = Iw.m[1] - m * c.x * c.y;        in10[8] = Iw.m[2] - m * c.x * c.z;        in10[9] = Iw.m[5] - m * c.y * c.z;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) sIb[b * 10 + i] = in10[i];
+        st_sp(sF + b * 6, inertia_apply(in10, a) + cross_f(v, inertia_apply(in10, v)));
+    }
+    wave_sync();
+    // ---- E + F: lane = dof. Composite inertia and subtree force of the dof's body = sums over its depth-first range.
+    if (valid && lane < nv) {
+        const int d = lane, bd = tb.dof_body[d];
+        double ic[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        Sp fc = {{0, 0, 0}, {0, 0, 0}};
+        for (int c = bd; c < tb.subtree_end[bd]; ++c) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) ic[i] += sIb[c * 10 + i];
+            fc = fc + ld_sp(sF + c * 6);
+        }
+        const Sp S = ld_sp(sS + d * 6);
+        if (qM_out) {
+            const Sp F = inertia_apply(ic, S);
+            double *out = qM_out + tb.dof_madr[d];
+            int i = d, k = 0;
+            while (i >= 0) {
+                double v = sdot(ld_sp(sS + i * 6), F);
+                if (i == d && d >= 6) v += tb.armature;
+                out[k++] = v;
+                i = tb.dof_parent[i];
+            }
+        }
+        if (bias_out) bias_out[d] = sdot(S, fc);
+    }
+}
+
+}  // namespace egp_dyn

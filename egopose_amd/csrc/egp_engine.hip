@@ -153,6 +153,7 @@ struct egp_engine {
     bool flag_poll = false;                   // leader polls a pinned completion flag instead of hipStreamSynchronize
     double *hd_state = nullptr, *hd_torque = nullptr, *hd_qM = nullptr, *hd_ee = nullptr;   // device-side aliases of h_state / h_torque / h_qM
     bool server_ok = false;                   // resident-K1 mode allowed (EGP_SERVER, block budget)
+    bool server_dyn_ok = false;               // ... also with device dynamics (its 110 kB of LDS: one workgroup per CU)
     bool device_dynamics = false;             // K8 supplies qM / qfrc_bias from the drained (qpos, qvel) each substep
     double *d_bias = nullptr;                 // [n_env][nv] K8's bias (device-dynamics mode)
     int spin_us = 0;                          // EGP_SPIN_US: poll this long for the next env-step before sleeping (off: measured no gain)
@@ -344,7 +345,8 @@ void run_step(egp_engine *E, Group &G, int tid) {
 }
 
 inline bool server_mode(const egp_engine *E, const Group &G) {
-    return !E->device_dynamics && E->server_ok && G.srv.n_slices > 0 && E->flag_poll && E->zero_copy && E->ctx->pd_variant == 0 && E->ctx->tree58;
+    return (!E->device_dynamics || E->server_dyn_ok) && E->server_ok && G.srv.n_slices > 0 && E->flag_poll && E->zero_copy &&
+           E->ctx->pd_variant == 0 && E->ctx->tree58;
 }
 
 // Resident-K1 env-step: one launch of k_pd_server_tree58 serves all substeps. Every host thread owns a few slices
@@ -397,7 +399,7 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
                                       S.hd_go, base, FS, S.hd_err, 2.0, S.d_trace, E->hd_ee + (size_t)G.e0 * 15,
                                       E->d_qpos + (size_t)G.e0 * E->nq, E->d_prev_qpos + (size_t)G.e0 * E->nq,
                                       E->d_qvel + (size_t)G.e0 * E->nv, E->d_ee + (size_t)G.e0 * 15,
-                                      G.has_active ? G.hd_active + G.e0 : nullptr);
+                                      G.has_active ? G.hd_active + G.e0 : nullptr, E->device_dynamics);
         if (rc != EGP_OK) fail(G, rc, "K1 server launch", egp_last_error());
         if (G.prof_now) G_HIP(hipEventRecord(G.k_end[0], G.stream));
         G_HIP(hipEventRecord(G.done, G.stream));      // the kernel's epilogue moves the final state to HBM
@@ -874,6 +876,10 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
         if (const char *mb = getenv("EGP_SERVER_MAX_BLOCKS")) max_blocks = atoi(mb);
         const char *sv = getenv("EGP_SERVER");
         E->server_ok = all_groups_sliced && total_server_blocks <= max_blocks && !(sv && atoi(sv) == 0);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
+            E->server_dyn_ok = total_server_blocks <= prop.multiProcessorCount &&
+                               egp_pd_server_dyn_lds_bytes() + 48 * 1024 <= (size_t)prop.maxSharedMemoryPerMultiProcessor;
     }
 #undef E_TRY
     const char *prof = getenv("EGP_PROFILE_K1");

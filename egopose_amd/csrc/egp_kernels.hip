@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include "egp_internal.hpp"
+#include "egp_dynamics_dev.hpp"
 #include "egp_quat.hpp"
 
 namespace egp {
@@ -381,6 +382,7 @@ struct PdServe {
     int poll_sleep;                       // s_sleep(1) (64 clocks) repeats between two polls of a go word
     const int *active;                    // optional [n] (pinned host): envs with 0 are not stepped this env-step -- their waves
                                           // move no state, torque or epilogue rows (in a rollout's tail that is most of the PCIe traffic)
+    const void *dyn;                      // DYN kernels: the egp_dyn::DynTables of the context (device)
 };
 
 // Poll a word of pinned host memory through the SCALAR memory path (s_load ... glc = always fetch from beyond the
@@ -398,9 +400,15 @@ __device__ __forceinline__ double sys_load_f64(const double *p) {
     return __longlong_as_double((long long)u);
 }
 
+// DYN (device_dynamics engines): the wave computes the inertia and the bias force itself from the (qpos, qvel) row it has
+// just read (K8's wave function: FK + CRBA + RNE, egp_dynamics_dev.hpp) instead of taking qM / qfrc_bias from the host --
+// a backend whose inertia changes with every substep (MuJoCo's does) then sends 117 doubles per env-substep, not 1 085,
+// at the price of a fresh factorisation per substep. Needs the dynamic LDS (tables + per-wave scratch).
+template <bool DYN>
 __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, const double *qpos, const double *qvel,
                                                           const double *__restrict__ action, const double *qM, const double *C,
                                                           int n, double *torque, PdServe sv) {
+    extern __shared__ double s_dynmem[];
     __shared__ short s_map[PD_NV * PD_NV];
     __shared__ double s_qM[4][PD_NM_MAX];
     __shared__ unsigned long long s_go[2];
@@ -439,6 +447,16 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
 #pragma unroll
         for (int k = 0; k < QM_IT; ++k) s_qM[wave][lane + 64 * k] = t_qM[k];
     }
+    constexpr int TB_DOUBLES = DYN ? (int)((sizeof(egp_dyn::DynTables) + 7) / 8) : 0;
+    egp_dyn::DynTables *tb = reinterpret_cast<egp_dyn::DynTables *>(s_dynmem);
+    double *s_scr = s_dynmem + TB_DOUBLES + wave * egp_dyn::DY_ENV_DOUBLES;                   // K8 scratch of this wave
+    double *s_q = s_dynmem + TB_DOUBLES + 4 * egp_dyn::DY_ENV_DOUBLES + wave * 192;            // qpos[64] | qvel[64] | bias[64]
+    if constexpr (DYN) {
+        const int words = sizeof(egp_dyn::DynTables) / 4;
+        const int *src = reinterpret_cast<const int *>(sv.dyn);
+        int *dst = reinterpret_cast<int *>(tb);
+        for (int i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
+    }
     if (threadIdx.x == 0) s_abort = 0;
     const double target = c_ref + r_a * c_scale;
     const bool tracer = sv.trace && blockIdx.x == 0 && threadIdx.x == 0;
@@ -466,12 +484,22 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
             if (threadIdx.x == 0) __hip_atomic_store(sv.err, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
-        const bool refresh = (s_go[sub & 1] & 1ull) != 0ull;
+        const bool refresh = DYN || (s_go[sub & 1] & 1ull) != 0ull;
         if (live) {
-            const double r_q = sys_load_f64(qpos + env * ld.qpos + 7 + act);
-            const double r_v = sys_load_f64(qvel + env * ld.qvel + row);
-            const double r_c = sys_load_f64(C + env * ld.bias + row);
-            if (refresh) {                      // this wave's inertia row changed on the host: LDS and HBM copies
+            double r_q, r_v, r_c;
+            if constexpr (DYN) {
+                if (lane < sv.nq) s_q[lane] = sys_load_f64(qpos + env * ld.qpos + lane);
+                if (lane < sv.nv) s_q[64 + lane] = sys_load_f64(qvel + env * ld.qvel + lane);
+                egp_dyn::wave_sync();
+                egp_dyn::dynamics_wave(*tb, s_scr, s_q, s_q + 64, lane, true, &s_qM[wave][0], s_q + 128, nullptr);
+                egp_dyn::wave_sync();
+                r_q = s_q[7 + act]; r_v = s_q[64 + row]; r_c = s_q[128 + row];
+            } else {
+                r_q = sys_load_f64(qpos + env * ld.qpos + 7 + act);
+                r_v = sys_load_f64(qvel + env * ld.qvel + row);
+                r_c = sys_load_f64(C + env * ld.bias + row);
+            }
+            if (!DYN && refresh) {              // this wave's inertia row changed on the host: LDS and HBM copies
                 const double *src = sv.qM_host + env * ld.qM;
                 double *dst = sv.qM_dev + env * ld.qM;
                 double t_qM[QM_IT];
@@ -1307,13 +1335,18 @@ int egp_launch_pd_torque_strided(egp_ctx *ctx, const double *qpos, long ld_qpos,
     return launch_pd<double>(ctx, ld, qpos, qvel, action, qM, bias, n, torque, nullptr, stream, done);
 }
 
+size_t egp_pd_server_dyn_lds_bytes() {
+    return ((sizeof(egp_dyn::DynTables) + 7) / 8 + 4 * (size_t)egp_dyn::DY_ENV_DOUBLES + 4 * 192) * sizeof(double);
+}
+
 // engine entry for the resident K1 (see k_pd_server_tree58); all flag arrays are device-visible addresses
 int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const double *qvel, long ld_qvel, const double *bias,
                          long ld_bias, const double *qM, long ld_qM, const double *qM_host, const double *action, int32_t n,
                          double *torque, hipStream_t stream, const int *block_slice, const unsigned long long *go,
                          unsigned long long base, int n_sub, int *err, double timeout_s, long long *trace, const double *ee_host,
-                         double *out_qpos, double *out_prev_qpos, double *out_qvel, double *out_ee, const int *active) {
+                         double *out_qpos, double *out_prev_qpos, double *out_qvel, double *out_ee, const int *active, bool device_dynamics) {
     EGP_REQUIRE(ctx && ctx->tree58 && ctx->pd_variant == 0, "the K1 server needs the humanoid tree kernel");
+    EGP_REQUIRE(!device_dynamics || ctx->dyn_tables, "device dynamics needs egp_set_dynamics_model on the context");
     EGP_REQUIRE(ee_host && out_qpos && out_prev_qpos && out_qvel && out_ee, "NULL epilogue pointer");
     EGP_REQUIRE(ctx->dm.nq <= 64 && ctx->dm.nv <= 64, "the epilogue moves one state row per wavefront");
     EGP_REQUIRE(qpos && qvel && bias && qM && qM_host && action && torque && block_slice && go && err, "NULL pointer");
@@ -1321,8 +1354,16 @@ int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const d
     PdLd ld{ld_qpos, ld_qvel, ctx->dm.nu, ld_qM, ld_bias};
     static const int poll_sleep = [] { const char *e = getenv("EGP_SERVER_POLL_SLEEP"); return e ? atoi(e) : 2; }();
     PdServe sv{block_slice, go, base, n_sub, qM_host, const_cast<double *>(qM), err, (long long)(timeout_s * 100.0e6), trace,
-               ee_host, out_qpos, out_prev_qpos, out_qvel, out_ee, ctx->dm.nq, ctx->dm.nv, poll_sleep, active};
-    k_pd_server_tree58<<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, bias, n, torque, sv);
+               ee_host, out_qpos, out_prev_qpos, out_qvel, out_ee, ctx->dm.nq, ctx->dm.nv, poll_sleep, active, ctx->dyn_tables};
+    if (device_dynamics) {
+        const size_t lds = egp_pd_server_dyn_lds_bytes();
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pd_server_tree58<true>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) { set_error("hipFuncSetAttribute(k_pd_server_tree58<true>, %zu B of LDS): %s", lds, hipGetErrorString(attr)); return EGP_E_HIP; }
+        k_pd_server_tree58<true><<<dim3((n + 3) / 4), dim3(256), lds, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, bias, n, torque, sv);
+    } else {
+        k_pd_server_tree58<false><<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, bias, n, torque, sv);
+    }
     return after_launch("k_pd_server_tree58");
 }
 

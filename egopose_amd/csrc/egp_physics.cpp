@@ -210,6 +210,10 @@ int egp_physics_create_surrogate(const egp_surrogate_desc *d, int32_t n_env, egp
     vt.user = S; vt.reset = sur_reset; vt.step = sur_step; vt.drain = sur_drain; vt.destroy = sur_destroy;
     vt.name = "surrogate-euler-M0";
     vt.inertia_epoch = sur_epoch;
+    // EGP_SURROGATE_ALWAYS_DIRTY=1: report "inertia changed" on every drain, as a simulator with a pose-dependent qM
+    // (MuJoCo) would -- same numbers (M0), but the full 7.3 kB inertia row crosses to the GPU every substep. Traffic
+    // emulation for measurements (DESIGN: inertia epochs / device dynamics).
+    if (const char *e = getenv("EGP_SURROGATE_ALWAYS_DIRTY")) if (atoi(e) != 0) vt.inertia_epoch = nullptr;
     egp_physics *p = new egp_physics();
     p->vt = vt; p->n_env = n_env; p->owns_user = true;
     *out = p;

@@ -103,10 +103,13 @@ def test_dynamics_feeds_stable_pd(ctx, skel):
 
 
 @pytest.mark.gpu
-def test_engine_device_dynamics_matches_host_loop(ctx, skel):
+@pytest.mark.parametrize("mode", ["resident", "per_substep"])
+def test_engine_device_dynamics_matches_host_loop(ctx, skel, mode, monkeypatch):
     """Engine with device_dynamics: the backend is only asked for qpos / qvel (drain always gets qM == NULL), K8 feeds K1
-    every substep; 2 env-steps == the host loop with the oracle's stable PD on the oracle's M(q), C(q, qvel) of the
-    CURRENT state."""
+    every substep -- inside the resident kernel (one launch per env-step), or as a K8 + K1 launch pair per substep;
+    2 env-steps == the host loop with the oracle's stable PD on the oracle's M(q), C(q, qvel) of the CURRENT state."""
+    if mode == "per_substep":
+        monkeypatch.setenv("EGP_SERVER", "0")
     from conftest import load_golden, VaryingInertiaBackend
     from egopose_amd.physics import RolloutEngine, SurrogatePhysics
     c = load_golden("config_subject_03.npz")
@@ -125,7 +128,7 @@ def test_engine_device_dynamics_matches_host_loop(ctx, skel):
 
     be._drain = spy_drain
     eng = RolloutEngine(ctx, be, n, n_threads=2, n_groups=1, device_dynamics=True)
-    assert (eng.launches_per_substep, eng.substeps_per_launch) == (1, 1)
+    assert eng.substeps_per_launch == (15 if mode == "resident" else 1)
     eng.reset(np.arange(n), qpos0, qvel0)
     acts = [rng.normal(size=(n, 52)) * 0.2 for _ in range(2)]
     for a in acts:
