@@ -204,6 +204,8 @@ class StateRegTrainer:
         self.net = VideoRegNet(self.state_dim, cfg.v_hdim, cfg.cnn_fdim, no_cnn=no_cnn, frame_shape=frame_shape, cnn_type=cfg.cnn_type,
                                mlp_dim=cfg.mlp_dim, v_net_type=cfg.v_net, v_net_param=cfg.v_net_param, causal=cfg.causal)
         self.net.to(self.device, dtype)
+        if self.device.type == "cuda" and not no_cnn:
+            self.net.channels_last()       # NHWC encoder: MIOpen's faster layout on the MI355X (nets.VideoRegNet.channels_last)
         self.optimizer = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=cfg.lr)
         self.autocast = autocast           # e.g. torch.bfloat16: MFMA convolutions / GEMMs with fp32 master weights
 

@@ -10,8 +10,11 @@ T = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 # (torch.backends.cudnn.benchmark = True -- MIOpen's exhaustive search -- was tried: six minutes of tuning, same step time)
 dev = torch.device("cuda")
 torch.manual_seed(0)
-for name, ac in (("fp32", None), ("bf16 autocast", torch.bfloat16)):
+for name, ac, cl in (("fp32 channels_last (default)", None, True), ("fp32 NCHW", None, False),
+                     ("bf16 autocast channels_last", torch.bfloat16, True), ("bf16 autocast NCHW", torch.bfloat16, False)):
     net = VideoRegNet(115, 128, 128, no_cnn=False).to(dev)
+    if cl:
+        net.channels_last()       # what StateRegTrainer does on the GPU
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     x = torch.randn(T, 1, 3, 224, 224, device=dev)
     gt = torch.randn(T, 115, device=dev)
@@ -29,4 +32,4 @@ for name, ac in (("fp32", None), ("bf16 autocast", torch.bfloat16)):
     n = 8
     for _ in range(n): step()
     torch.cuda.synchronize(); dt = (time.time() - t0) / n
-    print("%-14s clip of %d frames: %.1f ms per step, %.0f frames/s" % (name, T, dt * 1e3, T / dt))
+    print("%-28s clip of %d frames: %.1f ms per step, %.0f frames/s" % (name, T, dt * 1e3, T / dt))
