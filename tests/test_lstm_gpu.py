@@ -108,13 +108,13 @@ def test_statereg_training_step_on_gpu():
 
 
 @pytest.mark.gpu
-def test_grouped_sweeps_match_separate_ones():
+@pytest.mark.parametrize("T,B,D,H", [(37, 70, 24, 64), (16, 8, 24, 64), (21, 13, 40, 128)])
+def test_grouped_sweeps_match_separate_ones(T, B, D, H):
     """lstm.LstmGroup (one grouped launch each way for 4 cells over the same input) == four lstm_direction calls:
-    outputs, d_x and every parameter gradient."""
+    outputs, d_x and every parameter gradient (ragged and full tiles, both hidden sizes)."""
     from egopose_amd import lstm as hl
     dev = torch.device("cuda", 0)
     torch.manual_seed(11)
-    T, B, D, H = 37, 70, 24, 64          # ragged tile (70 % 4 != 0), T % 8 != 0
     cells = [torch.nn.LSTMCell(D, H).to(dev) for _ in range(4)]
     revs = [False, True, False, True]
     x = torch.randn(T, B, D, device=dev)
