@@ -198,7 +198,7 @@ class AgentPPO(AgentPG):
         self.clip_epsilon, self.opt_batch_size = clip_epsilon, opt_batch_size
         self.use_mini_batch, self.policy_grad_clip = use_mini_batch, policy_grad_clip
 
-    def _group_contexts(self):
+    def _group_contexts(self, states=None):
         """Hook: prepare the critic's and the actor's state transforms together (AgentEgo). False = nothing prepared."""
         return False
 
@@ -238,7 +238,7 @@ class AgentPPO(AgentPG):
             # critic and actor have disjoint parameters: both backward passes run before the single gradient
             # exchange; the value step precedes the policy step as in the reference. (Running the two passes on two
             # HIP streams was faster and hung the GPU intermittently -- concurrent library GEMMs)
-            if self._group_contexts():
+            if self._group_contexts(states):
                 # both video nets' recurrences in one grouped launch each way; disjoint parameters, so one backward
                 # over the sum of the two losses yields exactly the two separate gradients
                 if self.value_opt_niter != 1:
@@ -288,9 +288,10 @@ class AgentEgo(AgentPPO):
     def push_memory(self, memory, state, action, mask, next_state, reward, exp):
         memory.push(state, action, mask, next_state, reward, exp, np.array([self.env.expert_ind, self.env.start_ind]))
 
-    def _group_contexts(self):
-        from .nets import grouped_video_context
-        return grouped_video_context([self.value_vs_net, self.policy_vs_net])
+    def _group_contexts(self, states=None):
+        from .nets import grouped_forecast_context, grouped_video_context
+        nets = [self.value_vs_net, self.policy_vs_net]
+        return grouped_video_context(nets) or grouped_forecast_context(nets, states)
 
     def trans_policy(self, states):
         return self.policy_vs_net(states)
@@ -315,7 +316,7 @@ class AgentEgo(AgentPPO):
             net.initialize((c["masks"], self.env.cnn_feat, v_metas))
         with to_test(*self.update_modules):
             with torch.no_grad():
-                self._group_contexts()       # the policy net's context is consumed by update_policy's first pass
+                self._group_contexts(c["states"])       # the policy net's context is consumed by update_policy's first pass
                 values = self.value_net(self.trans_value(c["states"]))
         advantages, returns = self._advantages(c["rewards"], c["masks"], values)
         self.update_policy(c["states"], c["actions"], returns, advantages, c["exps"])

@@ -425,6 +425,7 @@ class VideoForecastNet(nn.Module):
         self.indices = self.gather_indices = self.cnn_feat_ctx = None
         self.num_episode = self.max_episode_len = None
         self._cnn_table = None
+        self._grp = self._ctx_key = None
         self.set_mode("test")
 
     def set_mode(self, mode):
@@ -496,6 +497,14 @@ class VideoForecastNet(nn.Module):
             ctx = torch.as_tensor(ctx, dtype=dtype, device=device)
         self.cnn_feat_ctx = ctx
         self.gather_indices = torch.as_tensor(idx, dtype=torch.long, device=device)
+        self._ctx_key = (int(max_len), meta.shape[0], hash(meta.tobytes()))       # which windows / episodes this batch holds
+        self._grp = None
+
+    def state_sequences(self, x):
+        """Flat batch of states -> (max_episode_len, num_episode, state_dim), zero where an episode is shorter."""
+        s_ctx = x.new_zeros(self.num_episode * self.max_episode_len, self.state_dim)
+        s_ctx = s_ctx.index_copy(0, self.gather_indices, x)
+        return s_ctx.view(self.num_episode, self.max_episode_len, self.state_dim).transpose(0, 1).contiguous()
 
     def forward(self, x):
         if self.mode == "test":
@@ -503,16 +512,19 @@ class VideoForecastNet(nn.Module):
                 x = self.s_net(x)
             self.t += 1
             return torch.cat((self.v_out, x), dim=1)
-        if self.dynamic_v:
-            v_ctx = self.forward_v_net(self.cnn_feat_ctx)[self.v_margin:]
-        else:
-            v_ctx = self.forward_v_net(self.cnn_feat_ctx)[[-1]].expand(self.max_episode_len, -1, -1)
+        v_seq = s_seq = None
+        if self._grp is not None:            # both sweeps came out of grouped launches (grouped_forecast_context)
+            (v_seq, s_seq, x_ref, with_grad), self._grp = self._grp, None
+            if x_ref is not x or with_grad != torch.is_grad_enabled():
+                v_seq = s_seq = None         # prepared for another batch / autograd mode: never reuse
+        if v_seq is None:
+            v_seq = self.forward_v_net(self.cnn_feat_ctx)
+        v_ctx = v_seq[self.v_margin:] if self.dynamic_v else v_seq[[-1]].expand(self.max_episode_len, -1, -1)
         v_out = v_ctx.transpose(0, 1).reshape(-1, self.v_hdim).index_select(0, self.gather_indices)
         if self.s_net_type == "lstm":
-            s_ctx = x.new_zeros(self.num_episode * self.max_episode_len, self.state_dim)
-            s_ctx = s_ctx.index_copy(0, self.gather_indices, x)
-            s_ctx = s_ctx.view(self.num_episode, self.max_episode_len, self.state_dim).transpose(0, 1).contiguous()
-            s_out = self.s_net(s_ctx).transpose(0, 1).reshape(-1, self.s_hdim).index_select(0, self.gather_indices)
+            if s_seq is None:
+                s_seq = self.s_net(self.state_sequences(x))
+            s_out = s_seq.transpose(0, 1).reshape(-1, self.s_hdim).index_select(0, self.gather_indices)
         else:
             s_out = x
         return torch.cat((v_out, s_out), dim=1)
@@ -542,6 +554,30 @@ def grouped_video_context(nets):
     hs = _hip_lstm.lstm_group(x, cells, revs, pairs=n0.v_net.bi_dir)     # bi-directional: (T, B, 2H) per net, no concatenation
     for i, n in enumerate(nets):
         n._v_ctx = (hs[i], torch.is_grad_enabled())
+    return True
+
+
+def grouped_forecast_context(nets, x):
+    """ego_forecast's counterpart of grouped_video_context: the causal video LSTMs of all nets in one grouped launch each
+    way, and their state LSTMs over the scattered states `x` in another. Each net's next forward(x) consumes its pair."""
+    if os.environ.get("EGP_LSTM_GROUP", "1") == "0" or _LSTM_IMPL == "torch" or len(nets) < 2 or x is None:
+        return False
+    n0 = nets[0]
+    for n in nets:
+        if not (isinstance(n, VideoForecastNet) and n.mode == "train" and n.s_net_type == "lstm" and n.cnn_feat_ctx is not None
+                and n._ctx_key is not None and n._ctx_key == n0._ctx_key and n.cnn_feat_ctx.shape == n0.cnn_feat_ctx.shape
+                and n.cnn_feat_ctx.dtype == n0.cnn_feat_ctx.dtype and n.dynamic_v == n0.dynamic_v and n.state_dim == n0.state_dim
+                and not n.v_net.bi_dir and not n.s_net.bi_dir and n.v_net.cell_type == "lstm" and n.s_net.cell_type == "lstm"):
+            return False
+    v_cells, s_cells = [n.v_net.rnn_f for n in nets], [n.s_net.rnn_f for n in nets]
+    s_in = n0.state_sequences(x)
+    if not (_hip_lstm.group_available(n0.cnn_feat_ctx, v_cells) and _hip_lstm.group_available(s_in, s_cells)):
+        return False
+    fwd = [False] * len(nets)
+    hv = _hip_lstm.lstm_group(n0.cnn_feat_ctx, v_cells, fwd)
+    hs = _hip_lstm.lstm_group(s_in, s_cells, fwd)
+    for n, a, b in zip(nets, hv, hs):
+        n._grp = (a, b, x, torch.is_grad_enabled())
     return True
 
 

@@ -227,3 +227,46 @@ print("fma ok")
     env = dict(os.environ, EGP_LSTM_MFMA="0", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fma ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dynamic_v", [False, True])
+def test_grouped_forecast_contexts_match_per_net_contexts(dynamic_v):
+    """nets.grouped_forecast_context for ego_forecast's (value, policy) front ends == each net running its causal video
+    LSTM and its state LSTM itself: outputs and every parameter gradient."""
+    import numpy as np
+    from egopose_amd.nets import VideoForecastNet, grouped_forecast_context
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(4)
+    cdim, sdim, hdim, margin, T_ep = 128, 21, 128, 8, 17
+    cnn = [rng.normal(size=(200, cdim))]
+    lens = rng.randint(1, T_ep + 1, size=23); lens[0] = T_ep
+    masks, metas = [], []
+    for Lk in lens:
+        s0 = int(rng.randint(margin, cnn[0].shape[0] - T_ep - margin))
+        masks += [1.0] * (Lk - 1) + [0.0]
+        metas += [[0, s0]] * int(Lk)
+    masks = torch.tensor(masks, dtype=torch.float32, device=dev)
+    metas = np.array(metas)
+    table = torch.tensor(cnn[0], dtype=torch.float32, device=dev)
+    states = torch.randn(len(masks), sdim, device=dev)
+    w = torch.randn(len(masks), 2 * hdim, device=dev)
+    torch.manual_seed(6)
+    nets = [VideoForecastNet(cdim, sdim, hdim, margin, "lstm", None, hdim, "lstm", dynamic_v).to(dev) for _ in range(2)]
+    res = []
+    for grouped in (True, False):
+        for n in nets:
+            n.zero_grad()
+            n.attach_feature_table(table, np.array([0]))
+            n.set_mode("train")
+            n.initialize((masks, cnn, metas))
+        if grouped:
+            assert grouped_forecast_context(nets, states)
+        ys = [n(states) for n in nets]
+        assert all(n._grp is None for n in nets)
+        sum((y * w).sum() for y in ys).backward()
+        res.append([(y.detach().clone(), {k: p.grad.clone() for k, p in n.named_parameters()}) for y, n in zip(ys, nets)])
+    for (oa, ga), (ob, gb) in zip(*res):
+        torch.testing.assert_close(oa, ob, rtol=1e-5, atol=1e-5)
+        for k in gb:
+            torch.testing.assert_close(ga[k], gb[k], rtol=1e-4, atol=1e-4 * float(gb[k].abs().max()) + 1e-6, msg=lambda m, k=k: k + ": " + m)
