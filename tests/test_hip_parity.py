@@ -301,6 +301,35 @@ def test_engine_step_matches_host_loop(ctx, skel, mode, monkeypatch):
         ref.close()
 
 
+def test_surrogate_always_dirty_changes_traffic_not_numbers(ctx, skel, monkeypatch):
+    """EGP_SURROGATE_ALWAYS_DIRTY=1 (the inertia row crosses to the GPU on every substep, the traffic of a backend with a
+    pose-dependent qM) must give bit-identical env-steps to the default (inertia sent once)."""
+    from egopose_amd.physics import SurrogatePhysics, RolloutEngine
+    g = load_golden("body_quat_obs.npz")
+    n = 21
+    rng = np.random.RandomState(4)
+    qpos0, qvel0 = g["qpos"][:n], g["qvel"][:n] * 0.2
+    actions = [rng.normal(size=(n, 52)) * 0.2 for _ in range(2)]
+    outs = []
+    for dirty in ("0", "1"):
+        monkeypatch.setenv("EGP_SURROGATE_ALWAYS_DIRTY", dirty)
+        ph = SurrogatePhysics(skel, n)
+        eng = RolloutEngine(ctx, ph, n, n_threads=3, n_groups=1)
+        assert eng.substeps_per_launch == 15
+        eng.reset(np.arange(n), qpos0, qvel0)
+        for a in actions:
+            ad = dev(a)
+            torch.cuda.synchronize()
+            eng.step_async(0, ad)
+            eng.wait(0)
+        torch.cuda.synchronize()
+        outs.append((eng.qpos.cpu().numpy().copy(), eng.qvel.cpu().numpy().copy(), eng.ee_wpos.cpu().numpy().copy()))
+        eng.close()
+        ph.close()
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("mode", ["resident", "pipelined", "barrier"])
 def test_engine_follows_changing_inertia(ctx, skel, mode, monkeypatch):
     """A backend whose qM changes on every step (what a MuJoCo adapter looks like): every torque row the engine
