@@ -202,6 +202,10 @@ class RNN(nn.Module):
             else:
                 self.hx = self.rnn_f(x, self.hx)
             return self.hx
+        if (self.bi_dir and self.cell_type == "lstm" and _LSTM_IMPL != "torch" and os.environ.get("EGP_LSTM_GROUP", "1") != "0"
+                and _hip_lstm.group_available(x, [self.rnn_f, self.rnn_b])):
+            # both directions in one grouped launch each way, writing the halves of one (T, B, 2H) buffer (lstm.LstmGroup)
+            return _hip_lstm.lstm_group(x, [self.rnn_f, self.rnn_b], [False, True], pairs=True)[0]
         out = self._sweep(self.rnn_f, x, False)
         if self.bi_dir:
             out = torch.cat((out, self._sweep(self.rnn_b, x, True)), 2)
