@@ -95,7 +95,7 @@ def main():
     cfg = (ForecastConfig if args.task == "egoforecast" else Config)(args.cfg, create_dirs=False)
     from egopose_amd.physics import available_cpus, default_threads
     cores = available_cpus()
-    n_threads = args.threads or max(args.groups, default_threads(share=world))
+    n_threads = args.threads or max(args.groups, default_threads(share=world, device_index=local))
     tr = Trainer(cfg, dev, torch.float32, num_envs=args.envs, num_threads=n_threads, num_groups=args.groups, seed_offset=rank)
     min_batch = (args.min_batch or cfg.min_batch_size) * world      # Agent.sample splits it evenly over ranks
 
@@ -149,6 +149,7 @@ def main():
                         "PPO 10 full-batch epochs" % (args.cfg, args.envs, cfg.fr_margin, cfg.env_episode_len)),
                        "envs_per_gpu": args.envs, "min_batch_per_gpu": min_batch // world, "physics": ro.sim.physics.name,
                        "host_threads_per_gpu": n_threads, "env_groups": args.groups, "host_cores_seen": cores,
+                       "host_cpus_pinned": (len(eng.pinned_cpus) if eng.pinned_cpus else None),
                        "parallelism": "dp%d" % world},
             "env_steps": total_steps, "rollout_only_env_steps_per_s": steps_local / max(t_sample, 1e-9) * world,
             "t_sample_s": t_sample, "t_update_s": t_update,

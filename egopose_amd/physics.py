@@ -158,10 +158,66 @@ def available_cpus():
     return n
 
 
-def default_threads(share=1):
-    """Engine threads spin at barriers inside the substep loop: never oversubscribe the CPU budget and
-    leave room for the Python driver thread. ``share`` = processes splitting this host (ranks per node)."""
-    return max(1, min(available_cpus() // max(1, share) - 2, 64))
+def _read(path):
+    with open(path) as f:
+        return f.read().strip()
+
+
+def _parse_cpulist(text):
+    out = set()
+    for part in text.split(","):
+        part = part.strip()
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_node(device_index, read=_read):
+    """NUMA node the GPU hangs off (sysfs, through its PCI address), or None when that cannot be told."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(read("/sys/bus/pci/devices/%s/numa_node" % bdf))
+        return node if node >= 0 else None
+    except Exception:
+        return None
+
+
+def numa_physical_cpus(node, allowed=None, read=_read):
+    """One hardware thread per physical core of NUMA `node`, restricted to `allowed` (default: the affinity mask).
+    The physics threads spin: two of them on SMT siblings halve each other, and a thread on the other socket pays the
+    inter-socket hop for every pinned row it trades with the GPU (measured: +3..7 % rollout rate, less run-to-run spread)."""
+    try:
+        cpus = _parse_cpulist(read("/sys/devices/system/node/node%d/cpulist" % node))
+        if allowed is None:
+            allowed = os.sched_getaffinity(0)
+        cpus &= set(allowed)
+        keep = set()
+        for c in sorted(cpus):
+            sib = _parse_cpulist(read("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c))
+            if c == min(sib & cpus if sib & cpus else {c}):
+                keep.add(c)
+        return keep
+    except Exception:
+        return set()
+
+
+def default_threads(share=1, device_index=None):
+    """Engine threads spin inside the substep loop: never oversubscribe the CPU budget and leave room for the Python
+    driver thread. ``share`` = processes splitting this host (ranks per node, rank r on GPU r). With a device index the
+    budget is also bounded by the physical cores of the GPU's NUMA node divided by the ranks whose GPU sits on that node
+    (the engine confines its threads to those cores, `RolloutEngine`)."""
+    budget = available_cpus() // max(1, share)
+    if device_index is not None and os.environ.get("EGP_PIN_NUMA", "1") != "0":
+        node = gpu_numa_node(device_index)
+        cores = numa_physical_cpus(node) if node is not None else set()
+        if cores:
+            same = sum(1 for r in range(max(1, share)) if gpu_numa_node(r) == node) or 1
+            budget = min(budget, len(cores) // same)
+    return max(1, min(budget - 2, 64))
 
 
 class RolloutEngine:
@@ -172,14 +228,33 @@ class RolloutEngine:
         self.lib = L.load()
         self.ctx, self.physics = ctx, physics
         self.n_env = int(n_env)
-        n_threads = default_threads() if n_threads is None else int(n_threads)
+        n_threads = default_threads(device_index=ctx.device) if n_threads is None else int(n_threads)
         n_threads = max(int(n_groups), min(n_threads, self.n_env))
         if device_dynamics and not getattr(ctx, "_has_dynamics", False):
             ctx.set_dynamics_model()
         d = L.EngineDesc(self.n_env, n_threads, int(n_groups), 1 if device_dynamics else 0)
         self.device_dynamics = bool(device_dynamics)
         h = C.c_void_p()
-        L.check(self.lib.egp_engine_create(ctx.handle, physics.handle, C.byref(d), C.byref(h)), "egp_engine_create")
+        # the engine's threads inherit the creating thread's affinity mask: narrow it to the physical cores of the GPU's
+        # NUMA node (when they can hold all of them) for the duration of the call only -- the caller's own mask, and with
+        # it every thread pool it creates later (OpenMP, the oracle in the tests, the CPU baseline), stays as it was
+        self.pinned_cpus = None
+        saved = None
+        if os.environ.get("EGP_PIN_NUMA", "1") != "0":
+            node = gpu_numa_node(ctx.device)
+            cores = numa_physical_cpus(node) if node is not None else set()
+            if len(cores) >= n_threads + 1:
+                try:
+                    saved = os.sched_getaffinity(0)
+                    os.sched_setaffinity(0, cores)
+                    self.pinned_cpus = sorted(cores)
+                except OSError:
+                    saved = None
+        try:
+            L.check(self.lib.egp_engine_create(ctx.handle, physics.handle, C.byref(d), C.byref(h)), "egp_engine_create")
+        finally:
+            if saved is not None:
+                os.sched_setaffinity(0, saved)
         self.handle = h
         self.n_threads, self.n_groups = n_threads, int(n_groups)
         ptrs = [C.c_void_p() for _ in range(7)]

@@ -294,3 +294,30 @@ def test_statereg_dataset_config_and_nets(tmp_path, monkeypatch):
     tr.save(str(tmp_path / "inf.p"), inference=True)
     cp, m2 = pickle.load(open(tmp_path / "inf.p", "rb"))
     assert "cfg" in m2 and not any(k.startswith("cnn.") for k in cp["state_net_dict"])
+
+
+def test_numa_core_selection_and_thread_budget(monkeypatch):
+    """physics.numa_physical_cpus / default_threads on a fake two-socket, SMT-2 topology: one hardware thread per core of
+    the GPU's node, inside the affinity mask; the thread budget is the node's cores split over the ranks on that node."""
+    from egopose_amd import physics as P
+    files = {"/sys/devices/system/node/node0/cpulist": "0-7,16-23", "/sys/devices/system/node/node1/cpulist": "8-15,24-31"}
+    for c in range(32):
+        sib = "%d,%d" % (c % 16, c % 16 + 16)
+        files["/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c] = sib
+
+    def read(path):
+        return files[path]
+    assert P._parse_cpulist("0-3,8,10-11") == {0, 1, 2, 3, 8, 10, 11}
+    assert P.numa_physical_cpus(0, allowed=range(32), read=read) == set(range(8))
+    assert P.numa_physical_cpus(1, allowed=range(32), read=read) == set(range(8, 16))
+    assert P.numa_physical_cpus(1, allowed=[9, 10, 25, 27], read=read) == {9, 10, 27}       # sibling 25 of 9 dropped, 27 alone kept
+    assert P.numa_physical_cpus(3, allowed=range(32), read=read) == set()                     # unknown node
+    # thread budget: 4 ranks, GPUs 0,1 on node 0 and 2,3 on node 1; 8 cores per node; no quota
+    monkeypatch.setattr(P, "available_cpus", lambda: 32)
+    monkeypatch.setattr(P, "gpu_numa_node", lambda dev, read=None: dev // 2)
+    monkeypatch.setattr(P, "numa_physical_cpus", lambda node, allowed=None, read=None: set(range(8 * node, 8 * node + 8)))
+    assert P.default_threads(share=4, device_index=2) == 8 // 2 - 2
+    assert P.default_threads(share=1, device_index=0) == 8 - 2
+    assert P.default_threads(share=4) == 32 // 4 - 2                                          # no device: the old rule
+    monkeypatch.setenv("EGP_PIN_NUMA", "0")
+    assert P.default_threads(share=4, device_index=2) == 32 // 4 - 2
