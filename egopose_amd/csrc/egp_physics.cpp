@@ -12,6 +12,9 @@
 // Like mj_step, `drain` after `step` returns the NEW qpos/qvel together with the inertia/bias that were
 // computed at the PREVIOUS state (compute_torque sees one-substep-stale M and C).
 // This is NOT MuJoCo: physics parity is unpinned.
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -100,6 +103,95 @@ void forward_kinematics(const Surrogate &S, const double *qpos, double *xpos) {
     }
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)      // (the file is also parsed for the GPU: no x86 code there)
+static inline void matvec_axpy(const double *, const double *, double *, int) {}
+#else
+// acc[i] = sum_j M[j][i] * f[j] with one fused multiply-add per term in ascending j (every variant below produces the
+// same bits). This product is most of a surrogate step; the plain loop keeps acc[] in memory (a load, an FMA and a store
+// per term: ~1 800 core cycles for nv = 58), the vector variants keep the accumulators in registers across j.
+static void matvec_axpy_plain(const double *M, const double *f, double *acc, int nv) {
+    for (int i = 0; i < nv; ++i) acc[i] = 0.0;
+    for (int j = 0; j < nv; ++j) {
+        const double *__restrict row = M + (size_t)j * nv;
+        const double fj = f[j];
+        for (int i = 0; i < nv; ++i) acc[i] = __builtin_fma(row[i], fj, acc[i]);
+    }
+}
+
+// (fixed unrolling: accumulators indexed by a run-time loop live on the stack and the variant is no faster than the plain one)
+__attribute__((target("avx2,fma"))) static void matvec_axpy_avx2(const double *M, const double *f, double *acc, int nv) {
+    // two passes of 8 ymm accumulators = 32 columns each; columns past nv are masked off (masked lanes are never touched)
+    for (int blk = 0; blk < 64 && blk < nv; blk += 32) {
+        __m256i mk[8];
+        for (int k = 0; k < 8; ++k) {
+            const int left = nv - blk - 4 * k;
+            mk[k] = _mm256_set_epi64x(left > 3 ? -1 : 0, left > 2 ? -1 : 0, left > 1 ? -1 : 0, left > 0 ? -1 : 0);
+        }
+        const __m256i m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3], m4 = mk[4], m5 = mk[5], m6 = mk[6], m7 = mk[7];
+        __m256d a0 = _mm256_setzero_pd(), a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0, a6 = a0, a7 = a0;
+        for (int j = 0; j < nv; ++j) {
+            const double *row = M + (size_t)j * nv + blk;
+            const __m256d fj = _mm256_set1_pd(f[j]);
+            a0 = _mm256_fmadd_pd(_mm256_maskload_pd(row + 0, m0), fj, a0);
+            a1 = _mm256_fmadd_pd(_mm256_maskload_pd(row + 4, m1), fj, a1);
+            a2 = _mm256_fmadd_pd(_mm256_maskload_pd(row + 8, m2), fj, a2);
+            a3 = _mm256_fmadd_pd(_mm256_maskload_pd(row + 12, m3), fj, a3);
+            a4 = _mm256_fmadd_pd(_mm256_maskload_pd(row + 16, m4), fj, a4);
+            a5 = _mm256_fmadd_pd(_mm256_maskload_pd(row + 20, m5), fj, a5);
+            a6 = _mm256_fmadd_pd(_mm256_maskload_pd(row + 24, m6), fj, a6);
+            a7 = _mm256_fmadd_pd(_mm256_maskload_pd(row + 28, m7), fj, a7);
+        }
+        double *o = acc + blk;
+        _mm256_maskstore_pd(o + 0, m0, a0); _mm256_maskstore_pd(o + 4, m1, a1); _mm256_maskstore_pd(o + 8, m2, a2);
+        _mm256_maskstore_pd(o + 12, m3, a3); _mm256_maskstore_pd(o + 16, m4, a4); _mm256_maskstore_pd(o + 20, m5, a5);
+        _mm256_maskstore_pd(o + 24, m6, a6); _mm256_maskstore_pd(o + 28, m7, a7);
+    }
+}
+
+__attribute__((target("avx512f"))) static void matvec_axpy_avx512(const double *M, const double *f, double *acc, int nv) {
+    // nv <= 64: eight zmm accumulators hold the whole result; vectors past nv are loaded / stored under an empty lane mask
+    __mmask8 mk[8];
+    for (int k = 0; k < 8; ++k) {
+        const int left = nv - 8 * k;
+        mk[k] = left >= 8 ? (__mmask8)0xFF : (left > 0 ? (__mmask8)((1u << left) - 1u) : (__mmask8)0);
+    }
+    const __mmask8 m0 = mk[0], m1 = mk[1], m2 = mk[2], m3 = mk[3], m4 = mk[4], m5 = mk[5], m6 = mk[6], m7 = mk[7];
+    __m512d a0 = _mm512_setzero_pd(), a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0, a6 = a0, a7 = a0;
+    for (int j = 0; j < nv; ++j) {
+        const double *row = M + (size_t)j * nv;
+        const __m512d fj = _mm512_set1_pd(f[j]);
+        a0 = _mm512_fmadd_pd(_mm512_maskz_loadu_pd(m0, row + 0), fj, a0);
+        a1 = _mm512_fmadd_pd(_mm512_maskz_loadu_pd(m1, row + 8), fj, a1);
+        a2 = _mm512_fmadd_pd(_mm512_maskz_loadu_pd(m2, row + 16), fj, a2);
+        a3 = _mm512_fmadd_pd(_mm512_maskz_loadu_pd(m3, row + 24), fj, a3);
+        a4 = _mm512_fmadd_pd(_mm512_maskz_loadu_pd(m4, row + 32), fj, a4);
+        a5 = _mm512_fmadd_pd(_mm512_maskz_loadu_pd(m5, row + 40), fj, a5);
+        a6 = _mm512_fmadd_pd(_mm512_maskz_loadu_pd(m6, row + 48), fj, a6);
+        a7 = _mm512_fmadd_pd(_mm512_maskz_loadu_pd(m7, row + 56), fj, a7);
+    }
+    _mm512_mask_storeu_pd(acc + 0, m0, a0); _mm512_mask_storeu_pd(acc + 8, m1, a1); _mm512_mask_storeu_pd(acc + 16, m2, a2);
+    _mm512_mask_storeu_pd(acc + 24, m3, a3); _mm512_mask_storeu_pd(acc + 32, m4, a4); _mm512_mask_storeu_pd(acc + 40, m5, a5);
+    _mm512_mask_storeu_pd(acc + 48, m6, a6); _mm512_mask_storeu_pd(acc + 56, m7, a7);
+}
+
+typedef void (*matvec_fn)(const double *, const double *, double *, int);
+static matvec_fn pick_matvec() {
+    const char *e = getenv("EGP_SURROGATE_SIMD");          // "plain" | "avx2" | "avx512" (default: the widest the CPU has)
+    __builtin_cpu_init();
+    const bool has512 = __builtin_cpu_supports("avx512f"), has2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+    if (e && !strcmp(e, "plain")) return matvec_axpy_plain;
+    if (e && !strcmp(e, "avx2")) return has2 ? matvec_axpy_avx2 : matvec_axpy_plain;
+    if (has512) return matvec_axpy_avx512;
+    return has2 ? matvec_axpy_avx2 : matvec_axpy_plain;
+}
+static inline void matvec_axpy(const double *M, const double *f, double *acc, int nv) {
+    static const matvec_fn fn = pick_matvec();
+    if (nv > 64) { matvec_axpy_plain(M, f, acc, nv); return; }
+    fn(M, f, acc, nv);
+}
+
+#endif
+
 void compute_bias(const Surrogate &S, int env, double *C) {
     const double *q = &S.qpos[(size_t)env * S.nq];
     const double *v = &S.qvel[(size_t)env * S.nv];
@@ -129,13 +221,8 @@ int sur_step(void *user, int32_t env, const double *ctrl) {
     double f[EGP_MAX_NV], acc[EGP_MAX_NV];
     for (int i = 0; i < 6; ++i) f[i] = -C[i];
     for (int i = 6; i < nv; ++i) f[i] = ctrl[i - 6] - C[i];
-    // acc = Minv0 * f as nv axpys over contiguous rows (Minv0 is symmetric): vectorises without reassociation
-    for (int i = 0; i < nv; ++i) acc[i] = 0.0;
-    for (int j = 0; j < nv; ++j) {
-        const double *__restrict row = &S.Minv0[(size_t)j * nv];
-        const double fj = f[j];
-        for (int i = 0; i < nv; ++i) acc[i] += row[i] * fj;
-    }
+    // acc = Minv0 * f as nv axpys over contiguous rows (Minv0 is symmetric): acc_i = fma(M[j][i], f[j], acc_i), j ascending
+    matvec_axpy(S.Minv0.data(), f, acc, nv);
     for (int i = 0; i < nv; ++i) v[i] += S.dt * acc[i];
     for (int k = 0; k < 3; ++k) q[k] += S.dt * v[k];
     // q <- q * exp(dt * omega / 2), omega in the body frame

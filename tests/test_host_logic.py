@@ -321,3 +321,40 @@ def test_numa_core_selection_and_thread_budget(monkeypatch):
     assert P.default_threads(share=4) == 32 // 4 - 2                                          # no device: the old rule
     monkeypatch.setenv("EGP_PIN_NUMA", "0")
     assert P.default_threads(share=4, device_index=2) == 32 // 4 - 2
+
+
+def test_surrogate_matvec_variants_are_bit_identical():
+    """EGP_SURROGATE_SIMD = plain / avx2 / avx512 (register-blocked Minv0 * f in the surrogate's step): the same fused
+    multiply-adds in the same order, so the trajectories must agree to the last bit. One fresh process per variant (the
+    choice is made once per process); variants the CPU lacks fall back and trivially agree."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, numpy as np
+from egopose_amd.skeleton import load_skeleton
+from egopose_amd.physics import SurrogatePhysics
+skel = load_skeleton()
+rng = np.random.RandomState(0)
+n = 5
+ph = SurrogatePhysics(skel, n)
+h = hashlib.sha256()
+for e in range(n):
+    q = rng.normal(size=59) * 0.2; q[3:7] = [1, 0, 0, 0]; q[2] = 0.9
+    ph.reset(e, q, rng.normal(size=58) * 0.5)
+for k in range(40):
+    for e in range(n):
+        ph.step(e, rng.normal(size=52) * 30)
+        q, v, qM, bias, xpos = ph.drain(e)
+        h.update(np.ascontiguousarray(q).tobytes()); h.update(np.ascontiguousarray(v).tobytes()); h.update(np.ascontiguousarray(xpos).tobytes())
+print("HASH", h.hexdigest())
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for variant in ("plain", "avx2", "avx512"):
+        env = dict(os.environ, EGP_SURROGATE_SIMD=variant, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        out[variant] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
+    assert out["plain"] == out["avx2"] == out["avx512"], out
