@@ -68,7 +68,9 @@ inline void mat_mul(const double *A, const double *B, double *O) {
 }
 
 inline void axis_angle_mat(const double *a, double ang, double *R) {
-    const double c = cos(ang), s = sin(ang), t = 1 - c;
+    double s, c;
+    sincos(ang, &s, &c);               // (glibc computes both from one argument reduction; same values as sin() / cos())
+    const double t = 1 - c;
     R[0] = c + a[0] * a[0] * t;        R[1] = a[0] * a[1] * t - a[2] * s; R[2] = a[0] * a[2] * t + a[1] * s;
     R[3] = a[1] * a[0] * t + a[2] * s; R[4] = c + a[1] * a[1] * t;        R[5] = a[1] * a[2] * t - a[0] * s;
     R[6] = a[2] * a[0] * t - a[1] * s; R[7] = a[2] * a[1] * t + a[0] * s; R[8] = c + a[2] * a[2] * t;
@@ -76,16 +78,16 @@ inline void axis_angle_mat(const double *a, double ang, double *R) {
 
 // body frame positions for one qpos: MJCF coordinate="global" tree, hinges about anchors (x->y->z per body)
 void forward_kinematics(const Surrogate &S, const double *qpos, double *xpos) {
-    std::vector<double> R((size_t)S.nbody * 9);
-    quat_to_mat(qpos + 3, R.data());
+    double R[EGP_MAX_BODY * 9];        // (no heap allocation on the per-env-step path)
+    quat_to_mat(qpos + 3, R);
     xpos[0] = qpos[0]; xpos[1] = qpos[1]; xpos[2] = qpos[2];
     int j = 0;
     for (int b = 1; b < S.nbody; ++b) {
         const int p = S.body_parent[b];
         double Rb[9], pb[3], off[3], tmp[3];
-        memcpy(Rb, &R[(size_t)p * 9], sizeof(Rb));
+        memcpy(Rb, &R[p * 9], sizeof(Rb));
         for (int k = 0; k < 3; ++k) off[k] = S.body_pos[b * 3 + k] - S.body_pos[p * 3 + k];
-        mat_vec(&R[(size_t)p * 9], off, tmp);
+        mat_vec(&R[p * 9], off, tmp);
         for (int k = 0; k < 3; ++k) pb[k] = xpos[p * 3 + k] + tmp[k];
         for (int d = 0; d < S.body_ndof[b]; ++d, ++j) {
             double al[3], aw[3], Rj[9], Rn[9];
@@ -98,7 +100,7 @@ void forward_kinematics(const Surrogate &S, const double *qpos, double *xpos) {
             mat_vec(Rb, al, tmp);
             for (int k = 0; k < 3; ++k) pb[k] = aw[k] - tmp[k];
         }
-        memcpy(&R[(size_t)b * 9], Rb, sizeof(Rb));
+        memcpy(&R[b * 9], Rb, sizeof(Rb));
         for (int k = 0; k < 3; ++k) xpos[b * 3 + k] = pb[k];
     }
 }
@@ -274,7 +276,7 @@ int egp_physics_create_surrogate(const egp_surrogate_desc *d, int32_t n_env, egp
     EGP_REQUIRE(d && out, "desc/out is NULL");
     EGP_REQUIRE(n_env > 0, "n_env must be positive");
     EGP_REQUIRE(d->nv > 6 && d->nv <= EGP_MAX_NV && d->nq == d->nv + 1 && d->nu == d->nv - 6, "bad dims");
-    EGP_REQUIRE(d->njoint == d->nv - 6 && d->nbody >= 2, "bad joint/body count");
+    EGP_REQUIRE(d->njoint == d->nv - 6 && d->nbody >= 2 && d->nbody <= EGP_MAX_BODY, "bad joint/body count");
     EGP_REQUIRE(d->qM0 && d->Minv0 && d->body_parent && d->body_pos && d->body_ndof && d->joint_axis && d->joint_anchor, "NULL table");
     EGP_REQUIRE(d->sub_dt > 0, "sub_dt must be positive");
     Surrogate *S = new Surrogate();
