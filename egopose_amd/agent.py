@@ -11,12 +11,21 @@ host physics threads). ``update_params`` keeps everything in HBM: values -> K5 G
 standardisation) -> ``opt_num_epochs`` full-batch epochs; with ``torch.distributed`` initialised the flat
 policy+value gradient is all-reduced once per epoch (RCCL over xGMI) so that every rank applies the
 gradient of the global batch mean, exactly what the reference's single-process full batch computes.
+
+Precision. The reference driver builds everything in float64 (ego_pose/ego_mimic.py:31-32,83-90) and hands
+``dtype=torch.float64`` nets to ``AgentEgo``. The HIP LSTM / fused policy kernels and the MFMA GEMMs are float32, so
+on a GPU a float64 agent keeps the caller's float64 modules as MASTER weights (state_dict, checkpoints, the caller's
+optimizers step them) and computes with float32 SHADOW copies (``ShadowNets``): shadow gradients are copied up into
+the masters' ``.grad`` before the all-reduce / clip / optimizer steps, the stepped masters are copied down again.
+``EGP_NET_DTYPE=float64`` keeps a float64 agent on the float64 torch paths (parity runs at 1e-9).
 """
 from __future__ import annotations
 
+import copy
 import math
 import os
 import time
+import types
 
 import numpy as np
 import torch
@@ -33,12 +42,69 @@ def _column(batch, name, dtype, device):
     return torch.from_numpy(np.asarray(getattr(batch, name))).to(dtype).to(device)
 
 
+def compute_dtype(dtype, device):
+    """Arithmetic type of the nets for an agent declared with `dtype` on `device` (see the module docstring)."""
+    if dtype == torch.float64 and torch.device(device).type == "cuda":
+        want = os.environ.get("EGP_NET_DTYPE", "float32")
+        if want not in ("float32", "float64"):
+            raise ValueError("EGP_NET_DTYPE must be float32 or float64, got %r" % want)
+        return getattr(torch, want)
+    return dtype
+
+
+class ShadowNets:
+    """Low-precision compute copies of the caller's (master) modules, matched parameter by parameter."""
+
+    def __init__(self, masters, dtype):
+        self.masters = dict(masters)
+        self.nets = {k: copy.deepcopy(m).to(dtype) for k, m in self.masters.items()}
+        self.pairs = []
+        for k, m in self.masters.items():
+            mp, sp = dict(m.named_parameters()), dict(self.nets[k].named_parameters())
+            if list(mp) != list(sp):
+                raise RuntimeError("shadow copy of %s lost parameters" % k)
+            self.pairs += [(mp[n], sp[n]) for n in mp]
+        self._train = [(m, s) for m, s in self.pairs if m.requires_grad]
+
+    @torch.no_grad()
+    def pull(self):
+        """masters -> shadows (after an optimizer step, a checkpoint load or the driver's `action_log_std.fill_`)."""
+        dst, src = [s for _, s in self.pairs], [m for m, _ in self.pairs]
+        if all(m.device == s.device for m, s in self.pairs):
+            torch._foreach_copy_(dst, src)
+        else:                                   # masters parked on the CPU (the driver's `with to_cpu(...)`)
+            for d, m in zip(dst, src):
+                d.copy_(m)
+
+    def zero_grad(self):
+        for _, s in self._train:
+            s.grad = None
+
+    @torch.no_grad()
+    def push_grads(self):
+        """shadow gradients -> the masters' .grad (master dtype), where the exchange / clip / optimizer steps find them."""
+        dst, src = [], []
+        for m, s in self._train:
+            if s.grad is None:
+                m.grad = None
+                continue
+            if m.grad is None or m.grad.shape != s.grad.shape:
+                m.grad = torch.empty_like(m)
+            dst.append(m.grad)
+            src.append(s.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+
 class Agent:
 
     def __init__(self, env, policy_net, value_net, dtype, device, custom_reward=None, mean_action=False,
-                 render=False, running_state=None, num_threads=1, num_envs=None, num_groups=None):
+                 render=False, running_state=None, num_threads=1, num_envs=None, num_groups=None, net_dtype=None):
         self.env, self.policy_net, self.value_net = env, policy_net, value_net
         self.dtype, self.device = dtype, device
+        self.cdtype = net_dtype if net_dtype is not None else compute_dtype(dtype, device)         # what the nets compute in (float32 shadows of float64 masters)
+        self.shadow = None
+        self.cn = types.SimpleNamespace(policy_net=policy_net, value_net=value_net)     # the nets the kernels run
         self.custom_reward = custom_reward
         self.mean_action, self.render = mean_action, render
         self.running_state = running_state
@@ -48,9 +114,41 @@ class Agent:
         self.noise_rate = 1.0
         self.traj_cls = TrajBatch
         self.logger_cls = LoggerRL
-        self.sample_modules = [policy_net]
-        self.update_modules = [policy_net, value_net]
         self._rollout = None
+        self._bind_compute_nets()
+
+    def _master_nets(self):
+        return dict(policy_net=self.policy_net, value_net=self.value_net)
+
+    def _bind_compute_nets(self):
+        """self.cn = the modules every kernel runs: the caller's own, or float32 shadows of float64 masters."""
+        masters = self._master_nets()
+        if any(m is None for m in masters.values()):
+            masters = {k: m for k, m in masters.items() if m is not None}        # (AgentEgo binds again with its video nets)
+            self.shadow, self.cn = None, types.SimpleNamespace(**masters)
+        elif self.cdtype != self.dtype:
+            self.shadow = ShadowNets(masters, self.cdtype)
+            self.cn = types.SimpleNamespace(**self.shadow.nets)
+        else:
+            self.shadow = None
+            self.cn = types.SimpleNamespace(**masters)
+        self.sample_modules = [self.cn.policy_net]
+        self.update_modules = [self.cn.policy_net, self.cn.value_net]
+
+    def _zero_grads(self):
+        self.optimizer_value.zero_grad()
+        self.optimizer_policy.zero_grad()
+        if self.shadow is not None:
+            self.shadow.zero_grad()
+
+    def _grads_ready(self):
+        """Called after backward: hand the gradients to the parameters the optimizers own."""
+        if self.shadow is not None:
+            self.shadow.push_grads()
+
+    def _params_stepped(self):
+        if self.shadow is not None:
+            self.shadow.pull()
 
     # hooks kept for subclasses / API compatibility
     def pre_episode(self):
@@ -87,11 +185,12 @@ class Agent:
             n_threads = None if self.num_threads in (None, 0) else int(self.num_threads)
             sim = self.env.batched(self.num_envs, idx, n_threads=n_threads, n_groups=self.num_groups)
             seed = int(getattr(self.env.cfg, "seed", 0)) * 1000 + D.rank()
-            self._rollout = LockstepRollout(sim, self.policy_net, self._video_net(), self.running_state, seed=seed)
+            self._rollout = LockstepRollout(sim, self.cn.policy_net, self._video_net(), self.running_state, seed=seed)
         return self._rollout
 
     def sample(self, min_batch_size):
         t0 = time.time()
+        self._params_stepped()              # shadows follow whatever the caller did to the masters since the last call
         self.pre_sample()
         ro = self._get_rollout()
         ro.noise_rate, ro.mean_action = self.noise_rate, self.mean_action
@@ -146,18 +245,20 @@ class AgentPG(Agent):
         """MSE critic loss of the global batch (this rank's share) -> gradients, no optimizer step."""
         if self.value_opt_niter != 1:
             raise NotImplementedError("value_opt_niter != 1 is not on the ego_mimic path")
-        pred = self.value_net(self.trans_value(states))
+        pred = self.cn.value_net(self.trans_value(states))
         loss = (pred - returns).pow(2).sum() / n_global
-        self.optimizer_value.zero_grad()
         loss.backward()
         return loss
 
     def update_value(self, states, returns):
         """update critic (agents/agent_pg.py:19-26)"""
+        self._zero_grads()
         loss = self._value_backward(states, returns, D.global_count(states.shape[0], states.device))
+        self._grads_ready()
         if D.world_size() > 1:
             D.FlatGradSync(self._value_params()).all_reduce()
         self.optimizer_value.step()
+        self._params_stepped()
         return loss
 
     def update_policy(self, states, actions, returns, advantages, exps):
@@ -165,27 +266,30 @@ class AgentPG(Agent):
         n_val = D.global_count(states.shape[0], states.device)
         n_exp = D.global_count(ind.shape[0], states.device)
         for _ in range(self.opt_num_epochs):
+            self._zero_grads()
             self._value_backward(states, returns, n_val)
-            logp = self.policy_net.get_log_prob(self.trans_policy(states)[ind], actions[ind])
+            logp = self.cn.policy_net.get_log_prob(self.trans_policy(states)[ind], actions[ind])
             loss = -(logp * advantages[ind]).sum() / n_exp
-            self.optimizer_policy.zero_grad()
             loss.backward()
+            self._grads_ready()
             self._sync_grads()
             self.optimizer_value.step()
             self.optimizer_policy.step()
+            self._params_stepped()
 
     def _load_batch(self, batch):
         dev = torch.device(self.device)
-        cols = {k: _column(batch, k, self.dtype, dev) for k in ("states", "actions", "rewards", "masks", "exps")}
+        cols = {k: _column(batch, k, self.cdtype, dev) for k in ("states", "actions", "rewards", "masks", "exps")}
         return cols
 
     def update_params(self, batch):
         t0 = time.time()
         to_train(*self.update_modules)
+        self._params_stepped()
         c = self._load_batch(batch)
         with to_test(*self.update_modules):
             with torch.no_grad():
-                values = self.value_net(self.trans_value(c["states"]))
+                values = self.cn.value_net(self.trans_value(c["states"]))
         advantages, returns = self._advantages(c["rewards"], c["masks"], values)
         self.update_policy(c["states"], c["actions"], returns, advantages, c["exps"])
         return time.time() - t0
@@ -211,12 +315,12 @@ class AgentPPO(AgentPG):
         """`ind` = rows with exps == 1 (agents/agent_ppo.py:45-51), or None when that is every row (no gather copies)."""
         if ind is None:
             n_exp = states.shape[0] if n_exp is None else n_exp
-            logp = self.policy_net.get_log_prob(self.trans_policy(states), actions)
+            logp = self.cn.policy_net.get_log_prob(self.trans_policy(states), actions)
             ratio = torch.exp(logp - fixed_log_probs)
             adv = advantages
         else:
             n_exp = ind.shape[0] if n_exp is None else n_exp
-            logp = self.policy_net.get_log_prob(self.trans_policy(states)[ind], actions[ind])
+            logp = self.cn.policy_net.get_log_prob(self.trans_policy(states)[ind], actions[ind])
             ratio = torch.exp(logp - fixed_log_probs[ind])
             adv = advantages[ind]
         clipped = torch.clamp(ratio, 1.0 - self.clip_epsilon, 1.0 + self.clip_epsilon) * adv
@@ -227,7 +331,7 @@ class AgentPPO(AgentPG):
             raise NotImplementedError("mini-batch PPO is not on the ego_mimic path (AgentEgo forces full batch)")
         with to_test(*self.update_modules):
             with torch.no_grad():
-                fixed_log_probs = self.policy_net.get_log_prob(self.trans_policy(states), actions)
+                fixed_log_probs = self.cn.policy_net.get_log_prob(self.trans_policy(states), actions)
         ind = exps.nonzero().squeeze(1)
         n_val = D.global_count(states.shape[0], states.device)
         n_exp = D.global_count(ind.shape[0], states.device)
@@ -243,21 +347,22 @@ class AgentPPO(AgentPG):
                 # over the sum of the two losses yields exactly the two separate gradients
                 if self.value_opt_niter != 1:
                     raise NotImplementedError("value_opt_niter != 1 is not on the ego_mimic path")
-                pred = self.value_net(self.trans_value(states))
+                pred = self.cn.value_net(self.trans_value(states))
                 v_loss = (pred - returns).pow(2).sum() / n_val
                 s_loss = self.ppo_loss(states, actions, advantages, fixed_log_probs, ind, n_exp)
-                self.optimizer_value.zero_grad()
-                self.optimizer_policy.zero_grad()
+                self._zero_grads()
                 (v_loss + s_loss).backward()
             else:
+                self._zero_grads()
                 v_loss = self._value_backward(states, returns, n_val)
                 s_loss = self.ppo_loss(states, actions, advantages, fixed_log_probs, ind, n_exp)
-                self.optimizer_policy.zero_grad()
                 s_loss.backward()
+            self._grads_ready()            # (shadow gradients -> the masters the optimizers / the clip list hold)
             self._sync_grads()
             self.optimizer_value.step()
             self.clip_policy_grad()
             self.optimizer_policy.step()
+            self._params_stepped()
             losses.append((v_loss.detach(), s_loss.detach()))
         self.update_stats = {"value_loss": [float(v) for v, _ in losses], "surr_loss": [float(s) for _, s in losses]}
 
@@ -273,51 +378,62 @@ class AgentEgo(AgentPPO):
         super().__init__(use_mini_batch=False, **kwargs)
         self.traj_cls = TrajBatchEgo
         self.policy_vs_net, self.value_vs_net = policy_vs_net, value_vs_net
-        self.sample_modules.append(policy_vs_net)
-        self.update_modules += [policy_vs_net, value_vs_net]
+        self._bind_compute_nets()
+
+    def _master_nets(self):
+        return dict(policy_net=self.policy_net, value_net=self.value_net, policy_vs_net=getattr(self, "policy_vs_net", None),
+                    value_vs_net=getattr(self, "value_vs_net", None))
+
+    def _bind_compute_nets(self):
+        super()._bind_compute_nets()
+        if getattr(self.cn, "policy_vs_net", None) is not None:
+            self.sample_modules = [self.cn.policy_net, self.cn.policy_vs_net]
+            self.update_modules = [self.cn.policy_net, self.cn.value_net, self.cn.policy_vs_net, self.cn.value_vs_net]
 
     def _video_net(self):
-        return self.policy_vs_net
+        return self.cn.policy_vs_net
 
     def pre_sample(self):
-        self.policy_vs_net.set_mode("test")
+        self.cn.policy_vs_net.set_mode("test")
 
     def pre_episode(self):
-        self.policy_vs_net.initialize(torch.as_tensor(self.env.get_episode_cnn_feat()))
+        self.cn.policy_vs_net.initialize(torch.as_tensor(self.env.get_episode_cnn_feat()))
 
     def push_memory(self, memory, state, action, mask, next_state, reward, exp):
         memory.push(state, action, mask, next_state, reward, exp, np.array([self.env.expert_ind, self.env.start_ind]))
 
     def _group_contexts(self, states=None):
         from .nets import grouped_forecast_context, grouped_video_context
-        nets = [self.value_vs_net, self.policy_vs_net]
+        nets = [self.cn.value_vs_net, self.cn.policy_vs_net]
         return grouped_video_context(nets) or grouped_forecast_context(nets, states)
 
     def trans_policy(self, states):
-        return self.policy_vs_net(states)
+        return self.cn.policy_vs_net(states)
 
     def trans_value(self, states):
-        return self.value_vs_net(states)
+        return self.cn.value_vs_net(states)
 
     def update_params(self, batch):
         t0 = time.time()
         to_train(*self.update_modules)
+        self._params_stepped()
         c = self._load_batch(batch)
         dev = c["states"].device
+        vs_nets = (self.cn.policy_vs_net, self.cn.value_vs_net)
         v_metas = batch.device_column("v_metas") if hasattr(batch, "device_column") else None
         v_metas = v_metas.cpu().numpy() if v_metas is not None else batch.v_metas
         if self._rollout is not None and self._rollout.experts is not None:
             ex = self._rollout.experts
-            pdt = next(self.policy_vs_net.parameters()).dtype
-            for net in (self.policy_vs_net, self.value_vs_net):
+            pdt = next(vs_nets[0].parameters()).dtype
+            for net in vs_nets:
                 net.attach_feature_table(ex.cnn_table(dev, pdt), ex.cnn_offset)
-        for net in (self.policy_vs_net, self.value_vs_net):
+        for net in vs_nets:
             net.set_mode("train")
             net.initialize((c["masks"], self.env.cnn_feat, v_metas))
         with to_test(*self.update_modules):
             with torch.no_grad():
                 self._group_contexts(c["states"])       # the policy net's context is consumed by update_policy's first pass
-                values = self.value_net(self.trans_value(c["states"]))
+                values = self.cn.value_net(self.trans_value(c["states"]))
         advantages, returns = self._advantages(c["rewards"], c["masks"], values)
         self.update_policy(c["states"], c["actions"], returns, advantages, c["exps"])
         if dev.type == "cuda":

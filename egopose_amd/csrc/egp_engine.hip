@@ -100,6 +100,8 @@ struct Group {
     int n_threads = 1;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;                // recorded after the last upload of an env-step
+    hipEvent_t reward_done = nullptr;         // recorded behind the reward job's kernel (it reads d_qpos / d_prev_qpos / d_ee rows
+    bool reward_in_flight = false;            //  that a reset on the caller's stream overwrites): egp_engine_reset waits for it
     std::vector<hipEvent_t> k_beg, k_end;     // per substep, when profiling K1
     SpinBarrier bar;
     std::mutex mu;
@@ -156,6 +158,7 @@ struct egp_engine {
     bool server_dyn_ok = false;               // ... also with device dynamics (its 110 kB of LDS: one workgroup per CU)
     bool device_dynamics = false;             // K8 supplies qM / qfrc_bias from the drained (qpos, qvel) each substep
     double *d_bias = nullptr;                 // [n_env][nv] K8's bias (device-dynamics mode)
+    int reward_delay_us = 0;                  // EGP_REWARD_JOB_DELAY_US (tests): a spin kernel ahead of the reward job's kernel
     int spin_us = 0;                          // EGP_SPIN_US: poll this long for the next env-step before sleeping (off: measured no gain)
     double *d_state = nullptr, *d_qM = nullptr, *d_prev_qpos = nullptr, *d_qpos = nullptr, *d_qvel = nullptr, *d_torque = nullptr, *d_ee = nullptr;
     double *h_state = nullptr, *h_qM = nullptr, *h_qpos = nullptr, *h_qvel = nullptr, *h_torque = nullptr, *h_ee = nullptr,
@@ -173,6 +176,12 @@ namespace {
 // egp_engine_reset on a zero-copy engine: ONE launch moves the freshly drained pinned rows of the listed envs to
 // their HBM mirrors (block per env; the list holds (env, qM_changed) pairs in pinned memory) instead of five
 // copy-engine calls per run of consecutive env ids.
+// test aid: hold the stream for `us` microseconds (wall_clock64 ticks at 100 MHz on gfx950)
+__global__ void k_engine_spin(long long us) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < us * 100) __builtin_amdgcn_s_sleep(32);
+}
+
 __global__ __launch_bounds__(256) void k_engine_reset_scatter(const int *__restrict__ list, const double *__restrict__ h_state, int ld_s,
                                                               int off_qpos, int off_qvel, const double *__restrict__ h_ee,
                                                               const double *__restrict__ h_qM, int ld_m, int nM, int nq, int nv,
@@ -407,10 +416,13 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
             // K2 of this env-step, stream-ordered behind the epilogue and ahead of the next env-step's kernel: off the
             // caller's critical path (filter -> policy -> next step), and its inputs cannot be overwritten under it
             const int m2 = G.e1 - G.e0;
+            if (E->reward_delay_us > 0) k_engine_spin<<<dim3(1), dim3(1), 0, G.stream>>>((long long)E->reward_delay_us);
             int rr = egp_reward_quat_v3_f64(E->ctx, E->d_qpos + (size_t)G.e0 * E->nq, E->d_prev_qpos + (size_t)G.e0 * E->nq,
                                             E->d_ee + (size_t)G.e0 * 15, G.rjob.t, G.rjob.frame, G.rjob.end, G.rjob.active,
                                             G.rjob.end_reward, m2, G.rjob.reward, G.rjob.cinfo, G.stream);
             if (rr != EGP_OK) fail(G, rr, "reward launch", egp_last_error());
+            G_HIP(hipEventRecord(G.reward_done, G.stream));
+            G.reward_in_flight = true;           // (published with the job's completion: pending -> 0)
             G.rjob.armed = false;
         }
         if (!S.host_trace.empty()) S.host_trace[0 * 4 + 3] = secs(t_job, clk::now()) * 1e6;     // launch issued
@@ -741,6 +753,7 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
         const char *zc = getenv("EGP_ZERO_COPY");
         E->zero_copy = !(zc && atoi(zc) == 0);
         if (const char *su = getenv("EGP_SPIN_US")) E->spin_us = atoi(su);
+        if (const char *rd = getenv("EGP_REWARD_JOB_DELAY_US")) E->reward_delay_us = atoi(rd);
         const char *fp = getenv("EGP_FLAG_POLL");
         E->flag_poll = !(fp && atoi(fp) == 0);
         void *p1 = nullptr, *p2 = nullptr;
@@ -786,6 +799,7 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
         for (int e = G.e0; e < G.e1; ++e) E->env_group[e] = g;
         E_TRY(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
         E_TRY(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
+        E_TRY(hipEventCreateWithFlags(&G.reward_done, hipEventDisableTiming));
         E_TRY(hipMalloc((void **)&G.d_done, sizeof(unsigned)));
         E_TRY(hipMemset(G.d_done, 0, sizeof(unsigned)));
         E_TRY(hipHostMalloc((void **)&G.h_flag, sizeof(unsigned long long), hipHostMallocDefault));
@@ -921,6 +935,7 @@ int egp_engine_destroy(egp_engine *E) {
         if (G.h_flag) (void)hipHostFree(G.h_flag);
         if (G.stream) (void)hipStreamDestroy(G.stream);
         if (G.done) (void)hipEventDestroy(G.done);
+        if (G.reward_done) (void)hipEventDestroy(G.reward_done);
         for (auto ev : G.k_beg) (void)hipEventDestroy(ev);
         for (auto ev : G.k_end) (void)hipEventDestroy(ev);
     }
@@ -961,6 +976,9 @@ int egp_engine_reset(egp_engine *E, const int32_t *ids, int32_t n, const double 
             if (g == last_group) continue;
             last_group = g;
             EGP_HIP_CHECK(hipEventSynchronize(E->groups[g].done));
+            // the reward kernel of that env-step (terminal step of the slots being reset) runs on the group's stream and
+            // still reads their device rows: order this reset's scatter / uploads behind it
+            if (E->groups[g].reward_in_flight) EGP_HIP_CHECK(hipStreamWaitEvent(s, E->groups[g].reward_done, 0));
         }
     }
     if (E->reset_pending) {              // the previous reset's kernel reads the pinned rows and the env list

@@ -220,6 +220,15 @@ def default_threads(share=1, device_index=None):
     return max(1, min(budget - 2, 64))
 
 
+def ranks_on_host():
+    """Processes sharing this host's cores: torchrun's LOCAL_WORLD_SIZE, else WORLD_SIZE (single-node launches), else 1."""
+    for k in ("LOCAL_WORLD_SIZE", "WORLD_SIZE"):
+        v = os.environ.get(k)
+        if v and v.isdigit() and int(v) > 0:
+            return int(v)
+    return 1
+
+
 class RolloutEngine:
     """egp_engine: n_env envs advance one env-step per step_async/wait pair."""
 
@@ -228,7 +237,8 @@ class RolloutEngine:
         self.lib = L.load()
         self.ctx, self.physics = ctx, physics
         self.n_env = int(n_env)
-        n_threads = default_threads(device_index=ctx.device) if n_threads is None else int(n_threads)
+        # (spinning threads: every rank of the host takes its share of the cores, not the whole machine)
+        n_threads = default_threads(share=ranks_on_host(), device_index=ctx.device) if n_threads is None else int(n_threads)
         n_threads = max(int(n_groups), min(n_threads, self.n_env))
         if device_dynamics and not getattr(ctx, "_has_dynamics", False):
             ctx.set_dynamics_model()

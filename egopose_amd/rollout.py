@@ -391,8 +391,12 @@ class LockstepRollout:
         # per group: a slot is reused two ticks later, after the env-step that was ordered behind its readers), every
         # tensor argument is a precomputed address, and the fused policy kernel reads rec.states[k] / writes
         # rec.actions[k] directly.
-        fast = (self._fused is not None and plain_noise and not self.forecast and os.environ.get("EGP_FAST_TICK", "1") != "0")
+        # (mean_action: the same kernel without a noise operand writes the mean; exps = 0 as agents/agent.py:45-46)
+        fast = (self._fused is not None and (plain_noise or self.mean_action) and not self.forecast
+                and os.environ.get("EGP_FAST_TICK", "1") != "0")
         if fast:
+            if self.mean_action:
+                rec["exps"].zero_()
             lib, hnd = ctx.lib, ctx.handle
             vp = ctypes.c_void_p
             P = {k: v.data_ptr() for k, v in rec.items()}
@@ -447,11 +451,14 @@ class LockstepRollout:
             if flags_upload:
                 lib.egp_upload_async(slab_dp + soff, slab_hp + soff, 24 * nmax, cur_stream)
             fbase = slab_dp + soff
-            nz = noise_t[g]
-            nz.normal_()
+            nz_p = None
+            if not self.mean_action:
+                nz = noise_t[g]
+                nz.normal_()
+                nz_p = nz.data_ptr()
             rc = lib.egp_policy_gaussian_f32(v_out_p + a * v_stride * 4, v_stride, H, fbase + 16 * nmax,
                                              P["states"] + (k * N + a) * od * 8, od, n, fz.desc, len(fz.layers), fz.act,
-                                             fz.log_std.data_ptr(), nz.data_ptr(), P["actions"] + (k * N + a) * nu * 8, None,
+                                             fz.log_std.data_ptr(), nz_p, P["actions"] + (k * N + a) * nu * 8, None,
                                              cur_stream)
             if rc != 0:
                 _lib.check(rc, "egp_policy_gaussian_f32")

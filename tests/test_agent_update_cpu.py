@@ -1,65 +1,69 @@
 """Host logic of the PPO update (AgentEgo.update_params) on CPU float64 against the golden run of the
 reference's AgentEgo. The GAE kernel is HIP-only, so here (test infrastructure) the oracle's GAE stands in
 for K5 -- K5 itself is checked on the GPU in test_hip_parity.py."""
-import types
-
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden
-from egopose_amd.agent import AgentEgo
-from egopose_amd.nets import MLP, PolicyGaussian, Value, VideoStateNet
-from egopose_amd.rl_core import TrajBatchEgo, Memory, LoggerRL
+from egopose_amd.rl_core import TrajBatchEgo, LoggerRL
 from oracle.gae import estimate_advantages as oracle_gae
+from update_fixture import batch_of, build_agent, check_final
 
 
-def _sd(g, prefix):
-    return {k[len(prefix):]: torch.as_tensor(g[k]) for k in g.files if k.startswith(prefix)}
-
-
-def build_agent(g, device="cpu"):
-    sdim, adim, cdim, hdim, margin, T_ep = [int(x) for x in g["dims"]]
-    p_vs = VideoStateNet(cdim, hdim, margin, "lstm", None, False)
-    v_vs = VideoStateNet(cdim, hdim, margin, "lstm", None, False)
-    p_net = PolicyGaussian(MLP(sdim + hdim, [12, 10], "relu"), adim, log_std=-1.0, fix_std=True)
-    v_net = Value(MLP(sdim + hdim, [12, 10], "relu"))
-    for mod, name in [(p_vs, "p_vs"), (v_vs, "v_vs"), (p_net, "p"), (v_net, "v")]:
-        mod.load_state_dict(_sd(g, "init_%s__" % name), strict=True)
-    p_params = list(p_net.parameters()) + list(p_vs.parameters())
-    v_params = list(v_net.parameters()) + list(v_vs.parameters())
-    env = types.SimpleNamespace(cnn_feat=[g["cnn_feat0"], g["cnn_feat1"]], cfg=types.SimpleNamespace(seed=1))
-    agent = AgentEgo(env=env, dtype=torch.float64, device=torch.device(device), running_state=None, custom_reward=None,
-                     mean_action=False, render=False, num_threads=1, policy_net=p_net, policy_vs_net=p_vs,
-                     value_net=v_net, value_vs_net=v_vs, optimizer_policy=torch.optim.Adam(p_params, lr=5e-3),
-                     optimizer_value=torch.optim.Adam(v_params, lr=3e-3), opt_num_epochs=3, gamma=0.95, tau=0.95,
-                     clip_epsilon=0.2, policy_grad_clip=[(p_params, 0.5)])
-
+def _with_oracle_gae(agent):
     def adv_fn(rewards, masks, values):
         a, r, _ = oracle_gae(rewards.cpu().numpy(), masks.cpu().numpy(), values.cpu().numpy(), agent.gamma, agent.tau)
         agent._seen = (a, r, values.cpu().numpy())
         return torch.as_tensor(a, device=rewards.device), torch.as_tensor(r, device=rewards.device)
     agent._advantages = adv_fn
-    return agent, dict(p_vs=p_vs, v_vs=v_vs, p=p_net, v=v_net)
+    return agent
 
 
-def test_update_params_matches_reference_run():
-    g = load_golden("ppo_update.npz")
+@pytest.mark.parametrize("fixture", ["ppo_update.npz", "ppo_update_h128.npz"])
+def test_update_params_matches_reference_run(fixture):
+    """float64 on the CPU: the host logic of update_params (episode segmentation, padded contexts, losses, gradient
+    clip, Adam order) reproduces the reference's final parameters; toy video net and the hidden-64-per-direction one."""
+    g = load_golden(fixture)
     torch.set_default_dtype(torch.float64)
     try:
         agent, mods = build_agent(g)
-        mem = Memory()
-        for i in range(g["states"].shape[0]):
-            mem.push(g["states"][i], g["actions"][i], g["masks"][i], g["states"][i], g["rewards"][i], g["exps"][i], g["v_metas"][i])
-        batch = TrajBatchEgo([mem])
+        _with_oracle_gae(agent)
+        batch = batch_of(g)
         assert batch.states.shape == g["states"].shape and batch.v_metas.shape == g["v_metas"].shape
         agent.update_params(batch)
         a, r, v0 = agent._seen
         np.testing.assert_allclose(v0, g["values0"], rtol=1e-11, atol=1e-12)
         np.testing.assert_allclose(a, g["adv0"], rtol=1e-10, atol=1e-11)
         np.testing.assert_allclose(r, g["ret0"], rtol=1e-11, atol=1e-12)
-        for name, mod in mods.items():
-            for k, v in mod.state_dict().items():
-                np.testing.assert_allclose(v.numpy(), g["final_%s__%s" % (name, k)], rtol=1e-9, atol=1e-10, err_msg=name + "." + k)
+        check_final(mods, g, rtol=1e-9, atol=1e-10)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def test_float64_masters_with_float32_shadows_follow_the_reference_run():
+    """The drop-in precision scheme (agent.ShadowNets): float64 master modules owned by the caller and its optimizers,
+    float32 compute copies. Final MASTER parameters stay within float32 round-off of the reference's float64 run, the
+    shadows equal the rounded masters, and the masters' state_dict keeps its dtype."""
+    g = load_golden("ppo_update_h128.npz")
+    torch.set_default_dtype(torch.float64)          # as the reference driver does (ego_mimic.py:31-32)
+    try:
+        agent, mods = build_agent(g, net_dtype=torch.float32)
+        assert agent.shadow is not None and agent.cn.policy_net is not mods["p"]
+        assert next(agent.cn.policy_vs_net.parameters()).dtype == torch.float32
+        _with_oracle_gae(agent)
+        with torch.no_grad():
+            mods["p"].action_log_std.fill_(-1.2)     # the driver writes the masters between calls
+        agent.update_params(batch_of(g))
+        a, r, v0 = agent._seen
+        np.testing.assert_allclose(v0, g["values0"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(r, g["ret0"], rtol=1e-4, atol=1e-5)          # north_star: returns / advantages 1e-4 in fp32
+        np.testing.assert_allclose(a, g["adv0"], rtol=1e-4, atol=1e-4)
+        check_final(mods, g, rtol=1e-4, atol=2e-6)
+        for m, s in agent.shadow.pairs:
+            assert m.dtype == torch.float64 and s.dtype == torch.float32
+            assert torch.equal(s, m.float())
+        assert all(v.dtype == torch.float64 for v in mods["p_vs"].state_dict().values())
     finally:
         torch.set_default_dtype(torch.float32)
 

@@ -30,7 +30,7 @@ def _worker(rank, world, port, out_dir):
     torch.set_default_dtype(torch.float64)
     torch.set_num_threads(1)
     from conftest import load_golden
-    from test_agent_update_cpu import build_agent
+    from update_fixture import build_agent
     from egopose_amd import dist as D
     from egopose_amd.rl_core import TrajBatchEgo, LoggerRL
     from egopose_amd.zfilter import ZFilter

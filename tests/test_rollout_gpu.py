@@ -326,12 +326,17 @@ def test_forecast_full_iteration(workspace):
     tr.close()
 
 
-def test_fast_tick_path_is_bit_identical_to_the_torch_path(workspace, monkeypatch):
+@pytest.mark.parametrize("reward_delay_us", ["0", "500"])
+def test_fast_tick_path_is_bit_identical_to_the_torch_path(workspace, monkeypatch, reward_delay_us):
     """The pointer-level tick (pinned flag slots read in place, one ctypes call per kernel) against the torch-tensor tick
-    with the same seeds: identical batches, filter statistics and logger totals."""
+    with the same seeds: identical batches, filter statistics and logger totals. With `reward_delay_us` the reward
+    kernel that rides behind the env-step on the engine's stream is held back (EGP_REWARD_JOB_DELAY_US) so that an
+    in-batch reset on the caller's stream would overtake it unless egp_engine_reset is ordered behind it: terminal
+    rewards (incl. the end bonus) must still equal the torch tick's."""
     outs = []
     for fast in ("0", "1"):
         monkeypatch.setenv("EGP_FAST_TICK", fast)
+        monkeypatch.setenv("EGP_REWARD_JOB_DELAY_US", reward_delay_us if fast == "1" else "0")
         monkeypatch.setenv("EGP_POLICY_GRAPH", "0")          # eager noise draws in both runs (same generator stream)
         torch.manual_seed(123)
         np.random.seed(5)
@@ -350,3 +355,146 @@ def test_fast_tick_path_is_bit_identical_to_the_torch_path(workspace, monkeypatc
     assert a["steps"] == b["steps"] and a["eps"] == b["eps"] and a["n"] == b["n"] and a["r"] == b["r"]
     for k in ("states", "actions", "rewards", "masks", "next_states", "v_metas", "mean", "std"):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def _train_mode_policy_mean(tr, ro, batch):
+    """Policy head over VideoStateNet's TRAIN-mode forward of the batch (the form pinned to the reference's golden
+    vectors, tests/test_update_gpu.py): what every recorded mean action must equal."""
+    dev = torch.device("cuda", 0)
+    vs, pol = tr.agent.cn.policy_vs_net, tr.agent.cn.policy_net
+    with torch.no_grad():
+        vs.set_mode("train")
+        vs.attach_feature_table(ro.experts.cnn_table(dev, torch.float32), ro.experts.cnn_offset)
+        masks = torch.as_tensor(batch.masks.astype(np.float32), device=dev)
+        vs.initialize((masks, tr.env.cnn_feat, batch.v_metas))
+        mean, _ = pol.mean_std(vs(torch.as_tensor(batch.states, dtype=torch.float32, device=dev)))
+        vs.set_mode("test")
+    return mean.double().cpu().numpy()
+
+
+@pytest.mark.parametrize("fast_tick", ["1", "0"])
+def test_mimic_rollout_actions_equal_policy_of_train_mode_context(workspace, fast_tick, monkeypatch):
+    """a1 + a9 + a10 tied together on the ego_mimic path: with the mean action every recorded action equals
+    policy(cat(video context of the step's episode and frame, state)). A wrong row of the episode-context pool
+    (pre-sampled future episodes), a wrong v_out / t index in the fast tick or a stale context after an in-batch reset
+    changes the mean by far more than the tolerance. Both tick implementations; several resets per slot."""
+    monkeypatch.setenv("EGP_FAST_TICK", fast_tick)
+    tr, cfg = _trainer(workspace, 48, 13, num_threads=4, num_groups=2)
+    tr.pre_iter_update(0)
+    tr.agent.mean_action = True
+    ro = tr.agent._get_rollout()
+    ro.pool_batch = 40                      # several refills of the episode pool inside one rollout
+    batch, log = tr.agent.sample(48 * 40)
+    N = len(batch)
+    ends = np.where(batch.masks == 0)[0]
+    assert N >= 48 * 40 and len(ends) >= 3 * 48 and batch.exps.max() == 0
+    mean = _train_mode_policy_mean(tr, ro, batch)
+    np.testing.assert_allclose(batch.actions, mean, rtol=2e-4, atol=2e-4)
+    # the check has teeth: shifting the frame index by one moves the mean well outside the tolerance
+    sh = batch.v_metas.copy()
+    sh[:, 1] += 1
+    shifted = type(batch).from_device(**{k: torch.as_tensor(getattr(batch, k)) for k in
+                                         ("states", "actions", "masks", "next_states", "rewards", "exps")}, v_metas=torch.as_tensor(sh))
+    assert np.abs(_train_mode_policy_mean(tr, ro, shifted) - batch.actions).max() > 1e-3
+    tr.close()
+
+
+def test_sampled_actions_are_policy_mean_plus_unit_noise(workspace):
+    """Exploration rollout (fast tick, fused policy kernel, hipGraph noise): (action - mean) / std is N(0, 1) noise, the
+    mean being the train-mode policy of the recorded states."""
+    tr, cfg = _trainer(workspace, 64, 15, num_threads=4, num_groups=2)
+    tr.pre_iter_update(0)
+    ro = tr.agent._get_rollout()
+    batch, log = tr.agent.sample(64 * 30)
+    mean = _train_mode_policy_mean(tr, ro, batch)
+    std = float(np.exp(tr.policy_net.action_log_std.detach().cpu().numpy().ravel()[0]))
+    z = (batch.actions - mean) / std
+    assert batch.exps.min() == 1 and abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02 and np.abs(z).max() < 6.5
+    # noise is independent across action dimensions and steps
+    assert abs(np.corrcoef(z[:-1, 0], z[1:, 0])[0, 1]) < 0.1 and abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 0.1
+    tr.close()
+
+
+def _replay_episodes(tr, cfg, skel, batch, episodes, end_reward, tol=1e-7):
+    from egopose_amd.physics import SurrogatePhysics
+    from oracle.cpu_env import OracleHumanoidEnv
+    from oracle import humanoid as H
+    ends = np.where(batch.masks == 0)[0]
+    starts = np.r_[0, ends[:-1] + 1]
+    ph = SurrogatePhysics(skel, 1)
+    env = OracleHumanoidEnv(skel, cfg, ph, tr.env.expert_arr, tr.env.cnn_feat)
+    env.end_reward = end_reward
+    for j in episodes:
+        s, e = starts[j], ends[j]
+        ei, si = batch.v_metas[s]
+        assert (batch.v_metas[s:e + 1] == [ei, si]).all()
+        env.expert_ind, env.start_ind, env.cur_t = int(ei), int(si), 0
+        ex = tr.env.expert_arr[ei]
+        ph.reset(0, ex["qpos"][si], ex["qvel"][si])
+        env._drain(True)
+        env.bquat = H.body_quat(env.qpos, skel.body_qpos_start, skel.body_ndof)[0]
+        np.testing.assert_allclose(batch.states[s], env._obs(), rtol=1e-9, atol=1e-9)
+        for i in range(s, e + 1):
+            obs, _, done, info = env.step(batch.actions[i])
+            r, _ = env.reward(None, None, info)
+            np.testing.assert_allclose(batch.next_states[i], obs, rtol=tol, atol=tol, err_msg="obs @%d" % i)
+            np.testing.assert_allclose(batch.rewards[i], r, rtol=tol, atol=tol, err_msg="reward @%d" % i)
+            assert done == (batch.masks[i] == 0)
+    ph.close()
+    return starts, ends
+
+
+def test_bench_shape_rollout_replayed_by_oracle_env(tmp_path_factory, skel):
+    """BASELINE config 2 exactly as bench.py runs it -- 1 024 env slots, 2 groups, the resident K1 engine, 200-step
+    episodes, min batch 50 000, the bench's thread budget -- replayed on a sample of episodes (first / last slots of
+    both groups, episodes started by in-batch resets) by the oracle's one-env CPU env."""
+    from egopose_amd.bench_support import write_synthetic_dataset
+    from egopose_amd.config import Config
+    from egopose_amd.physics import default_threads
+    from egopose_amd.train import Trainer
+    root = str(tmp_path_factory.mktemp("egp_bench_shape"))
+    write_synthetic_dataset(root, "subject_03")                     # 8 takes x 2 000 frames, as bench.py
+    os.chdir(root)
+    cfg = Config("subject_03", create_dirs=False)
+    cfg.num_optim_epoch = 1
+    n_threads = max(2, default_threads(share=1, device_index=0))
+    tr = Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=1024, num_threads=n_threads, num_groups=2)
+    tr.pre_iter_update(0)
+    tr.agent.running_state = None
+    tr.env.end_reward = 1.7
+    batch, log = tr.agent.sample(cfg.min_batch_size)
+    eng = tr.agent._get_rollout().engine
+    assert eng.substeps_per_launch == 15 and eng.n_groups == 2, "bench shape must run the resident K1 engine"
+    N = len(batch)
+    ends = np.where(batch.masks == 0)[0]
+    assert N >= 50000 and ends[-1] == N - 1 and log.num_steps == N
+    n_ep = len(ends)
+    sample = sorted({0, 1, n_ep // 4, n_ep // 2 - 1, n_ep // 2, n_ep // 2 + 1, n_ep - 2, n_ep - 1})
+    starts, _ = _replay_episodes(tr, cfg, skel, batch, sample, 1.7)
+    lens = ends - starts + 1
+    assert lens.max() <= cfg.env_episode_len and (lens[sample] > 1).all()
+    tr.close()
+
+
+def test_cross_01_config_short_rollout(tmp_path_factory, skel):
+    """BASELINE config 3's single-GPU form: the cross_01 config (its own meta / feature ids, 40-take-style dataset)
+    loads through Config -> HumanoidEnv.load_experts and a short lockstep rollout is replayed by the oracle env."""
+    from egopose_amd.bench_support import write_synthetic_dataset
+    from egopose_amd.config import Config
+    from egopose_amd.train import Trainer
+    root = str(tmp_path_factory.mktemp("egp_cross01"))
+    write_synthetic_dataset(root, "cross_01", n_takes=10, n_frames=260, seed=9)
+    os.chdir(root)
+    cfg = Config("cross_01", create_dirs=False)
+    assert cfg.meta_id == "meta_cross_01" and len(cfg.takes["train"]) == 10 and cfg.max_iter_num == 6000
+    cfg.env_episode_len = 16
+    cfg.num_optim_epoch = 2
+    tr = Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=96, num_threads=4, num_groups=2)
+    tr.agent.running_state = None
+    tr.env.end_reward = 0.4
+    batch, log = tr.agent.sample(96 * 24)
+    assert set(np.unique(batch.v_metas[:, 0])) <= set(range(10)) and len(np.unique(batch.v_metas[:, 0])) >= 8
+    _replay_episodes(tr, cfg, skel, batch, range(0, 12), 0.4)
+    log, t_s, t_u, n = tr.iteration(0, 96 * 24)
+    assert n >= 96 * 24 and np.isfinite(log.avg_c_reward) and all(np.isfinite(tr.agent.update_stats["value_loss"]))
+    tr.close()

@@ -1,0 +1,173 @@
+"""GPU parity of the assembled PPO update against golden runs of the reference's
+`AgentEgo.update_params` (ego_pose/core/agent_ego.py:34-57, agents/agent_ppo.py:16-65, agents/agent_pg.py:19-26) and
+`VideoStateNet.initialize('train') / forward('train')` (models/video_state_net.py:40-69):
+
+  * float64 on the device with K5 (GAE) through the C-ABI                    -> final parameters at 1e-9
+  * float32 through the path bench.py times: device gather of the episode windows, persistent HIP LSTM recurrences in
+    grouped launches, row / episode bucket padding, fused Adam                  -> final parameters at fp32 round-off
+  * float64 master modules + float32 shadows (what the unmodified driver gets) -> same tolerance, masters stay float64
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from update_fixture import batch_of, build_agent, check_final
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kctx(skel):
+    from egopose_amd.hip import EgpContext
+    c = load_golden("config_subject_03.npz")
+    ctx = EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"])
+    yield ctx
+    ctx.close()
+
+
+def _attach_tables(agent, g, dtype):
+    """Device-resident feature table + take offsets, as AgentEgo.update_params installs them from the rollout's experts."""
+    feats = [np.asarray(g["cnn_feat0"], np.float64), np.asarray(g["cnn_feat1"], np.float64)]
+    table = torch.as_tensor(np.concatenate(feats, 0), dtype=dtype, device="cuda")
+    off = np.concatenate(([0], np.cumsum([f.shape[0] for f in feats])[:-1]))
+    for net in (agent.cn.policy_vs_net, agent.cn.value_vs_net):
+        net.attach_feature_table(table, off)
+
+
+def _spy_gae(agent, kctx):
+    """Route K5 through `kctx` and keep what it saw / produced."""
+    agent._kernel_ctx = lambda: kctx
+    inner = agent._advantages
+
+    def adv_fn(rewards, masks, values):
+        adv, ret = inner(rewards, masks, values)
+        agent._seen = (adv.double().cpu().numpy(), ret.double().cpu().numpy(), values.double().cpu().numpy())
+        return adv, ret
+    agent._advantages = adv_fn
+
+
+@pytest.mark.parametrize("fixture", ["ppo_update.npz", "ppo_update_h128.npz"])
+@pytest.mark.parametrize("device_gather", [False, True])
+def test_update_params_float64_on_device_matches_reference(kctx, fixture, device_gather, monkeypatch):
+    monkeypatch.setenv("EGP_NET_DTYPE", "float64")
+    g = load_golden(fixture)
+    torch.set_default_dtype(torch.float64)
+    try:
+        agent, mods = build_agent(g, device="cuda")
+        assert agent.shadow is None and agent.cdtype == torch.float64
+        if device_gather:
+            _attach_tables(agent, g, torch.float64)
+        _spy_gae(agent, kctx)
+        agent.update_params(batch_of(g))
+        a, r, v0 = agent._seen
+        np.testing.assert_allclose(v0, g["values0"], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(a, g["adv0"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(r, g["ret0"], rtol=1e-10, atol=1e-11)
+        check_final(mods, g, rtol=1e-9, atol=1e-10)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def _count_calls(monkeypatch, module, name):
+    calls = []
+    inner = getattr(module, name)
+
+    def wrapped(*a, **k):
+        calls.append(name)
+        return inner(*a, **k)
+    monkeypatch.setattr(module, name, wrapped)
+    return calls
+
+
+@pytest.mark.parametrize("mode", ["float32", "float64-masters"])
+@pytest.mark.parametrize("buckets", [False, True])
+def test_update_params_float32_hip_path_matches_reference(kctx, mode, buckets, monkeypatch):
+    """The update bench.py times, pinned to the reference's float64 run of the same batch."""
+    from egopose_amd import gemm_tuning, lstm
+    g = load_golden("ppo_update_h128.npz")
+    if buckets:     # the bucket padding engages at >= 4 buckets of rows / episodes: shrink the buckets to this batch
+        monkeypatch.setattr(gemm_tuning, "ROW_BUCKET", 64)
+        monkeypatch.setattr(gemm_tuning, "EPISODE_BUCKET", 8)
+        monkeypatch.setitem(gemm_tuning._state, "on", True)
+    group_calls = _count_calls(monkeypatch, lstm, "lstm_group")
+    masters64 = mode == "float64-masters"
+    if masters64:
+        torch.set_default_dtype(torch.float64)          # ego_pose/ego_mimic.py:31-32
+    try:
+        agent, mods = build_agent(g, device="cuda", dtype=torch.float64 if masters64 else torch.float32, fused_adam=not masters64)
+        assert agent.cdtype == torch.float32 and (agent.shadow is not None) == masters64
+        _attach_tables(agent, g, torch.float32)
+        _spy_gae(agent, kctx)
+        agent.update_params(batch_of(g))
+        torch.cuda.synchronize()
+        # 1 no-grad values pass + 3 epochs, every one through the grouped HIP recurrences (4 sweeps per launch)
+        assert len(group_calls) >= 1 + 3, "the persistent HIP LSTM did not run: %r" % (group_calls,)
+        a, r, v0 = agent._seen
+        np.testing.assert_allclose(v0, g["values0"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(r, g["ret0"], rtol=1e-4, atol=1e-5)          # north_star tolerance
+        np.testing.assert_allclose(a, g["adv0"], rtol=1e-4, atol=1e-4)
+        # float32 round-off against float64; a handful of elements with a ~0 gradient may take Adam's other +-lr step
+        check_final(mods, g, rtol=1e-4, atol=3e-6, max_outliers=8, outlier_atol=1.3e-2)
+        want = torch.float64 if masters64 else torch.float32
+        assert all(v.dtype == want for m in mods.values() for v in m.state_dict().values())
+        if masters64:
+            for m, s in agent.shadow.pairs:
+                assert torch.equal(s, m.float())
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def test_video_state_net_train_mode_device_gather_matches_reference():
+    """a14 on the device: segmentation indices, padded context windows gathered from the HBM feature table and the
+    gathered output rows == the reference's numpy loop (float64 fixture of tools/gen_golden.py G8)."""
+    from egopose_amd.nets import VideoStateNet
+    g = load_golden("video_state_net.npz")
+    cdim, hdim, margin = int(g["cdim"]), int(g["hdim"]), int(g["margin"])
+    net = VideoStateNet(cdim, hdim, margin, "lstm", None, False).double()
+    net.load_state_dict({k[3:]: torch.as_tensor(g[k]) for k in g.files if k.startswith("sd_")})
+    net.cuda()
+    feats = [g["cnn_feat0"], g["cnn_feat1"]]
+    table = torch.as_tensor(np.concatenate(feats, 0), device="cuda")
+    net.attach_feature_table(table, [0, feats[0].shape[0]])
+    net.set_mode("train")
+    masks = torch.as_tensor(g["masks"], device="cuda")
+    net.initialize((masks, None, g["v_metas"]))              # cnn_feat list not needed: windows come from the table
+    np.testing.assert_array_equal(net.indices, g["indices"])
+    np.testing.assert_array_equal(net.cnn_feat_ctx.cpu().numpy(), g["cnn_feat_ctx"])
+    with torch.no_grad():
+        out = net(torch.as_tensor(g["states"], device="cuda"))
+    np.testing.assert_allclose(out.cpu().numpy(), g["train_out"], rtol=1e-10, atol=1e-11)
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_video_state_net_train_mode_hip_lstm_matches_reference(grouped, monkeypatch):
+    """Same row with the float32 persistent recurrences (hidden 64 per direction): the policy's train-mode input of the
+    h128 fixture, alone and computed together with a second net in one grouped launch."""
+    from egopose_amd import lstm
+    from egopose_amd.nets import VideoStateNet, grouped_video_context
+    g = load_golden("ppo_update_h128.npz")
+    sdim, adim, cdim, hdim, margin, T_ep = [int(x) for x in g["dims"]]
+    nets = []
+    for name in ("p_vs", "v_vs"):
+        net = VideoStateNet(cdim, hdim, margin, "lstm", None, False)
+        net.load_state_dict({k[len("init_%s__" % name):]: torch.as_tensor(g[k]) for k in g.files if k.startswith("init_%s__" % name)})
+        nets.append(net.cuda())
+    feats = [g["cnn_feat0"], g["cnn_feat1"]]
+    table = torch.as_tensor(np.concatenate(feats, 0), dtype=torch.float32, device="cuda")
+    masks = torch.as_tensor(g["masks"].astype(np.float32), device="cuda")
+    calls = _count_calls(monkeypatch, lstm, "lstm_group")
+    for net in nets:
+        net.attach_feature_table(table, [0, feats[0].shape[0]])
+        net.set_mode("train")
+        net.initialize((masks, None, g["v_metas"]))
+    np.testing.assert_array_equal(nets[0].indices, g["indices"])
+    assert tuple(nets[0].cnn_feat_ctx.shape) == tuple(g["ctx_shape"])
+    states = torch.as_tensor(g["states"], dtype=torch.float32, device="cuda")
+    with torch.no_grad():
+        if grouped:
+            assert grouped_video_context(nets[::-1])
+        out = nets[0](states)
+    assert len(calls) == 1            # the bi-LSTM is one grouped launch either way (2 or 4 problems)
+    rows = g["policy_in0_rows"]
+    np.testing.assert_allclose(out.double().cpu().numpy()[rows], g["policy_in0"], rtol=2e-5, atol=2e-6)
