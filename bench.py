@@ -7,9 +7,19 @@ step quota (min_batch_size 50 000 per GPU, config/egomimic/subject_03.yml) follo
 precomputed features, MLP policy/value" on a synthetic subject_03-shaped dataset and random-init nets.
 Weak scaling: every rank owns 1024 slots; value = env-steps of all ranks / max-over-ranks wall time.
 
+`--gpus N` with N > 1 and no torchrun environment (WORLD_SIZE unset) launches the N ranks itself -- one process per GPU
+with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, backend nccl (= RCCL) -- as the reference starts
+all of its parallelism from one command (agents/agent.py:93-108). Under torchrun it is one of the ranks.
+
 Prints ONE JSON line (rank 0) with the driver's fields plus
-  roofline     K1 (stable-PD torque, the dominant kernel): algorithmic bytes per launch / mean launch duration
-               measured with HIP events on the launch streams inside the timed region, against 8 TB/s HBM
+  roofline     K1 (stable-PD torque, the dominant kernel): algorithmic bytes of the env-substeps the timed launches
+               actually STEPPED (finished slots of the rollout's tail move nothing) / their duration, measured with HIP
+               events on the launch streams inside the timed region, against 8 TB/s HBM; `frac_slot_based` is the same
+               with every slot of a launch counted (round 1's figure)
+  kernels      K1-K6 / K8 with inputs resident in HBM at 1 024 and 65 536 envs: the figures an HBM roofline can bind
+  legs         (1 GPU) the same workload (i) through the float64 driver set-up of the unmodified reference
+               (`dropin_env_steps_per_s`), (ii) with an inertia that changes on every substep fed from the host (the
+               traffic of a MuJoCo-like backend), (iii) with that inertia computed on the GPU (row f1)
   cpu_baseline the oracle's restatement of the reference CPU sampler (2 forked workers, float64, OMP=1) on a
                bounded sample, same physics backend (rank 0, N=1 only)
 """
@@ -17,12 +27,12 @@ import argparse
 import faulthandler
 import json
 import os
+import signal
+import socket
 import subprocess
 import sys
 import tempfile
 import time
-
-import signal
 
 faulthandler.register(signal.SIGUSR1, all_threads=True)       # `kill -USR1 <pid>`: where is a stuck run waiting?
 
@@ -55,6 +65,168 @@ def cgroup_throttle():
         return None
 
 
+def launch_ranks(n, argv):
+    """Start the n ranks of this bench (one process per GPU) and wait for them. Rank 0 inherits stdout, so its JSON line
+    is this command's output; the other ranks' stdout goes to stderr. Any rank failing takes the others down."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL needs it on this host driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print("bench.py: rank %d exited with %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                    for q in live:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def aggregate(steps_local, elapsed, world, device):
+    """(env-steps of all ranks, max-over-ranks wall time)."""
+    import torch
+    if world == 1:
+        return float(steps_local), float(elapsed)
+    from egopose_amd import dist as D
+    dev = D._comm_device(device)
+    st = torch.tensor([float(steps_local)], dtype=torch.float64, device=dev)
+    el = torch.tensor([float(elapsed)], dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(st)
+    torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    return float(st.item()), float(el.item())
+
+
+def base_line(args, world, total_steps, elapsed):
+    return {"metric": "env-steps/sec (whole node) ego_mimic PPO", "value": total_steps / elapsed, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(1, args.steps) * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None}
+
+
+def dry_run(args):
+    """Launcher / rendezvous / aggregation self-test without a GPU (gloo): every rank 'steps' a fixed amount of fake work."""
+    import torch
+    from egopose_amd import dist as D
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.time()
+    time.sleep(0.02 * (rank + 1))
+    if world > 1:
+        torch.distributed.barrier()
+    total, elapsed = aggregate(100 * (rank + 1) * args.steps, time.time() - t0, world, "cpu")
+    if rank == 0:
+        res = base_line(args, world, total, elapsed)
+        res.update(dtype="none", data="none", dry_run=True, env_steps=total,
+                   config={"workload": "launcher self-test (no GPU work)", "parallelism": "dp%d" % world})
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def k1_roofline(tim, envs_per_group, eng, every):
+    """K1 roofline from the engine's event-bracketed launches (see the module docstring)."""
+    if tim["k1_launches"] <= 0:
+        return None
+    total_s = tim["k1_ms"] * 1e-3
+    avg_s = total_s / tim["k1_launches"]
+    sub_per_launch = max(1, eng.substeps_per_launch)       # 15 when the resident K1 serves a whole env-step
+    slots_per_launch = envs_per_group / max(1, eng.launches_per_substep)
+    achieved = K1_BYTES_PER_ENV * tim["k1_env_substeps"] / total_s
+    slot_based = K1_BYTES_PER_ENV * slots_per_launch * sub_per_launch / avg_s
+    stepped_per_launch = tim["k1_env_substeps"] / float(sub_per_launch) / tim["k1_launches"]
+    traffic, traffic_src = None, None
+    try:      # HBM bytes from the committed PMC passes (rocprofv3 cannot run inside this process): tools/profile_round.sh
+        pm = json.load(open(os.path.join(REPO, "profiles", "pmc_k1_traffic.json")))
+        per = pm.get("hbm_bytes_per_stepped_env_substep") or pm["hbm_bytes_per_env_substep"]
+        traffic = per * stepped_per_launch * sub_per_launch
+        traffic_src = "NOT measured in this run: committed profile, " + pm["source"] + "; " + pm["correction"]
+    except Exception:
+        pass
+    return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+            "traffic": traffic, "traffic_unit": "bytes per launch (mean stepped envs)", "traffic_source": traffic_src,
+            "kernel": "k_pd_server_tree58 (resident: one launch = 15 substeps, duration includes the waits for host physics)"
+                      if sub_per_launch > 1 else "k_pd_torque_tree58<double>",
+            "substeps_per_launch": sub_per_launch, "avg_launch_us": avg_s * 1e6,
+            "stepped_envs_per_launch": stepped_per_launch, "slots_per_launch": slots_per_launch,
+            "frac_slot_based": slot_based / HBM_PEAK, "achieved_slot_based": slot_based / 1e9,
+            "event_pair_overhead_us_subtracted": tim["event_overhead_us"], "launches_timed": tim["k1_launches"],
+            "event_sampling": "every %d-th env-step of each group inside the timed region" % every,
+            "alg_bytes_per_env_substep": K1_BYTES_PER_ENV,
+            "note": "the in-rollout launch is bound by the host physics round trip, not by HBM; see `kernels` for the "
+                    "HBM-resident rates of the same arithmetic"}
+
+
+def run_leg(make_trainer, steps, warmup, min_batch, every, env=None, default_dtype=None):
+    """A short extra measurement of the same workload under another configuration (module docstring: `legs`)."""
+    import torch
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    tr = None
+    try:
+        if default_dtype is not None:
+            torch.set_default_dtype(default_dtype)       # the reference driver's process-wide setting (ego_mimic.py:31-32)
+        tr = make_trainer()
+        it = 0
+        for _ in range(warmup):
+            tr.iteration(it, min_batch)
+            it += 1
+        eng = tr.agent._get_rollout().engine
+        eng.set_profile(True, every=every)
+        eng.reset_timing()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        n_steps, t_sample, t_update = 0, 0.0, 0.0
+        for _ in range(steps):
+            _, ts, tu, n = tr.iteration(it, min_batch)
+            n_steps += n
+            t_sample += ts
+            t_update += tu
+            it += 1
+        torch.cuda.synchronize()
+        elapsed = time.time() - t0
+        tim = eng.timing()
+        out = {"env_steps_per_s": n_steps / elapsed, "rollout_only_env_steps_per_s": n_steps / max(t_sample, 1e-9),
+               "steps": steps, "warmup": warmup, "t_sample_s": t_sample, "t_update_s": t_update,
+               "substeps_per_launch": eng.substeps_per_launch, "device_dynamics": bool(getattr(eng, "device_dynamics", False)),
+               "inertia_uploads": int(eng.lib.egp_engine_inertia_uploads(eng.handle))}
+        if tim["k1_launches"] > 0:
+            out["k1_avg_launch_us"] = tim["k1_ms"] * 1e3 / tim["k1_launches"]
+            out["k1_stepped_envs_per_launch"] = tim["k1_env_substeps"] / float(max(1, eng.substeps_per_launch)) / tim["k1_launches"]
+        return out
+    except Exception as e:                       # a leg never takes the headline down
+        return {"error": repr(e)[:300]}
+    finally:
+        if tr is not None:
+            tr.close()
+        torch.set_default_dtype(torch.float32)
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,28 +243,49 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-k1-events", action="store_true")
     ap.add_argument("--k1-event-every", type=int, default=8, help="bracket K1 with HIP events on every Nth env-step")
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra 1-GPU legs (drop-in dtype, changing inertia)")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the HBM-resident kernel microbenchmarks")
+    ap.add_argument("--leg-steps", type=int, default=2)
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous self-test: no GPU work (gloo on CPU)")
     args = ap.parse_args()
 
-    import numpy as np
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if env_world is None and args.gpus > 1:
+        # one command starts every rank (no torchrun needed); never fall back to one rank silently
+        if not args.dry_run:
+            import torch
+            have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if have < args.gpus:
+                raise SystemExit("--gpus %d but this node shows %d GPU(s)" % (args.gpus, have))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s" % (args.gpus, env_world))
+    if args.dry_run:
+        return dry_run(args)
+
+    import numpy as np          # noqa: F401
     import torch
     from egopose_amd import dist as D
     rank, world, local = D.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    local = local % max(1, torch.cuda.device_count())     # (several ranks may share a device in the gloo self-test)
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from egopose_amd.bench_support import write_synthetic_dataset
+    from egopose_amd.bench_support import kernel_microbench, write_synthetic_dataset
     from egopose_amd.config import Config, ForecastConfig
     from egopose_amd.train import Trainer
 
     root = tempfile.mkdtemp(prefix="egp_bench_r%d_" % rank)
     write_synthetic_dataset(root, args.cfg, device_index=local)
     os.chdir(root)
-    cfg = (ForecastConfig if args.task == "egoforecast" else Config)(args.cfg, create_dirs=False)
+    cfg_cls = ForecastConfig if args.task == "egoforecast" else Config
+    cfg = cfg_cls(args.cfg, create_dirs=False)
     from egopose_amd.physics import available_cpus, default_threads
     cores = available_cpus()
     n_threads = args.threads or max(args.groups, default_threads(share=world, device_index=local))
@@ -126,20 +319,12 @@ def main():
     elapsed = time.time() - t0
     thr1 = cgroup_throttle()
     tim = eng.timing()
-    tot = torch.tensor([float(steps_local), elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        steps_t, el_t = tot[:1].clone(), tot[1:].clone()
-        torch.distributed.all_reduce(steps_t)
-        torch.distributed.all_reduce(el_t, op=torch.distributed.ReduceOp.MAX)
-        total_steps, elapsed = float(steps_t.item()), float(el_t.item())
-    else:
-        total_steps = float(steps_local)
+    total_steps, elapsed = aggregate(steps_local, elapsed, world, dev)
     ro = tr.agent._get_rollout()
+    res = None
     if rank == 0:
-        res = {
-            "metric": "env-steps/sec (whole node) ego_mimic PPO", "value": total_steps / elapsed, "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(1, args.steps) * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        res = base_line(args, world, total_steps, elapsed)
+        res.update({
             "dtype": "f64 (rollout kernels K1-K6, physics state) + f32 (policy/value nets)", "data": "synthetic",
             "config": {"workload": ("ego_mimic %s, %d lockstep env slots per MI355X, precomputed (synthetic) CNN features, "
                                     "MLP policy/value + bi-LSTM video context, PPO 10 full-batch epochs" % (args.cfg, args.envs))
@@ -153,33 +338,41 @@ def main():
                        "parallelism": "dp%d" % world},
             "env_steps": total_steps, "rollout_only_env_steps_per_s": steps_local / max(t_sample, 1e-9) * world,
             "t_sample_s": t_sample, "t_update_s": t_update,
-            "host_cgroup_throttled": None if not (thr0 and thr1) else {"events": thr1[0] - thr0[0], "usec_all_threads": thr1[1] - thr0[1]}, "rollout_timing": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ro.timing.items()},
-        }
-        if tim["k1_launches"] > 0:
-            avg_s = tim["k1_ms"] * 1e-3 / tim["k1_launches"]
-            envs_per_launch = args.envs / float(args.groups) / max(1, eng.launches_per_substep)
-            sub_per_launch = max(1, eng.substeps_per_launch)       # 15 when the resident K1 serves a whole env-step
-            achieved = K1_BYTES_PER_ENV * envs_per_launch * sub_per_launch / avg_s
-            traffic, traffic_src = None, None
-            try:      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
-                pm = json.load(open(os.path.join(REPO, "profiles", "pmc_k1_traffic.json")))
-                traffic = pm["hbm_bytes_per_env_substep"] * envs_per_launch * sub_per_launch
-                traffic_src = pm["source"] + "; " + pm["correction"]
-            except Exception:
-                pass
-            res["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes per launch",
-                               "traffic_source": traffic_src,
-                               "kernel": "k_pd_server_tree58 (resident: one launch = 15 substeps, duration includes the waits for host physics)" if sub_per_launch > 1 else "k_pd_torque_tree58<double>",
-                               "substeps_per_launch": sub_per_launch,
-                               "avg_launch_us": avg_s * 1e6, "event_pair_overhead_us_subtracted": tim["event_overhead_us"], "launches_timed": tim["k1_launches"], "event_sampling": "every %d-th env-step of each group inside the timed region" % args.k1_event_every, "envs_per_launch": envs_per_launch,
-                               "alg_bytes_per_env_substep": K1_BYTES_PER_ENV}
-        else:
-            res["roofline"] = None
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(root, args.cpu_steps, 2)
-        print(json.dumps(res))
+            "host_cgroup_throttled": None if not (thr0 and thr1) else {"events": thr1[0] - thr0[0], "usec_all_threads": thr1[1] - thr0[1]},
+            "rollout_timing": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ro.timing.items()},
+        })
+        res["roofline"] = k1_roofline(tim, args.envs / float(args.groups), eng, args.k1_event_every)
     tr.close()
+    if world > 1:
+        torch.distributed.barrier()
+    if rank == 0 and world == 1:
+        if not args.no_kernels:
+            try:
+                res["kernels"] = {"what": "inputs resident in HBM, HIP events, float64, algorithmic bytes of SURVEY 8(d); us includes "
+                                          "the Python/ctypes call (~8 us)", "peak_GBps": HBM_PEAK / 1e9,
+                                  "rows": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
+                                           for r in kernel_microbench((1024, 65536), device_index=local)]}
+            except Exception as e:
+                res["kernels"] = {"error": repr(e)[:300]}
+        if not args.no_legs and args.task == "egomimic":
+            mk32 = lambda: Trainer(cfg_cls(args.cfg, create_dirs=False), dev, torch.float32, num_envs=args.envs, num_threads=n_threads,
+                                   num_groups=args.groups)
+
+            mk64 = lambda: Trainer(cfg_cls(args.cfg, create_dirs=False), dev, torch.float64, num_envs=args.envs, num_threads=n_threads,
+                                   num_groups=args.groups, plain_optim=True)
+            ev = args.k1_event_every
+            legs = {
+                "dropin_float64_driver": run_leg(mk64, args.leg_steps, 1, min_batch, ev, default_dtype=torch.float64),
+                "changing_inertia_host_fed": run_leg(mk32, args.leg_steps, 1, min_batch, ev, {"EGP_SURROGATE_ALWAYS_DIRTY": "1"}),
+                "changing_inertia_device_dynamics": run_leg(mk32, args.leg_steps, 1, min_batch, ev,
+                                                            {"EGP_SURROGATE_ALWAYS_DIRTY": "1", "EGP_DEVICE_DYNAMICS": "1"}),
+            }
+            res["legs"] = {k: {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items()} for k, v in legs.items()}
+            res["dropin_env_steps_per_s"] = legs["dropin_float64_driver"].get("env_steps_per_s")
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(root, args.cpu_steps, 2)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

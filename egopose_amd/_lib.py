@@ -135,6 +135,7 @@ SIGNATURES = {
     "egp_engine_timing": (C.c_int, [vp, c_dbl_p, c_dbl_p, c_dbl_p, C.POINTER(_i64)]),
     "egp_engine_reset_timing": (C.c_int, [vp]),
     "egp_engine_inertia_uploads": (_i64, [vp]),
+    "egp_engine_k1_env_substeps": (_i64, [vp]),
     "egp_engine_event_overhead_ms": (C.c_double, [vp]),
     "egp_engine_set_profile": (C.c_int, [vp, C.c_int]),
     "egp_engine_layout": (C.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p]),

@@ -21,3 +21,85 @@ def write_synthetic_dataset(root, cfg_id="subject_03", device_index=0, n_takes=8
     finally:
         phys.close()
         ctx.close()
+
+
+HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def _time_launches(fn, iters=50, warm=5):
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def kernel_microbench(sizes=(1024, 65536), device_index=0, variants=False, iters=50):
+    """K1-K6 / K8 with inputs resident in HBM (HIP events on the launch stream, float64): per (kernel, n) the time per
+    call, the ALGORITHMIC bytes (SURVEY.md 8d / DESIGN.md section 4), achieved GB/s and the fraction of the 8 TB/s HBM
+    peak. These are the numbers an HBM roofline can bind; the in-rollout K1 launch waits for host physics instead.
+    `variants=True` also times the K1 fall-back kernels (dense order, generic LDS)."""
+    import numpy as np
+    import torch
+    from .hip import EgpContext
+    from .presets import subject_03_params
+    from .skeleton import load_skeleton
+    sk = load_skeleton()
+    p = subject_03_params()
+    ctx = EgpContext(sk, p["jkp"], p["jkd"], p["a_ref"], p["a_scale"], p["torque_lim"], p["b_diffw"], p["reward_weights"],
+                     device=device_index)
+    dev = torch.device("cuda", device_index)
+    dt, W = torch.float64, 8
+    rng = np.random.RandomState(0)
+    qM0 = sk.sparse_from_full(sk.zero_pose_inertia())
+    F = 4096                                   # a small expert table for the reward gathers
+    take = dict(qpos=rng.normal(size=(F, 59)), qvel=rng.normal(size=(F, 58)), rlinv_local=rng.normal(size=(F, 3)),
+                rangv=rng.normal(size=(F, 3)), rq_rmh=rng.normal(size=(F, 4)), ee_pos=rng.normal(size=(F, 15)),
+                bquat=rng.normal(size=(F, 84)), bangvel=rng.normal(size=(F, 63)), head_height_lb=1.0)
+    ctx.upload_experts([take])
+    out = []
+    try:
+        for n in sizes:
+            g = lambda *s: torch.randn(*s, dtype=dt, device=dev)
+            qpos, qvel, act, C = g(n, 59) * 0.3, g(n, 58), g(n, 52) * 0.3, g(n, 58)
+            qpos[:, 3:7] = torch.nn.functional.normalize(g(n, 4), dim=1)
+            prev = qpos + g(n, 59) * 0.01
+            qM = torch.as_tensor(qM0, device=dev).repeat(n, 1).contiguous()
+            ee = g(n, 15)
+            t = torch.randint(1, 100, (n,), dtype=torch.int32, device=dev)
+            frame = torch.randint(0, F, (n,), dtype=torch.int32, device=dev)
+            end = torch.zeros(n, dtype=torch.int32, device=dev)
+            obs = g(n, 115)
+            qM_dyn = torch.empty(n, sk.nM, dtype=dt, device=dev)
+            st0 = torch.zeros(231, dtype=dt, device=dev)
+            st1 = torch.empty_like(st0)
+            ns = n * 200 // 8
+            rew, msk, val = torch.rand(ns, dtype=dt, device=dev), torch.ones(ns, dtype=dt, device=dev), g(ns)
+            cases = [
+                ("K1_pd_torque", lambda: ctx.pd_torque(qpos, qvel, act, qM, C), (910 + 58 + 52 + 58 + 52 + 52) * W, 1),
+                ("K2_reward", lambda: ctx.reward(qpos, prev, ee, t, frame, end, 0.0), (59 + 59 + 15 + 166 + 6) * W, 1),
+                ("K3_obs", lambda: ctx.obs(qpos, qvel), (59 + 58 + 115) * W, 1),
+                ("K4_body_quat", lambda: ctx.body_quat(qpos), (59 + 84) * W, 1),
+                ("K6_zfilter", lambda: ctx.zfilter(obs, st0, st1, update=True), (115 + 115) * W, 1),
+                ("K5_gae", lambda: ctx.gae(rew, msk, val, 0.95, 0.95), 5 * W, ns / n),
+                ("K8_dynamics", lambda: ctx.dynamics(qpos, qvel, want_xpos=True, qM_out=qM_dyn), (59 + 58 + 910 + 58 + 63) * W, 1),
+            ]
+            for name, fn, bytes_per_unit, units_per_env in cases:
+                todo = [(0, "_tree58")] + ([(2, "_reg58"), (1, "_lds")] if variants else []) if name == "K1_pd_torque" else [(None, "")]
+                for variant, sfx in todo:
+                    if variant is not None:
+                        ctx.set_pd_variant(variant)
+                    s = _time_launches(fn, iters=min(iters, 20) if variant == 1 else iters)
+                    ab = bytes_per_unit * n * units_per_env
+                    out.append(dict(kernel=name + sfx, n=n, us=s * 1e6, alg_bytes=ab, GBps=ab / s / 1e9, frac_hbm=ab / s / HBM_PEAK))
+                if name == "K1_pd_torque":
+                    ctx.set_pd_variant(0)
+    finally:
+        ctx.close()
+    return out

@@ -137,6 +137,7 @@ struct Group {
     // timing (leader only)
     double phys_s = 0.0, wait_s = 0.0, k1_ms = 0.0, ev_overhead_ms = 0.0;
     long k1_launches = 0, qM_uploads = 0;
+    long k1_env_substeps = 0;                 // env-substeps actually stepped inside the event-bracketed launches
     std::vector<std::thread> threads;
 };
 
@@ -269,6 +270,14 @@ void enqueue_k1(egp_engine *E, Group &G, int substep) {
                              hipMemcpyDeviceToHost, G.stream));
 }
 
+// envs of the group this env-step advances (finished slots of a rollout's tail are skipped)
+inline long stepped_envs(const Group &G) {
+    if (!G.has_active) return G.e1 - G.e0;
+    long n = 0;
+    for (int e = G.e0; e < G.e1; ++e) n += G.active[e] != 0;
+    return n;
+}
+
 void run_step(egp_engine *E, Group &G, int tid) {
     const bool leader = tid == 0;
     const int FS = E->frame_skip;
@@ -276,6 +285,7 @@ void run_step(egp_engine *E, Group &G, int tid) {
     const int my0 = G.e0 + (int)((long)m * tid / G.n_threads), my1 = G.e0 + (int)((long)m * (tid + 1) / G.n_threads);
     if (leader) {
         G.prof_now = E->profile_k1.load(std::memory_order_relaxed) && !G.k_beg.empty() && (G.job % E->profile_every == 0);
+        if (G.prof_now) G.k1_env_substeps += stepped_envs(G) * (long)E->frame_skip;
         G.polled = E->flag_poll && E->zero_copy && E->ctx->pd_variant == 0;
         if (G.ready) G_HIP(hipStreamWaitEvent(G.stream, G.ready, 0));
         // env.prev_qpos = data.qpos.copy() (humanoid_v1.py:182): kept on the device for the reward kernel
@@ -398,6 +408,7 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
     }
     if (tid == 0) {
         G.prof_now = E->profile_k1.load(std::memory_order_relaxed) && !G.k_beg.empty() && (G.job % E->profile_every == 0);
+        if (G.prof_now) G.k1_env_substeps += stepped_envs(G) * (long)E->frame_skip;
         const int m = G.e1 - G.e0;
         if (G.ready) G_HIP(hipStreamWaitEvent(G.stream, G.ready, 0));
         if (G.prof_now) G_HIP(hipEventRecord(G.k_beg[0], G.stream));
@@ -537,6 +548,7 @@ void run_step_pipelined(egp_engine *E, Group &G, int tid) {
     };
     if (tid == 0) {
         G.prof_now = E->profile_k1.load(std::memory_order_relaxed) && (int)G.k_beg.size() >= FS * NC && (G.job % E->profile_every == 0);
+        if (G.prof_now) G.k1_env_substeps += stepped_envs(G) * (long)E->frame_skip;
         if (G.ready) G_HIP(hipStreamWaitEvent(G.stream, G.ready, 0));
         G_HIP(hipMemcpyAsync(E->d_prev_qpos + (size_t)G.e0 * E->nq, E->d_qpos + (size_t)G.e0 * E->nq,
                              (size_t)(G.e1 - G.e0) * E->nq * sizeof(double), hipMemcpyDeviceToDevice, G.stream));
@@ -1121,6 +1133,12 @@ int egp_engine_timing(egp_engine *E, double *phys_s, double *gpu_wait_s, double 
     return EGP_OK;
 }
 
+int64_t egp_engine_k1_env_substeps(egp_engine *E) {
+    long n = 0;
+    if (E) for (auto &G : E->groups) n += G.k1_env_substeps;
+    return n;
+}
+
 int egp_engine_set_profile(egp_engine *E, int on) {
     EGP_REQUIRE(E, "engine is NULL");
     E->profile_every = on > 1 ? on : 1;            // on = N > 1: sample every Nth env-step of each group
@@ -1136,7 +1154,7 @@ int egp_engine_set_profile(egp_engine *E, int on) {
 
 int egp_engine_reset_timing(egp_engine *E) {
     EGP_REQUIRE(E, "engine is NULL");
-    for (auto &G : E->groups) { G.phys_s = 0; G.wait_s = 0; G.k1_ms = 0; G.k1_launches = 0; }
+    for (auto &G : E->groups) { G.phys_s = 0; G.wait_s = 0; G.k1_ms = 0; G.k1_launches = 0; G.k1_env_substeps = 0; }
     return EGP_OK;
 }
 

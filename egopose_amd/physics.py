@@ -335,6 +335,7 @@ class RolloutEngine:
         n = C.c_int64()
         L.check(self.lib.egp_engine_timing(self.handle, C.byref(p), C.byref(w), C.byref(k), C.byref(n)), "egp_engine_timing")
         return dict(phys_s=p.value, gpu_wait_s=w.value, k1_ms=k.value, k1_launches=n.value,
+                    k1_env_substeps=int(self.lib.egp_engine_k1_env_substeps(self.handle)),
                     event_overhead_us=float(self.lib.egp_engine_event_overhead_ms(self.handle)) * 1e3)
 
     def close(self):

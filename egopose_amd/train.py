@@ -18,22 +18,27 @@ import torch
 
 from . import dist as D
 from . import gemm_tuning
-from .agent import AgentEgo
+from .agent import AgentEgo, compute_dtype
 from .config import Config, ForecastConfig
 from .env import HumanoidEnv
 from .logging_utils import Logger, create_logger
 from .nets import MLP, PolicyGaussian, Value, VideoForecastNet, VideoStateNet
 from .reward import reward_func
 from .torch_utils import set_optimizer_lr, to_cpu, to_device
-from .zfilter import ZFilter
+from .zfilter import ZFilter, reference_pickle_names
 
 
 class Trainer:
     """Everything ego_mimic.py builds at module level, as one object."""
 
-    def __init__(self, cfg, device, dtype=torch.float32, num_envs=1024, num_threads=None, num_groups=2, seed_offset=0):
+    def __init__(self, cfg, device, dtype=torch.float32, num_envs=1024, num_threads=None, num_groups=2, seed_offset=0,
+                 plain_optim=False):
+        """`dtype=torch.float64` is the reference driver's set-up (ego_pose/ego_mimic.py:31-32): float64 modules and
+        state_dicts; on a GPU the agent computes with float32 shadow copies (agent.ShadowNets). `plain_optim=True`
+        builds the optimizers exactly as the driver does (no fused Adam)."""
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
-        if self.device.type == "cuda" and dtype == torch.float32 and not gemm_tuning.enabled():
+        self.plain_optim = bool(plain_optim)
+        if self.device.type == "cuda" and compute_dtype(dtype, self.device) == torch.float32 and not gemm_tuning.enabled():
             gemm_tuning.enable()                         # bucketed update shapes + pre-tuned rocBLAS/hipBLASLt picks
         np.random.seed(cfg.seed + seed_offset)
         torch.manual_seed(cfg.seed)                      # identical initial weights on every rank
@@ -76,12 +81,11 @@ class Trainer:
                               optimizer_value=self.optimizer_value, opt_num_epochs=cfg.num_optim_epoch, gamma=cfg.gamma,
                               tau=cfg.tau, clip_epsilon=cfg.clip_epsilon, policy_grad_clip=[(policy_params, 40)])
 
-    @staticmethod
-    def _optimizer(kind, params, lr, momentum, weight_decay):
+    def _optimizer(self, kind, params, lr, momentum, weight_decay):
         if kind == "Adam":
             params = list(params)
             # one fused launch per step on the GPU instead of a handful of multi-tensor ones (same update rule)
-            fused = bool(params) and all(p.is_cuda and p.is_floating_point() for p in params)
+            fused = not self.plain_optim and bool(params) and all(p.is_cuda and p.is_floating_point() for p in params)
             return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, **({"fused": True} if fused else {}))
         return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay)
 
@@ -110,11 +114,11 @@ class Trainer:
         with to_cpu(*self.nets.values()):
             cp = {k: net.state_dict() for k, net in self.nets.items()}
             cp["running_state"] = self.running_state
-            with open(path, "wb") as f:
+            with open(path, "wb") as f, reference_pickle_names():    # running_state pickles as utils.zfilter.ZFilter
                 pickle.dump(cp, f)
 
     def load(self, path):
-        with open(path, "rb") as f:
+        with open(path, "rb") as f, reference_pickle_names():
             cp = pickle.load(f)
         for k, net in self.nets.items():
             net.load_state_dict(cp[k])
@@ -125,7 +129,7 @@ class Trainer:
         """ego_forecast.py:60-68: start the policy / value MLPs from an ego_mimic checkpoint; the first affine layer is
         dropped when its input width differs (state LSTM, phase observation or another video width)."""
         from .torch_utils import filter_state_dict
-        with open(path, "rb") as f:
+        with open(path, "rb") as f, reference_pickle_names():
             cp = pickle.load(f)
         cfg = self.cfg
         differs = getattr(cfg, "obs_phase", False) or getattr(cfg, "policy_s_net", "id") != "id" or \

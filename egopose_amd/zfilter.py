@@ -98,3 +98,52 @@ class ZFilter:
         self.rs._n = int(round(st[0]))
         self.rs._M = st[1:1 + d].reshape(self.rs.shape).copy()
         self.rs._S = st[1 + d:].reshape(self.rs.shape).copy()
+
+
+# ---------------------------------------------------------------------- checkpoint compatibility
+import contextlib
+import sys
+import types
+
+_REF_MODULE = "utils.zfilter"      # where the reference defines RunningStat / ZFilter (utils/zfilter.py)
+
+
+@contextlib.contextmanager
+def reference_pickle_names():
+    """While active, RunningStat / ZFilter pickle under the reference's module path (`utils.zfilter.ZFilter`), so a
+    checkpoint's `running_state` (ego_pose/ego_mimic.py:135-139) written here loads in the unmodified reference and
+    one written by the reference loads here -- whether or not `egopose_amd/compat` is on the path. When `utils.zfilter`
+    is not importable in this process, alias modules stand in for the duration of the block and are removed afterwards."""
+    classes = (RunningStat, ZFilter)
+    saved = [c.__module__ for c in classes]
+    installed = []
+    cur = sys.modules.get(_REF_MODULE)
+    if cur is None or getattr(cur, "ZFilter", None) is not ZFilter:
+        try:
+            import importlib
+            cur = importlib.import_module(_REF_MODULE)           # egopose_amd/compat on the path: its re-export
+        except Exception:
+            cur = None
+        if cur is None or getattr(cur, "ZFilter", None) is not ZFilter:
+            prev = {k: sys.modules.get(k) for k in ("utils", _REF_MODULE)}
+            alias = types.ModuleType(_REF_MODULE)
+            alias.RunningStat, alias.ZFilter = RunningStat, ZFilter
+            pkg = prev["utils"] if prev["utils"] is not None else types.ModuleType("utils")
+            if prev["utils"] is None:
+                pkg.__path__ = []
+                sys.modules["utils"] = pkg
+            sys.modules[_REF_MODULE] = alias
+            installed = [prev]
+    for c in classes:
+        c.__module__ = _REF_MODULE
+    try:
+        yield
+    finally:
+        for c, m in zip(classes, saved):
+            c.__module__ = m
+        for prev in installed:
+            for k, v in prev.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v

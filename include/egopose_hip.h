@@ -364,6 +364,9 @@ int egp_engine_wait(egp_engine *e, int32_t group, void *stream);
  * streams (empty-bracket overhead subtracted) + number of K1 launches */
 int egp_engine_timing(egp_engine *e, double *phys_s, double *gpu_wait_s, double *k1_ms_events, int64_t *k1_launches);
 int egp_engine_reset_timing(egp_engine *e);
+/* env-substeps (stepped envs x frame_skip) served by the event-bracketed K1 launches counted in egp_engine_timing:
+ * finished slots of a rollout's tail are not stepped and do not count (bench.py's roofline is quoted on this) */
+int64_t egp_engine_k1_env_substeps(egp_engine *e);
 int64_t egp_engine_inertia_uploads(egp_engine *e);
 double egp_engine_event_overhead_ms(egp_engine *e);   /* calibrated cost of an empty begin/end event pair, already subtracted from k1_ms_events */   /* group-level qM uploads done inside step (not resets) */
 int egp_engine_set_profile(egp_engine *e, int on);   /* 0 off; 1: HIP events around every K1 launch; N>1: on every Nth env-step */

@@ -83,11 +83,52 @@ def test_config_matches_reference_parse(tmp_path, skel, monkeypatch):
         Config("does_not_exist")
 
 
-def test_compat_packages_expose_the_driver_surface(tmp_path, skel):
-    """What ego_pose/ego_mimic.py:8-16,29-99 imports and calls, resolved through egopose_amd/compat."""
+REF_DRIVER = "/root/reference/ego_pose/ego_mimic.py"
+
+
+def _driver_env():
+    return dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.path.join(REPO, "egopose_amd", "compat"), HIP_VISIBLE_DEVICES="")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="the reference tree only exists in the build container")
+def test_unmodified_reference_driver_runs_on_the_compat_packages(tmp_path, skel):
+    """Row (b): `python <reference>/ego_pose/ego_mimic.py --cfg subject_03` executed AS IS (the file under /root/reference,
+    not a restatement) with egopose_amd/compat on PYTHONPATH and a config whose max_iter_num is 0: the whole module-level
+    set-up (imports, Config, env + experts, nets, optimizers, AgentEgo(dtype=float64, ...)) and an empty main_loop run
+    through this package's classes. No MI355X in the build container, so the driver picks its CPU device and nothing
+    is sampled; the iterations themselves are covered on the GPU by tests/test_dropin_gpu.py."""
     root = _workspace(tmp_path, skel)
-    code = r'''
-import os, sys
+    cfg_path = os.path.join(root, "config", "egomimic", "subject_03.yml")
+    y = yaml.safe_load(open(cfg_path))
+    y["max_iter_num"] = 0
+    yaml.safe_dump(y, open(cfg_path, "w"))
+    out = subprocess.run([sys.executable, REF_DRIVER, "--cfg", "subject_03", "--num-threads", "2"], cwd=root, env=_driver_env(),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    log = open(os.path.join(root, "results/egomimic/subject_03/log/log.txt")).read()
+    assert "training done!" in log
+    # every module the driver imported came from this package's mirrors, none from the reference tree
+    probe = ("import runpy, sys; sys.argv = [%r, '--cfg', 'subject_03']; runpy.run_path(%r, run_name='__main__'); "
+             "mods = ['utils', 'core.policy_gaussian', 'core.critic', 'models.mlp', 'models.video_state_net', "
+             "'ego_pose.envs.humanoid_v1', 'ego_pose.core.agent_ego', 'ego_pose.utils.egomimic_config', "
+             "'ego_pose.core.reward_function']; "
+             "print('ORIGINS', [sys.modules[m].__file__ for m in mods])" % (REF_DRIVER, REF_DRIVER))
+    out = subprocess.run([sys.executable, "-c", probe], cwd=root, env=_driver_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    origins = eval(out.stdout.split("ORIGINS", 1)[1].strip().splitlines()[0])
+    assert len(origins) == 9 and all(o.startswith(os.path.join(REPO, "egopose_amd", "compat")) for o in origins), origins
+
+
+def test_compat_packages_expose_the_driver_surface(tmp_path, skel):
+    """The names ego_pose/ego_mimic.py:8-16 imports and the calls it makes on them (:29-99), resolved through
+    egopose_amd/compat -- runs everywhere (the test above needs the reference tree). Sampling without an MI355X must
+    refuse loudly."""
+    root = _workspace(tmp_path, skel)
+    code = r"""
+import os
+import utils as U
+for name in ("torch", "np", "Logger", "create_logger", "ZFilter", "to_device", "to_cpu", "set_optimizer_lr"):
+    assert hasattr(U, name), name
 from utils import *
 from core.policy_gaussian import PolicyGaussian
 from core.critic import Value
@@ -97,53 +138,34 @@ from ego_pose.envs.humanoid_v1 import HumanoidEnv
 from ego_pose.core.agent_ego import AgentEgo
 from ego_pose.utils.egomimic_config import Config
 from ego_pose.core.reward_function import reward_func
+torch.set_default_dtype(torch.float64)
 cfg = Config("subject_03", create_dirs=True)
-dtype = torch.float64
-torch.set_default_dtype(dtype)
-device = torch.device("cpu")
-np.random.seed(cfg.seed); torch.manual_seed(cfg.seed)
-tb_logger = Logger(cfg.tb_dir)
-logger = create_logger(os.path.join(cfg.log_dir, "log.txt"), file_handle=True)
 env = HumanoidEnv(cfg)
 env.seed(cfg.seed)
 env.load_experts(cfg.takes["train"], cfg.expert_feat_file, cfg.cnn_feat_file)
-cnn_feat_dim = env.cnn_feat[0].shape[-1]
-assert len(env.model.actuator_names) == 52
-state_dim, action_dim = env.observation_space.shape[0], env.action_space.shape[0]
-assert (state_dim, action_dim) == (115, 52)
-running_state = ZFilter((state_dim,), clip=5)
-policy_vs_net = VideoStateNet(cnn_feat_dim, cfg.policy_v_hdim, cfg.fr_margin, cfg.policy_v_net, cfg.policy_v_net_param, cfg.causal)
-value_vs_net = VideoStateNet(cnn_feat_dim, cfg.value_v_hdim, cfg.fr_margin, cfg.value_v_net, cfg.value_v_net_param, cfg.causal)
-policy_net = PolicyGaussian(MLP(state_dim + cfg.policy_v_hdim, cfg.policy_hsize, cfg.policy_htype), action_dim, log_std=cfg.log_std, fix_std=cfg.fix_std)
-value_net = Value(MLP(state_dim + cfg.value_v_hdim, cfg.value_hsize, cfg.value_htype))
-to_device(device, policy_net, value_net, policy_vs_net, value_vs_net)
-policy_params = list(policy_net.parameters()) + list(policy_vs_net.parameters())
-value_params = list(value_net.parameters()) + list(value_vs_net.parameters())
-optimizer_policy = torch.optim.Adam(policy_params, lr=cfg.policy_lr, weight_decay=cfg.policy_weightdecay)
-optimizer_value = torch.optim.Adam(value_params, lr=cfg.value_lr, weight_decay=cfg.value_weightdecay)
-agent = AgentEgo(env=env, dtype=dtype, device=device, running_state=running_state, custom_reward=reward_func[cfg.reward_id],
-                 mean_action=False, render=False, num_threads=2, policy_net=policy_net, policy_vs_net=policy_vs_net,
-                 value_net=value_net, value_vs_net=value_vs_net, optimizer_policy=optimizer_policy, optimizer_value=optimizer_value,
-                 opt_num_epochs=cfg.num_optim_epoch, gamma=cfg.gamma, tau=cfg.tau, clip_epsilon=cfg.clip_epsilon,
-                 policy_grad_clip=[(policy_params, 40)])
-cfg.update_adaptive_params(0)
-agent.set_noise_rate(cfg.adp_noise_rate)
-set_optimizer_lr(optimizer_policy, cfg.adp_policy_lr)
-policy_net.action_log_std.fill_(cfg.adp_log_std)
-tb_logger.scalar_summary("total_reward", 0.5, 0)
-with to_cpu(policy_net, value_net):
-    sd = policy_net.state_dict()
+assert len(env.model.actuator_names) == 52 and (env.observation_space.shape[0], env.action_space.shape[0]) == (115, 52)
+vs = [VideoStateNet(env.cnn_feat[0].shape[-1], cfg.policy_v_hdim, cfg.fr_margin, cfg.policy_v_net, cfg.policy_v_net_param, cfg.causal) for _ in range(2)]
+pol = PolicyGaussian(MLP(115 + cfg.policy_v_hdim, cfg.policy_hsize, cfg.policy_htype), 52, log_std=cfg.log_std, fix_std=cfg.fix_std)
+val = Value(MLP(115 + cfg.value_v_hdim, cfg.value_hsize, cfg.value_htype))
+pp, vp = list(pol.parameters()) + list(vs[0].parameters()), list(val.parameters()) + list(vs[1].parameters())
+agent = AgentEgo(env=env, dtype=torch.float64, device=torch.device("cpu"), running_state=ZFilter((115,), clip=5),
+                 custom_reward=reward_func[cfg.reward_id], mean_action=False, render=False, num_threads=2, policy_net=pol,
+                 policy_vs_net=vs[0], value_net=val, value_vs_net=vs[1], optimizer_policy=torch.optim.Adam(pp, lr=cfg.policy_lr),
+                 optimizer_value=torch.optim.Adam(vp, lr=cfg.value_lr), opt_num_epochs=cfg.num_optim_epoch, gamma=cfg.gamma,
+                 tau=cfg.tau, clip_epsilon=cfg.clip_epsilon, policy_grad_clip=[(pp, 40)])
+Logger(cfg.tb_dir).scalar_summary("total_reward", 0.5, 0)
+with to_cpu(pol, val):
+    sd = pol.state_dict()
 assert "net.affine_layers.0.weight" in sd and "action_log_std" in sd
 try:
-    agent.sample(100)                      # no MI355X here: the product path must refuse, loudly
+    agent.sample(100)
 except RuntimeError as e:
     assert "no CPU fallback" in str(e)
 else:
     raise SystemExit("sampling on CPU must fail")
 print("DRIVER_SURFACE_OK")
-'''
-    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.path.join(REPO, "egopose_amd", "compat"))
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+"""
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=_driver_env(), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "DRIVER_SURFACE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
     assert os.path.exists(os.path.join(root, "results/egomimic/subject_03/tb/scalars.jsonl"))
 
@@ -358,3 +380,34 @@ print("HASH", h.hexdigest())
         assert r.returncode == 0, r.stderr
         out[variant] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
     assert out["plain"] == out["avx2"] == out["avx512"], out
+
+
+def test_running_state_pickles_under_the_reference_module_path(tmp_path):
+    """Checkpoints name `utils.zfilter.ZFilter` (where the reference defines it), not egopose_amd.zfilter: the unmodified
+    reference can load what Trainer.save wrote, and the alias modules do not outlive the call."""
+    import pickletools
+    from egopose_amd.zfilter import ZFilter, reference_pickle_names
+    zf = ZFilter((5,), clip=5)
+    for x in np.random.RandomState(0).normal(size=(7, 5)):
+        zf(x)
+    had = {k: sys.modules.get(k) for k in ("utils", "utils.zfilter")}
+    with reference_pickle_names():
+        blob = pickle.dumps({"running_state": zf})
+    assert {k: sys.modules.get(k) for k in had} == had and ZFilter.__module__ == "egopose_amd.zfilter"
+    ops = [str(arg) for _, arg, _ in pickletools.genops(blob) if arg is not None]
+    assert any("utils.zfilter" in a for a in ops) and not any("egopose_amd" in a for a in ops)
+    with reference_pickle_names():
+        back = pickle.loads(blob)["running_state"]
+    assert isinstance(back, ZFilter) and back.rs.n == 7
+    np.testing.assert_array_equal(back.rs.std, zf.rs.std)
+    if os.path.exists("/root/reference/utils/zfilter.py"):       # build container: the reference's own class takes it
+        code = ("import sys, pickle, numpy as np; sys.path.insert(0, '/root/reference/utils'); import importlib.util as iu; "
+                "spec = iu.spec_from_file_location('utils.zfilter', '/root/reference/utils/zfilter.py'); m = iu.module_from_spec(spec); "
+                "import types; sys.modules['utils'] = types.ModuleType('utils'); sys.modules['utils.zfilter'] = m; spec.loader.exec_module(m); "
+                "rs = pickle.load(open(sys.argv[1], 'rb'))['running_state']; assert type(rs).__module__ == 'utils.zfilter'; "
+                "print('REF_LOADED', rs.rs.n, float(rs(np.zeros(5), update=False).sum()))")
+        path = str(tmp_path / "cp.p")
+        open(path, "wb").write(blob)
+        out = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and "REF_LOADED 7" in out.stdout, out.stdout + out.stderr
+        assert float(out.stdout.split()[-1]) == pytest.approx(float(zf(np.zeros(5), update=False).sum()), rel=1e-12)

@@ -5,14 +5,17 @@
 #   pmc_bench_fetch_write.csv   FETCH_SIZE / WRITE_SIZE per egp kernel (separate --pmc passes, kernel-trace only)
 #   pmc_k1_traffic.json         HBM bytes per env-substep of the dominant kernel from those passes
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+ROUND_TAG=${ROUND_TAG:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_round
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -o b -- python bench.py > $OUT/bench.log 2>&1
+# (headline only: the extra legs / microbenchmarks of the default run launch the same kernels under other conditions
+#  and would blur the per-kernel averages the bench line's roofline is checked against)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -o b -- python bench.py --no-legs --no-kernels > $OUT/bench.log 2>&1
 grep '^{' $OUT/bench.log | tail -1 > $OUT/bench_line_under_rocprof.json
 cp "$(find $OUT/raw -name '*kernel_stats.csv' | head -1)" $OUT/bench_kernel_stats.csv
 rm -rf $OUT/raw
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o b -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-k1-events > $OUT/$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o b -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-k1-events --no-legs --no-kernels > $OUT/$c.log 2>&1
 done
 python - <<PY
 import csv, glob, collections, json
@@ -37,11 +40,22 @@ open(OUT + "/pmc_bench_fetch_write.csv", "w").write("\n".join(rows) + "\n")
 if k1:
     grid = int(k1[0].split("grid=")[1])
     envs = grid // 256 * 4
+    # env-steps of the profiled run (its own JSON line): every one of them is 15 stepped env-substeps of some launch
+    steps = []
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        try:
+            line = [l for l in open(OUT + "/%s.log" % c) if l.startswith("{")][-1]
+            steps.append(json.loads(line)["env_steps"])
+        except Exception:
+            pass
+    env_steps = sum(steps) / len(steps) if steps else None
     d = {"kernel": "k_pd_server_tree58 (resident K1: one launch = 15 substeps of a %d-env group)" % envs,
-         "source": "profiles/r01_pmc_bench_n1_fetch_write.csv (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 1 --warmup 0, %d launches)" % k1[1],
+         "source": "profiles/${ROUND_TAG}_pmc_bench_n1_fetch_write.csv (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 1 --warmup 0, %d launches)" % k1[1],
          "fetch_kib_per_launch": k1[2], "write_kib_per_launch": k1[3], "envs_per_launch": envs, "substeps_per_launch": 15,
          "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads -> bytes = (2*FETCH + WRITE) * 1024; the counters also see the state rows / torques in pinned host memory (zero-copy) and the go-word polls",
-         "hbm_bytes_per_env_substep": (2 * k1[2] + k1[3]) * 1024 / (envs * 15)}
+         "hbm_bytes_per_env_substep": (2 * k1[2] + k1[3]) * 1024 / (envs * 15),
+         "launches": k1[1], "env_steps_of_profiled_run": env_steps,
+         "hbm_bytes_per_stepped_env_substep": (None if not env_steps else (2 * k1[2] + k1[3]) * 1024 * k1[1] / (env_steps * 15))}
     json.dump(d, open(OUT + "/pmc_k1_traffic.json", "w"), indent=1)
 print("\n".join(rows))
 PY
