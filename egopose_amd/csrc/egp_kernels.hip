@@ -1291,6 +1291,54 @@ static int launch_body_quat(egp_ctx *ctx, const T *qpos, int n, T *bquat, void *
     return after_launch("k_body_quat");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// a7: the quaternion algebra of egp_quat.hpp as a batched entry point of its own (one thread per row). The rollout
+// kernels inline these functions; this launch exists so that callers (and the parity tests against the reference's
+// utils/transformation.py / utils/math.py vectors) can reach each of them directly.
+template <typename T>
+__global__ __launch_bounds__(256) void k_quat_op(int op, const T *__restrict__ a, const T *__restrict__ b, int n, T *__restrict__ o) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto ldq = [](const T *p) { Q4<T> q; q.w = p[0]; q.x = p[1]; q.y = p[2]; q.z = p[3]; return q; };
+    auto stq = [](T *p, const Q4<T> &q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; };
+    switch (op) {
+    case EGP_QUAT_MUL: stq(o + 4 * i, qmul(ldq(a + 4 * i), ldq(b + 4 * i))); break;
+    case EGP_QUAT_INV: stq(o + 4 * i, qinv(ldq(a + 4 * i))); break;
+    case EGP_QUAT_FROM_EULER_SXYZ: stq(o + 4 * i, q_from_euler_sxyz<T>(a[3 * i], a[3 * i + 1], a[3 * i + 2])); break;
+    case EGP_QUAT_HEADING_Q: stq(o + 4 * i, heading_q(ldq(a + 4 * i))); break;
+    case EGP_QUAT_DE_HEADING: stq(o + 4 * i, de_heading(ldq(a + 4 * i))); break;
+    case EGP_QUAT_TRANSFORM_VEC_ROOT:
+    case EGP_QUAT_TRANSFORM_VEC_HEADING: {
+        Q4<T> q = ldq(b + 4 * i);
+        if (op == EGP_QUAT_TRANSFORM_VEC_HEADING) q = heading_q(q);
+        V3<T> v; v.x = a[3 * i]; v.y = a[3 * i + 1]; v.z = a[3 * i + 2];
+        const V3<T> r = rotate_T(q, v);
+        o[3 * i] = r.x; o[3 * i + 1] = r.y; o[3 * i + 2] = r.z;
+        break;
+    }
+    case EGP_QUAT_ROTATION: {
+        V3<T> ax; T an;
+        rot_axis_angle(ldq(a + 4 * i), &ax, &an);
+        o[4 * i] = ax.x; o[4 * i + 1] = ax.y; o[4 * i + 2] = ax.z; o[4 * i + 3] = an;
+        break;
+    }
+    case EGP_QUAT_DIFF_HALF_ANGLE: o[i] = half_angle(qmul(ldq(a + 4 * i), qinv(ldq(b + 4 * i)))); break;
+    default: break;
+    }
+}
+
+template <typename T>
+static int launch_quat_op(int op, const T *a, const T *b, int n, T *out, void *stream) {
+    EGP_REQUIRE(op >= 0 && op < EGP_QUAT_N_OPS, "unknown quaternion op");
+    EGP_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return EGP_OK;
+    const bool two = op == EGP_QUAT_MUL || op == EGP_QUAT_TRANSFORM_VEC_ROOT || op == EGP_QUAT_TRANSFORM_VEC_HEADING ||
+                     op == EGP_QUAT_DIFF_HALF_ANGLE;
+    EGP_REQUIRE(a && out && (b || !two), "NULL pointer");
+    k_quat_op<T><<<dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(op, a, b, n, out);
+    return after_launch("k_quat_op");
+}
+
 template <typename T>
 static int launch_obs(egp_ctx *ctx, const T *qpos, const T *qvel, int n, T *obs, void *stream) {
     EGP_REQUIRE(ctx, "ctx is NULL");
@@ -1504,6 +1552,8 @@ extern "C" {
 
 int egp_body_quat_f64(egp_ctx *c, const double *q, int32_t n, double *o, void *s) { return launch_body_quat<double>(c, q, n, o, s); }
 int egp_body_quat_f32(egp_ctx *c, const float *q, int32_t n, float *o, void *s) { return launch_body_quat<float>(c, q, n, o, s); }
+int egp_quat_op_f64(int32_t op, const double *a, const double *b, int32_t n, double *o, void *s) { return launch_quat_op<double>(op, a, b, n, o, s); }
+int egp_quat_op_f32(int32_t op, const float *a, const float *b, int32_t n, float *o, void *s) { return launch_quat_op<float>(op, a, b, n, o, s); }
 int egp_obs_f64(egp_ctx *c, const double *q, const double *v, int32_t n, double *o, void *s) { return launch_obs<double>(c, q, v, n, o, s); }
 int egp_obs_f32(egp_ctx *c, const float *q, const float *v, int32_t n, float *o, void *s) { return launch_obs<float>(c, q, v, n, o, s); }
 

@@ -55,6 +55,25 @@ DEFAULT_REWARD = dict(w_p=0.5, w_v=0.1, w_e=0.2, w_rp=0.1, w_rv=0.1, k_p=2.0, k_
                       k_rh=300.0, k_rq=300.0, k_rl=5.0, k_ra=0.5, v_ord=2, decay=False)
 
 
+QUAT_OPS = dict(mul=(0, 4, 4, 4), inv=(1, 4, 0, 4), from_euler_sxyz=(2, 3, 0, 4), heading_q=(3, 4, 0, 4), de_heading=(4, 4, 0, 4),
+                transform_vec_root=(5, 3, 4, 3), transform_vec_heading=(6, 3, 4, 3), rotation=(7, 4, 0, 4), diff_half_angle=(8, 4, 4, 1))
+
+
+def quat_op(name, a, b=None):
+    """Batched quaternion algebra on the device (`egp_quat_op_*`, include/egopose_hip.h): name -> (op, width a, width b, width out)."""
+    op, wa, wb, wo = QUAT_OPS[name]
+    n = a.shape[0]
+    _need(a, (n, wa), a.dtype, "a")
+    if wb:
+        if b is None:
+            raise ValueError("%s needs two operands" % name)
+        _need(b, (n, wb), a.dtype, "b")
+    out = torch.empty((n, wo) if wo > 1 else (n,), dtype=a.dtype, device=a.device)
+    fn = getattr(L.load(), "egp_quat_op_" + _DT[a.dtype])
+    L.check(fn(op, _ptr(a), _ptr(b if wb else None), n, _ptr(out), _stream()), "egp_quat_op")
+    return out
+
+
 class EgpContext:
     """Model constants + expert table resident in HBM (``egp_ctx``)."""
 

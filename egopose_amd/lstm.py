@@ -51,7 +51,7 @@ def _gate_perm(hidden, device):
 class LstmDirection(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, reverse):
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, reverse, train):
         lib = L.load()
         T, B, D = x.shape
         HIDDEN = w_hh.shape[1]
@@ -67,7 +67,8 @@ class LstmDirection(torch.autograd.Function):
         h_buf = torch.empty(T + 1, B, HIDDEN, dtype=x.dtype, device=x.device)
         h_buf[T if reverse else 0].zero_()
         h = h_buf[:T] if reverse else h_buf[1:]
-        train = any(ctx.needs_input_grad)
+        # `train` comes from the caller: ctx.needs_input_grad mirrors requires_grad of the inputs and is also set under
+        # torch.no_grad(), where nothing will ever call backward (no cell / gate saves: the inference kernel)
         cells = torch.empty(T, B, HIDDEN, dtype=x.dtype, device=x.device) if train else None
         w_hh_c = w_hh.contiguous()
         # the activated gates overwrite the pre-activations in place (a thread reads its part of gx[t] before it
@@ -103,7 +104,7 @@ class LstmDirection(torch.autograd.Function):
         d_w_hh = dw[:, D:D + HIDDEN].contiguous() if ctx.needs_input_grad[2] else None
         d_b = dw[:, D + HIDDEN].contiguous() if (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else None
         d_x = dpre.view(T * B, 4 * HIDDEN).mm(w_in).view(T, B, D) if ctx.needs_input_grad[0] else None
-        return d_x, d_w_ih, d_w_hh, d_b, d_b, None
+        return d_x, d_w_ih, d_w_hh, d_b, d_b, None, None
 
 
 class LstmGroup(torch.autograd.Function):
@@ -115,7 +116,7 @@ class LstmGroup(torch.autograd.Function):
     problems is one batched GEMM against x, dW_hh one per problem against its own h_prev (no concatenated operands)."""
 
     @staticmethod
-    def forward(ctx, x, reverse_mask, P, width, *params):
+    def forward(ctx, x, reverse_mask, P, width, train, *params):
         lib = L.load()
         T, B, D = x.shape
         w_ih, w_hh, b_ih, b_hh = params[0::4], params[1::4], params[2::4], params[3::4]
@@ -132,7 +133,6 @@ class LstmGroup(torch.autograd.Function):
         h_buf = torch.empty(n_out, T + 2, B, W, dtype=x.dtype, device=x.device)
         h_buf[:, 0].zero_()
         h_buf[:, T + 1].zero_()
-        train = any(ctx.needs_input_grad)
         cells = torch.empty(P, T, B, H, dtype=x.dtype, device=x.device) if train else None
         base, esz = h_buf.data_ptr(), h_buf.element_size()
         ptrs = (C.c_void_p * P)(*[base + esz * (((p // width) * (T + 2) + 1) * B * W + (p % width) * H) for p in range(P)])
@@ -170,7 +170,13 @@ class LstmGroup(torch.autograd.Function):
             d_b = db[p].index_select(0, inv)
             grads += [dw_ih, dw_hh, d_b, d_b]
         d_x = dpre.mm(w_in).view(T, B, D) if ctx.needs_input_grad[0] else None
-        return (d_x, None, None, None, *grads)
+        return (d_x, None, None, None, None, *grads)
+
+
+def _wants_grad(x, params):
+    """True when a backward pass can follow: grad mode on and something to differentiate. Decided outside the autograd
+    Function (inside its forward grad mode is always off, and needs_input_grad ignores torch.no_grad())."""
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
 
 
 def group_available(x, cells):
@@ -186,8 +192,9 @@ def lstm_group(x, cells, reverses, pairs=False):
     pairs=True [(T,B,2H)] * P/2 where problems 2i and 2i+1 fill the two halves of output i."""
     mask = sum(1 << i for i, r in enumerate(reverses) if r)
     params = [t for c in cells for t in (c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh)]
-    return list(LstmGroup.apply(x.contiguous(), mask, len(cells), 2 if pairs else 1, *params))
+    return list(LstmGroup.apply(x.contiguous(), mask, len(cells), 2 if pairs else 1, _wants_grad(x, params), *params))
 
 
 def lstm_direction(cell, x, reverse):
-    return LstmDirection.apply(x, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh, bool(reverse))
+    params = (cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)
+    return LstmDirection.apply(x, *params, bool(reverse), _wants_grad(x, params))

@@ -45,6 +45,26 @@ def bucket_rows(x):
     return x, None
 
 
+def _take_lengths(take_offset, n_rows):
+    off = np.asarray(take_offset, dtype=np.int64).ravel()
+    return np.diff(np.concatenate((off, [int(n_rows)])))
+
+
+def _check_windows(take_len, expert_ind, start_ind, before, after):
+    """Every window [start - before, start + after) inside its take, else ValueError (host-side, numpy indices)."""
+    e = np.asarray(expert_ind, dtype=np.int64).ravel()
+    s = np.asarray(start_ind, dtype=np.int64).ravel()
+    if e.size == 0:
+        return
+    if e.min() < 0 or e.max() >= len(take_len):
+        raise ValueError("take index out of range: [%d, %d] with %d takes" % (e.min(), e.max(), len(take_len)))
+    bad = (s - before < 0) | (s + after > take_len[e])
+    if bad.any():
+        k = int(np.nonzero(bad)[0][0])
+        raise ValueError("CNN-feature window [%d, %d) leaves take %d (%d frames): %d of %d windows do"
+                         % (s[k] - before, s[k] + after, e[k], take_len[e[k]], int(bad.sum()), e.size))
+
+
 class MLP(nn.Module):
     def __init__(self, input_dim, hidden_dims=(128, 128), activation="tanh"):
         super().__init__()
@@ -250,6 +270,13 @@ class VideoStateNet(nn.Module):
     def attach_feature_table(self, table, take_offset):
         """Device-resident concatenation of all takes' features (+ row offsets) for gather-built contexts."""
         self._cnn_table = (table, torch.as_tensor(np.asarray(take_offset), dtype=torch.long, device=table.device))
+        self._take_len = _take_lengths(take_offset, table.shape[0])
+
+    def check_windows(self, expert_ind, start_ind, length):
+        """Rows [start - m, start + length + m) must lie inside their own take: the table is the concatenation of all
+        takes, so a window that leaves its take would silently read a neighbour's frames (the reference's numpy slice
+        comes up short and raises on assignment, models/video_state_net.py:52-55)."""
+        _check_windows(self._take_len, expert_ind, start_ind, self.v_margin, length + self.v_margin)
 
     def window_features(self, expert_ind, start_ind, length):
         """Gather windows [start-m, start+length+m) of the given takes -> (length+2m, B, D) on device."""
@@ -290,6 +317,7 @@ class VideoStateNet(nn.Module):
             pad = _tuning.pad_to(len(ends), _tuning.EPISODE_BUCKET) if _tuning.enabled() and len(ends) >= 4 * _tuning.EPISODE_BUCKET else 0
             if pad:
                 meta = np.concatenate((meta, np.repeat(meta[:1], pad, axis=0)), 0)
+            self.check_windows(meta[:, 0], meta[:, 1], max_len)
             e_ind = torch.as_tensor(meta[:, 0], device=device)
             s_ind = torch.as_tensor(meta[:, 1], device=device)
             self.cnn_feat_ctx = self.window_features(e_ind, s_ind, max_len).to(dtype)
@@ -442,6 +470,11 @@ class VideoForecastNet(nn.Module):
 
     def attach_feature_table(self, table, take_offset):
         self._cnn_table = (table, torch.as_tensor(np.asarray(take_offset), dtype=torch.long, device=table.device))
+        self._take_len = _take_lengths(take_offset, table.shape[0])
+
+    def check_windows(self, expert_ind, start_ind, length=0):
+        """Rows [start - v_margin, start + length) must lie inside their own take (see VideoStateNet.check_windows)."""
+        _check_windows(self._take_len, expert_ind, start_ind, self.v_margin, length)
 
     def window_features(self, expert_ind, start_ind, length=0):
         """Rows [start - v_margin, start + length) of the given takes -> (v_margin + length, B, D) on device."""
@@ -491,6 +524,7 @@ class VideoForecastNet(nn.Module):
             if pad:
                 meta = np.concatenate((meta, np.repeat(meta[:1], pad, axis=0)), 0)
                 self.num_episode = meta.shape[0]
+            self.check_windows(meta[:, 0], meta[:, 1])
             win = self.window_features(torch.as_tensor(meta[:, 0], device=device), torch.as_tensor(meta[:, 1], device=device)).to(dtype)
             ctx = win.new_zeros(T_ctx, meta.shape[0], self.cnn_feat_dim)
             ctx[:m] = win

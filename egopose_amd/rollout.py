@@ -102,6 +102,12 @@ class LockstepRollout:
         self.ctx_T = 1 if self.forecast else self.T_ep          # context rows per episode kept in v_out
         if getattr(self.cfg, "obs_phase", False) or getattr(self.cfg, "random_cur_t", False):
             raise NotImplementedError("obs_phase / random_cur_t are not implemented in the lockstep rollout")
+        # K3 computes the observation every shipped config asks for (humanoid_v1.py:73-96 with egomimic_config.py:99-103's
+        # defaults); the other branches would change obs_dim / the root frame: refuse them instead of ignoring them
+        want = dict(obs_type="full", obs_coord="heading", obs_heading=False, obs_vel="full", root_deheading=True)
+        odd = {k: getattr(self.cfg, k) for k, v in want.items() if getattr(self.cfg, k, v) != v}
+        if odd:
+            raise NotImplementedError("observation options %r have no HIP kernel (K3 implements %r)" % (odd, want))
         self.gen = torch.Generator(device=self.dev)
         self.gen.manual_seed(int(seed))
         with torch.cuda.device(self.dev):
@@ -135,6 +141,7 @@ class LockstepRollout:
             if self._pool is None or self._pool_pos >= len(self._pool[0]):
                 m = max(need, self.pool_batch)
                 e_ind, s_ind = self.env.sample_reset(m)
+                self.policy_vs_net.check_windows(e_ind, s_ind, 0 if self.forecast else self.T_ep)
                 e_d, s_d = self.up(e_ind), self.up(s_ind)
                 if self.forecast:        # causal net over the v_margin frames before the episode, last output
                     ctx = self.policy_vs_net.context(self.policy_vs_net.window_features(e_d, s_d)).unsqueeze(1)      # (m, 1, H)

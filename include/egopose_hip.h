@@ -94,6 +94,30 @@ int egp_set_pd_variant(egp_ctx *ctx, int variant);
 /* HumanoidEnv.load_experts (ego_pose/envs/humanoid_v1.py:47-54): packs the reward rows into HBM */
 int egp_upload_experts(egp_ctx *ctx, const egp_expert_table *tbl);
 
+
+/* a7 -- quaternion algebra, (w, x, y, z) order, one row per thread. Replaces the per-call numpy functions of
+ * utils/transformation.py:348-356 (rotation_from_quaternion), :1194-1248 (quaternion_from_euler 'sxyz'), :1267-1291
+ * (quaternion_matrix), :1379-1393 (quaternion_multiply), :1410-1421 (quaternion_inverse) and utils/math.py:47-59
+ * (transform_vec), :62-67 (get_heading_q), :80-81 (de_heading), :84-100 (multi_quat_diff / multi_quat_norm).
+ *   op                              a         b         out
+ *   EGP_QUAT_MUL                    q1 [n][4] q0 [n][4] q1*q0 [n][4]
+ *   EGP_QUAT_INV                    q [n][4]  -         conj(q)/(q.q) [n][4]
+ *   EGP_QUAT_FROM_EULER_SXYZ        e [n][3]  -         [n][4]
+ *   EGP_QUAT_HEADING_Q              q [n][4]  -         [n][4]
+ *   EGP_QUAT_DE_HEADING             q [n][4]  -         [n][4]
+ *   EGP_QUAT_TRANSFORM_VEC_ROOT     v [n][3]  q [n][4]  R(q)^T v [n][3]
+ *   EGP_QUAT_TRANSFORM_VEC_HEADING  v [n][3]  q [n][4]  R(heading_q(q))^T v [n][3]
+ *   EGP_QUAT_ROTATION               q [n][4]  -         axis[3] | angle [n][4]   (identity branch 1 - w < 1e-8; no clamp, no wrap)
+ *   EGP_QUAT_DIFF_HALF_ANGLE        q1 [n][4] q0 [n][4] acos(clip(w(q1 * q0^-1))) [n]   (= multi_quat_norm(multi_quat_diff))
+ * The float32 variant evaluates the two angle ops through atan2(|xyz|, w) (deviation iii). */
+enum {
+    EGP_QUAT_MUL = 0, EGP_QUAT_INV = 1, EGP_QUAT_FROM_EULER_SXYZ = 2, EGP_QUAT_HEADING_Q = 3, EGP_QUAT_DE_HEADING = 4,
+    EGP_QUAT_TRANSFORM_VEC_ROOT = 5, EGP_QUAT_TRANSFORM_VEC_HEADING = 6, EGP_QUAT_ROTATION = 7, EGP_QUAT_DIFF_HALF_ANGLE = 8,
+    EGP_QUAT_N_OPS = 9
+};
+int egp_quat_op_f64(int32_t op, const double *a, const double *b, int32_t n, double *out, void *stream);
+int egp_quat_op_f32(int32_t op, const float *a, const float *b, int32_t n, float *out, void *stream);
+
 /* ---------------------------------------------------------------------------------------- K4
  * HumanoidEnv.get_body_quat (ego_pose/envs/humanoid_v1.py:113-125): qpos[n][nq] -> bquat[n][4*nbody] */
 int egp_body_quat_f64(egp_ctx *ctx, const double *qpos, int32_t n, double *bquat, void *stream);

@@ -460,3 +460,35 @@ def test_engine_reports_backend_failure_instead_of_hanging(ctx, skel, mode, monk
     finally:
         eng.close()
         be.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-6)])
+def test_quaternion_algebra_on_device_matches_reference_vectors(dtype, tol):
+    """Row a7 directly: every function of csrc/egp_quat.hpp through `egp_quat_op_*` against the reference's own
+    utils/transformation.py / utils/math.py outputs (tests/golden/quat.npz: 256 random cases + the doctest values)."""
+    from egopose_amd.hip import quat_op
+    g = load_golden("quat.npz")
+    d = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda")
+    chk = lambda got, ref, t=tol: np.testing.assert_allclose(got.double().cpu().numpy(), ref, rtol=t, atol=t)
+    chk(quat_op("mul", d(g["q1"]), d(g["q0"])), g["mul"], tol * 10)
+    chk(quat_op("mul", d([[4.0, 1, -2, 3]]), d([[8.0, -5, 6, 7]])), g["kat_mul"][None], tol * 100)   # transformation.py doctest
+    chk(quat_op("inv", d(g["q0"])), g["inv"], tol * 10)
+    chk(quat_op("from_euler_sxyz", d(g["eul"])), g["from_euler"])
+    qn = g["qn"]
+    chk(quat_op("heading_q", d(qn[4:])), g["heading_q"])
+    chk(quat_op("de_heading", d(qn[4:])), g["de_heading"])
+    chk(quat_op("transform_vec_root", d(g["v3"]), d(qn)), g["tv_root"], tol * 10)
+    chk(quat_op("transform_vec_heading", d(g["v3"][4:]), d(qn[4:])), g["tv_heading"], tol * 10)
+    rot = quat_op("rotation", d(qn)).double().cpu().numpy()
+    assert (rot[:2, 3] == 0.0).all() and (rot[:2, :3] == [1.0, 0.0, 0.0]).all()          # the 1 - w < 1e-8 branch
+    if dtype == torch.float64:
+        np.testing.assert_allclose(rot[:, :3], g["rot_axis"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(rot[:, 3], g["rot_angle"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(rot[:, :3] * rot[:, 3:], g["rot_vec"], rtol=1e-9, atol=1e-9)
+    else:       # float32 evaluates the angle through atan2(|xyz|, w) (documented deviation): compare the rotation vector
+        np.testing.assert_allclose(rot[:, :3] * rot[:, 3:], g["rot_vec"], rtol=1e-5, atol=1e-5)
+    half = quat_op("diff_half_angle", d(g["q1"]), d(qn))
+    chk(half, g["multi_norm"], 1e-9 if dtype == torch.float64 else 1e-5)
+    with pytest.raises(RuntimeError):
+        from egopose_amd import _lib as L
+        L.check(L.load().egp_quat_op_f64(99, None, None, 1, None, None), "egp_quat_op")

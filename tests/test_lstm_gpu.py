@@ -270,3 +270,42 @@ def test_grouped_forecast_contexts_match_per_net_contexts(dynamic_v):
         torch.testing.assert_close(oa, ob, rtol=1e-5, atol=1e-5)
         for k in gb:
             torch.testing.assert_close(ga[k], gb[k], rtol=1e-4, atol=1e-4 * float(gb[k].abs().max()) + 1e-6, msg=lambda m, k=k: k + ": " + m)
+
+
+def test_no_grad_passes_take_the_inference_kernels(monkeypatch):
+    """torch.no_grad() passes (rollout context pool, values / fixed log-probs) must not save gates and cells: the kernel
+    gets NULL save pointers even though the weights require grad (ctx.needs_input_grad ignores the grad mode)."""
+    from egopose_amd import lstm
+
+    class Spy:
+        def __init__(self, lib):
+            self._lib, self.saves = lib, []
+
+        def __getattr__(self, name):
+            fn = getattr(self._lib, name)
+            if name not in ("egp_lstm_fwd_f32", "egp_lstm_group_fwd_f32"):
+                return fn
+            k = 7 if name == "egp_lstm_fwd_f32" else 9            # gates_out, cells_out follow (include/egopose_hip.h)
+
+            def wrapped(*a):
+                self.saves.append((name, a[k].value, a[k + 1].value))
+                return fn(*a)
+            return wrapped
+
+    spy = Spy(lstm.L.load())
+    monkeypatch.setattr(lstm.L, "load", lambda: spy)
+    torch.manual_seed(0)
+    cells = [torch.nn.LSTMCell(16, 64).cuda() for _ in range(2)]
+    x = torch.randn(9, 5, 16, device="cuda")
+    with torch.no_grad():
+        a = lstm.lstm_direction(cells[0], x, False)
+        b = lstm.lstm_group(x, cells, [False, True], pairs=True)[0]
+    assert [s[1:] for s in spy.saves] == [(None, None), (None, None)] and not a.requires_grad and not b.requires_grad
+    spy.saves.clear()
+    a2 = lstm.lstm_direction(cells[0], x, False)
+    b2 = lstm.lstm_group(x, cells, [False, True], pairs=True)[0]
+    assert all(s[1] is not None and s[2] is not None for s in spy.saves) and a2.requires_grad and b2.requires_grad
+    torch.testing.assert_close(a2.detach(), a)
+    torch.testing.assert_close(b2.detach(), b)
+    (a2.sum() + b2.sum()).backward()
+    assert all(c.weight_hh.grad is not None for c in cells)

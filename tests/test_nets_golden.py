@@ -164,3 +164,31 @@ def test_length_bucketed_forward_lstm_is_exact(monkeypatch):
     np.testing.assert_allclose(outs[1], outs[0], rtol=1e-12, atol=1e-13)
     for n in grads[0]:
         np.testing.assert_allclose(grads[1][n], grads[0][n], rtol=1e-10, atol=1e-12, err_msg=n)
+
+
+def test_windows_that_leave_their_take_are_refused():
+    """The device feature table concatenates all takes: a window must not spill into its neighbour (the reference's
+    per-take numpy slice comes up short and raises, models/video_state_net.py:52-55)."""
+    import pytest
+    from egopose_amd.nets import VideoForecastNet, VideoStateNet
+    table = torch.zeros(50 + 40, 8)
+    net = VideoStateNet(8, 16, 5, "lstm", None, False)
+    net.attach_feature_table(table, [0, 50])
+    net.check_windows(np.array([0, 1, 1]), np.array([5, 5, 40 - 20 - 5]), 20)           # exactly fits
+    with pytest.raises(ValueError, match="leaves take 0"):
+        net.check_windows(np.array([0]), np.array([4]), 20)                             # start - margin < 0 (wraps to the table end)
+    with pytest.raises(ValueError, match="leaves take 1"):
+        net.check_windows(np.array([0, 1]), np.array([10, 16]), 20)                     # runs past the end of take 1
+    with pytest.raises(ValueError, match="leaves take 0"):
+        net.check_windows(np.array([0]), np.array([26]), 20)                            # would read take 1's first frame
+    with pytest.raises(ValueError, match="take index"):
+        net.check_windows(np.array([2]), np.array([10]), 20)
+    net.set_mode("train")
+    masks = torch.tensor([1.0, 1.0, 0.0])
+    with pytest.raises(ValueError, match="leaves take"):
+        net.initialize((masks, None, np.array([[0, 47]] * 3)))
+    fnet = VideoForecastNet(8, 4, 16, 5)
+    fnet.attach_feature_table(table, [0, 50])
+    fnet.check_windows(np.array([1]), np.array([5]))
+    with pytest.raises(ValueError, match="leaves take 1"):
+        fnet.check_windows(np.array([1]), np.array([3]))

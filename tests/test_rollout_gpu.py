@@ -106,7 +106,9 @@ def test_full_iteration_updates_parameters_and_filter(workspace):
     # checkpoint round trip in the reference's container (ego_mimic.py:133-139)
     path = os.path.join(workspace, "cp.p")
     tr.save(path)
-    cp = pickle.load(open(path, "rb"))
+    from egopose_amd.zfilter import reference_pickle_names
+    with reference_pickle_names():           # running_state is pickled under the reference's module path (utils.zfilter)
+        cp = pickle.load(open(path, "rb"))
     assert set(cp) == {"policy_dict", "policy_vs_dict", "value_dict", "value_vs_dict", "running_state"}
     assert "v_net.rnn_f.weight_ih" in cp["policy_vs_dict"] and "action_log_std" in cp["policy_dict"]
     tr.load(path)
@@ -312,7 +314,9 @@ def test_forecast_full_iteration(workspace):
     assert all(np.isfinite(tr.agent.update_stats["value_loss"]))
     path = os.path.join(workspace, "cp_forecast.p")
     tr.save(path)
-    cp = pickle.load(open(path, "rb"))
+    from egopose_amd.zfilter import reference_pickle_names
+    with reference_pickle_names():
+        cp = pickle.load(open(path, "rb"))
     assert "s_net.rnn_f.weight_ih" in cp["policy_vs_dict"] and "v_net.rnn_f.weight_hh" in cp["value_vs_dict"]
     # warm start from an ego_mimic-shaped checkpoint drops the first affine layer (input width differs)
     mim, mcfg = _trainer(workspace, 8, 10, num_threads=2, num_groups=1)
@@ -497,4 +501,15 @@ def test_cross_01_config_short_rollout(tmp_path_factory, skel):
     _replay_episodes(tr, cfg, skel, batch, range(0, 12), 0.4)
     log, t_s, t_u, n = tr.iteration(0, 96 * 24)
     assert n >= 96 * 24 and np.isfinite(log.avg_c_reward) and all(np.isfinite(tr.agent.update_stats["value_loss"]))
+    tr.close()
+
+
+@pytest.mark.parametrize("option", [("obs_heading", True), ("obs_vel", "root"), ("root_deheading", False), ("obs_coord", "root")])
+def test_non_default_observation_options_are_refused(workspace, option):
+    """K3 implements the observation of every shipped config (humanoid_v1.py:73-96 with the defaults of
+    egomimic_config.py:99-103); any other variant must be refused, not silently computed as the default."""
+    tr, cfg = _trainer(workspace, 8, 10, num_threads=2, num_groups=1)
+    setattr(cfg, *option)
+    with pytest.raises(NotImplementedError, match=option[0]):
+        tr.agent.sample(80)
     tr.close()
