@@ -62,6 +62,17 @@ class MlpLayer(C.Structure):
     _fields_ = [("wt", vp), ("bias", vp), ("in_dim", C.c_int32), ("out_dim", C.c_int32)]
 
 
+class GemmDesc(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("A", vp), ("lda", C.c_int64), ("a_kcontig", C.c_int32),
+                ("B", vp), ("ldb", C.c_int64), ("b_kcontig", C.c_int32),
+                ("C", vp), ("ldc", C.c_int64),
+                ("bias", vp), ("relu", C.c_int32),
+                ("mask", vp), ("ldmask", C.c_int64),
+                ("terms", C.c_int32), ("splits", C.c_int32), ("accumulate", C.c_int32),
+                ("bias_grad", vp), ("workspace", vp)]
+
+
 class EngineDesc(C.Structure):
     _fields_ = [("n_env", C.c_int32), ("n_threads", C.c_int32), ("n_groups", C.c_int32), ("device_dynamics", C.c_int32)]
 
@@ -111,6 +122,8 @@ SIGNATURES = {
     "egp_gae_standardize_f64": (C.c_int, [vp, _i32, vp, vp]),
     "egp_gae_standardize_f32": (C.c_int, [vp, _i32, vp, vp]),
     "egp_lstm_gate_layout": (_i32, []),
+    "egp_gemm_workspace_floats": (_i64, [_i32, _i32, _i32, _i32]),
+    "egp_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "egp_lstm_fwd_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp]),
     "egp_lstm_bwd_f32": (C.c_int, [vp, vp, vp, vp, _i32, _i32, _i32, _i32, vp, vp]),
     "egp_lstm_group_fwd_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_void_p), _i32, vp, vp, vp]),

@@ -389,6 +389,11 @@ class AgentEgo(AgentPPO):
         if getattr(self.cn, "policy_vs_net", None) is not None:
             self.sample_modules = [self.cn.policy_net, self.cn.policy_vs_net]
             self.update_modules = [self.cn.policy_net, self.cn.value_net, self.cn.policy_vs_net, self.cn.value_vs_net]
+            from .nets import VideoStateNet
+            for head, vs in ((self.cn.policy_net, self.cn.policy_vs_net), (self.cn.value_net, self.cn.value_vs_net)):
+                # VideoStateNet output = [video context | raw state]: the state columns need no gradient (gemm.MlpHead)
+                if isinstance(vs, VideoStateNet):
+                    head.input_grad_cols = vs.v_hdim
 
     def _video_net(self):
         return self.cn.policy_vs_net

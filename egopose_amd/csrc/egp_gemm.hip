@@ -1,0 +1,420 @@
+// egp_gemm.hip -- float32 GEMMs of the PPO update on the bf16 matrix cores (gfx950), float32-class accuracy.
+//
+// The update's products (core/policy_gaussian.py:19-24 + models/mlp.py:22-25 evaluated for the whole batch, the LSTM
+// input projection of models/rnn.py:45-61, and their gradients) are "one huge, two small" shapes: 134 k x 243 x 300,
+// 150 k x 128 x 1024, ... In float32 they run at the float32 MFMA rate, 1/16 of the bf16 rate, and gfx950 has no
+// xf32 / TF32 mode. Here every float32 operand is split on its way into LDS into a bf16 head and a bf16 tail
+// (x = hi + lo + O(2^-17 |x|)) and a product is three MFMAs, hi*hi + hi*lo + lo*hi, accumulated in float32: about 16
+// mantissa bits per product (the dropped lo*lo term is 2^-18), i.e. float32-class results at a third of the bf16 rate,
+// five times the float32 rate. `terms = 1` keeps only hi*hi (plain bf16 inputs).
+//
+//   C[M][N] = A[M][K] * B[K][N]      A given as [m][k] (k contiguous) or [k][m] (m contiguous),
+//                                    B given as [n][k] (k contiguous) or [k][n] (n contiguous)
+//   epilogue: + bias[n], ReLU, * (mask[m][n] > 0)       (bias + activation forward, dReLU in a data gradient)
+//   split-K:  partial sums go to a workspace, a second launch reduces them in a fixed order (deterministic); used by
+//             the weight gradients (K = batch rows). A virtual column of ones appended to B yields the bias gradient
+//             (column sums of A^T) from the same launch.
+//
+// Tiling: 256 threads = 4 waves, tile 128 x BN x 32 (BN = 128: waves 2 x 2, each 64 x 64 = 2 x 2 MFMA blocks of
+// v_mfma_f32_32x32x16_bf16; BN = 64: waves 4 x 1, each 32 x 64). Operand tiles live in LDS as four k-panels [row][8 bf16]
+// (fragment reads and staging stores are contiguous 16-byte accesses, no padding). Global -> register -> LDS staging; for
+// operands whose memory is not k-contiguous the transpose is in the register naming (a wave reads 64 consecutive rows of
+// one k-row per load). The loads of tile s+2 are issued before tile s is multiplied; one barrier per k-tile.
+#include "egp_internal.hpp"
+
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));       // 16-byte load, 4-byte aligned
+
+inline int after_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        egp::set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return EGP_E_HIP;
+    }
+    return EGP_OK;
+}
+
+constexpr int BM = 128, BK = 32;
+
+struct GemmArgs {
+    int M, N, K;                              // N counts the real columns of B (the virtual ones column is extra)
+    const float *A; long lda; int a_kc;       // a_kc: A[m * lda + k], else A[k * lda + m]
+    const float *B; long ldb; int b_kc;       // b_kc: B[n * ldb + k], else B[k * ldb + n]
+    float *C; long ldc;
+    const float *bias; int relu;
+    const float *mask; long ldmask;
+    int ones_col;                             // B has a virtual column N of ones (its result: column N of the workspace)
+    int k_per_split;                          // multiple of BK; gridDim.z splits
+    float *ws;                                // [splits][M][N + ones_col] when gridDim.z > 1 or ones_col
+    int tiles_m, tiles_n, xcd_order;
+};
+
+// LDS image of an operand tile (R rows x 32 k, bf16): four k-panels of [R][8], element (row, k) at ((k >> 3) * R + row) * 8
+// + (k & 7). An MFMA fragment read (32 consecutive rows x 8 k per half-wave) is 512 contiguous bytes and every staging
+// store is one 16-byte write of 8 consecutive k: no bank conflicts beyond the 4 passes a 1 KiB wave access needs anyway.
+//
+// Staging registers: v[8 u + j] = element (row_u, k0 + 8 * panel + j), u < R / 64 -- the same shape for both memory forms.
+// All loads are branch-free (the compiler keeps them in flight across the multiply with counted waits): row indices past
+// the operand are clamped -- such rows only feed output rows / columns that are never stored. The one k-tile that may
+// reach past the end of the k range is handled after the pipelined loop (`ktail`: element-wise loads, zero select).
+// k-contiguous memory (P[row * ld + k]): thread t -> panel t & 3, rows (t >> 2) + 64 u: two 16-byte loads per unit.
+template <int R, bool ktail>
+__device__ __forceinline__ void load_kc(const float *__restrict__ P, long ld, int rows, int r0, int k0, int kend, float (&v)[R / 8]) {
+    const int t = threadIdx.x, k = k0 + (t & 3) * 8, rb = t >> 2;
+#pragma unroll
+    for (int u = 0; u < R / 64; ++u) {
+        const int row = min(r0 + rb + 64 * u, rows - 1);
+        const float *src = P + (long)row * ld;
+        if constexpr (!ktail) {
+            const f32x4u x = *(const f32x4u *)(src + k), y = *(const f32x4u *)(src + k + 4);
+            v[8 * u] = x[0]; v[8 * u + 1] = x[1]; v[8 * u + 2] = x[2]; v[8 * u + 3] = x[3];
+            v[8 * u + 4] = y[0]; v[8 * u + 5] = y[1]; v[8 * u + 6] = y[2]; v[8 * u + 7] = y[3];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = src[min(k + j, kend - 1)];
+                v[8 * u + j] = k + j < kend ? x : 0.f;
+            }
+        }
+    }
+}
+
+// row-contiguous memory (P[k * ld + row]): lane l -> rows l + 64 u, wave w -> panel w (k0 + 8 w + j): every load instruction
+// reads 64 consecutive floats of one k-row; the transpose happens in the register naming.
+// `ones_row` >= 0: a virtual row of ones at that index (the bias-gradient column of a weight gradient).
+template <int R, bool ktail>
+__device__ __forceinline__ void load_rc(const float *__restrict__ P, long ld, int rows, int r0, int k0, int kend, int ones_row,
+                                        float (&v)[R / 8]) {
+    const int t = threadIdx.x, l = t & 63, kb = k0 + (t >> 6) * 8;
+#pragma unroll
+    for (int u = 0; u < R / 64; ++u) {
+        const int row = r0 + l + 64 * u;
+        const bool one = row == ones_row;
+        const float *src = P + min(row, rows - 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kb + j;
+            float x = src[(long)(ktail ? min(k, kend - 1) : k) * ld];
+            x = one ? 1.f : x;
+            v[8 * u + j] = (!ktail || k < kend) ? x : 0.f;
+        }
+    }
+}
+
+// registers -> LDS (hi and lo images): 8 consecutive k of one row = one 16-byte store each
+template <int R, bool LO>
+__device__ __forceinline__ void store_tile(const float (&v)[R / 8], __bf16 *hi, __bf16 *lo, int panel, int rb) {
+#pragma unroll
+    for (int u = 0; u < R / 64; ++u) {
+        bf16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = v[8 * u + j];
+            h[j] = (__bf16)x;                                  // v_cvt_pk_bf16_f32 (round to nearest even)
+            l[j] = (__bf16)(x - (float)h[j]);
+        }
+        const int off = (panel * R + rb + 64 * u) * 8;
+        *(bf16x8 *)(hi + off) = h;
+        if (LO) *(bf16x8 *)(lo + off) = l;
+    }
+}
+
+// Tile order. Workgroups are dealt round-robin to the 8 XCDs by their linear id. With many m-tiles (activations x
+// weights) the n-tiles of one m-tile read the same rows of A: they go to the same XCD (one L2) back to back. With few
+// tiles (weight gradients: the parallelism is in the k splits) the plain order spreads them over all XCDs.
+__device__ __forceinline__ bool tile_of(const GemmArgs &g, int L, int &tm, int &tn) {
+    if (g.xcd_order) {
+        const int xcd = L & 7, q = L >> 3;
+        tm = (q / g.tiles_n) * 8 + xcd;
+        tn = q % g.tiles_n;
+    } else {
+        tm = L / g.tiles_n;
+        tn = L % g.tiles_n;
+    }
+    return tm < g.tiles_m;
+}
+
+template <int BN, int TERMS, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void k_gemm_bf16x(GemmArgs g) {
+    constexpr bool LO = TERMS > 1;
+    constexpr int WN = BN == 128 ? 2 : 1;                 // waves along n
+    constexpr int MI = BN == 128 ? 2 : 1, NJ = 2;         // MFMA blocks per wave: rows x cols
+    constexpr int WROWS = 32 * MI;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // per buffer: A hi | A lo | B hi | B lo
+    constexpr int A_EL = BM * BK, B_EL = BN * BK;
+    constexpr int BUF_EL = (LO ? 2 : 1) * (A_EL + B_EL);
+    __bf16 *base = (__bf16 *)smem;
+
+    int tm, tn;
+    if (!tile_of(g, blockIdx.x, tm, tn)) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nst = (kend - kbeg + BK - 1) / BK;
+    const int ones_row = g.ones_col ? g.N : -1;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    // where this thread's staging registers go in the LDS image
+    const int a_panel = A_KC ? (t & 3) : wave, a_rb = A_KC ? (t >> 2) : lane;
+    const int b_panel = B_KC ? (t & 3) : wave, b_rb = B_KC ? (t >> 2) : lane;
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // two register sets: the loads of tile s + 2 are issued before tile s is multiplied, so a load has two full
+    // iterations to land (the k loops are short and only two workgroups share a CU: latency has to be hidden here).
+    // The steady-state loop has no conditional load, so every wait in it is a counted vmcnt.
+    float va0[BM / 8], vb0[BN / 8], va1[BM / 8], vb1[BN / 8];
+    auto gload = [&](int s, float (&va)[BM / 8], float (&vb)[BN / 8], auto ktail) {
+        constexpr bool KT = decltype(ktail)::value;
+        const int k0 = kbeg + s * BK;
+        if constexpr (A_KC) load_kc<BM, KT>(g.A, g.lda, g.M, m0, k0, kend, va);
+        else load_rc<BM, KT>(g.A, g.lda, g.M, m0, k0, kend, -1, va);
+        if constexpr (B_KC) load_kc<BN, KT>(g.B, g.ldb, g.N, n0, k0, kend, vb);
+        else load_rc<BN, KT>(g.B, g.ldb, g.N, n0, k0, kend, ones_row, vb);
+    };
+    constexpr std::false_type FULL{};
+    constexpr std::true_type TAIL{};
+    auto sstore = [&](int buf, const float (&va)[BM / 8], const float (&vb)[BN / 8]) {
+        __bf16 *p = base + buf * BUF_EL;
+        __bf16 *ah = p, *al = p + A_EL, *bh = p + (LO ? 2 : 1) * A_EL, *bl = bh + B_EL;
+        store_tile<BM, LO>(va, ah, al, a_panel, a_rb);
+        store_tile<BN, LO>(vb, bh, bl, b_panel, b_rb);
+    };
+    const int frow = lane & 31, fkh = lane >> 5;
+    auto compute = [&](int buf) {
+        const __bf16 *p = base + buf * BUF_EL;
+        const __bf16 *ah = p, *al = p + A_EL, *bh = p + (LO ? 2 : 1) * A_EL, *bl = bh + B_EL;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 fa_h[MI], fa_l[MI], fb_h[NJ], fb_l[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int off = ((2 * ks + fkh) * BM + wm * WROWS + 32 * i + frow) * 8;
+                fa_h[i] = *(const bf16x8 *)(ah + off);
+                if (LO) fa_l[i] = *(const bf16x8 *)(al + off);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int off = ((2 * ks + fkh) * BN + wn * 64 + 32 * j + frow) * 8;
+                fb_h[j] = *(const bf16x8 *)(bh + off);
+                if (LO) fb_l[j] = *(const bf16x8 *)(bl + off);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if (LO) {                             // small terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_l[i], fb_h[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_h[i], fb_l[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_h[i], fb_h[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    const int nfull = (kend - kbeg) / BK;
+    const bool has_tail = (kend - kbeg) % BK != 0;
+    int last = 1;                                         // LDS buffer multiplied last (1: none yet, the tail takes buffer 0)
+    if (nfull == 1) {
+        gload(0, va0, vb0, FULL);
+        sstore(0, va0, vb0);
+        __syncthreads();
+        compute(0);
+        last = 0;
+    } else if (nfull >= 2) {
+        gload(0, va0, vb0, FULL);
+        gload(1, va1, vb1, FULL);
+        sstore(0, va0, vb0);
+        __syncthreads();
+        int s = 0;
+        while (s + 3 < nfull) {                           // buffer 0 holds tile s, set 1 holds tile s + 1 (in flight)
+            // (sched_barrier: the compiler must not hoist the conversions of the in-flight set -- and with them the
+            //  wait for its loads -- above the multiply that is there to cover their latency)
+            gload(s + 2, va0, vb0, FULL);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(0);
+            __builtin_amdgcn_sched_barrier(0);
+            sstore(1, va1, vb1);
+            __syncthreads();
+            gload(s + 3, va1, vb1, FULL);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(1);
+            __builtin_amdgcn_sched_barrier(0);
+            sstore(0, va0, vb0);
+            __syncthreads();
+            s += 2;
+        }
+        const bool three = nfull - s == 3;                // two or three tiles left
+        if (three) gload(s + 2, va0, vb0, FULL);
+        compute(0);
+        sstore(1, va1, vb1);
+        __syncthreads();
+        compute(1);
+        last = 1;
+        if (three) {
+            sstore(0, va0, vb0);
+            __syncthreads();
+            compute(0);
+            last = 0;
+        }
+    }
+    if (has_tail) {                                       // buffer last ^ 1 was read before the previous barrier
+        gload(nfull, va0, vb0, TAIL);
+        sstore(last ^ 1, va0, vb0);
+        __syncthreads();
+        compute(last ^ 1);
+    }
+
+    // ---- epilogue. acc[i][j][r]: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31 of the 32 x 32 block.
+    // Branch-free per element: mask values of a block are fetched together (clamped addresses), stores of interior tiles
+    // carry no predicate.
+    const bool partial = gridDim.z > 1 || g.ones_col;
+    const int n_out = g.N + (g.ones_col ? 1 : 0);
+    const bool interior = m0 + BM <= g.M && n0 + BN <= n_out;
+    const float floor_v = g.relu ? 0.f : -__builtin_inff();
+    float *dst = partial ? g.ws + (long)blockIdx.z * g.M * n_out : g.C;
+    const long ldd = partial ? n_out : g.ldc;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = n0 + wn * 64 + 32 * j + (lane & 31);
+            const int rbase = m0 + wm * WROWS + 32 * i + 4 * (lane >> 5);
+            const int colc = min(col, n_out - 1);
+            const float bv = (!partial && g.bias) ? g.bias[min(colc, g.N - 1)] : 0.f;
+            float keep[16];
+            if (!partial && g.mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1);
+                    keep[r] = g.mask[(long)row * g.ldmask + min(colc, g.N - 1)];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep[r] = 1.f;
+            }
+            if (interior) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    float x = partial ? acc[i][j][r] : fmaxf(acc[i][j][r] + bv, floor_v);
+                    x = keep[r] > 0.f ? x : 0.f;
+                    dst[(long)row * ldd + col] = x;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    float x = partial ? acc[i][j][r] : fmaxf(acc[i][j][r] + bv, floor_v);
+                    x = keep[r] > 0.f ? x : 0.f;
+                    if (row < g.M && col < n_out) dst[(long)row * ldd + col] = x;
+                }
+            }
+        }
+}
+
+// partial sums -> C (+ the ones column -> bias_grad), splits added in index order
+__global__ __launch_bounds__(256) void k_gemm_reduce(const float *__restrict__ ws, int splits, int M, int N, int n_out, float *__restrict__ C,
+                                                     long ldc, float *__restrict__ bias_grad, int accumulate) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)M * n_out) return;
+    const int row = (int)(idx / n_out), col = (int)(idx % n_out);
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[(long)k * M * n_out + idx];
+    if (col < N) {
+        float *dst = C + (long)row * ldc + col;
+        *dst = accumulate ? *dst + s : s;
+    } else if (bias_grad) {
+        bias_grad[row] = accumulate ? bias_grad[row] + s : s;
+    }
+}
+
+template <int BN, int TERMS>
+int launch_variant(const GemmArgs &g, dim3 grid, size_t lds, hipStream_t s) {
+#define EGP_GEMM_LAUNCH(AK, BKC)                                                                                      \
+    do {                                                                                                              \
+        auto kern = k_gemm_bf16x<BN, TERMS, AK, BKC>;                                                                 \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) {                                                                                              \
+            EGP_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        kern<<<grid, dim3(256), lds, s>>>(g);                                                                         \
+    } while (0)
+    if (g.a_kc && g.b_kc) EGP_GEMM_LAUNCH(true, true);
+    else if (g.a_kc && !g.b_kc) EGP_GEMM_LAUNCH(true, false);
+    else if (!g.a_kc && g.b_kc) EGP_GEMM_LAUNCH(false, true);
+    else EGP_GEMM_LAUNCH(false, false);
+#undef EGP_GEMM_LAUNCH
+    return after_launch("k_gemm_bf16x");
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t egp_gemm_workspace_floats(int32_t M, int32_t N, int32_t ones_col, int32_t splits) {
+    if (splits <= 1 && !ones_col) return 0;
+    return (int64_t)(splits < 1 ? 1 : splits) * M * (N + (ones_col ? 1 : 0));
+}
+
+int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
+    EGP_REQUIRE(d, "descriptor is NULL");
+    EGP_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "negative size");
+    EGP_REQUIRE(d->terms == 1 || d->terms == 3, "terms must be 1 (bf16) or 3 (split float32)");
+    if (d->M == 0 || d->N + (d->bias_grad ? 1 : 0) == 0) return EGP_OK;
+    EGP_REQUIRE(d->A && d->B && d->C, "NULL operand");
+    const int ones = d->bias_grad ? 1 : 0;
+    const int splits = d->splits < 1 ? 1 : d->splits;
+    const bool partial = splits > 1 || ones;
+    EGP_REQUIRE(!partial || d->workspace, "split-K / bias-gradient launches need a workspace (egp_gemm_workspace_floats)");
+    EGP_REQUIRE(!partial || (!d->bias && !d->relu && !d->mask), "no epilogue on split-K launches");
+    EGP_REQUIRE(!ones || !d->b_kcontig, "the ones column (bias gradient) goes with B given as [k][n]");
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs g;
+    g.M = d->M; g.N = d->N; g.K = d->K;
+    g.A = d->A; g.lda = d->lda; g.a_kc = d->a_kcontig;
+    g.B = d->B; g.ldb = d->ldb; g.b_kc = d->b_kcontig;
+    g.C = d->C; g.ldc = d->ldc;
+    g.bias = d->bias; g.relu = d->relu; g.mask = d->mask; g.ldmask = d->ldmask;
+    g.ones_col = ones; g.ws = d->workspace;
+    const int n_out = d->N + ones;
+    const bool bn64 = n_out <= 64;                 // narrow outputs: 64-column tiles
+    const int BNv = bn64 ? 64 : 128;
+    g.tiles_m = (d->M + BM - 1) / BM;
+    g.tiles_n = (n_out + BNv - 1) / BNv;
+    const int kt = (d->K + BK - 1) / BK;
+    const int per = (kt + splits - 1) / splits;
+    g.k_per_split = (per < 1 ? 1 : per) * BK;
+    const int zs = d->K == 0 ? 1 : (d->K + g.k_per_split - 1) / g.k_per_split;
+    g.xcd_order = g.tiles_m >= 64;
+    dim3 grid((g.xcd_order ? ((g.tiles_m + 7) / 8) * 8 : g.tiles_m) * g.tiles_n, 1, zs);
+    const int lo = d->terms == 3 ? 2 : 1;
+    const size_t lds = (size_t)2 * lo * (BM + BNv) * BK * sizeof(__bf16);
+    int rc;
+    if (bn64) rc = d->terms == 3 ? launch_variant<64, 3>(g, grid, lds, s) : launch_variant<64, 1>(g, grid, lds, s);
+    else rc = d->terms == 3 ? launch_variant<128, 3>(g, grid, lds, s) : launch_variant<128, 1>(g, grid, lds, s);
+    if (rc != EGP_OK) return rc;
+    if (partial) {
+        const long total = (long)d->M * n_out;
+        k_gemm_reduce<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(d->workspace, zs, d->M, d->N, n_out, d->C, d->ldc,
+                                                                                d->bias_grad, d->accumulate);
+        return after_launch("k_gemm_reduce");
+    }
+    return EGP_OK;
+}
+
+}  // extern "C"

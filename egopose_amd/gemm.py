@@ -1,0 +1,167 @@
+"""float32 matrix products of the PPO update through `egp_gemm_f32` (csrc/egp_gemm.hip): bf16 matrix cores with split
+operands (three MFMAs per product, float32-class accuracy at ~5x the float32 MFMA rate), bias / ReLU / dReLU fused into
+the epilogues, deterministic split-K weight gradients that also return the bias gradient.
+
+  linear_fwd(x, W, b, relu)          y = x W^T + b        (nn.Linear of models/mlp.py:22-25, core/policy_gaussian.py:19-24)
+  linear_dgrad(dy, W, mask)          dx = (dy W) * (mask > 0)
+  linear_wgrad(dy, x)                dW = dy^T x, db = sum_rows dy
+  mlp_head(x, hidden_layers, head)   the reference's `head(MLP(x))` as ONE autograd node: activations saved once, every
+                                     ReLU derivative applied inside the producing data-gradient product
+
+`EGP_GEMM=torch` keeps every product on the library path (rocBLAS / hipBLASLt through torch); `EGP_GEMM_TERMS=1` runs
+plain bf16 inputs (one MFMA per product, ~3e-3 relative error) instead of the default 3.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib as L
+
+_WS = {}
+
+
+def enabled():
+    return os.environ.get("EGP_GEMM", "hip") != "torch"
+
+
+def default_terms():
+    return 1 if os.environ.get("EGP_GEMM_TERMS", "3") == "1" else 3
+
+
+def _workspace(n_floats, device):
+    key = str(device)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < n_floats:
+        buf = torch.empty(max(int(n_floats), 1 << 20), dtype=torch.float32, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _mat(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2):
+        raise ValueError("%s must be a 2-D float32 HIP tensor, got %s %s" % (name, tuple(t.shape), t.dtype))
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise ValueError("%s must have unit stride along its second dimension (strides %s)" % (name, t.stride()))
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def pick_splits(M, n_out, K):
+    """Split-K factor of a weight-gradient shaped product: enough workgroups for two per CU, at least 8 k-tiles each."""
+    tiles = ((M + 127) // 128) * ((n_out + 127) // 128)
+    return max(1, min((512 + tiles - 1) // tiles, K // 256))
+
+
+def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, relu=False, mask=None, terms=None, splits=1, want_bias_grad=False,
+         out=None, bias_grad_out=None, accumulate=False):
+    """C = A B with the operand forms of include/egopose_hip.h (`egp_gemm_desc`). A: (M, K) if a_kcontig else (K, M);
+    B: (N, K) if b_kcontig else (K, N). Returns C, or (C, bias_grad) with want_bias_grad."""
+    A, B = _mat(A, "A"), _mat(B, "B")
+    M, K = (A.shape if a_kcontig else A.shape[::-1])
+    N, Kb = (B.shape if b_kcontig else B.shape[::-1])
+    if K != Kb:
+        raise ValueError("inner dimensions differ: %d vs %d" % (K, Kb))
+    dev = A.device
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=dev)
+    _mat(out, "out")
+    d = L.GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.A, d.lda, d.a_kcontig = A.data_ptr(), _ld(A), 1 if a_kcontig else 0
+    d.B, d.ldb, d.b_kcontig = B.data_ptr(), _ld(B), 1 if b_kcontig else 0
+    d.C, d.ldc = out.data_ptr(), _ld(out)
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.relu = 1 if relu else 0
+    if mask is not None:
+        _mat(mask, "mask")
+        d.mask, d.ldmask = mask.data_ptr(), _ld(mask)
+    d.terms = int(terms or default_terms())
+    d.splits = int(splits)
+    d.accumulate = 1 if accumulate else 0
+    bg = None
+    if want_bias_grad:
+        bg = bias_grad_out if bias_grad_out is not None else torch.empty(M, dtype=torch.float32, device=dev)
+        d.bias_grad = bg.data_ptr()
+    if splits > 1 or want_bias_grad:
+        ws = _workspace(L.load().egp_gemm_workspace_floats(M, N, 1 if want_bias_grad else 0, int(splits)), dev)
+        d.workspace = ws.data_ptr()
+    L.check(L.load().egp_gemm_f32(C.byref(d), L.current_stream()), "egp_gemm_f32")
+    return (out, bg) if want_bias_grad else out
+
+
+def linear_fwd(x, W, b=None, relu=False, terms=None):
+    return gemm(x, W, True, True, bias=b, relu=relu, terms=terms)
+
+
+def linear_dgrad(dy, W, mask=None, n_cols=None, terms=None):
+    """dx[:, :n_cols] = (dy W[:, :n_cols]) * (mask > 0)."""
+    Wv = W if n_cols is None else W[:, :n_cols]
+    return gemm(dy, Wv, True, False, mask=mask, terms=terms)
+
+
+def linear_wgrad(dy, x, want_bias=True, terms=None):
+    """dW (out, in) = dy^T x [and db (out,) = column sums of dy], split-K over the batch rows.
+    Returns (dW, db) with want_bias, else dW."""
+    K, M = dy.shape
+    n_out = x.shape[1] + (1 if want_bias else 0)
+    return gemm(dy, x, False, False, terms=terms, splits=pick_splits(M, n_out, K), want_bias_grad=want_bias)
+
+
+class MlpHead(torch.autograd.Function):
+    """out = head(relu-MLP(x)): apply(x, n_grad_cols, W1, b1, ..., Wh, bh). Gradient w.r.t. x only for its first
+    n_grad_cols columns (the video context; the state columns of the reference's concatenated input need none),
+    zeros elsewhere."""
+
+    @staticmethod
+    def forward(ctx, x, n_grad_cols, *params):
+        Ws, bs = params[0::2], params[1::2]
+        hs = [x.contiguous()]
+        for i, (W, b) in enumerate(zip(Ws, bs)):
+            hs.append(linear_fwd(hs[-1], W.contiguous(), b, relu=i < len(Ws) - 1))
+        ctx.save_for_backward(*hs[:-1], *Ws)
+        ctx.n_layers, ctx.n_grad_cols = len(Ws), int(n_grad_cols)
+        return hs[-1]
+
+    @staticmethod
+    def backward(ctx, dout):
+        nl = ctx.n_layers
+        hs, Ws = ctx.saved_tensors[:nl], ctx.saved_tensors[nl:]
+        dz = dout.contiguous()
+        grads = [None] * (2 * nl)
+        dx = None
+        for i in range(nl - 1, -1, -1):
+            need_w, need_b = ctx.needs_input_grad[2 + 2 * i], ctx.needs_input_grad[3 + 2 * i]
+            if need_w or need_b:
+                dW, db = linear_wgrad(dz, hs[i], want_bias=True)
+                grads[2 * i], grads[2 * i + 1] = (dW if need_w else None), (db if need_b else None)
+            if i > 0:
+                dz = linear_dgrad(dz, Ws[i].contiguous(), mask=hs[i])         # hs[i] = relu output feeding layer i
+            elif ctx.needs_input_grad[0]:
+                nc = ctx.n_grad_cols
+                W0 = Ws[0].contiguous()
+                if nc >= W0.shape[1]:
+                    dx = linear_dgrad(dz, W0)
+                else:
+                    dx = torch.zeros(dz.shape[0], W0.shape[1], dtype=dz.dtype, device=dz.device)
+                    gemm(dz, W0[:, :nc], True, False, out=dx[:, :nc])
+        return (dx, None, *grads)
+
+
+def mlp_head_available(x, layers, head, activation):
+    if not (enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and activation is torch.relu):
+        return False
+    return all(l.weight.dtype == torch.float32 and l.bias is not None and l.weight.is_cuda for l in list(layers) + [head])
+
+
+def mlp_head(x, layers, head, n_grad_cols=None):
+    params = []
+    for l in list(layers) + [head]:
+        params += [l.weight, l.bias]
+    nc = x.shape[1] if n_grad_cols is None else int(n_grad_cols)
+    return MlpHead.apply(x, nc, *params)

@@ -15,6 +15,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
+from . import gemm as G
 
 HIDDEN_SIZES = (64, 128)      # hidden sizes the HIP kernels are built for
 
@@ -61,7 +62,10 @@ class LstmDirection(torch.autograd.Function):
         w_in = w_ih
         if pp is not None:
             w_in, bias = w_ih.index_select(0, pp[0]), bias.index_select(0, pp[0])
-        gx = torch.addmm(bias, x2, w_in.t()).view(T, B, 4 * HIDDEN)
+        if G.enabled():                     # bf16 matrix cores, split operands (csrc/egp_gemm.hip)
+            gx = G.linear_fwd(x2, w_in.contiguous(), bias).view(T, B, 4 * HIDDEN)
+        else:
+            gx = torch.addmm(bias, x2, w_in.t()).view(T, B, 4 * HIDDEN)
         # T + 1 time slots with a zero one in front (behind, for the reverse direction): h and the h_prev the weight
         # gradient needs are two views of the same buffer
         h_buf = torch.empty(T + 1, B, HIDDEN, dtype=x.dtype, device=x.device)
@@ -95,14 +99,25 @@ class LstmDirection(torch.autograd.Function):
         # dW_ih | dW_hh | db in ONE batched GEMM over the time axis + a reduction: [dPre_t^T (x_t | h_prev_t | 1)]
         # (a single (4H x T*B) @ (T*B x D) product runs 3x slower in rocBLAS than T independent ones; separate
         # products per operand would read dPre three times)
-        xh1 = torch.cat((x2.view(T, B, D), h_prev, h.new_ones(T, B, 1)), 2)
-        dw = torch.bmm(dpre.transpose(1, 2), xh1).sum(0)                       # (4H, D + H + 1), rows in the kernels' gate layout
         pp = _gate_perm(HIDDEN, h.device)
-        if pp is not None:
-            dw = dw.index_select(0, pp[1])
-        d_w_ih = dw[:, :D].contiguous() if ctx.needs_input_grad[1] else None
-        d_w_hh = dw[:, D:D + HIDDEN].contiguous() if ctx.needs_input_grad[2] else None
-        d_b = dw[:, D + HIDDEN].contiguous() if (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else None
+        if G.enabled():
+            # two split-K products over the (time, sequence) rows; the first also returns the bias gradient
+            d2 = dpre.view(T * B, 4 * HIDDEN)
+            dw_ih, dbias = G.linear_wgrad(d2, x2, want_bias=True)
+            dw_hh = G.linear_wgrad(d2, h_prev.reshape(T * B, HIDDEN), want_bias=False)
+            if pp is not None:
+                dw_ih, dw_hh, dbias = dw_ih.index_select(0, pp[1]), dw_hh.index_select(0, pp[1]), dbias.index_select(0, pp[1])
+            d_w_ih = dw_ih if ctx.needs_input_grad[1] else None
+            d_w_hh = dw_hh if ctx.needs_input_grad[2] else None
+            d_b = dbias if (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else None
+        else:
+            xh1 = torch.cat((x2.view(T, B, D), h_prev, h.new_ones(T, B, 1)), 2)
+            dw = torch.bmm(dpre.transpose(1, 2), xh1).sum(0)                   # (4H, D + H + 1), rows in the kernels' gate layout
+            if pp is not None:
+                dw = dw.index_select(0, pp[1])
+            d_w_ih = dw[:, :D].contiguous() if ctx.needs_input_grad[1] else None
+            d_w_hh = dw[:, D:D + HIDDEN].contiguous() if ctx.needs_input_grad[2] else None
+            d_b = dw[:, D + HIDDEN].contiguous() if (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else None
         d_x = dpre.view(T * B, 4 * HIDDEN).mm(w_in).view(T, B, D) if ctx.needs_input_grad[0] else None
         return d_x, d_w_ih, d_w_hh, d_b, d_b, None, None
 
@@ -125,7 +140,10 @@ class LstmGroup(torch.autograd.Function):
         x2 = x.reshape(T * B, D)
         w_in = torch.cat([w.index_select(0, perm) for w in w_ih], 0)                       # (P*4H, D)
         bias = torch.cat([(bi + bh).index_select(0, perm) for bi, bh in zip(b_ih, b_hh)], 0)
-        gx = torch.addmm(bias, x2, w_in.t())                                                # (T*B, P*4H)
+        if G.enabled():
+            gx = G.linear_fwd(x2, w_in, bias)                                               # (T*B, P*4H)
+        else:
+            gx = torch.addmm(bias, x2, w_in.t())
         w_hh_all = torch.stack([w.contiguous() for w in w_hh], 0)
         # per output T + 2 time slots, zero | h_0 .. h_{T-1} | zero: h_prev is the same buffer shifted by one slot
         # (down for a forward sweep, up for a reversed one)
@@ -159,13 +177,21 @@ class LstmGroup(torch.autograd.Function):
         L.check(lib.egp_lstm_group_bwd_f32(ptrs, W, _p(gates), _p(cells), _p(w_hh_all), T, B, H, P, reverse_mask, _p(dpre), _p(db), _s()),
                 "egp_lstm_group_bwd_f32")
         d3 = dpre.view(T, B, P * 4 * H)
-        dw_ih_all = torch.bmm(d3.transpose(1, 2), x2.view(T, B, D)).sum(0)                 # (P*4H, D), kernel gate order
+        use_g = G.enabled()
+        if use_g:      # one split-K product for the P stacked W_ih gradients
+            dw_ih_all = G.linear_wgrad(dpre, x2, want_bias=False)                          # (P*4H, D), kernel gate order
+        else:
+            dw_ih_all = torch.bmm(d3.transpose(1, 2), x2.view(T, B, D)).sum(0)
         grads = []
         for p in range(P):
             rev = (reverse_mask >> p) & 1
             slab = h_buf[p // width, 2:] if rev else h_buf[p // width, :T]
             h_prev = slab[:, :, (p % width) * H:(p % width + 1) * H]
-            dw_hh = torch.bmm(d3[:, :, p * 4 * H:(p + 1) * 4 * H].transpose(1, 2), h_prev).sum(0).index_select(0, inv)
+            if use_g:  # strided views: problem p's columns of d_pre against its half of the shifted hidden buffer
+                dw_hh = G.linear_wgrad(dpre[:, p * 4 * H:(p + 1) * 4 * H], slab.reshape(T * B, W)[:, (p % width) * H:(p % width + 1) * H],
+                                       want_bias=False).index_select(0, inv)
+            else:
+                dw_hh = torch.bmm(d3[:, :, p * 4 * H:(p + 1) * 4 * H].transpose(1, 2), h_prev).sum(0).index_select(0, inv)
             dw_ih = dw_ih_all[p * 4 * H:(p + 1) * 4 * H].index_select(0, inv)
             d_b = db[p].index_select(0, inv)
             grads += [dw_ih, dw_hh, d_b, d_b]

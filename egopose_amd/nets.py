@@ -22,6 +22,7 @@ import torch.nn as nn
 import os
 
 from . import dist as _dist
+from . import gemm as _gemm
 from . import gemm_tuning as _tuning
 from . import lstm as _hip_lstm
 
@@ -119,10 +120,15 @@ class PolicyGaussian(Policy):
         self.action_log_std = nn.Parameter(torch.full((1, action_dim), float(log_std)), requires_grad=not fix_std)
 
     def mean_std(self, x):
-        x, n = bucket_rows(x)
-        mean = self.action_mean(self.net(x))
-        if n is not None:
-            mean = mean[:n]
+        if _gemm.mlp_head_available(x, getattr(self.net, "affine_layers", ()), self.action_mean, getattr(self.net, "activation", None)):
+            # the whole head(MLP(x)) as one autograd node on the split-operand bf16 GEMM kernel (gemm.py); `input_grad_cols`
+            # (set by the agent): only the leading video-context columns of the input carry a gradient
+            mean = _gemm.mlp_head(x, self.net.affine_layers, self.action_mean, getattr(self, "input_grad_cols", None))
+        else:
+            x, n = bucket_rows(x)
+            mean = self.action_mean(self.net(x))
+            if n is not None:
+                mean = mean[:n]
         return mean, torch.exp(self.action_log_std.expand_as(mean))
 
     def forward(self, x):
@@ -149,6 +155,8 @@ class Value(nn.Module):
             self.value_head.bias.zero_()
 
     def forward(self, x):
+        if _gemm.mlp_head_available(x, getattr(self.net, "affine_layers", ()), self.value_head, getattr(self.net, "activation", None)):
+            return _gemm.mlp_head(x, self.net.affine_layers, self.value_head, getattr(self, "input_grad_cols", None))
         x, n = bucket_rows(x)
         out = self.value_head(self.net(x))
         return out if n is None else out[:n]

@@ -225,6 +225,36 @@ int egp_gae_f32(const float *rewards, const float *masks, const float *values, i
 int egp_gae_standardize_f64(double *adv, int32_t n, const double *stats, void *stream);
 int egp_gae_standardize_f32(float *adv, int32_t n, const double *stats, void *stream);
 
+
+/* ------------------------------------------------------------------------------------ update GEMMs
+ * float32 matrix products of the PPO update on the bf16 matrix cores with split operands (csrc/egp_gemm.hip): replaces
+ * the rocBLAS / hipBLASLt calls behind the reference's nn.Linear layers (models/mlp.py:22-25, core/policy_gaussian.py:19-24,
+ * core/critic.py:15-18) and behind the LSTM input projection / weight gradients (models/rnn.py:45-61 under autograd).
+ *   C[M][N] = A[M][K] B[K][N]  (+ bias[n]) (ReLU) (* (mask[m][n] > 0))
+ *   a_kcontig: A is given as [m][k] (element (m, k) at A[m*lda + k]); otherwise as [k][m] (A[k*lda + m])
+ *   b_kcontig: B is given as [n][k] (B[n*ldb + k], e.g. an nn.Linear weight in a forward pass); otherwise [k][n]
+ *   terms = 3: every operand is split x = hi + lo (two bf16) and a product is hi*hi + hi*lo + lo*hi in float32
+ *              accumulators (~16 mantissa bits per product); terms = 1: bf16 inputs (hi*hi only)
+ *   splits > 1: split-K, partial sums through `workspace` and a fixed-order reduction (deterministic); no epilogue then.
+ *   bias_grad != NULL (needs b_kcontig = 0): B gets a virtual column of ones, its result -- the column sums of A given
+ *              as [k][m], i.e. the bias gradient of a weight-gradient product -- goes to bias_grad[M].
+ *   accumulate: split-K / bias_grad launches add to C (and bias_grad) instead of overwriting.
+ * workspace: egp_gemm_workspace_floats(M, N, bias_grad != NULL, splits) floats, caller-owned, needed when splits > 1 or
+ * bias_grad is set. All pointers are device memory, rows need 4-byte alignment only. */
+typedef struct egp_gemm_desc {
+    int32_t M, N, K;
+    const float *A; int64_t lda; int32_t a_kcontig;
+    const float *B; int64_t ldb; int32_t b_kcontig;
+    float *C; int64_t ldc;
+    const float *bias; int32_t relu;
+    const float *mask; int64_t ldmask;
+    int32_t terms, splits, accumulate;
+    float *bias_grad;
+    float *workspace;
+} egp_gemm_desc;
+int64_t egp_gemm_workspace_floats(int32_t M, int32_t N, int32_t ones_col, int32_t splits);
+int egp_gemm_f32(const egp_gemm_desc *desc, void *stream);
+
 /* ---------------------------------------------------------------------------------------- LSTM
  * Recurrent sweep of ONE direction of the video-context LSTM (hidden size 64 or 128, float32, zero initial state):
  * the t-loop of RNN.batch_forward (models/rnn.py:45-61) in one launch.

@@ -1,0 +1,157 @@
+"""csrc/egp_gemm.hip through the C-ABI (`egp_gemm_f32`) against float64 products: the four operand layouts, ragged sizes
+(tiles cut in m, n and k; rows that are only 4-byte aligned), the fused epilogues, split-K with the bias-gradient column,
+and the autograd node that the update's MLPs run on (against torch's own float32 autograd of the reference's modules)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(got, ref):
+    return float((got.double() - ref).norm() / ref.norm().clamp_min(1e-300))
+
+
+def _operands(M, N, K, a_kc, b_kc, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    A64 = torch.randn(M, K, dtype=torch.float64, device="cuda", generator=g)
+    B64 = torch.randn(K, N, dtype=torch.float64, device="cuda", generator=g)
+    A = (A64 if a_kc else A64.t()).float().contiguous()          # (M, K) or (K, M)
+    B = (B64.t() if b_kc else B64).float().contiguous()          # (N, K) or (K, N)
+    A64 = (A if a_kc else A.t()).double()
+    B64 = (B.t() if b_kc else B).double()
+    return A, B, A64 @ B64
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("M,N,K", [(1000, 300, 243), (257, 200, 300), (129, 52, 200), (64, 1, 77), (5, 243, 1), (300, 243, 4097),
+                                   (128, 128, 32), (1, 1, 1)])
+def test_products_match_float64(a_kc, b_kc, M, N, K):
+    from egopose_amd.gemm import gemm
+    A, B, ref = _operands(M, N, K, a_kc, b_kc, seed=M + 7 * N + 13 * K)
+    c3 = gemm(A, B, a_kc, b_kc, terms=3)
+    c1 = gemm(A, B, a_kc, b_kc, terms=1)
+    assert c3.shape == (M, N)
+    assert _rel(c3, ref) < 2e-5, "split-operand product must be float32-class"
+    assert _rel(c1, ref) < 6e-3
+    # element-wise: 2^-15 of the sum of the magnitudes of the K products
+    A64 = (A if a_kc else A.t()).double().abs()
+    B64 = (B.t() if b_kc else B).double().abs()
+    assert ((c3.double() - ref).abs() <= 3.1e-5 * (A64 @ B64) + 1e-30).all()
+    lib = A.double() if a_kc else A.t().double()
+    f32 = (lib.float() @ (B.t() if b_kc else B)).double()          # the library's float32 product, for scale
+    assert _rel(c3, ref) < max(40 * _rel(f32, ref), 1.6e-5)
+
+
+def test_rows_with_4_byte_alignment_and_strided_views():
+    """Operands that are column slices of wider tensors (leading dimension != width, rows not 16-byte aligned)."""
+    from egopose_amd.gemm import gemm
+    g = torch.Generator(device="cuda").manual_seed(3)
+    big = torch.randn(700, 251, device="cuda", generator=g)
+    W = torch.randn(97, 131, device="cuda", generator=g)
+    x = big[:, 3:134]                                       # (700, 131), ld 251, offset 3 floats
+    ref = x.double() @ W.double().t()
+    assert _rel(gemm(x, W), ref) < 2e-5
+    out = torch.zeros(700, 120, device="cuda")
+    gemm(x, W, out=out[:, 11:108])                          # strided output
+    assert _rel(out[:, 11:108], ref) < 2e-5 and float(out[:, :11].abs().sum() + out[:, 108:].abs().sum()) == 0.0
+    dy = big[:, 100:197]                                    # (700, 97)
+    dW, db = gemm(dy, x, False, False, splits=5, want_bias_grad=True)
+    assert _rel(dW, dy.double().t() @ x.double()) < 2e-5 and _rel(db, dy.double().sum(0)) < 2e-5
+
+
+def test_epilogues():
+    from egopose_amd.gemm import gemm, linear_dgrad, linear_fwd
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(900, 243, device="cuda", generator=g)
+    W = torch.randn(300, 243, device="cuda", generator=g) * 0.1
+    b = torch.randn(300, device="cuda", generator=g)
+    z = x.double() @ W.double().t() + b.double()
+    y = linear_fwd(x, W, b, relu=True)
+    assert _rel(y, z.clamp_min(0)) < 2e-5
+    sure = z.abs() > 1e-4                                     # the sign of near-zero pre-activations may differ in float32
+    assert ((y > 0) == (z > 0))[sure].all()
+    assert _rel(linear_fwd(x, W, b), z) < 2e-5 and _rel(linear_fwd(x, W), z - b.double()) < 2e-5
+    dy = torch.randn(900, 300, device="cuda", generator=g)
+    h = torch.randn(900, 243, device="cuda", generator=g)
+    ref = (dy.double() @ W.double()) * (h > 0)
+    assert _rel(linear_dgrad(dy, W, mask=h), ref) < 2e-5
+    assert _rel(linear_dgrad(dy, W, n_cols=128), dy.double() @ W.double()[:, :128]) < 2e-5
+
+
+@pytest.mark.parametrize("splits", [1, 2, 7, 64])
+def test_split_k_weight_gradient_with_bias_column(splits):
+    from egopose_amd.gemm import gemm, linear_wgrad, pick_splits
+    g = torch.Generator(device="cuda").manual_seed(11)
+    n = 9001
+    dy = torch.randn(n, 300, device="cuda", generator=g)
+    x = torch.randn(n, 243, device="cuda", generator=g)
+    dW_ref, db_ref = dy.double().t() @ x.double(), dy.double().sum(0)
+    dW, db = gemm(dy, x, False, False, splits=splits, want_bias_grad=True)
+    assert dW.shape == (300, 243) and db.shape == (300,)
+    assert _rel(dW, dW_ref) < 2e-5 and _rel(db, db_ref) < 2e-5
+    dW2, db2 = gemm(dy, x, False, False, splits=splits, want_bias_grad=True)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2), "fixed-order reduction: bit-identical from run to run"
+    acc, accb = dW.clone(), db.clone()
+    gemm(dy, x, False, False, splits=splits, want_bias_grad=True, out=acc, bias_grad_out=accb, accumulate=True)
+    assert _rel(acc, 2 * dW_ref) < 2e-5 and _rel(accb, 2 * db_ref) < 2e-5
+    if splits == 1:
+        a, b2 = linear_wgrad(dy, x)
+        assert pick_splits(300, 244, n) > 1 and _rel(a, dW_ref) < 2e-5 and _rel(b2, db_ref) < 2e-5
+        assert _rel(gemm(dy, x, False, False, splits=3), dW_ref) < 2e-5          # split-K without the bias column
+
+
+def test_bad_arguments_are_refused():
+    from egopose_amd.gemm import gemm
+    a, b = torch.zeros(8, 4, device="cuda"), torch.zeros(5, 4, device="cuda")
+    with pytest.raises(ValueError):
+        gemm(a, torch.zeros(5, 3, device="cuda"))
+    with pytest.raises(ValueError):
+        gemm(a.double(), b.double())
+    with pytest.raises(ValueError):
+        gemm(a, b, terms=2)
+    with pytest.raises(ValueError):
+        gemm(a, b, splits=2, bias=torch.zeros(5, device="cuda"))
+    with pytest.raises(ValueError):
+        gemm(a.t(), b)                      # second dimension not unit-stride
+    assert gemm(torch.zeros(0, 4, device="cuda"), b).shape == (0, 5)
+
+
+@pytest.mark.parametrize("head_dim", [52, 1])
+def test_mlp_head_node_matches_torch_autograd(head_dim):
+    """The fused node (forward + every gradient) against torch autograd over the reference's modules in float64."""
+    from egopose_amd.gemm import mlp_head
+    from egopose_amd.nets import MLP
+    torch.manual_seed(0)
+    n = 5000
+    net = MLP(243, [300, 200], "relu").cuda()
+    head = torch.nn.Linear(200, head_dim).cuda()
+    x = torch.randn(n, 243, device="cuda", requires_grad=True)
+    tgt = torch.randn(n, head_dim, device="cuda")
+    out = mlp_head(x, net.affine_layers, head, n_grad_cols=128)
+    loss = (out - tgt).pow(2).mean()
+    loss.backward()
+    got = [x.grad.clone()] + [p.grad.clone() for p in list(net.parameters()) + list(head.parameters())]
+    net64, head64 = MLP(243, [300, 200], "relu").cuda().double(), torch.nn.Linear(200, head_dim).cuda().double()
+    net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    head64.load_state_dict({k: v.double() for k, v in head.state_dict().items()})
+    x64 = x.detach().double().requires_grad_(True)
+    out64 = head64(net64(x64))
+    (out64 - tgt.double()).pow(2).mean().backward()
+    ref = [x64.grad] + [p.grad for p in list(net64.parameters()) + list(head64.parameters())]
+    assert _rel(out.detach(), out64.detach()) < 2e-5
+    assert float(got[0][:, 128:].abs().max()) == 0.0
+    for a, b in zip(got[1:], ref[1:]):
+        assert a.shape == b.shape and _rel(a, b) < 5e-5
+    # the torch float32 path of the same modules, for scale: the fused node is no worse than 20x its error. (The input
+    # gradient of ANY float32 evaluation differs from float64 where a pre-activation is within round-off of zero and the
+    # ReLU derivative flips: ~1e-3 in norm for both.)
+    for p in list(net.parameters()) + list(head.parameters()):
+        p.grad = None
+    x2 = x.detach().clone().requires_grad_(True)
+    (head(net(x2)) - tgt).pow(2).mean().backward()
+    lib = [x2.grad] + [p.grad for p in list(net.parameters()) + list(head.parameters())]
+    assert _rel(got[0][:, :128], ref[0][:, :128]) < max(3 * _rel(lib[0][:, :128], ref[0][:, :128]), 5e-5)
+    assert _rel(got[0][:, :128], lib[0][:, :128].double()) < 5e-3
+    for a, l, b in zip(got[1:], lib[1:], ref[1:]):
+        assert _rel(a, b) < 20 * max(_rel(l, b), 2e-6)

@@ -489,6 +489,6 @@ def test_quaternion_algebra_on_device_matches_reference_vectors(dtype, tol):
         np.testing.assert_allclose(rot[:, :3] * rot[:, 3:], g["rot_vec"], rtol=1e-5, atol=1e-5)
     half = quat_op("diff_half_angle", d(g["q1"]), d(qn))
     chk(half, g["multi_norm"], 1e-9 if dtype == torch.float64 else 1e-5)
-    with pytest.raises(RuntimeError):
+    with pytest.raises(ValueError, match="unknown quaternion op"):
         from egopose_amd import _lib as L
         L.check(L.load().egp_quat_op_f64(99, None, None, 1, None, None), "egp_quat_op")
