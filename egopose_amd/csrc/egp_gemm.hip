@@ -41,6 +41,8 @@ inline int after_launch(const char *what) {
 }
 
 constexpr int BM = 128, BK = 32;
+__host__ __device__ constexpr int panel_el(int R) { return R * 8 + 32; }      // bf16 elements per k-panel of an R-row tile
+__host__ __device__ constexpr int tile_el(int R) { return 4 * panel_el(R); }
 
 struct GemmArgs {
     int M, N, K;                              // N counts the real columns of B (the virtual ones column is extra)
@@ -55,31 +57,32 @@ struct GemmArgs {
     int tiles_m, tiles_n, xcd_order;
 };
 
-// LDS image of an operand tile (R rows x 32 k, bf16): four k-panels of [R][8], element (row, k) at ((k >> 3) * R + row) * 8
-// + (k & 7). An MFMA fragment read (32 consecutive rows x 8 k per half-wave) is 512 contiguous bytes and every staging
-// store is one 16-byte write of 8 consecutive k: no bank conflicts beyond the 4 passes a 1 KiB wave access needs anyway.
+// LDS image of an operand tile (R rows x 32 k, bf16): four k-panels of [R][8] (+ 64 bytes between panels), element
+// (row, k) at (k >> 3) * PANEL(R) + row * 8 + (k & 7). An MFMA fragment read (32 consecutive rows x 8 k per half-wave) is
+// 512 contiguous bytes; staging stores are 8- or 16-byte writes of consecutive k of one row, and the panel pad keeps the
+// four panels a k-contiguous row is scattered over on different banks.
 //
-// Staging registers: v[8 u + j] = element (row_u, k0 + 8 * panel + j), u < R / 64 -- the same shape for both memory forms.
+// Staging registers: R / 8 floats per thread and operand, in the shape its memory form loads best.
 // All loads are branch-free (the compiler keeps them in flight across the multiply with counted waits): row indices past
 // the operand are clamped -- such rows only feed output rows / columns that are never stored. The one k-tile that may
 // reach past the end of the k range is handled after the pipelined loop (`ktail`: element-wise loads, zero select).
-// k-contiguous memory (P[row * ld + k]): thread t -> panel t & 3, rows (t >> 2) + 64 u: two 16-byte loads per unit.
+// k-contiguous memory (P[row * ld + k]): thread t -> k quad t & 7, rows (t >> 3) + 32 u: eight lanes read the 128 bytes one
+// row contributes to the tile with one 16-byte load each. Registers: v[4 u + j] = element (row_u, k0 + 4 (t & 7) + j).
 template <int R, bool ktail>
 __device__ __forceinline__ void load_kc(const float *__restrict__ P, long ld, int rows, int r0, int k0, int kend, float (&v)[R / 8]) {
-    const int t = threadIdx.x, k = k0 + (t & 3) * 8, rb = t >> 2;
+    const int t = threadIdx.x, k = k0 + (t & 7) * 4, rb = t >> 3;
 #pragma unroll
-    for (int u = 0; u < R / 64; ++u) {
-        const int row = min(r0 + rb + 64 * u, rows - 1);
+    for (int u = 0; u < R / 32; ++u) {
+        const int row = min(r0 + rb + 32 * u, rows - 1);
         const float *src = P + (long)row * ld;
         if constexpr (!ktail) {
-            const f32x4u x = *(const f32x4u *)(src + k), y = *(const f32x4u *)(src + k + 4);
-            v[8 * u] = x[0]; v[8 * u + 1] = x[1]; v[8 * u + 2] = x[2]; v[8 * u + 3] = x[3];
-            v[8 * u + 4] = y[0]; v[8 * u + 5] = y[1]; v[8 * u + 6] = y[2]; v[8 * u + 7] = y[3];
+            const f32x4u x = *(const f32x4u *)(src + k);
+            v[4 * u] = x[0]; v[4 * u + 1] = x[1]; v[4 * u + 2] = x[2]; v[4 * u + 3] = x[3];
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 const float x = src[min(k + j, kend - 1)];
-                v[8 * u + j] = k + j < kend ? x : 0.f;
+                v[4 * u + j] = k + j < kend ? x : 0.f;
             }
         }
     }
@@ -107,19 +110,39 @@ __device__ __forceinline__ void load_rc(const float *__restrict__ P, long ld, in
     }
 }
 
-// registers -> LDS (hi and lo images): 8 consecutive k of one row = one 16-byte store each
+// registers -> LDS (hi and lo images)
+#define EGP_SPLIT(x, H, L, j)                                                        \
+    do {                                                                             \
+        const __bf16 _h = (__bf16)(x);      /* v_cvt_pk_bf16_f32: round to nearest even */ \
+        (H)[j] = _h;                                                                 \
+        (L)[j] = (__bf16)((x) - (float)_h);                                          \
+    } while (0)
+
+// k-contiguous staging: 4 consecutive k of row (t >> 3) + 32 u -> one 8-byte store
 template <int R, bool LO>
-__device__ __forceinline__ void store_tile(const float (&v)[R / 8], __bf16 *hi, __bf16 *lo, int panel, int rb) {
+__device__ __forceinline__ void store_kc(const float (&v)[R / 8], __bf16 *hi, __bf16 *lo) {
+    const int t = threadIdx.x, kq = t & 7, rb = t >> 3;
+#pragma unroll
+    for (int u = 0; u < R / 32; ++u) {
+        bf16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) EGP_SPLIT(v[4 * u + j], h, l, j);
+        const int off = (kq >> 1) * panel_el(R) + (rb + 32 * u) * 8 + (kq & 1) * 4;
+        *(bf16x4 *)(hi + off) = h;
+        if (LO) *(bf16x4 *)(lo + off) = l;
+    }
+}
+
+// row-contiguous staging: 8 consecutive k (panel = wave) of row lane + 64 u -> one 16-byte store
+template <int R, bool LO>
+__device__ __forceinline__ void store_rc(const float (&v)[R / 8], __bf16 *hi, __bf16 *lo) {
+    const int t = threadIdx.x, l64 = t & 63, panel = t >> 6;
 #pragma unroll
     for (int u = 0; u < R / 64; ++u) {
         bf16x8 h, l;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float x = v[8 * u + j];
-            h[j] = (__bf16)x;                                  // v_cvt_pk_bf16_f32 (round to nearest even)
-            l[j] = (__bf16)(x - (float)h[j]);
-        }
-        const int off = (panel * R + rb + 64 * u) * 8;
+        for (int j = 0; j < 8; ++j) EGP_SPLIT(v[8 * u + j], h, l, j);
+        const int off = panel * panel_el(R) + (l64 + 64 * u) * 8;
         *(bf16x8 *)(hi + off) = h;
         if (LO) *(bf16x8 *)(lo + off) = l;
     }
@@ -148,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x(GemmArgs g) {
     constexpr int WROWS = 32 * MI;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // per buffer: A hi | A lo | B hi | B lo
-    constexpr int A_EL = BM * BK, B_EL = BN * BK;
+    constexpr int A_EL = tile_el(BM), B_EL = tile_el(BN);
     constexpr int BUF_EL = (LO ? 2 : 1) * (A_EL + B_EL);
     __bf16 *base = (__bf16 *)smem;
 
@@ -162,9 +185,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x(GemmArgs g) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    // where this thread's staging registers go in the LDS image
-    const int a_panel = A_KC ? (t & 3) : wave, a_rb = A_KC ? (t >> 2) : lane;
-    const int b_panel = B_KC ? (t & 3) : wave, b_rb = B_KC ? (t >> 2) : lane;
     f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -190,8 +210,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x(GemmArgs g) {
     auto sstore = [&](int buf, const float (&va)[BM / 8], const float (&vb)[BN / 8]) {
         __bf16 *p = base + buf * BUF_EL;
         __bf16 *ah = p, *al = p + A_EL, *bh = p + (LO ? 2 : 1) * A_EL, *bl = bh + B_EL;
-        store_tile<BM, LO>(va, ah, al, a_panel, a_rb);
-        store_tile<BN, LO>(vb, bh, bl, b_panel, b_rb);
+        if constexpr (A_KC) store_kc<BM, LO>(va, ah, al); else store_rc<BM, LO>(va, ah, al);
+        if constexpr (B_KC) store_kc<BN, LO>(vb, bh, bl); else store_rc<BN, LO>(vb, bh, bl);
     };
     const int frow = lane & 31, fkh = lane >> 5;
     auto compute = [&](int buf) {
@@ -202,13 +222,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x(GemmArgs g) {
             bf16x8 fa_h[MI], fa_l[MI], fb_h[NJ], fb_l[NJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const int off = ((2 * ks + fkh) * BM + wm * WROWS + 32 * i + frow) * 8;
+                const int off = (2 * ks + fkh) * panel_el(BM) + (wm * WROWS + 32 * i + frow) * 8;
                 fa_h[i] = *(const bf16x8 *)(ah + off);
                 if (LO) fa_l[i] = *(const bf16x8 *)(al + off);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int off = ((2 * ks + fkh) * BN + wn * 64 + 32 * j + frow) * 8;
+                const int off = (2 * ks + fkh) * panel_el(BN) + (wn * 64 + 32 * j + frow) * 8;
                 fb_h[j] = *(const bf16x8 *)(bh + off);
                 if (LO) fb_l[j] = *(const bf16x8 *)(bl + off);
             }
@@ -403,7 +423,7 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     g.xcd_order = g.tiles_m >= 64;
     dim3 grid((g.xcd_order ? ((g.tiles_m + 7) / 8) * 8 : g.tiles_m) * g.tiles_n, 1, zs);
     const int lo = d->terms == 3 ? 2 : 1;
-    const size_t lds = (size_t)2 * lo * (BM + BNv) * BK * sizeof(__bf16);
+    const size_t lds = (size_t)2 * lo * (tile_el(BM) + tile_el(BNv)) * sizeof(__bf16);
     int rc;
     if (bn64) rc = d->terms == 3 ? launch_variant<64, 3>(g, grid, lds, s) : launch_variant<64, 1>(g, grid, lds, s);
     else rc = d->terms == 3 ? launch_variant<128, 3>(g, grid, lds, s) : launch_variant<128, 1>(g, grid, lds, s);
