@@ -352,8 +352,16 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const float *__restrict__ w
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)M * n_out) return;
     const int row = (int)(idx / n_out), col = (int)(idx % n_out);
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += ws[(long)k * M * n_out + idx];
+    // eight independent chains (the loads of a chain are 0.5 us apart otherwise); the order is fixed, so results repeat
+    const long stride = (long)M * n_out;
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= splits; k += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[j] += ws[(k + j) * stride + idx];
+    }
+    for (; k < splits; ++k) p[k & 7] += ws[k * stride + idx];
+    const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     if (col < N) {
         float *dst = C + (long)row * ldc + col;
         *dst = accumulate ? *dst + s : s;

@@ -2,7 +2,7 @@
 # HBM traffic of the kernels by PMC counters: separate rocprofv3 passes for FETCH_SIZE and WRITE_SIZE
 # (MI355X_MICROARCH.md: TCC slots do not fit both; gpurun forbids mixing --pmc with trace domains other than kernel-trace).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_r01
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_microbench
 mkdir -p $OUT
 N=${1:-65536}
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -23,7 +23,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 keys = sorted(set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"]))
 print("kernel,launches,FETCH_SIZE_avg,WRITE_SIZE_avg")
 for k in keys:
-    if "egp::" not in k: continue
+    if "egp::" not in k and "k_dynamics" not in k and "k_gemm" not in k: continue
     f, nf = res["FETCH_SIZE"].get(k, [0, 1]); w, nw = res["WRITE_SIZE"].get(k, [0, 1])
     print("%s,%d,%.1f,%.1f" % (k, nf, f / max(nf, 1), w / max(nw, 1)))
 PY

@@ -59,6 +59,28 @@ if k1:
     json.dump(d, open(OUT + "/pmc_k1_traffic.json", "w"), indent=1)
 print("\n".join(rows))
 PY
+# matrix-core utilisation of the update's kernels (own PMC pass, kernel-trace only): the split-operand GEMM, the persistent
+# LSTM recurrences and whatever library GEMM is left
+timeout 900 rocprofv3 --pmc MfmaUtil VALUBusy --kernel-trace --output-format csv -d $OUT/mfma -o b -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-k1-events --no-legs --no-kernels > $OUT/mfma.log 2>&1
+python - <<PY
+import csv, glob, collections
+OUT = "$OUT"
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for path in glob.glob(OUT + "/mfma/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        n = r["Kernel_Name"]
+        if not ("k_gemm" in n or "k_lstm" in n or n.startswith("Cijk") or "k_policy" in n):
+            continue
+        a = acc[n[:110]][r["Counter_Name"]]
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+rows = sorted(acc.items(), key=lambda kv: -kv[1].get("MfmaUtil", [0, 0])[1])
+with open(OUT + "/update_mfma_util.csv", "w") as f:
+    f.write("kernel,launches,MfmaUtil_avg_pct,VALUBusy_avg_pct\n")
+    for k, v in rows:
+        m, b = v.get("MfmaUtil", [0, 1]), v.get("VALUBusy", [0, 1])
+        f.write('"%s",%d,%.2f,%.2f\n' % (k, m[1], m[0] / max(1, m[1]), b[0] / max(1, b[1])))
+print(open(OUT + "/update_mfma_util.csv").read()[:4000])
+PY
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 head -12 $OUT/bench_kernel_stats.csv | cut -c1-160
 cat $OUT/pmc_k1_traffic.json
