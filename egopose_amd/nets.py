@@ -388,6 +388,55 @@ class VideoStateNet(nn.Module):
         return torch.cat((ctx.reshape(-1, self.v_hdim).index_select(0, self._gather_tm), x), dim=1)
 
 
+class Bf16Shadow:
+    """bfloat16 compute copy of a convolutional encoder whose float32 parameters stay the MASTER weights (state_dict,
+    optimizer). `torch.autocast` is not the way to bf16 on this stack: it re-casts weights and activations around every
+    op (127 ms per 256-frame ResNet-18 step against 37 ms in float32); a module that simply IS bf16 runs MIOpen's
+    implicit-GEMM MFMA convolutions end to end (21 ms). Normalisation layers are shared with the master (float32 affine
+    parameters and running statistics, mixed-dtype batch norm), convolution / linear weights are bf16 copies:
+    `pull()` after an optimizer step or a checkpoint load, `push_grads()` between backward and the optimizer step."""
+
+    def __init__(self, master):
+        import copy
+        self.master = master
+        self.shadow = copy.deepcopy(master)
+        for name, m in list(master.named_modules()):
+            if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                parent = self.shadow
+                *path, leaf = name.split(".")
+                for part in path:
+                    parent = getattr(parent, part)
+                setattr(parent, leaf, m)
+        mp = dict(master.named_parameters())
+        self.pairs = []
+        for n, p in self.shadow.named_parameters():
+            if p is not mp[n]:
+                p.data = p.data.to(torch.bfloat16)
+                self.pairs.append((mp[n], p))
+
+    @torch.no_grad()
+    def pull(self):
+        torch._foreach_copy_([s for _, s in self.pairs], [m for m, _ in self.pairs])
+
+    @torch.no_grad()
+    def push_grads(self):
+        dst, src = [], []
+        for m, s in self.pairs:
+            if s.grad is None:
+                continue
+            if m.grad is None:
+                m.grad = torch.empty_like(m)
+            dst.append(m.grad)
+            src.append(s.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for _, s in self.pairs:
+            s.grad = None
+
+    def __call__(self, x):
+        return self.shadow(x.to(torch.bfloat16)).float()
+
+
 class VideoRegNet(nn.Module):          # (ResNet is defined further down; resolved at construction time)
     """State regressor of models/video_reg_net.py:10-59: [ResNet-18 per frame ->] temporal net -> MLP (relu) -> Linear.
     `no_cnn=True` (what the evaluation drivers load, ego_pose/ego_mimic_eval.py:71-80) takes precomputed features
@@ -419,18 +468,40 @@ class VideoRegNet(nn.Module):          # (ResNet is defined further down; resolv
             self._nhwc = True
         return self
 
+    def bf16_encoder(self, on=True):
+        """Run the image encoder in bfloat16 on the matrix cores with its float32 parameters as master weights
+        (BASELINE config 4; `Bf16Shadow`). Training loops call `encoder_grads_ready()` after backward and
+        `encoder_stepped()` after the optimizer step (or a checkpoint load). Returns self."""
+        self.__dict__["_enc16"] = Bf16Shadow(self.cnn) if (on and self.cnn is not None) else None
+        return self
+
+    def encoder_grads_ready(self):
+        if self.__dict__.get("_enc16") is not None:
+            self._enc16.push_grads()
+
+    def encoder_stepped(self):
+        if self.__dict__.get("_enc16") is not None:
+            self._enc16.pull()
+
+    def _encode(self, frames):
+        enc = self.__dict__.get("_enc16")
+        if enc is not None:
+            enc.shadow.train(self.training)
+            return enc(frames)
+        return self.cnn(frames)
+
     def _frames(self, x):
         x = x.reshape((-1,) + self.frame_shape)
         return x.contiguous(memory_format=torch.channels_last) if getattr(self, "_nhwc", False) else x
 
     def forward(self, x):
         if self.cnn is not None:        # x: (T, B, 3, H, W) optical-flow frames -> per-frame features
-            x = self.cnn(self._frames(x)).view(-1, x.size(1), self.cnn_fdim)
+            x = self._encode(self._frames(x)).view(-1, x.size(1), self.cnn_fdim)
         x = self.forward_v_net(x).reshape(-1, self.v_hdim)
         return self.linear(self.mlp(x))
 
     def get_cnn_feature(self, x):
-        return self.cnn(self._frames(x))
+        return self._encode(self._frames(x))
 
 
 class VideoForecastNet(nn.Module):

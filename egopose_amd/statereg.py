@@ -197,7 +197,8 @@ def get_traj_from_state_pred(state_pred, init_pos, init_heading, dt, traj_dim):
 class StateRegTrainer:
     """The three modes of ego_pose/state_reg.py over one object."""
 
-    def __init__(self, cfg, dataset, device, dtype=torch.float32, no_cnn=False, frame_shape=(3, 224, 224), autocast=None):
+    def __init__(self, cfg, dataset, device, dtype=torch.float32, no_cnn=False, frame_shape=(3, 224, 224), autocast=None,
+                 bf16_encoder=None):
         from .nets import VideoRegNet
         self.cfg, self.dataset, self.device, self.dtype = cfg, dataset, torch.device(device), dtype
         self.state_dim = (dataset.traj_dim - 1) // 2 + 6 if cfg.pose_only else dataset.traj_dim
@@ -207,7 +208,15 @@ class StateRegTrainer:
         if self.device.type == "cuda" and not no_cnn:
             self.net.channels_last()       # NHWC encoder: MIOpen's faster layout on the MI355X (nets.VideoRegNet.channels_last)
         self.optimizer = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=cfg.lr)
-        self.autocast = autocast           # e.g. torch.bfloat16: MFMA convolutions / GEMMs with fp32 master weights
+        self.autocast = autocast           # torch.autocast dtype (measured 3.4x SLOWER than float32 here: kept for A/B runs)
+        # BASELINE config 4: the ResNet-18 encoder in bf16 on the matrix cores, float32 master weights (nets.Bf16Shadow);
+        # default on the GPU for float32 trainers, EGP_STATEREG_BF16=0 or bf16_encoder=False keeps float32 convolutions
+        if bf16_encoder is None:
+            bf16_encoder = (self.device.type == "cuda" and dtype == torch.float32 and not no_cnn and autocast is None
+                            and os.environ.get("EGP_STATEREG_BF16", "1") != "0")
+        self.bf16_encoder = bool(bf16_encoder)
+        if self.bf16_encoder:
+            self.net.bf16_encoder()
 
     def _forward(self, of_np):
         x = of_to_frames(of_np, self.dtype, self.device)
@@ -227,7 +236,9 @@ class StateRegTrainer:
             loss = (gt - pred).pow(2).sum(dim=1).mean()
             self.optimizer.zero_grad()
             loss.backward()
+            self.net.encoder_grads_ready()
             self.optimizer.step()
+            self.net.encoder_stepped()
             loss_sum += float(loss.detach()) * num
             n_sample += num
         return loss_sum / max(1, n_sample), n_sample, time.time() - t0
@@ -286,6 +297,7 @@ class StateRegTrainer:
         with open(path, "rb") as f:
             cp, meta = pickle.load(f)
         self.net.load_state_dict(cp["state_net_dict"], strict=strict)
+        self.net.encoder_stepped()           # the bf16 encoder copy follows the loaded weights
         return meta
 
 

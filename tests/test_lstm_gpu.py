@@ -309,3 +309,57 @@ def test_no_grad_passes_take_the_inference_kernels(monkeypatch):
     torch.testing.assert_close(b2.detach(), b)
     (a2.sum() + b2.sum()).backward()
     assert all(c.weight_hh.grad is not None for c in cells)
+
+
+def test_video_reg_net_with_encoder_matches_float64_cpu_forward():
+    """Row f4: VideoRegNet with the ResNet-18 encoder (float32, NHWC, MIOpen convolutions + HIP LSTM + HIP GEMM head is
+    not used here: plain MLP) on the device against a float64 CPU forward of the same module, train and eval mode."""
+    import copy
+    from egopose_amd.nets import VideoRegNet
+    torch.manual_seed(5)
+    net64 = VideoRegNet(115, 128, 128, no_cnn=False, frame_shape=(3, 64, 64)).double()
+    x = torch.randn(12, 1, 3, 64, 64, dtype=torch.float64)
+    net = copy.deepcopy(net64).float().cuda().channels_last()
+    for train in (True, False):
+        net64.train(train); net.train(train)
+        with torch.no_grad():
+            ref = net64(x)
+            got = net(x.float().cuda())
+        err = float((got.double().cpu() - ref).norm() / ref.norm())
+        assert err < 2e-4, (train, err)
+    # batch-norm running statistics moved identically in the train-mode pass
+    np.testing.assert_allclose(net.cnn.resnet.bn1.running_mean.cpu().numpy(), net64.cnn.resnet.bn1.running_mean.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_bf16_encoder_keeps_float32_master_weights():
+    """BASELINE config 4's arithmetic: bf16 encoder copy (nets.Bf16Shadow) against the float32 encoder, and one
+    optimisation step through the master / shadow hand-over."""
+    from egopose_amd.nets import VideoRegNet
+    torch.manual_seed(6)
+    net = VideoRegNet(115, 128, 128, no_cnn=False, frame_shape=(3, 64, 64)).cuda().channels_last()
+    x = torch.randn(16, 1, 3, 64, 64, device="cuda")
+    gt = torch.randn(16, 115, device="cuda")
+    net.eval()
+    with torch.no_grad():
+        ref = net(x)
+    net.bf16_encoder()
+    assert len(net._enc16.pairs) == 22 and all(s.dtype == torch.bfloat16 and m.dtype == torch.float32 for m, s in net._enc16.pairs)
+    assert net._enc16.shadow.resnet.bn1 is net.cnn.resnet.bn1            # normalisation layers are shared (float32)
+    assert all(v.dtype in (torch.float32, torch.int64) for v in net.state_dict().values())          # nothing bf16 in a checkpoint
+    with torch.no_grad():
+        got = net(x)
+    assert float((got - ref).norm() / ref.norm()) < 3e-2
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    loss = (gt - net(x)).pow(2).sum(1).mean()
+    opt.zero_grad()
+    loss.backward()
+    net.encoder_grads_ready()
+    assert net.cnn.resnet.conv1.weight.grad is not None and net.cnn.resnet.conv1.weight.grad.dtype == torch.float32
+    opt.step()
+    net.encoder_stepped()
+    for n, p in net.named_parameters():
+        assert p.dtype == torch.float32 and not torch.equal(p, before[n]), n
+    for m, s in net._enc16.pairs:
+        assert torch.equal(s, m.to(torch.bfloat16))

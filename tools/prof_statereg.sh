@@ -1,12 +1,13 @@
 #!/bin/bash
-# state_reg step (ResNet-18 encoder + bi-LSTM + MLP, fp32 MFMA convolutions through MIOpen): kernel stats and MFMA utilisation
+# state_reg step (ResNet-18 encoder + bi-LSTM + MLP): kernel stats of the channels_last variants and the matrix-core
+# utilisation of the default one (bf16 encoder copy with float32 master weights, BASELINE config 4)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_statereg
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -o s -- python tools/statereg_bench.py 256 > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -o s -- python tools/statereg_bench.py 256 channels_last > $OUT/bench.log 2>&1
 cp "$(find $OUT/raw -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv
 rm -rf $OUT/raw
-timeout 900 rocprofv3 --pmc MfmaUtil VALUBusy --kernel-trace --output-format csv -d $OUT/pmc -o s -- python tools/statereg_bench.py 256 > $OUT/pmc.log 2>&1
+timeout 900 rocprofv3 --pmc MfmaUtil VALUBusy --kernel-trace --output-format csv -d $OUT/pmc -o s -- python tools/statereg_bench.py 256 Bf16Shadow > $OUT/pmc.log 2>&1
 python - <<PY
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
