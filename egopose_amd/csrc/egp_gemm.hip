@@ -110,41 +110,56 @@ __device__ __forceinline__ void load_rc(const float *__restrict__ P, long ld, in
     }
 }
 
-// registers -> LDS (hi and lo images)
-#define EGP_SPLIT(x, H, L, j)                                                        \
-    do {                                                                             \
-        const __bf16 _h = (__bf16)(x);      /* v_cvt_pk_bf16_f32: round to nearest even */ \
-        (H)[j] = _h;                                                                 \
-        (L)[j] = (__bf16)((x) - (float)_h);                                          \
-    } while (0)
-
-// k-contiguous staging: 4 consecutive k of row (t >> 3) + 32 u -> one 8-byte store
-template <int R, bool LO>
-__device__ __forceinline__ void store_kc(const float (&v)[R / 8], __bf16 *hi, __bf16 *lo) {
-    const int t = threadIdx.x, kq = t & 7, rb = t >> 3;
-#pragma unroll
-    for (int u = 0; u < R / 32; ++u) {
-        bf16x4 h, l;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) EGP_SPLIT(v[4 * u + j], h, l, j);
-        const int off = (kq >> 1) * panel_el(R) + (rb + 32 * u) * 8 + (kq & 1) * 4;
-        *(bf16x4 *)(hi + off) = h;
-        if (LO) *(bf16x4 *)(lo + off) = l;
+// registers -> LDS: NIMG bf16 images of the tile (head, tail, second tail), `img` elements apart
+template <int NIMG>
+__device__ __forceinline__ void split_to(float x, __bf16 (&piece)[3]) {
+    const __bf16 h = (__bf16)x;                       // v_cvt_pk_bf16_f32: round to nearest even
+    piece[0] = h;
+    if constexpr (NIMG > 1) {
+        const float r1 = x - (float)h;                // exact
+        const __bf16 m = (__bf16)r1;
+        piece[1] = m;
+        if constexpr (NIMG > 2) piece[2] = (__bf16)(r1 - (float)m);
     }
 }
 
-// row-contiguous staging: 8 consecutive k (panel = wave) of row lane + 64 u -> one 16-byte store
-template <int R, bool LO>
-__device__ __forceinline__ void store_rc(const float (&v)[R / 8], __bf16 *hi, __bf16 *lo) {
+// k-contiguous staging: 4 consecutive k of row (t >> 3) + 32 u -> one 8-byte store per image
+template <int R, int NIMG>
+__device__ __forceinline__ void store_kc(const float (&v)[R / 8], __bf16 *dst, int img) {
+    const int t = threadIdx.x, kq = t & 7, rb = t >> 3;
+#pragma unroll
+    for (int u = 0; u < R / 32; ++u) {
+        bf16x4 q[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __bf16 pc[3];
+            split_to<NIMG>(v[4 * u + j], pc);
+#pragma unroll
+            for (int c = 0; c < NIMG; ++c) q[c][j] = pc[c];
+        }
+        const int off = (kq >> 1) * panel_el(R) + (rb + 32 * u) * 8 + (kq & 1) * 4;
+#pragma unroll
+        for (int c = 0; c < NIMG; ++c) *(bf16x4 *)(dst + c * img + off) = q[c];
+    }
+}
+
+// row-contiguous staging: 8 consecutive k (panel = wave) of row lane + 64 u -> one 16-byte store per image
+template <int R, int NIMG>
+__device__ __forceinline__ void store_rc(const float (&v)[R / 8], __bf16 *dst, int img) {
     const int t = threadIdx.x, l64 = t & 63, panel = t >> 6;
 #pragma unroll
     for (int u = 0; u < R / 64; ++u) {
-        bf16x8 h, l;
+        bf16x8 q[3];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) EGP_SPLIT(v[8 * u + j], h, l, j);
+        for (int j = 0; j < 8; ++j) {
+            __bf16 pc[3];
+            split_to<NIMG>(v[8 * u + j], pc);
+#pragma unroll
+            for (int c = 0; c < NIMG; ++c) q[c][j] = pc[c];
+        }
         const int off = panel * panel_el(R) + (l64 + 64 * u) * 8;
-        *(bf16x8 *)(hi + off) = h;
-        if (LO) *(bf16x8 *)(lo + off) = l;
+#pragma unroll
+        for (int c = 0; c < NIMG; ++c) *(bf16x8 *)(dst + c * img + off) = q[c];
     }
 }
 
@@ -165,14 +180,18 @@ __device__ __forceinline__ bool tile_of(const GemmArgs &g, int L, int &tm, int &
 
 template <int BN, int TERMS, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void k_gemm_bf16x(GemmArgs g) {
-    constexpr bool LO = TERMS > 1;
+    // TERMS = 1: bf16 x bf16;  3: two-piece operands, hi*hi + hi*lo + lo*hi (~16 mantissa bits per product);
+    // 6: three-piece operands, every cross term down to 2^-16 (float32-class products). The three images of TERMS = 6
+    // take one LDS buffer (two barriers per k-tile) so that two workgroups still fit a CU.
+    constexpr int NIMG = TERMS == 1 ? 1 : (TERMS == 3 ? 2 : 3);
+    constexpr int NBUF = TERMS == 6 ? 1 : 2;
     constexpr int WN = BN == 128 ? 2 : 1;                 // waves along n
     constexpr int MI = BN == 128 ? 2 : 1, NJ = 2;         // MFMA blocks per wave: rows x cols
     constexpr int WROWS = 32 * MI;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // per buffer: A hi | A lo | B hi | B lo
     constexpr int A_EL = tile_el(BM), B_EL = tile_el(BN);
-    constexpr int BUF_EL = (LO ? 2 : 1) * (A_EL + B_EL);
+    constexpr int BUF_EL = NIMG * (A_EL + B_EL);
     __bf16 *base = (__bf16 *)smem;
 
     int tm, tn;
@@ -208,39 +227,41 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x(GemmArgs g) {
     constexpr std::false_type FULL{};
     constexpr std::true_type TAIL{};
     auto sstore = [&](int buf, const float (&va)[BM / 8], const float (&vb)[BN / 8]) {
-        __bf16 *p = base + buf * BUF_EL;
-        __bf16 *ah = p, *al = p + A_EL, *bh = p + (LO ? 2 : 1) * A_EL, *bl = bh + B_EL;
-        if constexpr (A_KC) store_kc<BM, LO>(va, ah, al); else store_rc<BM, LO>(va, ah, al);
-        if constexpr (B_KC) store_kc<BN, LO>(vb, bh, bl); else store_rc<BN, LO>(vb, bh, bl);
+        if constexpr (NBUF == 1) __syncthreads();         // the single buffer is still being multiplied
+        __bf16 *pa = base + (buf & (NBUF - 1)) * BUF_EL, *pb = pa + NIMG * A_EL;
+        if constexpr (A_KC) store_kc<BM, NIMG>(va, pa, A_EL); else store_rc<BM, NIMG>(va, pa, A_EL);
+        if constexpr (B_KC) store_kc<BN, NIMG>(vb, pb, B_EL); else store_rc<BN, NIMG>(vb, pb, B_EL);
     };
     const int frow = lane & 31, fkh = lane >> 5;
     auto compute = [&](int buf) {
-        const __bf16 *p = base + buf * BUF_EL;
-        const __bf16 *ah = p, *al = p + A_EL, *bh = p + (LO ? 2 : 1) * A_EL, *bl = bh + B_EL;
+        const __bf16 *pa = base + (buf & (NBUF - 1)) * BUF_EL, *pb = pa + NIMG * A_EL;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 fa_h[MI], fa_l[MI], fb_h[NJ], fb_l[NJ];
+            bf16x8 fa[NIMG][MI], fb[NIMG][NJ];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int off = (2 * ks + fkh) * panel_el(BM) + (wm * WROWS + 32 * i + frow) * 8;
-                fa_h[i] = *(const bf16x8 *)(ah + off);
-                if (LO) fa_l[i] = *(const bf16x8 *)(al + off);
-            }
+            for (int c = 0; c < NIMG; ++c) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int off = (2 * ks + fkh) * panel_el(BN) + (wn * 64 + 32 * j + frow) * 8;
-                fb_h[j] = *(const bf16x8 *)(bh + off);
-                if (LO) fb_l[j] = *(const bf16x8 *)(bl + off);
+                for (int i = 0; i < MI; ++i)
+                    fa[c][i] = *(const bf16x8 *)(pa + c * A_EL + (2 * ks + fkh) * panel_el(BM) + (wm * WROWS + 32 * i + frow) * 8);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    fb[c][j] = *(const bf16x8 *)(pb + c * B_EL + (2 * ks + fkh) * panel_el(BN) + (wn * 64 + 32 * j + frow) * 8);
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    if (LO) {                             // small terms first
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_l[i], fb_h[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_h[i], fb_l[j], acc[i][j], 0, 0, 0);
+                    f32x16 a = acc[i][j];                 // smallest terms first
+                    if constexpr (NIMG == 3) {
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], a, 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_h[i], fb_h[j], acc[i][j], 0, 0, 0);
+                    if constexpr (NIMG >= 2) {
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], a, 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], a, 0, 0, 0);
                 }
         }
     };
@@ -402,7 +423,7 @@ int64_t egp_gemm_workspace_floats(int32_t M, int32_t N, int32_t ones_col, int32_
 int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     EGP_REQUIRE(d, "descriptor is NULL");
     EGP_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "negative size");
-    EGP_REQUIRE(d->terms == 1 || d->terms == 3, "terms must be 1 (bf16) or 3 (split float32)");
+    EGP_REQUIRE(d->terms == 1 || d->terms == 3 || d->terms == 6, "terms must be 1 (bf16), 3 (two-piece split) or 6 (three-piece split)");
     if (d->M == 0 || d->N + (d->bias_grad ? 1 : 0) == 0) return EGP_OK;
     EGP_REQUIRE(d->A && d->B && d->C, "NULL operand");
     const int ones = d->bias_grad ? 1 : 0;
@@ -430,11 +451,11 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     const int zs = d->K == 0 ? 1 : (d->K + g.k_per_split - 1) / g.k_per_split;
     g.xcd_order = g.tiles_m >= 64;
     dim3 grid((g.xcd_order ? ((g.tiles_m + 7) / 8) * 8 : g.tiles_m) * g.tiles_n, 1, zs);
-    const int lo = d->terms == 3 ? 2 : 1;
-    const size_t lds = (size_t)2 * lo * (tile_el(BM) + tile_el(BNv)) * sizeof(__bf16);
+    const int nimg = d->terms == 1 ? 1 : (d->terms == 3 ? 2 : 3), nbuf = d->terms == 6 ? 1 : 2;
+    const size_t lds = (size_t)nbuf * nimg * (tile_el(BM) + tile_el(BNv)) * sizeof(__bf16);
     int rc;
-    if (bn64) rc = d->terms == 3 ? launch_variant<64, 3>(g, grid, lds, s) : launch_variant<64, 1>(g, grid, lds, s);
-    else rc = d->terms == 3 ? launch_variant<128, 3>(g, grid, lds, s) : launch_variant<128, 1>(g, grid, lds, s);
+    if (bn64) rc = d->terms == 6 ? launch_variant<64, 6>(g, grid, lds, s) : d->terms == 3 ? launch_variant<64, 3>(g, grid, lds, s) : launch_variant<64, 1>(g, grid, lds, s);
+    else rc = d->terms == 6 ? launch_variant<128, 6>(g, grid, lds, s) : d->terms == 3 ? launch_variant<128, 3>(g, grid, lds, s) : launch_variant<128, 1>(g, grid, lds, s);
     if (rc != EGP_OK) return rc;
     if (partial) {
         const long total = (long)d->M * n_out;

@@ -1,5 +1,5 @@
 """float32 matrix products of the PPO update through `egp_gemm_f32` (csrc/egp_gemm.hip): bf16 matrix cores with split
-operands (three MFMAs per product, float32-class accuracy at ~5x the float32 MFMA rate), bias / ReLU / dReLU fused into
+operands (every float32 value as a sum of bf16 pieces, float32-class products), bias / ReLU / dReLU fused into
 the epilogues, deterministic split-K weight gradients that also return the bias gradient.
 
   linear_fwd(x, W, b, relu)          y = x W^T + b        (nn.Linear of models/mlp.py:22-25, core/policy_gaussian.py:19-24)
@@ -8,8 +8,8 @@ the epilogues, deterministic split-K weight gradients that also return the bias 
   mlp_head(x, hidden_layers, head)   the reference's `head(MLP(x))` as ONE autograd node: activations saved once, every
                                      ReLU derivative applied inside the producing data-gradient product
 
-`EGP_GEMM=torch` keeps every product on the library path (rocBLAS / hipBLASLt through torch); `EGP_GEMM_TERMS=1` runs
-plain bf16 inputs (one MFMA per product, ~3e-3 relative error) instead of the default 3.
+`EGP_GEMM=torch` keeps every product on the library path (rocBLAS / hipBLASLt through torch); `EGP_GEMM_TERMS` picks the
+operand split: 6 (default: three bf16 pieces, float32-class products), 3 (two pieces, ~16 mantissa bits) or 1 (plain bf16).
 """
 from __future__ import annotations
 
@@ -28,7 +28,12 @@ def enabled():
 
 
 def default_terms():
-    return 1 if os.environ.get("EGP_GEMM_TERMS", "3") == "1" else 3
+    """Pieces per operand / MFMAs per product: 6 = three bf16 pieces, every cross term down to 2^-16 (float32-class
+    products, the default); 3 = two pieces (~16 mantissa bits); 1 = plain bf16 inputs."""
+    t = os.environ.get("EGP_GEMM_TERMS", "6")
+    if t not in ("1", "3", "6"):
+        raise ValueError("EGP_GEMM_TERMS must be 1, 3 or 6, got %r" % t)
+    return int(t)
 
 
 def _workspace(n_floats, device):

@@ -29,9 +29,10 @@ def _operands(M, N, K, a_kc, b_kc, seed):
 def test_products_match_float64(a_kc, b_kc, M, N, K):
     from egopose_amd.gemm import gemm
     A, B, ref = _operands(M, N, K, a_kc, b_kc, seed=M + 7 * N + 13 * K)
+    c6 = gemm(A, B, a_kc, b_kc, terms=6)
     c3 = gemm(A, B, a_kc, b_kc, terms=3)
     c1 = gemm(A, B, a_kc, b_kc, terms=1)
-    assert c3.shape == (M, N)
+    assert c3.shape == (M, N) and c6.shape == (M, N)
     assert _rel(c3, ref) < 2e-5, "split-operand product must be float32-class"
     assert _rel(c1, ref) < 6e-3
     # element-wise: 2^-15 of the sum of the magnitudes of the K products
@@ -41,6 +42,9 @@ def test_products_match_float64(a_kc, b_kc, M, N, K):
     lib = A.double() if a_kc else A.t().double()
     f32 = (lib.float() @ (B.t() if b_kc else B)).double()          # the library's float32 product, for scale
     assert _rel(c3, ref) < max(40 * _rel(f32, ref), 1.6e-5)
+    # three-piece operands: float32-class (the library's float32 product is the yardstick)
+    assert _rel(c6, ref) < max(3 * _rel(f32, ref), 2e-7), (_rel(c6, ref), _rel(f32, ref))
+    assert ((c6.double() - ref).abs() <= 8e-7 * (A64 @ B64) + 1e-30).all()
 
 
 def test_rows_with_4_byte_alignment_and_strided_views():
@@ -110,6 +114,8 @@ def test_bad_arguments_are_refused():
         gemm(a.double(), b.double())
     with pytest.raises(ValueError):
         gemm(a, b, terms=2)
+    with pytest.raises(ValueError):
+        gemm(a, b, terms=4)
     with pytest.raises(ValueError):
         gemm(a, b, splits=2, bias=torch.zeros(5, device="cuda"))
     with pytest.raises(ValueError):

@@ -82,13 +82,15 @@ def _count_calls(monkeypatch, module, name):
 
 @pytest.mark.parametrize("mode", ["float32", "float64-masters"])
 @pytest.mark.parametrize("buckets", [False, True])
-@pytest.mark.parametrize("gemms", ["hip", "torch"])
+@pytest.mark.parametrize("gemms", ["hip", "hip-2piece", "torch"])
 def test_update_params_float32_hip_path_matches_reference(kctx, mode, buckets, gemms, monkeypatch):
     """The update bench.py times, pinned to the reference's float64 run of the same batch.
-    gemms = "hip": every product through egp_gemm_f32 (bf16 matrix cores, operands split in two: ~16 mantissa bits per
-    product); "torch": the library's float32 products (EGP_GEMM=torch)."""
+    gemms = "hip": every product through egp_gemm_f32 on the bf16 matrix cores with three-piece operands (float32-class
+    products; the default); "hip-2piece": two-piece operands (EGP_GEMM_TERMS=3, ~16 mantissa bits per product);
+    "torch": the library's float32 products (EGP_GEMM=torch)."""
     from egopose_amd import gemm_tuning, lstm
-    monkeypatch.setenv("EGP_GEMM", gemms)
+    monkeypatch.setenv("EGP_GEMM", "torch" if gemms == "torch" else "hip")
+    monkeypatch.setenv("EGP_GEMM_TERMS", "3" if gemms == "hip-2piece" else "6")
     g = load_golden("ppo_update_h128.npz")
     if buckets:     # the bucket padding engages at >= 4 buckets of rows / episodes: shrink the buckets to this batch
         monkeypatch.setattr(gemm_tuning, "ROW_BUCKET", 64)
@@ -111,11 +113,11 @@ def test_update_params_float32_hip_path_matches_reference(kctx, mode, buckets, g
         np.testing.assert_allclose(v0, g["values0"], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(r, g["ret0"], rtol=1e-4, atol=1e-5)          # north_star tolerance
         np.testing.assert_allclose(a, g["adv0"], rtol=1e-4, atol=1e-4)
-        if gemms == "torch":
+        if gemms != "hip-2piece":
             # float32 round-off against float64; a handful of elements with a ~0 gradient may take Adam's other +-lr step
             check_final(mods, g, rtol=1e-4, atol=3e-6, max_outliers=8, outlier_atol=1.3e-2)
         else:
-            # split-operand products carry 2^-16 instead of 2^-24 per product. Adam divides every gradient element by
+            # two-piece products carry 2^-16 instead of 2^-24 per product. Adam divides every gradient element by
             # its own running magnitude, so the elements whose gradient is smaller than that round-off (about 1 % of them
             # here) take a visibly different step: at most 5 % of one step (lr = 2e-3 -> 1e-4 per epoch); everything
             # else stays within the float32 tolerance
