@@ -19,7 +19,8 @@ Prints ONE JSON line (rank 0) with the driver's fields plus
   kernels      K1-K6 / K8 with inputs resident in HBM at 1 024 and 65 536 envs: the figures an HBM roofline can bind
   legs         (1 GPU) the same workload (i) through the float64 driver set-up of the unmodified reference
                (`dropin_env_steps_per_s`), (ii) with an inertia that changes on every substep fed from the host (the
-               traffic of a MuJoCo-like backend), (iii) with that inertia computed on the GPU (row f1)
+               traffic of a MuJoCo-like backend), (iii) with that inertia computed on the GPU (row f1), (iv) the
+               ego_forecast nets of BASELINE config 5 on this GPU's 1 024-slot shard
   cpu_baseline the oracle's restatement of the reference CPU sampler (2 forked workers, float64, OMP=1) on a
                bounded sample, same physics backend (rank 0, N=1 only)
 """
@@ -308,12 +309,13 @@ def main():
     thr0 = cgroup_throttle()
     barrier()
     t0 = time.time()
-    steps_local, t_sample, t_update = 0, 0.0, 0.0
+    steps_local, t_sample, t_update, per_iter = 0, 0.0, 0.0, []
     for _ in range(args.steps):
         log, ts, tu, n = tr.iteration(it, min_batch)
         steps_local += n
         t_sample += ts
         t_update += tu
+        per_iter.append((round(ts * 1e3, 1), round(tu * 1e3, 1)))
         it += 1
     barrier()
     elapsed = time.time() - t0
@@ -337,7 +339,7 @@ def main():
                        "host_cpus_pinned": (len(eng.pinned_cpus) if eng.pinned_cpus else None),
                        "parallelism": "dp%d" % world},
             "env_steps": total_steps, "rollout_only_env_steps_per_s": steps_local / max(t_sample, 1e-9) * world,
-            "t_sample_s": t_sample, "t_update_s": t_update,
+            "t_sample_s": t_sample, "t_update_s": t_update, "per_iteration_ms_sample_update": per_iter,
             "host_cgroup_throttled": None if not (thr0 and thr1) else {"events": thr1[0] - thr0[0], "usec_all_threads": thr1[1] - thr0[1]},
             "rollout_timing": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ro.timing.items()},
         })
@@ -367,6 +369,11 @@ def main():
                 "changing_inertia_device_dynamics": run_leg(mk32, args.leg_steps, 1, min_batch, ev,
                                                             {"EGP_SURROGATE_ALWAYS_DIRTY": "1", "EGP_DEVICE_DYNAMICS": "1"}),
             }
+            # BASELINE config 5's nets on this GPU's shard (1 of the 4 x 1 024 env slots): VideoForecastNet front ends,
+            # per-tick state LSTM, 90-step episodes, decayed reward
+            mkf = lambda: Trainer(ForecastConfig(args.cfg, create_dirs=False), dev, torch.float32, num_envs=args.envs,
+                                  num_threads=n_threads, num_groups=args.groups)
+            legs["egoforecast_config5_shard"] = run_leg(mkf, args.leg_steps, 1, min_batch, ev)
             res["legs"] = {k: {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items()} for k, v in legs.items()}
             res["dropin_env_steps_per_s"] = legs["dropin_float64_driver"].get("env_steps_per_s")
         if not args.no_cpu_baseline:

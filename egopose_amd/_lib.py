@@ -122,6 +122,8 @@ SIGNATURES = {
     "egp_gae_standardize_f64": (C.c_int, [vp, _i32, vp, vp]),
     "egp_gae_standardize_f32": (C.c_int, [vp, _i32, vp, vp]),
     "egp_lstm_gate_layout": (_i32, []),
+    "egp_gather_concat_f32": (C.c_int, [vp, _i64, vp, vp, _i64, _i32, _i32, _i32, vp, _i64, vp]),
+    "egp_scatter_rows_f32": (C.c_int, [vp, _i64, vp, _i32, _i32, vp, _i64, vp]),
     "egp_gemm_workspace_floats": (_i64, [_i32, _i32, _i32, _i32]),
     "egp_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "egp_lstm_fwd_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp]),

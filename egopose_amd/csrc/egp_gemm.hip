@@ -391,6 +391,26 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const float *__restrict__ w
     }
 }
 
+// ---- the policy / value input of the update: out[i] = [ ctx[idx[i]][0:H] | x[i][0:S] ]  (models/video_state_net.py:65-69:
+// the gather of the per-sample video context and the concatenation with the state in one pass), and its adjoint for the
+// context rows (every context row is gathered at most once, so the scatter needs no atomics; rows nobody gathered keep
+// the zeros they were initialised with).
+__global__ __launch_bounds__(256) void k_gather_concat(const float *__restrict__ ctx, long ld_ctx, const long long *__restrict__ idx,
+                                                       const float *__restrict__ x, long ldx, int H, int S, float *__restrict__ out, long ldo) {
+    const long i = blockIdx.x;
+    const float *c = ctx + idx[i] * ld_ctx, *xs = x + i * ldx;
+    float *o = out + i * ldo;
+    for (int j = threadIdx.x; j < H + S; j += 256) o[j] = j < H ? c[j] : xs[j - H];
+}
+
+__global__ __launch_bounds__(256) void k_scatter_rows(const float *__restrict__ dout, long ldd, const long long *__restrict__ idx, int H,
+                                                      float *__restrict__ dctx, long ld_ctx) {
+    const long i = blockIdx.x;
+    const float *d = dout + i * ldd;
+    float *c = dctx + idx[i] * ld_ctx;
+    for (int j = threadIdx.x; j < H; j += 256) c[j] = d[j];
+}
+
 template <int BN, int TERMS>
 int launch_variant(const GemmArgs &g, dim3 grid, size_t lds, hipStream_t s) {
 #define EGP_GEMM_LAUNCH(AK, BKC)                                                                                      \
@@ -414,6 +434,23 @@ int launch_variant(const GemmArgs &g, dim3 grid, size_t lds, hipStream_t s) {
 }  // namespace
 
 extern "C" {
+
+int egp_gather_concat_f32(const float *ctx, int64_t ld_ctx, const int64_t *idx, const float *x, int64_t ldx, int32_t n, int32_t H, int32_t S,
+                          float *out, int64_t ldo, void *stream) {
+    EGP_REQUIRE(n >= 0 && H >= 0 && S >= 0, "negative size");
+    if (n == 0 || H + S == 0) return EGP_OK;
+    EGP_REQUIRE(ctx && idx && out && (x || S == 0), "NULL pointer");
+    k_gather_concat<<<dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream>>>(ctx, ld_ctx, (const long long *)idx, x, ldx, H, S, out, ldo);
+    return after_launch("k_gather_concat");
+}
+
+int egp_scatter_rows_f32(const float *dout, int64_t ldd, const int64_t *idx, int32_t n, int32_t H, float *dctx, int64_t ld_ctx, void *stream) {
+    EGP_REQUIRE(n >= 0 && H >= 0, "negative size");
+    if (n == 0 || H == 0) return EGP_OK;
+    EGP_REQUIRE(dout && idx && dctx, "NULL pointer");
+    k_scatter_rows<<<dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream>>>(dout, ldd, (const long long *)idx, H, dctx, ld_ctx);
+    return after_launch("k_scatter_rows");
+}
 
 int64_t egp_gemm_workspace_floats(int32_t M, int32_t N, int32_t ones_col, int32_t splits) {
     if (splits <= 1 && !ones_col) return 0;

@@ -170,3 +170,34 @@ def mlp_head(x, layers, head, n_grad_cols=None):
         params += [l.weight, l.bias]
     nc = x.shape[1] if n_grad_cols is None else int(n_grad_cols)
     return MlpHead.apply(x, nc, *params)
+
+
+class GatherConcat(torch.autograd.Function):
+    """out[i] = [ctx2d[idx[i]] | x[i]] (`egp_gather_concat_f32`); gradient to ctx2d only (idx must not repeat)."""
+
+    @staticmethod
+    def forward(ctx, ctx2d, idx, x):
+        n, H, S = idx.shape[0], ctx2d.shape[1], x.shape[1]
+        out = torch.empty(n, H + S, dtype=torch.float32, device=x.device)
+        L.check(L.load().egp_gather_concat_f32(ctx2d.data_ptr(), _ld(ctx2d), idx.data_ptr(), x.data_ptr(), _ld(x), n, H, S,
+                                               out.data_ptr(), H + S, L.current_stream()), "egp_gather_concat_f32")
+        ctx.save_for_backward(idx)
+        ctx.shape = tuple(ctx2d.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        R, H = ctx.shape
+        dout = _mat(dout if dout.stride(1) == 1 else dout.contiguous(), "dout")
+        dctx = torch.zeros(R, H, dtype=torch.float32, device=dout.device)
+        L.check(L.load().egp_scatter_rows_f32(dout.data_ptr(), _ld(dout), idx.data_ptr(), idx.shape[0], H, dctx.data_ptr(), H,
+                                              L.current_stream()), "egp_scatter_rows_f32")
+        return dctx, None, None
+
+
+def gather_concat_available(ctx2d, idx, x):
+    return (enabled() and x.is_cuda and ctx2d.dtype == torch.float32 and x.dtype == torch.float32 and ctx2d.dim() == 2 and x.dim() == 2
+            and ctx2d.is_contiguous() and x.stride(1) == 1 and idx.dtype == torch.int64 and idx.is_contiguous() and not x.requires_grad)

@@ -263,6 +263,7 @@ class VideoStateNet(nn.Module):
         self.indices = None
         self.gather_indices = None
         self._gather_tm = None
+        self._gather_unique = False
         self.cnn_feat_ctx = None
         self._buckets = None
         self._v_ctx = None
@@ -337,7 +338,9 @@ class VideoStateNet(nn.Module):
         self.gather_indices = torch.as_tensor(idx, dtype=torch.long, device=device)
         # the same rows addressed in the net's own (time, episode) order: forward() gathers straight from the LSTM output
         # instead of slicing off the margins, transposing and copying it first
-        self._gather_tm = torch.as_tensor(((idx % max_len) + m) * self.cnn_feat_ctx.shape[1] + idx // max_len, dtype=torch.long, device=device)
+        tm = ((idx % max_len) + m) * self.cnn_feat_ctx.shape[1] + idx // max_len
+        self._gather_tm = torch.as_tensor(tm, dtype=torch.long, device=device)
+        self._gather_unique = np.unique(tm).size == tm.size      # (always, for a batch cut into episodes: the scatter of the backward pass relies on it)
         self._ctx_key = (int(max_len), meta.shape[0], hash(meta.tobytes()))       # which windows cnn_feat_ctx holds
         # Length buckets for the forward direction: its output at frame t only depends on frames <= t and only frames
         # [m, m + len_e) of an episode are ever gathered, so episodes sorted by length let the forward LSTM stop early
@@ -385,7 +388,10 @@ class VideoStateNet(nn.Module):
                 ctx = None                   # left over from a pass in the other autograd mode: never reuse it
         if ctx is None:
             ctx = self.forward_v_net(self.cnn_feat_ctx)
-        return torch.cat((ctx.reshape(-1, self.v_hdim).index_select(0, self._gather_tm), x), dim=1)
+        ctx2d = ctx.reshape(-1, self.v_hdim)
+        if self._gather_unique and _gemm.gather_concat_available(ctx2d, self._gather_tm, x):
+            return _gemm.GatherConcat.apply(ctx2d, self._gather_tm, x)          # gather + concatenation in one pass
+        return torch.cat((ctx2d.index_select(0, self._gather_tm), x), dim=1)
 
 
 class Bf16Shadow:

@@ -252,6 +252,13 @@ typedef struct egp_gemm_desc {
     float *bias_grad;
     float *workspace;
 } egp_gemm_desc;
+/* The update's policy / value input in one pass (VideoStateNet.forward('train'), models/video_state_net.py:65-69):
+ * out[i] = [ ctx[idx[i]][0:H] | x[i][0:S] ] for i < n, and the adjoint for the context rows, dctx[idx[i]][0:H] = dout[i][0:H]
+ * (idx must not repeat: every (time, episode) row of the video net's output belongs to one sample; dctx is zero-filled by
+ * the caller). Row strides in elements. */
+int egp_gather_concat_f32(const float *ctx, int64_t ld_ctx, const int64_t *idx, const float *x, int64_t ldx, int32_t n, int32_t H, int32_t S,
+                          float *out, int64_t ldo, void *stream);
+int egp_scatter_rows_f32(const float *dout, int64_t ldd, const int64_t *idx, int32_t n, int32_t H, float *dctx, int64_t ld_ctx, void *stream);
 int64_t egp_gemm_workspace_floats(int32_t M, int32_t N, int32_t ones_col, int32_t splits);
 int egp_gemm_f32(const egp_gemm_desc *desc, void *stream);
 

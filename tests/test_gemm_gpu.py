@@ -164,3 +164,24 @@ def test_mlp_head_node_matches_torch_autograd(head_dim):
         assert _rel(a, l.double()) < 5e-3
     # without activation-derivative flips in the way (the head layer sees none): float32-class
     assert _rel(got[-2], ref[-2]) < 5e-5 and _rel(got[-1], ref[-1]) < 5e-5
+
+
+def test_gather_concat_node_matches_torch():
+    """`egp_gather_concat_f32` / `egp_scatter_rows_f32` (the update's policy input, models/video_state_net.py:65-69)
+    against index_select + cat under torch autograd, bit for bit (pure data movement)."""
+    from egopose_amd.gemm import GatherConcat, gather_concat_available
+    g = torch.Generator(device="cuda").manual_seed(2)
+    R, H, S, n = 977, 128, 115, 611
+    ctx = torch.randn(R, H, device="cuda", generator=g, requires_grad=True)
+    x = torch.randn(n, S, device="cuda", generator=g)
+    idx = torch.randperm(R, device="cuda", generator=g)[:n].contiguous()
+    assert gather_concat_available(ctx, idx, x)
+    out = GatherConcat.apply(ctx, idx, x)
+    w = torch.randn(n, H + S, device="cuda", generator=g)
+    (out * w).sum().backward()
+    got = ctx.grad.clone()
+    ctx.grad = None
+    ref = torch.cat((ctx.index_select(0, idx), x), 1)
+    (ref * w).sum().backward()
+    assert torch.equal(out, ref) and torch.equal(got, ctx.grad)
+    assert not gather_concat_available(ctx, idx, x.clone().requires_grad_(True))       # state gradients: the torch path
