@@ -326,23 +326,55 @@ class AgentPPO(AgentPG):
         clipped = torch.clamp(ratio, 1.0 - self.clip_epsilon, 1.0 + self.clip_epsilon) * adv
         return -torch.min(ratio * adv, clipped).sum() / n_exp
 
-    def update_policy(self, states, actions, returns, advantages, exps):
+    def _exploration_rows(self, exps, n):
+        """Rows with exps == 1 (agents/agent_ppo.py:45-46), or None when that is every row (no gather copies)."""
+        ind = exps.nonzero().squeeze(1)
+        return (None if ind.shape[0] == n else ind), ind.shape[0]
+
+    def _surrogate(self, logp, adv, fixed, n_exp):
+        ratio = torch.exp(logp - fixed)
+        clipped = torch.clamp(ratio, 1.0 - self.clip_epsilon, 1.0 + self.clip_epsilon) * adv
+        return -torch.min(ratio * adv, clipped).sum() / n_exp
+
+    def update_policy(self, states, actions, returns, advantages, exps, first_pass=None):
+        """`first_pass` = (pred, logp, ind) of a forward pass ALREADY made with the current weights and autograd on
+        (AgentEgo.update_params): it served as the no-grad value / fixed-log-prob pass and now is epoch 0's forward --
+        the weights have not moved in between, so the numbers are the reference's, with two forward passes fewer."""
         if self.use_mini_batch:
             raise NotImplementedError("mini-batch PPO is not on the ego_mimic path (AgentEgo forces full batch)")
-        with to_test(*self.update_modules):
-            with torch.no_grad():
-                fixed_log_probs = self.cn.policy_net.get_log_prob(self.trans_policy(states), actions)
-        ind = exps.nonzero().squeeze(1)
         n_val = D.global_count(states.shape[0], states.device)
-        n_exp = D.global_count(ind.shape[0], states.device)
-        if ind.shape[0] == states.shape[0]:
-            ind = None                       # every sample is an exploration sample: nothing to select
+        if first_pass is None:
+            with to_test(*self.update_modules):
+                with torch.no_grad():
+                    fixed_log_probs = self.cn.policy_net.get_log_prob(self.trans_policy(states), actions)
+            ind, n_ind = self._exploration_rows(exps, states.shape[0])
+        else:
+            pred0, logp0, ind = first_pass
+            n_ind = states.shape[0] if ind is None else ind.shape[0]
+            fixed_sel = logp0.detach()
+            fixed_log_probs = None
+        n_exp = D.global_count(n_ind, states.device)
         losses = []
-        for _ in range(self.opt_num_epochs):
+        for epoch in range(self.opt_num_epochs):
             # critic and actor have disjoint parameters: both backward passes run before the single gradient
             # exchange; the value step precedes the policy step as in the reference. (Running the two passes on two
             # HIP streams was faster and hung the GPU intermittently -- concurrent library GEMMs, DESIGN section 2.)
-            if self._group_contexts(states):
+            if first_pass is not None and epoch == 0:
+                v_loss = (pred0 - returns).pow(2).sum() / n_val
+                adv = advantages if ind is None else advantages[ind]
+                s_loss = self._surrogate(logp0, adv, fixed_sel, n_exp)
+                self._zero_grads()
+                (v_loss + s_loss).backward()
+            elif first_pass is not None:
+                self._group_contexts(states)
+                pred = self.cn.value_net(self.trans_value(states))
+                v_loss = (pred - returns).pow(2).sum() / n_val
+                x = self.trans_policy(states)
+                logp = self.cn.policy_net.get_log_prob(x if ind is None else x[ind], actions if ind is None else actions[ind])
+                s_loss = self._surrogate(logp, advantages if ind is None else advantages[ind], fixed_sel, n_exp)
+                self._zero_grads()
+                (v_loss + s_loss).backward()
+            elif self._group_contexts(states):
                 # both video nets' recurrences in one grouped launch each way; disjoint parameters, so one backward
                 # over the sum of the two losses yields exactly the two separate gradients
                 if self.value_opt_niter != 1:
@@ -435,12 +467,23 @@ class AgentEgo(AgentPPO):
         for net in vs_nets:
             net.set_mode("train")
             net.initialize((c["masks"], self.env.cnn_feat, v_metas))
-        with to_test(*self.update_modules):
-            with torch.no_grad():
-                self._group_contexts(c["states"])       # the policy net's context is consumed by update_policy's first pass
-                values = self.cn.value_net(self.trans_value(c["states"]))
-        advantages, returns = self._advantages(c["rewards"], c["masks"], values)
-        self.update_policy(c["states"], c["actions"], returns, advantages, c["exps"])
+        if self.value_opt_niter == 1 and os.environ.get("EGP_REUSE_FIRST_PASS", "1") != "0":
+            # ONE forward pass with autograd on serves three purposes: the values that GAE consumes, the fixed log-probs of
+            # the surrogate, and epoch 0's forward (nothing has stepped in between; no dropout / batch norm in these nets)
+            self._group_contexts(c["states"])
+            pred0 = self.cn.value_net(self.trans_value(c["states"]))
+            ind, _ = self._exploration_rows(c["exps"], c["states"].shape[0])
+            x = self.trans_policy(c["states"])
+            logp0 = self.cn.policy_net.get_log_prob(x if ind is None else x[ind], c["actions"] if ind is None else c["actions"][ind])
+            advantages, returns = self._advantages(c["rewards"], c["masks"], pred0.detach())
+            self.update_policy(c["states"], c["actions"], returns, advantages, c["exps"], first_pass=(pred0, logp0, ind))
+        else:
+            with to_test(*self.update_modules):
+                with torch.no_grad():
+                    self._group_contexts(c["states"])       # the policy net's context is consumed by update_policy's first pass
+                    values = self.cn.value_net(self.trans_value(c["states"]))
+            advantages, returns = self._advantages(c["rewards"], c["masks"], values)
+            self.update_policy(c["states"], c["actions"], returns, advantages, c["exps"])
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         return time.time() - t0

@@ -107,8 +107,9 @@ def test_update_params_float32_hip_path_matches_reference(kctx, mode, buckets, g
         _spy_gae(agent, kctx)
         agent.update_params(batch_of(g))
         torch.cuda.synchronize()
-        # 1 no-grad values pass + 3 epochs, every one through the grouped HIP recurrences (4 sweeps per launch)
-        assert len(group_calls) >= 1 + 3, "the persistent HIP LSTM did not run: %r" % (group_calls,)
+        # 3 epochs (the first one's forward also serves as the value / fixed-log-prob pass), every one through the
+        # grouped HIP recurrences (4 sweeps per launch)
+        assert len(group_calls) == 3, "the persistent HIP LSTM did not run as expected: %r" % (group_calls,)
         a, r, v0 = agent._seen
         np.testing.assert_allclose(v0, g["values0"], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(r, g["ret0"], rtol=1e-4, atol=1e-5)          # north_star tolerance
@@ -186,3 +187,21 @@ def test_video_state_net_train_mode_hip_lstm_matches_reference(grouped, monkeypa
     assert len(calls) == 1            # the bi-LSTM is one grouped launch either way (2 or 4 problems)
     rows = g["policy_in0_rows"]
     np.testing.assert_allclose(out.double().cpu().numpy()[rows], g["policy_in0"], rtol=2e-5, atol=2e-6)
+
+
+def test_reusing_the_first_forward_pass_changes_nothing(kctx, monkeypatch):
+    """EGP_REUSE_FIRST_PASS (default on): the forward that yields the values for GAE and the fixed log-probs is also
+    epoch 0's forward. Against the separate no-grad passes of the reference's flow: same parameters to round-off."""
+    g = load_golden("ppo_update_h128.npz")
+    outs = []
+    for reuse in ("1", "0"):
+        monkeypatch.setenv("EGP_REUSE_FIRST_PASS", reuse)
+        agent, mods = build_agent(g, device="cuda", dtype=torch.float32, fused_adam=True)
+        _attach_tables(agent, g, torch.float32)
+        _spy_gae(agent, kctx)
+        agent.update_params(batch_of(g))
+        outs.append(({k: v.clone() for m in mods.values() for k, v in m.state_dict().items()}, agent._seen))
+    (p1, s1), (p0, s0) = outs
+    np.testing.assert_allclose(s1[2], s0[2], rtol=1e-6, atol=1e-7)          # values (inference vs training LSTM kernels)
+    for k in p1:
+        np.testing.assert_allclose(p1[k].cpu().numpy(), p0[k].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
