@@ -258,7 +258,9 @@ def main():
         if not args.dry_run:
             import torch
             have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-            if have < args.gpus:
+            # EGP_BENCH_SHARE_GPU=1 (self-test of the multi-rank path on a one-GPU box, with EGP_DIST_BACKEND=gloo): ranks
+            # then share devices round-robin -- not a measurement
+            if have < args.gpus and not (have >= 1 and os.environ.get("EGP_BENCH_SHARE_GPU") == "1"):
                 raise SystemExit("--gpus %d but this node shows %d GPU(s)" % (args.gpus, have))
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if env_world is not None and int(env_world) != args.gpus:
@@ -328,6 +330,7 @@ def main():
         res = base_line(args, world, total_steps, elapsed)
         res.update({
             "dtype": "f64 (rollout kernels K1-K6, physics state) + f32 (policy/value nets)", "data": "synthetic",
+            "ranks_share_gpus": bool(world > torch.cuda.device_count()),
             "config": {"workload": ("ego_mimic %s, %d lockstep env slots per MI355X, precomputed (synthetic) CNN features, "
                                     "MLP policy/value + bi-LSTM video context, PPO 10 full-batch epochs" % (args.cfg, args.envs))
                        if args.task == "egomimic" else

@@ -49,3 +49,24 @@ def test_a_failing_rank_stops_the_launch():
     out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "x"], env=_env(), capture_output=True,
                          text=True, timeout=120)
     assert out.returncode != 0 and "{" not in out.stdout
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_ranks_through_the_launcher_on_a_gpu():
+    """The whole multi-rank path on real hardware: bench.py starts two ranks itself; with one GPU on the box they share it
+    and exchange through gloo (EGP_BENCH_SHARE_GPU=1: a self-test, not a measurement) -- env shards per rank, advantage /
+    filter / logger moments merged, one flat gradient all-reduce per epoch, rank-0 line with the summed env-steps."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT")}
+    env.update(EGP_BENCH_SHARE_GPU="1", EGP_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "1", "--envs", "128", "--min-batch", "2048",
+                          "--threads", "3"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["parallelism"] == "dp2" and r["scaling"] == "weak"
+    assert r["env_steps"] >= 2 * 2048 and r["value"] > 0 and r["roofline"] is not None
+    assert "legs" not in r and "cpu_baseline" not in r          # 1-GPU extras only
