@@ -31,6 +31,7 @@ class ModelDesc(C.Structure):
         ("k_p", C.c_double), ("k_v", C.c_double), ("k_e", C.c_double), ("k_rh", C.c_double), ("k_rq", C.c_double),
         ("k_rl", C.c_double), ("k_ra", C.c_double),
         ("v_ord", C.c_double), ("decay", C.c_int32),
+        ("obs_heading", C.c_int32), ("obs_keep_root_heading", C.c_int32), ("obs_coord_root", C.c_int32), ("obs_vel", C.c_int32),
     ]
 
 
@@ -94,6 +95,7 @@ _i32, _i64, _f64 = C.c_int32, C.c_int64, C.c_double
 SIGNATURES = {
     "egp_last_error": (C.c_char_p, []),
     "egp_version": (C.c_char_p, []),
+    "egp_obs_dim": (_i32, [vp]),
     "egp_create": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(vp)]),
     "egp_destroy": (C.c_int, [vp]),
     "egp_set_reward_weights": (C.c_int, [vp, C.POINTER(ModelDesc)]),

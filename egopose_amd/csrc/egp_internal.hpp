@@ -49,6 +49,8 @@ struct DevModel {
     const double *b_diffw;        // [nbody-1]
     double sub_dt;                // model timestep
     double dt;                    // env step = frame_skip * sub_dt
+    int obs_heading, obs_keep, obs_root, obs_vel;   // observation variants (egp_model_desc), all 0 = the shipped configs
+    int obs_dim;                  // width of an observation row
 };
 
 }  // namespace egp

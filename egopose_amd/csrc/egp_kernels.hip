@@ -65,12 +65,30 @@ __global__ __launch_bounds__(256) void k_body_quat(DevModel m, const T *__restri
 // ============================================================================================ K3
 // get_full_obs (ego_pose/envs/humanoid_v1.py:73-96): obs = [qpos[2:] (root quat de-headed), qvel
 // (root linear velocity in the heading frame)]
-// one element of get_full_obs for env row (q, v): column c of [qpos[2:] (root quat de-headed), qvel (root
-// linear velocity in the heading frame)]
+// Observation variants (cfg.obs_heading / root_deheading / obs_coord / obs_vel), all zero for every shipped config.
+struct ObsOpt { int heading, keep, root, vel, np, nv; };
+__host__ __device__ inline ObsOpt obs_opt_of(const DevModel &m) { return ObsOpt{m.obs_heading, m.obs_keep, m.obs_root, m.obs_vel, m.nq - 2, m.nv}; }
+__host__ __device__ inline int obs_width(int nq, int nv, int heading, int vel) {
+    return (heading ? 1 : 0) + (nq - 2) + (vel == 0 ? nv : (vel == 1 ? 6 : 0));
+}
+
+// one element of get_full_obs (humanoid_v1.py:73-96) for env row (q, v): column c of
+// [heading]? ++ qpos[2:] (root quat de-headed unless `keep`) ++ {qvel | qvel[:6] | -} (root linear velocity in the
+// heading frame, or in the root frame with `root`)
 template <typename T>
-__device__ __forceinline__ T obs_element(const T *q, const T *v, int np, int c) {
+__device__ __forceinline__ T obs_element(const T *q, const T *v, const ObsOpt &o, int c) {
+    if (o.heading) {
+        if (c == 0) {        // get_heading (utils/math.py:70-77): angle of the yaw-only quaternion, z made non-negative
+            T w = q[3], z = q[6];
+            if (z < T(0)) { w = -w; z = -z; }
+            if (sizeof(T) == 8) return T(2) * t_acos<T>(w / t_sqrt<T>(w * w + z * z));
+            return T(2) * (T)atan2f((float)z, (float)w);          // float32: acos loses its digits near w = 1
+        }
+        c -= 1;
+    }
+    const int np = o.np;
     T out;
-    if (c >= 1 && c <= 4) {
+    if (c >= 1 && c <= 4 && !o.keep) {
         Q4<T> r{q[3], q[4], q[5], q[6]};
         Q4<T> d = de_heading(r);
         out = c == 1 ? d.w : (c == 2 ? d.x : (c == 3 ? d.y : d.z));
@@ -79,9 +97,9 @@ __device__ __forceinline__ T obs_element(const T *q, const T *v, int np, int c) 
     } else if (c < np + 3) {
         Q4<T> r{q[3], q[4], q[5], q[6]};
         V3<T> lv{v[0], v[1], v[2]};
-        V3<T> o = rotate_T(heading_q(r), lv);
+        V3<T> w = rotate_T(o.root ? r : heading_q(r), lv);
         const int k = c - np;
-        out = k == 0 ? o.x : (k == 1 ? o.y : o.z);
+        out = k == 0 ? w.x : (k == 1 ? w.y : w.z);
     } else {
         out = v[c - np];
     }
@@ -91,11 +109,11 @@ __device__ __forceinline__ T obs_element(const T *q, const T *v, int np, int c) 
 template <typename T>
 __global__ __launch_bounds__(256) void k_obs(DevModel m, const T *__restrict__ qpos, const T *__restrict__ qvel,
                                              int n, T *__restrict__ obs) {
-    const int od = m.nq - 2 + m.nv;
+    const int od = m.obs_dim;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)n * od) return;
     const int env = gid / od, c = gid % od;
-    obs[gid] = obs_element<T>(qpos + (long)env * m.nq, qvel + (long)env * m.nv, m.nq - 2, c);
+    obs[gid] = obs_element<T>(qpos + (long)env * m.nq, qvel + (long)env * m.nv, obs_opt_of(m), c);
 }
 
 // ============================================================================================ K1
@@ -840,8 +858,9 @@ __global__ __launch_bounds__(256) void k_pose_features(DevModel m, const T *__re
 template <typename T>
 struct ZfSrc {
     const T *x; const T *qpos; const T *qvel; int nq, nv, dim;
+    ObsOpt opt;
     __device__ __forceinline__ T at(long r, int c) const {
-        return x ? x[r * dim + c] : obs_element<T>(qpos + r * nq, qvel + r * nv, nq - 2, c);
+        return x ? x[r * dim + c] : obs_element<T>(qpos + r * nq, qvel + r * nv, opt, c);
     }
 };
 
@@ -1151,7 +1170,8 @@ static int fill_reward(egp_ctx *ctx, const egp_model_desc *d) {
 extern "C" {
 
 const char *egp_last_error(void) { return g_err; }
-const char *egp_version(void) { return "egopose_hip 0.1.0 (gfx950)"; }
+const char *egp_version(void) { return "egopose_hip 0.2.0 (gfx950)"; }
+int32_t egp_obs_dim(const egp_ctx *ctx) { return ctx ? ctx->dm.obs_dim : -1; }
 
 int egp_create(const egp_model_desc *d, int device, egp_ctx **out) {
     EGP_REQUIRE(d && out, "desc/out is NULL");
@@ -1173,6 +1193,10 @@ int egp_create(const egp_model_desc *d, int device, egp_ctx **out) {
     m.nq = d->nq; m.nv = d->nv; m.nu = d->nu; m.nbody = d->nbody; m.nM = d->nM;
     m.sub_dt = d->sub_dt;
     m.dt = d->sub_dt * d->frame_skip;
+    m.obs_heading = d->obs_heading != 0; m.obs_keep = d->obs_keep_root_heading != 0; m.obs_root = d->obs_coord_root != 0;
+    m.obs_vel = d->obs_vel;
+    if (m.obs_vel < 0 || m.obs_vel > 2) { delete ctx; set_error("obs_vel must be 0 (full), 1 (root) or 2 (none)"); return EGP_E_INVALID; }
+    m.obs_dim = obs_width(d->nq, d->nv, m.obs_heading, m.obs_vel);
     // sparse-inertia index tables from the dof tree (what mj_fullM walks)
     std::vector<int> rows(d->nM), cols(d->nM);
     std::vector<short> mmap((size_t)d->nv * d->nv, (short)-1);
@@ -1345,7 +1369,7 @@ static int launch_obs(egp_ctx *ctx, const T *qpos, const T *qvel, int n, T *obs,
     EGP_REQUIRE(n >= 0, "n < 0");
     if (n == 0) return EGP_OK;
     EGP_REQUIRE(qpos && qvel && obs, "NULL pointer");
-    const long total = (long)n * (ctx->dm.nq - 2 + ctx->dm.nv);
+    const long total = (long)n * ctx->dm.obs_dim;
     k_obs<T><<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(ctx->dm, qpos, qvel, n, obs);
     return after_launch("k_obs");
 }
@@ -1481,7 +1505,7 @@ template <typename T>
 static int launch_zfilter(const T *x, const int *active, int n, int dim, const double *st_in, double *st_out, int update,
                           double clip, T *y, void *ws, void *stream) {
     EGP_REQUIRE(st_in && (n == 0 || (x && y)), "NULL pointer");
-    ZfSrc<T> src{x, nullptr, nullptr, 0, 0, dim};
+    ZfSrc<T> src{x, nullptr, nullptr, 0, 0, dim, ObsOpt{0, 0, 0, 0, 0, 0}};
     return launch_zfilter_src<T>(src, active, n, dim, st_in, st_out, update, clip, y, nullptr, nullptr, ws, stream);
 }
 
@@ -1491,8 +1515,8 @@ static int launch_obs_zfilter(egp_ctx *ctx, const T *qpos, const T *qvel, const 
     EGP_REQUIRE(ctx, "ctx is NULL");
     EGP_REQUIRE(n == 0 || (qpos && qvel), "NULL pointer");
     EGP_REQUIRE(!write_only_active || active, "write_only_active needs the active mask");
-    const int dim = ctx->dm.nq - 2 + ctx->dm.nv;
-    ZfSrc<T> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim};
+    const int dim = ctx->dm.obs_dim;
+    ZfSrc<T> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm)};
     return launch_zfilter_src<T>(src, active, n, dim, st_in, st_out, 1, clip, y, y2, write_only_active ? active : nullptr, ws, stream);
 }
 
@@ -1506,8 +1530,8 @@ static int launch_post_step(egp_ctx *ctx, const double *qpos, const double *qvel
     if (n == 0) return EGP_OK;
     EGP_REQUIRE(qpos && qvel && prev_qpos && ee_wpos && tcur && frame && endf && y && reward && cinfo, "NULL pointer");
     if (!ctx->expert_rows_f64) { set_error("egp_upload_experts must be called before the reward kernel"); return EGP_E_STATE; }
-    const int dim = ctx->dm.nq - 2 + ctx->dm.nv;
-    ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim};
+    const int dim = ctx->dm.obs_dim;
+    ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm)};
     const int identity = st_in == nullptr;
     EGP_REQUIRE(identity || (st_out && ws && st_out != st_in), "the filter update needs workspace and a distinct state_out");
     hipStream_t s = (hipStream_t)stream;

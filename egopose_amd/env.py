@@ -24,6 +24,11 @@ import numpy as np
 from .skeleton import load_skeleton, DEFAULT_ASSET
 
 
+def obs_options_of(cfg):
+    from .hip import obs_options_of as f          # (hip.py imports torch: keep this module light to import)
+    return f(cfg)
+
+
 class _Space:
     def __init__(self, dim):
         self.shape = (int(dim),)
@@ -43,7 +48,7 @@ class BatchedSim:
         self.n_env = int(n_env)
         self.ctx = EgpContext(env.skel, cfg.jkp, cfg.jkd, cfg.a_ref, cfg.a_scale, cfg.torque_lim, cfg.b_diffw,
                               reward_weights=cfg.reward_weights, episode_len=cfg.env_episode_len,
-                              frame_skip=env.frame_skip, device=device_index)
+                              frame_skip=env.frame_skip, device=device_index, obs_options=obs_options_of(cfg))
         self.physics = physics if physics is not None else SurrogatePhysics(env.skel, self.n_env)
         # EGP_DEVICE_DYNAMICS=1: qM / qfrc_bias of every substep from K8 on the GPU instead of the backend's drain
         self.engine = RolloutEngine(self.ctx, self.physics, self.n_env, n_threads=n_threads, n_groups=n_groups,
@@ -72,7 +77,8 @@ class HumanoidEnv:
             nq=sk.nq, nv=sk.nv, nu=sk.nu, opt=types.SimpleNamespace(timestep=sk.timestep),
             _body_name2id={n: i + 1 for i, n in enumerate(sk.body_names)})
         self.body_qposaddr = sk.body_qposaddr()
-        self.obs_dim = sk.nq - 2 + sk.nv
+        oo = obs_options_of(cfg)            # humanoid_v1.py:73-96: [heading]? ++ qpos[2:] ++ {qvel | qvel[:6] | -}
+        self.obs_dim = (1 if oo["obs_heading"] else 0) + sk.nq - 2 + {"full": sk.nv, "root": 6}.get(oo["obs_vel"], 0)
         self.observation_space = _Space(self.obs_dim)
         self.action_space = _Space(sk.nu)
         self.end_reward = 0.0

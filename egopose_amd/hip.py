@@ -74,18 +74,34 @@ def quat_op(name, a, b=None):
     return out
 
 
+def obs_options_of(cfg):
+    """The observation switches of a Config (egomimic_config.py:99-103) as EgpContext's `obs_options`."""
+    if getattr(cfg, "obs_type", "full") != "full":
+        raise NotImplementedError("obs_type %r: the reference's get_obs only knows 'full' (humanoid_v1.py:68-71)" % cfg.obs_type)
+    return dict(obs_heading=bool(getattr(cfg, "obs_heading", False)), root_deheading=bool(getattr(cfg, "root_deheading", True)),
+                obs_coord=getattr(cfg, "obs_coord", "heading"), obs_vel=getattr(cfg, "obs_vel", "full"))
+
+
 class EgpContext:
     """Model constants + expert table resident in HBM (``egp_ctx``)."""
 
     def __init__(self, skel: Skeleton, jkp, jkd, a_ref, a_scale, torque_lim, b_diffw, reward_weights=None,
-                 episode_len=200, frame_skip=15, device: int = 0):
+                 episode_len=200, frame_skip=15, device: int = 0, obs_options=None):
+        """`obs_options`: dict with any of obs_heading / root_deheading / obs_coord / obs_vel (the config keys of
+        egomimic_config.py:99-103; `obs_options_of(cfg)`); None = the defaults every shipped config uses."""
         self.lib = L.load()
         self.skel = skel
         self.device = int(device)
         self.frame_skip = int(frame_skip)
         self.episode_len = int(episode_len)
         self.nq, self.nv, self.nu, self.nbody, self.nM = skel.nq, skel.nv, skel.nu, len(skel.body_names), skel.nM
-        self.obs_dim = self.nq - 2 + self.nv
+        oo = dict(obs_heading=False, root_deheading=True, obs_coord="heading", obs_vel="full")
+        oo.update(obs_options or {})
+        if oo["obs_coord"] not in ("heading", "root"):
+            raise ValueError("obs_coord must be 'heading' or 'root', got %r" % (oo["obs_coord"],))      # transform_vec asserts
+        self.obs_options = oo
+        self._obs_vel = {"full": 0, "root": 1}.get(oo["obs_vel"], 2)        # anything else: no velocity block (humanoid_v1.py:86-89)
+        self.obs_dim = (1 if oo["obs_heading"] else 0) + self.nq - 2 + (self.nv, 6, 0)[self._obs_vel]
         self._keep = dict(
             bqs=_np_i32(skel.body_qpos_start), bnd=_np_i32(skel.body_ndof), dpar=_np_i32(skel.dof_parentid),
             madr=_np_i32(skel.dof_Madr), ee=_np_i32(skel.ee_body), jkp=_np_f64(jkp), jkd=_np_f64(jkd),
@@ -100,6 +116,8 @@ class EgpContext:
         h = C.c_void_p()
         L.check(self.lib.egp_create(C.byref(desc), self.device, C.byref(h)), "egp_create")
         self.handle = h
+        if int(self.lib.egp_obs_dim(h)) != self.obs_dim:
+            raise RuntimeError("observation width: library %d, binding %d" % (self.lib.egp_obs_dim(h), self.obs_dim))
         self.n_frames = 0
         self.take_offset = None
         self.head_height_lb = None
@@ -121,6 +139,11 @@ class EgpContext:
         for f in ("w_p", "w_v", "w_e", "w_rp", "w_rv", "k_p", "k_v", "k_e", "k_rh", "k_rq", "k_rl", "k_ra", "v_ord"):
             setattr(d, f, float(ws[f]))
         d.decay = 1 if ws.get("decay", False) else 0
+        oo = self.obs_options
+        d.obs_heading = 1 if oo["obs_heading"] else 0
+        d.obs_keep_root_heading = 0 if oo["root_deheading"] else 1
+        d.obs_coord_root = 1 if oo["obs_coord"] == "root" else 0
+        d.obs_vel = self._obs_vel
         return d
 
     def close(self):

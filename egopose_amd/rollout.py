@@ -102,12 +102,8 @@ class LockstepRollout:
         self.ctx_T = 1 if self.forecast else self.T_ep          # context rows per episode kept in v_out
         if getattr(self.cfg, "obs_phase", False) or getattr(self.cfg, "random_cur_t", False):
             raise NotImplementedError("obs_phase / random_cur_t are not implemented in the lockstep rollout")
-        # K3 computes the observation every shipped config asks for (humanoid_v1.py:73-96 with egomimic_config.py:99-103's
-        # defaults); the other branches would change obs_dim / the root frame: refuse them instead of ignoring them
-        want = dict(obs_type="full", obs_coord="heading", obs_heading=False, obs_vel="full", root_deheading=True)
-        odd = {k: getattr(self.cfg, k) for k, v in want.items() if getattr(self.cfg, k, v) != v}
-        if odd:
-            raise NotImplementedError("observation options %r have no HIP kernel (K3 implements %r)" % (odd, want))
+        # (the observation variants of humanoid_v1.py:73-96 -- obs_heading, obs_vel, root_deheading, obs_coord -- are part of
+        #  the kernel context: sim.ctx.obs_dim follows them; an unknown obs_type / obs_coord was refused when it was built)
         self.gen = torch.Generator(device=self.dev)
         self.gen.manual_seed(int(seed))
         with torch.cuda.device(self.dev):

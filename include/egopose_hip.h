@@ -62,7 +62,16 @@ typedef struct egp_model_desc {
     double k_p, k_v, k_e, k_rh, k_rq, k_rl, k_ra;
     double v_ord;                         /* norm order of the body-angular-velocity term (2) */
     int32_t decay;                        /* reward *= 1 - t/episode_len */
+    /* observation variants of HumanoidEnv.get_full_obs (humanoid_v1.py:73-96, defaults of egomimic_config.py:99-103 = all
+     * zero here): obs = [heading angle]? ++ qpos[2:] (root quaternion de-headed unless obs_keep_root_heading)
+     * ++ {qvel | qvel[:6] | nothing} with qvel[:3] rotated into the heading frame (obs_coord 'heading') or the root frame */
+    int32_t obs_heading;                  /* cfg.obs_heading: prepend get_heading(root quaternion) */
+    int32_t obs_keep_root_heading;        /* cfg.root_deheading == False */
+    int32_t obs_coord_root;               /* cfg.obs_coord == 'root' */
+    int32_t obs_vel;                      /* cfg.obs_vel: 0 'full', 1 'root', 2 none */
 } egp_model_desc;
+/* width of an observation row under those options (115 for the defaults) */
+int32_t egp_obs_dim(const egp_ctx *ctx);
 
 /* Expert table (ego_pose/data_process/gen_expert.py:28-83): all takes concatenated, HOST pointers.
  * frame f of take k lives at row take_offset[k] + f. */

@@ -48,7 +48,9 @@ class OracleHumanoidEnv:
             self.xpos = xpos
 
     def _obs(self):
-        return H.full_obs(self.qpos, self.qvel)[0]
+        c = self.cfg
+        return H.full_obs(self.qpos, self.qvel, obs_heading=getattr(c, "obs_heading", False), root_deheading=getattr(c, "root_deheading", True),
+                          obs_coord=getattr(c, "obs_coord", "heading"), obs_vel=getattr(c, "obs_vel", "full"))[0]
 
     def reset(self):
         cfg = self.cfg

@@ -37,14 +37,24 @@ def body_quat(qpos, body_qpos_start, body_ndof):
     return out.reshape(B, nb * 4)
 
 
-def full_obs(qpos, qvel):
-    """(B,59),(B,58) -> (B,115): [qpos[2:] with de-headed root quat, qvel with heading-frame root lin-vel]."""
+def full_obs(qpos, qvel, obs_heading=False, root_deheading=True, obs_coord="heading", obs_vel="full"):
+    """HumanoidEnv.get_full_obs (ego_pose/envs/humanoid_v1.py:73-96), batch-first. Defaults (every shipped config):
+    (B,59),(B,58) -> (B,115) = [qpos[2:] with de-headed root quat, qvel with heading-frame root lin-vel]."""
     qpos = np.atleast_2d(np.asarray(qpos, float)).copy()
     qvel = np.atleast_2d(np.asarray(qvel, float)).copy()
     root_q = qpos[:, 3:7].copy()
-    qvel[:, :3] = Q.transform_vec(qvel[:, :3], root_q, "heading")
-    qpos[:, 3:7] = Q.de_heading(root_q)
-    return np.concatenate([qpos[:, 2:], qvel], axis=1)
+    qvel[:, :3] = Q.transform_vec(qvel[:, :3], root_q, obs_coord)                     # :78
+    parts = []
+    if obs_heading:                                                                    # :81-82
+        parts.append(np.asarray(Q.heading(root_q), float).reshape(-1, 1))
+    if root_deheading:                                                                 # :83-84
+        qpos[:, 3:7] = Q.de_heading(root_q)
+    parts.append(qpos[:, 2:])
+    if obs_vel == "root":                                                              # :86-89
+        parts.append(qvel[:, :6])
+    elif obs_vel == "full":
+        parts.append(qvel)
+    return np.concatenate(parts, axis=1)
 
 
 def ee_pos(qpos, ee_wpos, transform="heading"):

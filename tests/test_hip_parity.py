@@ -492,3 +492,28 @@ def test_quaternion_algebra_on_device_matches_reference_vectors(dtype, tol):
     with pytest.raises(ValueError, match="unknown quaternion op"):
         from egopose_amd import _lib as L
         L.check(L.load().egp_quat_op_f64(99, None, None, 1, None, None), "egp_quat_op")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 3e-6)])
+def test_observation_variants_on_device(skel, dtype, tol):
+    """K3 under every combination of the observation switches (24 of them, reference vectors of get_full_obs), also
+    computed on the fly inside the fused K3+K6 call (raw observations: no filter state)."""
+    from egopose_amd.hip import EgpContext
+    c = load_golden("config_subject_03.npz")
+    g = load_golden("obs_variants.npz")
+    qpos = torch.as_tensor(g["qpos"], dtype=dtype, device="cuda")
+    qvel = torch.as_tensor(g["qvel"], dtype=dtype, device="cuda")
+    for k, (oh, deheading, root, vel) in enumerate(g["combos"]):
+        opts = dict(obs_heading=bool(oh), root_deheading=bool(deheading), obs_coord="root" if root else "heading", obs_vel=["full", "root", "no"][vel])
+        ctx = EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"], obs_options=opts)
+        ref = g["obs_%d" % k]
+        assert ctx.obs_dim == ref.shape[1]
+        got = ctx.obs(qpos, qvel).double().cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=tol, atol=tol, err_msg=str(opts))
+        if dtype == torch.float64:
+            out = torch.empty(qpos.shape[0], ctx.obs_dim, dtype=dtype, device="cuda")
+            ctx.obs_zfilter(qpos, qvel, None, None, 0.0, out)
+            np.testing.assert_array_equal(out.cpu().numpy(), got)
+        ctx.close()
+    with pytest.raises(ValueError):
+        EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"], obs_options=dict(obs_coord="bogus"))

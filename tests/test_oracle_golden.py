@@ -233,3 +233,14 @@ def test_metrics():
     np.testing.assert_allclose(M.joint_accels(jv, dt), g["accels"], rtol=1e-10, atol=1e-9)
     np.testing.assert_allclose(M.mean_dist(ja, M.joint_angles(g["traj2"])), g["mean_dist"], **TOL)
     np.testing.assert_allclose(M.mean_abs(g["accels"]), g["mean_abs"], **TOL)
+
+
+def test_observation_variants():
+    """get_full_obs under every combination of cfg.obs_heading / root_deheading / obs_coord / obs_vel (humanoid_v1.py:73-96)."""
+    g = load_golden("obs_variants.npz")
+    for k, (oh, deheading, root, vel) in enumerate(g["combos"]):
+        got = H.full_obs(g["qpos"], g["qvel"], obs_heading=bool(oh), root_deheading=bool(deheading), obs_coord="root" if root else "heading",
+                         obs_vel=["full", "root", "no"][vel])
+        ref = g["obs_%d" % k]
+        assert got.shape == ref.shape == (24, int(oh) + 57 + (58, 6, 0)[vel])
+        np.testing.assert_allclose(got, ref, **TOL)

@@ -505,11 +505,27 @@ def test_cross_01_config_short_rollout(tmp_path_factory, skel):
 
 
 @pytest.mark.parametrize("option", [("obs_heading", True), ("obs_vel", "root"), ("root_deheading", False), ("obs_coord", "root")])
-def test_non_default_observation_options_are_refused(workspace, option):
-    """K3 implements the observation of every shipped config (humanoid_v1.py:73-96 with the defaults of
-    egomimic_config.py:99-103); any other variant must be refused, not silently computed as the default."""
-    tr, cfg = _trainer(workspace, 8, 10, num_threads=2, num_groups=1)
+def test_non_default_observation_options_in_the_rollout(workspace, skel, option):
+    """The observation variants of humanoid_v1.py:73-96 run through the whole rollout: state width follows the option, the
+    recorded observations are the oracle env's (which evaluates the reference's branches), and an update step runs."""
+    from egopose_amd.config import Config
+    from egopose_amd.train import Trainer
+    os.chdir(workspace)
+    cfg = Config("subject_03", create_dirs=False)
+    cfg.env_episode_len = 10
+    cfg.num_optim_epoch = 1
     setattr(cfg, *option)
-    with pytest.raises(NotImplementedError, match=option[0]):
-        tr.agent.sample(80)
+    tr = Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=16, num_threads=2, num_groups=2)
+    want = 115 + (1 if option[0] == "obs_heading" else 0) - (52 if option[0] == "obs_vel" else 0)
+    assert tr.env.observation_space.shape[0] == want and tr.policy_net.net.affine_layers[0].in_features == want + cfg.policy_v_hdim
+    tr.agent.running_state = None
+    tr.env.end_reward = 0.2
+    batch, log = tr.agent.sample(16 * 12)
+    assert batch.states.shape[1] == want
+    _replay_episodes(tr, cfg, skel, batch, range(0, 6), 0.2)
+    tr.agent.update_params(batch)
+    assert all(np.isfinite(tr.agent.update_stats["value_loss"]))
     tr.close()
+    with pytest.raises(NotImplementedError):
+        cfg.obs_type = "something"
+        Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=8, num_threads=2, num_groups=1).agent.sample(8)

@@ -104,5 +104,32 @@ def main():
     print("wrote", out, "%.0f kB" % (os.path.getsize(out) / 1e3), "N =", len(batch.masks), "episodes =", len(ep_lens))
 
 
+def obs_variants():
+    """tests/golden/obs_variants.npz: HumanoidEnv.get_full_obs (humanoid_v1.py:73-96) under every non-default combination
+    of cfg.obs_heading / root_deheading / obs_coord / obs_vel on 24 random states (unbound method on a duck-typed env)."""
+    import itertools
+    from ego_pose.envs import humanoid_v1 as hv1
+    from egopose_amd.skeleton import load_skeleton
+    sk = load_skeleton()
+    rng = np.random.RandomState(77)
+    qpos = G.synth_qpos(rng, sk, 24)
+    qpos[:6, 3:7] *= -1.0                                    # both signs of the quaternion (get_heading flips on z < 0)
+    qvel = rng.normal(size=(24, sk.nv))
+    combos = list(itertools.product([False, True], [True, False], ["heading", "root"], ["full", "root", "no"]))
+    out = {"qpos": qpos, "qvel": qvel, "combos": np.array([[int(a), int(b), int(c == "root"), ["full", "root", "no"].index(d)]
+                                                             for a, b, c, d in combos])}
+    for k, (oh, rd, oc, ov) in enumerate(combos):
+        cfg = types.SimpleNamespace(obs_coord=oc, obs_heading=oh, root_deheading=rd, obs_vel=ov, obs_phase=False, env_episode_len=200)
+        rows = []
+        for i in range(qpos.shape[0]):
+            env = types.SimpleNamespace(cfg=cfg, cur_t=0, data=types.SimpleNamespace(qpos=qpos[i].copy(), qvel=qvel[i].copy()))
+            rows.append(hv1.HumanoidEnv.get_full_obs(env))
+        out["obs_%d" % k] = np.stack(rows)
+    path = os.path.join(G.OUT, "obs_variants.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.0f kB" % (os.path.getsize(path) / 1e3), "%d combinations" % len(combos))
+
+
 if __name__ == "__main__":
     main()
+    obs_variants()
