@@ -101,6 +101,7 @@ SIGNATURES = {
     "egp_set_reward_weights": (C.c_int, [vp, C.POINTER(ModelDesc)]),
     "egp_set_pd_variant": (C.c_int, [vp, C.c_int]),
     "egp_upload_experts": (C.c_int, [vp, C.POINTER(ExpertTable)]),
+    "egp_reward_simple_f64": (C.c_int, [vp, _i32, vp, vp, vp, vp, C.c_double, _i32, vp, vp, vp]),
     "egp_quat_op_f64": (C.c_int, [_i32, vp, vp, _i32, vp, vp]),
     "egp_quat_op_f32": (C.c_int, [_i32, vp, vp, _i32, vp, vp]),
     "egp_body_quat_f64": (C.c_int, [vp, vp, _i32, vp, vp]),

@@ -180,12 +180,15 @@ class Agent:
                 raise RuntimeError("egopose_amd samples on an MI355X only: device=%s has no HIP path (no CPU fallback)" % (dev,))
             idx = dev.index if dev.index is not None else torch.cuda.current_device()
             reward_id = getattr(self.env.cfg, "reward_id", "quat_v3")
-            if self.custom_reward is not None and getattr(self.custom_reward, "egp_kernel", None) != "quat_v3":
-                raise NotImplementedError("only the quat_v3 reward has a HIP kernel (reward_id=%s)" % reward_id)
+            kind = "quat_v3" if self.custom_reward is None else getattr(self.custom_reward, "egp_kernel", None)
+            if kind not in ("quat_v3", "constant", "pose_dist"):
+                raise NotImplementedError("custom_reward %r has no HIP kernel (the registry's quat_v3 / constant / pose_dist "
+                                          "do; reward_id=%s)" % (self.custom_reward, reward_id))
             n_threads = None if self.num_threads in (None, 0) else int(self.num_threads)
             sim = self.env.batched(self.num_envs, idx, n_threads=n_threads, n_groups=self.num_groups)
             seed = int(getattr(self.env.cfg, "seed", 0)) * 1000 + D.rank()
             self._rollout = LockstepRollout(sim, self.cn.policy_net, self._video_net(), self.running_state, seed=seed)
+            self._rollout.reward_kind = kind
         return self._rollout
 
     def sample(self, min_batch_size):

@@ -66,6 +66,7 @@ struct egp_ctx {
     int n_takes = 0, n_frames = 0;
     double *expert_rows_f64 = nullptr; // [n_frames][EGP_EXPERT_ROW]
     float *expert_rows_f32 = nullptr;
+    double *expert_qpos_f64 = nullptr; // [n_frames][nq]: the pose_dist reward compares whole poses
     int pd_variant = 0;                // 0 = tree-ordered in-register elimination, 2 = dense in-register, 1 = LDS
     bool tree58 = false;               // runtime dof tree == compiled-in humanoid tree
     void *dyn_tables = nullptr;        // device copy of the dynamics tree (egp_set_dynamics_model), owned through allocs

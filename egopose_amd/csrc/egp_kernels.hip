@@ -1282,7 +1282,9 @@ int egp_upload_experts(egp_ctx *ctx, const egp_expert_table *t) {
     std::vector<float> rows32(rows.size());
     for (size_t i = 0; i < rows.size(); ++i) rows32[i] = (float)rows[i];
     EGP_HIP_CHECK(hipSetDevice(ctx->device));
-    if (ctx->expert_rows_f64) { (void)hipFree(ctx->expert_rows_f64); (void)hipFree(ctx->expert_rows_f32); }
+    if (ctx->expert_rows_f64) { (void)hipFree(ctx->expert_rows_f64); (void)hipFree(ctx->expert_rows_f32); (void)hipFree(ctx->expert_qpos_f64); }
+    EGP_HIP_CHECK(hipMalloc((void **)&ctx->expert_qpos_f64, (size_t)t->n_frames * nq * sizeof(double)));
+    EGP_HIP_CHECK(hipMemcpy(ctx->expert_qpos_f64, t->qpos, (size_t)t->n_frames * nq * sizeof(double), hipMemcpyHostToDevice));
     EGP_HIP_CHECK(hipMalloc((void **)&ctx->expert_rows_f64, rows.size() * sizeof(double)));
     EGP_HIP_CHECK(hipMalloc((void **)&ctx->expert_rows_f32, rows.size() * sizeof(float)));
     EGP_HIP_CHECK(hipMemcpy(ctx->expert_rows_f64, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1361,6 +1363,31 @@ static int launch_quat_op(int op, const T *a, const T *b, int n, T *out, void *s
     EGP_REQUIRE(a && out && (b || !two), "NULL pointer");
     k_quat_op<T><<<dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(op, a, b, n, out);
     return after_launch("k_quat_op");
+}
+
+// The two small entries of the reward registry (ego_pose/core/reward_function.py:63-80), one thread per env:
+//   EGP_REWARD_CONSTANT   reward 1.0 (the reference computes 1 + end_reward at an episode's end but returns 1.0), c_info [0]
+//   EGP_REWARD_POSE_DIST  d = |expert qpos[2:] - qpos[2:]| of the step's expert frame (HumanoidEnv.get_pose_dist,
+//                         humanoid_v1.py:275-280), reward 5 - 3 d (+ end_reward on the last step), c_info [d]
+__global__ __launch_bounds__(256) void k_reward_simple(int kind, int nq, const double *__restrict__ qpos, const double *__restrict__ expert_qpos,
+                                                       const int *__restrict__ frame, const int *__restrict__ endf, const int *__restrict__ active,
+                                                       double end_reward, int n, double *__restrict__ reward, double *__restrict__ cinfo) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || (active && !active[e])) return;
+    if (kind == EGP_REWARD_CONSTANT) {
+        reward[e] = 1.0;
+        cinfo[e] = 0.0;
+        return;
+    }
+    const double *q = qpos + (long)e * nq, *x = expert_qpos + (long)frame[e] * nq;
+    double s = 0.0;
+    for (int k = 2; k < nq; ++k) {
+        const double d = x[k] - q[k];
+        s += d * d;
+    }
+    const double dist = sqrt(s);
+    reward[e] = 5.0 - 3.0 * dist + (endf[e] ? end_reward : 0.0);
+    cinfo[e] = dist;
 }
 
 template <typename T>
@@ -1576,6 +1603,18 @@ extern "C" {
 
 int egp_body_quat_f64(egp_ctx *c, const double *q, int32_t n, double *o, void *s) { return launch_body_quat<double>(c, q, n, o, s); }
 int egp_body_quat_f32(egp_ctx *c, const float *q, int32_t n, float *o, void *s) { return launch_body_quat<float>(c, q, n, o, s); }
+int egp_reward_simple_f64(egp_ctx *c, int32_t kind, const double *qpos, const int32_t *frame, const int32_t *endf, const int32_t *active,
+                          double end_reward, int32_t n, double *reward, double *cinfo, void *s) {
+    EGP_REQUIRE(c, "ctx is NULL");
+    EGP_REQUIRE(kind == EGP_REWARD_CONSTANT || kind == EGP_REWARD_POSE_DIST, "unknown reward kind");
+    EGP_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return EGP_OK;
+    EGP_REQUIRE(reward && cinfo && (kind == EGP_REWARD_CONSTANT || (qpos && frame && endf)), "NULL pointer");
+    if (kind == EGP_REWARD_POSE_DIST && !c->expert_qpos_f64) { set_error("egp_upload_experts must be called before the pose_dist reward"); return EGP_E_STATE; }
+    k_reward_simple<<<dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s>>>(kind, c->dm.nq, qpos, c->expert_qpos_f64, frame, endf, active,
+                                                                              end_reward, n, reward, cinfo);
+    return after_launch("k_reward_simple");
+}
 int egp_quat_op_f64(int32_t op, const double *a, const double *b, int32_t n, double *o, void *s) { return launch_quat_op<double>(op, a, b, n, o, s); }
 int egp_quat_op_f32(int32_t op, const float *a, const float *b, int32_t n, float *o, void *s) { return launch_quat_op<float>(op, a, b, n, o, s); }
 int egp_obs_f64(egp_ctx *c, const double *q, const double *v, int32_t n, double *o, void *s) { return launch_obs<double>(c, q, v, n, o, s); }

@@ -222,8 +222,29 @@ class EgpContext:
                    _stream()), "egp_pd_torque")
         return (tq, raw) if want_raw else tq
 
+    REWARD_KINDS = {"quat_v3": 0, "constant": 1, "pose_dist": 2}       # reward_function.py:78-80
+
+    def reward_cinfo_dim(self, kind="quat_v3"):
+        return 5 if kind == "quat_v3" else 1
+
+    def reward_simple(self, kind, cur_qpos, frame, end, end_reward, active=None, reward_out=None, cinfo_out=None):
+        """`constant` / `pose_dist` (egp_reward_simple_f64): float64, c_info (n, 1)."""
+        n = cur_qpos.shape[0]
+        _need(cur_qpos, (n, self.nq), torch.float64, "cur_qpos")
+        for name, a in (("frame", frame), ("end", end)):
+            _need(a, (n,), torch.int32, name)
+        r = torch.empty(n, dtype=torch.float64, device=cur_qpos.device) if reward_out is None else reward_out
+        ci = torch.empty(n, 1, dtype=torch.float64, device=cur_qpos.device) if cinfo_out is None else cinfo_out
+        _need(r, (n,), torch.float64, "reward_out")
+        _need(ci, (n, 1), torch.float64, "cinfo_out")
+        L.check(self.lib.egp_reward_simple_f64(self.handle, self.REWARD_KINDS[kind], _ptr(cur_qpos), _ptr(frame), _ptr(end), _ptr(active),
+                                               float(end_reward), n, _ptr(r), _ptr(ci), _stream()), "egp_reward_simple_f64")
+        return r, ci
+
     def reward(self, cur_qpos, prev_qpos, ee_wpos, t, frame, end, end_reward, active=None, reward_out=None,
-               cinfo_out=None):
+               cinfo_out=None, kind="quat_v3"):
+        if kind != "quat_v3":
+            return self.reward_simple(kind, cur_qpos, frame, end, end_reward, active, reward_out, cinfo_out)
         n, dt = cur_qpos.shape[0], cur_qpos.dtype
         _need(cur_qpos, (n, self.nq), dt, "cur_qpos")
         _need(prev_qpos, (n, self.nq), dt, "prev_qpos")

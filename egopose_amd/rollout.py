@@ -120,6 +120,7 @@ class LockstepRollout:
         self._fast_bufs = None              # pinned per-tick flag / index slots of the fast tick path
         self._graphs = None                 # per group: captured hipGraph of the policy step
         self._graph_key = None
+        self.reward_kind = "quat_v3"        # which entry of the reward registry the rollout evaluates (Agent sets it)
         self.pool_batch = max(256, self.N // 2)
         self._pool, self._pool_pos = None, 0
 
@@ -284,7 +285,8 @@ class LockstepRollout:
         rec = dict(
             states=torch.empty(T_max + 1, N, od, dtype=f64, device=dev), next_states=torch.empty(T_max, N, od, dtype=f64, device=dev),
             actions=torch.zeros(T_max, N, nu, dtype=f64, device=dev), rewards=torch.zeros(T_max, N, dtype=f64, device=dev),
-            cinfo=torch.zeros(T_max, N, 5, dtype=f64, device=dev), exps=torch.ones(T_max, N, dtype=torch.int64, device=dev))
+            cinfo=torch.zeros(T_max, N, ctx.reward_cinfo_dim(self.reward_kind), dtype=f64, device=dev),
+            exps=torch.ones(T_max, N, dtype=torch.int64, device=dev))
         host = dict(valid=np.zeros((T_max, N), bool), done=np.zeros((T_max, N), bool),
                     e_ind=np.zeros((T_max, N), np.int64), s_ind=np.zeros((T_max, N), np.int64))
         self._ensure_static(ndt)
@@ -368,7 +370,7 @@ class LockstepRollout:
             # K3+K6: filtered next observation -> next_states[k] and the policy input of tick k+1;  K2: reward
             self._obs_filter(a, b, rec["next_states"][k, a:b], rec["states"][k + 1, a:b], active=fl[3])
             ctx.reward(eng.qpos[a:b], eng.prev_qpos[a:b], eng.ee_wpos[a:b], fl[0], fl[1], fl[2], end_reward, active=fl[3],
-                       reward_out=rec["rewards"][k, a:b], cinfo_out=rec["cinfo"][k, a:b])
+                       reward_out=rec["rewards"][k, a:b], cinfo_out=rec["cinfo"][k, a:b], kind=self.reward_kind)
             steps_done[a:b] += act_g
             t2 = time.time()
             if done.any():
@@ -395,8 +397,9 @@ class LockstepRollout:
         # tensor argument is a precomputed address, and the fused policy kernel reads rec.states[k] / writes
         # rec.actions[k] directly.
         # (mean_action: the same kernel without a noise operand writes the mean; exps = 0 as agents/agent.py:45-46)
+        # (the registry's two small rewards, constant / pose_dist, take the torch tick: their kernel is called from there)
         fast = (self._fused is not None and (plain_noise or self.mean_action) and not self.forecast
-                and os.environ.get("EGP_FAST_TICK", "1") != "0")
+                and self.reward_kind == "quat_v3" and os.environ.get("EGP_FAST_TICK", "1") != "0")
         if fast:
             if self.mean_action:
                 rec["exps"].zero_()

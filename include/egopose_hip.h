@@ -167,6 +167,13 @@ int egp_reward_quat_v3_f32(egp_ctx *ctx, const float *cur_qpos, const float *pre
                            const float *ee_wpos, const int32_t *t, const int32_t *frame,
                            const int32_t *end, const int32_t *active, double end_reward, int32_t n,
                            float *reward, float *c_info, void *stream);
+/* the other two entries of the reward registry (ego_pose/core/reward_function.py:63-80), float64, one c_info column:
+ * EGP_REWARD_CONSTANT: reward 1.0, c_info 0;  EGP_REWARD_POSE_DIST: d = |(expert qpos - qpos)[2:]| at expert row frame[e]
+ * (HumanoidEnv.get_pose_dist, humanoid_v1.py:275-280), reward 5 - 3 d (+ end_reward where end[e]), c_info d */
+#define EGP_REWARD_CONSTANT 1
+#define EGP_REWARD_POSE_DIST 2
+int egp_reward_simple_f64(egp_ctx *ctx, int32_t kind, const double *qpos, const int32_t *frame, const int32_t *end, const int32_t *active,
+                          double end_reward, int32_t n, double *reward, double *cinfo, void *stream);
 
 /* ---------------------------------------------------------------------------------------- K7
  * Pose features of a (previous, current) frame pair in the reference's expert formats

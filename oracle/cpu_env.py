@@ -86,6 +86,11 @@ class OracleHumanoidEnv:
     def reward(self, state, action, info):
         e = self.expert_arr[self.expert_ind]
         ind = self.start_ind + self.cur_t
+        kind = getattr(self.cfg, "reward_id", "quat_v3")
+        if kind == "constant":
+            return R.constant(info["end"], self.end_reward)
+        if kind == "pose_dist":
+            return R.pose_dist(self.qpos, e["qpos"][ind], info["end"], self.end_reward)
         row = {k: e[k][ind] for k in ("qpos", "rlinv_local", "rangv", "rq_rmh", "ee_pos", "bquat", "bangvel")}
         r, ci = R.quat_v3(self.qpos, self.prev_qpos, self.prev_bquat, self.xpos[self.skel.ee_body].ravel(), self.cur_t, row,
                           self.cfg.reward_weights, self.cfg.b_diffw, self.dt, self.cfg.env_episode_len, info["end"],

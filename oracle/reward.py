@@ -66,3 +66,18 @@ def quat_v3(cur_qpos, prev_qpos, prev_bquat, ee_wpos, t, expert_row, weights, b_
         r = r * (1.0 - t / episode_len)
     r = r + np.where(end, end_reward, 0.0)
     return r, np.stack([pose_r, vel_r, ee_r, rp_r, rv_r], axis=1)
+
+
+def constant(end, end_reward):
+    """constant_reward (ego_pose/core/reward_function.py:63-67): the function builds 1 + end_reward at an episode's end
+    and then RETURNS 1.0 with a one-element zero c_info."""
+    return 1.0, np.zeros(1)
+
+
+def pose_dist(qpos, expert_qpos, end, end_reward):
+    """pose_dist_reward (reward_function.py:70-75) with HumanoidEnv.get_pose_dist (humanoid_v1.py:275-280)."""
+    d = float(np.linalg.norm((np.asarray(expert_qpos, float) - np.asarray(qpos, float))[2:]))
+    r = 5.0 - 3.0 * d
+    if end:
+        r += end_reward
+    return r, np.array([d])

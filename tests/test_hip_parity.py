@@ -517,3 +517,29 @@ def test_observation_variants_on_device(skel, dtype, tol):
         ctx.close()
     with pytest.raises(ValueError):
         EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"], obs_options=dict(obs_coord="bogus"))
+
+
+def test_constant_and_pose_dist_rewards_on_device(skel):
+    """The registry's two small rewards (reward_function.py:63-80) through `egp_reward_simple_f64` against the reference."""
+    from egopose_amd.hip import EgpContext
+    c = load_golden("config_subject_03.npz")
+    g = load_golden("reward_simple.npz")
+    ctx = EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"])
+    n = g["expert_qpos"].shape[0]
+    z = lambda *s: np.zeros(s)
+    bq = np.tile(np.array([1.0, 0, 0, 0]), (n, 21))
+    ctx.upload_experts([dict(qpos=g["expert_qpos"], qvel=z(n, 58), rlinv_local=z(n, 3), rangv=z(n, 3), rq_rmh=bq[:, :4], ee_pos=z(n, 15),
+                             bquat=bq, bangvel=z(n, 63), head_height_lb=1.0)])
+    d = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
+    qpos, frame, end = d(g["qpos"]), d(g["frame"], torch.int32), d(g["end"], torch.int32)
+    r, ci = ctx.reward_simple("pose_dist", qpos, frame, end, float(g["end_reward"]))
+    np.testing.assert_allclose(r.cpu().numpy(), g["pose_dist_reward"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ci.cpu().numpy(), g["pose_dist_cinfo"], rtol=1e-12, atol=1e-12)
+    r, ci = ctx.reward(qpos, qpos, torch.zeros(32, 15, dtype=torch.float64, device="cuda"), frame, frame, end, float(g["end_reward"]), kind="constant")
+    assert (r.cpu().numpy() == g["constant_reward"]).all() and (ci.cpu().numpy() == g["constant_cinfo"]).all()
+    active = torch.ones(32, dtype=torch.int32, device="cuda")
+    active[::3] = 0
+    keep = torch.full((32,), -7.0, dtype=torch.float64, device="cuda")
+    ctx.reward_simple("pose_dist", qpos, frame, end, 0.0, active=active, reward_out=keep)
+    assert (keep[::3] == -7.0).all() and (keep[1::3] != -7.0).all()
+    ctx.close()

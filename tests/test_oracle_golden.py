@@ -244,3 +244,12 @@ def test_observation_variants():
         ref = g["obs_%d" % k]
         assert got.shape == ref.shape == (24, int(oh) + 57 + (58, 6, 0)[vel])
         np.testing.assert_allclose(got, ref, **TOL)
+
+
+def test_constant_and_pose_dist_rewards():
+    g = load_golden("reward_simple.npz")
+    for i in range(len(g["frame"])):
+        r, c = R.constant(bool(g["end"][i]), float(g["end_reward"]))
+        assert r == g["constant_reward"][i] == 1.0 and (c == g["constant_cinfo"][i]).all()
+        r, c = R.pose_dist(g["qpos"][i], g["expert_qpos"][g["frame"][i]], bool(g["end"][i]), float(g["end_reward"]))
+        np.testing.assert_allclose([r, c[0]], [g["pose_dist_reward"][i], g["pose_dist_cinfo"][i][0]], **TOL)

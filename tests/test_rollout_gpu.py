@@ -529,3 +529,26 @@ def test_non_default_observation_options_in_the_rollout(workspace, skel, option)
     with pytest.raises(NotImplementedError):
         cfg.obs_type = "something"
         Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=8, num_threads=2, num_groups=1).agent.sample(8)
+
+
+@pytest.mark.parametrize("reward_id", ["pose_dist", "constant"])
+def test_rollout_with_the_small_rewards(workspace, skel, reward_id):
+    """reward_id 'pose_dist' / 'constant' (reward_function.py:63-80) through the lockstep rollout, replayed by the oracle env."""
+    from egopose_amd.config import Config
+    from egopose_amd.train import Trainer
+    os.chdir(workspace)
+    cfg = Config("subject_03", create_dirs=False)
+    cfg.env_episode_len = 9
+    cfg.num_optim_epoch = 1
+    cfg.reward_id = reward_id
+    tr = Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=16, num_threads=2, num_groups=2)
+    tr.agent.running_state = None
+    tr.env.end_reward = 0.6
+    batch, log = tr.agent.sample(16 * 12)
+    assert np.asarray(log.avg_c_info).shape == (1,)
+    if reward_id == "constant":
+        assert (batch.rewards == 1.0).all() and log.avg_c_reward == 1.0
+    else:
+        assert batch.rewards.max() < 5.0 + 0.6 and np.isclose(log.avg_c_info[0], (5.0 - (batch.rewards - 0.6 * (batch.masks == 0))).mean() / 3.0)
+    _replay_episodes(tr, cfg, skel, batch, range(0, 6), 0.6)
+    tr.close()

@@ -130,6 +130,37 @@ def obs_variants():
     print("wrote", path, "%.0f kB" % (os.path.getsize(path) / 1e3), "%d combinations" % len(combos))
 
 
+def small_rewards():
+    """tests/golden/reward_simple.npz: constant_reward / pose_dist_reward (ego_pose/core/reward_function.py:63-75) with
+    HumanoidEnv.get_pose_dist (humanoid_v1.py:275-280) bound to a duck-typed env, 32 cases with and without the end flag."""
+    from ego_pose.envs import humanoid_v1 as hv1
+    from ego_pose.core.reward_function import reward_func
+    from egopose_amd.skeleton import load_skeleton
+    sk = load_skeleton()
+    rng = np.random.RandomState(91)
+    expert_qpos = G.synth_qpos(rng, sk, 40)
+    qpos = G.synth_qpos(rng, sk, 32)
+    frame = rng.randint(0, 40, size=32)
+    end = (rng.uniform(size=32) < 0.4).astype(np.int64)
+    end_reward = 3.25
+    out = dict(expert_qpos=expert_qpos, qpos=qpos, frame=frame, end=end, end_reward=end_reward)
+    for name in ("constant", "pose_dist"):
+        rs, cs = [], []
+        for i in range(32):
+            env = types.SimpleNamespace(end_reward=end_reward, expert={"qpos": expert_qpos}, cur_t=0, start_ind=int(frame[i]),
+                                        data=types.SimpleNamespace(qpos=qpos[i].copy()))
+            env.get_expert_index = lambda t, env=env: env.start_ind + t
+            env.get_pose_dist = lambda env=env: hv1.HumanoidEnv.get_pose_dist(env)
+            r, c = reward_func[name](env, None, None, {"end": bool(end[i])})
+            rs.append(r); cs.append(np.asarray(c, float))
+        out[name + "_reward"] = np.array(rs, float)
+        out[name + "_cinfo"] = np.stack(cs)
+    path = os.path.join(G.OUT, "reward_simple.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.0f kB" % (os.path.getsize(path) / 1e3))
+
+
 if __name__ == "__main__":
     main()
     obs_variants()
+    small_rewards()
