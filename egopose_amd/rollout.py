@@ -209,12 +209,13 @@ class LockstepRollout:
     def _policy_body(self, g):
         """action = mean + std * N(0,1) for group g, reading / writing only static buffers (graph-capturable)."""
         a, b = self.groups[g]
+        # the exploration noise of the tick sits in self._g_noise[g]: the caller copies it there from the rollout's noise
+        # block (drawn once per rollout for every tick and slot, `sample`), so the body itself draws nothing
         if self._fused is not None:              # one HIP launch: concat + MLP + Gaussian head
-            self._g_noise[g].normal_()                # default generator: graph-safe philox offsets
             self._fused(self.v_out[a:b], self._g_tidx[g], self._g_state[g], self._g_act[g], noise=self._g_noise[g])
             return
         mean, std = self._mean_std(self._policy_input(g, self._g_tidx[g], self._g_state[g]))
-        self._g_act[g].copy_(torch.addcmul(mean, std, torch.randn_like(mean)))
+        self._g_act[g].copy_(torch.addcmul(mean, std, self._g_noise[g].to(mean.dtype)))
 
     def _ensure_static(self, ndt):
         """Persistent buffers (and, when possible, one captured hipGraph per group) for the per-tick policy step:
@@ -316,6 +317,10 @@ class LockstepRollout:
         self._obs_filter(0, N, rec["states"][0])
 
         plain_noise = (not self.mean_action) and self.noise_rate >= 1.0
+        # exploration noise of the whole rollout in ONE draw (T_max x N x nu float32, ~50 MB at the bench shape) instead of a
+        # launch per group and tick on the chain filter -> policy -> env-step; both tick implementations read the same block
+        noise_all = torch.randn(T_max, N, nu, dtype=torch.float32, device=dev) if plain_noise else None
+        noise_p = noise_all.data_ptr() if noise_all is not None else 0
 
         def pre_step(g):
             a, b = self.groups[g]
@@ -326,6 +331,7 @@ class LockstepRollout:
                 # static-buffer form (one hipGraph launch when captured)
                 self._g_tidx[g].copy_(t_idx)
                 self._g_state[g].copy_(rec["states"][k, a:b])
+                self._g_noise[g].copy_(noise_all[k, a:b])
                 if self._graphs is not None:
                     self._graphs[g].replay()
                 else:
@@ -416,9 +422,8 @@ class LockstepRollout:
             if self._fast_bufs is None or self._fast_bufs[3] != nmax:
                 # per (group, slot) one 24*nmax-byte slab: 4 x nmax int32 flags (t | frame | end | active), then nmax int64 context rows
                 self._fast_bufs = (torch.zeros(len(self.groups), 2, 24 * nmax, dtype=torch.uint8).pin_memory(),
-                                   torch.zeros(len(self.groups), 2, 24 * nmax, dtype=torch.uint8, device=dev),
-                                   [torch.zeros(b - a, nu, dtype=torch.float32, device=dev) for a, b in self.groups], nmax)
-            slab_h, slab_d, noise_t, _ = self._fast_bufs
+                                   torch.zeros(len(self.groups), 2, 24 * nmax, dtype=torch.uint8, device=dev), None, nmax)
+            slab_h, slab_d, _, _ = self._fast_bufs
             slab_np = slab_h.numpy()
             fl_np = slab_np[:, :, :16 * nmax].view(np.int32)            # (G, 2, 4*nmax)
             ti_np = slab_np[:, :, 16 * nmax:].view(np.int64)            # (G, 2, nmax)
@@ -457,11 +462,7 @@ class LockstepRollout:
             if flags_upload:
                 lib.egp_upload_async(slab_dp + soff, slab_hp + soff, 24 * nmax, cur_stream)
             fbase = slab_dp + soff
-            nz_p = None
-            if not self.mean_action:
-                nz = noise_t[g]
-                nz.normal_()
-                nz_p = nz.data_ptr()
+            nz_p = None if self.mean_action else noise_p + (k * N + a) * nu * 4
             rc = lib.egp_policy_gaussian_f32(v_out_p + a * v_stride * 4, v_stride, H, fbase + 16 * nmax,
                                              P["states"] + (k * N + a) * od * 8, od, n, fz.desc, len(fz.layers), fz.act,
                                              fz.log_std.data_ptr(), nz_p, P["actions"] + (k * N + a) * nu * 8, None,
