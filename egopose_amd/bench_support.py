@@ -44,7 +44,7 @@ def kernel_microbench(sizes=(1024, 65536), device_index=0, variants=False, iters
     """K1-K6 / K8 with inputs resident in HBM (HIP events on the launch stream, float64): per (kernel, n) the time per
     call, the ALGORITHMIC bytes (SURVEY.md 8d / DESIGN.md section 4), achieved GB/s and the fraction of the 8 TB/s HBM
     peak. These are the numbers an HBM roofline can bind; the in-rollout K1 launch waits for host physics instead.
-    `variants=True` also times the K1 fall-back kernels (dense order, generic LDS)."""
+    `variants=True` also times the other K1 kernels (lane per row, dense order, generic LDS)."""
     import numpy as np
     import torch
     from .hip import EgpContext
@@ -91,7 +91,7 @@ def kernel_microbench(sizes=(1024, 65536), device_index=0, variants=False, iters
                 ("K8_dynamics", lambda: ctx.dynamics(qpos, qvel, want_xpos=True, qM_out=qM_dyn), (59 + 58 + 910 + 58 + 63) * W, 1),
             ]
             for name, fn, bytes_per_unit, units_per_env in cases:
-                todo = [(0, "_tree58")] + ([(2, "_reg58"), (1, "_lds")] if variants else []) if name == "K1_pd_torque" else [(None, "")]
+                todo = [(0, "_tree58")] + ([(3, "_tree58_rows"), (2, "_reg58"), (1, "_lds")] if variants else []) if name == "K1_pd_torque" else [(None, "")]
                 for variant, sfx in todo:
                     if variant is not None:
                         ctx.set_pd_variant(variant)

@@ -69,6 +69,8 @@ struct egp_ctx {
     double *expert_qpos_f64 = nullptr; // [n_frames][nq]: the pose_dist reward compares whole poses
     int pd_variant = 0;                // 0 = tree-ordered in-register elimination, 2 = dense in-register, 1 = LDS
     bool tree58 = false;               // runtime dof tree == compiled-in humanoid tree
+    bool pd_grid = false;              // variant 0, one substep per launch: the lane-grid kernel (variant 3: the row kernel)
+    const unsigned short *pd_grid_off = nullptr;   // its [register][lane] gather table (device)
     void *dyn_tables = nullptr;        // device copy of the dynamics tree (egp_set_dynamics_model), owned through allocs
 };
 

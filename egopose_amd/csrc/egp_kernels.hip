@@ -277,6 +277,8 @@ __device__ __forceinline__ void tree_solve(const double (&a)[PD_NV], double &b) 
     if constexpr (K > 0) tree_solve<K - 1>(a, b);
 }
 
+#include "egp_pd_grid.hpp"
+
 template <typename TIO>
 __global__ __launch_bounds__(256) void k_pd_torque_tree58(DevModel m, PdLd ld, const TIO *__restrict__ qpos,
                                                           const TIO *__restrict__ qvel, const TIO *__restrict__ action,
@@ -1227,16 +1229,25 @@ int egp_create(const egp_model_desc *d, int device, egp_ctx **out) {
     EGP_TRY(dev_copy<double>(ctx, d->torque_lim, d->nu, &m.torque_lim));
     EGP_TRY(dev_copy<double>(ctx, d->b_diffw, d->nbody - 1, &m.b_diffw));
 #undef EGP_TRY
-    // fast paths: 0 = tree-ordered elimination (needs the compiled-in humanoid dof tree), 2 = dense in-register
-    // Gauss-Jordan (any tree with nv == 58), 1 = generic LDS kernel
+    // fast paths: 0 = tree-ordered elimination (needs the compiled-in humanoid dof tree; one substep per launch: the lane-grid
+    // kernel, 3 = its lane-per-row predecessor), 2 = dense in-register Gauss-Jordan (any tree with nv == 58), 1 = generic LDS kernel
     bool tree_ok = d->nv == Tree58::NV;
     for (int i = 0; tree_ok && i < d->nv; ++i) tree_ok = d->dof_parentid[i] == Tree58::PARENT[i];
     ctx->tree58 = tree_ok;
+    if (tree_ok) {          // gather table of the lane-grid K1 (k_pd_torque_grid58)
+        const std::vector<unsigned short> off = grid58_offsets(mmap);
+        const unsigned short *dev = nullptr;
+        rc = dev_copy<unsigned short>(ctx, off.data(), off.size(), &dev);
+        if (rc != EGP_OK) { egp_destroy(ctx); return rc; }
+        ctx->pd_grid_off = dev;
+        ctx->pd_grid = true;
+    }
     ctx->pd_variant = tree_ok ? 0 : (d->nv == PD_NV ? 2 : 1);
     const char *v = getenv("EGP_PD_VARIANT");
     if (v) {
         const int want = atoi(v);
         if (want == 1 || (want == 2 && d->nv == PD_NV) || (want == 0 && tree_ok)) ctx->pd_variant = want;
+        if (want == 3 && tree_ok) ctx->pd_grid = false;
     }
     *out = ctx;
     return EGP_OK;
@@ -1256,9 +1267,10 @@ int egp_set_reward_weights(egp_ctx *ctx, const egp_model_desc *d) {
 
 int egp_set_pd_variant(egp_ctx *ctx, int variant) {
     EGP_REQUIRE(ctx, "ctx is NULL");
-    EGP_REQUIRE(variant == 1 || (variant == 2 && ctx->dm.nv == PD_NV) || (variant == 0 && ctx->tree58),
-                "variant 0 needs the humanoid_1205_v1 dof tree, variant 2 needs nv == 58");
-    ctx->pd_variant = variant;
+    EGP_REQUIRE(variant == 1 || (variant == 2 && ctx->dm.nv == PD_NV) || ((variant == 0 || variant == 3) && ctx->tree58),
+                "variants 0 and 3 need the humanoid_1205_v1 dof tree, variant 2 needs nv == 58");
+    ctx->pd_variant = variant == 3 ? 0 : variant;
+    ctx->pd_grid = variant == 0;
     return EGP_OK;
 }
 
@@ -1408,6 +1420,10 @@ static int launch_pd(egp_ctx *ctx, const PdLd &ld, const T *qpos, const T *qvel,
     EGP_REQUIRE(n >= 0, "n < 0");
     if (n == 0) return EGP_OK;
     EGP_REQUIRE(qpos && qvel && action && qM && C && torque, "NULL pointer");
+    if (ctx->pd_variant == 0 && ctx->pd_grid) {
+        k_pd_torque_grid58<T><<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, ctx->pd_grid_off, qpos, qvel, action, qM, C, n, torque, torque_raw, done);
+        return after_launch("k_pd_torque_grid58");
+    }
     if (ctx->pd_variant == 0) {
         k_pd_torque_tree58<T><<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, C, n, torque, torque_raw, done);
         return after_launch("k_pd_torque_tree58");

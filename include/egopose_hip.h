@@ -97,8 +97,9 @@ int egp_create(const egp_model_desc *desc, int device, egp_ctx **out);
 int egp_destroy(egp_ctx *ctx);
 /* replaces reward weights in place (cfg.reward_weights can change between iterations) */
 int egp_set_reward_weights(egp_ctx *ctx, const egp_model_desc *desc);
-/* K1 implementation switch: 0 = tree-ordered in-register elimination (humanoid_1205_v1 dof tree, default),
- * 2 = dense in-register Gauss-Jordan (any tree with nv == 58), 1 = generic LDS kernel (any nv <= 64) */
+/* K1 implementation switch: 0 = tree-ordered in-register elimination (humanoid_1205_v1 dof tree, default; a launch of
+ * one substep runs it on a 4 x 16 lane grid per env), 3 = the same with one lane per matrix row (what the resident
+ * engine kernel uses), 2 = dense in-register Gauss-Jordan (any tree with nv == 58), 1 = generic LDS kernel (any nv <= 64) */
 int egp_set_pd_variant(egp_ctx *ctx, int variant);
 /* HumanoidEnv.load_experts (ego_pose/envs/humanoid_v1.py:47-54): packs the reward rows into HBM */
 int egp_upload_experts(egp_ctx *ctx, const egp_expert_table *tbl);

@@ -51,7 +51,7 @@ def test_obs_and_body_quat_edge_sizes(ctx):
 
 
 # ------------------------------------------------------------------------------------------------ K1
-@pytest.mark.parametrize("variant", [0, 1, 2])     # tree-ordered / generic LDS / dense in-register
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])     # tree-ordered on the lane grid / generic LDS / dense in-register / tree-ordered, lane per row
 def test_pd_torque_golden_f64(ctx, variant):
     g = load_golden("pd_torque.npz")
     ctx.set_pd_variant(variant)
