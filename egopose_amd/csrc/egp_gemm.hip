@@ -30,6 +30,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));       // 16-byte load, 4-byte aligned
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 inline int after_launch(const char *what) {
     hipError_t e = hipGetLastError();
@@ -41,6 +42,36 @@ inline int after_launch(const char *what) {
 }
 
 constexpr int BM = 128, BK = 32;
+
+// tools/probes/gemm_trace.hip compiles this file with EGP_GEMM_TRACE: cycle stamps of one wave of one workgroup
+#ifdef EGP_GEMM_TRACE
+__device__ long long g_gemm_trace[1024];
+__device__ int g_gemm_trace_n;
+#define EGP_TR(tag)                                                                         \
+    do {                                                                                    \
+        if (blockIdx.x == EGP_GEMM_TRACE && blockIdx.z == 0 && threadIdx.x == 0 && g_gemm_trace_n < 510) { \
+            g_gemm_trace[2 * g_gemm_trace_n] = (tag);                                       \
+            g_gemm_trace[2 * g_gemm_trace_n + 1] = (long long)__builtin_readcyclecounter(); \
+            ++g_gemm_trace_n;                                                               \
+        }                                                                                   \
+    } while (0)
+// the same for the two roles of k_gemm_ws: who = 0 consumer (thread 0), 1 producer (thread 256); separate halves of the
+// buffer, the entry counter lives in a register (a counter in memory costs a load round trip per stamp)
+__device__ int g_gemm_trace_n2[2];
+#define EGP_TRW_DECL int egp_trn = 0
+#define EGP_TRW(who, tag)                                                                   \
+    do {                                                                                    \
+        if (blockIdx.x == (EGP_GEMM_TRACE & 255) && threadIdx.x == (who) * 256 && egp_trn < 250) { \
+            g_gemm_trace[(who) * 512 + 2 * egp_trn] = (tag);                                \
+            g_gemm_trace[(who) * 512 + 2 * egp_trn + 1] = (long long)__builtin_readcyclecounter(); \
+            g_gemm_trace_n2[who] = ++egp_trn;                                               \
+        }                                                                                   \
+    } while (0)
+#else
+#define EGP_TR(tag) do { } while (0)
+#define EGP_TRW_DECL do { } while (0)
+#define EGP_TRW(who, tag) do { } while (0)
+#endif
 __host__ __device__ constexpr int panel_el(int R) { return R * 8 + 32; }      // bf16 elements per k-panel of an R-row tile
 __host__ __device__ constexpr int tile_el(int R) { return 4 * panel_el(R); }
 
@@ -53,8 +84,9 @@ struct GemmArgs {
     const float *mask; long ldmask;
     int ones_col;                             // B has a virtual column N of ones (its result: column N of the workspace)
     int k_per_split;                          // multiple of BK; gridDim.z splits
-    float *ws;                                // [splits][M][N + ones_col] when gridDim.z > 1 or ones_col
+    float *ws; int ldws;                      // [splits][M][ldws] when there are k splits or a ones column; ldws = N + ones_col rounded up to 4
     int tiles_m, tiles_n, xcd_order;
+    int grid_tiles, n_items;                  // k_gemm_ws: tile slots (the XCD order pads tiles_m to a multiple of 8), slots x k splits
 };
 
 // LDS image of an operand tile (R rows x 32 k, bf16): four k-panels of [R][8] (+ 64 bytes between panels), element
@@ -69,8 +101,9 @@ struct GemmArgs {
 // k-contiguous memory (P[row * ld + k]): thread t -> k quad t & 7, rows (t >> 3) + 32 u: eight lanes read the 128 bytes one
 // row contributes to the tile with one 16-byte load each. Registers: v[4 u + j] = element (row_u, k0 + 4 (t & 7) + j).
 template <int R, bool ktail>
-__device__ __forceinline__ void load_kc(const float *__restrict__ P, long ld, int rows, int r0, int k0, int kend, float (&v)[R / 8]) {
-    const int t = threadIdx.x, k = k0 + (t & 7) * 4, rb = t >> 3;
+__device__ __forceinline__ void load_kc(const float *__restrict__ P, long ld, int rows, int r0, int k0, int kend, float (&v)[R / 8],
+                                        const int t = threadIdx.x) {
+    const int k = k0 + (t & 7) * 4, rb = t >> 3;
 #pragma unroll
     for (int u = 0; u < R / 32; ++u) {
         const int row = min(r0 + rb + 32 * u, rows - 1);
@@ -93,8 +126,8 @@ __device__ __forceinline__ void load_kc(const float *__restrict__ P, long ld, in
 // `ones_row` >= 0: a virtual row of ones at that index (the bias-gradient column of a weight gradient).
 template <int R, bool ktail>
 __device__ __forceinline__ void load_rc(const float *__restrict__ P, long ld, int rows, int r0, int k0, int kend, int ones_row,
-                                        float (&v)[R / 8]) {
-    const int t = threadIdx.x, l = t & 63, kb = k0 + (t >> 6) * 8;
+                                        float (&v)[R / 8], const int t = threadIdx.x) {
+    const int l = t & 63, kb = k0 + (t >> 6) * 8;
 #pragma unroll
     for (int u = 0; u < R / 64; ++u) {
         const int row = r0 + l + 64 * u;
@@ -125,8 +158,8 @@ __device__ __forceinline__ void split_to(float x, __bf16 (&piece)[3]) {
 
 // k-contiguous staging: 4 consecutive k of row (t >> 3) + 32 u -> one 8-byte store per image
 template <int R, int NIMG>
-__device__ __forceinline__ void store_kc(const float (&v)[R / 8], __bf16 *dst, int img) {
-    const int t = threadIdx.x, kq = t & 7, rb = t >> 3;
+__device__ __forceinline__ void store_kc(const float (&v)[R / 8], __bf16 *dst, int img, const int t = threadIdx.x) {
+    const int kq = t & 7, rb = t >> 3;
 #pragma unroll
     for (int u = 0; u < R / 32; ++u) {
         bf16x4 q[3];
@@ -145,8 +178,8 @@ __device__ __forceinline__ void store_kc(const float (&v)[R / 8], __bf16 *dst, i
 
 // row-contiguous staging: 8 consecutive k (panel = wave) of row lane + 64 u -> one 16-byte store per image
 template <int R, int NIMG>
-__device__ __forceinline__ void store_rc(const float (&v)[R / 8], __bf16 *dst, int img) {
-    const int t = threadIdx.x, l64 = t & 63, panel = t >> 6;
+__device__ __forceinline__ void store_rc(const float (&v)[R / 8], __bf16 *dst, int img, const int t = threadIdx.x) {
+    const int l64 = t & 63, panel = t >> 6;
 #pragma unroll
     for (int u = 0; u < R / 64; ++u) {
         bf16x8 q[3];
@@ -196,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x(GemmArgs g) {
 
     int tm, tn;
     if (!tile_of(g, blockIdx.x, tm, tn)) return;
+    EGP_TR(1);
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = blockIdx.z * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
@@ -284,18 +318,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x(GemmArgs g) {
         while (s + 3 < nfull) {                           // buffer 0 holds tile s, set 1 holds tile s + 1 (in flight)
             // (sched_barrier: the compiler must not hoist the conversions of the in-flight set -- and with them the
             //  wait for its loads -- above the multiply that is there to cover their latency)
+            EGP_TR(10);
             gload(s + 2, va0, vb0, FULL);
             __builtin_amdgcn_sched_barrier(0);
+            EGP_TR(11);
             compute(0);
             __builtin_amdgcn_sched_barrier(0);
+            EGP_TR(12);
             sstore(1, va1, vb1);
+            EGP_TR(13);
             __syncthreads();
+            EGP_TR(14);
             gload(s + 3, va1, vb1, FULL);
             __builtin_amdgcn_sched_barrier(0);
             compute(1);
             __builtin_amdgcn_sched_barrier(0);
+            EGP_TR(15);
             sstore(0, va0, vb0);
             __syncthreads();
+            EGP_TR(16);
             s += 2;
         }
         const bool three = nfull - s == 3;                // two or three tiles left
@@ -319,6 +360,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x(GemmArgs g) {
         compute(last ^ 1);
     }
 
+    EGP_TR(20);
     // ---- epilogue. acc[i][j][r]: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31 of the 32 x 32 block.
     // Branch-free per element: mask values of a block are fetched together (clamped addresses), stores of interior tiles
     // carry no predicate.
@@ -326,8 +368,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x(GemmArgs g) {
     const int n_out = g.N + (g.ones_col ? 1 : 0);
     const bool interior = m0 + BM <= g.M && n0 + BN <= n_out;
     const float floor_v = g.relu ? 0.f : -__builtin_inff();
-    float *dst = partial ? g.ws + (long)blockIdx.z * g.M * n_out : g.C;
-    const long ldd = partial ? n_out : g.ldc;
+    float *dst = partial ? g.ws + (long)blockIdx.z * g.M * g.ldws : g.C;
+    const long ldd = partial ? g.ldws : g.ldc;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -365,16 +407,417 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x(GemmArgs g) {
                 }
             }
         }
+    EGP_TR(21);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Three-piece products, warp-specialised and persistent (the default for terms = 6).
+//
+// In k_gemm_bf16x every wave loads, splits, stores, waits at two barriers and multiplies in turn; with the short k loops
+// of the update (7-10 k-tiles) and two workgroups per CU a k-tile takes ~4 k cycles of which the matrix cores are busy
+// for 1.5 k (cycle stamps: tools/probes/gemm_trace.hip). Here a workgroup is 8 waves with fixed roles:
+//   waves 4-7 (producers): global loads of the operand tiles four k-tiles ahead (four register sets), split into the
+//                          three bf16 images, stores into one of TWO LDS buffers
+//   waves 0-3 (consumers): fragment reads + 48 MFMAs per k-tile, the epilogue
+// One barrier per k-tile: while the consumers multiply buffer p & 1 the producers fill the other one. A SIMD holds one
+// wave of each kind, so the conversions (VALU) and the matrix pipe overlap by hardware scheduling rather than by the
+// compiler's instruction order. The workgroup is persistent: it walks its work items (tile slot x k split, dealt
+// round-robin over the grid) as ONE stream of k-tiles, so the loads of the next tile are in flight while the consumers
+// write the previous tile's result -- no pipeline fill per tile.
+// A ragged last k-tile is loaded as the last 32 k of the range (in bounds, branch-free) with its already-multiplied head
+// zeroed on the way into LDS; ranges shorter than one k-tile take k_gemm_bf16x.
+struct WsCursor {                  // position in a workgroup's stream of k-tiles; wave-uniform
+    int w, s, nst;                 // work item, k-tile within it, k-tiles of the item
+    int m0, n0, z, kbeg, kend;
+};
+
+template <int BN>
+__device__ __forceinline__ bool ws_item(const GemmArgs &g, int w, WsCursor &c) {       // c is written only for a real tile
+    const int L = w % g.grid_tiles, z = w / g.grid_tiles;
+    int tm, tn;
+    if (!tile_of(g, L, tm, tn)) return false;
+    c.w = w; c.z = z; c.m0 = tm * BM; c.n0 = tn * BN;
+    c.kbeg = z * g.k_per_split;
+    c.kend = min(g.K, c.kbeg + g.k_per_split);
+    c.nst = (c.kend - c.kbeg + BK - 1) / BK;
+    return true;
+}
+
+// next k-tile; past the end the cursor stays on the last one (the producers' look-ahead then reloads it, harmlessly)
+template <int BN>
+__device__ __forceinline__ void ws_next(const GemmArgs &g, WsCursor &c, int &w_scan) {
+    if (++c.s < c.nst) return;
+    for (w_scan += gridDim.x; w_scan < g.n_items; w_scan += gridDim.x)
+        if (ws_item<BN>(g, w_scan, c)) { c.s = 0; return; }
+    c.s = c.nst - 1;
+}
+
+// Producer-side staging of k_gemm_ws. The per-thread part of a load address (row offset, clamped) is a 32-bit byte offset
+// computed once per work item; the k-tile's part is wave-uniform and goes into the scalar base of the load
+// (global_load ... v_off, s[base:base+1]): a k-tile's loads cost no vector address arithmetic.
+template <int R, bool KC>
+struct WsStage {
+    // k-contiguous memory: thread t -> k octet t & 3 (= LDS k-panel), rows (t >> 2) + 64 u: two 16-byte loads per row, and the
+    // eight values are exactly one [row][8 bf16] panel entry (one 16-byte LDS store per image, no bank conflicts).
+    // row-contiguous memory: lane -> rows lane + 64 u, wave -> k-panel (as load_rc).
+    unsigned off[R / 64];                      // byte offset of the thread's rows
+    bool one[KC ? 1 : R / 64];                 // row-contiguous form: the virtual row of ones
+    __device__ __forceinline__ void bind(long ld, int rows, int r0, int ones_row, int t) {
+        if constexpr (KC) {
+#pragma unroll
+            for (int u = 0; u < R / 64; ++u) off[u] = (unsigned)(((long)min(r0 + (t >> 2) + 64 * u, rows - 1) * ld + (t & 3) * 8) * 4);
+            one[0] = false;
+        } else {
+#pragma unroll
+            for (int u = 0; u < R / 64; ++u) {
+                const int row = r0 + (t & 63) + 64 * u;
+                one[u] = row == ones_row;
+                off[u] = (unsigned)min(row, rows - 1) * 4u;
+            }
+        }
+    }
+    // The loads are inline asm and the wait for them is explicit (ws_wait): the compiler's own wait insertion loses count
+    // of loads across the unrolled, branching producer loop and falls back to "everything older than the last few", which
+    // collapses the four-deep prefetch into one. Staged registers: k-contiguous -> 16-byte pieces q[2 u], q[2 u + 1] =
+    // k 0..3, 4..7 of row u; row-contiguous -> scalars f[8 u + j].
+    static constexpr int NLOAD = KC ? R / 32 : R / 8;                         // load instructions per k-tile and thread
+    using Regs = std::conditional_t<KC, f32x4[R / 32], float[R / 8]>;
+    // k0: first k of the tile; `panel`: the wave's k-panel (wave-uniform), used by the row-contiguous form
+    __device__ __forceinline__ void load(const float *__restrict__ P, long ld, int k0, int panel, Regs &r) const {
+        if constexpr (KC) {
+            const char *base = (const char *)(P + k0);
+#pragma unroll
+            for (int u = 0; u < R / 64; ++u) {
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[2 * u]) : "v"(off[u]), "s"(base));
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(r[2 * u + 1]) : "v"(off[u]), "s"(base));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const char *base = (const char *)(P + (long)(k0 + 8 * panel + j) * ld);
+#pragma unroll
+                for (int u = 0; u < R / 64; ++u) asm volatile("global_load_dword %0, %1, %2" : "=v"(r[8 * u + j]) : "v"(off[u]), "s"(base));
+            }
+        }
+    }
+    // after ws_wait: v[8 u + j] = element (row_u, k = 8 panel + j) of the tile in both forms
+    __device__ __forceinline__ void unpack(const Regs &r, float (&v)[R / 8]) const {
+        if constexpr (KC) {
+#pragma unroll
+            for (int u = 0; u < R / 64; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[8 * u + e] = r[2 * u][e]; v[8 * u + 4 + e] = r[2 * u + 1][e]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < R / 64; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[8 * u + j] = one[u] ? 1.f : r[8 * u + j];
+        }
+    }
+};
+
+// s_waitcnt vmcnt(N) tied to the registers of one staged set: no use (or copy) of them can move above the wait
+template <int N> __device__ __forceinline__ void ws_wait(f32x4 (&r)[2]) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[0]), "+v"(r[1]) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void ws_wait(f32x4 (&r)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void ws_wait(float (&r)[8]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void ws_wait(float (&r)[16]) {
+    asm volatile("s_waitcnt vmcnt(%16)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]),
+                   "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
+                 : "n"(N));
+}
+
+// exact three-way split by truncation: x = h + m + l with 8 significant bits each (the float32 mantissa is 24 bits), the
+// bf16 pieces are the upper halves of h, m and l. Two floats at a time: the pieces of a pair pack with one v_perm each.
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &ph, unsigned &pm, unsigned &pl) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    const float h0 = __uint_as_float(u0 & 0xffff0000u), h1 = __uint_as_float(u1 & 0xffff0000u);
+    const float r0 = x0 - h0, r1 = x1 - h1;                                   // exact
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    const float m0 = __uint_as_float(v0 & 0xffff0000u), m1 = __uint_as_float(v1 & 0xffff0000u);
+    const float l0 = r0 - m0, l1 = r1 - m1;                                   // exact, at most 8 significant bits
+    ph = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                          // { hi16(x1), hi16(x0) }
+    pm = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    pl = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+}
+
+// staged registers -> the three LDS images: v[8 u + j] = (row r_first + 64 u, k = 8 panel + j), one 16-byte store per image
+template <int R>
+__device__ __forceinline__ void ws_store(const float (&v)[R / 8], __bf16 *dst, int img, int panel, int r_first) {
+#pragma unroll
+    for (int u = 0; u < R / 64; ++u) {
+        unsigned q[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split3_pair(v[8 * u + 2 * j], v[8 * u + 2 * j + 1], q[0][j], q[1][j], q[2][j]);
+        const int off = panel * panel_el(R) + (r_first + 64 * u) * 8;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *(uint4 *)(dst + c * img + off) = make_uint4(q[c][0], q[c][1], q[c][2], q[c][3]);
+    }
+}
+// zero the elements of a staged tile whose k (relative to the tile's first k) lies before `zrel`
+template <int R>
+__device__ __forceinline__ void ws_zero_head(float (&v)[R / 8], int zrel, int panel) {
+#pragma unroll
+    for (int u = 0; u < R / 64; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[8 * u + j] = 8 * panel + j >= zrel ? v[8 * u + j] : 0.f;
+}
+
+template <int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
+    constexpr int NIMG = 3, NSET = 4;
+    constexpr int WN = BN == 128 ? 2 : 1;
+    constexpr int MI = BN == 128 ? 2 : 1, NJ = 2;
+    constexpr int WROWS = 32 * MI;
+    constexpr int A_EL = tile_el(BM), B_EL = tile_el(BN);
+    constexpr int BUF_EL = NIMG * (A_EL + B_EL);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16 *base = (__bf16 *)smem;
+    const int t = threadIdx.x, pt = t & 255, lane = t & 63;
+    const bool producer = __builtin_amdgcn_readfirstlane(t) >= 256;         // wave-uniform, and the compiler knows it
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6) & 3;
+    const int ones_row = g.ones_col ? g.N : -1;
+
+    // this workgroup's stream: P k-tiles over its items
+    int P = 0, w_first = -1;
+    WsCursor cur{};
+    for (int w = blockIdx.x; w < g.n_items; w += gridDim.x) {
+        WsCursor c{};
+        if (ws_item<BN>(g, w, c)) {
+            P += c.nst;
+            if (w_first < 0) { w_first = w; cur = c; }
+        }
+    }
+    if (P == 0) return;
+    cur.s = 0;
+    int w_scan = w_first;
+    EGP_TRW_DECL;
+
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
+    constexpr std::integral_constant<int, 2> S2{};
+    constexpr std::integral_constant<int, 3> S3{};
+
+    // iteration p: the consumers multiply k-tile p (buffer p & 1); the producers stage k-tile p + 1 from register set
+    // (p + 1) & 3 into the other buffer and request k-tile p + 5 into the freed set. Both roles run the same number of
+    // barriers, each in its own loop (separate loops keep the producers' staging registers and the consumers' accumulators
+    // out of each other's live ranges).
+    if (producer) {
+        using SA = WsStage<BM, A_KC>;
+        using SB = WsStage<BN, B_KC>;
+        typename SA::Regs ra[NSET];
+        typename SB::Regs rb[NSET];
+        int zrel[NSET] = {0, 0, 0, 0};
+        SA sa;
+        SB sb;
+        int bound = -1;
+        // loads of the younger sets that may still be in flight when a set is staged: three sets, or as many as the 6-bit
+        // counter can express (row-contiguous operands take 16 scalar loads each)
+        constexpr int PER_SET = SA::NLOAD + SB::NLOAD;
+        constexpr int YOUNGER = 3 * PER_SET <= 63 ? 3 * PER_SET : (2 * PER_SET <= 63 ? 2 * PER_SET : PER_SET);
+        auto issue = [&](auto setc) __attribute__((always_inline)) {      // loads of the k-tile under the cursor; cursor moves on
+            constexpr int SET = decltype(setc)::value;
+            if (cur.w != bound) {
+                sa.bind(g.lda, g.M, cur.m0, -1, pt);
+                sb.bind(g.ldb, g.N, cur.n0, ones_row, pt);
+                bound = cur.w;
+            }
+            const bool last = cur.s == cur.nst - 1;
+            const int kz = cur.kbeg + cur.s * BK;
+            const int k0 = last ? cur.kend - BK : kz;
+            zrel[SET] = kz - k0;
+            sa.load(g.A, g.lda, k0, wave, ra[SET]);
+            sb.load(g.B, g.ldb, k0, wave, rb[SET]);
+            ws_next<BN>(g, cur, w_scan);
+        };
+        auto stage = [&](auto setc, int buf) __attribute__((always_inline)) {   // register set -> LDS buffer `buf`
+            constexpr int SET = decltype(setc)::value;
+            // (panel, first row) of the thread: k-contiguous -> (t & 3, t >> 2), row-contiguous -> (wave, lane)
+            const int pa_panel = A_KC ? (pt & 3) : wave, pa_row = A_KC ? (pt >> 2) : lane;
+            const int pb_panel = B_KC ? (pt & 3) : wave, pb_row = B_KC ? (pt >> 2) : lane;
+            ws_wait<YOUNGER>(ra[SET]);
+            ws_wait<YOUNGER>(rb[SET]);
+            EGP_TRW(1, 33);
+            float va[BM / 8], vb[BN / 8];
+            sa.unpack(ra[SET], va);
+            sb.unpack(rb[SET], vb);
+            if (zrel[SET] > 0) {
+                ws_zero_head<BM>(va, zrel[SET], pa_panel);
+                ws_zero_head<BN>(vb, zrel[SET], pb_panel);
+            }
+            __bf16 *pa = base + buf * BUF_EL, *pb = pa + NIMG * A_EL;
+            ws_store<BM>(va, pa, A_EL, pa_panel, pa_row);
+            EGP_TRW(1, 34);
+            ws_store<BN>(vb, pb, B_EL, pb_panel, pb_row);
+        };
+        issue(S0); issue(S1); issue(S2); issue(S3);      // k-tiles 0..3 in flight
+        stage(S0, 0);
+        issue(S0);                                       // k-tile 4
+        __syncthreads();
+        auto iteration = [&](auto setc, int p) __attribute__((always_inline)) {
+            EGP_TRW(1, 30);
+            if (p + 1 < P) {
+#if !defined(EGP_WS_SKIP) || EGP_WS_SKIP != 2
+                stage(setc, (p + 1) & 1);
+#endif
+                EGP_TRW(1, 31);
+                issue(setc);
+            }
+            EGP_TRW(1, 32);
+            __syncthreads();
+        };
+        for (int p = 0; p < P; p += 4) {
+            iteration(S1, p);
+            if (p + 1 < P) iteration(S2, p + 1);
+            if (p + 2 < P) iteration(S3, p + 2);
+            if (p + 3 < P) iteration(S0, p + 3);
+        }
+        return;
+    }
+
+    // ---- consumers
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 31, fkh = lane >> 5;
+    f32x16 acc[MI][NJ];
+    auto clear = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    // The product is formed transposed (B fragment as the first MFMA operand): acc[i][j][r] is
+    //   C[m = 32 i + (lane & 31)][n = 32 j + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)]     (within the wave's 64 x 64 / 32 x 64 part)
+    // so that a lane holds four consecutive n of one row: 16-byte stores (and mask loads).
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const __bf16 *pa = base + buf * BUF_EL, *pb = pa + NIMG * A_EL;
+        // every fragment of the k-tile is requested before the first MFMA (the matrix pipe then runs the 48 products
+        // back to back instead of idling through an LDS round trip in the middle)
+        bf16x8 fa[BK / 16][NIMG][MI], fb[BK / 16][NIMG][NJ];
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks)
+#pragma unroll
+            for (int c = 0; c < NIMG; ++c) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    fa[ks][c][i] = *(const bf16x8 *)(pa + c * A_EL + (2 * ks + fkh) * panel_el(BM) + (wm * WROWS + 32 * i + frow) * 8);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    fb[ks][c][j] = *(const bf16x8 *)(pb + c * B_EL + (2 * ks + fkh) * panel_el(BN) + (wn * 64 + 32 * j + frow) * 8);
+            }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    f32x16 a = acc[i][j];                 // smallest terms first
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][0][j], fa[ks][2][i], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][2][j], fa[ks][0][i], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][1][j], fa[ks][1][i], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][0][j], fa[ks][1][i], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][1][j], fa[ks][0][i], a, 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][0][j], fa[ks][0][i], a, 0, 0, 0);
+                }
+    };
+    // Epilogue: a lane holds 4 consecutive n of row m = lane & 31 -- 16 bytes, but 32 different rows per store instruction.
+    // The wave's part of the tile therefore goes through a wave-private LDS patch (32 rows x 64 columns at a time, written
+    // as 16-byte pieces, read back row-major): every global store instruction then writes four 256-byte row segments.
+    constexpr int EP_LD = 64 + 4;                         // floats per patch row (+4: the 16-byte writes of 16 lanes hit 64 banks)
+    float *patch = (float *)(smem + (size_t)2 * BUF_EL * sizeof(__bf16)) + wave * 32 * EP_LD;
+    const bool partial = g.n_items > g.grid_tiles || g.ones_col;
+    // (the launcher sends only 16-byte-friendly outputs here: N, ldc, ldmask multiples of 4, aligned bases; the workspace
+    //  rows of split / ones-column launches are padded to a multiple of 4 floats)
+    const int ncols = partial ? g.ldws : g.N;
+    const long ldd = partial ? g.ldws : g.ldc;
+    const float floor_v = g.relu ? 0.f : -__builtin_inff();
+    // (the flags are template constants of the body: inside it there is no branch, so the compiler counts its waits --
+    //  all mask rows are requested first, and no store is ever waited for)
+    auto epilogue_body = [&](auto partial_c, auto mask_c) __attribute__((always_inline)) {
+        constexpr bool PARTIAL = decltype(partial_c)::value, MASK = decltype(mask_c)::value;
+        float *dst = PARTIAL ? g.ws + (long)cur.z * g.M * g.ldws : g.C;
+        const int col = cur.n0 + wn * 64 + 4 * (lane & 15);
+        const int colc = min(col, ncols - 4);
+        const bool col_ok = col < ncols;
+        const int row0 = cur.m0 + wm * WROWS + (lane >> 4);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (!PARTIAL) bv = *(const float4 *)((g.bias ? g.bias : g.C) + colc);      // (no bias: any readable address, the value is dropped)
+        if (PARTIAL || !g.bias) bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 keep[MI][8];
+        if constexpr (MASK) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int it = 0; it < 8; ++it)
+                    keep[i][it] = *(const float4 *)(g.mask + (long)min(row0 + 32 * i + 4 * it, g.M - 1) * g.ldmask + colc);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq)
+                    *(float4 *)(patch + (lane & 31) * EP_LD + 32 * j + 8 * rq + 4 * (lane >> 5)) =
+                        make_float4(acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = row0 + 32 * i + 4 * it;
+                float4 x = *(const float4 *)(patch + ((lane >> 4) + 4 * it) * EP_LD + 4 * (lane & 15));
+                if constexpr (!PARTIAL) {
+                    x.x = fmaxf(x.x + bv.x, floor_v); x.y = fmaxf(x.y + bv.y, floor_v);
+                    x.z = fmaxf(x.z + bv.z, floor_v); x.w = fmaxf(x.w + bv.w, floor_v);
+                }
+                if constexpr (MASK) {
+                    x.x = keep[i][it].x > 0.f ? x.x : 0.f; x.y = keep[i][it].y > 0.f ? x.y : 0.f;
+                    x.z = keep[i][it].z > 0.f ? x.z : 0.f; x.w = keep[i][it].w > 0.f ? x.w : 0.f;
+                }
+                if (row < g.M && col_ok) *(float4 *)(dst + (long)row * ldd + col) = x;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        if (partial) epilogue_body(std::true_type{}, std::false_type{});
+        else if (g.mask) epilogue_body(std::false_type{}, std::true_type{});
+        else epilogue_body(std::false_type{}, std::false_type{});
+    };
+    clear();
+    __syncthreads();
+    for (int p = 0; p < P; ++p) {
+        EGP_TRW(0, 40);
+#if !defined(EGP_WS_SKIP) || EGP_WS_SKIP != 1
+        compute(p & 1);
+#endif
+        EGP_TRW(0, 41);
+        if (cur.s == cur.nst - 1) {
+            epilogue();
+            EGP_TRW(0, 43);
+            clear();
+            EGP_TRW(0, 42);
+        }
+        ws_next<BN>(g, cur, w_scan);
+        __syncthreads();
+    }
 }
 
 // partial sums -> C (+ the ones column -> bias_grad), splits added in index order
-__global__ __launch_bounds__(256) void k_gemm_reduce(const float *__restrict__ ws, int splits, int M, int N, int n_out, float *__restrict__ C,
+__global__ __launch_bounds__(256) void k_gemm_reduce(const float *__restrict__ ws_, int ldws, int splits, int M, int N, int n_out, float *__restrict__ C,
                                                      long ldc, float *__restrict__ bias_grad, int accumulate) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)M * n_out) return;
-    const int row = (int)(idx / n_out), col = (int)(idx % n_out);
+    const long id0 = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id0 >= (long)M * n_out) return;
+    const int row = (int)(id0 / n_out), col = (int)(id0 % n_out);
+    const long idx = (long)row * ldws + col;
+    const float *__restrict__ ws = ws_;
     // eight independent chains (the loads of a chain are 0.5 us apart otherwise); the order is fixed, so results repeat
-    const long stride = (long)M * n_out;
+    const long stride = (long)M * ldws;
     float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int k = 0;
     for (; k + 8 <= splits; k += 8) {
@@ -431,6 +874,34 @@ int launch_variant(const GemmArgs &g, dim3 grid, size_t lds, hipStream_t s) {
     return after_launch("k_gemm_bf16x");
 }
 
+template <int BN>
+int launch_ws(const GemmArgs &g, hipStream_t s) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        EGP_HIP_CHECK(hipGetDevice(&dev));
+        EGP_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const size_t lds = (size_t)2 * 3 * (tile_el(BM) + tile_el(BN)) * sizeof(__bf16) + 4 * 32 * (64 + 4) * sizeof(float);   // + the epilogue patches
+    const dim3 grid((unsigned)(g.n_items < n_cu ? g.n_items : n_cu));
+#define EGP_GEMM_WS_LAUNCH(AK, BKC)                                                                                   \
+    do {                                                                                                              \
+        auto kern = k_gemm_ws<BN, AK, BKC>;                                                                           \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) {                                                                                              \
+            EGP_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        kern<<<grid, dim3(512), lds, s>>>(g);                                                                         \
+    } while (0)
+    if (g.a_kc && g.b_kc) EGP_GEMM_WS_LAUNCH(true, true);
+    else if (g.a_kc && !g.b_kc) EGP_GEMM_WS_LAUNCH(true, false);
+    else if (!g.a_kc && g.b_kc) EGP_GEMM_WS_LAUNCH(false, true);
+    else EGP_GEMM_WS_LAUNCH(false, false);
+#undef EGP_GEMM_WS_LAUNCH
+    return after_launch("k_gemm_ws");
+}
+
 }  // namespace
 
 extern "C" {
@@ -454,7 +925,7 @@ int egp_scatter_rows_f32(const float *dout, int64_t ldd, const int64_t *idx, int
 
 int64_t egp_gemm_workspace_floats(int32_t M, int32_t N, int32_t ones_col, int32_t splits) {
     if (splits <= 1 && !ones_col) return 0;
-    return (int64_t)(splits < 1 ? 1 : splits) * M * (N + (ones_col ? 1 : 0));
+    return (int64_t)(splits < 1 ? 1 : splits) * M * ((N + (ones_col ? 1 : 0) + 3) & ~3);      // rows padded to 16 bytes
 }
 
 int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
@@ -476,7 +947,7 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     g.B = d->B; g.ldb = d->ldb; g.b_kc = d->b_kcontig;
     g.C = d->C; g.ldc = d->ldc;
     g.bias = d->bias; g.relu = d->relu; g.mask = d->mask; g.ldmask = d->ldmask;
-    g.ones_col = ones; g.ws = d->workspace;
+    g.ones_col = ones; g.ws = d->workspace; g.ldws = (d->N + ones + 3) & ~3;
     const int n_out = d->N + ones;
     const bool bn64 = n_out <= 64;                 // narrow outputs: 64-column tiles
     const int BNv = bn64 ? 64 : 128;
@@ -490,13 +961,25 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     dim3 grid((g.xcd_order ? ((g.tiles_m + 7) / 8) * 8 : g.tiles_m) * g.tiles_n, 1, zs);
     const int nimg = d->terms == 1 ? 1 : (d->terms == 3 ? 2 : 3), nbuf = d->terms == 6 ? 1 : 2;
     const size_t lds = (size_t)nbuf * nimg * (tile_el(BM) + tile_el(BNv)) * sizeof(__bf16);
+    g.grid_tiles = (int)grid.x;
+    g.n_items = g.grid_tiles * zs;
+    // three-piece products: the warp-specialised persistent kernel, unless a k range is shorter than one k-tile
+    static const bool ws_on = []() { const char *e = getenv("EGP_GEMM_WS"); return !(e && atoi(e) == 0); }();
+    const int last_len = d->K - (zs - 1) * g.k_per_split;
     int rc;
+    const bool small32 = (size_t)d->M * (size_t)(d->a_kcontig ? d->lda : 1) < (1u << 30) && (size_t)d->N * (size_t)(d->b_kcontig ? d->ldb : 1) < (1u << 30);
+    const bool wide = partial ? ((size_t)d->workspace & 15) == 0
+                              : (d->N % 4 == 0 && d->ldc % 4 == 0 && ((size_t)d->C & 15) == 0 && (!d->bias || ((size_t)d->bias & 15) == 0) &&
+                                 (!d->mask || (d->ldmask % 4 == 0 && ((size_t)d->mask & 15) == 0)));
+    if (d->terms == 6 && ws_on && last_len >= BK && small32 && wide) {
+        rc = bn64 ? launch_ws<64>(g, s) : launch_ws<128>(g, s);
+    } else
     if (bn64) rc = d->terms == 6 ? launch_variant<64, 6>(g, grid, lds, s) : d->terms == 3 ? launch_variant<64, 3>(g, grid, lds, s) : launch_variant<64, 1>(g, grid, lds, s);
     else rc = d->terms == 6 ? launch_variant<128, 6>(g, grid, lds, s) : d->terms == 3 ? launch_variant<128, 3>(g, grid, lds, s) : launch_variant<128, 1>(g, grid, lds, s);
     if (rc != EGP_OK) return rc;
     if (partial) {
         const long total = (long)d->M * n_out;
-        k_gemm_reduce<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(d->workspace, zs, d->M, d->N, n_out, d->C, d->ldc,
+        k_gemm_reduce<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(d->workspace, g.ldws, zs, d->M, d->N, n_out, d->C, d->ldc,
                                                                                 d->bias_grad, d->accumulate);
         return after_launch("k_gemm_reduce");
     }

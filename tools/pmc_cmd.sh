@@ -1,0 +1,24 @@
+#!/bin/bash
+# Counters of the kernels of an arbitrary command: tools/pmc_cmd.sh "<kernel-name substring>" "<command>" <counter> [<counter> ...]
+# (rocprofv3 --pmc passes of <= 3 counters each, kernel-trace only)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+K=$1; CMD=$2; shift 2
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_cmd
+rm -rf $OUT; mkdir -p $OUT
+i=0
+while [ $# -gt 0 ]; do
+  grp="$1 ${2:-} ${3:-}"; shift; [ $# -gt 0 ] && shift; [ $# -gt 0 ] && shift
+  timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -o mb -- $CMD > $OUT/p$i.log 2>&1
+  i=$((i+1))
+done
+python - <<PY
+import csv, glob, collections
+acc = collections.defaultdict(lambda: [0.0, 0])
+for path in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        if "$K" in r["Kernel_Name"]:
+            a = acc[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+for k, (s, n) in sorted(acc.items()):
+    print("%-28s launches %4d  avg %.5g" % (k, n, s / max(n, 1)))
+PY
+rm -rf $OUT/p*/
