@@ -964,7 +964,8 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     g.grid_tiles = (int)grid.x;
     g.n_items = g.grid_tiles * zs;
     // three-piece products: the warp-specialised persistent kernel, unless a k range is shorter than one k-tile
-    static const bool ws_on = []() { const char *e = getenv("EGP_GEMM_WS"); return !(e && atoi(e) == 0); }();
+    const char *ws_env = getenv("EGP_GEMM_WS");            // EGP_GEMM_WS=0: k_gemm_bf16x for everything (read per call: tests switch it)
+    const bool ws_on = !(ws_env && atoi(ws_env) == 0);
     const int last_len = d->K - (zs - 1) * g.k_per_split;
     int rc;
     const bool small32 = (size_t)d->M * (size_t)(d->a_kcontig ? d->lda : 1) < (1u << 30) && (size_t)d->N * (size_t)(d->b_kcontig ? d->ldb : 1) < (1u << 30);

@@ -8,6 +8,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["ws", "classic"], autouse=True)
+def three_piece_kernel(request, monkeypatch):
+    """terms = 6 runs on the warp-specialised persistent kernel (k_gemm_ws) where its preconditions hold (k ranges of at
+    least one k-tile, 16-byte-friendly outputs) and on k_gemm_bf16x otherwise; EGP_GEMM_WS=0 sends everything to the latter.
+    Every test of this file runs both ways."""
+    monkeypatch.setenv("EGP_GEMM_WS", "1" if request.param == "ws" else "0")
+    return request.param
+
+
 def _rel(got, ref):
     return float((got.double() - ref).norm() / ref.norm().clamp_min(1e-300))
 
@@ -25,7 +34,7 @@ def _operands(M, N, K, a_kc, b_kc, seed):
 
 @pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
 @pytest.mark.parametrize("M,N,K", [(1000, 300, 243), (257, 200, 300), (129, 52, 200), (64, 1, 77), (5, 243, 1), (300, 243, 4097),
-                                   (128, 128, 32), (1, 1, 1)])
+                                   (128, 128, 32), (1, 1, 1), (3000, 244, 300), (700, 128, 33), (20000, 1024, 128)])
 def test_products_match_float64(a_kc, b_kc, M, N, K):
     from egopose_amd.gemm import gemm
     A, B, ref = _operands(M, N, K, a_kc, b_kc, seed=M + 7 * N + 13 * K)

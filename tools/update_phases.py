@@ -37,7 +37,9 @@ timed(ag.optimizer_policy, "step", "  optimizer steps")
 timed(ag.optimizer_value, "step", "  optimizer steps")
 for it in range(4):
     acc.clear()
+    m0 = torch.cuda.memory_reserved()
     log, ts, tu, n = tr.iteration(it, cfg.min_batch_size)
-print("T_update %.1f ms (%d steps)" % (tu * 1e3, n))
-for k, v in acc.items():
-    print("%-42s %7.1f ms" % (k, v * 1e3))
+    print("iteration %d: T_update %.1f ms (%d steps), allocator reserved %.2f -> %.2f GB" % (it, tu * 1e3, n, m0 / 2**30, torch.cuda.memory_reserved() / 2**30))
+    if it in (1, 3):
+        for k, v in acc.items():
+            print("    %-42s %7.1f ms" % (k, v * 1e3))
