@@ -78,6 +78,14 @@ struct Grid58 {
 inline constexpr Grid58::Order GRID58_ORDER = Grid58::make_order();
 static_assert(Grid58::order_ok(GRID58_ORDER), "grid58: elimination order is not leaves -> root for the compiled-in dof tree");
 
+// 1 / x: v_rcp_f64 (2^-25 relative on gfx950) and ONE third-order step r (1 + e + e^2), e = 1 - x r: three FMAs instead of the
+// four of two Newton steps (fast_rcp), <= 1 ulp for normal x (tools/probes/rcp_probe.hip)
+__device__ __forceinline__ double grid_rcp(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, fma(e, e, e), r);
+}
+
 // acc += bcast(src, lane C of every 16-lane row) * mul, written only in the 16-lane rows of RM
 template <int C, int RM>
 __device__ __forceinline__ void grid_fmac(double &acc, const double &src, const double &mul) {
@@ -150,7 +158,7 @@ __device__ __forceinline__ void grid_pivot(double (&A)[Grid58::IHN][Grid58::JHN]
     for (int jh = 0; jh < Grid58::JHN; ++jh)
         if (((CG | (1u << jhk)) >> jh) & 1) p[jh] = grid_fetch(A[ihk][jh], xa[rk]);
     const double d = grid_bcast<ck>(p[jhk]);
-    const double inv = fast_rcp(d);
+    const double inv = grid_rcp(d);
     const double ninv = -inv;
 #pragma unroll
     for (int jh = 0; jh < Grid58::JHN; ++jh)
