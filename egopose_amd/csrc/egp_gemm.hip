@@ -86,7 +86,8 @@ struct GemmArgs {
     int k_per_split;                          // multiple of BK; gridDim.z splits
     float *ws; int ldws;                      // [splits][M][ldws] when there are k splits or a ones column; ldws = N + ones_col rounded up to 4
     int tiles_m, tiles_n, xcd_order;
-    int grid_tiles, n_items;                  // k_gemm_ws: tile slots (the XCD order pads tiles_m to a multiple of 8), slots x k splits
+    int partial;                              // results go to the workspace (k splits and / or the ones column), reduced by k_gemm_reduce
+    int grid_tiles, n_items, zs;              // k_gemm_ws: tile slots (the XCD order pads tiles_m to a multiple of 8), slots x k splits, k splits
 };
 
 // LDS image of an operand tile (R rows x 32 k, bf16): four k-panels of [R][8] (+ 64 bytes between panels), element
@@ -438,7 +439,7 @@ __device__ __forceinline__ bool ws_item(const GemmArgs &g, int w, WsCursor &c) {
     if (!tile_of(g, L, tm, tn)) return false;
     c.w = w; c.z = z; c.m0 = tm * BM; c.n0 = tn * BN;
     c.kbeg = z * g.k_per_split;
-    c.kend = min(g.K, c.kbeg + g.k_per_split);
+    c.kend = z == g.zs - 1 ? g.K : c.kbeg + g.k_per_split;        // (the last split may carry up to one k-tile more, see the launcher)
     c.nst = (c.kend - c.kbeg + BK - 1) / BK;
     return true;
 }
@@ -732,9 +733,9 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
     // as 16-byte pieces, read back row-major): every global store instruction then writes four 256-byte row segments.
     constexpr int EP_LD = 64 + 4;                         // floats per patch row (+4: the 16-byte writes of 16 lanes hit 64 banks)
     float *patch = (float *)(smem + (size_t)2 * BUF_EL * sizeof(__bf16)) + wave * 32 * EP_LD;
-    const bool partial = g.n_items > g.grid_tiles || g.ones_col;
-    // (the launcher sends only 16-byte-friendly outputs here: N, ldc, ldmask multiples of 4, aligned bases; the workspace
-    //  rows of split / ones-column launches are padded to a multiple of 4 floats)
+    const bool partial = g.partial != 0;
+    // (the launcher sends only outputs with N a multiple of 4 here; the workspace rows of split / ones-column launches are
+    //  padded to a multiple of 4 floats)
     const int ncols = partial ? g.ldws : g.N;
     const long ldd = partial ? g.ldws : g.ldc;
     const float floor_v = g.relu ? 0.f : -__builtin_inff();
@@ -747,16 +748,17 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
         const int colc = min(col, ncols - 4);
         const bool col_ok = col < ncols;
         const int row0 = cur.m0 + wm * WROWS + (lane >> 4);
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (!PARTIAL) bv = *(const float4 *)((g.bias ? g.bias : g.C) + colc);      // (no bias: any readable address, the value is dropped)
-        if (PARTIAL || !g.bias) bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 keep[MI][8];
+        // (16-byte accesses on 4-byte-aligned addresses throughout: leading dimensions like 243 are welcome)
+        f32x4u bv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!PARTIAL) bv = *(const f32x4u *)((g.bias ? g.bias : g.C) + colc);      // (no bias: any readable address, the value is dropped)
+        if (PARTIAL || !g.bias) bv = f32x4u{0.f, 0.f, 0.f, 0.f};
+        f32x4u keep[MI][8];
         if constexpr (MASK) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int it = 0; it < 8; ++it)
-                    keep[i][it] = *(const float4 *)(g.mask + (long)min(row0 + 32 * i + 4 * it, g.M - 1) * g.ldmask + colc);
+                    keep[i][it] = *(const f32x4u *)(g.mask + (long)min(row0 + 32 * i + 4 * it, g.M - 1) * g.ldmask + colc);
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -772,14 +774,14 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
                 const int row = row0 + 32 * i + 4 * it;
                 float4 x = *(const float4 *)(patch + ((lane >> 4) + 4 * it) * EP_LD + 4 * (lane & 15));
                 if constexpr (!PARTIAL) {
-                    x.x = fmaxf(x.x + bv.x, floor_v); x.y = fmaxf(x.y + bv.y, floor_v);
-                    x.z = fmaxf(x.z + bv.z, floor_v); x.w = fmaxf(x.w + bv.w, floor_v);
+                    x.x = fmaxf(x.x + bv[0], floor_v); x.y = fmaxf(x.y + bv[1], floor_v);
+                    x.z = fmaxf(x.z + bv[2], floor_v); x.w = fmaxf(x.w + bv[3], floor_v);
                 }
                 if constexpr (MASK) {
-                    x.x = keep[i][it].x > 0.f ? x.x : 0.f; x.y = keep[i][it].y > 0.f ? x.y : 0.f;
-                    x.z = keep[i][it].z > 0.f ? x.z : 0.f; x.w = keep[i][it].w > 0.f ? x.w : 0.f;
+                    x.x = keep[i][it][0] > 0.f ? x.x : 0.f; x.y = keep[i][it][1] > 0.f ? x.y : 0.f;
+                    x.z = keep[i][it][2] > 0.f ? x.z : 0.f; x.w = keep[i][it][3] > 0.f ? x.w : 0.f;
                 }
-                if (row < g.M && col_ok) *(float4 *)(dst + (long)row * ldd + col) = x;
+                if (row < g.M && col_ok) *(f32x4u *)(dst + (long)row * ldd + col) = f32x4u{x.x, x.y, x.z, x.w};
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -947,7 +949,7 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     g.B = d->B; g.ldb = d->ldb; g.b_kc = d->b_kcontig;
     g.C = d->C; g.ldc = d->ldc;
     g.bias = d->bias; g.relu = d->relu; g.mask = d->mask; g.ldmask = d->ldmask;
-    g.ones_col = ones; g.ws = d->workspace; g.ldws = (d->N + ones + 3) & ~3;
+    g.ones_col = ones; g.ws = d->workspace; g.ldws = (d->N + ones + 3) & ~3; g.partial = partial ? 1 : 0;
     const int n_out = d->N + ones;
     const bool bn64 = n_out <= 64;                 // narrow outputs: 64-column tiles
     const int BNv = bn64 ? 64 : 128;
@@ -962,25 +964,29 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     const int nimg = d->terms == 1 ? 1 : (d->terms == 3 ? 2 : 3), nbuf = d->terms == 6 ? 1 : 2;
     const size_t lds = (size_t)nbuf * nimg * (tile_el(BM) + tile_el(BNv)) * sizeof(__bf16);
     g.grid_tiles = (int)grid.x;
-    g.n_items = g.grid_tiles * zs;
+    // k_gemm_ws wants k ranges of at least one k-tile: a shorter remainder rides with the split before it
+    const int rem = d->K - (zs - 1) * g.k_per_split;
+    const int zs_ws = (zs > 1 && rem < BK) ? zs - 1 : zs;
+    g.zs = zs_ws;
+    g.n_items = g.grid_tiles * zs_ws;
     // three-piece products: the warp-specialised persistent kernel, unless a k range is shorter than one k-tile
     const char *ws_env = getenv("EGP_GEMM_WS");            // EGP_GEMM_WS=0: k_gemm_bf16x for everything (read per call: tests switch it)
     const bool ws_on = !(ws_env && atoi(ws_env) == 0);
-    const int last_len = d->K - (zs - 1) * g.k_per_split;
+    const int last_len = d->K - (zs_ws - 1) * g.k_per_split;
     int rc;
     const bool small32 = (size_t)d->M * (size_t)(d->a_kcontig ? d->lda : 1) < (1u << 30) && (size_t)d->N * (size_t)(d->b_kcontig ? d->ldb : 1) < (1u << 30);
-    const bool wide = partial ? ((size_t)d->workspace & 15) == 0
-                              : (d->N % 4 == 0 && d->ldc % 4 == 0 && ((size_t)d->C & 15) == 0 && (!d->bias || ((size_t)d->bias & 15) == 0) &&
-                                 (!d->mask || (d->ldmask % 4 == 0 && ((size_t)d->mask & 15) == 0)));
+    const bool wide = partial || d->N % 4 == 0;
+    int n_splits_written = zs;
     if (d->terms == 6 && ws_on && last_len >= BK && small32 && wide) {
         rc = bn64 ? launch_ws<64>(g, s) : launch_ws<128>(g, s);
+        n_splits_written = zs_ws;
     } else
     if (bn64) rc = d->terms == 6 ? launch_variant<64, 6>(g, grid, lds, s) : d->terms == 3 ? launch_variant<64, 3>(g, grid, lds, s) : launch_variant<64, 1>(g, grid, lds, s);
     else rc = d->terms == 6 ? launch_variant<128, 6>(g, grid, lds, s) : d->terms == 3 ? launch_variant<128, 3>(g, grid, lds, s) : launch_variant<128, 1>(g, grid, lds, s);
     if (rc != EGP_OK) return rc;
     if (partial) {
         const long total = (long)d->M * n_out;
-        k_gemm_reduce<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(d->workspace, g.ldws, zs, d->M, d->N, n_out, d->C, d->ldc,
+        k_gemm_reduce<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(d->workspace, g.ldws, n_splits_written, d->M, d->N, n_out, d->C, d->ldc,
                                                                                 d->bias_grad, d->accumulate);
         return after_launch("k_gemm_reduce");
     }
