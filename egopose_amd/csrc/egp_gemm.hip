@@ -31,6 +31,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));       // 16-byte load, 4-byte aligned
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 inline int after_launch(const char *what) {
     hipError_t e = hipGetLastError();
@@ -460,15 +461,29 @@ template <int R, bool KC>
 struct WsStage {
     // k-contiguous memory: thread t -> k octet t & 3 (= LDS k-panel), rows (t >> 2) + 64 u: two 16-byte loads per row, and the
     // eight values are exactly one [row][8 bf16] panel entry (one 16-byte LDS store per image, no bank conflicts).
-    // row-contiguous memory: lane -> rows lane + 64 u, wave -> k-panel (as load_rc).
-    unsigned off[R / 64];                      // byte offset of the thread's rows
-    bool one[KC ? 1 : R / 64];                 // row-contiguous form: the virtual row of ones
+    // row-contiguous memory, 128-row tiles: lane -> the row PAIR (2 lane, 2 lane + 1), wave -> k-panel: one 8-byte load per k
+    // (a wave reads 128 consecutive floats of a k-row per instruction). A pair that would start on the operand's last row
+    // (odd row counts: 243 input features) is read one row earlier and shifted, so no load leaves the operand.
+    // row-contiguous memory, 64-row tiles: lane -> row, wave -> k-panel, scalar loads (as load_rc).
+    static constexpr bool PAIR = !KC && R == 128;
+    static constexpr int ROW0_MUL = PAIR ? 2 : 1, ROW_STEP = PAIR ? 1 : 64;   // rows of a thread: ROW0_MUL * first + ROW_STEP * u
+    unsigned off[PAIR ? 1 : R / 64];           // byte offset of the thread's rows
+    bool one[KC ? 1 : 2];                      // row-contiguous forms: the thread's row u is the virtual row of ones
+    bool shift;                                // PAIR: the pair was read one row early
     __device__ __forceinline__ void bind(long ld, int rows, int r0, int ones_row, int t) {
+        shift = false;
         if constexpr (KC) {
 #pragma unroll
             for (int u = 0; u < R / 64; ++u) off[u] = (unsigned)(((long)min(r0 + (t >> 2) + 64 * u, rows - 1) * ld + (t & 3) * 8) * 4);
             one[0] = false;
+        } else if constexpr (PAIR) {
+            const int row = r0 + 2 * (t & 63);
+            one[0] = row == ones_row;
+            one[1] = row + 1 == ones_row;
+            shift = row == rows - 1;
+            off[0] = (unsigned)max(min(row, rows - 2), 0) * 4u;
         } else {
+            one[1] = false;
 #pragma unroll
             for (int u = 0; u < R / 64; ++u) {
                 const int row = r0 + (t & 63) + 64 * u;
@@ -480,10 +495,10 @@ struct WsStage {
     // The loads are inline asm and the wait for them is explicit (ws_wait): the compiler's own wait insertion loses count
     // of loads across the unrolled, branching producer loop and falls back to "everything older than the last few", which
     // collapses the four-deep prefetch into one. Staged registers: k-contiguous -> 16-byte pieces q[2 u], q[2 u + 1] =
-    // k 0..3, 4..7 of row u; row-contiguous -> scalars f[8 u + j].
-    static constexpr int NLOAD = KC ? R / 32 : R / 8;                         // load instructions per k-tile and thread
-    using Regs = std::conditional_t<KC, f32x4[R / 32], float[R / 8]>;
-    // k0: first k of the tile; `panel`: the wave's k-panel (wave-uniform), used by the row-contiguous form
+    // k 0..3, 4..7 of row u; row pairs -> p[j] = (row 0, row 1) at k j; scalar form -> f[8 u + j].
+    static constexpr int NLOAD = KC ? R / 32 : (PAIR ? 8 : R / 8);            // load instructions per k-tile and thread
+    using Regs = std::conditional_t<KC, f32x4[R / 32], std::conditional_t<PAIR, f32x2[8], float[R / 8]>>;
+    // k0: first k of the tile; `panel`: the wave's k-panel (wave-uniform), used by the row-contiguous forms
     __device__ __forceinline__ void load(const float *__restrict__ P, long ld, int k0, int panel, Regs &r) const {
         if constexpr (KC) {
             const char *base = (const char *)(P + k0);
@@ -496,18 +511,29 @@ struct WsStage {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const char *base = (const char *)(P + (long)(k0 + 8 * panel + j) * ld);
+                if constexpr (PAIR) {
+                    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r[j]) : "v"(off[0]), "s"(base));
+                } else {
 #pragma unroll
-                for (int u = 0; u < R / 64; ++u) asm volatile("global_load_dword %0, %1, %2" : "=v"(r[8 * u + j]) : "v"(off[u]), "s"(base));
+                    for (int u = 0; u < R / 64; ++u) asm volatile("global_load_dword %0, %1, %2" : "=v"(r[8 * u + j]) : "v"(off[u]), "s"(base));
+                }
             }
         }
     }
-    // after ws_wait: v[8 u + j] = element (row_u, k = 8 panel + j) of the tile in both forms
+    // after ws_wait: v[8 u + j] = element (row u of the thread, k = 8 panel + j) of the tile in all forms
     __device__ __forceinline__ void unpack(const Regs &r, float (&v)[R / 8]) const {
         if constexpr (KC) {
 #pragma unroll
             for (int u = 0; u < R / 64; ++u)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[8 * u + e] = r[2 * u][e]; v[8 * u + 4 + e] = r[2 * u + 1][e]; }
+        } else if constexpr (PAIR) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = shift ? r[j][1] : r[j][0];
+                v[j] = one[0] ? 1.f : a;
+                v[8 + j] = one[1] ? 1.f : r[j][1];
+            }
         } else {
 #pragma unroll
             for (int u = 0; u < R / 64; ++u)
@@ -523,6 +549,9 @@ template <int N> __device__ __forceinline__ void ws_wait(f32x4 (&r)[2]) {
 }
 template <int N> __device__ __forceinline__ void ws_wait(f32x4 (&r)[4]) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void ws_wait(f32x2 (&r)[8]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "n"(N));
 }
 template <int N> __device__ __forceinline__ void ws_wait(float (&r)[8]) {
     asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "n"(N));
@@ -548,15 +577,15 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &ph, un
     pl = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
 }
 
-// staged registers -> the three LDS images: v[8 u + j] = (row r_first + 64 u, k = 8 panel + j), one 16-byte store per image
-template <int R>
+// staged registers -> the three LDS images: v[8 u + j] = (row r_first + ROW_STEP u, k = 8 panel + j), one 16-byte store per image
+template <int R, int ROW_STEP>
 __device__ __forceinline__ void ws_store(const float (&v)[R / 8], __bf16 *dst, int img, int panel, int r_first) {
 #pragma unroll
     for (int u = 0; u < R / 64; ++u) {
         unsigned q[3][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) split3_pair(v[8 * u + 2 * j], v[8 * u + 2 * j + 1], q[0][j], q[1][j], q[2][j]);
-        const int off = panel * panel_el(R) + (r_first + 64 * u) * 8;
+        const int off = panel * panel_el(R) + (r_first + ROW_STEP * u) * 8;
 #pragma unroll
         for (int c = 0; c < 3; ++c) *(uint4 *)(dst + c * img + off) = make_uint4(q[c][0], q[c][1], q[c][2], q[c][3]);
     }
@@ -639,9 +668,9 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
         };
         auto stage = [&](auto setc, int buf) __attribute__((always_inline)) {   // register set -> LDS buffer `buf`
             constexpr int SET = decltype(setc)::value;
-            // (panel, first row) of the thread: k-contiguous -> (t & 3, t >> 2), row-contiguous -> (wave, lane)
-            const int pa_panel = A_KC ? (pt & 3) : wave, pa_row = A_KC ? (pt >> 2) : lane;
-            const int pb_panel = B_KC ? (pt & 3) : wave, pb_row = B_KC ? (pt >> 2) : lane;
+            // (panel, first row) of the thread: k-contiguous -> (t & 3, t >> 2), row-contiguous -> (wave, lane or 2 lane)
+            const int pa_panel = A_KC ? (pt & 3) : wave, pa_row = A_KC ? (pt >> 2) : SA::ROW0_MUL * lane;
+            const int pb_panel = B_KC ? (pt & 3) : wave, pb_row = B_KC ? (pt >> 2) : SB::ROW0_MUL * lane;
             ws_wait<YOUNGER>(ra[SET]);
             ws_wait<YOUNGER>(rb[SET]);
             EGP_TRW(1, 33);
@@ -653,9 +682,9 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
                 ws_zero_head<BN>(vb, zrel[SET], pb_panel);
             }
             __bf16 *pa = base + buf * BUF_EL, *pb = pa + NIMG * A_EL;
-            ws_store<BM>(va, pa, A_EL, pa_panel, pa_row);
+            ws_store<BM, SA::ROW_STEP>(va, pa, A_EL, pa_panel, pa_row);
             EGP_TRW(1, 34);
-            ws_store<BN>(vb, pb, B_EL, pb_panel, pb_row);
+            ws_store<BN, SB::ROW_STEP>(vb, pb, B_EL, pb_panel, pb_row);
         };
         issue(S0); issue(S1); issue(S2); issue(S3);      // k-tiles 0..3 in flight
         stage(S0, 0);
@@ -975,7 +1004,7 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     const int last_len = d->K - (zs_ws - 1) * g.k_per_split;
     int rc;
     const bool small32 = (size_t)d->M * (size_t)(d->a_kcontig ? d->lda : 1) < (1u << 30) && (size_t)d->N * (size_t)(d->b_kcontig ? d->ldb : 1) < (1u << 30);
-    const bool wide = partial || d->N % 4 == 0;
+    const bool wide = (partial || d->N % 4 == 0) && (d->a_kcontig || d->M >= 2) && (d->b_kcontig || d->N >= 2);
     int n_splits_written = zs;
     if (d->terms == 6 && ws_on && last_len >= BK && small32 && wide) {
         rc = bn64 ? launch_ws<64>(g, s) : launch_ws<128>(g, s);
