@@ -71,7 +71,10 @@ class GemmDesc(C.Structure):
                 ("bias", vp), ("relu", C.c_int32),
                 ("mask", vp), ("ldmask", C.c_int64),
                 ("terms", C.c_int32), ("splits", C.c_int32), ("accumulate", C.c_int32),
-                ("bias_grad", vp), ("workspace", vp)]
+                ("bias_grad", vp), ("workspace", vp),
+                ("a_rows", vp), ("A2", vp), ("lda2", C.c_int64), ("a_split", C.c_int32), ("a_src_rows", C.c_int64),
+                ("b_krows", vp), ("B2", vp), ("ldb2", C.c_int64), ("b_split", C.c_int32), ("b_src_rows", C.c_int64),
+                ("c_rows", vp)]
 
 
 class EngineDesc(C.Structure):

@@ -429,6 +429,10 @@ class AgentEgo(AgentPPO):
                 # VideoStateNet output = [video context | raw state]: the state columns need no gradient (gemm.MlpHead)
                 if isinstance(vs, VideoStateNet):
                     head.input_grad_cols = vs.v_hdim
+                    # ... and when the head is an MLP on the HIP GEMMs its first layer can gather the context rows and
+                    # append the state columns itself: the video net then hands over the parts, not the concatenation
+                    layers = getattr(getattr(head, "net", None), "affine_layers", None)
+                    vs.lazy_gather = int(layers[0].out_features) if layers is not None and len(layers) > 0 else 0
 
     def _video_net(self):
         return self.cn.policy_vs_net

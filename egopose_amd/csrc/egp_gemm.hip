@@ -87,6 +87,10 @@ struct GemmArgs {
     int k_per_split;                          // multiple of BK; gridDim.z splits
     float *ws; int ldws;                      // [splits][M][ldws] when there are k splits or a ones column; ldws = N + ones_col rounded up to 4
     int tiles_m, tiles_n, xcd_order;
+    // fused gather / scatter (egp_gemm_desc: a_rows ... c_rows), k_gemm_ws only
+    const long long *a_rows; const float *A2; long lda2; int a_split;
+    const long long *b_krows; const float *B2; long ldb2; int b_split;
+    const long long *c_rows;
     int partial;                              // results go to the workspace (k splits and / or the ones column), reduced by k_gemm_reduce
     int grid_tiles, n_items, zs;              // k_gemm_ws: tile slots (the XCD order pads tiles_m to a multiple of 8), slots x k splits, k splits
 };
@@ -468,13 +472,21 @@ struct WsStage {
     static constexpr bool PAIR = !KC && R == 128;
     static constexpr int ROW0_MUL = PAIR ? 2 : 1, ROW_STEP = PAIR ? 1 : 64;   // rows of a thread: ROW0_MUL * first + ROW_STEP * u
     unsigned off[PAIR ? 1 : R / 64];           // byte offset of the thread's rows
+    unsigned off2[KC ? R / 64 : 1];            // k-contiguous form with a second source (columns k >= split): its row offsets
     bool one[KC ? 1 : 2];                      // row-contiguous forms: the thread's row u is the virtual row of ones
     bool shift;                                // PAIR: the pair was read one row early
-    __device__ __forceinline__ void bind(long ld, int rows, int r0, int ones_row, int t) {
+    // `gather` (k-contiguous form): the operand's row m lives at row gather[m] of P; `ld2`: row stride of the second source
+    __device__ __forceinline__ void bind(long ld, int rows, int r0, int ones_row, int t, const long long *gather = nullptr, long ld2 = 0) {
         shift = false;
+        off2[0] = 0;
         if constexpr (KC) {
 #pragma unroll
-            for (int u = 0; u < R / 64; ++u) off[u] = (unsigned)(((long)min(r0 + (t >> 2) + 64 * u, rows - 1) * ld + (t & 3) * 8) * 4);
+            for (int u = 0; u < R / 64; ++u) {
+                const long row = min(r0 + (t >> 2) + 64 * u, rows - 1);
+                const long src = gather ? gather[row] : row;
+                off[u] = (unsigned)((src * ld + (t & 3) * 8) * 4);
+                off2[u] = (unsigned)((row * ld2 + (t & 3) * 8) * 4);
+            }
             one[0] = false;
         } else if constexpr (PAIR) {
             const int row = r0 + 2 * (t & 63);
@@ -498,19 +510,26 @@ struct WsStage {
     // k 0..3, 4..7 of row u; row pairs -> p[j] = (row 0, row 1) at k j; scalar form -> f[8 u + j].
     static constexpr int NLOAD = KC ? R / 32 : (PAIR ? 8 : R / 8);            // load instructions per k-tile and thread
     using Regs = std::conditional_t<KC, f32x4[R / 32], std::conditional_t<PAIR, f32x2[8], float[R / 8]>>;
-    // k0: first k of the tile; `panel`: the wave's k-panel (wave-uniform), used by the row-contiguous forms
-    __device__ __forceinline__ void load(const float *__restrict__ P, long ld, int k0, int panel, Regs &r) const {
+    // k0: first k of the tile; `panel`: the wave's k-panel (wave-uniform), used by the row-contiguous forms;
+    // `second` (k-contiguous form): the rows of the second source; `kgather` (row-contiguous forms): k-row k lives at row kgather[k] of P
+    __device__ __forceinline__ void load(const float *__restrict__ P, long ld, int k0, int panel, Regs &r, bool second = false,
+                                         const long long *kgather = nullptr) const {
         if constexpr (KC) {
             const char *base = (const char *)(P + k0);
 #pragma unroll
             for (int u = 0; u < R / 64; ++u) {
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[2 * u]) : "v"(off[u]), "s"(base));
-                asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(r[2 * u + 1]) : "v"(off[u]), "s"(base));
+                const unsigned o = second ? off2[u] : off[u];
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[2 * u]) : "v"(o), "s"(base));
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(r[2 * u + 1]) : "v"(o), "s"(base));
             }
         } else {
+            int krow[8];                               // wave-uniform (scalar loads, scalar address arithmetic)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                krow[j] = __builtin_amdgcn_readfirstlane(kgather ? (int)kgather[k0 + 8 * panel + j] : k0 + 8 * panel + j);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const char *base = (const char *)(P + (long)(k0 + 8 * panel + j) * ld);
+                const char *base = (const char *)(P + (long)krow[j] * ld);
                 if constexpr (PAIR) {
                     asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r[j]) : "v"(off[0]), "s"(base));
                 } else {
@@ -653,17 +672,21 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
         constexpr int YOUNGER = 3 * PER_SET <= 63 ? 3 * PER_SET : (2 * PER_SET <= 63 ? 2 * PER_SET : PER_SET);
         auto issue = [&](auto setc) __attribute__((always_inline)) {      // loads of the k-tile under the cursor; cursor moves on
             constexpr int SET = decltype(setc)::value;
+            // B given as [k][n] with a second source: the tile's columns come from one of them (b_split is a multiple of BN)
+            const bool b_second = !B_KC && g.B2 && cur.n0 >= g.b_split;
             if (cur.w != bound) {
-                sa.bind(g.lda, g.M, cur.m0, -1, pt);
-                sb.bind(g.ldb, g.N, cur.n0, ones_row, pt);
+                sa.bind(g.lda, g.M, cur.m0, -1, pt, A_KC ? g.a_rows : nullptr, g.lda2);
+                if (b_second) sb.bind(g.ldb2, g.N - g.b_split, cur.n0 - g.b_split, ones_row - g.b_split, pt);
+                else sb.bind(g.ldb, (!B_KC && g.B2) ? g.b_split : g.N, cur.n0, (!B_KC && g.B2) ? -1 : ones_row, pt);
                 bound = cur.w;
             }
             const bool last = cur.s == cur.nst - 1;
             const int kz = cur.kbeg + cur.s * BK;
             const int k0 = last ? cur.kend - BK : kz;
             zrel[SET] = kz - k0;
-            sa.load(g.A, g.lda, k0, wave, ra[SET]);
-            sb.load(g.B, g.ldb, k0, wave, rb[SET]);
+            const bool a_second = A_KC && g.A2 && k0 >= g.a_split;        // (a_split is a multiple of BK: a k-tile has one source)
+            sa.load(a_second ? g.A2 : g.A, a_second ? g.lda2 : g.lda, a_second ? k0 - g.a_split : k0, wave, ra[SET], a_second);
+            sb.load(b_second ? g.B2 : g.B, b_second ? g.ldb2 : g.ldb, k0, wave, rb[SET], false, (!B_KC && !b_second) ? g.b_krows : nullptr);
             ws_next<BN>(g, cur, w_scan);
         };
         auto stage = [&](auto setc, int buf) __attribute__((always_inline)) {   // register set -> LDS buffer `buf`
@@ -777,6 +800,14 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
         const int colc = min(col, ncols - 4);
         const bool col_ok = col < ncols;
         const int row0 = cur.m0 + wm * WROWS + (lane >> 4);
+        long drow[MI][8];                                 // destination rows (scatter: c_rows)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = row0 + 32 * i + 4 * it;
+                drow[i][it] = (!PARTIAL && g.c_rows) ? (long)g.c_rows[min(row, g.M - 1)] : (long)row;
+            }
         // (16-byte accesses on 4-byte-aligned addresses throughout: leading dimensions like 243 are welcome)
         f32x4u bv = {0.f, 0.f, 0.f, 0.f};
         if constexpr (!PARTIAL) bv = *(const f32x4u *)((g.bias ? g.bias : g.C) + colc);      // (no bias: any readable address, the value is dropped)
@@ -810,7 +841,7 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
                     x.x = keep[i][it][0] > 0.f ? x.x : 0.f; x.y = keep[i][it][1] > 0.f ? x.y : 0.f;
                     x.z = keep[i][it][2] > 0.f ? x.z : 0.f; x.w = keep[i][it][3] > 0.f ? x.w : 0.f;
                 }
-                if (row < g.M && col_ok) *(f32x4u *)(dst + (long)row * ldd + col) = f32x4u{x.x, x.y, x.z, x.w};
+                if (row < g.M && col_ok) *(f32x4u *)(dst + drow[i][it] * ldd + col) = f32x4u{x.x, x.y, x.z, x.w};
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -979,6 +1010,21 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     g.C = d->C; g.ldc = d->ldc;
     g.bias = d->bias; g.relu = d->relu; g.mask = d->mask; g.ldmask = d->ldmask;
     g.ones_col = ones; g.ws = d->workspace; g.ldws = (d->N + ones + 3) & ~3; g.partial = partial ? 1 : 0;
+    g.a_rows = (const long long *)d->a_rows; g.A2 = d->A2; g.lda2 = d->lda2; g.a_split = d->a_split;
+    g.b_krows = (const long long *)d->b_krows; g.B2 = d->B2; g.ldb2 = d->ldb2; g.b_split = d->b_split;
+    g.c_rows = (const long long *)d->c_rows;
+    const bool fused_io = d->a_rows || d->A2 || d->b_krows || d->B2 || d->c_rows;
+    if (fused_io) {
+        EGP_REQUIRE(!(d->a_rows || d->A2) || d->a_kcontig, "a_rows / A2 go with a k-contiguous A");
+        EGP_REQUIRE(!(d->b_krows || d->B2) || !d->b_kcontig, "b_krows / B2 go with B given as [k][n]");
+        EGP_REQUIRE(!d->A2 || (d->a_split > 0 && d->a_split % BK == 0 && d->K - d->a_split >= BK),
+                    "a_split must be a multiple of 32 and leave at least 32 columns to A2 (a k-tile reads one source)");
+        EGP_REQUIRE(!d->A2 || splits == 1, "A2 does not go with split-K");
+        EGP_REQUIRE(!d->B2 || (d->b_split > 0 && d->b_split % 128 == 0 && d->b_split < d->N + ones), "b_split must be a multiple of 128 inside (0, N)");
+        EGP_REQUIRE(!d->c_rows || !partial, "c_rows (scatter) does not go with split-K / bias-gradient launches");
+        EGP_REQUIRE(!d->a_rows || d->a_src_rows > 0, "a_rows needs a_src_rows (rows of the gathered source)");
+        EGP_REQUIRE(!d->b_krows || d->b_src_rows > 0, "b_krows needs b_src_rows (rows of the gathered source)");
+    }
     const int n_out = d->N + ones;
     const bool bn64 = n_out <= 64;                 // narrow outputs: 64-column tiles
     const int BNv = bn64 ? 64 : 128;
@@ -1003,12 +1049,16 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     const bool ws_on = !(ws_env && atoi(ws_env) == 0);
     const int last_len = d->K - (zs_ws - 1) * g.k_per_split;
     int rc;
-    const bool small32 = (size_t)d->M * (size_t)(d->a_kcontig ? d->lda : 1) < (1u << 30) && (size_t)d->N * (size_t)(d->b_kcontig ? d->ldb : 1) < (1u << 30);
+    const bool small32 = (size_t)(d->a_rows ? d->a_src_rows : d->M) * (size_t)(d->a_kcontig ? d->lda : 1) < (1u << 30) &&
+                         (size_t)d->N * (size_t)(d->b_kcontig ? d->ldb : 1) < (1u << 30) && (!d->A2 || (size_t)d->M * (size_t)d->lda2 < (1u << 30));
     const bool wide = (partial || d->N % 4 == 0) && (d->a_kcontig || d->M >= 2) && (d->b_kcontig || d->N >= 2);
     int n_splits_written = zs;
     if (d->terms == 6 && ws_on && last_len >= BK && small32 && wide) {
         rc = bn64 ? launch_ws<64>(g, s) : launch_ws<128>(g, s);
         n_splits_written = zs_ws;
+    } else if (fused_io) {
+        egp::set_error("invalid argument: %s", "gather / scatter operands need the persistent three-piece kernel (terms = 6, EGP_GEMM_WS != 0, k ranges >= 32, N %% 4 == 0)");
+        return EGP_E_INVALID;
     } else
     if (bn64) rc = d->terms == 6 ? launch_variant<64, 6>(g, grid, lds, s) : d->terms == 3 ? launch_variant<64, 3>(g, grid, lds, s) : launch_variant<64, 1>(g, grid, lds, s);
     else rc = d->terms == 6 ? launch_variant<128, 6>(g, grid, lds, s) : d->terms == 3 ? launch_variant<128, 3>(g, grid, lds, s) : launch_variant<128, 1>(g, grid, lds, s);

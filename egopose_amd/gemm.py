@@ -63,21 +63,64 @@ def pick_splits(M, n_out, K):
     return max(1, min((512 + tiles - 1) // tiles, K // 256))
 
 
+def _index(t, name):
+    if not (t.is_cuda and t.dtype == torch.int64 and t.dim() == 1 and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous 1-D int64 HIP tensor" % name)
+    return t
+
+
 def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, relu=False, mask=None, terms=None, splits=1, want_bias_grad=False,
-         out=None, bias_grad_out=None, accumulate=False):
+         out=None, bias_grad_out=None, accumulate=False, a_rows=None, a2=None, b_krows=None, b2=None, c_rows=None):
     """C = A B with the operand forms of include/egopose_hip.h (`egp_gemm_desc`). A: (M, K) if a_kcontig else (K, M);
-    B: (N, K) if b_kcontig else (K, N). Returns C, or (C, bias_grad) with want_bias_grad."""
+    B: (N, K) if b_kcontig else (K, N). Returns C, or (C, bias_grad) with want_bias_grad.
+    Fused gather / scatter (three-piece products only): `a_rows` (int64, M entries) -- operand row m is A[a_rows[m]], and with
+    `a2` (M, K2) its columns continue with a2[m] (K = A.shape[1] + K2); `b_krows` / `b2` the same for B given as (K, N) along
+    k and n; `c_rows` -- result row m goes to out[c_rows[m]] (`out` required, rows nobody writes keep their content)."""
     A, B = _mat(A, "A"), _mat(B, "B")
     M, K = (A.shape if a_kcontig else A.shape[::-1])
     N, Kb = (B.shape if b_kcontig else B.shape[::-1])
+    a_split = b_split = 0
+    if a_rows is not None or a2 is not None:
+        if not a_kcontig:
+            raise ValueError("a_rows / a2 go with a k-contiguous A")
+        if a_rows is not None:
+            M = _index(a_rows, "a_rows").shape[0]
+        if a2 is not None:
+            _mat(a2, "a2")
+            if a2.shape[0] != M:
+                raise ValueError("a2 has %d rows, the operand %d" % (a2.shape[0], M))
+            a_split, K = K, K + a2.shape[1]
+    if b_krows is not None or b2 is not None:
+        if b_kcontig:
+            raise ValueError("b_krows / b2 go with B given as (K, N)")
+        if b_krows is not None:
+            Kb = _index(b_krows, "b_krows").shape[0]
+        if b2 is not None:
+            _mat(b2, "b2")
+            if b2.shape[0] != Kb:
+                raise ValueError("b2 has %d rows, the operand %d" % (b2.shape[0], Kb))
+            b_split, N = N, N + b2.shape[1]
     if K != Kb:
         raise ValueError("inner dimensions differ: %d vs %d" % (K, Kb))
     dev = A.device
-    if out is None:
+    if c_rows is not None:
+        if out is None or _index(c_rows, "c_rows").shape[0] != M:
+            raise ValueError("c_rows needs `out` (the scatter destination) and one entry per result row")
+    elif out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=dev)
     _mat(out, "out")
     d = L.GemmDesc()
     d.M, d.N, d.K = M, N, K
+    if a_rows is not None:
+        d.a_rows, d.a_src_rows = a_rows.data_ptr(), A.shape[0]
+    if a2 is not None:
+        d.A2, d.lda2, d.a_split = a2.data_ptr(), _ld(a2), a_split
+    if b_krows is not None:
+        d.b_krows, d.b_src_rows = b_krows.data_ptr(), B.shape[0]
+    if b2 is not None:
+        d.B2, d.ldb2, d.b_split = b2.data_ptr(), _ld(b2), b_split
+    if c_rows is not None:
+        d.c_rows = c_rows.data_ptr()
     d.A, d.lda, d.a_kcontig = A.data_ptr(), _ld(A), 1 if a_kcontig else 0
     d.B, d.ldb, d.b_kcontig = B.data_ptr(), _ld(B), 1 if b_kcontig else 0
     d.C, d.ldc = out.data_ptr(), _ld(out)
@@ -159,6 +202,8 @@ class MlpHead(torch.autograd.Function):
 
 
 def mlp_head_available(x, layers, head, activation):
+    if isinstance(x, GatheredInput):
+        x = x.x
     if not (enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and activation is torch.relu):
         return False
     return all(l.weight.dtype == torch.float32 and l.bias is not None and l.weight.is_cuda for l in list(layers) + [head])
@@ -170,6 +215,89 @@ def mlp_head(x, layers, head, n_grad_cols=None):
         params += [l.weight, l.bias]
     nc = x.shape[1] if n_grad_cols is None else int(n_grad_cols)
     return MlpHead.apply(x, nc, *params)
+
+
+class GatheredInput:
+    """[ctx2d[idx] | x] that has not been formed: what VideoStateNet.forward('train') hands to a policy / value MLP that can
+    read the two tensors itself (GatherMlpHead). Anything else calls `materialize()` (GatherConcat)."""
+
+    def __init__(self, ctx2d, idx, x):
+        self.ctx2d, self.idx, self.x = ctx2d, idx, x
+        self.shape = (x.shape[0], ctx2d.shape[1] + x.shape[1])
+        self.dtype, self.device, self.is_cuda = x.dtype, x.device, x.is_cuda
+
+    def dim(self):
+        return 2
+
+    def size(self, k=None):
+        return torch.Size(self.shape) if k is None else self.shape[k]
+
+    def materialize(self):
+        return GatherConcat.apply(self.ctx2d, self.idx, self.x)
+
+    def __getitem__(self, ind):
+        if torch.is_tensor(ind) and ind.dtype == torch.int64 and ind.dim() == 1:      # a row subset stays lazy (rows stay unique)
+            return GatheredInput(self.ctx2d, self.idx.index_select(0, ind), self.x.index_select(0, ind))
+        return self.materialize()[ind]
+
+
+def fused_gather_available(H, n_hidden, S):
+    """The first MLP layer can read [ctx[idx] | state] itself: three-piece products on the persistent kernel, the context
+    width H a multiple of the 128-column tile (the weight gradient switches source between column tiles), at least one
+    k-tile of state columns S (a k-tile reads one source)."""
+    import os
+    return enabled() and default_terms() == 6 and os.environ.get("EGP_GEMM_WS", "1") != "0" and H % 128 == 0 and n_hidden % 4 == 0 \
+        and S >= 32 and os.environ.get("EGP_FUSED_GATHER", "1") != "0"
+
+
+class GatherMlpHead(torch.autograd.Function):
+    """out = head(relu-MLP([ctx2d[idx] | x])) without forming the concatenated input: apply(ctx2d, idx, x, W1, b1, ..., Wh, bh).
+    The first layer's product gathers the context rows and appends the state columns on its way into LDS
+    (`egp_gemm_desc.a_rows / A2`), its weight gradient does the same along k (`b_krows / B2`), and its data gradient writes the
+    context rows it belongs to (`c_rows`; idx must not repeat). Gradient w.r.t. ctx2d only, as GatherConcat + MlpHead."""
+
+    @staticmethod
+    def forward(ctx, ctx2d, idx, x, *params):
+        Ws, bs = params[0::2], params[1::2]
+        ctx2d, x = ctx2d.contiguous(), (x if x.stride(1) == 1 else x.contiguous())
+        h = gemm(ctx2d, Ws[0].contiguous(), True, True, bias=bs[0], relu=len(Ws) > 1, a_rows=idx, a2=x)
+        hs = [h]
+        for i in range(1, len(Ws)):
+            hs.append(linear_fwd(hs[-1], Ws[i].contiguous(), bs[i], relu=i < len(Ws) - 1))
+        ctx.save_for_backward(ctx2d, idx, x, *hs[:-1], *Ws)
+        ctx.n_layers = len(Ws)
+        return hs[-1]
+
+    @staticmethod
+    def backward(ctx, dout):
+        nl = ctx.n_layers
+        ctx2d, idx, x = ctx.saved_tensors[:3]
+        hs, Ws = ctx.saved_tensors[3:3 + nl - 1], ctx.saved_tensors[3 + nl - 1:]        # hs[i - 1] = relu output feeding layer i
+        dz = dout.contiguous()
+        grads = [None] * (2 * nl)
+        for i in range(nl - 1, 0, -1):
+            need_w, need_b = ctx.needs_input_grad[3 + 2 * i], ctx.needs_input_grad[4 + 2 * i]
+            if need_w or need_b:
+                dW, db = linear_wgrad(dz, hs[i - 1], want_bias=True)
+                grads[2 * i], grads[2 * i + 1] = (dW if need_w else None), (db if need_b else None)
+            dz = linear_dgrad(dz, Ws[i].contiguous(), mask=hs[i - 1])
+        H, S = ctx2d.shape[1], x.shape[1]
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+            n = dz.shape[0]
+            dW, db = gemm(dz, ctx2d, False, False, splits=pick_splits(dz.shape[1], H + S + 1, n), want_bias_grad=True, b_krows=idx, b2=x)
+            grads[0], grads[1] = (dW if ctx.needs_input_grad[3] else None), (db if ctx.needs_input_grad[4] else None)
+        dctx = None
+        if ctx.needs_input_grad[0]:
+            dctx = torch.zeros_like(ctx2d)
+            gemm(dz, Ws[0][:, :H], True, False, out=dctx, c_rows=idx)
+        return (dctx, None, None, *grads)
+
+
+def gather_mlp_head(gi, layers, head):
+    params = []
+    for l in list(layers) + [head]:
+        params += [l.weight, l.bias]
+    return GatherMlpHead.apply(gi.ctx2d, gi.idx, gi.x, *params)
 
 
 class GatherConcat(torch.autograd.Function):

@@ -123,8 +123,13 @@ class PolicyGaussian(Policy):
         if _gemm.mlp_head_available(x, getattr(self.net, "affine_layers", ()), self.action_mean, getattr(self.net, "activation", None)):
             # the whole head(MLP(x)) as one autograd node on the split-operand bf16 GEMM kernel (gemm.py); `input_grad_cols`
             # (set by the agent): only the leading video-context columns of the input carry a gradient
-            mean = _gemm.mlp_head(x, self.net.affine_layers, self.action_mean, getattr(self, "input_grad_cols", None))
+            if isinstance(x, _gemm.GatheredInput):      # [context | state] never formed: the first layer gathers it itself
+                mean = _gemm.gather_mlp_head(x, self.net.affine_layers, self.action_mean)
+            else:
+                mean = _gemm.mlp_head(x, self.net.affine_layers, self.action_mean, getattr(self, "input_grad_cols", None))
         else:
+            if isinstance(x, _gemm.GatheredInput):
+                x = x.materialize()
             x, n = bucket_rows(x)
             mean = self.action_mean(self.net(x))
             if n is not None:
@@ -156,7 +161,11 @@ class Value(nn.Module):
 
     def forward(self, x):
         if _gemm.mlp_head_available(x, getattr(self.net, "affine_layers", ()), self.value_head, getattr(self.net, "activation", None)):
+            if isinstance(x, _gemm.GatheredInput):
+                return _gemm.gather_mlp_head(x, self.net.affine_layers, self.value_head)
             return _gemm.mlp_head(x, self.net.affine_layers, self.value_head, getattr(self, "input_grad_cols", None))
+        if isinstance(x, _gemm.GatheredInput):
+            x = x.materialize()
         x, n = bucket_rows(x)
         out = self.value_head(self.net(x))
         return out if n is None else out[:n]
@@ -264,6 +273,7 @@ class VideoStateNet(nn.Module):
         self.gather_indices = None
         self._gather_tm = None
         self._gather_unique = False
+        self.lazy_gather = 0                 # > 0 (width of the consumer's first layer, set by the agent): forward('train') may return gemm.GatheredInput
         self.cnn_feat_ctx = None
         self._buckets = None
         self._v_ctx = None
@@ -390,6 +400,8 @@ class VideoStateNet(nn.Module):
             ctx = self.forward_v_net(self.cnn_feat_ctx)
         ctx2d = ctx.reshape(-1, self.v_hdim)
         if self._gather_unique and _gemm.gather_concat_available(ctx2d, self._gather_tm, x):
+            if self.lazy_gather and _gemm.fused_gather_available(self.v_hdim, self.lazy_gather, x.shape[1]):
+                return _gemm.GatheredInput(ctx2d, self._gather_tm, x)            # the consumer's first layer gathers (gemm.GatherMlpHead)
             return _gemm.GatherConcat.apply(ctx2d, self._gather_tm, x)          # gather + concatenation in one pass
         return torch.cat((ctx2d.index_select(0, self._gather_tm), x), dim=1)
 

@@ -268,6 +268,20 @@ typedef struct egp_gemm_desc {
     int32_t terms, splits, accumulate;
     float *bias_grad;
     float *workspace;
+    /* Optional gather / scatter fused into the product: the update's first MLP layer reads its input
+     * [ ctx[idx[i]] | state[i] ] (models/video_state_net.py:65-69) straight from the two tensors, its weight gradient does the
+     * same along k, and its data gradient writes the context rows it belongs to -- no concatenated copy, no scatter pass.
+     * Only with three-piece products on the persistent kernel (terms = 6, k ranges >= 32, N % 4 == 0 unless split-K);
+     * anything else is refused with EGP_E_INVALID. All index arrays are device int64; gathered sources must stay below
+     * 2^30 elements (a_src_rows * lda, b_src_rows * ldb).
+     *   a_rows / A2 / a_split (A k-contiguous): row m of the operand is A[a_rows[m]][k] for k < a_split and
+     *       A2[m][k - a_split] for k >= a_split (a_split a multiple of 32, K - a_split >= 32, no split-K; A2 = NULL: every k from A).
+     *   b_krows / B2 / b_split (B given as [k][n]): element (k, n) is B[b_krows[k]][n] for n < b_split and
+     *       B2[k][n - b_split] for n >= b_split (b_split a multiple of 128; B2 = NULL: every n from B).
+     *   c_rows: result row m goes to row c_rows[m] of C (rows must not repeat; rows nobody writes keep their content). */
+    const int64_t *a_rows; const float *A2; int64_t lda2; int32_t a_split; int64_t a_src_rows;
+    const int64_t *b_krows; const float *B2; int64_t ldb2; int32_t b_split; int64_t b_src_rows;
+    const int64_t *c_rows;
 } egp_gemm_desc;
 /* The update's policy / value input in one pass (VideoStateNet.forward('train'), models/video_state_net.py:65-69):
  * out[i] = [ ctx[idx[i]][0:H] | x[i][0:S] ] for i < n, and the adjoint for the context rows, dctx[idx[i]][0:H] = dout[i][0:H]

@@ -194,3 +194,63 @@ def test_gather_concat_node_matches_torch():
     (ref * w).sum().backward()
     assert torch.equal(out, ref) and torch.equal(got, ctx.grad)
     assert not gather_concat_available(ctx, idx, x.clone().requires_grad_(True))       # state gradients: the torch path
+
+
+def test_fused_gather_scatter_operands(three_piece_kernel):
+    """a_rows / a2 (first layer reads [ctx[idx] | state]), b_krows / b2 (its weight gradient) and c_rows (its data gradient
+    writes the context rows) against the same products on materialised operands."""
+    from egopose_amd.gemm import gemm
+    g = torch.Generator(device="cuda").manual_seed(21)
+    R, n, H, S, N1 = 5000, 4321, 128, 115, 300
+    ctx2d = torch.randn(R, H, device="cuda", generator=g)
+    state = torch.randn(n, S, device="cuda", generator=g)
+    idx = torch.randperm(R, device="cuda", generator=g)[:n].contiguous()
+    W = torch.randn(N1, H + S, device="cuda", generator=g) * 0.1
+    b = torch.randn(N1, device="cuda", generator=g)
+    x = torch.cat((ctx2d[idx], state), 1)
+    dz = torch.randn(n, N1, device="cuda", generator=g)
+    if three_piece_kernel == "classic":          # the classic kernel has no gather path: refused, not silently wrong
+        with pytest.raises(ValueError):
+            gemm(ctx2d, W, True, True, bias=b, relu=True, a_rows=idx, a2=state)
+        return
+    y = gemm(ctx2d, W, True, True, bias=b, relu=True, a_rows=idx, a2=state)
+    assert torch.equal(y, gemm(x, W, True, True, bias=b, relu=True)), "same products, same order: bit-identical to the materialised input"
+    dW, db = gemm(dz, ctx2d, False, False, splits=7, want_bias_grad=True, b_krows=idx, b2=state)
+    dW_ref, db_ref = gemm(dz, x, False, False, splits=7, want_bias_grad=True)
+    assert dW.shape == (N1, H + S) and torch.equal(dW, dW_ref) and torch.equal(db, db_ref)
+    with pytest.raises(ValueError):              # fewer than one k-tile of second-source columns: a k-tile would straddle the sources
+        gemm(ctx2d, W[:, :H + 20].contiguous(), True, True, a_rows=idx, a2=state[:, :20].contiguous())
+    dctx = torch.zeros(R, H, device="cuda")
+    gemm(dz, W[:, :H], True, False, out=dctx, c_rows=idx)
+    ref = torch.zeros(R, H, device="cuda")
+    ref[idx] = gemm(dz, W[:, :H], True, False)
+    assert torch.equal(dctx, ref)
+    assert _rel(y, (x.double() @ W.double().t() + b.double()).clamp_min(0)) < 2e-5
+
+
+def test_gather_mlp_head_node_matches_the_two_node_form(three_piece_kernel):
+    from egopose_amd import gemm as G
+    if three_piece_kernel == "classic":
+        assert not G.fused_gather_available(128, 300, 115)
+        return
+    assert G.fused_gather_available(128, 300, 115) and not G.fused_gather_available(100, 300, 115) and not G.fused_gather_available(128, 300, 20)
+    g = torch.Generator(device="cuda").manual_seed(22)
+    R, n, H, S = 3000, 2500, 128, 115
+    layers = torch.nn.ModuleList([torch.nn.Linear(H + S, 300), torch.nn.Linear(300, 200)]).cuda()
+    head = torch.nn.Linear(200, 52).cuda()
+    idx = torch.randperm(R, device="cuda", generator=g)[:n].contiguous()
+    state = torch.randn(n, S, device="cuda", generator=g)
+    w = torch.randn(n, 52, device="cuda", generator=g)
+    outs = []
+    for fused in (True, False):
+        ctx2d = torch.randn(R, H, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)).requires_grad_()
+        for p in list(layers.parameters()) + list(head.parameters()):
+            p.grad = None
+        if fused:
+            out = G.gather_mlp_head(G.GatheredInput(ctx2d, idx, state), layers, head)
+        else:
+            out = G.mlp_head(G.GatherConcat.apply(ctx2d, idx, state), layers, head, H)
+        (out * w).sum().backward()
+        outs.append([out.detach().clone(), ctx2d.grad.clone()] + [p.grad.clone() for p in list(layers.parameters()) + list(head.parameters())])
+    for a, b2 in zip(*outs):
+        assert torch.equal(a, b2)

@@ -80,18 +80,22 @@ def _count_calls(monkeypatch, module, name):
     return calls
 
 
+@pytest.mark.parametrize("fixture", ["ppo_update_h128.npz", "ppo_update_h128_s40.npz"])
 @pytest.mark.parametrize("mode", ["float32", "float64-masters"])
 @pytest.mark.parametrize("buckets", [False, True])
 @pytest.mark.parametrize("gemms", ["hip", "hip-2piece", "torch"])
-def test_update_params_float32_hip_path_matches_reference(kctx, mode, buckets, gemms, monkeypatch):
+def test_update_params_float32_hip_path_matches_reference(kctx, mode, buckets, gemms, fixture, monkeypatch):
     """The update bench.py times, pinned to the reference's float64 run of the same batch.
     gemms = "hip": every product through egp_gemm_f32 on the bf16 matrix cores with three-piece operands (float32-class
     products; the default); "hip-2piece": two-piece operands (EGP_GEMM_TERMS=3, ~16 mantissa bits per product);
-    "torch": the library's float32 products (EGP_GEMM=torch)."""
-    from egopose_amd import gemm_tuning, lstm
+    "torch": the library's float32 products (EGP_GEMM=torch).
+    fixture "..._s40": 40 state columns -- from 32 on, the first MLP layer of both nets gathers [context | state] itself
+    (gemm.GatherMlpHead: no concatenated input, no scatter pass); with 24 it takes the two-node form."""
+    from egopose_amd import gemm as gemm_mod, gemm_tuning, lstm
     monkeypatch.setenv("EGP_GEMM", "torch" if gemms == "torch" else "hip")
     monkeypatch.setenv("EGP_GEMM_TERMS", "3" if gemms == "hip-2piece" else "6")
-    g = load_golden("ppo_update_h128.npz")
+    g = load_golden(fixture)
+    fused_calls = _count_calls(monkeypatch, gemm_mod, "gather_mlp_head")
     if buckets:     # the bucket padding engages at >= 4 buckets of rows / episodes: shrink the buckets to this batch
         monkeypatch.setattr(gemm_tuning, "ROW_BUCKET", 64)
         monkeypatch.setattr(gemm_tuning, "EPISODE_BUCKET", 8)
@@ -110,6 +114,12 @@ def test_update_params_float32_hip_path_matches_reference(kctx, mode, buckets, g
         # 3 epochs (the first one's forward also serves as the value / fixed-log-prob pass), every one through the
         # grouped HIP recurrences (4 sweeps per launch)
         assert len(group_calls) == 3, "the persistent HIP LSTM did not run as expected: %r" % (group_calls,)
+        # the fused first layer: both nets, 3 epochs -- exactly when its preconditions hold (three-piece HIP products, >= 32
+        # state columns; with episode buckets the context may take the sorted-gather path instead)
+        if gemms == "hip" and fixture.endswith("_s40.npz"):
+            assert len(fused_calls) == 6 or (buckets and len(fused_calls) == 0), fused_calls
+        else:
+            assert len(fused_calls) == 0, fused_calls
         a, r, v0 = agent._seen
         np.testing.assert_allclose(v0, g["values0"], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(r, g["ret0"], rtol=1e-4, atol=1e-5)          # north_star tolerance

@@ -7,7 +7,8 @@ persistent HIP recurrences (hidden 64 / 128 per direction) never see. This scrip
 and records one float64 run of `AgentEgo.update_params` (ego_pose/core/agent_ego.py:34-57 -> agents/agent_ppo.py:16-65)
 with `VideoStateNet(v_hdim=128)` -- the shape of every shipped ego_mimic config -- on a ragged batch of 44 episodes:
 
-    tests/golden/ppo_update_h128.npz   inputs, initial parameters (float32-representable, stored as float32), the
+    tests/golden/ppo_update_h128.npz, ppo_update_h128_s40.npz (24 / 40 state columns)
+                                       inputs, initial parameters (float32-representable, stored as float32), the
                                        reference's values / advantages / returns / log-probs / train-mode policy input
                                        before the update and every parameter after 3 epochs
 
@@ -26,7 +27,9 @@ sys.path.insert(0, os.path.join(REPO, "tools"))
 import gen_golden as G          # noqa: E402  (stubs + workdir helpers)
 
 
-def main():
+def main(out_name="ppo_update_h128.npz", sdim=24, seed_np=2024, seed_torch=17):
+    """`sdim` = 24: the round's first fixture. `sdim` = 40 (ppo_update_h128_s40.npz): at least one 32-wide k-tile of state
+    columns, the shape from which on the first MLP layer gathers [context | state] itself (egopose_amd/gemm.py: GatherMlpHead)."""
     G.install_stubs()
     sys.path.insert(0, G.REF)
     G.enter_workdir()
@@ -40,9 +43,9 @@ def main():
     from models.video_state_net import VideoStateNet
     from ego_pose.core.agent_ego import AgentEgo
 
-    rng = np.random.RandomState(2024)
-    torch.manual_seed(17)
-    sdim, adim, cdim, hdim, margin, T_ep = 24, 6, 16, 128, 10, 20
+    rng = np.random.RandomState(seed_np)
+    torch.manual_seed(seed_torch)
+    adim, cdim, hdim, margin, T_ep = 6, 16, 128, 10, 20
     p_vs = VideoStateNet(cdim, hdim, margin, 'lstm', None, False)
     v_vs = VideoStateNet(cdim, hdim, margin, 'lstm', None, False)
     p_net = PolicyGaussian(MLP(sdim + hdim, [32, 24], 'relu'), adim, log_std=-1.2, fix_std=True)
@@ -92,7 +95,7 @@ def main():
         logp0 = s_p.get_log_prob(policy_in0, ac_t)
     agent.update_params(batch)
     final_np = {"final_%s__%s" % (a, k): v.detach().numpy().copy() for a, mod in mods for k, v in mod.state_dict().items()}
-    out = os.path.join(G.OUT, "ppo_update_h128.npz")
+    out = os.path.join(G.OUT, out_name)
     np.savez_compressed(
         out, cnn_feat0=cnn_feat[0].astype(np.float32), cnn_feat1=cnn_feat[1].astype(np.float32),
         states=batch.states.astype(np.float32), actions=batch.actions.astype(np.float32), masks=batch.masks,
@@ -162,5 +165,6 @@ def small_rewards():
 
 if __name__ == "__main__":
     main()
+    main("ppo_update_h128_s40.npz", sdim=40, seed_np=2025, seed_torch=18)
     obs_variants()
     small_rewards()
