@@ -80,8 +80,41 @@ class MLP(nn.Module):
         return x
 
 
+class _DiagLogProb(torch.autograd.Function):
+    """sum_j log N(value_j; loc_j, exp(log_std_j)) per row (core/distributions.py: normal_log_density + sum(1, keepdim)) in four
+    full-size element-wise kernels forward and two backward (torch.distributions.Normal.log_prob takes about eight each way,
+    plus a validity check of the sample that synchronises with the host). log_std: one row (1, d), broadcast over the batch."""
+
+    @staticmethod
+    def forward(ctx, value, loc, log_std):
+        inv_std = torch.exp(-log_std)
+        z = (value - loc) * inv_std
+        ctx.save_for_backward(z, inv_std)
+        const = log_std.sum() + 0.5 * log_std.shape[-1] * math.log(2.0 * math.pi)
+        return (z * z).sum(1, keepdim=True).mul_(-0.5).sub_(const)
+
+    @staticmethod
+    def backward(ctx, g):
+        z, inv_std = ctx.saved_tensors
+        d_loc = d_ls = None
+        if ctx.needs_input_grad[1]:
+            d_loc = (z * inv_std).mul_(g)
+        if ctx.needs_input_grad[2]:
+            d_ls = ((z * z - 1.0) * g).sum(0, keepdim=True)
+        d_val = None
+        if ctx.needs_input_grad[0]:
+            d_val = -((z * inv_std) * g)
+        return d_val, d_loc, d_ls
+
+
 class DiagGaussian(torch.distributions.Normal):
-    """Normal with summed log-prob and the reference's 'KL to a detached copy of itself'."""
+    """Normal with summed log-prob and the reference's 'KL to a detached copy of itself'. `log_std_row`: the (1, d) log
+    standard deviation the scale was expanded from, when the caller has it (PolicyGaussian): log_prob then takes the short
+    route (_DiagLogProb)."""
+
+    def __init__(self, loc, scale, log_std_row=None):
+        super().__init__(loc, scale, validate_args=False)       # (the argument checks cost a device reduction + host sync per call)
+        self._log_std_row = log_std_row
 
     def kl(self):
         mu0, s0 = self.loc.detach(), self.scale.detach()
@@ -90,6 +123,8 @@ class DiagGaussian(torch.distributions.Normal):
         return out.sum(1, keepdim=True)
 
     def log_prob(self, value):
+        if self._log_std_row is not None and value.dim() == 2:
+            return _DiagLogProb.apply(value, self.loc, self._log_std_row)
         return super().log_prob(value).sum(1, keepdim=True)
 
     def mean_sample(self):
@@ -134,10 +169,11 @@ class PolicyGaussian(Policy):
             mean = self.action_mean(self.net(x))
             if n is not None:
                 mean = mean[:n]
-        return mean, torch.exp(self.action_log_std.expand_as(mean))
+        return mean, torch.exp(self.action_log_std).expand_as(mean)         # (a view: no (n, d) tensor of standard deviations)
 
     def forward(self, x):
-        return DiagGaussian(*self.mean_std(x))
+        mean, std = self.mean_std(x)
+        return DiagGaussian(mean, std, self.action_log_std if self.action_log_std.dim() == 2 and self.action_log_std.shape[0] == 1 else None)
 
     def get_fim(self, x):
         mean, _ = self.mean_std(x)
