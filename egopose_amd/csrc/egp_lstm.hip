@@ -249,7 +249,26 @@ struct LstmGroup {
     float *h[4];            // forward: h_out per problem (row (t, b) at h[p] + (t*B + b) * ld_h)
     const float *dh[4];     // backward: d h_out per problem
     float *db;              // backward, optional: [P][4H] accumulates sum_t,b d_pre (atomics; zeroed by the caller)
+    // optional (egp_lstm_group_*_len_f32): ragged batches. order[p] = sequence (column b of the [T][B] layout) at position p,
+    // workgroups take ROWS consecutive positions; steps[p] = time steps the sequence at position p needs FROM THE START
+    // (its outputs at t >= steps[p] are never read). A problem that runs forward in time stops at the longest of its rows
+    // (h_out / d_pre of the skipped steps are written as zeros); problems that run backward in time go through all T
+    // steps -- their state at the last needed step depends on everything after it. Sorting the positions by steps makes the
+    // rows of a workgroup alike.
+    const int *order;
+    const int *steps;
 };
+
+// steps a forward-running workgroup has to make: the longest of its rows
+template <int ROWS>
+__device__ __forceinline__ int lstm_group_steps(const LstmGroup &grp, int reverse, int r0, int B, int T) {
+    if (reverse || !grp.steps) return T;
+    int mx = 0;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i)
+        if (r0 + i < B) mx = max(mx, grp.steps[r0 + i]);
+    return min(T, mx);
+}
 
 // FULL = every row of every workgroup exists (B % ROWS == 0), TRAIN = gates / cells are saved. Both are template
 // parameters so that the timestep body is straight-line code: with a branch around any load or store the compiler's
@@ -279,8 +298,10 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
     for (int q = 0; q < NQ; ++q) {
         cst[q] = 0.f;
         live[q] = FULL || r0 + 4 * q + sub < B;
-        rowc[q] = live[q] ? r0 + 4 * q + sub : B - 1;
+        const int pos = live[q] ? r0 + 4 * q + sub : B - 1;
+        rowc[q] = grp.order ? grp.order[pos] : pos;
     }
+    const int Tp = lstm_group_steps<ROWS>(grp, reverse, r0, B, T);       // (wave-uniform)
     for (int i = threadIdx.x; i < 2 * ROWS * (LH + 4); i += 4 * LH) (&s_h[0][0][0])[i] = 0.f;
 
 #define EGP_LSTM_FETCH_GX(STEP, DST)                                                                 \
@@ -327,7 +348,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
             cst[q] = cn;
             s_h[par ^ 1][4 * q + sub][u] = hn;
             if (FULL || live[q]) {
-                const long row = (long)t * B + r0 + 4 * q + sub;
+                const long row = (long)t * B + rowc[q];
                 h_out[row * ld_h + u] = hn;
                 if (TRAIN) {
                     *reinterpret_cast<f32x4 *>(gates_out + row * ld + 4 * u) = f32x4{ig, fg, gg, og};
@@ -342,7 +363,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
     for (int d = 0; d < PD; ++d) EGP_LSTM_FETCH_GX(d, pre[d])
     __syncthreads();
     int s0 = 0;
-    for (; s0 + PD <= T; s0 += PD) {
+    for (; s0 + PD <= Tp; s0 += PD) {
         // this iteration's tiles move to `cur`, then ALL loads of the next iteration are issued before the first step:
         // when they are needed (next iteration) only operations issued after them -- this iteration's stores -- may
         // still be outstanding, so the in-order vmcnt wait never stalls on a young load or store. No exit from the
@@ -360,7 +381,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
 #pragma unroll
         for (int d = 0; d < PD; ++d) do_step(s0 + d, d & 1, cur[d]);
     }
-    for (int d = 0; s0 + d < T; ++d) {          // T % PD last steps: their tiles are pre[0..] (fetched, not clamped)
+    for (int d = 0; s0 + d < Tp; ++d) {         // Tp % PD last steps: their tiles are pre[0..] (fetched, not clamped)
         f32x4 last[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) last[q] = d == 0 ? pre[0][q] : d == 1 ? pre[1 % PD][q] : d == 2 ? pre[2 % PD][q] : d == 3 ? pre[3 % PD][q]
@@ -368,6 +389,12 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
         do_step(s0 + d, d & 1, last);
     }
 #undef EGP_LSTM_FETCH_GX
+    // the steps a ragged forward-running workgroup skipped: zeros (a weight gradient multiplies these rows with a zero d_pre,
+    // and 0 * whatever an uninitialised buffer holds may be NaN)
+    for (int t = Tp; t < T; ++t)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (FULL || live[q]) h_out[((long)t * B + rowc[q]) * ld_h + u] = 0.f;
 }
 
 template <int NQ, int LH, bool FULL>
@@ -404,8 +431,16 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
         dc_next[qq] = 0.f; dh_rec[qq] = 0.f; dsum[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int r = (threadIdx.x + NT * qq) / LH;
         live[qq] = FULL || r0 + r < B;
-        rowc[qq] = live[qq] ? r0 + r : B - 1;
+        const int pos = live[qq] ? r0 + r : B - 1;
+        rowc[qq] = grp.order ? grp.order[pos] : pos;
     }
+    // ragged forward-running problems: the steps the forward sweep skipped carry no gradient (their d_pre is written as zeros)
+    const int Tp = lstm_group_steps<ROWS>(grp, reverse, r0, B, T);
+    for (int t = Tp; t < T; ++t)
+#pragma unroll
+        for (int qq = 0; qq < NP; ++qq)
+            if (FULL || live[qq])
+                *reinterpret_cast<f32x4 *>(dpre + ((long)t * B + rowc[qq]) * ld + 4 * ((threadIdx.x + NT * qq) % LH)) = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #define EGP_LSTM_FETCH(STEP, D)                                                                      \
     {                                                                                                \
@@ -437,7 +472,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
             const float dg = dc * ig * (1.f - gg * gg);
             dc_next[qq] = dc * fg;
             const f32x4 d4 = f32x4{di, df, dg, d_o};
-            if (FULL || live[qq]) { *reinterpret_cast<f32x4 *>(dpre + ((long)t * B + r0 + r) * ld + 4 * j) = d4; dsum[qq] += d4; }
+            if (FULL || live[qq]) { *reinterpret_cast<f32x4 *>(dpre + ((long)t * B + rowc[qq]) * ld + 4 * j) = d4; dsum[qq] += d4; }
             *reinterpret_cast<f32x4 *>(&s_d[r][4 * j]) = d4;
         }
         __syncthreads();
@@ -480,8 +515,8 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
     };
 
 #pragma unroll
-    for (int d = 0; d < PD; ++d) EGP_LSTM_FETCH(T - 1 - d, d)
-    int s0 = T - 1;
+    for (int d = 0; d < PD; ++d) EGP_LSTM_FETCH(Tp - 1 - d, d)
+    int s0 = Tp - 1;
     for (; s0 - PD + 1 >= 0; s0 -= PD) {
         // as in the forward kernel: this iteration's operands move to `c*`, all loads of the next iteration go out
         // first, and nothing leaves the iteration half way
@@ -652,6 +687,13 @@ int egp_lstm_bwd_f32(const float *dh_out, const float *gates_save, const float *
 
 int egp_lstm_group_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t B, int32_t hidden, int32_t n_problems,
                            int32_t reverse_mask, float *const *h_out, int32_t ld_h, float *gates_save, float *cells_save, void *stream) {
+    return egp_lstm_group_fwd_len_f32(gates_x, w_hh, T, B, hidden, n_problems, reverse_mask, h_out, ld_h, gates_save, cells_save, nullptr, nullptr, stream);
+}
+
+int egp_lstm_group_fwd_len_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t B, int32_t hidden, int32_t n_problems,
+                               int32_t reverse_mask, float *const *h_out, int32_t ld_h, float *gates_save, float *cells_save,
+                               const int32_t *seq_order, const int32_t *seq_steps, void *stream) {
+    EGP_REQUIRE((seq_order == nullptr) == (seq_steps == nullptr), "seq_order and seq_steps go together");
     EGP_REQUIRE(lstm_mfma(), "grouped LSTM sweeps need the matrix-core kernels (EGP_LSTM_MFMA=0 is set)");
     EGP_REQUIRE(hidden == 64 || hidden == 128, "egp_lstm kernels are built for hidden size 64 and 128");
     EGP_REQUIRE(n_problems >= 1 && n_problems <= 4, "1..4 problems per group");
@@ -665,6 +707,7 @@ int egp_lstm_group_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, i
         EGP_REQUIRE(h_out[p], "NULL h_out");
         g.h[p] = h_out[p];
     }
+    g.order = seq_order; g.steps = seq_steps;
     launch_fwd_mfma(hidden, n_problems, gates_x, w_hh, T, B, g, gates_save, cells_save, (hipStream_t)stream);
     return lstm_launch_check("k_lstm_fwd_mfma (group)");
 }
@@ -672,6 +715,14 @@ int egp_lstm_group_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, i
 int egp_lstm_group_bwd_f32(const float *const *dh_out, int32_t ld_dh, const float *gates_save, const float *cells_save, const float *w_hh,
                            int32_t T, int32_t B, int32_t hidden, int32_t n_problems, int32_t reverse_mask, float *d_pre, float *d_bias,
                            void *stream) {
+    return egp_lstm_group_bwd_len_f32(dh_out, ld_dh, gates_save, cells_save, w_hh, T, B, hidden, n_problems, reverse_mask, d_pre, d_bias, nullptr,
+                                      nullptr, stream);
+}
+
+int egp_lstm_group_bwd_len_f32(const float *const *dh_out, int32_t ld_dh, const float *gates_save, const float *cells_save, const float *w_hh,
+                               int32_t T, int32_t B, int32_t hidden, int32_t n_problems, int32_t reverse_mask, float *d_pre, float *d_bias,
+                               const int32_t *seq_order, const int32_t *seq_steps, void *stream) {
+    EGP_REQUIRE((seq_order == nullptr) == (seq_steps == nullptr), "seq_order and seq_steps go together");
     EGP_REQUIRE(lstm_mfma(), "grouped LSTM sweeps need the matrix-core kernels (EGP_LSTM_MFMA=0 is set)");
     EGP_REQUIRE(hidden == 64 || hidden == 128, "egp_lstm kernels are built for hidden size 64 and 128");
     EGP_REQUIRE(n_problems >= 1 && n_problems <= 4, "1..4 problems per group");
@@ -684,6 +735,7 @@ int egp_lstm_group_bwd_f32(const float *const *dh_out, int32_t ld_dh, const floa
         EGP_REQUIRE(dh_out[p], "NULL d h_out");
         g.dh[p] = dh_out[p];
     }
+    g.order = seq_order; g.steps = seq_steps;
     launch_bwd_mfma(hidden, n_problems, gates_save, cells_save, w_hh, T, B, g, d_pre, (hipStream_t)stream);
     return lstm_launch_check("k_lstm_bwd_mfma (group)");
 }

@@ -11,6 +11,7 @@ float32, zero initial state: exactly what ``RNN.batch_forward`` of the reference
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -131,7 +132,9 @@ class LstmGroup(torch.autograd.Function):
     problems is one batched GEMM against x, dW_hh one per problem against its own h_prev (no concatenated operands)."""
 
     @staticmethod
-    def forward(ctx, x, reverse_mask, P, width, train, *params):
+    def forward(ctx, x, reverse_mask, P, width, train, ragged, *params):
+        """`ragged` = None or (order, steps): int32 device tensors of B entries (include/egopose_hip.h,
+        egp_lstm_group_fwd_len_f32) -- forward-running problems stop at the longest sequence of their workgroup."""
         lib = L.load()
         T, B, D = x.shape
         w_ih, w_hh, b_ih, b_hh = params[0::4], params[1::4], params[2::4], params[3::4]
@@ -154,12 +157,14 @@ class LstmGroup(torch.autograd.Function):
         cells = torch.empty(P, T, B, H, dtype=x.dtype, device=x.device) if train else None
         base, esz = h_buf.data_ptr(), h_buf.element_size()
         ptrs = (C.c_void_p * P)(*[base + esz * (((p // width) * (T + 2) + 1) * B * W + (p % width) * H) for p in range(P)])
-        L.check(lib.egp_lstm_group_fwd_f32(_p(gx), _p(w_hh_all), T, B, H, P, reverse_mask, ptrs, W,
-                                           _p(gx if train else None), _p(cells), _s()), "egp_lstm_group_fwd_f32")
+        order, steps = ragged if ragged is not None else (None, None)
+        L.check(lib.egp_lstm_group_fwd_len_f32(_p(gx), _p(w_hh_all), T, B, H, P, reverse_mask, ptrs, W,
+                                               _p(gx if train else None), _p(cells), _p(order), _p(steps), _s()), "egp_lstm_group_fwd_len_f32")
         outs = tuple(h_buf[i, 1:T + 1] for i in range(n_out))
         if train:
             ctx.save_for_backward(x2, w_in, w_hh_all, h_buf, gx, cells)
             ctx.meta = (T, B, D, H, P, width, reverse_mask)
+            ctx.ragged = ragged
         return outs
 
     @staticmethod
@@ -174,8 +179,9 @@ class LstmGroup(torch.autograd.Function):
         ptrs = (C.c_void_p * P)(*[douts[p // width].data_ptr() + esz * (p % width) * H for p in range(P)])
         dpre = torch.empty(T * B, P * 4 * H, dtype=x2.dtype, device=x2.device)
         db = torch.zeros(P, 4 * H, dtype=x2.dtype, device=x2.device)
-        L.check(lib.egp_lstm_group_bwd_f32(ptrs, W, _p(gates), _p(cells), _p(w_hh_all), T, B, H, P, reverse_mask, _p(dpre), _p(db), _s()),
-                "egp_lstm_group_bwd_f32")
+        order, steps = ctx.ragged if ctx.ragged is not None else (None, None)
+        L.check(lib.egp_lstm_group_bwd_len_f32(ptrs, W, _p(gates), _p(cells), _p(w_hh_all), T, B, H, P, reverse_mask, _p(dpre), _p(db),
+                                               _p(order), _p(steps), _s()), "egp_lstm_group_bwd_len_f32")
         d3 = dpre.view(T, B, P * 4 * H)
         use_g = G.enabled()
         if use_g:      # one split-K product for the P stacked W_ih gradients
@@ -196,7 +202,7 @@ class LstmGroup(torch.autograd.Function):
             d_b = db[p].index_select(0, inv)
             grads += [dw_ih, dw_hh, d_b, d_b]
         d_x = dpre.mm(w_in).view(T, B, D) if ctx.needs_input_grad[0] else None
-        return (d_x, None, None, None, None, *grads)
+        return (d_x, None, None, None, None, None, *grads)
 
 
 def _wants_grad(x, params):
@@ -213,12 +219,23 @@ def group_available(x, cells):
     return all(available(x, c) and c.hidden_size == c0.hidden_size and c.input_size == c0.input_size for c in cells)
 
 
-def lstm_group(x, cells, reverses, pairs=False):
+def ragged_order(seq_steps, device):
+    """(order, steps) for LstmGroup from the time steps each sequence needs (B entries, in layout order): positions sorted by
+    decreasing length, so that the four sequences of a workgroup are alike."""
+    st = torch.as_tensor(seq_steps, dtype=torch.int32).reshape(-1)
+    order = torch.argsort(st, descending=True, stable=True).to(torch.int32)
+    return order.to(device).contiguous(), st[order.long()].to(device).contiguous()
+
+
+def lstm_group(x, cells, reverses, pairs=False, ragged=None):
     """P (cell, reverse) pairs over the same x (T,B,D), one grouped launch each way. Returns [(T,B,H)] * P, or with
-    pairs=True [(T,B,2H)] * P/2 where problems 2i and 2i+1 fill the two halves of output i."""
+    pairs=True [(T,B,2H)] * P/2 where problems 2i and 2i+1 fill the two halves of output i. `ragged` (ragged_order(...)):
+    outputs of a forward-running problem beyond a sequence's own steps are not computed (zeros) and carry no gradient."""
     mask = sum(1 << i for i, r in enumerate(reverses) if r)
     params = [t for c in cells for t in (c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh)]
-    return list(LstmGroup.apply(x.contiguous(), mask, len(cells), 2 if pairs else 1, _wants_grad(x, params), *params))
+    if ragged is not None and (ragged[0].shape[0] != x.shape[1] or os.environ.get("EGP_LSTM_RAGGED", "1") == "0"):
+        ragged = None
+    return list(LstmGroup.apply(x.contiguous(), mask, len(cells), 2 if pairs else 1, _wants_grad(x, params), ragged, *params))
 
 
 def lstm_direction(cell, x, reverse):

@@ -247,6 +247,7 @@ class RNN(nn.Module):
         if bi_dir:
             self.rnn_b = make(input_dim, hidden)
         self.hx = self.cx = None
+        self.ragged = None       # set by the caller around a batch forward: (order, steps) of lstm.ragged_order
 
     def set_mode(self, mode):
         self.mode = mode
@@ -278,7 +279,7 @@ class RNN(nn.Module):
         if (self.bi_dir and self.cell_type == "lstm" and _LSTM_IMPL != "torch" and os.environ.get("EGP_LSTM_GROUP", "1") != "0"
                 and _hip_lstm.group_available(x, [self.rnn_f, self.rnn_b])):
             # both directions in one grouped launch each way, writing the halves of one (T, B, 2H) buffer (lstm.LstmGroup)
-            return _hip_lstm.lstm_group(x, [self.rnn_f, self.rnn_b], [False, True], pairs=True)[0]
+            return _hip_lstm.lstm_group(x, [self.rnn_f, self.rnn_b], [False, True], pairs=True, ragged=self.ragged)[0]
         out = self._sweep(self.rnn_f, x, False)
         if self.bi_dir:
             out = torch.cat((out, self._sweep(self.rnn_b, x, True)), 2)
@@ -315,6 +316,7 @@ class VideoStateNet(nn.Module):
         self._v_ctx = None
         self._ctx_key = None
         self._cnn_table = None   # optional (device table, take offsets) installed by the env
+        self._ragged = None      # (order, steps) of the train-mode windows for the grouped HIP sweeps
 
     def set_mode(self, mode):
         self.mode = mode
@@ -388,6 +390,13 @@ class VideoStateNet(nn.Module):
         self._gather_tm = torch.as_tensor(tm, dtype=torch.long, device=device)
         self._gather_unique = np.unique(tm).size == tm.size      # (always, for a batch cut into episodes: the scatter of the backward pass relies on it)
         self._ctx_key = (int(max_len), meta.shape[0], hash(meta.tobytes()))       # which windows cnn_feat_ctx holds
+        # Ragged sweeps (lstm.ragged_order): the forward direction's output at frame t depends on frames <= t only and only
+        # frames [m, m + len_e) of an episode are ever gathered, so it stops after m + len_e steps (workgroups of sequences
+        # sorted by length); the backward direction starts at the end of the padded window and runs it all, as in the
+        # reference. Windows added to fill an episode bucket need no step at all.
+        steps = np.zeros(self.cnn_feat_ctx.shape[1], np.int64)
+        steps[:len(lens)] = lens + m
+        self._ragged = _hip_lstm.ragged_order(steps, device) if self.cnn_feat_ctx.is_cuda else None
         # Length buckets for the forward direction: its output at frame t only depends on frames <= t and only frames
         # [m, m + len_e) of an episode are ever gathered, so episodes sorted by length let the forward LSTM stop early
         # (the backward direction starts at the end of the padded window and must run it all, as in the reference).
@@ -433,7 +442,11 @@ class VideoStateNet(nn.Module):
             if with_grad != torch.is_grad_enabled():
                 ctx = None                   # left over from a pass in the other autograd mode: never reuse it
         if ctx is None:
-            ctx = self.forward_v_net(self.cnn_feat_ctx)
+            self.v_net.ragged = self._ragged
+            try:
+                ctx = self.forward_v_net(self.cnn_feat_ctx)
+            finally:
+                self.v_net.ragged = None
         ctx2d = ctx.reshape(-1, self.v_hdim)
         if self._gather_unique and _gemm.gather_concat_available(ctx2d, self._gather_tm, x):
             if self.lazy_gather and _gemm.fused_gather_available(self.v_hdim, self.lazy_gather, x.shape[1]):
@@ -722,7 +735,7 @@ def grouped_video_context(nets):
     x = n0.cnn_feat_ctx                      # same episodes, same windows for every net (initialize() of the same batch)
     if not _hip_lstm.group_available(x, cells):
         return False
-    hs = _hip_lstm.lstm_group(x, cells, revs, pairs=n0.v_net.bi_dir)     # bi-directional: (T, B, 2H) per net, no concatenation
+    hs = _hip_lstm.lstm_group(x, cells, revs, pairs=n0.v_net.bi_dir, ragged=n0._ragged)     # bi-directional: (T, B, 2H) per net, no concatenation
     for i, n in enumerate(nets):
         n._v_ctx = (hs[i], torch.is_grad_enabled())
     return True

@@ -283,7 +283,7 @@ def test_no_grad_passes_take_the_inference_kernels(monkeypatch):
 
         def __getattr__(self, name):
             fn = getattr(self._lib, name)
-            if name not in ("egp_lstm_fwd_f32", "egp_lstm_group_fwd_f32"):
+            if name not in ("egp_lstm_fwd_f32", "egp_lstm_group_fwd_len_f32"):
                 return fn
             k = 7 if name == "egp_lstm_fwd_f32" else 9            # gates_out, cells_out follow (include/egopose_hip.h)
 
@@ -363,3 +363,41 @@ def test_bf16_encoder_keeps_float32_master_weights():
         assert p.dtype == torch.float32 and not torch.equal(p, before[n]), n
     for m, s in net._enc16.pairs:
         assert torch.equal(s, m.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("T,B", [(40, 37), (220, 70), (9, 4)])
+def test_ragged_grouped_sweeps_match_the_full_ones_where_it_counts(T, B):
+    """lstm.ragged_order / egp_lstm_group_*_len_f32: with per-sequence step counts the forward-running direction stops
+    early. Outputs inside every sequence's own steps (both directions) and ALL parameter gradients must equal the full
+    sweeps' when the loss only looks at those outputs -- which is how the update uses the video context (rows beyond an
+    episode are never gathered); the skipped outputs are zeros."""
+    from egopose_amd import lstm as lstm_mod
+    from egopose_amd.nets import RNN
+    torch.manual_seed(T + B)
+    rng = np.random.RandomState(T * B)
+    steps = rng.randint(0, T + 1, size=B)
+    steps[0] = T                                            # one full-length sequence, one empty one
+    if B > 1:
+        steps[1] = 0
+    mask = (torch.arange(T).unsqueeze(1) < torch.as_tensor(steps).unsqueeze(0)).float().unsqueeze(2).cuda()     # (T, B, 1)
+    dy = torch.randn(T, B, 128, device="cuda") * mask       # no gradient into rows nobody reads
+    x = torch.randn(T, B, 128, device="cuda")
+    res = []
+    for ragged in (None, lstm_mod.ragged_order(steps, torch.device("cuda"))):
+        torch.manual_seed(3)
+        rnn = RNN(128, 128, "lstm", bi_dir=True).cuda()
+        rnn.ragged = ragged
+        out = rnn(x)
+        (out * dy).sum().backward()
+        res.append((out.detach(), {k: p.grad.clone() for k, p in rnn.named_parameters()}))
+    (full, gfull), (rag, grag) = res
+    H = 64
+    np.testing.assert_array_equal((rag * mask).cpu().numpy(), (full * mask).cpu().numpy())
+    # beyond its own steps a sequence still rides along to the longest of its workgroup: the full sweep's value, then zeros
+    fwd_r, fwd_f = rag[:, :, :H], full[:, :, :H]
+    assert bool(((fwd_r == fwd_f) | (fwd_r == 0)).all())
+    np.testing.assert_array_equal(rag[:, :, H:].cpu().numpy(), full[:, :, H:].cpu().numpy())        # the reversed direction runs it all
+    for k in gfull:
+        a, b = grag[k].cpu().numpy(), gfull[k].cpu().numpy()
+        scale = max(1.0, np.abs(b).max())
+        np.testing.assert_allclose(a / scale, b / scale, rtol=0, atol=2e-6, err_msg=k)      # (split-K sums see zeros instead of tiny products)
