@@ -524,9 +524,13 @@ struct WsStage {
             }
         } else {
             int krow[8];                               // wave-uniform (scalar loads, scalar address arithmetic)
+            if (kgather) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                krow[j] = __builtin_amdgcn_readfirstlane(kgather ? (int)kgather[k0 + 8 * panel + j] : k0 + 8 * panel + j);
+                for (int j = 0; j < 8; ++j) krow[j] = __builtin_amdgcn_readfirstlane((int)kgather[k0 + 8 * panel + j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) krow[j] = k0 + 8 * panel + j;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const char *base = (const char *)(P + (long)krow[j] * ld);
@@ -618,7 +622,10 @@ __device__ __forceinline__ void ws_zero_head(float (&v)[R / 8], int zrel, int pa
         for (int j = 0; j < 8; ++j) v[8 * u + j] = 8 * panel + j >= zrel ? v[8 * u + j] : 0.f;
 }
 
-template <int BN, bool A_KC, bool B_KC>
+#ifndef WS_CONSUMER_PRIO
+#define WS_CONSUMER_PRIO 0
+#endif
+template <int BN, bool A_KC, bool B_KC, bool FUSED>      // FUSED: the gather / scatter operands of egp_gemm_desc (a_rows ... c_rows) are compiled in
 __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
     constexpr int NIMG = 3, NSET = 4;
     constexpr int WN = BN == 128 ? 2 : 1;
@@ -673,20 +680,30 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
         auto issue = [&](auto setc) __attribute__((always_inline)) {      // loads of the k-tile under the cursor; cursor moves on
             constexpr int SET = decltype(setc)::value;
             // B given as [k][n] with a second source: the tile's columns come from one of them (b_split is a multiple of BN)
-            const bool b_second = !B_KC && g.B2 && cur.n0 >= g.b_split;
+            const bool b_second = FUSED && !B_KC && g.B2 && cur.n0 >= g.b_split;
             if (cur.w != bound) {
-                sa.bind(g.lda, g.M, cur.m0, -1, pt, A_KC ? g.a_rows : nullptr, g.lda2);
-                if (b_second) sb.bind(g.ldb2, g.N - g.b_split, cur.n0 - g.b_split, ones_row - g.b_split, pt);
-                else sb.bind(g.ldb, (!B_KC && g.B2) ? g.b_split : g.N, cur.n0, (!B_KC && g.B2) ? -1 : ones_row, pt);
+                if constexpr (FUSED) {
+                    sa.bind(g.lda, g.M, cur.m0, -1, pt, A_KC ? g.a_rows : nullptr, g.lda2);
+                    if (b_second) sb.bind(g.ldb2, g.N - g.b_split, cur.n0 - g.b_split, ones_row - g.b_split, pt);
+                    else sb.bind(g.ldb, (!B_KC && g.B2) ? g.b_split : g.N, cur.n0, (!B_KC && g.B2) ? -1 : ones_row, pt);
+                } else {
+                    sa.bind(g.lda, g.M, cur.m0, -1, pt);
+                    sb.bind(g.ldb, g.N, cur.n0, ones_row, pt);
+                }
                 bound = cur.w;
             }
             const bool last = cur.s == cur.nst - 1;
             const int kz = cur.kbeg + cur.s * BK;
             const int k0 = last ? cur.kend - BK : kz;
             zrel[SET] = kz - k0;
-            const bool a_second = A_KC && g.A2 && k0 >= g.a_split;        // (a_split is a multiple of BK: a k-tile has one source)
-            sa.load(a_second ? g.A2 : g.A, a_second ? g.lda2 : g.lda, a_second ? k0 - g.a_split : k0, wave, ra[SET], a_second);
-            sb.load(b_second ? g.B2 : g.B, b_second ? g.ldb2 : g.ldb, k0, wave, rb[SET], false, (!B_KC && !b_second) ? g.b_krows : nullptr);
+            if constexpr (FUSED) {
+                const bool a_second = A_KC && g.A2 && k0 >= g.a_split;        // (a_split is a multiple of BK: a k-tile has one source)
+                sa.load(a_second ? g.A2 : g.A, a_second ? g.lda2 : g.lda, a_second ? k0 - g.a_split : k0, wave, ra[SET], a_second);
+                sb.load(b_second ? g.B2 : g.B, b_second ? g.ldb2 : g.ldb, k0, wave, rb[SET], false, (!B_KC && !b_second) ? g.b_krows : nullptr);
+            } else {
+                sa.load(g.A, g.lda, k0, wave, ra[SET]);
+                sb.load(g.B, g.ldb, k0, wave, rb[SET]);
+            }
             ws_next<BN>(g, cur, w_scan);
         };
         auto stage = [&](auto setc, int buf) __attribute__((always_inline)) {   // register set -> LDS buffer `buf`
@@ -735,6 +752,7 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
     }
 
     // ---- consumers
+    if (WS_CONSUMER_PRIO) __builtin_amdgcn_s_setprio(WS_CONSUMER_PRIO);      // (the matrix pipe's wave goes first when both want to issue)
     const int wm = wave / WN, wn = wave % WN;
     const int frow = lane & 31, fkh = lane >> 5;
     f32x16 acc[MI][NJ];
@@ -806,7 +824,7 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int row = row0 + 32 * i + 4 * it;
-                drow[i][it] = (!PARTIAL && g.c_rows) ? (long)g.c_rows[min(row, g.M - 1)] : (long)row;
+                drow[i][it] = (FUSED && !PARTIAL && g.c_rows) ? (long)g.c_rows[min(row, g.M - 1)] : (long)row;
             }
         // (16-byte accesses on 4-byte-aligned addresses throughout: leading dimensions like 243 are welcome)
         f32x4u bv = {0.f, 0.f, 0.f, 0.f};
@@ -936,7 +954,7 @@ int launch_variant(const GemmArgs &g, dim3 grid, size_t lds, hipStream_t s) {
     return after_launch("k_gemm_bf16x");
 }
 
-template <int BN>
+template <int BN, bool FUSED>
 int launch_ws(const GemmArgs &g, hipStream_t s) {
     static int n_cu = 0;
     if (!n_cu) {
@@ -948,7 +966,7 @@ int launch_ws(const GemmArgs &g, hipStream_t s) {
     const dim3 grid((unsigned)(g.n_items < n_cu ? g.n_items : n_cu));
 #define EGP_GEMM_WS_LAUNCH(AK, BKC)                                                                                   \
     do {                                                                                                              \
-        auto kern = k_gemm_ws<BN, AK, BKC>;                                                                           \
+        auto kern = k_gemm_ws<BN, AK, BKC, FUSED>;                                                                    \
         static bool attr_set = false;                                                                                 \
         if (!attr_set) {                                                                                              \
             EGP_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
@@ -1054,7 +1072,8 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     const bool wide = (partial || d->N % 4 == 0) && (d->a_kcontig || d->M >= 2) && (d->b_kcontig || d->N >= 2);
     int n_splits_written = zs;
     if (d->terms == 6 && ws_on && last_len >= BK && small32 && wide) {
-        rc = bn64 ? launch_ws<64>(g, s) : launch_ws<128>(g, s);
+        if (fused_io) rc = bn64 ? launch_ws<64, true>(g, s) : launch_ws<128, true>(g, s);
+        else rc = bn64 ? launch_ws<64, false>(g, s) : launch_ws<128, false>(g, s);
         n_splits_written = zs_ws;
     } else if (fused_io) {
         egp::set_error("invalid argument: %s", "gather / scatter operands need the persistent three-piece kernel (terms = 6, EGP_GEMM_WS != 0, k ranges >= 32, N %% 4 == 0)");
