@@ -74,7 +74,7 @@ class GemmDesc(C.Structure):
                 ("bias_grad", vp), ("workspace", vp),
                 ("a_rows", vp), ("A2", vp), ("lda2", C.c_int64), ("a_split", C.c_int32), ("a_src_rows", C.c_int64),
                 ("b_krows", vp), ("B2", vp), ("ldb2", C.c_int64), ("b_split", C.c_int32), ("b_src_rows", C.c_int64),
-                ("c_rows", vp)]
+                ("c_rows", vp), ("a_krows", vp)]
 
 
 class EngineDesc(C.Structure):

@@ -89,6 +89,7 @@ struct GemmArgs {
     int tiles_m, tiles_n, xcd_order;
     // fused gather / scatter (egp_gemm_desc: a_rows ... c_rows), k_gemm_ws only
     const long long *a_rows; const float *A2; long lda2; int a_split;
+    const long long *a_krows;                 // A given as [k][m]: k-row k lives at row a_krows[k]
     const long long *b_krows; const float *B2; long ldb2; int b_split;
     const long long *c_rows;
     int partial;                              // results go to the workspace (k splits and / or the ones column), reduced by k_gemm_reduce
@@ -511,9 +512,10 @@ struct WsStage {
     static constexpr int NLOAD = KC ? R / 32 : (PAIR ? 8 : R / 8);            // load instructions per k-tile and thread
     using Regs = std::conditional_t<KC, f32x4[R / 32], std::conditional_t<PAIR, f32x2[8], float[R / 8]>>;
     // k0: first k of the tile; `panel`: the wave's k-panel (wave-uniform), used by the row-contiguous forms;
-    // `second` (k-contiguous form): the rows of the second source; `kgather` (row-contiguous forms): k-row k lives at row kgather[k] of P
-    __device__ __forceinline__ void load(const float *__restrict__ P, long ld, int k0, int panel, Regs &r, bool second = false,
-                                         const long long *kgather = nullptr) const {
+    // `second` (k-contiguous form): the rows of the second source; `krows` (row-contiguous forms): the 8 k-rows of the wave's panel
+    // live at rows krows[0..7] of P (a k-gather; the producer loop resolves the indices one stage early)
+    __device__ __forceinline__ void load(const float *__restrict__ P, long ld, int k0, int panel, Regs &r, bool second, bool kgather,
+                                         const int (&krows)[8]) const {
         if constexpr (KC) {
             const char *base = (const char *)(P + k0);
 #pragma unroll
@@ -523,14 +525,9 @@ struct WsStage {
                 asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(r[2 * u + 1]) : "v"(o), "s"(base));
             }
         } else {
-            int krow[8];                               // wave-uniform (scalar loads, scalar address arithmetic)
-            if (kgather) {
+            int krow[8];                               // wave-uniform (scalar address arithmetic); `krows`: gathered k-rows, resolved by the caller
 #pragma unroll
-                for (int j = 0; j < 8; ++j) krow[j] = __builtin_amdgcn_readfirstlane((int)kgather[k0 + 8 * panel + j]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) krow[j] = k0 + 8 * panel + j;
-            }
+            for (int j = 0; j < 8; ++j) krow[j] = __builtin_amdgcn_readfirstlane(kgather ? krows[j] : k0 + 8 * panel + j);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const char *base = (const char *)(P + (long)krow[j] * ld);
@@ -677,6 +674,23 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
         // counter can express (row-contiguous operands take 16 scalar loads each)
         constexpr int PER_SET = SA::NLOAD + SB::NLOAD;
         constexpr int YOUNGER = 3 * PER_SET <= 63 ? 3 * PER_SET : (2 * PER_SET <= 63 ? 2 * PER_SET : PER_SET);
+        // k-gathers (a_krows / b_krows): the index entries of the k-tile under the cursor, fetched (scalar loads) BEFORE the
+        // staging work of the iteration so that they have landed when `issue` forms the load addresses from them
+        int ka[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto prefetch = [&]() __attribute__((always_inline)) {
+            if constexpr (FUSED && (!A_KC || !B_KC)) {
+                const bool last = cur.s == cur.nst - 1;
+                const int k0 = (last ? cur.kend - BK : cur.kbeg + cur.s * BK) + 8 * wave;
+                if (!A_KC && g.a_krows) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ka[j] = __builtin_amdgcn_readfirstlane((int)g.a_krows[k0 + j]);
+                }
+                if (!B_KC && g.b_krows) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) kb[j] = __builtin_amdgcn_readfirstlane((int)g.b_krows[k0 + j]);
+                }
+            }
+        };
         auto issue = [&](auto setc) __attribute__((always_inline)) {      // loads of the k-tile under the cursor; cursor moves on
             constexpr int SET = decltype(setc)::value;
             // B given as [k][n] with a second source: the tile's columns come from one of them (b_split is a multiple of BN)
@@ -698,11 +712,12 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
             zrel[SET] = kz - k0;
             if constexpr (FUSED) {
                 const bool a_second = A_KC && g.A2 && k0 >= g.a_split;        // (a_split is a multiple of BK: a k-tile has one source)
-                sa.load(a_second ? g.A2 : g.A, a_second ? g.lda2 : g.lda, a_second ? k0 - g.a_split : k0, wave, ra[SET], a_second);
-                sb.load(b_second ? g.B2 : g.B, b_second ? g.ldb2 : g.ldb, k0, wave, rb[SET], false, (!B_KC && !b_second) ? g.b_krows : nullptr);
+                sa.load(a_second ? g.A2 : g.A, a_second ? g.lda2 : g.lda, a_second ? k0 - g.a_split : k0, wave, ra[SET], a_second,
+                        !A_KC && g.a_krows != nullptr, ka);
+                sb.load(b_second ? g.B2 : g.B, b_second ? g.ldb2 : g.ldb, k0, wave, rb[SET], false, !B_KC && !b_second && g.b_krows != nullptr, kb);
             } else {
-                sa.load(g.A, g.lda, k0, wave, ra[SET]);
-                sb.load(g.B, g.ldb, k0, wave, rb[SET]);
+                sa.load(g.A, g.lda, k0, wave, ra[SET], false, false, ka);
+                sb.load(g.B, g.ldb, k0, wave, rb[SET], false, false, kb);
             }
             ws_next<BN>(g, cur, w_scan);
         };
@@ -726,13 +741,15 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
             EGP_TRW(1, 34);
             ws_store<BN, SB::ROW_STEP>(vb, pb, B_EL, pb_panel, pb_row);
         };
-        issue(S0); issue(S1); issue(S2); issue(S3);      // k-tiles 0..3 in flight
+        prefetch(); issue(S0); prefetch(); issue(S1); prefetch(); issue(S2); prefetch(); issue(S3);      // k-tiles 0..3 in flight
+        prefetch();
         stage(S0, 0);
         issue(S0);                                       // k-tile 4
         __syncthreads();
         auto iteration = [&](auto setc, int p) __attribute__((always_inline)) {
             EGP_TRW(1, 30);
             if (p + 1 < P) {
+                prefetch();
 #if !defined(EGP_WS_SKIP) || EGP_WS_SKIP != 2
                 stage(setc, (p + 1) & 1);
 #endif
@@ -1031,10 +1048,12 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     g.a_rows = (const long long *)d->a_rows; g.A2 = d->A2; g.lda2 = d->lda2; g.a_split = d->a_split;
     g.b_krows = (const long long *)d->b_krows; g.B2 = d->B2; g.ldb2 = d->ldb2; g.b_split = d->b_split;
     g.c_rows = (const long long *)d->c_rows;
-    const bool fused_io = d->a_rows || d->A2 || d->b_krows || d->B2 || d->c_rows;
+    g.a_krows = (const long long *)d->a_krows;
+    const bool fused_io = d->a_rows || d->A2 || d->b_krows || d->B2 || d->c_rows || d->a_krows;
     if (fused_io) {
         EGP_REQUIRE(!(d->a_rows || d->A2) || d->a_kcontig, "a_rows / A2 go with a k-contiguous A");
         EGP_REQUIRE(!(d->b_krows || d->B2) || !d->b_kcontig, "b_krows / B2 go with B given as [k][n]");
+        EGP_REQUIRE(!d->a_krows || !d->a_kcontig, "a_krows goes with A given as [k][m]");
         EGP_REQUIRE(!d->A2 || (d->a_split > 0 && d->a_split % BK == 0 && d->K - d->a_split >= BK),
                     "a_split must be a multiple of 32 and leave at least 32 columns to A2 (a k-tile reads one source)");
         EGP_REQUIRE(!d->A2 || splits == 1, "A2 does not go with split-K");

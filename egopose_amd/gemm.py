@@ -70,12 +70,13 @@ def _index(t, name):
 
 
 def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, relu=False, mask=None, terms=None, splits=1, want_bias_grad=False,
-         out=None, bias_grad_out=None, accumulate=False, a_rows=None, a2=None, b_krows=None, b2=None, c_rows=None):
+         out=None, bias_grad_out=None, accumulate=False, a_rows=None, a2=None, b_krows=None, b2=None, c_rows=None, a_krows=None):
     """C = A B with the operand forms of include/egopose_hip.h (`egp_gemm_desc`). A: (M, K) if a_kcontig else (K, M);
     B: (N, K) if b_kcontig else (K, N). Returns C, or (C, bias_grad) with want_bias_grad.
     Fused gather / scatter (three-piece products only): `a_rows` (int64, M entries) -- operand row m is A[a_rows[m]], and with
     `a2` (M, K2) its columns continue with a2[m] (K = A.shape[1] + K2); `b_krows` / `b2` the same for B given as (K, N) along
-    k and n; `c_rows` -- result row m goes to out[c_rows[m]] (`out` required, rows nobody writes keep their content)."""
+    k and n; `c_rows` -- result row m goes to out[c_rows[m]] (`out` required, rows nobody writes keep their content);
+    `a_krows` -- A given as (K, M): k-row k is A[a_krows[k]] (with `b_krows`: a weight gradient over a subset of the rows)."""
     A, B = _mat(A, "A"), _mat(B, "B")
     M, K = (A.shape if a_kcontig else A.shape[::-1])
     N, Kb = (B.shape if b_kcontig else B.shape[::-1])
@@ -90,6 +91,10 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, relu=False, mask=None,
             if a2.shape[0] != M:
                 raise ValueError("a2 has %d rows, the operand %d" % (a2.shape[0], M))
             a_split, K = K, K + a2.shape[1]
+    if a_krows is not None:
+        if a_kcontig:
+            raise ValueError("a_krows goes with A given as (K, M)")
+        K = _index(a_krows, "a_krows").shape[0]
     if b_krows is not None or b2 is not None:
         if b_kcontig:
             raise ValueError("b_krows / b2 go with B given as (K, N)")
@@ -121,6 +126,8 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, relu=False, mask=None,
         d.B2, d.ldb2, d.b_split = b2.data_ptr(), _ld(b2), b_split
     if c_rows is not None:
         d.c_rows = c_rows.data_ptr()
+    if a_krows is not None:
+        d.a_krows = a_krows.data_ptr()
     d.A, d.lda, d.a_kcontig = A.data_ptr(), _ld(A), 1 if a_kcontig else 0
     d.B, d.ldb, d.b_kcontig = B.data_ptr(), _ld(B), 1 if b_kcontig else 0
     d.C, d.ldc = out.data_ptr(), _ld(out)
@@ -248,6 +255,12 @@ def fused_gather_available(H, n_hidden, S):
     import os
     return enabled() and default_terms() == 6 and os.environ.get("EGP_GEMM_WS", "1") != "0" and H % 128 == 0 and n_hidden % 4 == 0 \
         and S >= 32 and os.environ.get("EGP_FUSED_GATHER", "1") != "0"
+
+
+def fused_rows_available():
+    """Row / k-row index operands (a_rows, c_rows, a_krows, b_krows) need three-piece products on the persistent kernel."""
+    import os
+    return enabled() and default_terms() == 6 and os.environ.get("EGP_GEMM_WS", "1") != "0"
 
 
 class GatherMlpHead(torch.autograd.Function):

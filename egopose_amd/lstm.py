@@ -13,6 +13,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -141,13 +142,27 @@ class LstmGroup(torch.autograd.Function):
         H = w_hh[0].shape[1]
         perm, inv = _gate_perm(H, x.device)
         x2 = x.reshape(T * B, D)
-        w_in = torch.cat([w.index_select(0, perm) for w in w_ih], 0)                       # (P*4H, D)
-        bias = torch.cat([(bi + bh).index_select(0, perm) for bi, bh in zip(b_ih, b_hh)], 0)
-        if G.enabled():
+        # problems that run forward in time first: their gate columns are one block (a ragged batch visits fewer rows for them)
+        pord = [p for p in range(P) if not (reverse_mask >> p) & 1] + [p for p in range(P) if (reverse_mask >> p) & 1]
+        nf = sum(1 for p in range(P) if not (reverse_mask >> p) & 1)
+        kmask = sum(1 << q for q in range(nf, P))                                           # reverse bits in kernel order
+        w_in = torch.cat([w_ih[p].index_select(0, perm) for p in pord], 0)                  # (P*4H, D)
+        bias = torch.cat([(b_ih[p] + b_hh[p]).index_select(0, perm) for p in pord], 0)
+        rows = None
+        if ragged is not None and ragged.rows is not None and 0 < nf and G.enabled() and G.fused_rows_available() \
+                and ragged.T == T and ragged.rows.shape[0] >= 4096 and os.environ.get("EGP_LSTM_ROWS", "1") != "0":
+            rows = ragged.rows
+        if rows is not None:
+            gx = torch.empty(T * B, P * 4 * H, dtype=x.dtype, device=x.device)
+            nfc = nf * 4 * H
+            G.gemm(x2, w_in[:nfc], True, True, bias=bias[:nfc], a_rows=rows, c_rows=rows, out=gx[:, :nfc])
+            if nf < P:
+                G.gemm(x2, w_in[nfc:], True, True, bias=bias[nfc:], out=gx[:, nfc:])
+        elif G.enabled():
             gx = G.linear_fwd(x2, w_in, bias)                                               # (T*B, P*4H)
         else:
             gx = torch.addmm(bias, x2, w_in.t())
-        w_hh_all = torch.stack([w.contiguous() for w in w_hh], 0)
+        w_hh_all = torch.stack([w_hh[p].contiguous() for p in pord], 0)
         # per output T + 2 time slots, zero | h_0 .. h_{T-1} | zero: h_prev is the same buffer shifted by one slot
         # (down for a forward sweep, up for a reversed one)
         n_out, W = P // width, width * H
@@ -156,15 +171,15 @@ class LstmGroup(torch.autograd.Function):
         h_buf[:, T + 1].zero_()
         cells = torch.empty(P, T, B, H, dtype=x.dtype, device=x.device) if train else None
         base, esz = h_buf.data_ptr(), h_buf.element_size()
-        ptrs = (C.c_void_p * P)(*[base + esz * (((p // width) * (T + 2) + 1) * B * W + (p % width) * H) for p in range(P)])
-        order, steps = ragged if ragged is not None else (None, None)
-        L.check(lib.egp_lstm_group_fwd_len_f32(_p(gx), _p(w_hh_all), T, B, H, P, reverse_mask, ptrs, W,
+        ptrs = (C.c_void_p * P)(*[base + esz * (((p // width) * (T + 2) + 1) * B * W + (p % width) * H) for p in pord])
+        order, steps = (ragged.order, ragged.steps) if ragged is not None else (None, None)
+        L.check(lib.egp_lstm_group_fwd_len_f32(_p(gx), _p(w_hh_all), T, B, H, P, kmask, ptrs, W,
                                                _p(gx if train else None), _p(cells), _p(order), _p(steps), _s()), "egp_lstm_group_fwd_len_f32")
         outs = tuple(h_buf[i, 1:T + 1] for i in range(n_out))
         if train:
             ctx.save_for_backward(x2, w_in, w_hh_all, h_buf, gx, cells)
             ctx.meta = (T, B, D, H, P, width, reverse_mask)
-            ctx.ragged = ragged
+            ctx.ragged, ctx.rows, ctx.pord, ctx.nf, ctx.kmask = ragged, rows, pord, nf, kmask
         return outs
 
     @staticmethod
@@ -175,32 +190,43 @@ class LstmGroup(torch.autograd.Function):
         W = width * H
         perm, inv = _gate_perm(H, x2.device)
         douts = [d.contiguous() if d is not None else h_buf.new_zeros(T, B, W) for d in douts]
+        ragged, rows, pord, nf, kmask = ctx.ragged, ctx.rows, ctx.pord, ctx.nf, ctx.kmask
         esz = h_buf.element_size()
-        ptrs = (C.c_void_p * P)(*[douts[p // width].data_ptr() + esz * (p % width) * H for p in range(P)])
+        ptrs = (C.c_void_p * P)(*[douts[p // width].data_ptr() + esz * (p % width) * H for p in pord])
         dpre = torch.empty(T * B, P * 4 * H, dtype=x2.dtype, device=x2.device)
         db = torch.zeros(P, 4 * H, dtype=x2.dtype, device=x2.device)
-        order, steps = ctx.ragged if ctx.ragged is not None else (None, None)
-        L.check(lib.egp_lstm_group_bwd_len_f32(ptrs, W, _p(gates), _p(cells), _p(w_hh_all), T, B, H, P, reverse_mask, _p(dpre), _p(db),
+        order, steps = (ragged.order, ragged.steps) if ragged is not None else (None, None)
+        L.check(lib.egp_lstm_group_bwd_len_f32(ptrs, W, _p(gates), _p(cells), _p(w_hh_all), T, B, H, P, kmask, _p(dpre), _p(db),
                                                _p(order), _p(steps), _s()), "egp_lstm_group_bwd_len_f32")
         d3 = dpre.view(T, B, P * 4 * H)
         use_g = G.enabled()
-        if use_g:      # one split-K product for the P stacked W_ih gradients
+        nfc = nf * 4 * H
+        if rows is not None:      # forward-running problems: the rows their workgroups stepped through; the others: every row
+            n_rows = rows.shape[0]
+            parts = [G.gemm(dpre[:, :nfc], x2, False, False, splits=G.pick_splits(nfc, D, n_rows), a_krows=rows, b_krows=rows)]
+            if nf < P:
+                parts.append(G.linear_wgrad(dpre[:, nfc:], x2, want_bias=False))
+            dw_ih_all = torch.cat(parts, 0)
+        elif use_g:      # one split-K product for the P stacked W_ih gradients
             dw_ih_all = G.linear_wgrad(dpre, x2, want_bias=False)                          # (P*4H, D), kernel gate order
         else:
             dw_ih_all = torch.bmm(d3.transpose(1, 2), x2.view(T, B, D)).sum(0)
-        grads = []
-        for p in range(P):
-            rev = (reverse_mask >> p) & 1
+        grads = [None] * (4 * P)
+        for q, p in enumerate(pord):          # q: the problem's place in the kernels' order, p: in the caller's
+            rev = (kmask >> q) & 1
             slab = h_buf[p // width, 2:] if rev else h_buf[p // width, :T]
             h_prev = slab[:, :, (p % width) * H:(p % width + 1) * H]
-            if use_g:  # strided views: problem p's columns of d_pre against its half of the shifted hidden buffer
-                dw_hh = G.linear_wgrad(dpre[:, p * 4 * H:(p + 1) * 4 * H], slab.reshape(T * B, W)[:, (p % width) * H:(p % width + 1) * H],
-                                       want_bias=False).index_select(0, inv)
+            if use_g:  # strided views: problem q's columns of d_pre against its half of the shifted hidden buffer
+                dq, hq = dpre[:, q * 4 * H:(q + 1) * 4 * H], slab.reshape(T * B, W)[:, (p % width) * H:(p % width + 1) * H]
+                if rows is not None and not rev:
+                    dw_hh = G.gemm(dq, hq, False, False, splits=G.pick_splits(4 * H, H, rows.shape[0]), a_krows=rows, b_krows=rows).index_select(0, inv)
+                else:
+                    dw_hh = G.linear_wgrad(dq, hq, want_bias=False).index_select(0, inv)
             else:
-                dw_hh = torch.bmm(d3[:, :, p * 4 * H:(p + 1) * 4 * H].transpose(1, 2), h_prev).sum(0).index_select(0, inv)
-            dw_ih = dw_ih_all[p * 4 * H:(p + 1) * 4 * H].index_select(0, inv)
-            d_b = db[p].index_select(0, inv)
-            grads += [dw_ih, dw_hh, d_b, d_b]
+                dw_hh = torch.bmm(d3[:, :, q * 4 * H:(q + 1) * 4 * H].transpose(1, 2), h_prev).sum(0).index_select(0, inv)
+            dw_ih = dw_ih_all[q * 4 * H:(q + 1) * 4 * H].index_select(0, inv)
+            d_b = db[q].index_select(0, inv)
+            grads[4 * p:4 * p + 4] = [dw_ih, dw_hh, d_b, d_b]
         d_x = dpre.mm(w_in).view(T, B, D) if ctx.needs_input_grad[0] else None
         return (d_x, None, None, None, None, None, *grads)
 
@@ -219,12 +245,34 @@ def group_available(x, cells):
     return all(available(x, c) and c.hidden_size == c0.hidden_size and c.input_size == c0.input_size for c in cells)
 
 
-def ragged_order(seq_steps, device):
-    """(order, steps) for LstmGroup from the time steps each sequence needs (B entries, in layout order): positions sorted by
-    decreasing length, so that the four sequences of a workgroup are alike."""
-    st = torch.as_tensor(seq_steps, dtype=torch.int32).reshape(-1)
-    order = torch.argsort(st, descending=True, stable=True).to(torch.int32)
-    return order.to(device).contiguous(), st[order.long()].to(device).contiguous()
+class Ragged:
+    """What the grouped sweeps need to know about a ragged batch (ragged_order)."""
+
+    def __init__(self, order, steps, rows, n_seq, T):
+        self.order, self.steps, self.rows, self.n_seq, self.T = order, steps, rows, n_seq, T
+
+
+def ragged_order(seq_steps, device, T=None):
+    """Ragged (order, steps[, rows]) for LstmGroup from the time steps each sequence needs (B entries, in layout order):
+    positions sorted by decreasing length, so that the sequences of a workgroup are alike. With the window length `T`
+    also `rows`: the (t, b) rows -- flattened t * B + b, ascending -- that forward-running workgroups step through
+    (a workgroup of up to 8 positions runs to its longest sequence); the input projection and the weight gradients of the
+    forward-running problems visit only these."""
+    st = np.asarray(torch.as_tensor(seq_steps).cpu().numpy(), dtype=np.int64).reshape(-1)
+    B = st.shape[0]
+    order = np.argsort(-st, kind="stable")
+    st_sorted = st[order]
+    rows = None
+    if T is not None and B > 0:
+        wg = np.maximum.reduceat(st_sorted, np.arange(0, B, 8))              # positions are sorted: the first of each group of 8
+        t_wg = np.minimum(np.repeat(wg, 8)[:B], int(T))                      # steps the workgroup of position p runs
+        n = int(t_wg.sum())
+        if n < 0.9 * T * B:                                                  # otherwise not worth the indirection
+            seq = np.repeat(order, t_wg)
+            tt = np.arange(n) - np.repeat(np.cumsum(t_wg) - t_wg, t_wg)
+            rows = torch.as_tensor(np.sort(tt * B + seq), dtype=torch.int64, device=device)
+    return Ragged(torch.as_tensor(order, dtype=torch.int32, device=device), torch.as_tensor(st_sorted, dtype=torch.int32, device=device),
+                  rows, B, T)
 
 
 def lstm_group(x, cells, reverses, pairs=False, ragged=None):
@@ -233,7 +281,7 @@ def lstm_group(x, cells, reverses, pairs=False, ragged=None):
     outputs of a forward-running problem beyond a sequence's own steps are not computed (zeros) and carry no gradient."""
     mask = sum(1 << i for i, r in enumerate(reverses) if r)
     params = [t for c in cells for t in (c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh)]
-    if ragged is not None and (ragged[0].shape[0] != x.shape[1] or os.environ.get("EGP_LSTM_RAGGED", "1") == "0"):
+    if ragged is not None and (ragged.n_seq != x.shape[1] or os.environ.get("EGP_LSTM_RAGGED", "1") == "0"):
         ragged = None
     return list(LstmGroup.apply(x.contiguous(), mask, len(cells), 2 if pairs else 1, _wants_grad(x, params), ragged, *params))
 

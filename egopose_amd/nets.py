@@ -396,7 +396,7 @@ class VideoStateNet(nn.Module):
         # reference. Windows added to fill an episode bucket need no step at all.
         steps = np.zeros(self.cnn_feat_ctx.shape[1], np.int64)
         steps[:len(lens)] = lens + m
-        self._ragged = _hip_lstm.ragged_order(steps, device) if self.cnn_feat_ctx.is_cuda else None
+        self._ragged = _hip_lstm.ragged_order(steps, device, T=self.cnn_feat_ctx.shape[0]) if self.cnn_feat_ctx.is_cuda else None
         # Length buckets for the forward direction: its output at frame t only depends on frames <= t and only frames
         # [m, m + len_e) of an episode are ever gathered, so episodes sorted by length let the forward LSTM stop early
         # (the backward direction starts at the end of the padded window and must run it all, as in the reference).

@@ -278,10 +278,12 @@ typedef struct egp_gemm_desc {
      *       A2[m][k - a_split] for k >= a_split (a_split a multiple of 32, K - a_split >= 32, no split-K; A2 = NULL: every k from A).
      *   b_krows / B2 / b_split (B given as [k][n]): element (k, n) is B[b_krows[k]][n] for n < b_split and
      *       B2[k][n - b_split] for n >= b_split (b_split a multiple of 128; B2 = NULL: every n from B).
-     *   c_rows: result row m goes to row c_rows[m] of C (rows must not repeat; rows nobody writes keep their content). */
+     *   c_rows: result row m goes to row c_rows[m] of C (rows must not repeat; rows nobody writes keep their content).
+     *   a_krows (A given as [k][m]): k-row k of the operand is A[a_krows[k]] (a weight gradient over a subset of the rows). */
     const int64_t *a_rows; const float *A2; int64_t lda2; int32_t a_split; int64_t a_src_rows;
     const int64_t *b_krows; const float *B2; int64_t ldb2; int32_t b_split; int64_t b_src_rows;
     const int64_t *c_rows;
+    const int64_t *a_krows;
 } egp_gemm_desc;
 /* The update's policy / value input in one pass (VideoStateNet.forward('train'), models/video_state_net.py:65-69):
  * out[i] = [ ctx[idx[i]][0:H] | x[i][0:S] ] for i < n, and the adjoint for the context rows, dctx[idx[i]][0:H] = dout[i][0:H]

@@ -365,8 +365,9 @@ def test_bf16_encoder_keeps_float32_master_weights():
         assert torch.equal(s, m.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("T,B", [(40, 37), (220, 70), (9, 4)])
-def test_ragged_grouped_sweeps_match_the_full_ones_where_it_counts(T, B):
+@pytest.mark.parametrize("with_rows", [False, True])
+@pytest.mark.parametrize("T,B", [(40, 37), (220, 70), (9, 4), (150, 200)])
+def test_ragged_grouped_sweeps_match_the_full_ones_where_it_counts(T, B, with_rows):
     """lstm.ragged_order / egp_lstm_group_*_len_f32: with per-sequence step counts the forward-running direction stops
     early. Outputs inside every sequence's own steps (both directions) and ALL parameter gradients must equal the full
     sweeps' when the loss only looks at those outputs -- which is how the update uses the video context (rows beyond an
@@ -383,7 +384,11 @@ def test_ragged_grouped_sweeps_match_the_full_ones_where_it_counts(T, B):
     dy = torch.randn(T, B, 128, device="cuda") * mask       # no gradient into rows nobody reads
     x = torch.randn(T, B, 128, device="cuda")
     res = []
-    for ragged in (None, lstm_mod.ragged_order(steps, torch.device("cuda"))):
+    # with_rows: the window length is known, so the input projection and the weight gradients of the forward-running
+    # direction visit only the (t, b) rows its workgroups step through (row-index operands of egp_gemm_f32)
+    rg = lstm_mod.ragged_order(steps, torch.device("cuda"), T=T if with_rows else None)
+    assert (rg.rows is not None) == (with_rows and T * B > 1000)
+    for ragged in (None, rg):
         torch.manual_seed(3)
         rnn = RNN(128, 128, "lstm", bi_dir=True).cuda()
         rnn.ragged = ragged
@@ -392,12 +397,14 @@ def test_ragged_grouped_sweeps_match_the_full_ones_where_it_counts(T, B):
         res.append((out.detach(), {k: p.grad.clone() for k, p in rnn.named_parameters()}))
     (full, gfull), (rag, grag) = res
     H = 64
-    np.testing.assert_array_equal((rag * mask).cpu().numpy(), (full * mask).cpu().numpy())
+    # (not bit for bit: which steps fall into the kernel's unrolled main loop and which into its remainder loop depends on
+    #  the step count, and the compiler contracts the cell update differently in the two copies -- one ulp)
+    np.testing.assert_allclose((rag * mask).cpu().numpy(), (full * mask).cpu().numpy(), rtol=0, atol=1e-6)
     # beyond its own steps a sequence still rides along to the longest of its workgroup: the full sweep's value, then zeros
     fwd_r, fwd_f = rag[:, :, :H], full[:, :, :H]
-    assert bool(((fwd_r == fwd_f) | (fwd_r == 0)).all())
+    assert bool((((fwd_r - fwd_f).abs() <= 1e-6) | (fwd_r == 0)).all())
     np.testing.assert_array_equal(rag[:, :, H:].cpu().numpy(), full[:, :, H:].cpu().numpy())        # the reversed direction runs it all
     for k in gfull:
         a, b = grag[k].cpu().numpy(), gfull[k].cpu().numpy()
         scale = max(1.0, np.abs(b).max())
-        np.testing.assert_allclose(a / scale, b / scale, rtol=0, atol=2e-6, err_msg=k)      # (split-K sums see zeros instead of tiny products)
+        np.testing.assert_allclose(a / scale, b / scale, rtol=0, atol=5e-6, err_msg=k)      # (other split-K partitions, zeros instead of tiny products)
