@@ -619,9 +619,6 @@ __device__ __forceinline__ void ws_zero_head(float (&v)[R / 8], int zrel, int pa
         for (int j = 0; j < 8; ++j) v[8 * u + j] = 8 * panel + j >= zrel ? v[8 * u + j] : 0.f;
 }
 
-#ifndef WS_CONSUMER_PRIO
-#define WS_CONSUMER_PRIO 0
-#endif
 template <int BN, bool A_KC, bool B_KC, bool FUSED>      // FUSED: the gather / scatter operands of egp_gemm_desc (a_rows ... c_rows) are compiled in
 __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
     constexpr int NIMG = 3, NSET = 4;
@@ -769,7 +766,7 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
     }
 
     // ---- consumers
-    if (WS_CONSUMER_PRIO) __builtin_amdgcn_s_setprio(WS_CONSUMER_PRIO);      // (the matrix pipe's wave goes first when both want to issue)
+    // (s_setprio 3 for these waves -- the matrix pipe's wave first when both want to issue -- was measured: no effect)
     const int wm = wave / WN, wn = wave % WN;
     const int frow = lane & 31, fkh = lane >> 5;
     f32x16 acc[MI][NJ];
