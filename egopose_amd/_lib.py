@@ -77,6 +77,24 @@ class GemmDesc(C.Structure):
                 ("c_rows", vp), ("a_krows", vp)]
 
 
+class RolloutTick(C.Structure):
+    """egp_rollout_tick (include/egopose_hip.h): field order and types must match the header."""
+    _fields_ = [("ctx", vp), ("eng", vp), ("stream", vp),
+                ("n_env", C.c_int32), ("nmax", C.c_int32), ("obs_dim", C.c_int32), ("nu", C.c_int32), ("nq", C.c_int32), ("nv", C.c_int32),
+                ("ctx_dim", C.c_int32), ("ctx_T", C.c_int32), ("episode_len", C.c_int32), ("reward_job", C.c_int32),
+                ("flags_upload", C.c_int32), ("has_fix_head_lb", C.c_int32),
+                ("end_reward", C.c_double), ("zf_clip", C.c_double), ("fix_head_lb", C.c_double),
+                ("cur_t", vp), ("frame_base", vp), ("e_ind", vp), ("s_ind", vp), ("steps_done", vp),
+                ("active", vp), ("active_i32", vp), ("head_z", vp), ("head_lb", vp),
+                ("rec_valid", vp), ("rec_done", vp), ("rec_e_ind", vp), ("rec_s_ind", vp),
+                ("states", vp), ("next_states", vp), ("actions", vp), ("rewards", vp), ("cinfo", vp),
+                ("noise", vp), ("v_out", vp), ("v_stride", C.c_int64),
+                ("layers", vp), ("n_layers", C.c_int32), ("activation", C.c_int32), ("log_std", vp),
+                ("slab_host", vp), ("slab_dev", vp),
+                ("qpos", vp), ("qvel", vp), ("prev_qpos", vp), ("ee", vp),
+                ("zf_workspace", vp)]
+
+
 class EngineDesc(C.Structure):
     _fields_ = [("n_env", C.c_int32), ("n_threads", C.c_int32), ("n_groups", C.c_int32), ("device_dynamics", C.c_int32)]
 
@@ -136,6 +154,8 @@ SIGNATURES = {
     "egp_lstm_bwd_f32": (C.c_int, [vp, vp, vp, vp, _i32, _i32, _i32, _i32, vp, vp]),
     "egp_lstm_group_fwd_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_void_p), _i32, vp, vp, vp]),
     "egp_lstm_group_bwd_f32": (C.c_int, [C.POINTER(C.c_void_p), _i32, vp, vp, vp, _i32, _i32, _i32, _i32, _i32, vp, vp, vp]),
+    "egp_rollout_tick_pre": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp]),
+    "egp_rollout_tick_post": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp]),
     "egp_lstm_group_fwd_len_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_void_p), _i32, vp, vp, vp, vp, vp]),
     "egp_lstm_group_bwd_len_f32": (C.c_int, [C.POINTER(C.c_void_p), _i32, vp, vp, vp, _i32, _i32, _i32, _i32, _i32, vp, vp, vp, vp, vp]),
     "egp_upload_async": (C.c_int, [vp, vp, C.c_int64, vp]),

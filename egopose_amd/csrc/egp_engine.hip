@@ -1109,6 +1109,84 @@ int egp_engine_wait(egp_engine *E, int32_t group, void *stream) {
     return EGP_OK;
 }
 
+int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, void *ready_event) {
+    EGP_REQUIRE(d && d->ctx && d->eng && ready_event, "NULL pointer");
+    EGP_REQUIRE(0 <= a && a < b && b <= d->n_env && b - a <= d->nmax && k >= 0, "slot range / tick out of range");
+    const int n = b - a, nmax = d->nmax, N = d->n_env;
+    const size_t soff = (size_t)(group * 2 + (k & 1)) * 24 * nmax;
+    int32_t *fl = reinterpret_cast<int32_t *>(d->slab_host + soff);
+    int64_t *ti = reinterpret_cast<int64_t *>(d->slab_host + soff + 16 * (size_t)nmax);
+    // flags of the state this env-step will produce (they do not depend on its outcome) + context rows of this tick
+    for (int i = 0; i < n; ++i) {
+        const int e = a + i;
+        const int act = d->active[e] ? 1 : 0;
+        const int64_t t_next = d->cur_t[e] + act;
+        fl[i] = (int32_t)t_next;
+        fl[nmax + i] = (int32_t)(d->frame_base[e] + t_next);
+        fl[2 * nmax + i] = (t_next >= d->episode_len) && act;
+        fl[3 * nmax + i] = act;
+        ti[i] = d->cur_t[e] < d->ctx_T - 1 ? d->cur_t[e] : d->ctx_T - 1;
+    }
+    uint8_t *fbase = d->slab_dev + soff;
+    int rc = EGP_OK;
+    if (d->flags_upload && (rc = egp_upload_async(fbase, d->slab_host + soff, 24 * (int64_t)nmax, d->stream)) != EGP_OK) return rc;
+    const size_t row = (size_t)k * N + a;
+    rc = egp_policy_gaussian_f32(d->v_out + (size_t)a * d->v_stride, d->v_stride, d->ctx_dim, reinterpret_cast<const int64_t *>(fbase + 16 * (size_t)nmax),
+                                 d->states + row * d->obs_dim, d->obs_dim, n, d->layers, d->n_layers, d->activation, d->log_std,
+                                 d->noise ? d->noise + row * d->nu : nullptr, d->actions + row * d->nu, nullptr, d->stream);
+    if (rc != EGP_OK) return rc;
+    EGP_HIP_CHECK(hipEventRecord((hipEvent_t)ready_event, (hipStream_t)d->stream));
+    if (d->reward_job) {      // K2 rides behind this env-step's kernel on the engine's stream
+        const int32_t *f32 = reinterpret_cast<const int32_t *>(fbase);
+        rc = egp_engine_set_reward_job(d->eng, group, f32, f32 + nmax, f32 + 2 * nmax, f32 + 3 * nmax, d->end_reward, d->rewards + row,
+                                       d->cinfo + row * 5);
+        if (rc != EGP_OK) return rc;
+    }
+    for (int e = 0; e < N; ++e) d->active_i32[e] = d->active[e] ? 1 : 0;
+    return egp_engine_step_async(d->eng, group, d->actions + (size_t)k * N * d->nu, d->active_i32, ready_event);
+}
+
+int egp_rollout_tick_post(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, const double *zf_cur, double *zf_new,
+                          int32_t *n_done, double *wait_s) {
+    EGP_REQUIRE(d && d->ctx && d->eng && n_done, "NULL pointer");
+    EGP_REQUIRE(0 <= a && a < b && b <= d->n_env && b - a <= d->nmax && k >= 0, "slot range / tick out of range");
+    const auto t0 = clk::now();
+    int rc = egp_engine_wait(d->eng, group, d->stream);
+    if (wait_s) *wait_s = secs(t0, clk::now());
+    if (rc != EGP_OK) return rc;
+    const int n = b - a, nmax = d->nmax, N = d->n_env;
+    const size_t soff = (size_t)(group * 2 + (k & 1)) * 24 * nmax;
+    const int32_t *f32 = reinterpret_cast<const int32_t *>(d->slab_dev + soff);          // the flags `pre` staged for this env-step
+    const size_t row = (size_t)k * N + a;
+    // the filter -> policy chain of the next tick starts here: K3 + K6 (-> next_states[k] and states[k + 1]) and K2 before the bookkeeping
+    rc = egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, f32 + 3 * nmax, n, zf_cur, zf_new, d->zf_clip,
+                             d->next_states + row * d->obs_dim, d->states + (row + N) * d->obs_dim, 0, d->zf_workspace, d->stream);
+    if (rc != EGP_OK) return rc;
+    if (!d->reward_job) {
+        rc = egp_reward_quat_v3_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->prev_qpos + (size_t)a * d->nq, d->ee + (size_t)a * 15, f32, f32 + nmax,
+                                    f32 + 2 * nmax, f32 + 3 * nmax, d->end_reward, n, d->rewards + row, d->cinfo + row * 5, d->stream);
+        if (rc != EGP_OK) return rc;
+    }
+    int nd = 0;
+    for (int i = 0; i < n; ++i) {
+        const int e = a + i;
+        const int act = d->active[e] ? 1 : 0;
+        d->cur_t[e] += act;
+        const bool fail = d->has_fix_head_lb ? d->head_z[e] < d->fix_head_lb : d->head_z[e] < d->head_lb[d->e_ind[e]] - 0.1;
+        const bool end = d->cur_t[e] >= d->episode_len;
+        const bool done = (fail || end) && act;
+        const size_t r = (size_t)k * N + e;
+        d->rec_valid[r] = (uint8_t)act;
+        d->rec_done[r] = (uint8_t)done;
+        d->rec_e_ind[r] = d->e_ind[e];
+        d->rec_s_ind[r] = d->s_ind[e];
+        d->steps_done[e] += act;
+        nd += done;
+    }
+    *n_done = nd;
+    return EGP_OK;
+}
+
 double egp_engine_event_overhead_ms(egp_engine *E) {
     double a = 0.0;
     if (E && !E->groups.empty()) { for (auto &G : E->groups) a += G.ev_overhead_ms; a /= E->groups.size(); }

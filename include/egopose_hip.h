@@ -481,6 +481,38 @@ int egp_engine_layout(egp_engine *e, int32_t *pack_ld, int32_t *n_env, int32_t *
 int egp_engine_group_range(egp_engine *e, int32_t group, int32_t *env_begin, int32_t *env_end);
 /* K1 launches a group issues per substep: 1, or the number of chunks when the group runs pipelined
  * (>= 3 threads, >= 16 envs, polled zero-copy mode; EGP_CHUNKS, default 2) */
+/* ----------------------------------------------------------------------------------------
+ * One tick of the lockstep sampler (Agent.sample_worker's loop body, core/agent.py:31-66, for every slot of an env group
+ * at once) on the native side: the per-slot bookkeeping and the calls the rollout driver otherwise makes one by one from
+ * Python (flags of the coming env-step, their upload, the fused policy step, the reward job, the env-step; then the wait,
+ * K3 + K6, K2 and the termination flags of HumanoidEnv.step, ego_pose/envs/humanoid_v1.py:182-199). The driver fills the
+ * descriptor once per rollout; the arrays are its own (NumPy / device tensors) and stay valid for the rollout.
+ *   pre : flags / context rows of tick k for slots [a, b) -> policy -> env-step (asynchronous)
+ *   post: wait for the env-step, observation + filter into states[k + 1] / next_states[k], reward, cur_t / done / record rows;
+ *         *n_done = slots whose episode ended, *wait_s = seconds blocked on the env-step */
+typedef struct egp_rollout_tick {
+    egp_ctx *ctx; egp_engine *eng; void *stream;
+    int32_t n_env, nmax, obs_dim, nu, nq, nv, ctx_dim, ctx_T, episode_len, reward_job, flags_upload, has_fix_head_lb;
+    double end_reward, zf_clip, fix_head_lb;
+    /* host state of the env slots */
+    int64_t *cur_t, *frame_base, *e_ind, *s_ind, *steps_done;
+    uint8_t *active; int32_t *active_i32;
+    const double *head_z, *head_lb;
+    /* host record of the rollout, [T_max][n_env] */
+    uint8_t *rec_valid, *rec_done; int64_t *rec_e_ind, *rec_s_ind;
+    /* device record, [T_max (+ 1)][n_env][...] */
+    double *states, *next_states, *actions, *rewards, *cinfo;
+    const float *noise;                          /* [T_max][n_env][nu], NULL: mean action */
+    const float *v_out; int64_t v_stride;        /* per-slot context rows of the video net */
+    const egp_mlp_layer *layers; int32_t n_layers, activation; const float *log_std;
+    uint8_t *slab_host, *slab_dev;               /* [n_groups][2][24 * nmax] flags + context-row slabs (pinned / device) */
+    const double *qpos, *qvel, *prev_qpos, *ee;  /* the engine's device state */
+    void *zf_workspace;
+} egp_rollout_tick;
+int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, void *ready_event);
+int egp_rollout_tick_post(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, const double *zf_cur, double *zf_new,
+                          int32_t *n_done, double *wait_s);
+
 /* Resident-K1 mode only: hand the NEXT egp_engine_step_async of `group` its reward launch. The flag arrays (device
  * memory, group-local: t / frame / end / active of the state the step will produce) must be ready by the step's
  * ready_event; the engine launches egp_reward_quat_v3_f64 on the group's stream right behind the env-step's kernel (inputs:

@@ -338,9 +338,12 @@ def test_fast_tick_path_is_bit_identical_to_the_torch_path(workspace, monkeypatc
     in-batch reset on the caller's stream would overtake it unless egp_engine_reset is ordered behind it: terminal
     rewards (incl. the end bonus) must still equal the torch tick's."""
     outs = []
-    for fast in ("0", "1"):
-        monkeypatch.setenv("EGP_FAST_TICK", fast)
-        monkeypatch.setenv("EGP_REWARD_JOB_DELAY_US", reward_delay_us if fast == "1" else "0")
+    # "1": the tick's bookkeeping and launches in two native calls (egp_rollout_tick_pre / _post, the default);
+    # "py": the same from Python, one ctypes call per kernel (EGP_TICK_NATIVE=0); "0": the torch-tensor tick
+    for fast in ("0", "1", "py"):
+        monkeypatch.setenv("EGP_FAST_TICK", "0" if fast == "0" else "1")
+        monkeypatch.setenv("EGP_TICK_NATIVE", "0" if fast == "py" else "1")
+        monkeypatch.setenv("EGP_REWARD_JOB_DELAY_US", reward_delay_us if fast != "0" else "0")
         monkeypatch.setenv("EGP_POLICY_GRAPH", "0")          # eager noise draws in both runs (same generator stream)
         torch.manual_seed(123)
         np.random.seed(5)
@@ -355,10 +358,11 @@ def test_fast_tick_path_is_bit_identical_to_the_torch_path(workspace, monkeypatc
                          next_states=batch.next_states.copy(), v_metas=batch.v_metas.copy(), n=rs.n, mean=np.array(rs.mean).copy(),
                          std=np.array(rs.std).copy(), steps=log.num_steps, eps=log.num_episodes, r=log.avg_c_reward))
         tr.close()
-    a, b = outs
-    assert a["steps"] == b["steps"] and a["eps"] == b["eps"] and a["n"] == b["n"] and a["r"] == b["r"]
-    for k in ("states", "actions", "rewards", "masks", "next_states", "v_metas", "mean", "std"):
-        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    a = outs[0]
+    for b in outs[1:]:
+        assert a["steps"] == b["steps"] and a["eps"] == b["eps"] and a["n"] == b["n"] and a["r"] == b["r"]
+        for k in ("states", "actions", "rewards", "masks", "next_states", "v_metas", "mean", "std"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
 def _train_mode_policy_mean(tr, ro, batch):
