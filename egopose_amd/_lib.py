@@ -116,6 +116,7 @@ _i32, _i64, _f64 = C.c_int32, C.c_int64, C.c_double
 SIGNATURES = {
     "egp_last_error": (C.c_char_p, []),
     "egp_version": (C.c_char_p, []),
+    "egp_abi_sizeof": (C.c_int64, [C.c_char_p]),
     "egp_obs_dim": (_i32, [vp]),
     "egp_create": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(vp)]),
     "egp_destroy": (C.c_int, [vp]),

@@ -1173,6 +1173,15 @@ extern "C" {
 
 const char *egp_last_error(void) { return g_err; }
 const char *egp_version(void) { return "egopose_hip 0.2.0 (gfx950)"; }
+int64_t egp_abi_sizeof(const char *name) {
+    if (!name) return -1;
+#define EGP_ABI_SIZE(T) if (!strcmp(name, #T)) return (int64_t)sizeof(T);
+    EGP_ABI_SIZE(egp_model_desc) EGP_ABI_SIZE(egp_expert_table) EGP_ABI_SIZE(egp_gemm_desc)
+    EGP_ABI_SIZE(egp_dynamics_desc) EGP_ABI_SIZE(egp_mlp_layer) EGP_ABI_SIZE(egp_physics_vtable)
+    EGP_ABI_SIZE(egp_surrogate_desc) EGP_ABI_SIZE(egp_engine_desc) EGP_ABI_SIZE(egp_rollout_tick)
+#undef EGP_ABI_SIZE
+    return -1;
+}
 int32_t egp_obs_dim(const egp_ctx *ctx) { return ctx ? ctx->dm.obs_dim : -1; }
 
 int egp_create(const egp_model_desc *d, int device, egp_ctx **out) {

@@ -92,6 +92,9 @@ typedef struct egp_expert_table {
 
 const char *egp_last_error(void);
 const char *egp_version(void);
+/* sizeof() of the descriptor struct called `name` ("egp_gemm_desc", ...) as this library was built, or -1: lets a
+ * binding check its own mirror of the layout before the first call */
+int64_t egp_abi_sizeof(const char *name);
 
 int egp_create(const egp_model_desc *desc, int device, egp_ctx **out);
 int egp_destroy(egp_ctx *ctx);

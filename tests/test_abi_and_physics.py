@@ -27,6 +27,25 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.egp_version()
 
 
+def test_ctypes_mirrors_have_the_library_s_struct_sizes():
+    """every descriptor struct the Python side mirrors must have the size the library was compiled with -- a field
+    added on one side only would otherwise show up as garbage arguments, not as an error"""
+    from egopose_amd import _lib
+    L = _lib.load()
+    mirrors = {"egp_model_desc": _lib.ModelDesc, "egp_expert_table": _lib.ExpertTable,
+               "egp_gemm_desc": _lib.GemmDesc, "egp_dynamics_desc": _lib.DynamicsDesc,
+               "egp_mlp_layer": _lib.MlpLayer, "egp_physics_vtable": _lib.PhysicsVtable,
+               "egp_surrogate_desc": _lib.SurrogateDesc, "egp_engine_desc": _lib.EngineDesc,
+               "egp_rollout_tick": _lib.RolloutTick}
+    header = open(os.path.join(REPO, "include", "egopose_hip.h")).read()
+    declared = set(re.findall(r"^\} (egp_[a-z_]+);", header, flags=re.M))
+    assert declared == set(mirrors), "a struct in include/egopose_hip.h has no ctypes mirror (or the reverse)"
+    import ctypes
+    for name, cls in mirrors.items():
+        assert L.egp_abi_sizeof(name.encode()) == ctypes.sizeof(cls), name
+    assert L.egp_abi_sizeof(b"no_such_struct") == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from egopose_amd import _lib as L
     monkeypatch.setattr(L, "_lib", None)
