@@ -26,11 +26,19 @@ def write_synthetic_dataset(root, cfg_id="subject_03", device_index=0, n_takes=8
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def _time_launches(fn, iters=50, warm=5):
+def _time_launches(fn, iters=50, warm=5, warm_s=0.03):
+    """Seconds per call in the steady state: at least `warm` calls AND `warm_s` seconds of back-to-back launches before
+    the timed ones (a few short launches after an idle stretch are timed at the clocks the GPU idles at, not the ones
+    it sustains: K1 at 65 536 envs read 334 us after five warm-up calls in `bench.py` and 271 us after 30 ms of them)."""
+    import time
     import torch
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = 0
+    while done < warm or time.perf_counter() - t0 < warm_s:
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        done += warm
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
