@@ -20,7 +20,9 @@ Prints ONE JSON line (rank 0) with the driver's fields plus
   legs         (1 GPU) the same workload (i) through the float64 driver set-up of the unmodified reference
                (`dropin_env_steps_per_s`), (ii) with an inertia that changes on every substep fed from the host (the
                traffic of a MuJoCo-like backend), (iii) with that inertia computed on the GPU (row f1), (iv) the
-               ego_forecast nets of BASELINE config 5 on this GPU's 1 024-slot shard
+               ego_forecast nets of BASELINE config 5 on this GPU's 1 024-slot shard, (v) with a physics substep that costs
+               `--sim-cost-us` (20 us: the order of an mj_step of this humanoid; the surrogate's own is ~0.3 us) next to the
+               CPU sampler at the same cost and to what the host threads alone allow
   cpu_baseline the oracle's restatement of the reference CPU sampler (2 forked workers, float64, OMP=1) on a
                bounded sample, same physics backend (rank 0, N=1 only)
 """
@@ -44,8 +46,8 @@ HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec
 K1_BYTES_PER_ENV = (910 + 58 + 52 + 58 + 52 + 52) * 8   # qM + qfrc_bias + qpos[7:] + qvel + action + torque, float64
 
 
-def cpu_baseline(dataset, steps, threads):
-    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="")
+def cpu_baseline(dataset, steps, threads, extra_env=None):
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", **(extra_env or {}))
     cmd = [sys.executable, "-m", "oracle.cpu_env", "--dataset", dataset, "--threads", str(threads), "--steps", str(steps)]
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
     if out.returncode != 0:
@@ -245,6 +247,8 @@ def main():
     ap.add_argument("--no-k1-events", action="store_true")
     ap.add_argument("--k1-event-every", type=int, default=8, help="bracket K1 with HIP events on every Nth env-step")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra 1-GPU legs (drop-in dtype, changing inertia)")
+    ap.add_argument("--sim-cost-us", type=float, default=20.0,
+                    help="per-substep physics cost of the `simulator_cost_per_substep` leg (busy wait inside the surrogate's step)")
     ap.add_argument("--no-kernels", action="store_true", help="skip the HBM-resident kernel microbenchmarks")
     ap.add_argument("--leg-steps", type=int, default=2)
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous self-test: no GPU work (gloo on CPU)")
@@ -377,6 +381,19 @@ def main():
             mkf = lambda: Trainer(ForecastConfig(args.cfg, create_dirs=False), dev, torch.float32, num_envs=args.envs,
                                   num_threads=n_threads, num_groups=args.groups)
             legs["egoforecast_config5_shard"] = run_leg(mkf, args.leg_steps, 1, min_batch, ev)
+            # the same pipeline when a physics substep costs what a real simulator's does (the surrogate's own is ~0.3 us;
+            # an mj_step of this humanoid is tens of us): host-bound, and the CPU sampler beside it at the same cost
+            cost = {"EGP_SURROGATE_SUBSTEP_US": str(args.sim_cost_us)}
+            leg = run_leg(mk32, 1, 1, min_batch, ev, cost)
+            if not args.no_cpu_baseline and "error" not in leg:
+                cb = cpu_baseline(root, max(200, args.cpu_steps // 6), 2, cost)
+                leg.update({"cpu_sampler_env_steps_per_s": cb["value"], "cpu_sampler_cores": cb["cores"], "cpu_sampler_sample": cb["sample"]})
+            leg["substep_cost_us"] = args.sim_cost_us
+            if "error" not in leg:       # what the host threads alone allow: one env-step = substeps x cost on one thread
+                leg["host_threads"] = n_threads
+                leg["host_physics_ceiling_env_steps_per_s"] = n_threads / (leg["substeps_per_launch"] * args.sim_cost_us * 1e-6)
+                leg["frac_of_host_physics_ceiling"] = leg["rollout_only_env_steps_per_s"] / leg["host_physics_ceiling_env_steps_per_s"]
+            legs["simulator_cost_per_substep"] = leg
             res["legs"] = {k: {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items()} for k, v in legs.items()}
             res["dropin_env_steps_per_s"] = legs["dropin_float64_driver"].get("env_steps_per_s")
         if not args.no_cpu_baseline:

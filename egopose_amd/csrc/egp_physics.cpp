@@ -19,6 +19,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <stdio.h>
+#include <string>
 #include <vector>
 
 #include "egp_internal.hpp"
@@ -39,6 +42,10 @@ struct Surrogate {
     // per-env state
     std::vector<double> qpos, qvel, bias, zref;
     int n_env;
+    // EGP_SURROGATE_SUBSTEP_US: every step() takes at least this long (busy wait), to measure the pipeline at the per-substep
+    // cost of a real simulator (an mj_step of this humanoid is tens of microseconds; the surrogate's own step is ~0.3)
+    long long min_step_ns = 0;
+    std::string name = "surrogate-euler-M0";
 };
 
 inline void quat_mul(const double *a, const double *b, double *o) {
@@ -219,6 +226,8 @@ int sur_step(void *user, int32_t env, const double *ctrl) {
     double *v = &S.qvel[(size_t)env * S.nv];
     double *C = &S.bias[(size_t)env * S.nv];
     const int nv = S.nv;
+    std::chrono::steady_clock::time_point t_in;
+    if (S.min_step_ns > 0) t_in = std::chrono::steady_clock::now();
     compute_bias(S, env, C);
     double f[EGP_MAX_NV], acc[EGP_MAX_NV];
     for (int i = 0; i < 6; ++i) f[i] = -C[i];
@@ -239,6 +248,8 @@ int sur_step(void *user, int32_t env, const double *ctrl) {
         for (int k = 0; k < 4; ++k) q[3 + k] = o[k] / n;
     }
     for (int i = 6; i < nv; ++i) q[i + 1] += S.dt * v[i];
+    if (S.min_step_ns > 0)
+        while (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_in).count() < S.min_step_ns) {}
     return EGP_OK;
 }
 
@@ -297,7 +308,16 @@ int egp_physics_create_surrogate(const egp_surrogate_desc *d, int32_t n_env, egp
     for (int e = 0; e < n_env; ++e) S->qpos[(size_t)e * d->nq + 3] = 1.0;
     egp_physics_vtable vt{};
     vt.user = S; vt.reset = sur_reset; vt.step = sur_step; vt.drain = sur_drain; vt.destroy = sur_destroy;
-    vt.name = "surrogate-euler-M0";
+    if (const char *e = getenv("EGP_SURROGATE_SUBSTEP_US")) {
+        const double us = atof(e);
+        if (us > 0) {
+            S->min_step_ns = (long long)(us * 1e3);
+            char buf[64];
+            snprintf(buf, sizeof buf, "+%gus-per-substep", us);
+            S->name += buf;
+        }
+    }
+    vt.name = S->name.c_str();
     vt.inertia_epoch = sur_epoch;
     // EGP_SURROGATE_ALWAYS_DIRTY=1: report "inertia changed" on every drain, as a simulator with a pose-dependent qM
     // (MuJoCo) would -- same numbers (M0), but the full 7.3 kB inertia row crosses to the GPU every substep. Traffic

@@ -114,6 +114,32 @@ def test_surrogate_step_is_deterministic_and_stale_bias(skel):
     ph.close()
 
 
+def test_surrogate_minimum_substep_cost_changes_time_only(skel, monkeypatch):
+    """EGP_SURROGATE_SUBSTEP_US (bench.py's `simulator_cost_per_substep` leg): every step takes at least that long, the
+    backend's name says so, and the numbers are the ones the plain surrogate produces."""
+    import time
+    from egopose_amd.physics import SurrogatePhysics
+    g = load_golden("pd_torque.npz")
+    ctrl = g["torque_clipped"][0]
+    plain = SurrogatePhysics(skel, 1)
+    monkeypatch.setenv("EGP_SURROGATE_SUBSTEP_US", "200")
+    slow = SurrogatePhysics(skel, 1)
+    monkeypatch.delenv("EGP_SURROGATE_SUBSTEP_US")
+    assert plain.name == "surrogate-euler-M0" and slow.name == "surrogate-euler-M0+200us-per-substep"
+    for ph in (plain, slow):
+        ph.reset(0, g["qpos"][0], g["qvel"][0])
+    t0 = time.perf_counter()
+    for _ in range(50):
+        slow.step(0, ctrl)
+    assert time.perf_counter() - t0 >= 50 * 200e-6
+    for _ in range(50):
+        plain.step(0, ctrl)
+    for x, y in zip(plain.drain(0), slow.drain(0)):
+        np.testing.assert_array_equal(x, y)
+    plain.close()
+    slow.close()
+
+
 def test_callback_backend_round_trip(skel):
     """egp_physics_register with Python callables: reset/step/drain reach the callables with views of the caller's
     buffers, the epoch callback is wired, and a raising callable turns into an error code instead of unwinding."""
