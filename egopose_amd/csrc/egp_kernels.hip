@@ -866,50 +866,80 @@ struct ZfSrc {
     }
 };
 
-// tile statistics: thread = column, rows of the tile in chunks of 8 (8 independent loads in flight, then an
-// exact two-pass mean / M2 of the chunk, Chan-merged into the running tile statistics)
+// tile statistics: a workgroup is G = blockDim / 128 row groups x 128 columns. A thread takes its group's share of the
+// tile's rows in chunks of 8 (8 independent loads in flight, then an exact two-pass mean / M2 of the chunk, Chan-merged
+// into the thread's running statistics); the groups' results meet in LDS and group 0 merges them in row order. With
+// 1 024 threads and 64-row tiles every thread has ONE round of loads and a 512-env tick leaves 8 partials -- few
+// enough for k_zf_apply to merge them itself (one launch and its memory round trips less on the tick's critical path).
 template <typename T>
 __device__ __forceinline__ void zf_partial_body(const ZfSrc<T> &src, const int *__restrict__ active, int n, int dim,
                                                 int rows_per_tile, double *__restrict__ ws, int p) {
+    __shared__ double s_mean[8][128], s_m2[8][128], s_cnt[8];
+    const int G = blockDim.x >> 7, g = threadIdx.x >> 7, lc = threadIdx.x & 127;
     const int r0 = p * rows_per_tile, r1 = min(n, r0 + rows_per_tile);
+    const int per = ((rows_per_tile + G - 1) / G + 7) / 8 * 8;
+    const int g0 = r0 + g * per, g1 = min(r1, g0 + per);
     double *out = ws + (long)p * (1 + 2 * dim);
-    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+    for (int cb = 0; cb < dim; cb += 128) {
+        const int c = cb + lc;
         double cnt = 0.0, mean = 0.0, m2 = 0.0;
-        for (int rb = r0; rb < r1; rb += 8) {
-            double v[8];
-            int on[8], k = 0;
+        if (c < dim)
+            for (int rb = g0; rb < g1; rb += 8) {
+                double v[8];
+                int on[8], k = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = rb + i;
-                on[i] = r < r1 && (!active || active[r]);
-                v[i] = on[i] ? (double)src.at(r, c) : 0.0;
-                k += on[i];
+                for (int i = 0; i < 8; ++i) {
+                    const int r = rb + i;
+                    on[i] = r < g1 && (!active || active[r]);
+                    v[i] = on[i] ? (double)src.at(r, c) : 0.0;
+                    k += on[i];
+                }
+                if (k == 0) continue;
+                double sum = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sum += v[i];
+                const double mb = sum / k;
+                double sb = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sb += on[i] ? (v[i] - mb) * (v[i] - mb) : 0.0;
+                if (cnt == 0.0) {
+                    cnt = k; mean = mb; m2 = sb;
+                } else {
+                    const double tot = cnt + k, d = mb - mean;
+                    m2 += sb + d * d * (cnt * k / tot);
+                    mean += d * (k / tot);
+                    cnt = tot;
+                }
             }
-            if (k == 0) continue;
-            double s = 0.0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) s += v[i];
-            const double mb = s / k;
-            double sb = 0.0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) sb += on[i] ? (v[i] - mb) * (v[i] - mb) : 0.0;
-            if (cnt == 0.0) {
-                cnt = k; mean = mb; m2 = sb;
-            } else {
-                const double tot = cnt + k, d = mb - mean;
-                m2 += sb + d * d * (cnt * k / tot);
-                mean += d * (k / tot);
-                cnt = tot;
+        s_mean[g][lc] = mean;
+        s_m2[g][lc] = m2;
+        if (lc == 0 && cb == 0) s_cnt[g] = cnt;          // (the count is the same for every column)
+        __syncthreads();
+        if (g == 0 && c < dim) {
+            double C = s_cnt[0], M = s_mean[0][lc], S = s_m2[0][lc];
+            for (int j = 1; j < G; ++j) {
+                const double nb = s_cnt[j];
+                if (nb > 0.0) {
+                    if (C == 0.0) {
+                        C = nb; M = s_mean[j][lc]; S = s_m2[j][lc];
+                    } else {
+                        const double d = s_mean[j][lc] - M, tot = C + nb;
+                        S = S + s_m2[j][lc] + d * d * (C * nb / tot);
+                        M = M + d * (nb / tot);
+                        C = tot;
+                    }
+                }
             }
+            out[1 + c] = M;
+            out[1 + dim + c] = S;
+            if (c == 0) out[0] = C;
         }
-        out[1 + c] = mean;
-        out[1 + dim + c] = m2;
-        if (c == 0) out[0] = cnt;
+        __syncthreads();
     }
 }
 
 template <typename T>
-__global__ __launch_bounds__(128) void k_zf_partial(ZfSrc<T> src, const int *__restrict__ active, int n, int dim,
+__global__ __launch_bounds__(1024) void k_zf_partial(ZfSrc<T> src, const int *__restrict__ active, int n, int dim,
                                                     int rows_per_tile, double *__restrict__ ws) {
     zf_partial_body<T>(src, active, n, dim, rows_per_tile, ws, blockIdx.x);
 }
@@ -931,35 +961,42 @@ __global__ __launch_bounds__(256) void k_post_step(ZfSrc<T> src, const int *__re
                        (int)blockIdx.x - n_tiles);
 }
 
-// one block: Chan-merge the tile partials into the running state, fixed order (deterministic)
-__global__ __launch_bounds__(128) void k_zf_merge(int dim, int n_tiles, const double *__restrict__ ws,
-                                                  const double *__restrict__ st_in, double *__restrict__ st_out) {
-    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
-        double cnt = st_in[0], mean = st_in[1 + c], S = st_in[1 + dim + c];
-        for (int q0 = 0; q0 < n_tiles; q0 += 8) {
-            double nb[8], mb[8], Sb[8];
+// Chan-merge of the tile partials of column c into the running state, fixed order (deterministic)
+__device__ __forceinline__ void zf_merge_column(int dim, int n_tiles, const double *__restrict__ ws, const double *__restrict__ st_in,
+                                                int c, double &cnt, double &mean, double &S) {
+    cnt = st_in[0]; mean = st_in[1 + c]; S = st_in[1 + dim + c];
+    for (int q0 = 0; q0 < n_tiles; q0 += 8) {
+        double nb[8], mb[8], Sb[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {          // 24 independent loads in flight, then the ordered merge
-                const int q = q0 + i;
-                const double *pp = ws + (long)(q < n_tiles ? q : 0) * (1 + 2 * dim);
-                nb[i] = q < n_tiles ? pp[0] : 0.0;
-                mb[i] = pp[1 + c];
-                Sb[i] = pp[1 + dim + c];
-            }
+        for (int i = 0; i < 8; ++i) {          // 24 independent loads in flight, then the ordered merge
+            const int q = q0 + i;
+            const double *pp = ws + (long)(q < n_tiles ? q : 0) * (1 + 2 * dim);
+            nb[i] = q < n_tiles ? pp[0] : 0.0;
+            mb[i] = pp[1 + c];
+            Sb[i] = pp[1 + dim + c];
+        }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (nb[i] > 0.0) {
-                    if (cnt == 0.0) {
-                        cnt = nb[i]; mean = mb[i]; S = Sb[i];
-                    } else {
-                        const double d = mb[i] - mean, tot = cnt + nb[i];
-                        S = S + Sb[i] + d * d * (cnt * nb[i] / tot);
-                        mean = mean + d * (nb[i] / tot);
-                        cnt = tot;
-                    }
+        for (int i = 0; i < 8; ++i) {
+            if (nb[i] > 0.0) {
+                if (cnt == 0.0) {
+                    cnt = nb[i]; mean = mb[i]; S = Sb[i];
+                } else {
+                    const double d = mb[i] - mean, tot = cnt + nb[i];
+                    S = S + Sb[i] + d * d * (cnt * nb[i] / tot);
+                    mean = mean + d * (nb[i] / tot);
+                    cnt = tot;
                 }
             }
         }
+    }
+}
+
+// one block: the merged state of a batch with many tiles (few tiles: k_zf_apply merges them itself)
+__global__ __launch_bounds__(128) void k_zf_merge(int dim, int n_tiles, const double *__restrict__ ws,
+                                                  const double *__restrict__ st_in, double *__restrict__ st_out) {
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+        double cnt, mean, S;
+        zf_merge_column(dim, n_tiles, ws, st_in, c, cnt, mean, S);
         st_out[1 + c] = mean;
         st_out[1 + dim + c] = S;
         if (c == 0) st_out[0] = cnt;
@@ -968,13 +1005,26 @@ __global__ __launch_bounds__(128) void k_zf_merge(int dim, int n_tiles, const do
 
 // y = clip((x - mean) / (std + 1e-8)) with the statistics in `st` (identity: raw copy)
 template <typename T>
+// `ws` != nullptr: `st` is the state BEFORE this batch and every block merges the batch's n_tiles partials into it for
+// itself (same operations in the same order: identical in every block); block 0 writes the new state to st_out
 __global__ __launch_bounds__(128) void k_zf_apply(ZfSrc<T> src, int n, int dim, int rows_per_block, const double *__restrict__ st,
                                                   double clip, T *__restrict__ y, T *__restrict__ y2,
-                                                  const int *__restrict__ write_mask, int identity) {
+                                                  const int *__restrict__ write_mask, int identity,
+                                                  const double *__restrict__ ws, int n_tiles, double *__restrict__ st_out) {
     extern __shared__ double s_ms[];   // mean[dim], inv[dim]
     for (int c = threadIdx.x; c < dim; c += blockDim.x) {
         if (identity) { s_ms[c] = 0.0; s_ms[dim + c] = 1.0; continue; }
-        const double cnt = st[0], mean = st[1 + c], S = st[1 + dim + c];
+        double cnt, mean, S;
+        if (ws) {
+            zf_merge_column(dim, n_tiles, ws, st, c, cnt, mean, S);
+            if (blockIdx.x == 0) {
+                st_out[1 + c] = mean;
+                st_out[1 + dim + c] = S;
+                if (c == 0) st_out[0] = cnt;
+            }
+        } else {
+            cnt = st[0]; mean = st[1 + c]; S = st[1 + dim + c];
+        }
         const double var = cnt > 1.0 ? S / (cnt - 1.0) : mean * mean;
         s_ms[c] = mean;
         s_ms[dim + c] = 1.0 / (sqrt(var) + 1e-8);
@@ -1519,9 +1569,11 @@ static int launch_features(egp_ctx *ctx, const T *cur, const T *prev, const T *e
     return after_launch("k_pose_features");
 }
 
-// 8-row tiles while that gives <= 512 partials (the merge is one block walking them in order), larger tiles beyond
+// 64-row tiles (8 rows per thread of a 1 024-thread workgroup) while that gives <= 512 partials, larger tiles beyond.
+// Up to ZF_FUSED_TILES partials the apply kernel merges them itself (two launches per update), beyond that k_zf_merge does.
+constexpr int ZF_FUSED_TILES = 16;
 static inline void zf_tiling(int n, int *rows_per_tile, int *n_tiles) {
-    int rpt = 8;
+    int rpt = 64;
     while ((n + rpt - 1) / rpt > 512) rpt *= 2;
     *rows_per_tile = rpt;
     *n_tiles = n > 0 ? (n + rpt - 1) / rpt : 1;
@@ -1541,15 +1593,17 @@ static int launch_zfilter_src(const ZfSrc<T> &src, const int *active, int n, int
     }
     int rpt, nt;
     zf_tiling(n, &rpt, &nt);
+    const bool fused = update && nt <= ZF_FUSED_TILES;
     if (update) {
-        k_zf_partial<T><<<dim3(nt), dim3(128), 0, (hipStream_t)stream>>>(src, active, n, dim, rpt, (double *)ws);
-        k_zf_merge<<<dim3(1), dim3(128), 0, (hipStream_t)stream>>>(dim, nt, (const double *)ws, st_in, st_out);
+        k_zf_partial<T><<<dim3(nt), dim3(1024), 0, (hipStream_t)stream>>>(src, active, n, dim, rpt, (double *)ws);
+        if (!fused) k_zf_merge<<<dim3(1), dim3(128), 0, (hipStream_t)stream>>>(dim, nt, (const double *)ws, st_in, st_out);
         int rc = after_launch("k_zf_partial/merge");
         if (rc != EGP_OK) return rc;
     }
-    const int rows_per_block = n <= 8192 ? 2 : 16;     // small batches: enough blocks to cover the latency
+    const int rows_per_block = fused ? 8 : (n <= 8192 ? 2 : 16);     // small batches: enough blocks to cover the latency
     k_zf_apply<T><<<dim3((n + rows_per_block - 1) / rows_per_block), dim3(128), 2 * dim * sizeof(double), (hipStream_t)stream>>>(
-        src, n, dim, rows_per_block, update ? st_out : st_in, clip, y, y2, write_mask, identity);
+        src, n, dim, rows_per_block, update && !fused ? st_out : st_in, clip, y, y2, write_mask, identity,
+        fused ? (const double *)ws : nullptr, nt, st_out);
     return after_launch("k_zf_apply");
 }
 
@@ -1593,10 +1647,12 @@ static int launch_post_step(egp_ctx *ctx, const double *qpos, const double *qvel
     k_post_step<double><<<dim3(nt + reward_blocks), dim3(256), 0, s>>>(src, active, n, dim, rpt, (double *)ws, nt, ctx->dm, ctx->rw,
                                                                        ctx->expert_rows_f64, prev_qpos, ee_wpos, tcur, frame, endf,
                                                                        end_reward, reward, cinfo);
-    if (!identity) k_zf_merge<<<dim3(1), dim3(128), 0, s>>>(dim, nt, (const double *)ws, st_in, st_out);
-    const int rows_per_block = n <= 8192 ? 2 : 16;
+    const bool fused = !identity && nt <= ZF_FUSED_TILES;
+    if (!identity && !fused) k_zf_merge<<<dim3(1), dim3(128), 0, s>>>(dim, nt, (const double *)ws, st_in, st_out);
+    const int rows_per_block = fused ? 8 : (n <= 8192 ? 2 : 16);
     k_zf_apply<double><<<dim3((n + rows_per_block - 1) / rows_per_block), dim3(128), 2 * dim * sizeof(double), s>>>(
-        src, n, dim, rows_per_block, identity ? st_in : st_out, clip, y, y2, nullptr, identity);
+        src, n, dim, rows_per_block, identity || fused ? st_in : st_out, clip, y, y2, nullptr, identity,
+        fused ? (const double *)ws : nullptr, nt, st_out);
     return after_launch("k_post_step / k_zf_merge / k_zf_apply");
 }
 

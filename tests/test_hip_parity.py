@@ -301,6 +301,44 @@ def test_engine_step_matches_host_loop(ctx, skel, mode, monkeypatch):
         ref.close()
 
 
+def test_resident_engine_dealt_slices_are_bit_identical(ctx, skel, monkeypatch):
+    """With an active mask the resident engine may deal its slices out to the host threads per env-step
+    (EGP_SERVER_BALANCE: 1 = always, 0 = never, unset = when a substep of physics is expensive enough): who steps an env
+    changes, the env's numbers do not, and an inactive env is never touched."""
+    from egopose_amd.physics import SurrogatePhysics, RolloutEngine
+    g = load_golden("body_quat_obs.npz")
+    n = 203
+    rng = np.random.RandomState(11)
+    pick = rng.randint(0, len(g["qpos"]), n)
+    qpos0, qvel0 = g["qpos"][pick], g["qvel"][pick] * 0.2
+    action = dev(rng.normal(size=(n, 52)) * 0.2)
+    masks = [(rng.rand(n) < p).astype(np.int32) for p in (0.6, 0.15, 0.03)]
+    masks[2][:8] = 1                                   # a crowded first slice: the case dealing is for
+    out = {}
+    for bal in ("0", "1"):
+        monkeypatch.setenv("EGP_SERVER_BALANCE", bal)
+        ph = SurrogatePhysics(skel, n)
+        eng = RolloutEngine(ctx, ph, n, n_threads=6, n_groups=2)
+        assert eng.substeps_per_launch == 15
+        eng.reset(np.arange(n), qpos0, qvel0)
+        torch.cuda.synchronize()
+        for m in masks:
+            for gi in range(2):
+                eng.step_async(gi, action, active_host=m)
+            for gi in range(2):
+                eng.wait(gi)
+            torch.cuda.synchronize()
+        out[bal] = (eng.qpos.cpu().numpy().copy(), eng.qvel.cpu().numpy().copy(), eng.ee_wpos.cpu().numpy().copy())
+        eng.close()
+        ph.close()
+    for a, b in zip(out["0"], out["1"]):
+        np.testing.assert_array_equal(a, b)
+    never = (masks[0] | masks[1] | masks[2]) == 0
+    assert never.any()
+    np.testing.assert_array_equal(out["1"][0][never], qpos0[never])
+    assert np.abs(out["1"][0][~never] - qpos0[~never]).max() > 0
+
+
 def test_surrogate_always_dirty_changes_traffic_not_numbers(ctx, skel, monkeypatch):
     """EGP_SURROGATE_ALWAYS_DIRTY=1 (the inertia row crosses to the GPU on every substep, the traffic of a backend with a
     pose-dependent qM) must give bit-identical env-steps to the default (inertia sent once)."""
