@@ -87,6 +87,7 @@ struct GemmArgs {
     int k_per_split;                          // multiple of BK; gridDim.z splits
     float *ws; int ldws;                      // [splits][M][ldws] when there are k splits or a ones column; ldws = N + ones_col rounded up to 4
     int tiles_m, tiles_n, xcd_order;
+    int split_xcd;        // k_gemm_ws, split-K launches: the tiles of one k range go to ONE XCD (they read the same k rows of A and B)
     // fused gather / scatter (egp_gemm_desc: a_rows ... c_rows), k_gemm_ws only
     const long long *a_rows; const float *A2; long lda2; int a_split;
     const long long *a_krows;                 // A given as [k][m]: k-row k lives at row a_krows[k]
@@ -635,9 +636,16 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
     const int ones_row = g.ones_col ? g.N : -1;
 
     // this workgroup's stream: P k-tiles over its items
+    // Workgroups are dealt to the 8 XCDs round-robin by their id. In a split-K launch the few output tiles of one k range read
+    // the same k rows of both operands: with consecutive ids they would sit on different XCDs and every one of them
+    // would fetch those rows from HBM for itself (2.4 x the operands' bytes for a 300 x 243 weight gradient). The
+    // transposed numbering puts consecutive work items on consecutive workgroups of ONE XCD, so a k row crosses from
+    // HBM once and the other tiles hit that XCD's L2.
+    int vb = blockIdx.x;
+    if (g.split_xcd && (gridDim.x & 7) == 0) vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     int P = 0, w_first = -1;
     WsCursor cur{};
-    for (int w = blockIdx.x; w < g.n_items; w += gridDim.x) {
+    for (int w = vb; w < g.n_items; w += gridDim.x) {
         WsCursor c{};
         if (ws_item<BN>(g, w, c)) {
             P += c.nst;
@@ -1078,6 +1086,8 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     const int zs_ws = (zs > 1 && rem < BK) ? zs - 1 : zs;
     g.zs = zs_ws;
     g.n_items = g.grid_tiles * zs_ws;
+    const char *sx_env = getenv("EGP_GEMM_SPLIT_XCD");     // =0: plain numbering (read per call, for A/B runs)
+    g.split_xcd = zs_ws > 1 && !g.xcd_order && g.grid_tiles > 1 && !(sx_env && atoi(sx_env) == 0);
     // three-piece products: the warp-specialised persistent kernel, unless a k range is shorter than one k-tile
     const char *ws_env = getenv("EGP_GEMM_WS");            // EGP_GEMM_WS=0: k_gemm_bf16x for everything (read per call: tests switch it)
     const bool ws_on = !(ws_env && atoi(ws_env) == 0);
