@@ -471,9 +471,13 @@ class AgentEgo(AgentPPO):
             pdt = next(vs_nets[0].parameters()).dtype
             for net in vs_nets:
                 net.attach_feature_table(ex.cnn_table(dev, pdt), ex.cnn_offset)
-        for net in vs_nets:
+        x_init = (c["masks"], self.env.cnn_feat, v_metas)
+        for i, net in enumerate(vs_nets):
             net.set_mode("train")
-            net.initialize((c["masks"], self.env.cnn_feat, v_metas))
+            if i > 0 and hasattr(net, "adopt_train_context") and os.environ.get("EGP_SHARE_TRAIN_CONTEXT", "1") != "0":
+                net.adopt_train_context(vs_nets[0], x_init)      # same batch, same feature table: segment and gather once
+            else:
+                net.initialize(x_init)
         if self.value_opt_niter == 1 and os.environ.get("EGP_REUSE_FIRST_PASS", "1") != "0":
             # ONE forward pass with autograd on serves three purposes: the values that GAE consumes, the fixed log-probs of
             # the surrogate, and epoch 0's forward (nothing has stepped in between; no dropout / batch norm in these nets)

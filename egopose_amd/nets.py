@@ -327,6 +327,7 @@ class VideoStateNet(nn.Module):
     def attach_feature_table(self, table, take_offset):
         """Device-resident concatenation of all takes' features (+ row offsets) for gather-built contexts."""
         self._cnn_table = (table, torch.as_tensor(np.asarray(take_offset), dtype=torch.long, device=table.device))
+        self._take_offset_host = np.asarray(take_offset, dtype=np.int64).copy()
         self._take_len = _take_lengths(take_offset, table.shape[0])
 
     def check_windows(self, expert_ind, start_ind, length):
@@ -413,6 +414,26 @@ class VideoStateNet(nn.Module):
             cuts = [n_ep * k // _FWD_BUCKETS for k in range(_FWD_BUCKETS + 1)]
             lens_sorted = lens[order]
             self._buckets = [(cuts[k], cuts[k + 1], int(m + lens_sorted[cuts[k]])) for k in range(_FWD_BUCKETS)]
+
+    _TRAIN_CONTEXT = ("indices", "cnn_feat_ctx", "gather_indices", "_gather_tm", "_gather_unique", "_ctx_key", "_ragged",
+                      "_buckets", "_gather_sorted", "_ctx_sorted")
+
+    def adopt_train_context(self, other, x):
+        """``initialize(x)`` in train mode when ``other`` has just been initialised with the SAME ``x``: the episode
+        segmentation, the gather indices, the gathered feature windows and the ragged order depend on ``x``, the margin and
+        the feature table only (not on the net's weights), so the policy's and the value function's front ends
+        (ego_pose/core/agent_ego.py:34-41 initialises one after the other) share them -- one device sync and one pass of
+        index arithmetic over the batch instead of two. Falls back to ``initialize`` when the two nets are not alike."""
+        alike = (isinstance(other, VideoStateNet) and self.mode == "train" and other.mode == "train" and other.cnn_feat_ctx is not None
+                 and other._ctx_key is not None and self.v_margin == other.v_margin and self.cnn_feat_dim == other.cnn_feat_dim
+                 and self.v_net_type == other.v_net_type and self._cnn_table is not None and other._cnn_table is not None
+                 and self._cnn_table[0].data_ptr() == other._cnn_table[0].data_ptr()
+                 and np.array_equal(self._take_offset_host, other._take_offset_host) and other.cnn_feat_ctx.dtype == x[0].dtype)
+        if not alike:
+            return self.initialize(x)
+        for k in self._TRAIN_CONTEXT:
+            if hasattr(other, k):
+                setattr(self, k, getattr(other, k))
 
     def _bucketed_context(self):
         """(T - 2m, n_ep sorted by length, v_hdim): backward direction over the full window, forward direction per length bucket."""

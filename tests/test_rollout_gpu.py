@@ -118,6 +118,30 @@ def test_full_iteration_updates_parameters_and_filter(workspace):
     tr.close()
 
 
+def test_value_front_end_adopts_the_policy_s_train_context(workspace, monkeypatch):
+    """update_params initialises the policy's VideoStateNet for the batch and lets the value function's adopt the derived
+    context (nets.VideoStateNet.adopt_train_context): every adopted field equals what its own initialize builds, and the
+    update's parameters agree with and without sharing (to the 1e-8 that two identical runs differ by: a torch reduction
+    in the backward pass is not order-deterministic)."""
+    out = {}
+    for share in ("1", "0"):
+        monkeypatch.setenv("EGP_SHARE_TRAIN_CONTEXT", share)
+        tr, cfg = _trainer(workspace, 32, 12, num_threads=4, num_groups=2)
+        tr.iteration(0, 32 * 16)
+        pv, vv = tr.agent.cn.policy_vs_net, tr.agent.cn.value_vs_net
+        if share == "1":
+            assert vv.cnn_feat_ctx is pv.cnn_feat_ctx and vv.gather_indices is pv.gather_indices
+        else:
+            assert vv.cnn_feat_ctx is not pv.cnn_feat_ctx
+            assert torch.equal(vv.cnn_feat_ctx, pv.cnn_feat_ctx) and torch.equal(vv._gather_tm, pv._gather_tm)
+            assert np.array_equal(vv.indices, pv.indices) and vv._ctx_key == pv._ctx_key
+        out[share] = [p.detach().clone() for p in list(tr.value_net.parameters()) + list(tr.value_vs_net.parameters())
+                      + list(tr.policy_vs_net.parameters())]
+        tr.close()
+    for a, b in zip(out["1"], out["0"]):
+        torch.testing.assert_close(a, b, rtol=0, atol=1e-6)
+
+
 def test_single_env_facade_matches_oracle_env(workspace, skel):
     """HumanoidEnv.reset/step + reward_func['quat_v3'] on a batch of one == the oracle's CPU env (eval-style use)."""
     from egopose_amd.config import Config
