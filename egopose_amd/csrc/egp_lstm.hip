@@ -274,6 +274,18 @@ __device__ __forceinline__ int lstm_group_steps(const LstmGroup &grp, int revers
 // parameters so that the timestep body is straight-line code: with a branch around any load or store the compiler's
 // s_waitcnt pass no longer knows how many memory operations are outstanding and waits for ALL of them (vmcnt(0))
 // before touching a prefetched register -- i.e. for the acknowledgement of the stores it has just issued, every step.
+#ifndef EGP_LSTM_PD1
+#define EGP_LSTM_PD1 (NQ == 1 ? 4 : 4)
+#endif
+#ifndef EGP_LSTM_KCH
+#define EGP_LSTM_KCH (NQ == 1 && LH == 64 ? 32 : 64)
+#endif
+#ifndef EGP_LSTM_BPD
+#define EGP_LSTM_BPD ((NQ == 1 && LH == 64) ? 4 : 2)
+#endif
+#ifndef EGP_LSTM_BKCH
+#define EGP_LSTM_BKCH 64
+#endif
 template <int NQ, int LH, bool FULL, bool TRAIN>
 __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restrict__ gx, const float *__restrict__ w_hh, int T, int B,
                                                           LstmGroup grp, float *__restrict__ gates_out, float *__restrict__ c_out) {
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
     float *__restrict__ h_out = grp.h[prob];
     gx += prob * LG; w_hh += (long)prob * LG * LH;
     if (TRAIN) { gates_out += prob * LG; c_out += prob * grp.c_stride; }
-    constexpr int PD = LH == 128 ? 2 : (NQ == 1 ? 8 : 4);   // steps per unrolled iteration = input-projection tiles in flight (even)
+    constexpr int PD = LH == 128 ? 2 : EGP_LSTM_PD1;   // steps per unrolled iteration = input-projection tiles in flight (even)
     __shared__ __attribute__((aligned(16))) float s_h[2][ROWS][LH + 4];     // +4: the 4 rows of a read hit distinct banks
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u = 16 * wave + (lane >> 2), sub = lane & 3;                   // sub = gate index as A, row-in-quad as B / D
@@ -320,17 +332,18 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
         f32x4 acc[NQ], acc2[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { acc[q] = init[q]; acc2[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        constexpr int KCH = EGP_LSTM_KCH;
 #pragma unroll
-        for (int kc = 0; kc < LH; kc += 64) {
-            float4 hv[NQ][16];
+        for (int kc = 0; kc < LH; kc += KCH) {
+            float4 hv[NQ][KCH / 4];
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int k4 = 0; k4 < 16; ++k4) hv[q][k4] = *reinterpret_cast<const float4 *>(&s_h[par][4 * q + sub][kc + 4 * k4]);
+                for (int k4 = 0; k4 < KCH / 4; ++k4) hv[q][k4] = *reinterpret_cast<const float4 *>(&s_h[par][4 * q + sub][kc + 4 * k4]);
             __builtin_amdgcn_sched_barrier(0);
             // ... then the products; two accumulator chains per quad cover the dependent-issue latency (four: no gain)
 #pragma unroll
-            for (int k4 = 0; k4 < 16; ++k4)
+            for (int k4 = 0; k4 < KCH / 4; ++k4)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[kc + 4 * k4 + 0], hv[q][k4].x, acc[q], 0, 0, 0);
@@ -406,7 +419,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
     const float *__restrict__ dh_out = grp.dh[prob];
     gates += prob * LG; dpre += prob * LG; cells += prob * grp.c_stride; w_hh += (long)prob * LG * LH;
     constexpr int NP = (ROWS * LH + NT - 1) / NT;     // = NQ: (row, unit) pairs per thread in the pointwise phase
-    constexpr int PD = (NQ == 1 && LH == 64) ? 4 : 2;   // steps per unrolled iteration = operand sets in flight
+    constexpr int PD = EGP_LSTM_BPD;   // steps per unrolled iteration = operand sets in flight
     __shared__ __attribute__((aligned(16))) float s_d[ROWS][LG + 4];     // d-gates of the step, [row][unit][gate]
     __shared__ float s_part[4][ROWS][LH + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -480,15 +493,15 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
 #pragma unroll
         for (int qd = 0; qd < NQ; ++qd) acc[qd] = acc2[qd] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kc = 0; kc < LH; kc += 64) {
-            float4 dv[NQ][16];
+        for (int kc = 0; kc < LH; kc += EGP_LSTM_BKCH) {
+            float4 dv[NQ][EGP_LSTM_BKCH / 4];
 #pragma unroll
             for (int qd = 0; qd < NQ; ++qd)
 #pragma unroll
-                for (int c4 = 0; c4 < 16; ++c4) dv[qd][c4] = *reinterpret_cast<const float4 *>(&s_d[4 * qd + sub][q * LH + kc + 4 * c4]);
+                for (int c4 = 0; c4 < EGP_LSTM_BKCH / 4; ++c4) dv[qd][c4] = *reinterpret_cast<const float4 *>(&s_d[4 * qd + sub][q * LH + kc + 4 * c4]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c4 = 0; c4 < 16; ++c4)
+            for (int c4 = 0; c4 < EGP_LSTM_BKCH / 4; ++c4)
 #pragma unroll
                 for (int qd = 0; qd < NQ; ++qd) {
                     acc[qd] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[kc + 4 * c4 + 0], dv[qd][c4].x, acc[qd], 0, 0, 0);

@@ -389,7 +389,10 @@ class VideoStateNet(nn.Module):
         # instead of slicing off the margins, transposing and copying it first
         tm = ((idx % max_len) + m) * self.cnn_feat_ctx.shape[1] + idx // max_len
         self._gather_tm = torch.as_tensor(tm, dtype=torch.long, device=device)
-        self._gather_unique = np.unique(tm).size == tm.size      # (always, for a batch cut into episodes: the scatter of the backward pass relies on it)
+        # the backward pass's scatter relies on distinct rows. Samples inside episodes have them by construction (episode e,
+        # offset < len_e <= max_len -> a distinct (frame, episode) cell); only a batch with samples after its last episode
+        # end (idx = the sample's own number there) needs the look
+        self._gather_unique = covered == n or np.unique(tm).size == tm.size
         self._ctx_key = (int(max_len), meta.shape[0], hash(meta.tobytes()))       # which windows cnn_feat_ctx holds
         # Ragged sweeps (lstm.ragged_order): the forward direction's output at frame t depends on frames <= t only and only
         # frames [m, m + len_e) of an episode are ever gathered, so it stops after m + len_e steps (workgroups of sequences
