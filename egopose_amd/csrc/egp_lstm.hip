@@ -257,6 +257,7 @@ struct LstmGroup {
     // rows of a workgroup alike.
     const int *order;
     const int *steps;
+    int leave_skipped;     // the skipped steps' h_out / d_pre stay unwritten (the caller never reads those rows)
 };
 
 // steps a forward-running workgroup has to make: the longest of its rows
@@ -404,10 +405,11 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
 #undef EGP_LSTM_FETCH_GX
     // the steps a ragged forward-running workgroup skipped: zeros (a weight gradient multiplies these rows with a zero d_pre,
     // and 0 * whatever an uninitialised buffer holds may be NaN)
-    for (int t = Tp; t < T; ++t)
+    if (!grp.leave_skipped)
+        for (int t = Tp; t < T; ++t)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-            if (FULL || live[q]) h_out[((long)t * B + rowc[q]) * ld_h + u] = 0.f;
+            for (int q = 0; q < NQ; ++q)
+                if (FULL || live[q]) h_out[((long)t * B + rowc[q]) * ld_h + u] = 0.f;
 }
 
 template <int NQ, int LH, bool FULL>
@@ -449,11 +451,12 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
     }
     // ragged forward-running problems: the steps the forward sweep skipped carry no gradient (their d_pre is written as zeros)
     const int Tp = lstm_group_steps<ROWS>(grp, reverse, r0, B, T);
-    for (int t = Tp; t < T; ++t)
+    if (!grp.leave_skipped)
+        for (int t = Tp; t < T; ++t)
 #pragma unroll
-        for (int qq = 0; qq < NP; ++qq)
-            if (FULL || live[qq])
-                *reinterpret_cast<f32x4 *>(dpre + ((long)t * B + rowc[qq]) * ld + 4 * ((threadIdx.x + NT * qq) % LH)) = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int qq = 0; qq < NP; ++qq)
+                if (FULL || live[qq])
+                    *reinterpret_cast<f32x4 *>(dpre + ((long)t * B + rowc[qq]) * ld + 4 * ((threadIdx.x + NT * qq) % LH)) = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #define EGP_LSTM_FETCH(STEP, D)                                                                      \
     {                                                                                                \
@@ -700,12 +703,12 @@ int egp_lstm_bwd_f32(const float *dh_out, const float *gates_save, const float *
 
 int egp_lstm_group_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t B, int32_t hidden, int32_t n_problems,
                            int32_t reverse_mask, float *const *h_out, int32_t ld_h, float *gates_save, float *cells_save, void *stream) {
-    return egp_lstm_group_fwd_len_f32(gates_x, w_hh, T, B, hidden, n_problems, reverse_mask, h_out, ld_h, gates_save, cells_save, nullptr, nullptr, stream);
+    return egp_lstm_group_fwd_len_f32(gates_x, w_hh, T, B, hidden, n_problems, reverse_mask, h_out, ld_h, gates_save, cells_save, nullptr, nullptr, 0, stream);
 }
 
 int egp_lstm_group_fwd_len_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t B, int32_t hidden, int32_t n_problems,
                                int32_t reverse_mask, float *const *h_out, int32_t ld_h, float *gates_save, float *cells_save,
-                               const int32_t *seq_order, const int32_t *seq_steps, void *stream) {
+                               const int32_t *seq_order, const int32_t *seq_steps, int32_t leave_skipped, void *stream) {
     EGP_REQUIRE((seq_order == nullptr) == (seq_steps == nullptr), "seq_order and seq_steps go together");
     EGP_REQUIRE(lstm_mfma(), "grouped LSTM sweeps need the matrix-core kernels (EGP_LSTM_MFMA=0 is set)");
     EGP_REQUIRE(hidden == 64 || hidden == 128, "egp_lstm kernels are built for hidden size 64 and 128");
@@ -720,7 +723,7 @@ int egp_lstm_group_fwd_len_f32(const float *gates_x, const float *w_hh, int32_t 
         EGP_REQUIRE(h_out[p], "NULL h_out");
         g.h[p] = h_out[p];
     }
-    g.order = seq_order; g.steps = seq_steps;
+    g.order = seq_order; g.steps = seq_steps; g.leave_skipped = seq_steps && leave_skipped;
     launch_fwd_mfma(hidden, n_problems, gates_x, w_hh, T, B, g, gates_save, cells_save, (hipStream_t)stream);
     return lstm_launch_check("k_lstm_fwd_mfma (group)");
 }
@@ -729,12 +732,12 @@ int egp_lstm_group_bwd_f32(const float *const *dh_out, int32_t ld_dh, const floa
                            int32_t T, int32_t B, int32_t hidden, int32_t n_problems, int32_t reverse_mask, float *d_pre, float *d_bias,
                            void *stream) {
     return egp_lstm_group_bwd_len_f32(dh_out, ld_dh, gates_save, cells_save, w_hh, T, B, hidden, n_problems, reverse_mask, d_pre, d_bias, nullptr,
-                                      nullptr, stream);
+                                      nullptr, 0, stream);
 }
 
 int egp_lstm_group_bwd_len_f32(const float *const *dh_out, int32_t ld_dh, const float *gates_save, const float *cells_save, const float *w_hh,
                                int32_t T, int32_t B, int32_t hidden, int32_t n_problems, int32_t reverse_mask, float *d_pre, float *d_bias,
-                               const int32_t *seq_order, const int32_t *seq_steps, void *stream) {
+                               const int32_t *seq_order, const int32_t *seq_steps, int32_t leave_skipped, void *stream) {
     EGP_REQUIRE((seq_order == nullptr) == (seq_steps == nullptr), "seq_order and seq_steps go together");
     EGP_REQUIRE(lstm_mfma(), "grouped LSTM sweeps need the matrix-core kernels (EGP_LSTM_MFMA=0 is set)");
     EGP_REQUIRE(hidden == 64 || hidden == 128, "egp_lstm kernels are built for hidden size 64 and 128");
@@ -748,7 +751,7 @@ int egp_lstm_group_bwd_len_f32(const float *const *dh_out, int32_t ld_dh, const 
         EGP_REQUIRE(dh_out[p], "NULL d h_out");
         g.dh[p] = dh_out[p];
     }
-    g.order = seq_order; g.steps = seq_steps;
+    g.order = seq_order; g.steps = seq_steps; g.leave_skipped = seq_steps && leave_skipped;
     launch_bwd_mfma(hidden, n_problems, gates_save, cells_save, w_hh, T, B, g, d_pre, (hipStream_t)stream);
     return lstm_launch_check("k_lstm_bwd_mfma (group)");
 }

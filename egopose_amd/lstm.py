@@ -173,13 +173,16 @@ class LstmGroup(torch.autograd.Function):
         base, esz = h_buf.data_ptr(), h_buf.element_size()
         ptrs = (C.c_void_p * P)(*[base + esz * (((p // width) * (T + 2) + 1) * B * W + (p % width) * H) for p in pord])
         order, steps = (ragged.order, ragged.steps) if ragged is not None else (None, None)
+        # with row lists every later product visits only the rows the workgroups stepped through: the skipped steps of the
+        # (HBM-bound) sweeps need not be filled with zeros
+        leave = int(rows is not None and train and os.environ.get("EGP_LSTM_LEAVE_SKIPPED", "1") != "0")
         L.check(lib.egp_lstm_group_fwd_len_f32(_p(gx), _p(w_hh_all), T, B, H, P, kmask, ptrs, W,
-                                               _p(gx if train else None), _p(cells), _p(order), _p(steps), _s()), "egp_lstm_group_fwd_len_f32")
+                                               _p(gx if train else None), _p(cells), _p(order), _p(steps), leave, _s()), "egp_lstm_group_fwd_len_f32")
         outs = tuple(h_buf[i, 1:T + 1] for i in range(n_out))
         if train:
             ctx.save_for_backward(x2, w_in, w_hh_all, h_buf, gx, cells)
             ctx.meta = (T, B, D, H, P, width, reverse_mask)
-            ctx.ragged, ctx.rows, ctx.pord, ctx.nf, ctx.kmask = ragged, rows, pord, nf, kmask
+            ctx.ragged, ctx.rows, ctx.pord, ctx.nf, ctx.kmask, ctx.leave = ragged, rows, pord, nf, kmask, leave
         return outs
 
     @staticmethod
@@ -196,8 +199,9 @@ class LstmGroup(torch.autograd.Function):
         dpre = torch.empty(T * B, P * 4 * H, dtype=x2.dtype, device=x2.device)
         db = torch.zeros(P, 4 * H, dtype=x2.dtype, device=x2.device)
         order, steps = (ragged.order, ragged.steps) if ragged is not None else (None, None)
+        leave = int(bool(ctx.leave) and not ctx.needs_input_grad[0])     # (d_x = d_pre W_in reads every row)
         L.check(lib.egp_lstm_group_bwd_len_f32(ptrs, W, _p(gates), _p(cells), _p(w_hh_all), T, B, H, P, kmask, _p(dpre), _p(db),
-                                               _p(order), _p(steps), _s()), "egp_lstm_group_bwd_len_f32")
+                                               _p(order), _p(steps), leave, _s()), "egp_lstm_group_bwd_len_f32")
         d3 = dpre.view(T, B, P * 4 * H)
         use_g = G.enabled()
         nfc = nf * 4 * H
