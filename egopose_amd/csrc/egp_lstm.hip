@@ -405,11 +405,13 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
 #undef EGP_LSTM_FETCH_GX
     // the steps a ragged forward-running workgroup skipped: zeros (a weight gradient multiplies these rows with a zero d_pre,
     // and 0 * whatever an uninitialised buffer holds may be NaN)
-    if (!grp.leave_skipped)
-        for (int t = Tp; t < T; ++t)
+    // (leave_skipped: zeros only up to the longest sequence of the aligned group of 8 positions -- the granularity of the
+    //  caller's row lists, which must not meet an unwritten row --, nothing beyond)
+    const int Tz = grp.leave_skipped ? lstm_group_steps<8>(grp, reverse, r0 & ~7, B, T) : T;
+    for (int t = Tp; t < Tz; ++t)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                if (FULL || live[q]) h_out[((long)t * B + rowc[q]) * ld_h + u] = 0.f;
+        for (int q = 0; q < NQ; ++q)
+            if (FULL || live[q]) h_out[((long)t * B + rowc[q]) * ld_h + u] = 0.f;
 }
 
 template <int NQ, int LH, bool FULL>
@@ -451,12 +453,12 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
     }
     // ragged forward-running problems: the steps the forward sweep skipped carry no gradient (their d_pre is written as zeros)
     const int Tp = lstm_group_steps<ROWS>(grp, reverse, r0, B, T);
-    if (!grp.leave_skipped)
-        for (int t = Tp; t < T; ++t)
+    const int Tz = grp.leave_skipped ? lstm_group_steps<8>(grp, reverse, r0 & ~7, B, T) : T;     // (as in the forward kernel)
+    for (int t = Tp; t < Tz; ++t)
 #pragma unroll
-            for (int qq = 0; qq < NP; ++qq)
-                if (FULL || live[qq])
-                    *reinterpret_cast<f32x4 *>(dpre + ((long)t * B + rowc[qq]) * ld + 4 * ((threadIdx.x + NT * qq) % LH)) = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qq = 0; qq < NP; ++qq)
+            if (FULL || live[qq])
+                *reinterpret_cast<f32x4 *>(dpre + ((long)t * B + rowc[qq]) * ld + 4 * ((threadIdx.x + NT * qq) % LH)) = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #define EGP_LSTM_FETCH(STEP, D)                                                                      \
     {                                                                                                \

@@ -393,6 +393,11 @@ def test_ragged_grouped_sweeps_match_the_full_ones_where_it_counts(T, B, with_ro
         torch.manual_seed(3)
         rnn = RNN(128, 128, "lstm", bi_dir=True).cuda()
         rnn.ragged = ragged
+        # what the sweeps leave unwritten must not be read by anything: hand the allocator blocks full of NaN to reuse
+        for rows_ in (T * B, (T + 2) * B):
+            for width in (128, 512, 1024):
+                junk = torch.full((rows_, width), float("nan"), device="cuda")
+                del junk
         out = rnn(x)
         out.backward(dy)                                     # (= d/d out of sum(out * dy), without touching unwritten rows)
         res.append((out.detach(), {k: p.grad.clone() for k, p in rnn.named_parameters()}))
