@@ -86,6 +86,7 @@ struct Server {
     std::vector<int> e0, e1;                  // env range of each slice
     int *d_block_slice = nullptr;
     unsigned long long *h_go = nullptr, *hd_go = nullptr;   // [n_slices * 8]
+    bool go_in_vram = false;                  // the go words live in fine-grained device memory (host writes through the BAR)
     int *h_err = nullptr, *hd_err = nullptr;
     unsigned long long seq = 1, base = 0;     // next free sequence number / first substep of the env-step in flight
     std::unique_ptr<std::atomic<int>[]> dirty;   // some qM row of the slice changed since the kernel last read it
@@ -206,6 +207,15 @@ struct egp_engine {
     bool zero_copy = false;                   // K1 reads state rows / writes torques in pinned host memory directly
     bool flag_poll = false;                   // leader polls a pinned completion flag instead of hipStreamSynchronize
     double *hd_state = nullptr, *hd_torque = nullptr, *hd_qM = nullptr, *hd_ee = nullptr;   // device-side aliases of h_state / h_torque / h_qM
+    // Resident-K1 mode: the slices' go words live in FINE-GRAINED DEVICE memory that the host threads write through the PCIe
+    // BAR (posted stores); the resident waves then poll HBM instead of host memory -- one PCIe read round trip less per
+    // substep. Opt-in (EGP_BAR_GO=1): T_sample -1 .. -3 ms on two boxes, nothing on a third, i.e. within the spread.
+    // The state rows stay in pinned host memory in any case: mirroring them the same
+    // way was built and measured (tools/probes/bar_pingpong.hip: 4.7 instead of 8.1 us per round trip for ONE wave's four
+    // rows), but a host thread's write-combined stores move ~0.4 us per env and substep one after the other where the
+    // waves' PCIe reads run in parallel: T_sample 102 -> 118 ms with every row mirrored, and erratic (100 .. 270 ms)
+    // when only env-steps with few running envs used the mirror.
+    bool bar_go = false;
     bool server_ok = false;                   // resident-K1 mode allowed (EGP_SERVER, block budget)
     bool server_dyn_ok = false;               // ... also with device dynamics (its 110 kB of LDS: one workgroup per CU)
     bool device_dynamics = false;             // K8 supplies qM / qfrc_bias from the drained (qpos, qvel) each substep
@@ -849,6 +859,10 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
             E->hd_reset_list = (int *)p;
     }
     memset(E->h_state, 0, N * E->ld_s * sizeof(double));
+    {
+        const char *bg = getenv("EGP_BAR_GO");
+        E->bar_go = E->zero_copy && E->hd_state && bg && atoi(bg) != 0;       // opt-in: within the run-to-run spread (see the field)
+    }
     memset(E->h_qM, 0, N * E->ld_m * sizeof(double));
     memset(E->h_headz, 0, N * sizeof(double));
     E->groups = std::vector<Group>(E->n_groups);
@@ -938,12 +952,21 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
                 }
                 E_TRY(hipMalloc((void **)&S.d_block_slice, nb * sizeof(int)));
                 E_TRY(hipMemcpy(S.d_block_slice, block_slice.data(), nb * sizeof(int), hipMemcpyHostToDevice));
-                E_TRY(hipHostMalloc((void **)&S.h_go, (size_t)ns * 8 * sizeof(unsigned long long), hipHostMallocDefault));
-                E_TRY(hipHostMalloc((void **)&S.h_err, 64, hipHostMallocDefault));
-                memset(S.h_go, 0, (size_t)ns * 8 * sizeof(unsigned long long));
-                *S.h_err = 0;
                 void *p = nullptr;
-                E_TRY(hipHostGetDevicePointer(&p, S.h_go, 0));   S.hd_go = (unsigned long long *)p;
+                if (E->bar_go && hipExtMallocWithFlags(&p, (size_t)ns * 8 * sizeof(unsigned long long), hipDeviceMallocFinegrained) == hipSuccess && p) {
+                    // go words next to the state mirror: written by the host through the BAR, polled by the waves in HBM
+                    S.h_go = S.hd_go = (unsigned long long *)p;
+                    S.go_in_vram = true;
+                    E_TRY(hipMemset(p, 0, (size_t)ns * 8 * sizeof(unsigned long long)));
+                    E_TRY(hipDeviceSynchronize());
+                } else {
+                    (void)hipGetLastError();
+                    E_TRY(hipHostMalloc((void **)&S.h_go, (size_t)ns * 8 * sizeof(unsigned long long), hipHostMallocDefault));
+                    memset(S.h_go, 0, (size_t)ns * 8 * sizeof(unsigned long long));
+                    E_TRY(hipHostGetDevicePointer(&p, S.h_go, 0));   S.hd_go = (unsigned long long *)p;
+                }
+                E_TRY(hipHostMalloc((void **)&S.h_err, 64, hipHostMallocDefault));
+                *S.h_err = 0;
                 E_TRY(hipHostGetDevicePointer(&p, S.h_err, 0));  S.hd_err = (int *)p;
                 if (const char *tr = getenv("EGP_SERVER_TRACE")) {
                     if (atoi(tr) != 0) {
@@ -1001,8 +1024,8 @@ int egp_engine_destroy(egp_engine *E) {
             Server &S = G.srv;
             void *dv[] = {S.d_block_slice, S.d_trace};
             for (void *p : dv) if (p) (void)hipFree(p);
-            void *hv[] = {S.h_go, S.h_err};
-            for (void *p : hv) if (p) (void)hipHostFree(p);
+            if (S.h_go) { if (S.go_in_vram) (void)hipFree(S.h_go); else (void)hipHostFree(S.h_go); }
+            if (S.h_err) (void)hipHostFree(S.h_err);
         }
         if (G.active) (void)hipHostFree(G.active);
         if (G.d_done) (void)hipFree(G.d_done);
