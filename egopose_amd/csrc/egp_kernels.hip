@@ -991,15 +991,66 @@ __device__ __forceinline__ void zf_merge_column(int dim, int n_tiles, const doub
     }
 }
 
-// one block: the merged state of a batch with many tiles (few tiles: k_zf_apply merges them itself)
-__global__ __launch_bounds__(128) void k_zf_merge(int dim, int n_tiles, const double *__restrict__ ws,
-                                                  const double *__restrict__ st_in, double *__restrict__ st_out) {
-    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
-        double cnt, mean, S;
-        zf_merge_column(dim, n_tiles, ws, st_in, c, cnt, mean, S);
-        st_out[1 + c] = mean;
-        st_out[1 + dim + c] = S;
-        if (c == 0) st_out[0] = cnt;
+// one block: the merged state of a batch with many tiles (few tiles: k_zf_apply merges them itself). 8 tile groups x 128
+// columns: group g merges its contiguous eighth of the tiles in order, then group 0 merges the eight results in order
+// through LDS -- eight times fewer dependent rounds of loads than one pass over all tiles (90 -> 15 us for 512 tiles).
+__global__ __launch_bounds__(1024) void k_zf_merge(int dim, int n_tiles, const double *__restrict__ ws,
+                                                   const double *__restrict__ st_in, double *__restrict__ st_out) {
+    __shared__ double s_n[8], s_mean[8][128], s_S[8][128];
+    const int g = threadIdx.x >> 7, lc = threadIdx.x & 127;
+    const int per = (n_tiles + 7) / 8, q0 = g * per, q1 = min(n_tiles, q0 + per);
+    for (int cb = 0; cb < dim; cb += 128) {
+        const int c = cb + lc;
+        double cnt = 0.0, mean = 0.0, S = 0.0;
+        if (c < dim && q0 < q1) {
+            for (int qa = q0; qa < q1; qa += 8) {
+                double nb[8], mb[8], Sb[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int q = qa + i;
+                    const double *pp = ws + (long)(q < q1 ? q : q0) * (1 + 2 * dim);
+                    nb[i] = q < q1 ? pp[0] : 0.0;
+                    mb[i] = pp[1 + c];
+                    Sb[i] = pp[1 + dim + c];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (nb[i] > 0.0) {
+                        if (cnt == 0.0) {
+                            cnt = nb[i]; mean = mb[i]; S = Sb[i];
+                        } else {
+                            const double d = mb[i] - mean, tot = cnt + nb[i];
+                            S = S + Sb[i] + d * d * (cnt * nb[i] / tot);
+                            mean = mean + d * (nb[i] / tot);
+                            cnt = tot;
+                        }
+                    }
+                }
+            }
+        }
+        s_mean[g][lc] = mean; s_S[g][lc] = S;
+        if (lc == 0 && cb == 0) s_n[g] = cnt;            // (the count is the same for every column)
+        __syncthreads();
+        if (g == 0 && c < dim) {
+            double C = st_in[0], M = st_in[1 + c], SS = st_in[1 + dim + c];
+            for (int j = 0; j < 8; ++j) {
+                const double nb = s_n[j];
+                if (nb > 0.0) {
+                    if (C == 0.0) {
+                        C = nb; M = s_mean[j][lc]; SS = s_S[j][lc];
+                    } else {
+                        const double d = s_mean[j][lc] - M, tot = C + nb;
+                        SS = SS + s_S[j][lc] + d * d * (C * nb / tot);
+                        M = M + d * (nb / tot);
+                        C = tot;
+                    }
+                }
+            }
+            st_out[1 + c] = M;
+            st_out[1 + dim + c] = SS;
+            if (c == 0) st_out[0] = C;
+        }
+        __syncthreads();
     }
 }
 
@@ -1061,20 +1112,34 @@ __device__ __forceinline__ void gae_coeffs(const T *r, const T *mk, const T *v, 
 template <typename T>
 __global__ __launch_bounds__(256) void k_gae_summary(const T *__restrict__ r, const T *__restrict__ mk,
                                                      const T *__restrict__ v, int n, double gamma, double gt,
-                                                     double *__restrict__ chunkP, double *__restrict__ chunkA) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+                                                     double *__restrict__ chunkP, double *__restrict__ chunkA,
+                                                     double *__restrict__ blockP, double *__restrict__ blockA) {
+    __shared__ double sP[256], sA[256];
+    const int t = threadIdx.x, ch = blockIdx.x * blockDim.x + t;
     const int i0 = ch * GAE_CHUNK;
-    if (i0 >= n) return;
-    const int i1 = min(n, i0 + GAE_CHUNK);
-    double P = 1.0, A = 0.0;
-    for (int i = i1 - 1; i >= i0; --i) {
-        double d, c;
-        gae_coeffs<T>(r, mk, v, i, n, gamma, gt, d, c);
-        A = d + c * A;      // value at i given zero carry
-        P = c * P;          // sensitivity of a_i0 to the carry entering the chunk
+    double P = 1.0, A = 0.0;                              // (a chunk past the end: the identity map)
+    if (i0 < n) {
+        const int i1 = min(n, i0 + GAE_CHUNK);
+        for (int i = i1 - 1; i >= i0; --i) {
+            double d, c;
+            gae_coeffs<T>(r, mk, v, i, n, gamma, gt, d, c);
+            A = d + c * A;      // value at i given zero carry
+            P = c * P;          // sensitivity of a_i0 to the carry entering the chunk
+        }
+        chunkP[ch] = P;
+        chunkA[ch] = A;
     }
-    chunkP[ch] = P;
-    chunkA[ch] = A;
+    // the block's 256 chunk maps composed in order (f_0 o f_1 o ... o f_255: the sweep runs right to left)
+    sP[t] = P; sA[t] = A;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        if ((t & (2 * off - 1)) == 0) {
+            sA[t] = sA[t] + sP[t] * sA[t + off];
+            sP[t] = sP[t] * sP[t + off];
+        }
+        __syncthreads();
+    }
+    if (t == 0) { blockP[blockIdx.x] = sP[0]; blockA[blockIdx.x] = sA[0]; }
 }
 
 // one block: carry[ch] = a at the first element of chunk ch+1 (0 for the last chunk)
@@ -1123,15 +1188,37 @@ __global__ __launch_bounds__(1024) void k_gae_scan(int n_chunks, const double *_
 template <typename T>
 __global__ __launch_bounds__(256) void k_gae_replay(const T *__restrict__ r, const T *__restrict__ mk,
                                                     const T *__restrict__ v, int n, double gamma, double gt,
-                                                    const double *__restrict__ carry, T *__restrict__ adv,
+                                                    const double *__restrict__ chunkP, const double *__restrict__ chunkA,
+                                                    const double *__restrict__ block_carry, T *__restrict__ adv,
                                                     T *__restrict__ ret, double *__restrict__ part) {
     __shared__ double s_n[256], s_mean[256], s_m2[256];
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = threadIdx.x, ch = blockIdx.x * blockDim.x + t;
     const int i0 = ch * GAE_CHUNK;
+    // carry entering this thread's chunk = (f_{t+1} o ... o f_255)(carry entering the block): suffix scan of the chunk maps
+    // (s_n / s_mean double as the scan's P / A arrays; they are rewritten after the barrier below)
+    {
+        const bool real = i0 < n;
+        s_n[t] = real ? chunkP[ch] : 1.0;
+        s_mean[t] = real ? chunkA[ch] : 0.0;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            double pP = 1.0, pA = 0.0;
+            if (t + off < 256) { pP = s_n[t + off]; pA = s_mean[t + off]; }
+            __syncthreads();
+            if (t + off < 256) {
+                s_mean[t] = s_mean[t] + s_n[t] * pA;
+                s_n[t] = s_n[t] * pP;
+            }
+            __syncthreads();
+        }
+    }
+    const double bc = block_carry[blockIdx.x];
+    const double carry_in = t < 255 ? s_mean[t + 1] + s_n[t + 1] * bc : bc;
+    __syncthreads();
     double cnt = 0.0, mean = 0.0, m2 = 0.0;
     if (i0 < n) {
         const int i1 = min(n, i0 + GAE_CHUNK);
-        double A = carry[ch];
+        double A = carry_in;
         for (int i = i1 - 1; i >= i0; --i) {
             double d, c;
             gae_coeffs<T>(r, mk, v, i, n, gamma, gt, d, c);
@@ -1166,11 +1253,13 @@ __global__ __launch_bounds__(256) void k_gae_replay(const T *__restrict__ r, con
     }
 }
 
-// stats = {n, mean, M2}: serial Chan merge of the block partials (fixed order)
-__global__ void k_gae_stats(int n_parts, const double *__restrict__ part, double *__restrict__ stats) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// stats = {n, mean, M2}: Chan merge of the block partials in a fixed order (deterministic): 256 threads take contiguous
+// runs of partials, then a tree over the threads (one thread walking 200 partials took 45 us of dependent divisions)
+__global__ __launch_bounds__(256) void k_gae_stats(int n_parts, const double *__restrict__ part, double *__restrict__ stats) {
+    __shared__ double s_n[256], s_mean[256], s_m2[256];
+    const int t = threadIdx.x, per = (n_parts + 255) / 256;
     double cnt = 0.0, mean = 0.0, m2 = 0.0;
-    for (int p = 0; p < n_parts; ++p) {
+    for (int p = t * per; p < min(n_parts, (t + 1) * per); ++p) {
         const double nb = part[p * 3];
         if (nb > 0.0) {
             const double tot = cnt + nb, d = part[p * 3 + 1] - mean;
@@ -1179,7 +1268,21 @@ __global__ void k_gae_stats(int n_parts, const double *__restrict__ part, double
             cnt = tot;
         }
     }
-    stats[0] = cnt; stats[1] = mean; stats[2] = m2;
+    s_n[t] = cnt; s_mean[t] = mean; s_m2[t] = m2;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {            // neighbours first: the merge order follows the partials' order
+        if ((t & (2 * off - 1)) == 0) {
+            const double na = s_n[t], nb = s_n[t + off];
+            if (nb > 0.0) {
+                const double tot = na + nb, d = s_mean[t + off] - s_mean[t];
+                s_m2[t] += s_m2[t + off] + d * d * (na * nb / tot);
+                s_mean[t] += d * (nb / tot);
+                s_n[t] = tot;
+            }
+        }
+        __syncthreads();
+    }
+    if (t == 0) { stats[0] = s_n[0]; stats[1] = s_mean[0]; stats[2] = s_m2[0]; }
 }
 
 template <typename T>
@@ -1596,7 +1699,7 @@ static int launch_zfilter_src(const ZfSrc<T> &src, const int *active, int n, int
     const bool fused = update && nt <= ZF_FUSED_TILES;
     if (update) {
         k_zf_partial<T><<<dim3(nt), dim3(1024), 0, (hipStream_t)stream>>>(src, active, n, dim, rpt, (double *)ws);
-        if (!fused) k_zf_merge<<<dim3(1), dim3(128), 0, (hipStream_t)stream>>>(dim, nt, (const double *)ws, st_in, st_out);
+        if (!fused) k_zf_merge<<<dim3(1), dim3(1024), 0, (hipStream_t)stream>>>(dim, nt, (const double *)ws, st_in, st_out);
         int rc = after_launch("k_zf_partial/merge");
         if (rc != EGP_OK) return rc;
     }
@@ -1648,7 +1751,7 @@ static int launch_post_step(egp_ctx *ctx, const double *qpos, const double *qvel
                                                                        ctx->expert_rows_f64, prev_qpos, ee_wpos, tcur, frame, endf,
                                                                        end_reward, reward, cinfo);
     const bool fused = !identity && nt <= ZF_FUSED_TILES;
-    if (!identity && !fused) k_zf_merge<<<dim3(1), dim3(128), 0, s>>>(dim, nt, (const double *)ws, st_in, st_out);
+    if (!identity && !fused) k_zf_merge<<<dim3(1), dim3(1024), 0, s>>>(dim, nt, (const double *)ws, st_in, st_out);
     const int rows_per_block = fused ? 8 : (n <= 8192 ? 2 : 16);
     k_zf_apply<double><<<dim3((n + rows_per_block - 1) / rows_per_block), dim3(128), 2 * dim * sizeof(double), s>>>(
         src, n, dim, rows_per_block, identity || fused ? st_in : st_out, clip, y, y2, nullptr, identity,
@@ -1663,12 +1766,15 @@ static int launch_gae(const T *r, const T *mk, const T *v, int n, double gamma, 
     EGP_REQUIRE(n > 0, "n must be positive");
     const int n_chunks = (n + GAE_CHUNK - 1) / GAE_CHUNK;
     const int n_blocks = (n_chunks + 255) / 256;
-    double *chunkP = (double *)ws, *chunkA = chunkP + n_chunks, *carry = chunkA + n_chunks, *part = carry + n_chunks;
+    // three levels: 32-sample chunks (one thread each) -> blocks of 256 chunks (composed / scanned in LDS) -> ONE block over the
+    // block maps. (Two levels with one block scanning all chunks took 177 of 364 us at 1.6 M samples.)
+    double *chunkP = (double *)ws, *chunkA = chunkP + n_chunks, *part = chunkA + n_chunks, *blockP = part + 3 * n_blocks,
+           *blockA = blockP + n_blocks, *block_carry = blockA + n_blocks;
     hipStream_t s = (hipStream_t)stream;
-    k_gae_summary<T><<<dim3(n_blocks), dim3(256), 0, s>>>(r, mk, v, n, gamma, gamma * tau, chunkP, chunkA);
-    k_gae_scan<<<dim3(1), dim3(1024), 0, s>>>(n_chunks, chunkP, chunkA, carry);
-    k_gae_replay<T><<<dim3(n_blocks), dim3(256), 0, s>>>(r, mk, v, n, gamma, gamma * tau, carry, adv, ret, part);
-    k_gae_stats<<<dim3(1), dim3(64), 0, s>>>(n_blocks, part, stats);
+    k_gae_summary<T><<<dim3(n_blocks), dim3(256), 0, s>>>(r, mk, v, n, gamma, gamma * tau, chunkP, chunkA, blockP, blockA);
+    k_gae_scan<<<dim3(1), dim3(1024), 0, s>>>(n_blocks, blockP, blockA, block_carry);
+    k_gae_replay<T><<<dim3(n_blocks), dim3(256), 0, s>>>(r, mk, v, n, gamma, gamma * tau, chunkP, chunkA, block_carry, adv, ret, part);
+    k_gae_stats<<<dim3(1), dim3(256), 0, s>>>(n_blocks, part, stats);
     return after_launch("k_gae_*");
 }
 
@@ -1778,7 +1884,7 @@ int egp_post_step_f64(egp_ctx *c, const double *qpos, const double *qvel, const 
 int64_t egp_gae_workspace_bytes(int32_t n) {
     const int64_t n_chunks = ((int64_t)n + GAE_CHUNK - 1) / GAE_CHUNK;
     const int64_t n_blocks = (n_chunks + 255) / 256;
-    return (3 * n_chunks + 3 * n_blocks) * (int64_t)sizeof(double);
+    return (2 * n_chunks + 6 * n_blocks) * (int64_t)sizeof(double);
 }
 int egp_gae_f64(const double *r, const double *m, const double *v, int32_t n, double gamma, double tau, double *adv,
                 double *ret, double *stats, void *ws, void *s) {
