@@ -272,9 +272,10 @@ def ragged_order(seq_steps, device, T=None):
         t_wg = np.minimum(np.repeat(wg, 8)[:B], int(T))                      # steps the workgroup of position p runs
         n = int(t_wg.sum())
         if n < 0.9 * T * B:                                                  # otherwise not worth the indirection
-            seq = np.repeat(order, t_wg)
-            tt = np.arange(n) - np.repeat(np.cumsum(t_wg) - t_wg, t_wg)
-            rows = torch.as_tensor(np.sort(tt * B + seq), dtype=torch.int64, device=device)
+            t_seq = np.empty(B, np.int64)
+            t_seq[order] = t_wg                                              # steps of the workgroup that sequence b sits in
+            stepped = np.arange(int(T), dtype=np.int64)[:, None] < t_seq[None, :]      # (T, B): row t * B + b is stepped through
+            rows = torch.as_tensor(np.flatnonzero(stepped), dtype=torch.int64, device=device)     # ascending, no sort
     return Ragged(torch.as_tensor(order, dtype=torch.int32, device=device), torch.as_tensor(st_sorted, dtype=torch.int32, device=device),
                   rows, B, T)
 
