@@ -275,6 +275,20 @@ __device__ __forceinline__ int lstm_group_steps(const LstmGroup &grp, int revers
 // parameters so that the timestep body is straight-line code: with a branch around any load or store the compiler's
 // s_waitcnt pass no longer knows how many memory operations are outstanding and waits for ALL of them (vmcnt(0))
 // before touching a prefetched register -- i.e. for the acknowledgement of the stores it has just issued, every step.
+// tools/probes/lstm_trace.hip compiles this file with EGP_LSTM_TRACE = a workgroup index: per-phase cycle sums of wave 0 of that
+// workgroup of the LAST problem of a grouped forward launch (a problem that runs backward in time: every step)
+#ifdef EGP_LSTM_TRACE
+__device__ long long g_lstm_trace[8];
+#define EGP_LT_DECL long long lt_acc[6] = {0, 0, 0, 0, 0, 0}, lt_prev = 0; const bool lt_on = blockIdx.x == EGP_LSTM_TRACE && blockIdx.y == gridDim.y - 1 && threadIdx.x == 0
+#define EGP_LT_START if (lt_on) lt_prev = (long long)__builtin_readcyclecounter()
+#define EGP_LT(i) if (lt_on) { const long long lt_now = (long long)__builtin_readcyclecounter(); lt_acc[i] += lt_now - lt_prev; lt_prev = lt_now; }
+#define EGP_LT_END(steps) if (lt_on) { for (int i = 0; i < 6; ++i) g_lstm_trace[i] = lt_acc[i]; g_lstm_trace[6] = (steps); }
+#else
+#define EGP_LT_DECL do { } while (0)
+#define EGP_LT_START do { } while (0)
+#define EGP_LT(i) do { } while (0)
+#define EGP_LT_END(steps) do { } while (0)
+#endif
 #ifndef EGP_LSTM_PD1
 #define EGP_LSTM_PD1 (NQ == 1 ? 4 : 4)
 #endif
@@ -326,8 +340,10 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
     }
 
     // one timestep: products, cell update in registers, stores, barrier
+    EGP_LT_DECL;
     auto do_step = [&](const int step, const int par, const f32x4 (&init)[NQ]) {
         const int t = reverse ? T - 1 - step : step;
+        EGP_LT(0);                                           // since the end of the previous step: loop overhead, prefetch issue, waits on the tile
         // the whole hidden tile of this lane's rows first (16 reads per quad in flight, one exposed LDS latency) ...
         // (64 hidden columns at a time: with LH = 128 the registers do not hold the whole row next to W_hh)
         f32x4 acc[NQ], acc2[NQ];
@@ -342,6 +358,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
 #pragma unroll
                 for (int k4 = 0; k4 < KCH / 4; ++k4) hv[q][k4] = *reinterpret_cast<const float4 *>(&s_h[par][4 * q + sub][kc + 4 * k4]);
             __builtin_amdgcn_sched_barrier(0);
+            EGP_LT(1);                                       // hidden-tile reads issued (not yet waited for)
             // ... then the products; two accumulator chains per quad cover the dependent-issue latency (four: no gain)
 #pragma unroll
             for (int k4 = 0; k4 < KCH / 4; ++k4)
@@ -353,6 +370,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
                     acc2[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[kc + 4 * k4 + 3], hv[q][k4].w, acc2[q], 0, 0, 0);
                 }
         }
+        EGP_LT(2);                                           // products issued
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const f32x4 a = acc[q] + acc2[q];
@@ -370,12 +388,15 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
                 }
             }
         }
+        EGP_LT(3);                                           // cell update, LDS / global stores issued
         __syncthreads();       // the whole new hidden tile before the next step's products (s_h is double-buffered)
+        EGP_LT(4);                                           // barrier
     };
 
 #pragma unroll
     for (int d = 0; d < PD; ++d) EGP_LSTM_FETCH_GX(d, pre[d])
     __syncthreads();
+    EGP_LT_START;
     int s0 = 0;
     for (; s0 + PD <= Tp; s0 += PD) {
         // this iteration's tiles move to `cur`, then ALL loads of the next iteration are issued before the first step:
@@ -403,6 +424,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
         do_step(s0 + d, d & 1, last);
     }
 #undef EGP_LSTM_FETCH_GX
+    EGP_LT_END(Tp);
     // the steps a ragged forward-running workgroup skipped: zeros (a weight gradient multiplies these rows with a zero d_pre,
     // and 0 * whatever an uninitialised buffer holds may be NaN)
     // (leave_skipped: zeros only up to the longest sequence of the aligned group of 8 positions -- the granularity of the
