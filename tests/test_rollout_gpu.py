@@ -142,6 +142,59 @@ def test_value_front_end_adopts_the_policy_s_train_context(workspace, monkeypatc
         torch.testing.assert_close(a, b, rtol=0, atol=1e-6)
 
 
+def test_update_gradients_hip_path_vs_library_path_at_row_list_scale(workspace, monkeypatch):
+    """The update's first backward pass on a rollout batch big enough for everything the small golden fixtures do not reach
+    (ragged LSTM sweeps with row lists and unwritten skipped steps, the first MLP layer gathering its own input, split-K
+    weight gradients over > 4 096 rows): every parameter gradient of the HIP path against the same pass through the
+    library's products and torch's LSTM on the same batch and weights (lr = 0, one epoch: the gradients stay in .grad)."""
+    from egopose_amd import gemm as G, lstm as lstm_mod, nets as N
+    from egopose_amd.config import Config
+    from egopose_amd.train import Trainer
+    os.chdir(workspace)
+    cfg = Config("subject_03", create_dirs=False)
+    cfg.env_episode_len = 150
+    cfg.num_optim_epoch = 1
+    tr = Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=96, num_threads=4, num_groups=2)
+    tr.pre_iter_update(0)
+    batch, log = tr.agent.sample(96 * 80)
+    for opt in (tr.optimizer_policy, tr.optimizer_value):
+        for grp in opt.param_groups:
+            grp["lr"] = 0.0
+    named = [(n + "." + k, p) for n in ("policy_net", "policy_vs_net", "value_net", "value_vs_net") for k, p in getattr(tr, n).named_parameters()
+             if p.requires_grad]
+    before = [p.detach().clone() for _, p in named]
+    rows_used, fused_used = [], []
+    real_group, real_head = lstm_mod.LstmGroup.forward, G.gather_mlp_head
+
+    def run(hip):
+        monkeypatch.setenv("EGP_GEMM", "hip" if hip else "torch")
+        monkeypatch.setattr(N, "_LSTM_IMPL", "hip" if hip else "torch")
+        for _, p in named:
+            p.grad = None
+        tr.agent.update_params(batch)
+        torch.cuda.synchronize()
+        return [p.grad.detach().clone() for _, p in named], dict(tr.agent.update_stats)
+
+    # spies: the row lists and the gathering first layer must actually be in play on the HIP pass
+    def spy_group(ctx, x, reverse_mask, P, width, train, ragged, *params):
+        rows_used.append(ragged is not None and ragged.rows is not None and ragged.rows.shape[0] >= 4096)
+        return real_group(ctx, x, reverse_mask, P, width, train, ragged, *params)
+    monkeypatch.setattr(lstm_mod.LstmGroup, "forward", staticmethod(spy_group))
+    monkeypatch.setattr(G, "gather_mlp_head", lambda *a, **k: (fused_used.append(1), real_head(*a, **k))[1])
+    g_hip, st_hip = run(True)
+    assert rows_used and all(rows_used), "the batch is too regular for row lists: %r" % (rows_used,)
+    assert fused_used, "the gathering first layer did not run"
+    g_lib, st_lib = run(False)
+    for (name, p), b0, a, b in zip(named, before, g_hip, g_lib):
+        assert torch.equal(p.detach(), b0), name                      # lr = 0: nothing moved between the two passes
+        scale = max(float(b.abs().max()), 1e-12)
+        err = float((a - b).abs().max()) / scale
+        assert err < 2e-4, "%s: gradient differs by %.2e of its largest element" % (name, err)
+    assert st_hip["value_loss"][0] == pytest.approx(st_lib["value_loss"][0], rel=1e-4)
+    assert st_hip["surr_loss"][0] == pytest.approx(st_lib["surr_loss"][0], rel=1e-3, abs=1e-5)
+    tr.close()
+
+
 def test_single_env_facade_matches_oracle_env(workspace, skel):
     """HumanoidEnv.reset/step + reward_func['quat_v3'] on a batch of one == the oracle's CPU env (eval-style use)."""
     from egopose_amd.config import Config
