@@ -312,11 +312,15 @@ def test_resident_engine_dealt_slices_are_bit_identical(ctx, skel, monkeypatch):
     pick = rng.randint(0, len(g["qpos"]), n)
     qpos0, qvel0 = g["qpos"][pick], g["qvel"][pick] * 0.2
     action = dev(rng.normal(size=(n, 52)) * 0.2)
-    masks = [(rng.rand(n) < p).astype(np.int32) for p in (0.6, 0.15, 0.03)]
-    masks[2][:8] = 1                                   # a crowded first slice: the case dealing is for
+    masks = [(rng.rand(n) < p).astype(np.int32) for p in (0.6, 0.5, 0.15, 0.03)]
+    masks[3][:8] = 1                                   # a crowded first slice: the case dealing is for
     out = {}
-    for bal in ("0", "1"):
-        monkeypatch.setenv("EGP_SERVER_BALANCE", bal)
+    for bal in ("0", "1", "by-cost"):
+        if bal == "by-cost":            # the default rule, with a physics step slow enough (3 us) for it to start dealing
+            monkeypatch.delenv("EGP_SERVER_BALANCE")
+            monkeypatch.setenv("EGP_SURROGATE_SUBSTEP_US", "3")
+        else:
+            monkeypatch.setenv("EGP_SERVER_BALANCE", bal)
         ph = SurrogatePhysics(skel, n)
         eng = RolloutEngine(ctx, ph, n, n_threads=6, n_groups=2)
         assert eng.substeps_per_launch == 15
@@ -331,9 +335,10 @@ def test_resident_engine_dealt_slices_are_bit_identical(ctx, skel, monkeypatch):
         out[bal] = (eng.qpos.cpu().numpy().copy(), eng.qvel.cpu().numpy().copy(), eng.ee_wpos.cpu().numpy().copy())
         eng.close()
         ph.close()
-    for a, b in zip(out["0"], out["1"]):
-        np.testing.assert_array_equal(a, b)
-    never = (masks[0] | masks[1] | masks[2]) == 0
+    for other in ("1", "by-cost"):
+        for a, b in zip(out["0"], out[other]):
+            np.testing.assert_array_equal(a, b)
+    never = (masks[0] | masks[1] | masks[2] | masks[3]) == 0
     assert never.any()
     np.testing.assert_array_equal(out["1"][0][never], qpos0[never])
     assert np.abs(out["1"][0][~never] - qpos0[~never]).max() > 0
