@@ -910,6 +910,91 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Thin products. A value function's output layer makes three of them per epoch -- y = X w (N = 1), dX = dy w^T under the
+// ReLU mask (K = 1) and dw = dy^T X (M = 1) -- that are one pass over the activations each: as 128-wide matrix-core tiles
+// they took 40 / 72 / 96 us for 105 MB, as plain float32 streaming kernels they are bound by those bytes. Products and
+// sums in float32 (fmaf), fixed order: the same class as the split-operand products.
+__global__ __launch_bounds__(256) void k_gemv_rows(GemmArgs g) {         // N == 1, A k-contiguous: C[m] = A[m][:] . B[:]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long bs = g.b_kc ? 1 : g.ldb;
+    const float floor_v = g.relu ? 0.f : -__builtin_inff();
+    for (long m = (long)blockIdx.x * 4 + wave; m < g.M; m += (long)gridDim.x * 4) {
+        const float *__restrict__ a = g.A + m * g.lda;
+        float acc = 0.f;
+        for (int k = lane; k < g.K; k += 64) acc = fmaf(a[k], g.B[k * bs], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) {
+            float x = fmaxf(acc + (g.bias ? g.bias[0] : 0.f), floor_v);
+            if (g.mask && !(g.mask[m * g.ldmask] > 0.f)) x = 0.f;
+            g.C[m * g.ldc] = x;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rank1(GemmArgs g) {             // K == 1: C[m][n] = A[m] * B[n] (+ bias, ReLU, mask)
+    const long as = g.a_kc ? g.lda : 1, bs = g.b_kc ? g.ldb : 1;
+    const float floor_v = g.relu ? 0.f : -__builtin_inff();
+    const long total = (long)g.M * g.N;
+    for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+        const long m = id / g.N;
+        const int n = (int)(id - m * g.N);
+        float x = fmaxf(fmaf(g.A[m * as], g.B[n * bs], g.bias ? g.bias[n] : 0.f), floor_v);
+        if (g.mask && !(g.mask[m * g.ldmask + n] > 0.f)) x = 0.f;
+        g.C[m * g.ldc + n] = x;
+    }
+}
+
+// M == 1, B given as [k][n], split-K / ones-column launch: workgroup z sums its k range of a[k] * B[k][:] (four waves take
+// every fourth row, 8 rows in flight each) into row z of the workspace, the ones column = sum of a[k]; k_gemm_reduce follows
+__global__ __launch_bounds__(256) void k_colsum(GemmArgs g) {
+    __shared__ float s_part[4][256 + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, z = blockIdx.x;
+    const long as = g.a_kc ? 1 : g.lda;
+    const int kbeg = z * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
+    const int n_out = g.N + (g.ones_col ? 1 : 0);
+    float *__restrict__ dst = g.ws + (long)z * g.ldws;                   // (M = 1: a split's block is one row)
+    for (int n0 = 0; n0 < g.N; n0 += 256) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};                             // columns n0 + lane + 64 j
+        for (int k = kbeg + wave; k < kend; k += 32) {
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = k + 4 * u < kend ? g.A[(long)(k + 4 * u) * as] : 0.f;
+            float b[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float *__restrict__ row = g.B + (long)min(k + 4 * u, kend - 1) * g.ldb + n0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[u][j] = n0 + lane + 64 * j < g.N ? row[lane + 64 * j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(a[u], b[u][j], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s_part[wave][lane + 64 * j] = acc[j];
+        __syncthreads();
+        if (wave == 0)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + lane + 64 * j;
+                if (n < g.N) dst[n] = (s_part[0][lane + 64 * j] + s_part[1][lane + 64 * j]) + (s_part[2][lane + 64 * j] + s_part[3][lane + 64 * j]);
+            }
+        __syncthreads();
+    }
+    if (g.ones_col) {                                                    // bias gradient: sum of a over the k range
+        float sa = 0.f;
+        for (int k = kbeg + threadIdx.x; k < kend; k += 256) sa += g.A[(long)k * as];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sa += __shfl_down(sa, off, 64);
+        if (lane == 0) s_part[wave][0] = sa;
+        __syncthreads();
+        if (threadIdx.x == 0) dst[n_out - 1] = (s_part[0][0] + s_part[1][0]) + (s_part[2][0] + s_part[3][0]);
+    }
+}
+
 // partial sums -> C (+ the ones column -> bias_grad), splits added in index order
 __global__ __launch_bounds__(256) void k_gemm_reduce(const float *__restrict__ ws_, int ldws, int splits, int M, int N, int n_out, float *__restrict__ C,
                                                      long ldc, float *__restrict__ bias_grad, int accumulate) {
@@ -1066,6 +1151,31 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
         EGP_REQUIRE(!d->c_rows || !partial, "c_rows (scatter) does not go with split-K / bias-gradient launches");
         EGP_REQUIRE(!d->a_rows || d->a_src_rows > 0, "a_rows needs a_src_rows (rows of the gathered source)");
         EGP_REQUIRE(!d->b_krows || d->b_src_rows > 0, "b_krows needs b_src_rows (rows of the gathered source)");
+    }
+    // thin products (see k_gemv_rows / k_rank1 / k_colsum): plain float32 streaming kernels, no tiles
+    if (!fused_io && !(getenv("EGP_GEMM_THIN") && atoi(getenv("EGP_GEMM_THIN")) == 0)) {
+        if (d->N == 1 && !partial && d->a_kcontig && d->K >= 1) {
+            const long blocks = std::min<long>(((long)d->M + 3) / 4, 256 * 16);
+            k_gemv_rows<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(g);
+            return after_launch("k_gemv_rows");
+        }
+        if (d->K == 1 && !partial) {
+            const long blocks = std::min<long>(((long)d->M * d->N + 255) / 256, 256 * 32);
+            k_rank1<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(g);
+            return after_launch("k_rank1");
+        }
+        if (d->M == 1 && partial && !d->b_kcontig && d->K >= 1) {
+            const int per_rows = (d->K + splits - 1) / splits;
+            g.k_per_split = per_rows < 1 ? 1 : per_rows;
+            const int zs1 = (d->K + g.k_per_split - 1) / g.k_per_split;
+            k_colsum<<<dim3((unsigned)zs1), dim3(256), 0, s>>>(g);
+            int rc1 = after_launch("k_colsum");
+            if (rc1 != EGP_OK) return rc1;
+            const int n_out1 = d->N + ones;
+            k_gemm_reduce<<<dim3((unsigned)((n_out1 + 255) / 256)), dim3(256), 0, s>>>(d->workspace, g.ldws, zs1, 1, d->N, n_out1, d->C, d->ldc, d->bias_grad,
+                                                                                    d->accumulate);
+            return after_launch("k_gemm_reduce");
+        }
     }
     const int n_out = d->N + ones;
     const bool bn64 = n_out <= 64;                 // narrow outputs: 64-column tiles
