@@ -8,7 +8,7 @@ import sys
 def cls(n):
     if "k_pd_server" in n or "k_pd_torque" in n: return "K1 (stable PD)"
     if "k_lstm" in n: return "LSTM recurrences (HIP)"
-    if "k_gemm" in n: return "GEMM (HIP, split bf16 MFMA)"
+    if "k_gemm" in n or "k_gemv_rows" in n or "k_rank1" in n or "k_colsum" in n: return "GEMM (HIP, split bf16 MFMA + thin float32 products)"
     if n.startswith("Cijk") or "rocblas" in n.lower(): return "GEMM (library)"
     if "k_policy" in n: return "policy step (HIP)"
     if "egp::" in n or "k_engine" in n or "k_zf" in n: return "other egp kernels (K2-K6, engine)"
