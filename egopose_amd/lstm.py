@@ -51,6 +51,16 @@ def _gate_perm(hidden, device):
     return _PERM[key]
 
 
+def _stacked_perm(hidden, P, device):
+    """The gate permutation applied to P stacked (4H)-row blocks at once, and its inverse (cached)."""
+    key = (hidden, P, str(device))
+    if key not in _PERM:
+        perm, inv = _gate_perm(hidden, device)
+        off = (torch.arange(P, device=device) * 4 * hidden).unsqueeze(1)
+        _PERM[key] = ((perm.unsqueeze(0) + off).reshape(-1), (inv.unsqueeze(0) + off).reshape(-1))
+    return _PERM[key]
+
+
 class LstmDirection(torch.autograd.Function):
 
     @staticmethod
@@ -146,8 +156,10 @@ class LstmGroup(torch.autograd.Function):
         pord = [p for p in range(P) if not (reverse_mask >> p) & 1] + [p for p in range(P) if (reverse_mask >> p) & 1]
         nf = sum(1 for p in range(P) if not (reverse_mask >> p) & 1)
         kmask = sum(1 << q for q in range(nf, P))                                           # reverse bits in kernel order
-        w_in = torch.cat([w_ih[p].index_select(0, perm) for p in pord], 0)                  # (P*4H, D)
-        bias = torch.cat([(b_ih[p] + b_hh[p]).index_select(0, perm) for p in pord], 0)
+        # one gather for the P stacked blocks instead of one per problem (the update runs this every epoch)
+        bperm, _ = _stacked_perm(H, P, x.device)
+        w_in = torch.cat([w_ih[p] for p in pord], 0).index_select(0, bperm)                 # (P*4H, D)
+        bias = (torch.cat([b_ih[p] for p in pord]) + torch.cat([b_hh[p] for p in pord])).index_select(0, bperm)
         rows = None
         if ragged is not None and ragged.rows is not None and 0 < nf and G.enabled() and G.fused_rows_available() \
                 and ragged.T == T and ragged.rows.shape[0] >= 4096 and os.environ.get("EGP_LSTM_ROWS", "1") != "0":
@@ -216,6 +228,9 @@ class LstmGroup(torch.autograd.Function):
         else:
             dw_ih_all = torch.bmm(d3.transpose(1, 2), x2.view(T, B, D)).sum(0)
         grads = [None] * (4 * P)
+        _, binv = _stacked_perm(H, P, x2.device)
+        dw_ih_t = dw_ih_all.index_select(0, binv)                                           # torch row order, P blocks at once
+        db_t = db.reshape(-1).index_select(0, binv).view(P, 4 * H)
         for q, p in enumerate(pord):          # q: the problem's place in the kernels' order, p: in the caller's
             rev = (kmask >> q) & 1
             slab = h_buf[p // width, 2:] if rev else h_buf[p // width, :T]
@@ -228,8 +243,8 @@ class LstmGroup(torch.autograd.Function):
                     dw_hh = G.linear_wgrad(dq, hq, want_bias=False).index_select(0, inv)
             else:
                 dw_hh = torch.bmm(d3[:, :, q * 4 * H:(q + 1) * 4 * H].transpose(1, 2), h_prev).sum(0).index_select(0, inv)
-            dw_ih = dw_ih_all[q * 4 * H:(q + 1) * 4 * H].index_select(0, inv)
-            d_b = db[q].index_select(0, inv)
+            dw_ih = dw_ih_t[q * 4 * H:(q + 1) * 4 * H]
+            d_b = db_t[q]
             grads[4 * p:4 * p + 4] = [dw_ih, dw_hh, d_b, d_b]
         d_x = dpre.mm(w_in).view(T, B, D) if ctx.needs_input_grad[0] else None
         return (d_x, None, None, None, None, None, *grads)
