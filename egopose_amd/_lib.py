@@ -32,6 +32,7 @@ class ModelDesc(C.Structure):
         ("k_rl", C.c_double), ("k_ra", C.c_double),
         ("v_ord", C.c_double), ("decay", C.c_int32),
         ("obs_heading", C.c_int32), ("obs_keep_root_heading", C.c_int32), ("obs_coord_root", C.c_int32), ("obs_vel", C.c_int32),
+        ("action_torque", C.c_int32),
     ]
 
 

@@ -375,6 +375,34 @@ __global__ __launch_bounds__(256) void k_pd_torque_tree58(DevModel m, PdLd ld, c
     }
 }
 
+// cfg.action_type == 'torque' (humanoid_v1.py:167-172): torque = clip(a_ref + action * a_scale, +-torque_lim); nothing of
+// the state enters. Same launch geometry and completion signal as the PD kernels it stands in for (4 envs per block).
+template <typename TIO>
+__global__ __launch_bounds__(256) void k_torque_direct(DevModel m, PdLd ld, const TIO *__restrict__ action, int n,
+                                                       TIO *__restrict__ torque, TIO *__restrict__ torque_raw, PdDone done) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long env = (long)blockIdx.x * 4 + wave;
+    if (env < n && lane < m.nu) {
+        const double tau = m.a_ref[lane] + (double)action[env * ld.action + lane] * m.a_scale[lane];
+        const double lim = m.torque_lim[lane];
+        torque[env * m.nu + lane] = (TIO)fmin(fmax(tau, -lim), lim);
+        if (torque_raw) torque_raw[env * m.nu + lane] = (TIO)tau;
+    }
+    if (done.counter) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            const unsigned prev = atomicAdd(done.counter, 1u);
+            if (prev == gridDim.x - 1) {
+                *done.counter = 0u;
+                __threadfence_system();
+                __hip_atomic_store(done.host_flag, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
 // Resident form of the tree kernel for the rollout engine ("K1 server"): ONE launch covers all frame_skip
 // substeps of an env-step. The launch is cut into slices of whole blocks, each owned by one host physics thread.
 // For every substep a block waits until its slice's `go` word (pinned host memory, written by the owner after it
@@ -505,7 +533,12 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
             return;
         }
         const bool refresh = DYN || (s_go[sub & 1] & 1ull) != 0ull;
-        if (live) {
+        if (live && m.action_torque) {          // action_type 'torque' (humanoid_v1.py:170-172): the clipped control itself
+            if (lane < PD_NV && row >= 6)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(torque + env * m.nu + act),
+                                   (unsigned long long)__double_as_longlong(fmin(fmax(target, -c_lim), c_lim)), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        } else if (live) {
             double r_q, r_v, r_c;
             if constexpr (DYN) {
                 if (lane < sv.nq) s_q[lane] = sys_load_f64(qpos + env * ld.qpos + lane);
@@ -689,12 +722,19 @@ __device__ __forceinline__ void root_velocity(const T *cq, const T *pq, T dt, V3
     *rv = rotate_T(rp, rvw);
 }
 
-// end-effector lane: world position -> root-relative, heading frame (get_ee_pos, humanoid_v1.py:98-111)
+// transform_vec(v, q, cfg.obs_coord) (utils/math.py:47-59): R(q)^T v in the 'root' frame, R(heading_q(q))^T v in the 'heading' frame
 template <typename T>
-__device__ __forceinline__ V3<T> ee_local(const T *cq, const T *wp) {
+__device__ __forceinline__ V3<T> coord_vec(const Q4<T> &q, const V3<T> &v, bool root_frame) {
+    return rotate_T(root_frame ? q : heading_q(q), v);
+}
+
+// end-effector lane: world position -> root-relative, in the frame cfg.obs_coord names (get_ee_pos(transform),
+// humanoid_v1.py:98-111; the reward passes cfg.obs_coord, reward_function.py:23; gen_expert.py:18-22 always 'heading')
+template <typename T>
+__device__ __forceinline__ V3<T> ee_local(const T *cq, const T *wp, bool root_frame) {
     const Q4<T> rc{cq[3], cq[4], cq[5], cq[6]};
     const V3<T> rel{wp[0] - cq[0], wp[1] - cq[1], wp[2] - cq[2]};
-    return rotate_T(heading_q(rc), rel);
+    return coord_vec(rc, rel, root_frame);
 }
 
 template <typename T>
@@ -747,7 +787,8 @@ __device__ __forceinline__ void reward_body(const DevModel &m, const RewardW &w,
         V3<T> v, rv;
         root_velocity<T>(cq, pq, dt, &v, &rv);
         const Q4<T> rp{pq[3], pq[4], pq[5], pq[6]};
-        const V3<T> vl = rotate_T(heading_q(rp), v);        // learner: heading frame of the PREVIOUS root quat
+        // learner: get_qvel_fd(prev, cur, dt, cfg.obs_coord) (reward_function.py:19): frame of the PREVIOUS root quat
+        const V3<T> vl = coord_vec(rp, v, m.obs_root != 0);
         const T dl = (vl.x - er[ER_RLINV]) * (vl.x - er[ER_RLINV]) + (vl.y - er[ER_RLINV + 1]) * (vl.y - er[ER_RLINV + 1]) +
                      (vl.z - er[ER_RLINV + 2]) * (vl.z - er[ER_RLINV + 2]);
         const T da = (rv.x - er[ER_RANGV]) * (rv.x - er[ER_RANGV]) + (rv.y - er[ER_RANGV + 1]) * (rv.y - er[ER_RANGV + 1]) +
@@ -761,7 +802,7 @@ __device__ __forceinline__ void reward_body(const DevModel &m, const RewardW &w,
         rp_r = t_exp<T>(-(T)w.k_rh * dh * dh - (T)w.k_rq * dq * dq);
     } else if (l < m.nbody + 5) {
         const int k = l - m.nbody;
-        const V3<T> o = ee_local<T>(cq, ee_wpos + env * 15 + 3 * k);
+        const V3<T> o = ee_local<T>(cq, ee_wpos + env * 15 + 3 * k, m.obs_root != 0);
         const T *ee = er + ER_EE + 3 * k;
         ee_sq = (o.x - ee[0]) * (o.x - ee[0]) + (o.y - ee[1]) * (o.y - ee[1]) + (o.z - ee[2]) * (o.z - ee[2]);
     }
@@ -797,8 +838,10 @@ __global__ __launch_bounds__(256) void k_reward_quat_v3(DevModel m, RewardW w, c
 // Expert / learner pose features of one frame pair, reference formats (gen_expert.py:28-83 keys):
 //   qvel[nv] = get_qvel_fd(prev, cur, dt) (world-frame root lin-vel), rlinv_local[3], rangv[3], rq_rmh[4],
 //   ee_pos[15], bquat[4*nbody], bangvel[3*nbody].
-// expert_convention != 0: rlinv_local uses the heading of the CURRENT root quat (gen_expert.py:53);
-// otherwise the previous one (get_qvel_fd(..., 'heading') as in the reward, reward_function.py:19-21).
+// expert_convention != 0: rlinv_local uses the heading of the CURRENT root quat (gen_expert.py:53) and the heading
+// frame whatever cfg.obs_coord says (gen_expert.py:18-22 builds its own config with obs_coord 'heading');
+// otherwise the previous root quat and cfg.obs_coord's frame (get_qvel_fd(..., cfg.obs_coord) and
+// get_ee_pos(cfg.obs_coord) as in the reward, reward_function.py:19-23).
 template <typename T>
 __global__ __launch_bounds__(256) void k_pose_features(DevModel m, const T *__restrict__ cur_qpos,
                                                        const T *__restrict__ prev_qpos, const T *__restrict__ ee_wpos,
@@ -834,7 +877,7 @@ __global__ __launch_bounds__(256) void k_pose_features(DevModel m, const T *__re
         const Q4<T> rp{pq[3], pq[4], pq[5], pq[6]};
         T *qv = qvel + env * m.nv;
         qv[0] = v.x; qv[1] = v.y; qv[2] = v.z; qv[3] = rv.x; qv[4] = rv.y; qv[5] = rv.z;
-        const V3<T> vl = rotate_T(heading_q(expert_convention ? rc : rp), v);
+        const V3<T> vl = coord_vec(expert_convention ? rc : rp, v, !expert_convention && m.obs_root != 0);
         T *o = rlinv_local + env * 3; o[0] = vl.x; o[1] = vl.y; o[2] = vl.z;
         o = rangv + env * 3; o[0] = rv.x; o[1] = rv.y; o[2] = rv.z;
         const Q4<T> rq = de_heading(rc);
@@ -847,7 +890,7 @@ __global__ __launch_bounds__(256) void k_pose_features(DevModel m, const T *__re
         o = bangvel + env * 3 * m.nbody; o[0] = ax.x * ang / dt; o[1] = ax.y * ang / dt; o[2] = ax.z * ang / dt;
     } else if (l < m.nbody + 5) {
         const int k = l - m.nbody;
-        const V3<T> e = ee_local<T>(cq, ee_wpos + env * 15 + 3 * k);
+        const V3<T> e = ee_local<T>(cq, ee_wpos + env * 15 + 3 * k, !expert_convention && m.obs_root != 0);
         T *o = ee_pos + env * 15 + 3 * k; o[0] = e.x; o[1] = e.y; o[2] = e.z;
     }
 }
@@ -1359,6 +1402,7 @@ int egp_create(const egp_model_desc *d, int device, egp_ctx **out) {
     m.dt = d->sub_dt * d->frame_skip;
     m.obs_heading = d->obs_heading != 0; m.obs_keep = d->obs_keep_root_heading != 0; m.obs_root = d->obs_coord_root != 0;
     m.obs_vel = d->obs_vel;
+    m.action_torque = d->action_torque != 0;
     if (m.obs_vel < 0 || m.obs_vel > 2) { delete ctx; set_error("obs_vel must be 0 (full), 1 (root) or 2 (none)"); return EGP_E_INVALID; }
     m.obs_dim = obs_width(d->nq, d->nv, m.obs_heading, m.obs_vel);
     // sparse-inertia index tables from the dof tree (what mj_fullM walks)
@@ -1581,6 +1625,11 @@ static int launch_pd(egp_ctx *ctx, const PdLd &ld, const T *qpos, const T *qvel,
     EGP_REQUIRE(ctx, "ctx is NULL");
     EGP_REQUIRE(n >= 0, "n < 0");
     if (n == 0) return EGP_OK;
+    if (ctx->dm.action_torque) {        // action_type 'torque': no state, no inertia
+        EGP_REQUIRE(action && torque, "NULL pointer");
+        k_torque_direct<T><<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, action, n, torque, torque_raw, done);
+        return after_launch("k_torque_direct");
+    }
     EGP_REQUIRE(qpos && qvel && action && qM && C && torque, "NULL pointer");
     if (ctx->pd_variant == 0 && ctx->pd_grid) {
         k_pd_torque_grid58<T><<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, ctx->pd_grid_off, qpos, qvel, action, qM, C, n, torque, torque_raw, done);

@@ -102,9 +102,16 @@ template <typename T> __device__ __forceinline__ void rot_axis_angle(const Q4<T>
     } else {
         // float32 variant: sqrt(1-w^2) and acos(w) lose all digits for small rotations; for a unit
         // quaternion |xyz| == sqrt(1-w^2) and atan2(|xyz|, w) == acos(w), both well conditioned.
+        // (w can round to 1 - 1 ulp for q q^-1 while the vector part is exactly zero: the float64 test above does not
+        //  catch that in float32, and 0 / 0 must not become the axis)
         const T s = t_sqrt<T>(q.x * q.x + q.y * q.y + q.z * q.z);
-        axis->x = q.x / s; axis->y = q.y / s; axis->z = q.z / s;
-        *angle = T(2) * atan2f((float)s, (float)q.w);
+        if (s == T(0)) {
+            axis->x = T(1); axis->y = T(0); axis->z = T(0);
+            *angle = T(0);
+        } else {
+            axis->x = q.x / s; axis->y = q.y / s; axis->z = q.z / s;
+            *angle = T(2) * atan2f((float)s, (float)q.w);
+        }
     }
 }
 

@@ -242,15 +242,21 @@ class HumanoidEnv:
         return sim.ctx.body_quat(sim.engine.qpos).cpu().numpy()[0]
 
     def get_ee_pos(self, transform):
-        """World end-effector positions, or root-relative in the heading frame (humanoid_v1.py:98-111)."""
-        sim = self._one()
-        eng = sim.engine
+        """World end-effector positions (transform None), or root-relative in the 'heading' / 'root' frame
+        (humanoid_v1.py:98-111 with transform_vec, utils/math.py:47-59). Single-env facade: host arithmetic."""
+        from .metrics import _heading_q, _rot_matrix
+        eng = self._one().engine
+        w = eng.ee_wpos.cpu().numpy()[0].reshape(-1, 3)
         if transform is None:
-            return eng.ee_wpos.cpu().numpy()[0]
-        if transform != "heading":
-            raise AssertionError("only the 'heading' transform is on the hot path")
-        f = sim.ctx.pose_features(eng.qpos, eng.qpos, eng.ee_wpos)
-        return f["ee_pos"].cpu().numpy()[0]
+            return w.ravel()
+        q = eng.qpos_host[0]
+        if transform == "root":
+            R = _rot_matrix(q[3:7])
+        elif transform == "heading":
+            R = _rot_matrix(_heading_q(q[3:7]))
+        else:
+            raise AssertionError("unknown transform %r" % (transform,))          # transform_vec's `assert False`
+        return ((w - q[:3]) @ R).ravel()                                         # rows R^T (w - root)
 
     def sample_reset(self, n):
         """Reset sampling of reset_model (humanoid_v1.py:206-216) for n envs at once:

@@ -75,11 +75,13 @@ def quat_op(name, a, b=None):
 
 
 def obs_options_of(cfg):
-    """The observation switches of a Config (egomimic_config.py:99-103) as EgpContext's `obs_options`."""
+    """The env switches of a Config (egomimic_config.py:99-105) as EgpContext's `obs_options`: the observation variants,
+    the frame `obs_coord` (which the reward uses too, reward_function.py:19,23) and `action_type`."""
     if getattr(cfg, "obs_type", "full") != "full":
         raise NotImplementedError("obs_type %r: the reference's get_obs only knows 'full' (humanoid_v1.py:68-71)" % cfg.obs_type)
     return dict(obs_heading=bool(getattr(cfg, "obs_heading", False)), root_deheading=bool(getattr(cfg, "root_deheading", True)),
-                obs_coord=getattr(cfg, "obs_coord", "heading"), obs_vel=getattr(cfg, "obs_vel", "full"))
+                obs_coord=getattr(cfg, "obs_coord", "heading"), obs_vel=getattr(cfg, "obs_vel", "full"),
+                action_type=getattr(cfg, "action_type", "position"))
 
 
 class EgpContext:
@@ -95,10 +97,13 @@ class EgpContext:
         self.frame_skip = int(frame_skip)
         self.episode_len = int(episode_len)
         self.nq, self.nv, self.nu, self.nbody, self.nM = skel.nq, skel.nv, skel.nu, len(skel.body_names), skel.nM
-        oo = dict(obs_heading=False, root_deheading=True, obs_coord="heading", obs_vel="full")
+        oo = dict(obs_heading=False, root_deheading=True, obs_coord="heading", obs_vel="full", action_type="position")
         oo.update(obs_options or {})
         if oo["obs_coord"] not in ("heading", "root"):
             raise ValueError("obs_coord must be 'heading' or 'root', got %r" % (oo["obs_coord"],))      # transform_vec asserts
+        if oo["action_type"] not in ("position", "torque"):
+            # humanoid_v1.py:167-172 knows these two; anything else leaves `torque` unbound there (UnboundLocalError)
+            raise ValueError("action_type must be 'position' or 'torque', got %r" % (oo["action_type"],))
         self.obs_options = oo
         self._obs_vel = {"full": 0, "root": 1}.get(oo["obs_vel"], 2)        # anything else: no velocity block (humanoid_v1.py:86-89)
         self.obs_dim = (1 if oo["obs_heading"] else 0) + self.nq - 2 + (self.nv, 6, 0)[self._obs_vel]
@@ -144,6 +149,7 @@ class EgpContext:
         d.obs_keep_root_heading = 0 if oo["root_deheading"] else 1
         d.obs_coord_root = 1 if oo["obs_coord"] == "root" else 0
         d.obs_vel = self._obs_vel
+        d.action_torque = 1 if oo["action_type"] == "torque" else 0
         return d
 
     def close(self):

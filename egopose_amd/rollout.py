@@ -102,8 +102,13 @@ class LockstepRollout:
         self.ctx_T = 1 if self.forecast else self.T_ep          # context rows per episode kept in v_out
         if getattr(self.cfg, "obs_phase", False) or getattr(self.cfg, "random_cur_t", False):
             raise NotImplementedError("obs_phase / random_cur_t are not implemented in the lockstep rollout")
-        # (the observation variants of humanoid_v1.py:73-96 -- obs_heading, obs_vel, root_deheading, obs_coord -- are part of
-        #  the kernel context: sim.ctx.obs_dim follows them; an unknown obs_type / obs_coord was refused when it was built)
+        if getattr(self.cfg, "action_type", "position") == "torque" and hasattr(self.cfg, "j_stiff"):
+            # humanoid_v1.py:56-58 writes cfg.j_stiff into the MuJoCo model's joint stiffness: a property of the physics
+            # backend, which the built-in surrogate does not have
+            raise NotImplementedError("cfg.j_stiff (joint stiffness under action_type 'torque') needs a physics backend that models it")
+        # (the env switches of humanoid_v1.py:73-96,167-172 -- obs_heading, obs_vel, root_deheading, obs_coord (observation AND
+        #  reward), action_type -- are part of the kernel context: sim.ctx.obs_dim follows them; an unknown obs_type /
+        #  obs_coord / action_type was refused when it was built)
         self.gen = torch.Generator(device=self.dev)
         self.gen.manual_seed(int(seed))
         with torch.cuda.device(self.dev):

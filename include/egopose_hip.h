@@ -69,6 +69,10 @@ typedef struct egp_model_desc {
     int32_t obs_keep_root_heading;        /* cfg.root_deheading == False */
     int32_t obs_coord_root;               /* cfg.obs_coord == 'root' */
     int32_t obs_vel;                      /* cfg.obs_vel: 0 'full', 1 'root', 2 none */
+    /* cfg.action_type (egomimic_config.py:105, humanoid_v1.py:167-172): 0 'position' -- the action is a PD target and K1
+     * solves the stable-PD system per substep; 1 'torque' -- torque = clip(a_ref + action * a_scale, +-torque_lim), the
+     * same on every substep of the env-step, no solve (every K1 entry point and the engine follow this switch) */
+    int32_t action_torque;
 } egp_model_desc;
 /* width of an observation row under those options (115 for the defaults) */
 int32_t egp_obs_dim(const egp_ctx *ctx);

@@ -68,8 +68,8 @@ class OracleHumanoidEnv:
         self.prev_qpos, self.prev_bquat = self.qpos.copy(), self.bquat.copy()
         for i in range(15):
             M = H.full_from_sparse(self.qM, sk.dof_parentid, sk.dof_Madr)
-            _, tau = H.pd_torque(self.qpos, self.qvel, action, M, self.bias, cfg.jkp, cfg.jkd, cfg.a_ref, cfg.a_scale,
-                                 cfg.torque_lim, sk.timestep)
+            _, tau = H.control_torque(getattr(cfg, "action_type", "position"), self.qpos, self.qvel, action, M, self.bias, cfg.jkp,
+                                      cfg.jkd, cfg.a_ref, cfg.a_scale, cfg.torque_lim, sk.timestep)
             self.phys.step(self.slot, tau[0])
             self._drain(i == 14)
         self.cur_t += 1
@@ -94,7 +94,8 @@ class OracleHumanoidEnv:
         row = {k: e[k][ind] for k in ("qpos", "rlinv_local", "rangv", "rq_rmh", "ee_pos", "bquat", "bangvel")}
         r, ci = R.quat_v3(self.qpos, self.prev_qpos, self.prev_bquat, self.xpos[self.skel.ee_body].ravel(), self.cur_t, row,
                           self.cfg.reward_weights, self.cfg.b_diffw, self.dt, self.cfg.env_episode_len, info["end"],
-                          self.end_reward, self.skel.body_qpos_start, self.skel.body_ndof)
+                          self.end_reward, self.skel.body_qpos_start, self.skel.body_ndof,
+                          obs_coord=getattr(self.cfg, "obs_coord", "heading"))
         return float(r[0]), ci[0]
 
 

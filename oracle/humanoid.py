@@ -127,6 +127,19 @@ def pd_torque(qpos, qvel, action, M, C, jkp, jkd, a_ref, a_scale, torque_lim, dt
     return tau, np.clip(tau, -torque_lim, torque_lim)
 
 
+def control_torque(action_type, qpos, qvel, action, M, C, jkp, jkd, a_ref, a_scale, torque_lim, dt):
+    """One substep of do_simulation's control law (ego_pose/envs/humanoid_v1.py:167-172); returns (torque, clipped torque).
+
+    ctrl = a_ref + action * a_scale; 'position': torque = compute_torque(ctrl) (stable PD); 'torque': torque = ctrl;
+    then clip to +-torque_lim. Any other action_type leaves `torque` unbound in the reference (UnboundLocalError)."""
+    if action_type == "position":
+        return pd_torque(qpos, qvel, action, M, C, jkp, jkd, a_ref, a_scale, torque_lim, dt)
+    if action_type == "torque":
+        tau = a_ref + np.atleast_2d(np.asarray(action, float)) * a_scale
+        return tau, np.clip(tau, -torque_lim, torque_lim)
+    raise UnboundLocalError("action_type %r: local variable 'torque' referenced before assignment" % (action_type,))
+
+
 def qvel_fd(cur_qpos, next_qpos, dt, transform=None):
     """Finite-difference generalized velocity (B,58): world lin-vel (or heading frame), root-frame ang-vel."""
     a = np.atleast_2d(np.asarray(cur_qpos, float))

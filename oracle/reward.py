@@ -22,8 +22,12 @@ def resolve_weights(ws):
 
 
 def quat_v3(cur_qpos, prev_qpos, prev_bquat, ee_wpos, t, expert_row, weights, b_diffw, dt,
-            episode_len, end, end_reward, skel_start, skel_ndof):
+            episode_len, end, end_reward, skel_start, skel_ndof, obs_coord="heading"):
     """Returns (reward (B,), c_info (B,5)).
+
+    ``obs_coord`` = cfg.obs_coord: the frame of the learner's root linear velocity and end-effector offsets
+    (reward_function.py:19,23: get_qvel_fd(..., cfg.obs_coord), env.get_ee_pos(cfg.obs_coord)); the expert rows were
+    written by gen_expert.py, which always uses 'heading' (gen_expert.py:18-22).
 
     ``expert_row`` is a dict of the expert table rows at index start_ind + t:
     qpos(…,59), rlinv_local(…,3), rangv(…,3), rq_rmh(…,4), ee_pos(…,15), bquat(…,84), bangvel(…,63).
@@ -36,9 +40,9 @@ def quat_v3(cur_qpos, prev_qpos, prev_bquat, ee_wpos, t, expert_row, weights, b_
     t = np.broadcast_to(np.asarray(t, float), (B,))
     end = np.broadcast_to(np.asarray(end, bool), (B,))
     # learner features (reward_function.py:18-26)
-    cur_qvel = H.qvel_fd(prev_qpos, cur_qpos, dt, "heading")
+    cur_qvel = H.qvel_fd(prev_qpos, cur_qpos, dt, obs_coord)
     cur_rq_rmh = Q.de_heading(cur_qpos[:, 3:7])
-    cur_ee = H.ee_pos(cur_qpos, ee_wpos, "heading")
+    cur_ee = H.ee_pos(cur_qpos, ee_wpos, obs_coord)
     cur_bquat = H.body_quat(cur_qpos, skel_start, skel_ndof)
     cur_bangvel = H.angvel_fd(prev_bquat, cur_bquat, dt)
     e = {k: np.atleast_2d(np.asarray(v, float)) for k, v in expert_row.items()}

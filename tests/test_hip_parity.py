@@ -142,6 +142,61 @@ def test_reward_golden(ctx, dtype, tol):
         ctx.set_reward_weights(wsets[0])
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-5)])
+def test_reward_and_pose_features_in_the_root_frame(skel, dtype, tol):
+    """cfg.obs_coord = 'root' reaches the reward (reward_function.py:19,23): K2 and the learner convention of K7 against the
+    reference's own numbers (tests/golden/reward_root.npz); the same cases under 'heading' differ and are matched too."""
+    from egopose_amd.hip import EgpContext
+    g = load_golden("reward_root.npz")
+    c = load_golden("config_subject_03.npz")
+    wsets = [yaml.safe_load(str(s)) for s in g["wset_json"]]
+    i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32, device="cuda")
+    for coord, rk, ck in (("root", "reward", "c_info"), ("heading", "reward_heading", "c_info_heading")):
+        cx = EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"], episode_len=int(g["episode_len"]),
+                        obs_options=dict(obs_coord=coord))
+        _upload_golden_expert(cx, g)
+        for wi, ws in enumerate(wsets):
+            cx.set_reward_weights(ws)
+            sel = np.where(g["wset"] == wi)[0]
+            r, ci = cx.reward(dev(g["cur_qpos"][sel], dtype), dev(g["prev_qpos"][sel], dtype), dev(g["ee_wpos"][sel], dtype),
+                              i32(g["t"][sel]), i32(g["start_ind"][sel] + g["t"][sel]), i32(g["end"][sel]), 0.0)
+            want = g[rk][sel] - np.where(g["end"][sel], g["end_reward"][sel], 0.0)
+            np.testing.assert_allclose(ci.cpu().numpy(), g[ck][sel], rtol=0, atol=tol * 5, err_msg=coord)
+            np.testing.assert_allclose(r.cpu().numpy(), want, rtol=tol, atol=tol * 5, err_msg=coord)
+        f = cx.pose_features(dev(g["cur_qpos"], dtype), dev(g["prev_qpos"], dtype), dev(g["ee_wpos"], dtype))
+        if coord == "root":
+            vtol = tol * 50          # velocities are O(10) finite differences over dt = 1/30
+            np.testing.assert_allclose(f["rlinv_local"].cpu().numpy(), g["learner_qvel_root"][:, :3], rtol=vtol, atol=vtol)
+            np.testing.assert_allclose(f["rangv"].cpu().numpy(), g["learner_qvel_root"][:, 3:6], rtol=vtol, atol=vtol)
+            np.testing.assert_allclose(f["ee_pos"].cpu().numpy(), g["learner_ee_root"], rtol=0, atol=tol * 5)
+        # the expert convention (gen_expert.py) stays in the heading frame whatever cfg.obs_coord says
+        fe = cx.pose_features(dev(g["cur_qpos"], dtype), dev(g["prev_qpos"], dtype), dev(g["ee_wpos"], dtype), expert_convention=True)
+        np.testing.assert_allclose(fe["ee_pos"].cpu().numpy(), H.ee_pos(g["cur_qpos"], g["ee_wpos"], "heading"), rtol=0, atol=tol * 5)
+        cx.close()
+
+
+def test_action_type_torque_and_position_controls(skel):
+    """do_simulation's control law (humanoid_v1.py:167-172) through the K1 entry point under both action types, against the
+    controls the reference wrote into data.ctrl (tests/golden/do_simulation.npz); float32 i/o; unknown types refused."""
+    from egopose_amd.hip import EgpContext
+    g = load_golden("do_simulation.npz")
+    c = load_golden("config_subject_03.npz")
+    for mode in ("position", "torque"):
+        cx = EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"], obs_options=dict(action_type=mode))
+        for variant in ((0, 1, 2, 3) if mode == "position" else (0, 1)):
+            cx.set_pd_variant(variant)
+            for s in range(g["qpos"].shape[1]):
+                tq = cx.pd_torque(dev(g["qpos"][:, s]), dev(g["qvel"][:, s]), dev(g["action"]), dev(g["qM"]), dev(g["C"]))
+                np.testing.assert_allclose(tq.cpu().numpy(), g["ctrl_" + mode][:, s], rtol=1e-10, atol=1e-9, err_msg="%s v%d" % (mode, variant))
+        cx.set_pd_variant(0)
+        f32 = torch.float32
+        tq = cx.pd_torque(dev(g["qpos"][:, 0], f32), dev(g["qvel"][:, 0], f32), dev(g["action"], f32), dev(g["qM"], f32), dev(g["C"], f32))
+        np.testing.assert_allclose(tq.cpu().numpy(), g["ctrl_" + mode][:, 0], rtol=2e-5, atol=2e-3)
+        cx.close()
+    with pytest.raises(ValueError, match="action_type"):
+        EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"], obs_options=dict(action_type="velocity"))
+
+
 def test_reward_active_mask_and_state_errors(ctx, skel):
     from egopose_amd.hip import EgpContext
     g = load_golden("reward.npz")
@@ -299,6 +354,48 @@ def test_engine_step_matches_host_loop(ctx, skel, mode, monkeypatch):
             np.testing.assert_allclose(got_ee[e], xpos[skel.ee_body].ravel(), rtol=1e-9, atol=1e-9)
             np.testing.assert_allclose(head_z[e], xpos[6, 2], rtol=1e-9, atol=1e-9)
         ref.close()
+
+
+@pytest.mark.parametrize("mode", ["resident", "pipelined", "barrier", "copies"])
+def test_engine_step_with_torque_actions(skel, mode, monkeypatch):
+    """cfg.action_type = 'torque' through the engine: every substep applies clip(a_ref + a * a_scale) (humanoid_v1.py:167-172),
+    no PD solve -- against the host loop with the oracle's control law, in every mode of the substep loop."""
+    from egopose_amd.hip import EgpContext
+    from egopose_amd.physics import SurrogatePhysics, RolloutEngine
+    for k, v in ENGINE_MODES[mode][0].items():
+        monkeypatch.setenv(k, v)
+    c = load_golden("config_subject_03.npz")
+    g = load_golden("body_quat_obs.npz")
+    cx = EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"], obs_options=dict(action_type="torque"))
+    n = 23
+    rng = np.random.RandomState(19)
+    qpos0, qvel0 = g["qpos"][:n], g["qvel"][:n] * 0.2
+    action = rng.normal(size=(n, 52)) * 40.0                 # some beyond the limits (50 ... 200)
+    ph = SurrogatePhysics(skel, n)
+    eng = RolloutEngine(cx, ph, n, n_threads=3, n_groups=2)
+    eng.reset(np.arange(n), qpos0, qvel0)
+    act_d = dev(action)
+    torch.cuda.synchronize()
+    for gi in range(2):
+        eng.step_async(gi, act_d)
+    for gi in range(2):
+        eng.wait(gi)
+    torch.cuda.synchronize()
+    got_q, got_v = eng.qpos.cpu().numpy(), eng.qvel.cpu().numpy()
+    eng.close()
+    ph.close()
+    cx.close()
+    ref = SurrogatePhysics(skel, n)
+    _, tc = H.control_torque("torque", None, None, action, None, None, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], skel.timestep)
+    assert (np.abs(tc) == c["torque_lim"]).any()
+    for e in range(n):
+        ref.reset(e, qpos0[e], qvel0[e])
+        for s in range(15):
+            ref.step(e, tc[e])
+        q, v, _, _, _ = ref.drain(e)
+        np.testing.assert_allclose(got_q[e], q, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(got_v[e], v, rtol=1e-12, atol=1e-12)
+    ref.close()
 
 
 def test_resident_engine_dealt_slices_are_bit_identical(ctx, skel, monkeypatch):

@@ -90,6 +90,44 @@ def test_reward_quat_v3(skel):
     np.testing.assert_allclose(H.body_quat(g["prev_qpos"], skel.body_qpos_start, skel.body_ndof), g["prev_bquat"], **TOL)
 
 
+def test_reward_quat_v3_in_the_root_frame(skel):
+    """cfg.obs_coord = 'root' inside the reward (reward_function.py:19,23): learner root velocity / end effectors in the root
+    frame against expert rows that keep gen_expert.py's heading frame. The fixture also holds the same cases evaluated with
+    'heading', and the two differ -- an oracle that ignored the option could not pass both."""
+    g = load_golden("reward_root.npz")
+    c = load_golden("config_subject_03.npz")
+    wsets = [yaml.safe_load(str(s)) for s in g["wset_json"]]
+    for coord, rk, ck in (("root", "reward", "c_info"), ("heading", "reward_heading", "c_info_heading")):
+        for wi, ws in enumerate(wsets):
+            sel = np.where(g["wset"] == wi)[0]
+            ind = g["start_ind"][sel] + g["t"][sel]
+            r, ci = R.quat_v3(g["cur_qpos"][sel], g["prev_qpos"][sel], g["prev_bquat"][sel], g["ee_wpos"][sel], g["t"][sel],
+                              _expert_rows(g, ind), ws, c["b_diffw"], float(g["dt"]), int(g["episode_len"]), g["end"][sel],
+                              g["end_reward"][sel], skel.body_qpos_start, skel.body_ndof, obs_coord=coord)
+            np.testing.assert_allclose(ci, g[ck][sel], rtol=1e-11, atol=1e-12)
+            np.testing.assert_allclose(r, g[rk][sel], rtol=1e-11, atol=1e-12)
+    assert np.abs(g["c_info"][:, [2, 4]] - g["c_info_heading"][:, [2, 4]]).max() > 1e-3
+    np.testing.assert_allclose(H.qvel_fd(g["prev_qpos"], g["cur_qpos"], float(g["dt"]), "root"), g["learner_qvel_root"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(H.ee_pos(g["cur_qpos"], g["ee_wpos"], "root"), g["learner_ee_root"], **TOL)
+
+
+def test_do_simulation_control_law(skel):
+    """do_simulation (humanoid_v1.py:158-177) under both action types: the clipped control of every substep."""
+    g = load_golden("do_simulation.npz")
+    c = load_golden("config_subject_03.npz")
+    M_ = H.full_from_sparse(g["qM"], skel.dof_parentid, skel.dof_Madr)
+    for mode in ("position", "torque"):
+        for s in range(g["qpos"].shape[1]):
+            _, tc = H.control_torque(mode, g["qpos"][:, s], g["qvel"][:, s], g["action"], M_, g["C"], c["jkp"], c["jkd"], c["a_ref"],
+                                     c["a_scale"], c["torque_lim"], float(g["dt"]))
+            np.testing.assert_allclose(tc, g["ctrl_" + mode][:, s], rtol=1e-11, atol=1e-10)
+    assert (np.abs(g["ctrl_torque"]) == c["torque_lim"]).any() and (np.abs(g["ctrl_torque"]) < c["torque_lim"]).any()
+    assert np.ptp(g["ctrl_torque"], axis=1).max() == 0.0 and np.ptp(g["ctrl_position"], axis=1).max() > 0.0
+    with pytest.raises(UnboundLocalError):
+        H.control_torque("velocity", g["qpos"][:, 0], g["qvel"][:, 0], g["action"], M_, g["C"], c["jkp"], c["jkd"], c["a_ref"],
+                         c["a_scale"], c["torque_lim"], float(g["dt"]))
+
+
 def test_gae():
     g = load_golden("gae.npz")
     adv, ret, _ = G.estimate_advantages(g["rewards"], g["masks"], g["values"], float(g["gamma"]), float(g["tau"]))

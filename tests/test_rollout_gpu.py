@@ -585,10 +585,13 @@ def test_cross_01_config_short_rollout(tmp_path_factory, skel):
     tr.close()
 
 
-@pytest.mark.parametrize("option", [("obs_heading", True), ("obs_vel", "root"), ("root_deheading", False), ("obs_coord", "root")])
+@pytest.mark.parametrize("option", [("obs_heading", True), ("obs_vel", "root"), ("root_deheading", False), ("obs_coord", "root"),
+                                    ("action_type", "torque")])
 def test_non_default_observation_options_in_the_rollout(workspace, skel, option):
-    """The observation variants of humanoid_v1.py:73-96 run through the whole rollout: state width follows the option, the
-    recorded observations are the oracle env's (which evaluates the reference's branches), and an update step runs."""
+    """The env switches of humanoid_v1.py:73-96,167-172 run through the whole rollout: state width follows the option, the
+    recorded observations and rewards are the oracle env's (which evaluates the reference's branches -- obs_coord inside
+    the reward too, pinned to the reference by tests/golden/reward_root.npz; the control law by do_simulation.npz), and an
+    update step runs."""
     from egopose_amd.config import Config
     from egopose_amd.train import Trainer
     os.chdir(workspace)
@@ -609,6 +612,23 @@ def test_non_default_observation_options_in_the_rollout(workspace, skel, option)
     tr.close()
     with pytest.raises(NotImplementedError):
         cfg.obs_type = "something"
+        Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=8, num_threads=2, num_groups=1).agent.sample(8)
+
+
+@pytest.mark.parametrize("key,value,exc", [("obs_phase", True, NotImplementedError), ("random_cur_t", True, NotImplementedError),
+                                           ("action_type", "velocity", ValueError), ("obs_coord", "world", ValueError),
+                                           ("obs_type", "partial", NotImplementedError), ("j_stiff", 5.0, NotImplementedError)])
+def test_unsupported_env_options_are_refused(workspace, key, value, exc):
+    """Every env key of egomimic_config.py:82-105 / egoforecast_config.py:90-95 is honoured on the HIP path or refused loudly."""
+    from egopose_amd.config import Config
+    from egopose_amd.train import Trainer
+    os.chdir(workspace)
+    cfg = Config("subject_03", create_dirs=False)
+    cfg.env_episode_len = 10
+    setattr(cfg, key, value)
+    if key == "j_stiff":
+        cfg.action_type = "torque"
+    with pytest.raises(exc):
         Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=8, num_threads=2, num_groups=1).agent.sample(8)
 
 
