@@ -22,7 +22,8 @@ Prints ONE JSON line (rank 0) with the driver's fields plus
                traffic of a MuJoCo-like backend), (iii) with that inertia computed on the GPU (row f1), (iv) the
                ego_forecast nets of BASELINE config 5 on this GPU's 1 024-slot shard, (v) with a physics substep that costs
                `--sim-cost-us` (20 us: the order of an mj_step of this humanoid; the surrogate's own is ~0.3 us) next to the
-               CPU sampler at the same cost and to what the host threads alone allow
+               CPU sampler at the same cost and to what the host threads alone allow, (vi) BASELINE config 4: frames/s of the
+               state regressor's optimisation step (bf16 ResNet-18 encoder, batch 256 x 224 x 224)
   cpu_baseline the oracle's restatement of the reference CPU sampler (2 forked workers, float64, OMP=1) on a
                bounded sample, same physics backend (rank 0, N=1 only)
 """
@@ -394,6 +395,12 @@ def main():
                 leg["host_physics_ceiling_env_steps_per_s"] = n_threads / (leg["substeps_per_launch"] * args.sim_cost_us * 1e-6)
                 leg["frac_of_host_physics_ceiling"] = leg["rollout_only_env_steps_per_s"] / leg["host_physics_ceiling_env_steps_per_s"]
             legs["simulator_cost_per_substep"] = leg
+            # BASELINE config 4: the state regressor's optimisation step (ResNet-18 encoder in bf16 on the matrix cores)
+            try:
+                from egopose_amd.bench_support import statereg_config4
+                legs["statereg_config4"] = statereg_config4(local)
+            except Exception as e:
+                legs["statereg_config4"] = {"error": repr(e)[:300]}
             res["legs"] = {k: {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items()} for k, v in legs.items()}
             res["dropin_env_steps_per_s"] = legs["dropin_float64_driver"].get("env_steps_per_s")
         if not args.no_cpu_baseline:

@@ -111,3 +111,48 @@ def kernel_microbench(sizes=(1024, 65536), device_index=0, variants=False, iters
     finally:
         ctx.close()
     return out
+
+
+def statereg_config4(device_index=0, frames=256, steps=8, warmup=3, lr=1e-4):
+    """BASELINE config 4 ("state_reg cross_01: ResNet-18 VideoRegNet bf16 on MFMA, batch 256, 1xMI355X") as a timed leg:
+    optimisation steps of VideoRegNet (ResNet-18 -> bi-LSTM -> MLP[300,200] -> 115, models/video_reg_net.py:10-59,
+    ego_pose/state_reg.py:60-95, config/statereg/cross_01.yml: fr_num 120-frame clips are the reference's unit; 256
+    frames per step is BASELINE's batch) on synthetic optical-flow clips of 224 x 224 frames resident in HBM. The encoder
+    runs as a bf16 copy on the matrix cores with float32 master weights (nets.Bf16Shadow), the LSTM / MLP in float32.
+    HIP events around exactly `steps` steps; loss read back after the timed region."""
+    import torch
+    from .nets import VideoRegNet
+    dev = torch.device("cuda", device_index)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    net = VideoRegNet(115, 128, 128, no_cnn=False).to(dev).channels_last().bf16_encoder()
+    net.train()
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=lr)
+    x = torch.randn(frames, 1, 3, 224, 224, device=dev, generator=gen)
+    gt = torch.randn(frames, 115, device=dev, generator=gen)
+
+    def step():
+        loss = (gt - net(x)).pow(2).sum(dim=1).mean()
+        opt.zero_grad()
+        loss.backward()
+        net.encoder_grads_ready()
+        opt.step()
+        net.encoder_stepped()
+        return loss
+
+    first = None
+    for _ in range(warmup):
+        l = step()
+        first = l if first is None else first
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    a.record()
+    for _ in range(steps):
+        l = step()
+    b.record()
+    torch.cuda.synchronize(dev)
+    ms = a.elapsed_time(b) / steps
+    n_par = sum(p.numel() for p in net.parameters())
+    return {"frames_per_s": frames / (ms * 1e-3), "ms_per_step": ms, "frames_per_step": frames, "frame_shape": [3, 224, 224], "steps": steps,
+            "warmup": warmup, "dtype": "bf16 ResNet-18 encoder on MFMA (float32 master weights) + f32 bi-LSTM / MLP",
+            "parameters": int(n_par), "loss_first": float(first), "loss_last": float(l), "data": "synthetic frames resident in HBM",
+            "config": "state_reg: VideoRegNet(out 115, v_hdim 128, cnn_fdim 128, mlp [300, 200]), Adam lr %g, one clip of %d frames per step" % (lr, frames)}

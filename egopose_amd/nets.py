@@ -575,9 +575,12 @@ class VideoRegNet(nn.Module):          # (ResNet is defined further down; resolv
             self._enc16.pull()
 
     def _encode(self, frames):
+        # The bf16 copy serves OPTIMISATION steps only (train mode with autograd on). Everything whose output is kept --
+        # the features gen_cnn_feature stores for the RL nets, test-mode predictions, eval metrics -- goes through the
+        # float32 master encoder: ~8 mantissa bits would change stored features with no opt-in.
         enc = self.__dict__.get("_enc16")
-        if enc is not None:
-            enc.shadow.train(self.training)
+        if enc is not None and self.training and torch.is_grad_enabled():
+            enc.shadow.train(True)
             return enc(frames)
         return self.cnn(frames)
 

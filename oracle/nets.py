@@ -109,3 +109,32 @@ def vsnet_train_forward(p, ctx, idx, states, margin):
     v = bilstm(p, as_t(ctx))[margin:-margin]
     v = v.transpose(0, 1).contiguous().view(-1, v.shape[-1])
     return torch.cat([v[torch.as_tensor(idx, dtype=torch.long)], as_t(states)], dim=1)
+
+
+def resnet18_forward(sd, x, prefix="", train=False, eps=1e-5):
+    """ResNet-18 (He et al. 2016, the layout of torchvision's `resnet18`, which models/resnet.py:6-18 wraps with `fc` ->
+    out_dim) written with torch.nn.functional calls over a state dict with torchvision's key names -- an independent
+    restatement of the published architecture (torchvision itself is not in the image): stem conv 7x7/2 pad 3 -> BN -> ReLU ->
+    max-pool 3x3/2 pad 1; layers 1-4 = two basic blocks each (conv 3x3 -> BN -> ReLU -> conv 3x3 -> BN, + identity or a
+    1x1/2 conv + BN projection, ReLU), the first block of layers 2-4 strides by 2; global average pool; fc.
+    `train`: batch statistics in the normalisation layers (running statistics are not updated here)."""
+    import torch.nn.functional as F
+    g = lambda k: sd[prefix + k]
+
+    def bn(h, name):
+        return F.batch_norm(h, None if train else g(name + ".running_mean"), None if train else g(name + ".running_var"),
+                            g(name + ".weight"), g(name + ".bias"), training=train, momentum=0.0, eps=eps)
+
+    h = F.relu(bn(F.conv2d(x, g("conv1.weight"), None, stride=2, padding=3), "bn1"))
+    h = F.max_pool2d(h, kernel_size=3, stride=2, padding=1)
+    for li in range(1, 5):
+        for b in range(2):
+            p = "layer%d.%d" % (li, b)
+            stride = 2 if (b == 0 and li > 1) else 1
+            o = F.relu(bn(F.conv2d(h, g(p + ".conv1.weight"), None, stride=stride, padding=1), p + ".bn1"))
+            o = bn(F.conv2d(o, g(p + ".conv2.weight"), None, stride=1, padding=1), p + ".bn2")
+            if (prefix + p + ".downsample.0.weight") in sd:
+                h = bn(F.conv2d(h, g(p + ".downsample.0.weight"), None, stride=stride, padding=0), p + ".downsample.1")
+            h = F.relu(o + h)
+    h = F.adaptive_avg_pool2d(h, 1).flatten(1)
+    return F.linear(h, g("fc.weight"), g("fc.bias"))

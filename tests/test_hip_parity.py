@@ -191,7 +191,8 @@ def test_action_type_torque_and_position_controls(skel):
         cx.set_pd_variant(0)
         f32 = torch.float32
         tq = cx.pd_torque(dev(g["qpos"][:, 0], f32), dev(g["qvel"][:, 0], f32), dev(g["action"], f32), dev(g["qM"], f32), dev(g["C"], f32))
-        np.testing.assert_allclose(tq.cpu().numpy(), g["ctrl_" + mode][:, 0], rtol=2e-5, atol=2e-3)
+        # (float32 i/o on PD targets of up to 1 000 rad: the rounding of the inputs alone moves the unclipped torques by 1e-2)
+        np.testing.assert_allclose(tq.cpu().numpy(), g["ctrl_" + mode][:, 0], rtol=1e-4, atol=5e-2 if mode == "position" else 1e-4)
         cx.close()
     with pytest.raises(ValueError, match="action_type"):
         EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"], obs_options=dict(action_type="velocity"))

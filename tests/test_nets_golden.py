@@ -192,3 +192,40 @@ def test_windows_that_leave_their_take_are_refused():
     fnet.check_windows(np.array([1]), np.array([5]))
     with pytest.raises(ValueError, match="leaves take 1"):
         fnet.check_windows(np.array([1]), np.array([3]))
+
+
+def test_resnet18_state_dict_is_torchvisions_layout():
+    """nets.ResNet18 against the committed key / shape table of torchvision's resnet18 with fc -> 128 (models/resnet.py:6-18;
+    tools/make_resnet18_table.py writes it from torchvision's published layout, not from this module): same keys, same order,
+    same shapes -- a torchvision checkpoint loads with strict=True -- and the reference's wrapper prefix `resnet.`."""
+    import json
+    import os
+    from egopose_amd.nets import ResNet, ResNet18
+    tbl = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "resnet18_keys.json")))
+    sd = ResNet18(128).state_dict()
+    assert [[k, list(v.shape)] for k, v in sd.items()] == tbl["keys"]
+    n = sum(v.numel() for k, v in ResNet18(128).named_parameters() if not k.startswith("fc."))
+    assert n == tbl["trainable_backbone_parameters"] == 11176512
+    assert list(ResNet(128).state_dict()) == ["resnet." + k for k, _ in tbl["keys"]]
+    fake = {k: torch.zeros(shp, dtype=torch.int64 if k.endswith("num_batches_tracked") else torch.float32) for k, shp in tbl["keys"]}
+    ResNet18(128).load_state_dict(fake, strict=True)
+
+
+def test_resnet18_forward_matches_the_functional_restatement():
+    """The module's forward (strides, paddings, where the projection shortcuts sit, pooling) against oracle.nets.resnet18_forward,
+    an independent torch.nn.functional restatement of the published architecture; float64, eval and train-mode statistics."""
+    from egopose_amd.nets import ResNet18
+    from oracle.nets import resnet18_forward
+    torch.manual_seed(3)
+    net = ResNet18(128).double()
+    with torch.no_grad():
+        for m in net.modules():                      # non-trivial running statistics / affine parameters
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    x = torch.randn(3, 3, 96, 80, dtype=torch.float64)
+    sd = net.state_dict()
+    with torch.no_grad():
+        net.eval()
+        np.testing.assert_allclose(net(x).numpy(), resnet18_forward(sd, x).numpy(), rtol=1e-10, atol=1e-10)
+        net.train()
+        np.testing.assert_allclose(net(x).numpy(), resnet18_forward(sd, x, train=True).numpy(), rtol=1e-9, atol=1e-9)
