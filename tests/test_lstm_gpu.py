@@ -346,16 +346,18 @@ def test_bf16_encoder_keeps_float32_master_weights():
     assert len(net._enc16.pairs) == 22 and all(s.dtype == torch.bfloat16 and m.dtype == torch.float32 for m, s in net._enc16.pairs)
     assert net._enc16.shadow.resnet.bn1 is net.cnn.resnet.bn1            # normalisation layers are shared (float32)
     assert all(v.dtype in (torch.float32, torch.int64) for v in net.state_dict().values())          # nothing bf16 in a checkpoint
-    # kept outputs (test mode, stored CNN features) never see the bf16 copy: bit-identical to the float32 encoder
+    # kept outputs (test mode, stored CNN features) never see the bf16 copy: the float32 encoder's result at float32 round-off
+    # (two MIOpen float32 calls are not bit-identical; the bf16 copy would be 1e-3 .. 1e-2 away)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
     with torch.no_grad():
-        assert torch.equal(net(x), ref)
-        assert torch.equal(net.get_cnn_feature(x), net.cnn(net._frames(x)))
+        assert rel(net(x), ref) < 1e-5
+        assert rel(net.get_cnn_feature(x), net.cnn(net._frames(x))) < 1e-5
     # the optimisation step's forward (train mode, autograd on) does: bf16 copy against float32, same batch statistics
     net.train()
     import copy
     net32 = copy.deepcopy(net).bf16_encoder(False)
     got, ref_t = net(x), net32(x)
-    assert got.requires_grad and float((got - ref_t).norm() / ref_t.norm()) < 3e-2 and not torch.equal(got, ref_t)
+    assert got.requires_grad and 1e-5 < rel(got, ref_t) < 3e-2
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
     before = {n: p.detach().clone() for n, p in net.named_parameters()}
     loss = (gt - net(x)).pow(2).sum(1).mean()

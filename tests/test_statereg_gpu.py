@@ -28,7 +28,7 @@ def test_config4_shape_optimisation_step_bf16_encoder():
     pred = net(x)                                     # bf16 encoder on the matrix cores
     assert pred.shape == (256, 115) and pred.dtype == torch.float32
     rel = float((pred.detach() - ref).norm() / ref.norm())
-    assert rel < 3e-2, rel
+    assert 1e-5 < rel < 3e-2, rel
     opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-4)
     before = {n: p.detach().clone() for n, p in net.named_parameters()}
     loss = (gt - pred).pow(2).sum(dim=1).mean()
@@ -37,7 +37,7 @@ def test_config4_shape_optimisation_step_bf16_encoder():
     net.encoder_grads_ready()
     opt.step()
     net.encoder_stepped()
-    assert np.isfinite(float(loss))
+    assert np.isfinite(float(loss.detach()))
     for n, p in net.named_parameters():
         assert p.dtype == torch.float32 and torch.isfinite(p).all() and not torch.equal(p, before[n]), n
     for m, s in net._enc16.pairs:
@@ -48,7 +48,8 @@ def test_config4_shape_optimisation_step_bf16_encoder():
     net.eval()
     with torch.no_grad():
         feats = net.get_cnn_feature(x[:32])
-        assert feats.shape == (32, 128) and torch.equal(feats, net.cnn(net._frames(x[:32])))
+        want = net.cnn(net._frames(x[:32]))            # (two MIOpen float32 calls agree to round-off, not bit for bit)
+        assert feats.shape == (32, 128) and float((feats - want).norm() / want.norm()) < 1e-5
 
 
 def test_config4_bench_leg_reports_frames_per_second():
