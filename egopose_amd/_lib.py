@@ -78,6 +78,30 @@ class GemmDesc(C.Structure):
                 ("c_rows", vp), ("a_krows", vp)]
 
 
+class PpoLossDesc(C.Structure):
+    """egp_ppo_loss_desc (include/egopose_hip.h)."""
+    _fields_ = [("n", C.c_int32), ("n_pol", C.c_int32), ("act_dim", C.c_int32),
+                ("rows", vp), ("pred", vp), ("returns", vp),
+                ("mean", vp), ("ld_mean", C.c_int64),
+                ("actions", vp), ("ld_act", C.c_int64),
+                ("log_std", vp), ("adv", vp),
+                ("fixed_logp", vp), ("write_fixed", C.c_int32),
+                ("clip_eps", C.c_double), ("inv_n_val", C.c_double), ("inv_n_exp", C.c_double),
+                ("d_pred", vp), ("d_mean", vp), ("ld_dmean", C.c_int64), ("d_log_std", vp),
+                ("losses", vp), ("workspace", vp)]
+
+
+class AdamSegment(C.Structure):
+    """egp_adam_segment (include/egopose_hip.h)."""
+    _fields_ = [("begin", C.c_int64), ("end", C.c_int64),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
+                ("bias1", C.c_double), ("bias2", C.c_double), ("max_norm", C.c_double),
+                ("clip_group", C.c_int32)]
+
+
+ADAM_MAX_SEGMENTS = 8
+
+
 class RolloutTick(C.Structure):
     """egp_rollout_tick (include/egopose_hip.h): field order and types must match the header."""
     _fields_ = [("ctx", vp), ("eng", vp), ("stream", vp),
@@ -152,6 +176,12 @@ SIGNATURES = {
     "egp_scatter_rows_f32": (C.c_int, [vp, _i64, vp, _i32, _i32, vp, _i64, vp]),
     "egp_gemm_workspace_floats": (_i64, [_i32, _i32, _i32, _i32]),
     "egp_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "egp_ppo_loss_workspace_bytes": (_i64, [_i32, _i32, _i32]),
+    "egp_ppo_loss_f32": (C.c_int, [C.POINTER(PpoLossDesc), vp]),
+    "egp_adam_workspace_bytes": (_i64, []),
+    "egp_adam_step_f32": (C.c_int, [_i32, C.POINTER(AdamSegment), vp, vp, vp, vp, vp, vp, vp]),
+    "egp_adam_step_f64": (C.c_int, [_i32, C.POINTER(AdamSegment), vp, vp, vp, vp, vp, vp, vp, vp]),
+    "egp_adam_step_f64g": (C.c_int, [_i32, C.POINTER(AdamSegment), vp, vp, vp, vp, vp, vp, vp]),
     "egp_lstm_fwd_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp]),
     "egp_lstm_bwd_f32": (C.c_int, [vp, vp, vp, vp, _i32, _i32, _i32, _i32, vp, vp]),
     "egp_lstm_group_fwd_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_void_p), _i32, vp, vp, vp]),

@@ -24,6 +24,7 @@ from __future__ import annotations
 import copy
 import math
 import os
+import sys
 import time
 import types
 
@@ -31,6 +32,7 @@ import numpy as np
 import torch
 
 from . import dist as D
+from . import optim as O
 from .rl_core import LoggerRL, TrajBatch, TrajBatchEgo
 from .torch_utils import to_test, to_train
 
@@ -116,6 +118,11 @@ class Agent:
         self.logger_cls = LoggerRL
         self._rollout = None
         self._bind_compute_nets()
+        if self.cdtype != self.dtype and os.environ.get("EGP_QUIET", "0") != "1":
+            #  a float64 driver gets float32 arithmetic on the GPU: say so once, where the agent is built
+            print("egopose_amd: agent declared %s computes in %s on %s (float64 master weights for checkpoints / optimizers; "
+                  "EGP_NET_DTYPE=float64 keeps float64 arithmetic)" % (str(self.dtype).replace("torch.", ""),
+                                                                     str(self.cdtype).replace("torch.", ""), self.device), file=sys.stderr)
 
     def _master_nets(self):
         return dict(policy_net=self.policy_net, value_net=self.value_net)
@@ -136,8 +143,15 @@ class Agent:
         self.update_modules = [self.cn.policy_net, self.cn.value_net]
 
     def _zero_grads(self):
-        self.optimizer_value.zero_grad()
-        self.optimizer_policy.zero_grad()
+        up = self._get_updater() if hasattr(self, "_updater") else None
+        if up is not None:
+            up.zero_grad()
+            return
+        if getattr(self, "_grad_sync", None) is not None:
+            self._grad_sync.attach()            # gradients accumulate inside the all-reduce buffer (p.grad = its views)
+        else:
+            self.optimizer_value.zero_grad()
+            self.optimizer_policy.zero_grad()
         if self.shadow is not None:
             self.shadow.zero_grad()
 
@@ -147,6 +161,9 @@ class Agent:
             self.shadow.push_grads()
 
     def _params_stepped(self):
+        up = getattr(self, "_updater", None) or None
+        if up is not None:
+            up.rebind()          # (a caller may have moved its modules: `with to_cpu(...)` around a checkpoint)
         if self.shadow is not None:
             self.shadow.pull()
 
@@ -218,16 +235,29 @@ class AgentPG(Agent):
         self.optimizer_policy, self.optimizer_value = optimizer_policy, optimizer_value
         self.opt_num_epochs, self.value_opt_niter = opt_num_epochs, value_opt_niter
         self._grad_sync = None
+        self._updater = None            # optim.FlatUpdater (fused clip + Adam over flat buffers) once built; False = not eligible
         self.update_stats = {}
 
     # -- pieces shared by the A2C and PPO updates -------------------------------------------------
     def _advantages(self, rewards, masks, values):
-        """K5 on device + standardisation with the GLOBAL mean / unbiased std (core/common.py:5-25)."""
+        """K5 on device + standardisation with the GLOBAL mean / unbiased std (core/common.py:5-25). This rank's sample
+        counts left in `self._pending_counts` (rows, exploration rows) ride in the same all-reduce as the advantage moments and
+        come back as `self._global_counts`: one scalar exchange per update."""
         ctx = self._kernel_ctx()
         adv, ret, stats = ctx.gae(rewards.contiguous(), masks.contiguous(), values.reshape(-1).contiguous(), self.gamma, self.tau)
-        stats = D.merge_moments(stats)
+        stats, self._global_counts = D.merge_moments_and_counts(stats, getattr(self, "_pending_counts", None))
         ctx.gae_standardize(adv, stats)
         return adv.unsqueeze(1), ret.unsqueeze(1)
+
+    def _advantages_with_counts(self, rewards, masks, values, counts):
+        """-> (advantages, returns, global counts or None). None: `_advantages` was replaced (tests put the oracle's GAE
+        there) and did not exchange the counts; update_policy then does it itself."""
+        self._pending_counts, self._global_counts = counts, None
+        try:
+            adv, ret = self._advantages(rewards, masks, values)
+        finally:
+            self._pending_counts = None
+        return adv, ret, self._global_counts
 
     def _kernel_ctx(self):
         return self._get_rollout().sim.ctx
@@ -244,6 +274,41 @@ class AgentPG(Agent):
                 self._grad_sync = D.FlatGradSync(self._value_params() + self._policy_params())
             self._grad_sync.all_reduce()
 
+    def _clip_list(self):
+        return []
+
+    def _get_updater(self):
+        """optim.FlatUpdater for this agent's two optimizers, or None (CPU device, non-Adam optimizers, EGP_FUSED_OPTIM=0, ...)."""
+        if self._updater is None:
+            up = None
+            if torch.device(self.device).type == "cuda" and os.environ.get("EGP_FUSED_OPTIM", "1") != "0" and \
+                    self.optimizer_value is not None and self.optimizer_policy is not None:
+                compute_of = {m: c for m, c in self.shadow.pairs} if self.shadow is not None else None
+                up = O.FlatUpdater.build([self.optimizer_value, self.optimizer_policy], self._clip_list(), compute_of)
+            self._updater = up if up is not None else False
+        return self._updater or None
+
+    def _optim_step(self, which=(0, 1)):
+        """After backward: gradient exchange, clip, optimizer steps (0 = value, 1 = policy; the reference steps the critic
+        first, agents/agent_ppo.py:24-30), compute copies refreshed."""
+        up = self._get_updater()
+        if up is not None:
+            up.collect_grads(which)
+            up.all_reduce(which)
+            up.step(which)
+            return
+        self._grads_ready()
+        self._sync_grads()
+        if 0 in which:
+            self.optimizer_value.step()
+        if 1 in which:
+            self.clip_policy_grad()
+            self.optimizer_policy.step()
+        self._params_stepped()
+
+    def clip_policy_grad(self):
+        return
+
     def _value_backward(self, states, returns, n_global):
         """MSE critic loss of the global batch (this rank's share) -> gradients, no optimizer step."""
         if self.value_opt_niter != 1:
@@ -257,11 +322,7 @@ class AgentPG(Agent):
         """update critic (agents/agent_pg.py:19-26)"""
         self._zero_grads()
         loss = self._value_backward(states, returns, D.global_count(states.shape[0], states.device))
-        self._grads_ready()
-        if D.world_size() > 1:
-            D.FlatGradSync(self._value_params()).all_reduce()
-        self.optimizer_value.step()
-        self._params_stepped()
+        self._optim_step(which=(0,))
         return loss
 
     def update_policy(self, states, actions, returns, advantages, exps):
@@ -274,11 +335,7 @@ class AgentPG(Agent):
             logp = self.cn.policy_net.get_log_prob(self.trans_policy(states)[ind], actions[ind])
             loss = -(logp * advantages[ind]).sum() / n_exp
             loss.backward()
-            self._grads_ready()
-            self._sync_grads()
-            self.optimizer_value.step()
-            self.optimizer_policy.step()
-            self._params_stepped()
+            self._optim_step()
 
     def _load_batch(self, batch):
         dev = torch.device(self.device)
@@ -309,10 +366,22 @@ class AgentPPO(AgentPG):
         """Hook: prepare the critic's and the actor's state transforms together (AgentEgo). False = nothing prepared."""
         return False
 
+    def _clip_list(self):
+        return [(list(params), max_norm) for params, max_norm in (self.policy_grad_clip or [])]
+
     def clip_policy_grad(self):
         if self.policy_grad_clip is not None:
             for params, max_norm in self.policy_grad_clip:
                 torch.nn.utils.clip_grad_norm_(params, max_norm)
+
+    def _fused_losses(self):
+        """Both losses and their gradients w.r.t. the nets' outputs from ONE HIP launch (optim.ppo_losses) instead of ~35
+        element-wise library kernels per epoch: float32 compute nets on the GPU with a Gaussian policy head."""
+        pol = self.cn.policy_net
+        ls = getattr(pol, "action_log_std", None)
+        return (torch.device(self.device).type == "cuda" and self.cdtype == torch.float32 and self.value_opt_niter == 1
+                and hasattr(pol, "mean_std") and ls is not None and ls.dim() == 2 and ls.shape[0] == 1 and ls.shape[1] <= 256
+                and ls.dtype == torch.float32 and os.environ.get("EGP_FUSED_LOSS", "1") != "0")
 
     def ppo_loss(self, states, actions, advantages, fixed_log_probs, ind, n_exp=None):
         """`ind` = rows with exps == 1 (agents/agent_ppo.py:45-51), or None when that is every row (no gather copies)."""
@@ -339,24 +408,35 @@ class AgentPPO(AgentPG):
         clipped = torch.clamp(ratio, 1.0 - self.clip_epsilon, 1.0 + self.clip_epsilon) * adv
         return -torch.min(ratio * adv, clipped).sum() / n_exp
 
-    def update_policy(self, states, actions, returns, advantages, exps, first_pass=None):
-        """`first_pass` = (pred, logp, ind) of a forward pass ALREADY made with the current weights and autograd on
+    def update_policy(self, states, actions, returns, advantages, exps, first_pass=None, counts=None):
+        """`first_pass` = (pred, head, ind) of a forward pass ALREADY made with the current weights and autograd on
         (AgentEgo.update_params): it served as the no-grad value / fixed-log-prob pass and now is epoch 0's forward --
-        the weights have not moved in between, so the numbers are the reference's, with two forward passes fewer."""
+        the weights have not moved in between, so the numbers are the reference's, with two forward passes fewer.
+        `head` is the policy's action mean when the fused loss kernel runs (`_fused_losses`), else its log-probabilities.
+        `counts` = (global rows, global exploration rows) when the caller has exchanged them already."""
         if self.use_mini_batch:
             raise NotImplementedError("mini-batch PPO is not on the ego_mimic path (AgentEgo forces full batch)")
-        n_val = D.global_count(states.shape[0], states.device)
+        fused = self._fused_losses()
+        if first_pass is None:
+            ind, n_ind = self._exploration_rows(exps, states.shape[0])
+        else:
+            ind = first_pass[2]
+            n_ind = states.shape[0] if ind is None else ind.shape[0]
+        if counts is None:
+            n_val = D.global_count(states.shape[0], states.device)
+            n_exp = D.global_count(n_ind, states.device)
+        else:
+            n_val, n_exp = counts
+        if fused:
+            return self._update_policy_fused(states, actions, returns, advantages, ind, n_ind, n_val, n_exp, first_pass)
         if first_pass is None:
             with to_test(*self.update_modules):
                 with torch.no_grad():
                     fixed_log_probs = self.cn.policy_net.get_log_prob(self.trans_policy(states), actions)
-            ind, n_ind = self._exploration_rows(exps, states.shape[0])
         else:
-            pred0, logp0, ind = first_pass
-            n_ind = states.shape[0] if ind is None else ind.shape[0]
+            pred0, logp0, _ = first_pass
             fixed_sel = logp0.detach()
             fixed_log_probs = None
-        n_exp = D.global_count(n_ind, states.device)
         losses = []
         for epoch in range(self.opt_num_epochs):
             # critic and actor have disjoint parameters: both backward passes run before the single gradient
@@ -392,14 +472,46 @@ class AgentPPO(AgentPG):
                 v_loss = self._value_backward(states, returns, n_val)
                 s_loss = self.ppo_loss(states, actions, advantages, fixed_log_probs, ind, n_exp)
                 s_loss.backward()
-            self._grads_ready()            # (shadow gradients -> the masters the optimizers / the clip list hold)
-            self._sync_grads()
-            self.optimizer_value.step()
-            self.clip_policy_grad()
-            self.optimizer_policy.step()
-            self._params_stepped()
+            self._optim_step()
             losses.append((v_loss.detach(), s_loss.detach()))
         self.update_stats = {"value_loss": [float(v) for v, _ in losses], "surr_loss": [float(s) for _, s in losses]}
+
+    def _policy_mean(self, x):
+        return self.cn.policy_net.mean_std(x)[0]
+
+    def _update_policy_fused(self, states, actions, returns, advantages, ind, n_ind, n_val, n_exp, first_pass):
+        """The epochs with optim.ppo_losses: forward passes -> ONE launch for both losses and d loss / d (values, action mean)
+        -> autograd from those two tensors -> fused exchange / clip / Adam (`_optim_step`). Epoch 0's forward doubles as the
+        pass that fixes the sampling policy's log-probabilities (the weights have not moved since the rollout), whether it
+        arrives as `first_pass` or is made here."""
+        dev = states.device
+        n, A = states.shape[0], actions.shape[1]
+        pol = self.cn.policy_net
+        log_std = pol.action_log_std
+        learn_std = bool(log_std.requires_grad)
+        fixed = torch.empty(n_ind, dtype=torch.float32, device=dev)
+        d_pred = torch.empty(n, 1, dtype=torch.float32, device=dev)
+        d_mean = torch.empty(n_ind, A, dtype=torch.float32, device=dev)
+        rec = torch.zeros(max(1, self.opt_num_epochs), 2, dtype=torch.float64, device=dev)
+        act = actions if actions.stride(1) == 1 else actions.contiguous()
+        for epoch in range(self.opt_num_epochs):
+            if first_pass is not None and epoch == 0:
+                pred, mean = first_pass[0], first_pass[1]
+            else:
+                self._group_contexts(states)
+                pred = self.cn.value_net(self.trans_value(states))
+                x = self.trans_policy(states)
+                mean = self._policy_mean(x if ind is None else x[ind])
+            self._zero_grads()
+            _, _, _, d_ls = O.ppo_losses(pred.detach(), returns, mean.detach(), act, log_std.detach(), advantages, fixed, epoch == 0,
+                                         self.clip_epsilon, n_val, n_exp, rows=ind, d_pred=d_pred, d_mean=d_mean,
+                                         want_d_log_std=learn_std, losses_out=rec[epoch])
+            torch.autograd.backward([pred, mean], [d_pred, d_mean])
+            if learn_std:
+                log_std.grad = d_ls.view_as(log_std)
+            self._optim_step()
+        host = rec.tolist()
+        self.update_stats = {"value_loss": [r[0] for r in host[:self.opt_num_epochs]], "surr_loss": [r[1] for r in host[:self.opt_num_epochs]]}
 
 
 def _quat_v3_marker(fn):
@@ -478,23 +590,28 @@ class AgentEgo(AgentPPO):
                 net.adopt_train_context(vs_nets[0], x_init)      # same batch, same feature table: segment and gather once
             else:
                 net.initialize(x_init)
+        n_rows = c["states"].shape[0]
+        ind, n_ind = self._exploration_rows(c["exps"], n_rows)
         if self.value_opt_niter == 1 and os.environ.get("EGP_REUSE_FIRST_PASS", "1") != "0":
             # ONE forward pass with autograd on serves three purposes: the values that GAE consumes, the fixed log-probs of
             # the surrogate, and epoch 0's forward (nothing has stepped in between; no dropout / batch norm in these nets)
             self._group_contexts(c["states"])
             pred0 = self.cn.value_net(self.trans_value(c["states"]))
-            ind, _ = self._exploration_rows(c["exps"], c["states"].shape[0])
             x = self.trans_policy(c["states"])
-            logp0 = self.cn.policy_net.get_log_prob(x if ind is None else x[ind], c["actions"] if ind is None else c["actions"][ind])
-            advantages, returns = self._advantages(c["rewards"], c["masks"], pred0.detach())
-            self.update_policy(c["states"], c["actions"], returns, advantages, c["exps"], first_pass=(pred0, logp0, ind))
+            xs = x if ind is None else x[ind]
+            if self._fused_losses():
+                head0 = self._policy_mean(xs)           # the loss kernel forms the log-probabilities itself
+            else:
+                head0 = self.cn.policy_net.get_log_prob(xs, c["actions"] if ind is None else c["actions"][ind])
+            advantages, returns, counts = self._advantages_with_counts(c["rewards"], c["masks"], pred0.detach(), (n_rows, n_ind))
+            self.update_policy(c["states"], c["actions"], returns, advantages, c["exps"], first_pass=(pred0, head0, ind), counts=counts)
         else:
             with to_test(*self.update_modules):
                 with torch.no_grad():
                     self._group_contexts(c["states"])       # the policy net's context is consumed by update_policy's first pass
                     values = self.cn.value_net(self.trans_value(c["states"]))
-            advantages, returns = self._advantages(c["rewards"], c["masks"], values)
-            self.update_policy(c["states"], c["actions"], returns, advantages, c["exps"])
+            advantages, returns, counts = self._advantages_with_counts(c["rewards"], c["masks"], values, (n_rows, n_ind))
+            self.update_policy(c["states"], c["actions"], returns, advantages, c["exps"], counts=counts)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         return time.time() - t0

@@ -65,16 +65,31 @@ def chan_merge(parts):
     return n, mean, m2
 
 
-def merge_moments(stats):
-    """stats: device float64[3] = {n, mean, M2} of this rank's raw advantages -> the global moments."""
+def merge_moments_and_counts(stats, counts=None):
+    """ONE float64 all-reduce for the scalars of an update: `stats` = device float64[3] {n, mean, M2} of this rank's raw
+    advantages, `counts` = this rank's sample counts (any number of them, or None). Returns (global {n, mean, M2} on the
+    device, [global counts] or None). Every rank sends {n, n mean, M2 + n mean^2, counts...}; from the sums
+    mean = S1 / N and M2 = S2 - N mean^2 (Chan's merge written as sums: exact for one rank, and the subtraction loses
+    nothing that matters at float64 -- advantages have |mean| << std). The result stays on the device (no host copy of the
+    moments); only the counts come back to the host, in the same transfer."""
     if not is_on():
-        return stats
+        return stats, (None if counts is None else [int(c) for c in counts])
     dev = _comm_device(stats.device)
-    gathered = [torch.empty(3, dtype=torch.float64, device=dev) for _ in range(world_size())]
-    dist.all_gather(gathered, stats.to(dev))
-    rows = torch.stack(gathered).cpu().numpy()
-    n, mean, m2 = chan_merge([(r[0], r[1], r[2]) for r in rows])
-    return torch.tensor([n, float(mean), float(m2)], dtype=torch.float64, device=stats.device)
+    n, mean, m2 = stats[0], stats[1], stats[2]
+    head = torch.stack((n, n * mean, m2 + n * mean * mean))
+    if counts is not None:
+        head = torch.cat((head, torch.tensor([float(c) for c in counts], dtype=torch.float64, device=stats.device)))
+    vec = head.to(dev)
+    dist.all_reduce(vec)
+    vec = vec.to(stats.device)
+    gm = vec[1] / vec[0]
+    out = torch.stack((vec[0], gm, torch.clamp(vec[2] - vec[0] * gm * gm, min=0.0)))
+    return out, (None if counts is None else [int(round(c)) for c in vec[3:].tolist()])
+
+
+def merge_moments(stats):
+    """stats: device float64[3] = {n, mean, M2} of this rank's raw advantages -> the global moments (on the device)."""
+    return merge_moments_and_counts(stats, None)[0]
 
 
 class FlatGradSync:
@@ -96,12 +111,24 @@ class FlatGradSync:
             self.views.append(self.flat[pos:pos + p.numel()].view_as(p))
             pos += p.numel()
 
-    def all_reduce(self):
+    def attach(self):
+        """Zero the flat buffer and make its views the parameters' .grad: autograd then accumulates straight into the buffer
+        the collective runs on (what `zero_grad` is to the single-process update)."""
+        self.flat.zero_()
         for p, v in zip(self.params, self.views):
-            if p.grad is None:
+            p.grad = v
+
+    def all_reduce(self):
+        """One SUM all-reduce over the flat buffer. Gradients that already live in it (`attach`) are not copied; any other
+        .grad is copied in first and the parameter is re-pointed at the buffer."""
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
                 v.zero_()
-            else:
-                v.copy_(p.grad)
+                p.grad = v
+            elif g.data_ptr() != v.data_ptr():
+                v.copy_(g)
+                p.grad = v
         if is_on():
             dev = _comm_device(self.flat.device)
             if dev == self.flat.device:
@@ -110,11 +137,6 @@ class FlatGradSync:
                 tmp = self.flat.to(dev)
                 dist.all_reduce(tmp)
                 self.flat.copy_(tmp)
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
 
 
 def merge_loggers(log, device):

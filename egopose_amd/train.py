@@ -83,10 +83,9 @@ class Trainer:
 
     def _optimizer(self, kind, params, lr, momentum, weight_decay):
         if kind == "Adam":
-            params = list(params)
-            # one fused launch per step on the GPU instead of a handful of multi-tensor ones (same update rule)
-            fused = not self.plain_optim and bool(params) and all(p.is_cuda and p.is_floating_point() for p in params)
-            return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, **({"fused": True} if fused else {}))
+            # built exactly as the driver builds them (ego_pose/ego_mimic.py:70-77); on the GPU the agent steps them through
+            # optim.FlatUpdater (clip + both Adam steps in two launches over flat buffers, same update rule)
+            return torch.optim.Adam(list(params), lr=lr, weight_decay=weight_decay)
         return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay)
 
     def pre_iter_update(self, i_iter):

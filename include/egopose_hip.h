@@ -292,6 +292,65 @@ typedef struct egp_gemm_desc {
     const int64_t *c_rows;
     const int64_t *a_krows;
 } egp_gemm_desc;
+/* ------------------------------------------------------------------------------------ update: losses and the optimizer step
+ * (csrc/egp_update.hip) The element-wise tail of a PPO epoch in two launches instead of ~45 small library kernels.
+ *
+ * egp_ppo_loss_f32 -- the critic's MSE loss (agents/agent_pg.py:19-26: (values_pred - returns).pow(2).mean()) and the clipped
+ * surrogate (agents/agent_ppo.py:58-65 over core/distributions.py:6-25 / utils/math.py:14-17):
+ *     logp_i   = sum_j -(a_ij - mean_ij)^2 / (2 var_j) - 0.5 log(2 pi) - log_std_j
+ *     ratio_i  = exp(logp_i - fixed_logp_i);  surr = min(ratio_i A_i, clamp(ratio_i, 1 - eps, 1 + eps) A_i)
+ *     losses[0] = inv_n_val * sum_i (pred_i - returns_i)^2,  losses[1] = -inv_n_exp * sum_i surr_i
+ * together with their gradients w.r.t. the nets' outputs -- d_pred = 2 inv_n_val (pred - returns), d_mean (through
+ * ratio -> logp -> mean, with torch.min / torch.clamp's sub-gradients: ties share, clamp passes inside [1 - eps, 1 + eps]),
+ * d_log_std (only when the policy learns its standard deviation) -- so the caller back-propagates from (pred, mean) directly.
+ * inv_n_val / inv_n_exp carry the GLOBAL counts (every rank divides by them; the gradient all-reduce sums).
+ * `rows` (or NULL): policy row i is sample rows[i] of actions / adv (the rows with exps == 1, agent_ppo.py:45-46); mean,
+ * fixed_logp and d_mean are dense over the n_pol policy rows. write_fixed = 1: this is the pass that defines the sampling
+ * policy's log-probabilities -- logp is written to fixed_logp and used (ratio == 1), what get_log_prob under no_grad
+ * (agent_ppo.py:40-42) followed by epoch 0 computes. Sums in float64, fixed order (deterministic). All pointers device memory. */
+typedef struct egp_ppo_loss_desc {
+    int32_t n, n_pol, act_dim;
+    const int64_t *rows;
+    const float *pred; const float *returns;
+    const float *mean; int64_t ld_mean;
+    const float *actions; int64_t ld_act;
+    const float *log_std;
+    const float *adv;
+    float *fixed_logp; int32_t write_fixed;
+    double clip_eps, inv_n_val, inv_n_exp;
+    float *d_pred;
+    float *d_mean; int64_t ld_dmean;
+    float *d_log_std;
+    double *losses;
+    void *workspace;
+} egp_ppo_loss_desc;
+int64_t egp_ppo_loss_workspace_bytes(int32_t n, int32_t n_pol, int32_t act_dim);
+int egp_ppo_loss_f32(const egp_ppo_loss_desc *desc, void *stream);
+
+/* egp_adam_step_* -- gradient-norm clip + Adam over FLAT parameter buffers: clip_policy_grad (agents/agent_ppo.py:53-56,
+ * torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (||g||_2 + 1e-6))) followed by optimizer_value.step() /
+ * optimizer_policy.step() (agent_ppo.py:24-30; torch.optim.Adam, no amsgrad) in two launches for all parameter sets.
+ * A segment = one optimizer parameter group laid out contiguously in the flat buffers:
+ *     g = clip_coef * grad (+ weight_decay * p);  m = m + (1 - beta1)(g - m);  v = beta2 v + (1 - beta2) g^2
+ *     p -= (lr / bias1) * m / (sqrt(v) / sqrt(bias2) + eps)        bias1 = 1 - beta1^t, bias2 = 1 - beta2^t (host-computed)
+ * Segments with the same clip_group > 0 share one norm (the reference clips policy_net + policy_vs_net together); 0 = no clip.
+ * _f32: float32 parameters / moments / gradients. _f64: float64 MASTER parameters and moments, float32 gradients (of the
+ * float32 compute copies), and `shadow` (or NULL) receives the stepped parameters rounded to float32 -- the compute copy is
+ * refreshed by the same launch. _f64g: float64 throughout. */
+typedef struct egp_adam_segment {
+    int64_t begin, end;
+    double lr, beta1, beta2, eps, weight_decay, bias1, bias2, max_norm;
+    int32_t clip_group;
+} egp_adam_segment;
+#define EGP_ADAM_MAX_SEGMENTS 8
+int64_t egp_adam_workspace_bytes(void);
+int egp_adam_step_f32(int32_t n_seg, const egp_adam_segment *seg, const float *grad, float *param, float *exp_avg, float *exp_avg_sq,
+                      void *workspace, double *norms_out, void *stream);
+int egp_adam_step_f64(int32_t n_seg, const egp_adam_segment *seg, const float *grad, double *param, double *exp_avg, double *exp_avg_sq,
+                      float *shadow, void *workspace, double *norms_out, void *stream);
+int egp_adam_step_f64g(int32_t n_seg, const egp_adam_segment *seg, const double *grad, double *param, double *exp_avg, double *exp_avg_sq,
+                       void *workspace, double *norms_out, void *stream);
+
 /* The update's policy / value input in one pass (VideoStateNet.forward('train'), models/video_state_net.py:65-69):
  * out[i] = [ ctx[idx[i]][0:H] | x[i][0:S] ] for i < n, and the adjoint for the context rows, dctx[idx[i]][0:H] = dout[i][0:H]
  * (idx must not repeat: every (time, episode) row of the video net's output belongs to one sample; dctx is zero-filled by

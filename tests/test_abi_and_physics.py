@@ -36,7 +36,8 @@ def test_ctypes_mirrors_have_the_library_s_struct_sizes():
                "egp_gemm_desc": _lib.GemmDesc, "egp_dynamics_desc": _lib.DynamicsDesc,
                "egp_mlp_layer": _lib.MlpLayer, "egp_physics_vtable": _lib.PhysicsVtable,
                "egp_surrogate_desc": _lib.SurrogateDesc, "egp_engine_desc": _lib.EngineDesc,
-               "egp_rollout_tick": _lib.RolloutTick}
+               "egp_rollout_tick": _lib.RolloutTick, "egp_ppo_loss_desc": _lib.PpoLossDesc,
+               "egp_adam_segment": _lib.AdamSegment}
     header = open(os.path.join(REPO, "include", "egopose_hip.h")).read()
     declared = set(re.findall(r"^\} (egp_[a-z_]+);", header, flags=re.M))
     assert declared == set(mirrors), "a struct in include/egopose_hip.h has no ctypes mirror (or the reverse)"
