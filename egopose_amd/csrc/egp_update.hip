@@ -8,7 +8,7 @@
 //   k_adam       torch.optim.Adam.step for every parameter group of both optimizers (agent_ppo.py:24-30)
 //
 // All three are one pass over their operands (HBM-bound, a few MB): what they replace is ~45 launch-bound library kernels per
-// epoch. Reductions are float64 in a fixed order: per-workgroup partials, summed in index order by whoever comes last.
+// epoch. Reductions are float64 in a fixed order: per-workgroup partials, summed in index order by a one-workgroup launch.
 #include <hip/hip_runtime.h>
 
 #include <math.h>
@@ -61,7 +61,6 @@ __device__ __forceinline__ double block_sum(double v, double *s_red) {
 __global__ __launch_bounds__(LOSS_BLOCK) void k_ppo_loss(LossArgs a) {
     __shared__ double s_red[4];
     __shared__ float s_grp[LOSS_BLOCK / LOSS_GROUP][LOSS_MAX_ACT];        // d_log_std sums of the block's 16 row groups
-    __shared__ int s_last;
     const int t = threadIdx.x;
     double v_sum = 0.0, s_sum = 0.0;
     const bool want_dls = a.d_log_std != nullptr;
@@ -159,21 +158,17 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_ppo_loss(LossArgs a) {
             mine[2 + j] = d;
         }
     }
-    // ---- whoever finishes last adds the partials up in index order
-    __threadfence();
-    __syncthreads();
-    if (t == 0) {
-        const unsigned prev = atomicAdd(a.counter, 1u);
-        s_last = prev == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    const int nb = gridDim.x, stride = 2 + a.act_dim;
+}
+
+// The partials -> losses[2] (and d_log_std): one workgroup, index order. A launch of its own rather than "whoever finishes
+// last": a device-scope release / acquire per workgroup writes back and invalidates the XCD's whole L2 on this chip -- the
+// loss kernel took 170 us with that pattern and 1 100 workgroups, against the ~30 us its 84 MB of traffic need.
+__global__ __launch_bounds__(LOSS_BLOCK) void k_ppo_loss_final(LossArgs a, int nb) {
+    __shared__ double s_red[4];
+    const int t = threadIdx.x, stride = 2 + a.act_dim;
     double v = 0.0, s = 0.0;
-    // 256 threads take interleaved slices; the slice sums are combined by block_sum's fixed tree
-    for (int b = t; b < nb; b += LOSS_BLOCK) {
-        const volatile double *p = a.part + (long)b * stride;
+    for (int b = t; b < nb; b += LOSS_BLOCK) {               // 256 interleaved slices, combined by block_sum's fixed tree
+        const double *p = a.part + (long)b * stride;
         v += p[0];
         s += p[1];
     }
@@ -182,12 +177,11 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_ppo_loss(LossArgs a) {
     if (t == 0) {
         a.losses[0] = v * a.inv_n_val;
         a.losses[1] = -s * a.inv_n_exp;
-        *a.counter = 0u;
     }
-    if (want_dls) {
+    if (a.d_log_std) {
         for (int j = t; j < a.act_dim; j += LOSS_BLOCK) {
             double d = 0.0;
-            for (int b = 0; b < a.pol_blocks; ++b) d += ((const volatile double *)a.part)[(long)b * stride + 2 + j];
+            for (int b = 0; b < a.pol_blocks; ++b) d += a.part[(long)b * stride + 2 + j];
             a.d_log_std[j] = (float)d;
         }
     }
@@ -330,10 +324,8 @@ int egp_ppo_loss_f32(const egp_ppo_loss_desc *d, void *stream) {
     a.clip_eps = d->clip_eps; a.inv_n_val = d->inv_n_val; a.inv_n_exp = d->inv_n_exp;
     a.d_pred = d->d_pred; a.d_mean = d->d_mean; a.d_log_std = d->d_log_std;
     a.losses = d->losses;
-    // workspace: a zero-initialised arrival counter (64 bytes; the kernel leaves it at zero) followed by the partials.
-    // The caller hands a buffer it zeroed once at allocation.
-    a.counter = (unsigned *)d->workspace;
-    a.part = (double *)((char *)d->workspace + 64);
+    a.counter = nullptr;
+    a.part = (double *)d->workspace;                        // [workgroups][2 + act_dim] partial sums
     constexpr int GPB = LOSS_BLOCK / LOSS_GROUP;
     long pb = ((long)d->n_pol + 4 * GPB - 1) / (4 * GPB);          // ~4 passes of 16 rows per block
     pb = pb < 1 ? (d->n_pol > 0 ? 1 : 0) : (pb > LOSS_MAX_BLOCKS ? LOSS_MAX_BLOCKS : pb);
@@ -347,7 +339,10 @@ int egp_ppo_loss_f32(const egp_ppo_loss_desc *d, void *stream) {
     }
     a.pol_blocks = (int)pb;
     k_ppo_loss<<<dim3((unsigned)(pb + vb)), dim3(LOSS_BLOCK), 0, (hipStream_t)stream>>>(a);
-    return after_launch("k_ppo_loss");
+    int rc = after_launch("k_ppo_loss");
+    if (rc != EGP_OK) return rc;
+    k_ppo_loss_final<<<dim3(1), dim3(LOSS_BLOCK), 0, (hipStream_t)stream>>>(a, (int)(pb + vb));
+    return after_launch("k_ppo_loss_final");
 }
 
 int64_t egp_adam_workspace_bytes(void) { return (int64_t)(EGP_ADAM_MAX_SEGMENTS + 1) * NORM_BLOCKS * (int64_t)sizeof(double); }

@@ -123,8 +123,8 @@ def test_flat_updater_equals_clip_grad_norm_plus_adam(master, compute):
             if not rp.requires_grad:
                 continue
             gr = torch.randn(rp.shape, device="cuda", generator=g, dtype=torch.float32) * scale
-            rp.grad = gr.to(master)                           # the reference side sees the same float32 gradient values
-            comp(npar).grad = gr.to(compute)
+            rp.grad = gr.to(master).clone()                   # the reference side sees the same float32 gradient values
+            comp(npar).grad = gr.to(compute).clone()          # (own storage: clip_grad_norm_ scales the reference's in place)
         r_ov.step()
         torch.nn.utils.clip_grad_norm_(ref_p, 40.0)
         r_op.step()
