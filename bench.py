@@ -217,6 +217,9 @@ def run_leg(make_trainer, steps, warmup, min_batch, every, env=None, default_dty
         if tim["k1_launches"] > 0:
             out["k1_avg_launch_us"] = tim["k1_ms"] * 1e3 / tim["k1_launches"]
             out["k1_stepped_envs_per_launch"] = tim["k1_env_substeps"] / float(max(1, eng.substeps_per_launch)) / tim["k1_launches"]
+        rt = tr.agent._get_rollout().timing                  # of the last rollout
+        out.update({"env_steps_per_iteration": n_steps / max(1, steps), "ticks": rt.get("ticks"), "step_budget": rt.get("step_budget"),
+                    "small_group_ticks": rt.get("small_group_ticks"), "small_group_tick_s": rt.get("small_group_tick_s")})
         return out
     except Exception as e:                       # a leg never takes the headline down
         return {"error": repr(e)[:300]}
@@ -395,6 +398,9 @@ def main():
                 leg["host_physics_ceiling_env_steps_per_s"] = n_threads / (leg["substeps_per_launch"] * args.sim_cost_us * 1e-6)
                 leg["frac_of_host_physics_ceiling"] = leg["rollout_only_env_steps_per_s"] / leg["host_physics_ceiling_env_steps_per_s"]
             legs["simulator_cost_per_substep"] = leg
+            # the reference's loop condition applied to all slots together (no new episode once the batch is there) against the
+            # per-slot quota of the default: what the rollout's latency-bound tail costs, and what it buys in batch size
+            legs["step_budget_global"] = run_leg(mk32, args.leg_steps, 1, min_batch, ev, {"EGP_STEP_BUDGET": "global"})
             # BASELINE config 4: the state regressor's optimisation step (ResNet-18 encoder in bf16 on the matrix cores)
             try:
                 from egopose_amd.bench_support import statereg_config4

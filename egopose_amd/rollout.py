@@ -281,6 +281,15 @@ class LockstepRollout:
         ndt = self._net_dtype()
         quota = max(1, int(math.floor(min_batch_size / N)))
         T_max = quota + T_ep
+        # When does a slot whose episode has just ended stop? 'slot' (default): when IT has its share of the batch, the
+        # reference's per-worker rule (agents/agent.py:36,93: every worker loops `while num_steps < thread_batch_size`).
+        # 'global' (EGP_STEP_BUDGET / self.step_budget): when the batch as a whole is there -- the same loop condition applied to all
+        # slots together, i.e. no new episode once the steps collected so far cover min_batch_size. With 1 024 slots and
+        # 200-step episodes the per-slot rule restarts every episode that fails before its 48th step and the rollout ends
+        # with ~45 ticks that step a few dozen envs; the global rule ends at the longest first episode (bench.py leg).
+        budget = getattr(self, "step_budget", None) or os.environ.get("EGP_STEP_BUDGET", "slot")
+        if budget not in ("slot", "global"):
+            raise ValueError("step budget must be 'slot' or 'global', got %r" % (budget,))
         H = self.policy_vs_net.v_hdim
         self.policy_vs_net.attach_feature_table(self.experts.cnn_table(dev, ndt), self.experts.cnn_offset)
         self._pool, self._pool_pos = None, 0          # contexts depend on this iteration's weights
@@ -302,6 +311,12 @@ class LockstepRollout:
         self.frame_base = np.zeros(N, np.int64)
         steps_done = np.zeros(N, np.int64)
         active = np.ones(N, bool)
+
+        def slot_finished(ids):
+            done_ = steps_done[ids] >= quota
+            if budget == "global" and int(steps_done.sum()) >= min_batch_size:
+                done_[:] = True
+            return done_
         if self.running_state is not None:
             rs = self.running_state.rs
             self.zf_delta_base = (float(rs._n), np.array(rs._M, float).ravel().copy(), np.array(rs._S, float).ravel().copy())
@@ -314,7 +329,17 @@ class LockstepRollout:
         lb = self.experts.head_height_lb
         ep_lens = []
         tick = [0] * len(self.groups)
-        tm = dict(policy=0.0, wait=0.0, post=0.0, reset=0.0)
+        tm = dict(policy=0.0, wait=0.0, post=0.0, reset=0.0, small_group_ticks=0, small_group_tick_s=0.0)
+        last_post = [None] * len(self.groups)
+
+        def note_tick(g, n_stepped, now):
+            """env-steps of a group that stepped fewer than 64 envs (the latency-bound tail of a rollout): how many, and
+            the sum of their periods (time since the group's previous env-step ended; the groups overlap, so divide by
+            their number for wall time)."""
+            if last_post[g] is not None and n_stepped < 64:
+                tm["small_group_ticks"] += 1
+                tm["small_group_tick_s"] += now - last_post[g]
+            last_post[g] = now
         trace = [] if os.environ.get("EGP_TICK_TRACE") else None
 
         # ---- initial reset of every slot; group g's first state goes to rec["states"][0, a:b]
@@ -387,7 +412,7 @@ class LockstepRollout:
             if done.any():
                 ids = np.nonzero(done)[0] + a
                 ep_lens.extend(self.cur_t[ids].tolist())
-                finished = steps_done[ids] >= quota
+                finished = slot_finished(ids)
                 active[ids[finished]] = False
                 again = ids[~finished]
                 if len(again):
@@ -515,7 +540,7 @@ class LockstepRollout:
             if n_done.value:
                 ids = np.nonzero(host["done"][k, a:b])[0] + a
                 ep_lens.extend(self.cur_t[ids].tolist())
-                finished = steps_done[ids] >= quota
+                finished = slot_finished(ids)
                 active[ids[finished]] = False
                 again = ids[~finished]
                 if len(again):
@@ -528,6 +553,7 @@ class LockstepRollout:
             tm["wait"] += wait_s.value
             tm["post"] += t2 - t0 - wait_s.value
             tm["reset"] += t3 - t2
+            note_tick(g, int(np.count_nonzero(host["valid"][k, a:b])), t3)
             if trace is not None:
                 trace.append((g, k, int(host["valid"][k, a:b].sum()), wait_s.value, t2 - t0 - wait_s.value, t3 - t2))
 
@@ -624,7 +650,7 @@ class LockstepRollout:
             if done.any():
                 ids = np.nonzero(done)[0] + a
                 ep_lens.extend(self.cur_t[ids].tolist())
-                finished = steps_done[ids] >= quota
+                finished = slot_finished(ids)
                 active[ids[finished]] = False
                 again = ids[~finished]
                 if len(again):
@@ -637,6 +663,7 @@ class LockstepRollout:
             tm["wait"] += t1 - t0
             tm["post"] += t2 - t1
             tm["reset"] += t3 - t2
+            note_tick(g, int(act_g.sum()), t3)
             if trace is not None:           # EGP_TICK_TRACE: (group, tick, stepped envs, wait, post, reset) per env-step
                 trace.append((g, k, int(act_g.sum()), t1 - t0, t2 - t1, t3 - t2))
 
@@ -679,7 +706,7 @@ class LockstepRollout:
             self.running_state.from_device_state(self.zf_state)
         torch.cuda.synchronize(dev)
         log.sample_time = time.time() - t_start
-        tm.update(ticks=T_used, quota=quota, policy_graph=self._graphs is not None, **eng.timing())
+        tm.update(ticks=T_used, quota=quota, step_budget=budget, policy_graph=self._graphs is not None, **eng.timing())
         self.timing = tm
         self.tick_trace = trace
         return batch, log
