@@ -41,7 +41,7 @@ class BatchedSim:
 
     def __init__(self, env, n_env, device_index=0, n_threads=None, n_groups=1, physics=None):
         from .hip import EgpContext
-        from .physics import SurrogatePhysics, RolloutEngine
+        from .physics import make_physics, RolloutEngine
         from .expert import ExpertSet
         cfg = env.cfg
         self.env = env
@@ -49,7 +49,7 @@ class BatchedSim:
         self.ctx = EgpContext(env.skel, cfg.jkp, cfg.jkd, cfg.a_ref, cfg.a_scale, cfg.torque_lim, cfg.b_diffw,
                               reward_weights=cfg.reward_weights, episode_len=cfg.env_episode_len,
                               frame_skip=env.frame_skip, device=device_index, obs_options=obs_options_of(cfg))
-        self.physics = physics if physics is not None else SurrogatePhysics(env.skel, self.n_env)
+        self.physics = physics if physics is not None else make_physics(env.skel, self.n_env, cfg)
         # EGP_DEVICE_DYNAMICS=1: qM / qfrc_bias of every substep from K8 on the GPU instead of the backend's drain
         self.engine = RolloutEngine(self.ctx, self.physics, self.n_env, n_threads=n_threads, n_groups=n_groups,
                                     device_dynamics=os.environ.get("EGP_DEVICE_DYNAMICS", "0") == "1")

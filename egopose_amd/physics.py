@@ -136,6 +136,74 @@ class CallbackPhysics:
             self.handle = None
 
 
+class MujocoPhysics(SurrogatePhysics):
+    """MuJoCo behind the physics boundary: the compiled plugin csrc/egp_physics_mujoco.cpp (one shared mjModel, one mjData per
+    env, stepped by the engine's own threads -- no Python in the loop). The plugin is built separately
+    (`MUJOCO_DIR=... python -m egopose_amd.build_mujoco`): MuJoCo is not in the build image. Same host accessors as the surrogate
+    (reset / step / drain through `egp_physics_*_host`)."""
+
+    PLUGIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libegopose_mujoco.so")
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(cls.PLUGIN)
+
+    def __init__(self, skel: Skeleton, n_env: int, mjcf_path: str):
+        self.lib = L.load()
+        if not self.available():
+            raise L.EgpError("the MuJoCo plugin %s is not built: MUJOCO_DIR=<mujoco tree> python -m egopose_amd.build_mujoco "
+                             "(MuJoCo does not ship with this package)" % self.PLUGIN)
+        self.plugin = C.CDLL(self.PLUGIN, mode=C.RTLD_GLOBAL)
+        fn = self.plugin.egp_physics_create_mujoco
+        fn.restype, fn.argtypes = C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p), C.c_char_p, C.c_int32]
+        self.skel, self.n_env = skel, int(n_env)
+        err = C.create_string_buffer(1024)
+        h = C.c_void_p()
+        rc = fn(os.fsencode(mjcf_path), self.n_env, C.byref(h), err, 1024)
+        if rc != 0:
+            raise L.EgpError("egp_physics_create_mujoco(%s) failed (%d): %s" % (mjcf_path, rc, err.value.decode("utf-8", "replace")))
+        self.handle = h
+        self._check_model(mjcf_path)
+
+    def _check_model(self, mjcf_path):
+        """The kernel context was built from egopose_amd.skeleton's reading of the MJCF: MuJoCo's own mjModel must agree on the
+        dof tree and the sparse-inertia addressing (what mj_fullM walks), or K1 would expand qM wrongly."""
+        fn = self.plugin.egp_mujoco_model_tables
+        i32p = C.POINTER(C.c_int32)
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_char_p] + [i32p] * 5 + [C.POINTER(C.c_double)] + [i32p] * 4 + [C.c_char_p, C.c_int32]
+        sk = self.skel
+        dims = [C.c_int32() for _ in range(5)]
+        ts = C.c_double()
+        par, madr = np.zeros(sk.nv, np.int32), np.zeros(sk.nv, np.int32)
+        qadr, ndof = np.zeros(len(sk.body_names), np.int32), np.zeros(len(sk.body_names), np.int32)
+        err = C.create_string_buffer(1024)
+        rc = fn(os.fsencode(mjcf_path), *[C.byref(x) for x in dims], C.byref(ts), par.ctypes.data_as(i32p), madr.ctypes.data_as(i32p),
+                qadr.ctypes.data_as(i32p), ndof.ctypes.data_as(i32p), err, 1024)
+        if rc != 0:
+            raise L.EgpError("egp_mujoco_model_tables failed: %s" % err.value.decode("utf-8", "replace"))
+        got = tuple(x.value for x in dims)
+        want = (sk.nq, sk.nv, sk.nu, len(sk.body_names), sk.nM)
+        if got != want or not np.array_equal(par, sk.dof_parentid) or not np.array_equal(madr, sk.dof_Madr) \
+                or not np.array_equal(qadr, sk.body_qpos_start) or abs(ts.value - sk.timestep) > 1e-15:
+            raise L.EgpError("MuJoCo's model %s disagrees with the skeleton tables the kernels were built from "
+                             "(dims %s vs %s)" % (mjcf_path, got, want))
+
+
+def make_physics(skel, n_env, cfg=None):
+    """The backend `EGP_PHYSICS` names: 'surrogate' (default; deterministic stand-in, physics parity unpinned) or 'mujoco' (the
+    plugin over cfg.mujoco_model_file, humanoid_v1.py:15 -> mujoco_env.py:18-23)."""
+    kind = os.environ.get("EGP_PHYSICS", "surrogate")
+    if kind == "surrogate":
+        return SurrogatePhysics(skel, n_env)
+    if kind == "mujoco":
+        path = getattr(cfg, "mujoco_model_file", None)
+        if not path or not os.path.exists(path):
+            raise IOError("File %s does not exist" % path)                  # envs/common/mujoco_env.py:19-20
+        return MujocoPhysics(skel, n_env, path)
+    raise ValueError("EGP_PHYSICS must be 'surrogate' or 'mujoco', got %r" % kind)
+
+
 def available_cpus():
     """CPUs this process may actually use: min(affinity mask, cgroup CPU quota)."""
     n = os.cpu_count() or 1

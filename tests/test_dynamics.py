@@ -157,3 +157,57 @@ def test_engine_device_dynamics_matches_host_loop(ctx, skel, mode, monkeypatch):
         np.testing.assert_allclose(got_q[e], q, rtol=1e-7, atol=1e-7)
     ref.close()
     be.close()
+
+
+# ---------------------------------------------------------------------------------------------- MuJoCo-pinned (when the fixture exists)
+def _mujoco_fixture():
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "mujoco_dynamics.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/mujoco_dynamics.npz is written by tools/gen_mujoco_golden.py on a machine that has MuJoCo "
+                    "(not in this image): row f1 stays pinned to first principles only")
+    return np.load(path)
+
+
+def test_oracle_dynamics_matches_mujoco(skel):
+    """mjData.qM / qfrc_bias / xpos (what humanoid_v1.py:98-111,130-144 reads) against the oracle's restatement."""
+    g = _mujoco_fixture()
+    assert tuple(g["dims"]) == (skel.nq, skel.nv, skel.nu, len(skel.body_names), skel.nM)
+    for i in range(min(16, g["qpos"].shape[0])):
+        Ms, Cs, _ = D.crba_rne_spatial(skel, g["qpos"][i], g["qvel"][i])
+        np.testing.assert_allclose(Ms, skel.full_from_sparse(g["qM"][i]), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(Cs, g["qfrc_bias"][i], rtol=1e-8, atol=1e-7)
+        np.testing.assert_allclose(skel.body_xpos(g["qpos"][i]), g["xpos"][i], rtol=0, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_dynamics_kernel_matches_mujoco(ctx, skel):
+    """K8 on the device against MuJoCo's own numbers: the comparison that pins SURVEY row f1."""
+    g = _mujoco_fixture()
+    dev = torch.device("cuda")
+    out = ctx.dynamics(torch.as_tensor(g["qpos"], device=dev), torch.as_tensor(g["qvel"], device=dev), want_xpos=True)
+    np.testing.assert_allclose(out["qM"].cpu().numpy(), g["qM"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(out["bias"].cpu().numpy(), g["qfrc_bias"], rtol=1e-8, atol=1e-7)
+    np.testing.assert_allclose(out["xpos"].cpu().numpy(), g["xpos"], rtol=0, atol=1e-10)
+
+
+def test_mujoco_plugin_replays_the_recorded_trajectory(skel):
+    """The compiled backend (csrc/egp_physics_mujoco.cpp) stepping the fixture's controls reproduces MuJoCo's own trajectory."""
+    import os
+    from egopose_amd.physics import MujocoPhysics
+    g = _mujoco_fixture()
+    model = os.environ.get("EGP_MUJOCO_MODEL")
+    if not MujocoPhysics.available() or not model:
+        pytest.skip("needs the plugin (python -m egopose_amd.build_mujoco) and EGP_MUJOCO_MODEL=<the MJCF the fixture was made from>")
+    ph = MujocoPhysics(skel, 2, model)
+    ph.reset(1, g["qpos"][1], g["qvel"][1])
+    q, v, qM, bias, xpos = ph.drain(1)
+    np.testing.assert_allclose(qM, g["qM"][1], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(bias, g["qfrc_bias"][1], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(xpos, g["xpos"][1], rtol=0, atol=1e-12)
+    for t in range(g["ctrl"].shape[0]):
+        ph.step(1, g["ctrl"][t])
+        q, v, _, _, _ = ph.drain(1, want_xpos=False)
+        np.testing.assert_allclose(q, g["traj_qpos"][t], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(v, g["traj_qvel"][t], rtol=1e-12, atol=1e-12)
+    ph.close()
