@@ -283,13 +283,17 @@ class LockstepRollout:
         T_max = quota + T_ep
         # When does a slot whose episode has just ended stop? 'slot' (default): when IT has its share of the batch, the
         # reference's per-worker rule (agents/agent.py:36,93: every worker loops `while num_steps < thread_batch_size`).
-        # 'global' (EGP_STEP_BUDGET / self.step_budget): when the batch as a whole is there -- the same loop condition applied to all
-        # slots together, i.e. no new episode once the steps collected so far cover min_batch_size. With 1 024 slots and
+        # 'global' (EGP_STEP_BUDGET / self.step_budget): when the batch as a whole is covered -- the same loop condition applied to all
+        # slots together, counting what the running episodes can still deliver: a slot starts a new episode only while
+        # (steps collected) + (steps the episodes in flight have left if they run to their end) < min_batch_size. The batch
+        # still reaches min_batch_size (when the episodes in flight fall short, restarts resume). With 1 024 slots and
         # 200-step episodes the per-slot rule restarts every episode that fails before its 48th step and the rollout ends
-        # with ~45 ticks that step a few dozen envs; the global rule ends at the longest first episode (bench.py leg).
+        # with ~45 ticks that step a few dozen envs; the global rule ends with the longest first episode (bench.py leg).
         budget = getattr(self, "step_budget", None) or os.environ.get("EGP_STEP_BUDGET", "slot")
         if budget not in ("slot", "global"):
             raise ValueError("step budget must be 'slot' or 'global', got %r" % (budget,))
+        if budget == "global":
+            T_max = quota + 2 * T_ep          # (a slot may start another episode late, when the ones in flight fell short)
         H = self.policy_vs_net.v_hdim
         self.policy_vs_net.attach_feature_table(self.experts.cnn_table(dev, ndt), self.experts.cnn_offset)
         self._pool, self._pool_pos = None, 0          # contexts depend on this iteration's weights
@@ -314,8 +318,12 @@ class LockstepRollout:
 
         def slot_finished(ids):
             done_ = steps_done[ids] >= quota
-            if budget == "global" and int(steps_done.sum()) >= min_batch_size:
-                done_[:] = True
+            if budget == "global":
+                running = active.copy()
+                running[ids] = False                  # the episodes that have just ended deliver nothing more
+                t_eff = T_ep if self.env.fix_len is None else self.env.fix_len
+                in_flight = int(np.maximum(t_eff - self.cur_t[running], 0).sum())
+                done_[:] = int(steps_done.sum()) + in_flight >= min_batch_size
             return done_
         if self.running_state is not None:
             rs = self.running_state.rs
