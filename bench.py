@@ -47,17 +47,30 @@ HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec
 K1_BYTES_PER_ENV = (910 + 58 + 52 + 58 + 52 + 52) * 8   # qM + qfrc_bias + qpos[7:] + qvel + action + torque, float64
 
 
-def cpu_baseline(dataset, steps, threads, extra_env=None):
-    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", **(extra_env or {}))
+def cpu_baseline(dataset, steps, threads, extra_env=None, update_steps=0):
+    """The oracle's restatement of the reference sampler on `threads` forked workers (and, with `update_steps`, of the
+    reference's CPU update on the first episodes of that sample): a bounded sample in a subprocess."""
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", **(extra_env or {}))
+    if not update_steps:            # README.md:25-27: OMP_NUM_THREADS=1 for the multi-process sampler (the update uses torch's threads)
+        env.update(OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "oracle.cpu_env", "--dataset", dataset, "--threads", str(threads), "--steps", str(steps)]
+    if update_steps:
+        cmd += ["--update-steps", str(update_steps), "--update-threads", str(threads)]
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
     if out.returncode != 0:
         return {"value": None, "unit": "env-steps/s", "cores": threads, "kind": "port", "sample": "failed: " + out.stderr[-300:]}
     r = json.loads(out.stdout.strip().splitlines()[-1])
-    return {"value": r["env_steps_per_s"], "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": "oracle CPU sampler (reference structure: %d forked workers, batch-1 float64 policy, numpy reward/PD, "
-                      "OMP_NUM_THREADS=1), %d env-steps of the same synthetic subject_03 workload in %.1f s, physics=%s"
-                      % (threads, r["env_steps"], r["seconds"], r["physics"])}
+    res = {"value": r["env_steps_per_s"], "unit": "env-steps/s", "cores": threads, "kind": "port",
+           "sample": "oracle CPU sampler (reference structure: %d forked workers, batch-1 float64 policy, numpy reward/PD, "
+                     "OMP_NUM_THREADS=1), %d env-steps of the same synthetic subject_03 workload in %.1f s, physics=%s"
+                     % (threads, r["env_steps"], r["seconds"], r["physics"])}
+    if "update" in r:
+        u = r["update"]
+        res["t_update"] = {"seconds": u["seconds"], "samples": u["samples"], "episodes": u["episodes"], "epochs": u["epochs"],
+                           "torch_threads": u["torch_threads"], "samples_per_s": u["samples"] / max(u["seconds"], 1e-9),
+                           "what": "oracle.ppo.update_params: the reference's update structure on the CPU (float64, LSTMCell loops over "
+                                   "220-frame windows, 10 full-batch epochs) on the first episodes of the sample"}
+    return res
 
 
 def cgroup_throttle():
@@ -247,6 +260,7 @@ def main():
     ap.add_argument("--task", choices=["egomimic", "egoforecast"], default="egomimic",
                     help="egoforecast = BASELINE config 5's nets (VideoForecastNet, 90-step episodes, decayed reward)")
     ap.add_argument("--cpu-steps", type=int, default=24000, help="env-steps of the CPU baseline sample (~15 s on 2 cores)")
+    ap.add_argument("--cpu-update-steps", type=int, default=1500, help="steps of the CPU sample the CPU update leg runs on (~10 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-k1-events", action="store_true")
     ap.add_argument("--k1-event-every", type=int, default=8, help="bracket K1 with HIP events on every Nth env-step")
@@ -316,6 +330,10 @@ def main():
     if not args.no_k1_events:
         eng.set_profile(True, every=args.k1_event_every)
     eng.reset_timing()
+    updater = tr.agent._get_updater()
+    if world > 1 and updater is not None:
+        updater.collective_ms()                 # (drop the warm-up's)
+        updater.time_collectives = True
     thr0 = cgroup_throttle()
     barrier()
     t0 = time.time()
@@ -331,6 +349,7 @@ def main():
     elapsed = time.time() - t0
     thr1 = cgroup_throttle()
     tim = eng.timing()
+    ar_ms = updater.collective_ms() if (world > 1 and updater is not None) else []
     total_steps, elapsed = aggregate(steps_local, elapsed, world, dev)
     ro = tr.agent._get_rollout()
     res = None
@@ -355,6 +374,13 @@ def main():
             "rollout_timing": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ro.timing.items()},
         })
         res["roofline"] = k1_roofline(tim, args.envs / float(args.groups), eng, args.k1_event_every)
+        if world > 1:
+            # SURVEY 8e / BASELINE.md G2: one fused gradient all-reduce per PPO epoch (476 109 floats), timed with HIP events on rank 0
+            res["collectives"] = {"backend": torch.distributed.get_backend(), "ranks": world,
+                                  "allreduce_ms_per_epoch": (sum(ar_ms) / len(ar_ms)) if ar_ms else None, "allreduces_timed": len(ar_ms),
+                                  "allreduce_floats": int(updater.numel) if updater is not None else None,
+                                  "per_update": "1 MAX (padded window length) + 1 SUM (advantage moments + sample counts, 5 x float64) + "
+                                                "%d gradient all-reduces" % cfg.num_optim_epoch}
     tr.close()
     if world > 1:
         torch.distributed.barrier()
@@ -410,7 +436,14 @@ def main():
             res["legs"] = {k: {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items()} for k, v in legs.items()}
             res["dropin_env_steps_per_s"] = legs["dropin_float64_driver"].get("env_steps_per_s")
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(root, args.cpu_steps, 2)
+            # BASELINE config 1 / B1: 2 sampling workers (+ the CPU update on a bounded part of their sample); B2: as many
+            # workers as this box's cores allow (the same bounded sample, so about nproc / 2 times shorter)
+            res["cpu_baseline"] = cpu_baseline(root, args.cpu_steps, 2, update_steps=args.cpu_update_steps)
+            nproc = max(2, cores - 2)
+            res["cpu_baseline_nproc"] = cpu_baseline(root, args.cpu_steps * 2, nproc)
+            for k in ("cpu_baseline", "cpu_baseline_nproc"):
+                if res[k].get("value"):
+                    res[k]["gpu_over_cpu_rollout"] = res["rollout_only_env_steps_per_s"] / res[k]["value"]
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -150,6 +150,7 @@ class FlatUpdater:
         self.G = mk(cdt)                                         # gradients of the compute parameters = the all-reduce buffer
         self.S = mk(torch.float32) if self.shadowed else None    # float32 compute copies of float64 masters
         self.steps = [0] * len(self.optimizers)
+        self.time_collectives, self.collective_events = False, []
         self.step_tensors = [torch.tensor(0.0) for _ in self.optimizers]       # what the optimizers' state shows as `step` (one per optimizer)
         self._views = lambda flat: [flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, masters)]
         self.p_views, self.m_views, self.v_views, self.g_views = (self._views(f) for f in (self.P, self.M, self.V, self.G))
@@ -225,12 +226,28 @@ class FlatUpdater:
             return
         G = self.G[min(b for b, _ in spans):max(e for _, e in spans)]
         dev = D._comm_device(self.device)
+        ev = None
+        if self.time_collectives:           # HIP events around the collective (bench.py --gpus N: allreduce_ms_per_epoch)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         if dev == G.device:
             torch.distributed.all_reduce(G)
         else:
             tmp = G.to(dev)
             torch.distributed.all_reduce(tmp)
             G.copy_(tmp)
+        if ev is not None:
+            ev[1].record()
+            self.collective_events.append(ev)
+
+    def collective_ms(self):
+        """[ms] of every timed gradient all-reduce since the last call (synchronises)."""
+        if not self.collective_events:
+            return []
+        torch.cuda.synchronize(self.device)
+        out = [a.elapsed_time(b) for a, b in self.collective_events]
+        self.collective_events = []
+        return out
 
     def step(self, which=None):
         """Clip + Adam for the optimizers in `which` (indices; None = all), hyper-parameters read from their param_groups now."""

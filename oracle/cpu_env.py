@@ -134,6 +134,10 @@ def main():
     ap.add_argument("--cfg", default="subject_03")
     ap.add_argument("--threads", type=int, default=2)
     ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--update-steps", type=int, default=0,
+                    help="also time the reference-structured CPU update (oracle.ppo.update_params: LSTMCell loops, 10 full-batch epochs, "
+                         "float64) on the first episodes of the sample that cover this many steps; torch threads = --update-threads")
+    ap.add_argument("--update-threads", type=int, default=0)
     args = ap.parse_args()
     torch.set_num_threads(1)
     torch.set_default_dtype(torch.float64)
@@ -161,9 +165,29 @@ def main():
     p_pvs = {k: v.detach().clone() for k, v in pvs.state_dict().items()}
     phys = SurrogatePhysics(skel, 1)
     batch, log, secs = run_sampler(skel, cfg, phys, expert_arr, cnn_feat, p_pol, p_pvs, args.steps, args.threads, seed=cfg.seed)
-    print(json.dumps({"env_steps": int(log.num_steps), "seconds": secs, "env_steps_per_s": log.num_steps / secs,
-                      "threads": args.threads, "episodes": int(log.num_episodes), "avg_c_reward": float(log.avg_c_reward),
-                      "physics": phys.name}))
+    out = {"env_steps": int(log.num_steps), "seconds": secs, "env_steps_per_s": log.num_steps / secs,
+           "threads": args.threads, "episodes": int(log.num_episodes), "avg_c_reward": float(log.avg_c_reward),
+           "physics": phys.name}
+    if args.update_steps > 0:
+        # AgentEgo.update_params as the reference runs it (ego_pose/core/agent_ego.py:34-57 on to_device(...) CPU tensors):
+        # the update sees whole episodes, so cut at an episode end
+        from . import ppo as P
+        from egopose_amd.nets import Value
+        ends = np.nonzero(np.asarray(batch["masks"]) == 0)[0]
+        cut = int(ends[np.searchsorted(ends, min(args.update_steps, len(batch["masks"])) - 1)]) + 1
+        sub = {k: v[:cut] for k, v in batch.items()}
+        vvs = VideoStateNet(cdim, cfg.value_v_hdim, cfg.fr_margin, "lstm", None, False)
+        val = Value(MLP(115 + cfg.value_v_hdim, cfg.value_hsize, cfg.value_htype))
+        p_val = {k: v.detach().clone() for k, v in val.state_dict().items()}
+        p_vvs = {k: v.detach().clone() for k, v in vvs.state_dict().items()}
+        n_thr = args.update_threads or args.threads
+        torch.set_num_threads(n_thr)
+        t0 = time.time()
+        P.update_params(dict(p_pol), dict(p_pvs), p_val, p_vvs, sub, cnn_feat, margin=cfg.fr_margin, gamma=cfg.gamma, tau=cfg.tau,
+                        clip_eps=cfg.clip_epsilon, epochs=cfg.num_optim_epoch, lr_policy=cfg.policy_lr, lr_value=cfg.value_lr, grad_clip=40)
+        out["update"] = {"samples": cut, "episodes": int((np.asarray(sub["masks"]) == 0).sum()), "seconds": time.time() - t0,
+                         "epochs": int(cfg.num_optim_epoch), "torch_threads": n_thr}
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

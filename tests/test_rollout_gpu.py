@@ -632,6 +632,40 @@ def test_unsupported_env_options_are_refused(workspace, key, value, exc):
         Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=8, num_threads=2, num_groups=1).agent.sample(8)
 
 
+def test_global_step_budget_covers_the_batch_without_the_tail(workspace, skel, monkeypatch):
+    """EGP_STEP_BUDGET=global: a slot starts a new episode only while collected + in-flight steps fall short of min_batch_size
+    (the reference's `while num_steps < min_batch_size` applied to all slots together). The batch still reaches the minimum,
+    is never larger than the per-slot rule's, and every recorded step is the oracle env's."""
+    from egopose_amd.config import Config
+    from egopose_amd.train import Trainer
+    os.chdir(workspace)
+    sizes = {}
+    for mode in ("slot", "global"):
+        monkeypatch.setenv("EGP_STEP_BUDGET", mode)
+        cfg = Config("subject_03", create_dirs=False)
+        cfg.env_episode_len = 12
+        tr = Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=32, num_threads=2, num_groups=2)
+        tr.agent.running_state = None
+        tr.env.end_reward = 0.3
+        for min_batch in (32 * 5, 32 * 30):                  # covered by the first episodes / needs restarts
+            batch, log = tr.agent.sample(min_batch)
+            n_ep = int((batch.masks == 0).sum())
+            assert len(batch.masks) >= min_batch and tr.agent._get_rollout().timing["step_budget"] == mode
+            sizes[(mode, min_batch)] = (len(batch.masks), n_ep)
+            _replay_episodes(tr, cfg, skel, batch, range(0, min(6, n_ep)), 0.3)
+        tr.close()
+    for min_batch in (32 * 5, 32 * 30):
+        assert sizes[("global", min_batch)][0] <= sizes[("slot", min_batch)][0]
+    assert sizes[("global", 32 * 5)][1] == 32                # one episode per slot: nothing restarted
+    with pytest.raises(ValueError):
+        monkeypatch.setenv("EGP_STEP_BUDGET", "bogus")
+        tr2 = Trainer(Config("subject_03", create_dirs=False), torch.device("cuda", 0), torch.float32, num_envs=8, num_threads=2, num_groups=1)
+        try:
+            tr2.agent.sample(8)
+        finally:
+            tr2.close()
+
+
 @pytest.mark.parametrize("reward_id", ["pose_dist", "constant"])
 def test_rollout_with_the_small_rewards(workspace, skel, reward_id):
     """reward_id 'pose_dist' / 'constant' (reward_function.py:63-80) through the lockstep rollout, replayed by the oracle env."""
