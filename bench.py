@@ -85,9 +85,11 @@ def cgroup_throttle():
 def launch_ranks(n, argv):
     """Start the n ranks of this bench (one process per GPU) and wait for them. Rank 0 inherits stdout, so its JSON line
     is this command's output; the other ranks' stdout goes to stderr. Any rank failing takes the others down."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # (the probe socket stays open, SO_REUSEADDR, until the ranks are started: nobody else is handed the port in between)
+    probe = socket.socket()
+    probe.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    probe.bind(("127.0.0.1", 0))
+    port = probe.getsockname()[1]
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
@@ -95,6 +97,7 @@ def launch_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL needs it on this host driver
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else sys.stderr))
+    probe.close()
     rc = 0
     try:
         live = set(range(n))

@@ -537,14 +537,14 @@ class AgentEgo(AgentPPO):
             self.sample_modules = [self.cn.policy_net, self.cn.policy_vs_net]
             self.update_modules = [self.cn.policy_net, self.cn.value_net, self.cn.policy_vs_net, self.cn.value_vs_net]
             from .nets import VideoStateNet
-            for head, vs in ((self.cn.policy_net, self.cn.policy_vs_net), (self.cn.value_net, self.cn.value_vs_net)):
-                # VideoStateNet output = [video context | raw state]: the state columns need no gradient (gemm.MlpHead)
-                if isinstance(vs, VideoStateNet):
-                    head.input_grad_cols = vs.v_hdim
-                    # ... and when the head is an MLP on the HIP GEMMs its first layer can gather the context rows and
-                    # append the state columns itself: the video net then hands over the parts, not the concatenation
-                    layers = getattr(getattr(head, "net", None), "affine_layers", None)
-                    vs.lazy_gather = int(layers[0].out_features) if layers is not None and len(layers) > 0 else 0
+            # When a head is an MLP on the HIP GEMMs its first layer can gather the context rows and append the state columns
+            # itself: the video net is then asked (per call, `lazy_width`) for the parts instead of the concatenation. (That a
+            # VideoStateNet output's state columns need no gradient travels as a tag on the tensor it returns.) Nothing is
+            # stored on the caller's modules.
+            self._lazy_width = {}
+            for key, head, vs in (("policy", self.cn.policy_net, self.cn.policy_vs_net), ("value", self.cn.value_net, self.cn.value_vs_net)):
+                layers = getattr(getattr(head, "net", None), "affine_layers", None)
+                self._lazy_width[key] = int(layers[0].out_features) if (isinstance(vs, VideoStateNet) and layers is not None and len(layers) > 0) else 0
 
     def _video_net(self):
         return self.cn.policy_vs_net
@@ -564,10 +564,12 @@ class AgentEgo(AgentPPO):
         return grouped_video_context(nets) or grouped_forecast_context(nets, states)
 
     def trans_policy(self, states):
-        return self.cn.policy_vs_net(states)
+        w = getattr(self, "_lazy_width", {}).get("policy", 0)
+        return self.cn.policy_vs_net(states, lazy_width=w) if w else self.cn.policy_vs_net(states)
 
     def trans_value(self, states):
-        return self.cn.value_vs_net(states)
+        w = getattr(self, "_lazy_width", {}).get("value", 0)
+        return self.cn.value_vs_net(states, lazy_width=w) if w else self.cn.value_vs_net(states)
 
     def update_params(self, batch):
         t0 = time.time()

@@ -173,9 +173,9 @@ def main(argv=None):
     policy_vs, value_vs = mk(cfg.policy_v_hdim, cfg.policy_v_net, cfg.policy_v_net_param), mk(cfg.value_v_hdim, cfg.value_v_net, cfg.value_v_net_param)
     policy = PolicyGaussian(MLP(sd + cfg.policy_v_hdim, cfg.policy_hsize, cfg.policy_htype), ad, log_std=cfg.log_std, fix_std=cfg.fix_std)
     value = Value(MLP(sd + cfg.value_v_hdim, cfg.value_hsize, cfg.value_htype))
-    from .zfilter import reference_pickle_names
-    with reference_pickle_names():          # checkpoints written by the reference name utils.zfilter.ZFilter
-        cp = pickle.load(open("%s/iter_%04d.p" % (cfg.model_dir, args.iter), "rb"))
+    from .zfilter import load_reference_pickle
+    with open("%s/iter_%04d.p" % (cfg.model_dir, args.iter), "rb") as f:      # checkpoints written by the reference name utils.zfilter.ZFilter
+        cp = load_reference_pickle(f)
     policy.load_state_dict(cp["policy_dict"]); policy_vs.load_state_dict(cp["policy_vs_dict"])
     value.load_state_dict(cp["value_dict"]); value_vs.load_state_dict(cp["value_vs_dict"])
     sn_cp, meta = pickle.load(open(cfg.state_net_model, "rb"))

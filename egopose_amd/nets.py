@@ -156,12 +156,14 @@ class PolicyGaussian(Policy):
 
     def mean_std(self, x):
         if _gemm.mlp_head_available(x, getattr(self.net, "affine_layers", ()), self.action_mean, getattr(self.net, "activation", None)):
-            # the whole head(MLP(x)) as one autograd node on the split-operand bf16 GEMM kernel (gemm.py); `input_grad_cols`
+            # the whole head(MLP(x)) as one autograd node on the split-operand bf16 GEMM kernel (gemm.py); `_egp_ctx_cols`
+            # (a tag VideoStateNet.forward leaves on the tensor it returns, not a module attribute): only the leading
+            # video-context columns of that input carry a gradient -- any other input gets the full gradient
             # (set by the agent): only the leading video-context columns of the input carry a gradient
             if isinstance(x, _gemm.GatheredInput):      # [context | state] never formed: the first layer gathers it itself
                 mean = _gemm.gather_mlp_head(x, self.net.affine_layers, self.action_mean)
             else:
-                mean = _gemm.mlp_head(x, self.net.affine_layers, self.action_mean, getattr(self, "input_grad_cols", None))
+                mean = _gemm.mlp_head(x, self.net.affine_layers, self.action_mean, getattr(x, "_egp_ctx_cols", None))
         else:
             if isinstance(x, _gemm.GatheredInput):
                 x = x.materialize()
@@ -199,7 +201,7 @@ class Value(nn.Module):
         if _gemm.mlp_head_available(x, getattr(self.net, "affine_layers", ()), self.value_head, getattr(self.net, "activation", None)):
             if isinstance(x, _gemm.GatheredInput):
                 return _gemm.gather_mlp_head(x, self.net.affine_layers, self.value_head)
-            return _gemm.mlp_head(x, self.net.affine_layers, self.value_head, getattr(self, "input_grad_cols", None))
+            return _gemm.mlp_head(x, self.net.affine_layers, self.value_head, getattr(x, "_egp_ctx_cols", None))
         if isinstance(x, _gemm.GatheredInput):
             x = x.materialize()
         x, n = bucket_rows(x)
@@ -310,7 +312,6 @@ class VideoStateNet(nn.Module):
         self.gather_indices = None
         self._gather_tm = None
         self._gather_unique = False
-        self.lazy_gather = 0                 # > 0 (width of the consumer's first layer, set by the agent): forward('train') may return gemm.GatheredInput
         self.cnn_feat_ctx = None
         self._buckets = None
         self._v_ctx = None
@@ -451,15 +452,23 @@ class VideoStateNet(nn.Module):
             return out_f
         return torch.cat((out_f, rnn._sweep(rnn.rnn_b, ctx, True)), 2)
 
-    def forward(self, x):
+    def forward(self, x, lazy_width=0):
+        """`lazy_width` > 0 (train mode; the width of the consumer's first layer, passed per call by an agent whose heads can
+        read the parts themselves): the result may be a gemm.GatheredInput -- [context rows | x] not yet formed -- instead of
+        a tensor. The tensors this returns in train mode carry `_egp_ctx_cols` = v_hdim when x needs no gradient: their
+        trailing columns are raw states, so a consumer may skip that part of the input gradient."""
         if self.mode == "test":
             out = torch.cat((self.v_out[[self.t], :], x), dim=1)
             self.t += 1
             return out
         m = self.v_margin
+        def tagged(out):
+            if not x.requires_grad:
+                out._egp_ctx_cols = self.v_hdim
+            return out
         if self._buckets is not None:
             ctx = self._bucketed_context()[m:-m].transpose(0, 1).reshape(-1, self.v_hdim)
-            return torch.cat((ctx.index_select(0, self._gather_sorted), x), dim=1)
+            return tagged(torch.cat((ctx.index_select(0, self._gather_sorted), x), dim=1))
         ctx = None
         if self._v_ctx is not None:          # computed together with another net's (grouped_video_context)
             (ctx, with_grad), self._v_ctx = self._v_ctx, None
@@ -473,10 +482,10 @@ class VideoStateNet(nn.Module):
                 self.v_net.ragged = None
         ctx2d = ctx.reshape(-1, self.v_hdim)
         if self._gather_unique and _gemm.gather_concat_available(ctx2d, self._gather_tm, x):
-            if self.lazy_gather and _gemm.fused_gather_available(self.v_hdim, self.lazy_gather, x.shape[1]):
+            if lazy_width and _gemm.fused_gather_available(self.v_hdim, lazy_width, x.shape[1]):
                 return _gemm.GatheredInput(ctx2d, self._gather_tm, x)            # the consumer's first layer gathers (gemm.GatherMlpHead)
-            return _gemm.GatherConcat.apply(ctx2d, self._gather_tm, x)          # gather + concatenation in one pass
-        return torch.cat((ctx2d.index_select(0, self._gather_tm), x), dim=1)
+            return tagged(_gemm.GatherConcat.apply(ctx2d, self._gather_tm, x))  # gather + concatenation in one pass
+        return tagged(torch.cat((ctx2d.index_select(0, self._gather_tm), x), dim=1))
 
 
 class Bf16Shadow:

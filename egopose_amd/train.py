@@ -25,7 +25,7 @@ from .logging_utils import Logger, create_logger
 from .nets import MLP, PolicyGaussian, Value, VideoForecastNet, VideoStateNet
 from .reward import reward_func
 from .torch_utils import set_optimizer_lr, to_cpu, to_device
-from .zfilter import ZFilter, reference_pickle_names
+from .zfilter import ZFilter, dump_reference_pickle, load_reference_pickle
 
 
 class Trainer:
@@ -113,12 +113,12 @@ class Trainer:
         with to_cpu(*self.nets.values()):
             cp = {k: net.state_dict() for k, net in self.nets.items()}
             cp["running_state"] = self.running_state
-            with open(path, "wb") as f, reference_pickle_names():    # running_state pickles as utils.zfilter.ZFilter
-                pickle.dump(cp, f)
+            with open(path, "wb") as f:                   # running_state pickles as utils.zfilter.ZFilter
+                dump_reference_pickle(cp, f)
 
     def load(self, path):
-        with open(path, "rb") as f, reference_pickle_names():
-            cp = pickle.load(f)
+        with open(path, "rb") as f:
+            cp = load_reference_pickle(f)
         for k, net in self.nets.items():
             net.load_state_dict(cp[k])
         self.running_state = cp["running_state"]
@@ -128,8 +128,8 @@ class Trainer:
         """ego_forecast.py:60-68: start the policy / value MLPs from an ego_mimic checkpoint; the first affine layer is
         dropped when its input width differs (state LSTM, phase observation or another video width)."""
         from .torch_utils import filter_state_dict
-        with open(path, "rb") as f, reference_pickle_names():
-            cp = pickle.load(f)
+        with open(path, "rb") as f:
+            cp = load_reference_pickle(f)
         cfg = self.cfg
         differs = getattr(cfg, "obs_phase", False) or getattr(cfg, "policy_s_net", "id") != "id" or \
             (em_cfg is not None and cfg.policy_v_hdim != em_cfg.policy_v_hdim)

@@ -108,12 +108,54 @@ import types
 _REF_MODULE = "utils.zfilter"      # where the reference defines RunningStat / ZFilter (utils/zfilter.py)
 
 
+import pickle
+import threading
+
+_NAMES_LOCK = threading.RLock()
+
+
+class _RefPickler(pickle._Pickler):
+    """pickle.Pickler that writes RunningStat / ZFilter under the reference's module path, `utils.zfilter` -- per pickler, no
+    process-wide state touched (the pure-Python pickler: the C one offers no hook for a class's global name)."""
+
+    def save_global(self, obj, name=None):
+        if obj is RunningStat or obj is ZFilter:
+            self.write(pickle.GLOBAL + _REF_MODULE.encode() + b"\n" + obj.__name__.encode() + b"\n")
+            self.memoize(obj)
+            return
+        super().save_global(obj, name)
+
+
+class _RefUnpickler(pickle.Unpickler):
+    """pickle.Unpickler that resolves `utils.zfilter.{RunningStat, ZFilter}` to this module's classes, whatever `utils` package
+    (if any) is importable in the process."""
+
+    def find_class(self, module, name):
+        if module == _REF_MODULE and name in ("RunningStat", "ZFilter"):
+            return {"RunningStat": RunningStat, "ZFilter": ZFilter}[name]
+        return super().find_class(module, name)
+
+
+def dump_reference_pickle(obj, f):
+    """pickle.dump(obj, f) with `running_state` objects named as the reference names them (ego_pose/ego_mimic.py:135-139): the
+    file loads in the unmodified reference. Thread-safe (nothing global changes); what Trainer.save uses."""
+    _RefPickler(f, protocol=pickle.DEFAULT_PROTOCOL).dump(obj)
+
+
+def load_reference_pickle(f):
+    """pickle.load(f) for checkpoints written by the reference or by dump_reference_pickle. Thread-safe."""
+    return _RefUnpickler(f).load()
+
+
 @contextlib.contextmanager
 def reference_pickle_names():
-    """While active, RunningStat / ZFilter pickle under the reference's module path (`utils.zfilter.ZFilter`), so a
+    """Context-manager form for code that calls plain `pickle.dump / pickle.load` itself. PROCESS-WIDE while active (it renames
+    the classes and may install alias modules), serialised by a lock -- prefer dump_reference_pickle / load_reference_pickle.
+    While active, RunningStat / ZFilter pickle under the reference's module path (`utils.zfilter.ZFilter`), so a
     checkpoint's `running_state` (ego_pose/ego_mimic.py:135-139) written here loads in the unmodified reference and
     one written by the reference loads here -- whether or not `egopose_amd/compat` is on the path. When `utils.zfilter`
     is not importable in this process, alias modules stand in for the duration of the block and are removed afterwards."""
+    _NAMES_LOCK.acquire()
     classes = (RunningStat, ZFilter)
     saved = [c.__module__ for c in classes]
     installed = []
@@ -147,3 +189,4 @@ def reference_pickle_names():
                     sys.modules.pop(k, None)
                 else:
                     sys.modules[k] = v
+        _NAMES_LOCK.release()

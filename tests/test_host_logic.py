@@ -400,6 +400,27 @@ def test_running_state_pickles_under_the_reference_module_path(tmp_path):
         back = pickle.loads(blob)["running_state"]
     assert isinstance(back, ZFilter) and back.rs.n == 7
     np.testing.assert_array_equal(back.rs.std, zf.rs.std)
+    # the thread-safe forms Trainer.save / load use: same bytes on the wire, nothing process-wide touched, usable from threads
+    import io
+    import threading
+    from egopose_amd.zfilter import dump_reference_pickle, load_reference_pickle
+    blobs, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            for _ in range(20):
+                b = io.BytesIO()
+                dump_reference_pickle({"running_state": zf, "i": i}, b)
+                got = load_reference_pickle(io.BytesIO(b.getvalue()))
+                assert isinstance(got["running_state"], ZFilter) and got["i"] == i and ZFilter.__module__ == "egopose_amd.zfilter"
+            blobs[i] = b.getvalue()
+        except Exception as e:           # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs and all(b is not None and b"utils.zfilter" in b and b"egopose_amd" not in b for b in blobs)
+    assert isinstance(load_reference_pickle(io.BytesIO(blob))["running_state"], ZFilter)          # the context manager's bytes load too
     if os.path.exists("/root/reference/utils/zfilter.py"):       # build container: the reference's own class takes it
         code = ("import sys, pickle, numpy as np; sys.path.insert(0, '/root/reference/utils'); import importlib.util as iu; "
                 "spec = iu.spec_from_file_location('utils.zfilter', '/root/reference/utils/zfilter.py'); m = iu.module_from_spec(spec); "
