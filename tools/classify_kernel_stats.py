@@ -11,6 +11,7 @@ def cls(n):
     if "k_gemm" in n or "k_gemv_rows" in n or "k_rank1" in n or "k_colsum" in n: return "GEMM (HIP, split bf16 MFMA + thin float32 products)"
     if n.startswith("Cijk") or "rocblas" in n.lower(): return "GEMM (library)"
     if "k_policy" in n: return "policy step (HIP)"
+    if "k_ppo_loss" in n or "k_adam" in n or "k_sqnorm" in n: return "update tail (HIP: losses, clip + Adam)"
     if "egp::" in n or "k_engine" in n or "k_zf" in n: return "other egp kernels (K2-K6, engine)"
     if "copyBuffer" in n or "fillBuffer" in n: return "copy / fill"
     if "Adam" in n or "multi_tensor" in n: return "optimizer"
