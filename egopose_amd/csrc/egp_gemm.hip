@@ -586,31 +586,33 @@ template <int N> __device__ __forceinline__ void ws_wait(float (&r)[16]) {
 
 // exact three-way split by truncation: x = h + m + l with 8 significant bits each (the float32 mantissa is 24 bits), the
 // bf16 pieces are the upper halves of h, m and l. Two floats at a time: the pieces of a pair pack with one v_perm each.
+// (Round 3, measured and NOT adopted -- A/B runs of whole-library builds inside one GPU lease, tools/probes/ab_libs.sh +
+//  update_time.py: the two subtractions of a pair as v_pk_add_f32 (9 vector instructions per pair instead of 11) make the
+//  update 1.5-2 ms SLOWER (51.9 -> 53.5 ms); two producer sets per workgroup (12 waves, half a tile each, which needs the
+//  consumers' fragments loaded per k-step to fit 168 VGPRs) are neutral (51.1 vs 50.9 ms). Why neither helps:
+//  tools/probes/mfma_valu_overlap.hip -- a SIMD's vector ALU makes no progress while its matrix pipe runs back to back, so a
+//  k-tile costs MFMA time PLUS conversion time whoever issues the conversion; this kernel is at 82 % of that serial bound.)
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &ph, unsigned &pm, unsigned &pl) {
-    // (the two subtractions of a pair are ONE v_pk_add_f32 each: 9 vector instructions per pair instead of 11 -- they count,
-    //  because a SIMD's vector ALU does not run while its matrix pipe does, tools/probes/mfma_valu_overlap.hip)
     const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-    const f32x2 x = {x0, x1};
-    const f32x2 h = {__uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 & 0xffff0000u)};
-    const f32x2 r = x - h;                                                    // exact
-    const unsigned v0 = __float_as_uint(r[0]), v1 = __float_as_uint(r[1]);
-    const f32x2 m = {__uint_as_float(v0 & 0xffff0000u), __uint_as_float(v1 & 0xffff0000u)};
-    const f32x2 l = r - m;                                                    // exact, at most 8 significant bits
+    const float h0 = __uint_as_float(u0 & 0xffff0000u), h1 = __uint_as_float(u1 & 0xffff0000u);
+    const float r0 = x0 - h0, r1 = x1 - h1;                                   // exact
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    const float m0 = __uint_as_float(v0 & 0xffff0000u), m1 = __uint_as_float(v1 & 0xffff0000u);
+    const float l0 = r0 - m0, l1 = r1 - m1;                                   // exact, at most 8 significant bits
     ph = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                          // { hi16(x1), hi16(x0) }
     pm = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    pl = __builtin_amdgcn_perm(__float_as_uint(l[1]), __float_as_uint(l[0]), 0x07060302u);
+    pl = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
 }
 
-// staged registers -> the three LDS images: v[8 u + j] = (row r_first + ROW_STEP u, k = 8 panel + j), one 16-byte store per image.
-// R: rows this thread group stages (a whole tile, or one producer set's half of it); TR: rows of the tile (panel stride)
-template <int R, int ROW_STEP, int TR>
+// staged registers -> the three LDS images: v[8 u + j] = (row r_first + ROW_STEP u, k = 8 panel + j), one 16-byte store per image
+template <int R, int ROW_STEP>
 __device__ __forceinline__ void ws_store(const float (&v)[R / 8], __bf16 *dst, int img, int panel, int r_first) {
 #pragma unroll
     for (int u = 0; u < R / 64; ++u) {
         unsigned q[3][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) split3_pair(v[8 * u + 2 * j], v[8 * u + 2 * j + 1], q[0][j], q[1][j], q[2][j]);
-        const int off = panel * panel_el(TR) + (r_first + ROW_STEP * u) * 8;
+        const int off = panel * panel_el(R) + (r_first + ROW_STEP * u) * 8;
 #pragma unroll
         for (int c = 0; c < 3; ++c) *(uint4 *)(dst + c * img + off) = make_uint4(q[c][0], q[c][1], q[c][2], q[c][3]);
     }
@@ -624,25 +626,9 @@ __device__ __forceinline__ void ws_zero_head(float (&v)[R / 8], int zrel, int pa
         for (int j = 0; j < 8; ++j) v[8 * u + j] = 8 * panel + j >= zrel ? v[8 * u + j] : 0.f;
 }
 
-// Producer sets. A lone producer wave per SIMD converts a k-tile in ~2.5 k cycles against the 1.5 k its 48 MFMAs take
-// (cycle stamps, tools/probes/gemm_trace.hip: the consumers idle a third of every k-tile): a wave issues a VALU instruction
-// every 4 cycles at best and shares its SIMD's issue port with the consumer wave. With 128-column tiles the workgroup
-// therefore has TWO producer sets of four waves (12 waves, three per SIMD): set s stages rows [64 s, 64 s + 64) of both
-// operand tiles, so the conversion of a k-tile is spread over two waves per SIMD that fill each other's issue gaps.
-template <int BN> struct WsShape {
-#ifdef EGP_WS_PSETS                                               // (A/B builds: -DEGP_WS_PSETS=1 = one producer set everywhere)
-    static constexpr int PSETS = BN == 128 ? EGP_WS_PSETS : 1;
-#else
-    static constexpr int PSETS = BN == 128 ? 2 : 1;             // producer sets (64-column tiles: B has no half to give)
-#endif
-    static constexpr int THREADS = 256 + 256 * PSETS;
-};
-
 template <int BN, bool A_KC, bool B_KC, bool FUSED>      // FUSED: the gather / scatter operands of egp_gemm_desc (a_rows ... c_rows) are compiled in
-__global__ __launch_bounds__(WsShape<BN>::THREADS) void k_gemm_ws(GemmArgs g) {
+__global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
     constexpr int NIMG = 3, NSET = 4;
-    constexpr int PSETS = WsShape<BN>::PSETS;
-    constexpr int AR = BM / PSETS, BR = BN / PSETS;             // rows of the A / B tile one producer set stages
     constexpr int WN = BN == 128 ? 2 : 1;
     constexpr int MI = BN == 128 ? 2 : 1, NJ = 2;
     constexpr int WROWS = 32 * MI;
@@ -652,8 +638,7 @@ __global__ __launch_bounds__(WsShape<BN>::THREADS) void k_gemm_ws(GemmArgs g) {
     __bf16 *base = (__bf16 *)smem;
     const int t = threadIdx.x, pt = t & 255, lane = t & 63;
     const bool producer = __builtin_amdgcn_readfirstlane(t) >= 256;         // wave-uniform, and the compiler knows it
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6) & 3;            // wave within its role / producer set
-    const int pset = PSETS > 1 ? (__builtin_amdgcn_readfirstlane(t >> 8) - 1) & (PSETS - 1) : 0;      // producer set of this wave
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6) & 3;
     const int ones_row = g.ones_col ? g.N : -1;
 
     // this workgroup's stream: P k-tiles over its items
@@ -688,9 +673,8 @@ __global__ __launch_bounds__(WsShape<BN>::THREADS) void k_gemm_ws(GemmArgs g) {
     // barriers, each in its own loop (separate loops keep the producers' staging registers and the consumers' accumulators
     // out of each other's live ranges).
     if (producer) {
-        using SA = WsStage<AR, A_KC>;
-        using SB = WsStage<BR, B_KC>;
-        const int a_r0 = pset * AR, b_r0 = pset * BR;            // this set's first row inside the tiles
+        using SA = WsStage<BM, A_KC>;
+        using SB = WsStage<BN, B_KC>;
         typename SA::Regs ra[NSET];
         typename SB::Regs rb[NSET];
         int zrel[NSET] = {0, 0, 0, 0};
@@ -724,12 +708,12 @@ __global__ __launch_bounds__(WsShape<BN>::THREADS) void k_gemm_ws(GemmArgs g) {
             const bool b_second = FUSED && !B_KC && g.B2 && cur.n0 >= g.b_split;
             if (cur.w != bound) {
                 if constexpr (FUSED) {
-                    sa.bind(g.lda, g.M, cur.m0 + a_r0, -1, pt, A_KC ? g.a_rows : nullptr, g.lda2);
-                    if (b_second) sb.bind(g.ldb2, g.N - g.b_split, cur.n0 + b_r0 - g.b_split, ones_row - g.b_split, pt);
-                    else sb.bind(g.ldb, (!B_KC && g.B2) ? g.b_split : g.N, cur.n0 + b_r0, (!B_KC && g.B2) ? -1 : ones_row, pt);
+                    sa.bind(g.lda, g.M, cur.m0, -1, pt, A_KC ? g.a_rows : nullptr, g.lda2);
+                    if (b_second) sb.bind(g.ldb2, g.N - g.b_split, cur.n0 - g.b_split, ones_row - g.b_split, pt);
+                    else sb.bind(g.ldb, (!B_KC && g.B2) ? g.b_split : g.N, cur.n0, (!B_KC && g.B2) ? -1 : ones_row, pt);
                 } else {
-                    sa.bind(g.lda, g.M, cur.m0 + a_r0, -1, pt);
-                    sb.bind(g.ldb, g.N, cur.n0 + b_r0, ones_row, pt);
+                    sa.bind(g.lda, g.M, cur.m0, -1, pt);
+                    sb.bind(g.ldb, g.N, cur.n0, ones_row, pt);
                 }
                 bound = cur.w;
             }
@@ -751,22 +735,22 @@ __global__ __launch_bounds__(WsShape<BN>::THREADS) void k_gemm_ws(GemmArgs g) {
         auto stage = [&](auto setc, int buf) __attribute__((always_inline)) {   // register set -> LDS buffer `buf`
             constexpr int SET = decltype(setc)::value;
             // (panel, first row) of the thread: k-contiguous -> (t & 3, t >> 2), row-contiguous -> (wave, lane or 2 lane)
-            const int pa_panel = A_KC ? (pt & 3) : wave, pa_row = a_r0 + (A_KC ? (pt >> 2) : SA::ROW0_MUL * lane);
-            const int pb_panel = B_KC ? (pt & 3) : wave, pb_row = b_r0 + (B_KC ? (pt >> 2) : SB::ROW0_MUL * lane);
+            const int pa_panel = A_KC ? (pt & 3) : wave, pa_row = A_KC ? (pt >> 2) : SA::ROW0_MUL * lane;
+            const int pb_panel = B_KC ? (pt & 3) : wave, pb_row = B_KC ? (pt >> 2) : SB::ROW0_MUL * lane;
             ws_wait<YOUNGER>(ra[SET]);
             ws_wait<YOUNGER>(rb[SET]);
             EGP_TRW(1, 33);
-            float va[AR / 8], vb[BR / 8];
+            float va[BM / 8], vb[BN / 8];
             sa.unpack(ra[SET], va);
             sb.unpack(rb[SET], vb);
             if (zrel[SET] > 0) {
-                ws_zero_head<AR>(va, zrel[SET], pa_panel);
-                ws_zero_head<BR>(vb, zrel[SET], pb_panel);
+                ws_zero_head<BM>(va, zrel[SET], pa_panel);
+                ws_zero_head<BN>(vb, zrel[SET], pb_panel);
             }
             __bf16 *pa = base + buf * BUF_EL, *pb = pa + NIMG * A_EL;
-            ws_store<AR, SA::ROW_STEP, BM>(va, pa, A_EL, pa_panel, pa_row);
+            ws_store<BM, SA::ROW_STEP>(va, pa, A_EL, pa_panel, pa_row);
             EGP_TRW(1, 34);
-            ws_store<BR, SB::ROW_STEP, BN>(vb, pb, B_EL, pb_panel, pb_row);
+            ws_store<BN, SB::ROW_STEP>(vb, pb, B_EL, pb_panel, pb_row);
         };
         prefetch(); issue(S0); prefetch(); issue(S1); prefetch(); issue(S2); prefetch(); issue(S3);      // k-tiles 0..3 in flight
         prefetch();
@@ -813,34 +797,34 @@ __global__ __launch_bounds__(WsShape<BN>::THREADS) void k_gemm_ws(GemmArgs g) {
     // so that a lane holds four consecutive n of one row: 16-byte stores (and mask loads).
     auto compute = [&](int buf) __attribute__((always_inline)) {
         const __bf16 *pa = base + buf * BUF_EL, *pb = pa + NIMG * A_EL;
-        // One k-step (16 k) at a time: its 12 fragments are requested together, then its 24 MFMAs run back to back. (With
-        // three waves per SIMD a wave has 168 VGPRs: the 24 fragments of a whole k-tile no longer fit next to the
-        // accumulators; the second k-step's reads are issued behind the first one's MFMAs and land while those run.)
+        // every fragment of the k-tile is requested before the first MFMA (the matrix pipe then runs the 48 products
+        // back to back instead of idling through an LDS round trip in the middle)
+        bf16x8 fa[BK / 16][NIMG][MI], fb[BK / 16][NIMG][NJ];
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 fa[NIMG][MI], fb[NIMG][NJ];
+        for (int ks = 0; ks < BK / 16; ++ks)
 #pragma unroll
             for (int c = 0; c < NIMG; ++c) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
-                    fa[c][i] = *(const bf16x8 *)(pa + c * A_EL + (2 * ks + fkh) * panel_el(BM) + (wm * WROWS + 32 * i + frow) * 8);
+                    fa[ks][c][i] = *(const bf16x8 *)(pa + c * A_EL + (2 * ks + fkh) * panel_el(BM) + (wm * WROWS + 32 * i + frow) * 8);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    fb[c][j] = *(const bf16x8 *)(pb + c * B_EL + (2 * ks + fkh) * panel_el(BN) + (wn * 64 + 32 * j + frow) * 8);
+                    fb[ks][c][j] = *(const bf16x8 *)(pb + c * B_EL + (2 * ks + fkh) * panel_el(BN) + (wn * 64 + 32 * j + frow) * 8);
             }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     f32x16 a = acc[i][j];                 // smallest terms first
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[2][i], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[2][j], fa[0][i], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][j], fa[1][i], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[1][i], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][j], fa[0][i], a, 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[0][i], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][0][j], fa[ks][2][i], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][2][j], fa[ks][0][i], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][1][j], fa[ks][1][i], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][0][j], fa[ks][1][i], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][1][j], fa[ks][0][i], a, 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][0][j], fa[ks][0][i], a, 0, 0, 0);
                 }
-        }
     };
     // Epilogue: a lane holds 4 consecutive n of row m = lane & 31 -- 16 bytes, but 32 different rows per store instruction.
     // The wave's part of the tile therefore goes through a wave-private LDS patch (32 rows x 64 columns at a time, written
@@ -862,26 +846,28 @@ __global__ __launch_bounds__(WsShape<BN>::THREADS) void k_gemm_ws(GemmArgs g) {
         const int colc = min(col, ncols - 4);
         const bool col_ok = col < ncols;
         const int row0 = cur.m0 + wm * WROWS + (lane >> 4);
+        long drow[MI][8];                                 // destination rows (scatter: c_rows)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = row0 + 32 * i + 4 * it;
+                drow[i][it] = (FUSED && !PARTIAL && g.c_rows) ? (long)g.c_rows[min(row, g.M - 1)] : (long)row;
+            }
         // (16-byte accesses on 4-byte-aligned addresses throughout: leading dimensions like 243 are welcome)
         f32x4u bv = {0.f, 0.f, 0.f, 0.f};
         if constexpr (!PARTIAL) bv = *(const f32x4u *)((g.bias ? g.bias : g.C) + colc);      // (no bias: any readable address, the value is dropped)
         if (PARTIAL || !g.bias) bv = f32x4u{0.f, 0.f, 0.f, 0.f};
-        // one 32-row slab of the wave's part at a time (its destination rows and mask rows are requested together, before the
-        // slab's first store): with three waves per SIMD the registers do not hold the mask rows of both slabs
+        f32x4u keep[MI][8];
+        if constexpr (MASK) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            long drow[8];                                 // destination rows (scatter: c_rows)
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = row0 + 32 * i + 4 * it;
-                drow[it] = (FUSED && !PARTIAL && g.c_rows) ? (long)g.c_rows[min(row, g.M - 1)] : (long)row;
-            }
-            f32x4u keep[8];
-            if constexpr (MASK) {
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int it = 0; it < 8; ++it)
-                    keep[it] = *(const f32x4u *)(g.mask + (long)min(row0 + 32 * i + 4 * it, g.M - 1) * g.ldmask + colc);
-            }
+                    keep[i][it] = *(const f32x4u *)(g.mask + (long)min(row0 + 32 * i + 4 * it, g.M - 1) * g.ldmask + colc);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -898,10 +884,10 @@ __global__ __launch_bounds__(WsShape<BN>::THREADS) void k_gemm_ws(GemmArgs g) {
                     x.z = fmaxf(x.z + bv[2], floor_v); x.w = fmaxf(x.w + bv[3], floor_v);
                 }
                 if constexpr (MASK) {
-                    x.x = keep[it][0] > 0.f ? x.x : 0.f; x.y = keep[it][1] > 0.f ? x.y : 0.f;
-                    x.z = keep[it][2] > 0.f ? x.z : 0.f; x.w = keep[it][3] > 0.f ? x.w : 0.f;
+                    x.x = keep[i][it][0] > 0.f ? x.x : 0.f; x.y = keep[i][it][1] > 0.f ? x.y : 0.f;
+                    x.z = keep[i][it][2] > 0.f ? x.z : 0.f; x.w = keep[i][it][3] > 0.f ? x.w : 0.f;
                 }
-                if (row < g.M && col_ok) *(f32x4u *)(dst + drow[it] * ldd + col) = f32x4u{x.x, x.y, x.z, x.w};
+                if (row < g.M && col_ok) *(f32x4u *)(dst + drow[i][it] * ldd + col) = f32x4u{x.x, x.y, x.z, x.w};
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -1099,7 +1085,7 @@ int launch_ws(const GemmArgs &g, hipStream_t s) {
             EGP_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_set = true;                                                                                          \
         }                                                                                                             \
-        kern<<<grid, dim3(WsShape<BN>::THREADS), lds, s>>>(g);                                                        \
+        kern<<<grid, dim3(512), lds, s>>>(g);                                                                         \
     } while (0)
     if (g.a_kc && g.b_kc) EGP_GEMM_WS_LAUNCH(true, true);
     else if (g.a_kc && !g.b_kc) EGP_GEMM_WS_LAUNCH(true, false);
