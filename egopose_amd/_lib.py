@@ -195,6 +195,8 @@ SIGNATURES = {
     "egp_set_dynamics_model": (C.c_int, [vp, C.POINTER(DynamicsDesc)]),
     "egp_dynamics_f64": (C.c_int, [vp, vp, vp, _i32, vp, C.c_int64, vp, vp, vp]),
     "egp_policy_gaussian_f32": (C.c_int, [vp, C.c_int64, _i32, vp, vp, _i32, _i32, C.POINTER(MlpLayer), _i32, _i32, vp, vp, vp, vp, vp]),
+    "egp_policy_gaussian_staged_f32": (C.c_int, [vp, C.c_int64, _i32, vp, vp, _i32, _i32, C.POINTER(MlpLayer), _i32, _i32, vp, vp, vp, vp, vp, vp,
+                                                 C.c_int64, vp]),
     "egp_physics_register": (C.c_int, [C.POINTER(PhysicsVtable), _i32, C.POINTER(vp)]),
     "egp_physics_create_surrogate": (C.c_int, [C.POINTER(SurrogateDesc), _i32, C.POINTER(vp)]),
     "egp_physics_destroy": (C.c_int, [vp]),

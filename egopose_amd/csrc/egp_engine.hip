@@ -1215,11 +1215,21 @@ int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, in
     }
     uint8_t *fbase = d->slab_dev + soff;
     int rc = EGP_OK;
-    if (d->flags_upload && (rc = egp_upload_async(fbase, d->slab_host + soff, 24 * (int64_t)nmax, d->stream)) != EGP_OK) return rc;
     const size_t row = (size_t)k * N + a;
-    rc = egp_policy_gaussian_f32(d->v_out + (size_t)a * d->v_stride, d->v_stride, d->ctx_dim, reinterpret_cast<const int64_t *>(fbase + 16 * (size_t)nmax),
-                                 d->states + row * d->obs_dim, d->obs_dim, n, d->layers, d->n_layers, d->activation, d->log_std,
-                                 d->noise ? d->noise + row * d->nu : nullptr, d->actions + row * d->nu, nullptr, d->stream);
+    // flags_upload: 1 = a copy-engine transfer in front of the policy step; 2 (default) = the policy kernel moves the slab
+    // itself and reads its context-row indices straight from the pinned copy (one dependent operation less per tick)
+    if (d->flags_upload == 2) {
+        rc = egp_policy_gaussian_staged_f32(d->v_out + (size_t)a * d->v_stride, d->v_stride, d->ctx_dim,
+                                            reinterpret_cast<const int64_t *>(d->slab_host + soff + 16 * (size_t)nmax),
+                                            d->states + row * d->obs_dim, d->obs_dim, n, d->layers, d->n_layers, d->activation, d->log_std,
+                                            d->noise ? d->noise + row * d->nu : nullptr, d->actions + row * d->nu, nullptr,
+                                            d->slab_host + soff, fbase, 24 * (int64_t)nmax, d->stream);
+    } else {
+        if (d->flags_upload && (rc = egp_upload_async(fbase, d->slab_host + soff, 24 * (int64_t)nmax, d->stream)) != EGP_OK) return rc;
+        rc = egp_policy_gaussian_f32(d->v_out + (size_t)a * d->v_stride, d->v_stride, d->ctx_dim, reinterpret_cast<const int64_t *>(fbase + 16 * (size_t)nmax),
+                                     d->states + row * d->obs_dim, d->obs_dim, n, d->layers, d->n_layers, d->activation, d->log_std,
+                                     d->noise ? d->noise + row * d->nu : nullptr, d->actions + row * d->nu, nullptr, d->stream);
+    }
     if (rc != EGP_OK) return rc;
     EGP_HIP_CHECK(hipEventRecord((hipEvent_t)ready_event, (hipStream_t)d->stream));
     if (d->reward_job) {      // K2 rides behind this env-step's kernel on the engine's stream

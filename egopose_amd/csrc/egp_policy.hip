@@ -32,21 +32,32 @@ __device__ __forceinline__ float pol_act(float v, int kind) {
 
 // Thread t of a layer pass owns 4 consecutive outputs (one 16-byte weight load per input feature) for one slice of
 // the input features; the slices' partial sums meet in LDS. With 512 threads: 300 outputs -> 75 columns x 6 slices.
+// `stage_src` / `stage_dst` (optional): the tick's flag slab. The rollout stages the integer flags and context-row indices of a
+// tick in pinned host memory; instead of a copy-engine transfer in front of this kernel (one more dependent operation, ~6 us,
+// on the chain filter -> policy -> env-step of every tick) the workgroups copy the slab to its device copy themselves -- the
+// kernels that run after the env-step (reward, filter) read it there -- and take their own rows' indices (`t_idx`, which then
+// points into the pinned slab) with ONE load per row.
 __global__ void k_policy_gaussian(const float *__restrict__ ctx_rows, long ctx_row_stride, int ctx_dim,
                                   const long long *__restrict__ t_idx, const double *__restrict__ state, int state_dim, int n,
                                   PolLayers L, int act_kind, int kmax, int part_elems, const float *__restrict__ log_std,
-                                  const float *__restrict__ noise, double *__restrict__ action, float *__restrict__ mean_out) {
+                                  const float *__restrict__ noise, double *__restrict__ action, float *__restrict__ mean_out,
+                                  const unsigned *__restrict__ stage_src, unsigned *__restrict__ stage_dst, int stage_words) {
     extern __shared__ float4 s_act[];     // cur[kmax] | nxt[kmax] | part[part_elems]   (one float per row of the tile)
+    __shared__ long long s_ti[POL_ROWS];
     float4 *cur = s_act, *nxt = s_act + kmax, *part = s_act + 2 * kmax;
     const int r0 = blockIdx.x * POL_ROWS;
     const int in0 = ctx_dim + state_dim;
+    if (threadIdx.x < POL_ROWS) s_ti[threadIdx.x] = r0 + (int)threadIdx.x < n ? t_idx[r0 + threadIdx.x] : 0;
+    if (stage_src)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < stage_words; i += gridDim.x * blockDim.x) stage_dst[i] = stage_src[i];
+    __syncthreads();
     for (int k = threadIdx.x; k < in0; k += blockDim.x) {
         float v[POL_ROWS];
 #pragma unroll
         for (int r = 0; r < POL_ROWS; ++r) {
             const int row = r0 + r;
             if (row >= n) { v[r] = 0.0f; continue; }
-            v[r] = k < ctx_dim ? ctx_rows[(long)row * ctx_row_stride + (long)t_idx[row] * ctx_dim + k]
+            v[r] = k < ctx_dim ? ctx_rows[(long)row * ctx_row_stride + (long)s_ti[r] * ctx_dim + k]
                                : (float)state[(long)row * state_dim + (k - ctx_dim)];
         }
         cur[k] = make_float4(v[0], v[1], v[2], v[3]);
@@ -131,11 +142,12 @@ __global__ void k_policy_gaussian(const float *__restrict__ ctx_rows, long ctx_r
 
 }  // namespace
 
-extern "C" int egp_policy_gaussian_f32(const float *ctx_rows, int64_t ctx_row_stride, int32_t ctx_dim, const int64_t *t_idx,
-                                       const double *state, int32_t state_dim, int32_t n, const egp_mlp_layer *layers,
-                                       int32_t n_layers, int32_t activation, const float *log_std, const float *noise,
-                                       double *action, float *mean_out, void *stream) {
+static int policy_launch(const float *ctx_rows, int64_t ctx_row_stride, int32_t ctx_dim, const int64_t *t_idx,
+                         const double *state, int32_t state_dim, int32_t n, const egp_mlp_layer *layers,
+                         int32_t n_layers, int32_t activation, const float *log_std, const float *noise,
+                         double *action, float *mean_out, const void *stage_src, void *stage_dst, int64_t stage_bytes, void *stream) {
     EGP_REQUIRE(n >= 0, "n < 0");
+    EGP_REQUIRE(stage_bytes >= 0 && stage_bytes % 4 == 0 && stage_bytes < (1ll << 31) && (stage_bytes == 0 || (stage_src && stage_dst)), "bad staging slab");
     if (n == 0) return EGP_OK;
     EGP_REQUIRE(ctx_rows && t_idx && state && layers && action, "NULL pointer");
     EGP_REQUIRE(!noise || log_std, "noise needs log_std");
@@ -167,8 +179,25 @@ extern "C" int egp_policy_gaussian_f32(const float *ctx_rows, int64_t ctx_row_st
     EGP_REQUIRE(lds <= 150 * 1024, "layers too wide for the LDS tile");
     k_policy_gaussian<<<dim3((n + POL_ROWS - 1) / POL_ROWS), dim3(threads), lds, (hipStream_t)stream>>>(
         ctx_rows, (long)ctx_row_stride, ctx_dim, (const long long *)t_idx, state, state_dim, n, L, activation, kmax, part_elems,
-        log_std, noise, action, mean_out);
+        log_std, noise, action, mean_out, stage_bytes ? (const unsigned *)stage_src : nullptr, (unsigned *)stage_dst, (int)(stage_bytes / 4));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { egp::set_error("k_policy_gaussian launch failed: %s", hipGetErrorString(e)); return EGP_E_HIP; }
     return EGP_OK;
+}
+
+extern "C" int egp_policy_gaussian_f32(const float *ctx_rows, int64_t ctx_row_stride, int32_t ctx_dim, const int64_t *t_idx,
+                                       const double *state, int32_t state_dim, int32_t n, const egp_mlp_layer *layers,
+                                       int32_t n_layers, int32_t activation, const float *log_std, const float *noise,
+                                       double *action, float *mean_out, void *stream) {
+    return policy_launch(ctx_rows, ctx_row_stride, ctx_dim, t_idx, state, state_dim, n, layers, n_layers, activation, log_std, noise, action,
+                         mean_out, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int egp_policy_gaussian_staged_f32(const float *ctx_rows, int64_t ctx_row_stride, int32_t ctx_dim, const int64_t *t_idx,
+                                              const double *state, int32_t state_dim, int32_t n, const egp_mlp_layer *layers,
+                                              int32_t n_layers, int32_t activation, const float *log_std, const float *noise,
+                                              double *action, float *mean_out, const void *stage_src, void *stage_dst, int64_t stage_bytes,
+                                              void *stream) {
+    return policy_launch(ctx_rows, ctx_row_stride, ctx_dim, t_idx, state, state_dim, n, layers, n_layers, activation, log_std, noise, action,
+                         mean_out, stage_src, stage_dst, stage_bytes, stream);
 }

@@ -466,7 +466,7 @@ class LockstepRollout:
             fl_np = slab_np[:, :, :16 * nmax].view(np.int32)            # (G, 2, 4*nmax)
             ti_np = slab_np[:, :, 16 * nmax:].view(np.int64)            # (G, 2, nmax)
             slab_hp, slab_dp = slab_h.data_ptr(), slab_d.data_ptr()
-            flags_upload = os.environ.get("EGP_TICK_FLAGS", "upload") != "zerocopy"
+            flags_upload = os.environ.get("EGP_TICK_FLAGS", "kernel") != "zerocopy"
             if not flags_upload:       # kernels read the pinned slab in place (same address on the device): every access is a PCIe read
                 slab_dp = slab_hp
             reward_job = eng.substeps_per_launch > 1 and os.environ.get("EGP_REWARD_JOB", "1") != "0"
@@ -490,7 +490,10 @@ class LockstepRollout:
             td.ctx, td.eng, td.stream = hnd, eng.handle, cur_stream
             td.n_env, td.nmax, td.obs_dim, td.nu, td.nq, td.nv = N, nmax, od, nu, ctx.nq, ctx.nv
             td.ctx_dim, td.ctx_T, td.episode_len = H, self.ctx_T, int(T_eff)
-            td.reward_job, td.flags_upload = int(bool(reward_job)), int(bool(flags_upload))
+            # EGP_TICK_FLAGS: 'kernel' (default: the policy kernel stages the tick's flag slab itself), 'upload' (a copy-engine
+            # transfer in front of it, round 2's form), 'zerocopy' (every kernel reads the pinned slab over PCIe)
+            stage_mode = os.environ.get("EGP_TICK_FLAGS", "kernel")
+            td.reward_job, td.flags_upload = int(bool(reward_job)), (0 if not flags_upload else (2 if stage_mode == "kernel" else 1))
             td.has_fix_head_lb = int(self.env.fix_head_lb is not None)
             td.fix_head_lb = float(self.env.fix_head_lb) if self.env.fix_head_lb is not None else 0.0
             td.end_reward, td.zf_clip = end_r, zclip

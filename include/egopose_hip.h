@@ -452,6 +452,15 @@ int egp_policy_gaussian_f32(const float *ctx_rows, int64_t ctx_row_stride, int32
                             const double *state, int32_t state_dim, int32_t n, const egp_mlp_layer *layers,
                             int32_t n_layers, int32_t activation, const float *log_std, const float *noise,
                             double *action, float *mean_out, void *stream);
+/* The same launch also moving a staging slab: `stage_bytes` (a multiple of 4) bytes from `stage_src` -- device-visible pinned
+ * host memory, `t_idx` may point into it -- to `stage_dst` in HBM, spread over the launch's workgroups. The rollout's tick
+ * uses it for its per-tick flag slab (egp_rollout_tick.slab_host / slab_dev) instead of a copy-engine transfer in front of
+ * the policy step; kernels launched later on the stream read `stage_dst`. */
+int egp_policy_gaussian_staged_f32(const float *ctx_rows, int64_t ctx_row_stride, int32_t ctx_dim, const int64_t *t_idx,
+                                   const double *state, int32_t state_dim, int32_t n, const egp_mlp_layer *layers,
+                                   int32_t n_layers, int32_t activation, const float *log_std, const float *noise,
+                                   double *action, float *mean_out, const void *stage_src, void *stage_dst, int64_t stage_bytes,
+                                   void *stream);
 
 /* ----------------------------------------------------------------------------------------
  * Host physics boundary (replaces mujoco_py's MjSim inside HumanoidEnv: envs/common/mujoco_env.py:84-105,
@@ -556,6 +565,8 @@ int egp_engine_group_range(egp_engine *e, int32_t group, int32_t *env_begin, int
  * Python (flags of the coming env-step, their upload, the fused policy step, the reward job, the env-step; then the wait,
  * K3 + K6, K2 and the termination flags of HumanoidEnv.step, ego_pose/envs/humanoid_v1.py:182-199). The driver fills the
  * descriptor once per rollout; the arrays are its own (NumPy / device tensors) and stay valid for the rollout.
+ *   flags_upload: how the tick's flag slab reaches the device -- 0 kernels read slab_host in place (then slab_dev == slab_host),
+ *                 1 a copy-engine transfer in front of the policy step, 2 the policy kernel moves it (egp_policy_gaussian_staged_f32)
  *   pre : flags / context rows of tick k for slots [a, b) -> policy -> env-step (asynchronous)
  *   post: wait for the env-step, observation + filter into states[k + 1] / next_states[k], reward, cur_t / done / record rows;
  *         *n_done = slots whose episode ended, *wait_s = seconds blocked on the env-step */
