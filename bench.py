@@ -254,7 +254,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2,
+                    help="untimed iterations (the first two still grow the allocator's pools: batch sizes differ from rollout to rollout)")
     ap.add_argument("--envs", type=int, default=1024, help="env slots per GPU")
     ap.add_argument("--threads", type=int, default=0, help="host physics threads per GPU (0 = auto)")
     ap.add_argument("--groups", type=int, default=2)
