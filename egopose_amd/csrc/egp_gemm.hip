@@ -1133,28 +1133,9 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     EGP_REQUIRE(!partial || d->workspace, "split-K / bias-gradient launches need a workspace (egp_gemm_workspace_floats)");
     EGP_REQUIRE(!partial || (!d->bias && !d->relu && !d->mask), "no epilogue on split-K launches");
     EGP_REQUIRE(!ones || !d->b_kcontig, "the ones column (bias gradient) goes with B given as [k][n]");
-    // Column remainders. 128-column tiles waste (128 - N mod 128) columns of matrix-core AND conversion work in the last column
-    // tile: N = 300 pays for 384. When the remainder fits a 64-column tile (0 < N mod 128 <= 64, N > 128) the product is
-    // launched as [0, N - rem) on 128-column tiles + [N - rem, N) on 64-column tiles (a 64-column tile costs ~0.58 of a
-    // 128-column one: half the MFMAs, the same A conversion): 3 -> 2.58 tile units for N = 300. Plain epilogue launches only
-    // (a split-K workspace has one column layout; B gathered along k or split over two sources keeps one launch).
-    {
-        static const bool rem_on = [] { const char *e = getenv("EGP_GEMM_COLREM"); return !(e && atoi(e) == 0); }();
-        const int rem = d->N % 128;
-        if (rem_on && !partial && d->N > 128 && rem > 0 && rem <= 64 && rem % 4 == 0 && d->terms == 6 && !d->b_krows && !d->B2) {
-            egp_gemm_desc lo = *d, hi = *d;
-            const int n_lo = d->N - rem;
-            lo.N = n_lo;
-            hi.N = rem;
-            hi.B = d->b_kcontig ? d->B + (int64_t)n_lo * d->ldb : d->B + n_lo;
-            hi.C = d->C + n_lo;
-            if (d->bias) hi.bias = d->bias + n_lo;
-            if (d->mask) hi.mask = d->mask + n_lo;
-            const int rc_lo = egp_gemm_f32(&lo, stream);
-            if (rc_lo != EGP_OK) return rc_lo;
-            return egp_gemm_f32(&hi, stream);
-        }
-    }
+    // (Round 3, measured and not kept: launching the column remainder of N = 300 as a 64-column-tile product of its own
+    //  -- [0, 256) on 128-column tiles + [256, 300) on 64-column tiles, 2.58 instead of 3 tile units -- makes the update 1 ms
+    //  SLOWER in in-lease A/B runs (51.6 vs 50.6 ms): the narrow launch converts the whole A operand again for 44 columns.)
     hipStream_t s = (hipStream_t)stream;
     GemmArgs g;
     g.M = d->M; g.N = d->N; g.K = d->K;
