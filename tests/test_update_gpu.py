@@ -215,3 +215,47 @@ def test_reusing_the_first_forward_pass_changes_nothing(kctx, monkeypatch):
     np.testing.assert_allclose(s1[2], s0[2], rtol=1e-6, atol=1e-7)          # values (inference vs training LSTM kernels)
     for k in p1:
         np.testing.assert_allclose(p1[k].cpu().numpy(), p0[k].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("mode", ["float32", "float64-masters"])
+def test_fused_update_tail_equals_the_torch_formulation(kctx, mode, monkeypatch):
+    """Round 3's tail -- optim.ppo_losses (one launch for both losses and their gradients w.r.t. values / action mean) and
+    optim.FlatUpdater (clip + both Adam steps over flat buffers) -- against the same update with the losses as torch element-wise
+    ops under autograd and the caller's own `clip_grad_norm_` + `torch.optim.Adam.step()` (EGP_FUSED_LOSS=0, EGP_FUSED_OPTIM=0):
+    same per-epoch losses, same parameters to float32 round-off, and the reference's run is matched by both."""
+    from egopose_amd.optim import FlatUpdater
+    g = load_golden("ppo_update_h128_s40.npz")
+    masters64 = mode == "float64-masters"
+    outs = []
+    if masters64:
+        torch.set_default_dtype(torch.float64)
+    try:
+        for fused in ("1", "0"):
+            monkeypatch.setenv("EGP_FUSED_LOSS", fused)
+            monkeypatch.setenv("EGP_FUSED_OPTIM", fused)
+            agent, mods = build_agent(g, device="cuda", dtype=torch.float64 if masters64 else torch.float32, fused_adam=False)
+            _attach_tables(agent, g, torch.float32)
+            _spy_gae(agent, kctx)
+            agent.update_params(batch_of(g))
+            torch.cuda.synchronize()
+            assert isinstance(agent._get_updater(), FlatUpdater) == (fused == "1")
+            assert agent._fused_losses() == (fused == "1")
+            if fused == "1":
+                up = agent._get_updater()
+                assert up.steps == [3, 3] and float(agent.optimizer_policy.state[agent._policy_params()[0]]["step"]) == 3.0
+                if masters64:
+                    assert up.mdt == torch.float64 and up.cdt == torch.float32 and up.S is not None
+            check_final(mods, g, rtol=1e-4, atol=3e-6, max_outliers=8, outlier_atol=1.3e-2)
+            outs.append(({k: v.detach().double().cpu().numpy().copy() for m in mods.values() for k, v in m.state_dict().items()},
+                         dict(agent.update_stats)))
+    finally:
+        torch.set_default_dtype(torch.float32)
+    (p1, st1), (p0, st0) = outs
+    np.testing.assert_allclose(st1["value_loss"], st0["value_loss"], rtol=2e-5)
+    np.testing.assert_allclose(st1["surr_loss"], st0["surr_loss"], rtol=2e-4, atol=1e-7)
+    n_bad = 0
+    for k in p1:
+        bad = ~np.isclose(p1[k], p0[k], rtol=1e-4, atol=3e-6)
+        n_bad += int(bad.sum())
+        assert np.abs(p1[k] - p0[k]).max() <= 1.3e-2, k              # (an element with a ~0 gradient may take Adam's other step)
+    assert n_bad <= 8

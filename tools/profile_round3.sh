@@ -17,7 +17,7 @@ cp $P/bench_line_under_rocprof.json $OUT/r03_bench_n1_line_under_rocprof.json
 cp $P/pmc_bench_fetch_write.csv $OUT/r03_pmc_bench_n1_fetch_write.csv
 cp $P/pmc_k1_traffic.json $OUT/pmc_k1_traffic.json
 cp $P/update_mfma_util.csv $OUT/r03_update_mfma_util.csv
-python tools/classify_kernel_stats.py $OUT/r03_bench_n1_kernel_stats.csv 4 > $OUT/r03_bench_n1_kernel_classes.txt 2>&1
+python tools/classify_kernel_stats.py $OUT/r03_bench_n1_kernel_stats.csv 5 > $OUT/r03_bench_n1_kernel_classes.txt 2>&1
 python tools/microbench.py 1024 8192 65536 > $OUT/r03_microbench.jsonl 2> $OUT/microbench.err
 for n in 65536 1024; do
   bash tools/pmc_k1.sh $n > $OUT/r03_pmc_microbench_${n}_fetch_write.csv 2> $OUT/pmc_k1_$n.err
