@@ -242,7 +242,8 @@ def test_fused_update_tail_equals_the_torch_formulation(kctx, mode, monkeypatch)
             assert agent._fused_losses() == (fused == "1")
             if fused == "1":
                 up = agent._get_updater()
-                assert up.steps == [3, 3] and float(agent.optimizer_policy.state[agent._policy_params()[0]]["step"]) == 3.0
+                first = [q for q in agent._policy_params() if q.requires_grad][0]      # (parameters() leads with the fixed log-std)
+                assert up.steps == [3, 3] and float(agent.optimizer_policy.state[first]["step"]) == 3.0
                 if masters64:
                     assert up.mdt == torch.float64 and up.cdt == torch.float32 and up.S is not None
             check_final(mods, g, rtol=1e-4, atol=3e-6, max_outliers=8, outlier_atol=1.3e-2)
