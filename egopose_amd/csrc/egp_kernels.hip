@@ -1152,20 +1152,48 @@ __device__ __forceinline__ void gae_coeffs(const T *r, const T *mk, const T *v, 
     c = gt * mi;
 }
 
+// Staging. A thread owns a chunk of 32 CONSECUTIVE samples (the recurrence is sequential), so its own loads and stores would
+// touch 64 different 128-byte lines per wave instruction. The block's 8 192 samples therefore pass through LDS: coalesced
+// loads form (delta_i, c_i) straight away -- element e of the block at s[e + (e >> 5)], one pad word per chunk so that the
+// 64 lanes of a wave, 33 words apart, hit different banks -- and the replay's results leave the same way (round 3: K5 at
+// 1.6 M samples 142 -> see DESIGN section 4; same arithmetic in the same order, bit for bit).
+constexpr int GAE_BLOCK_ELEMS = 256 * GAE_CHUNK;
+constexpr int GAE_LDS_DOUBLES = 2 * (GAE_BLOCK_ELEMS + GAE_BLOCK_ELEMS / 32);
+__device__ __forceinline__ int gae_pad(int e) { return e + (e >> 5); }
+
+template <typename T>
+__device__ __forceinline__ void gae_stage(const T *__restrict__ r, const T *__restrict__ mk, const T *__restrict__ v, int n, double gamma,
+                                          double gt, double *s_d, double *s_c) {
+    const long base = (long)blockIdx.x * GAE_BLOCK_ELEMS;
+#pragma unroll 4
+    for (int j = 0; j < GAE_CHUNK; ++j) {
+        const int e = j * 256 + threadIdx.x;
+        const long i = base + e;
+        double d = 0.0, c = 1.0;                          // (past the end: the identity map)
+        if (i < n) gae_coeffs<T>(r, mk, v, (int)i, n, gamma, gt, d, c);
+        s_d[gae_pad(e)] = d;
+        s_c[gae_pad(e)] = c;
+    }
+    __syncthreads();
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_gae_summary(const T *__restrict__ r, const T *__restrict__ mk,
                                                      const T *__restrict__ v, int n, double gamma, double gt,
                                                      double *__restrict__ chunkP, double *__restrict__ chunkA,
                                                      double *__restrict__ blockP, double *__restrict__ blockA) {
+    extern __shared__ double s_gae[];
+    double *s_d = s_gae, *s_c = s_gae + GAE_LDS_DOUBLES / 2;
     __shared__ double sP[256], sA[256];
     const int t = threadIdx.x, ch = blockIdx.x * blockDim.x + t;
     const int i0 = ch * GAE_CHUNK;
+    gae_stage<T>(r, mk, v, n, gamma, gt, s_d, s_c);
     double P = 1.0, A = 0.0;                              // (a chunk past the end: the identity map)
     if (i0 < n) {
         const int i1 = min(n, i0 + GAE_CHUNK);
         for (int i = i1 - 1; i >= i0; --i) {
-            double d, c;
-            gae_coeffs<T>(r, mk, v, i, n, gamma, gt, d, c);
+            const int e = gae_pad(t * GAE_CHUNK + (i - i0));
+            const double d = s_d[e], c = s_c[e];
             A = d + c * A;      // value at i given zero carry
             P = c * P;          // sensitivity of a_i0 to the carry entering the chunk
         }
@@ -1234,9 +1262,12 @@ __global__ __launch_bounds__(256) void k_gae_replay(const T *__restrict__ r, con
                                                     const double *__restrict__ chunkP, const double *__restrict__ chunkA,
                                                     const double *__restrict__ block_carry, T *__restrict__ adv,
                                                     T *__restrict__ ret, double *__restrict__ part) {
+    extern __shared__ double s_gae[];
+    double *s_d = s_gae, *s_c = s_gae + GAE_LDS_DOUBLES / 2;
     __shared__ double s_n[256], s_mean[256], s_m2[256];
     const int t = threadIdx.x, ch = blockIdx.x * blockDim.x + t;
     const int i0 = ch * GAE_CHUNK;
+    gae_stage<T>(r, mk, v, n, gamma, gt, s_d, s_c);
     // carry entering this thread's chunk = (f_{t+1} o ... o f_255)(carry entering the block): suffix scan of the chunk maps
     // (s_n / s_mean double as the scan's P / A arrays; they are rewritten after the barrier below)
     {
@@ -1263,16 +1294,28 @@ __global__ __launch_bounds__(256) void k_gae_replay(const T *__restrict__ r, con
         const int i1 = min(n, i0 + GAE_CHUNK);
         double A = carry_in;
         for (int i = i1 - 1; i >= i0; --i) {
-            double d, c;
-            gae_coeffs<T>(r, mk, v, i, n, gamma, gt, d, c);
-            A = d + c * A;
+            const int e = gae_pad(t * GAE_CHUNK + (i - i0));
+            A = s_d[e] + s_c[e] * A;
+            s_d[e] = A;                                   // leaves through the coalesced pass below
             const T a_out = (T)A;
-            adv[i] = a_out;
-            ret[i] = (T)((double)v[i] + A);
             cnt += 1.0;                                   // Welford on the stored (rounded) advantage
             const double x = (double)a_out, dl = x - mean;
             mean += dl / cnt;
             m2 += dl * (x - mean);
+        }
+    }
+    __syncthreads();
+    {
+        const long base = (long)blockIdx.x * GAE_BLOCK_ELEMS;
+#pragma unroll 4
+        for (int j = 0; j < GAE_CHUNK; ++j) {
+            const int e = j * 256 + t;
+            const long i = base + e;
+            if (i < n) {
+                const double A = s_d[gae_pad(e)];
+                adv[i] = (T)A;
+                ret[i] = (T)((double)v[i] + A);
+            }
         }
     }
     s_n[threadIdx.x] = cnt; s_mean[threadIdx.x] = mean; s_m2[threadIdx.x] = m2;
@@ -1822,9 +1865,15 @@ static int launch_gae(const T *r, const T *mk, const T *v, int n, double gamma, 
     double *chunkP = (double *)ws, *chunkA = chunkP + n_chunks, *part = chunkA + n_chunks, *blockP = part + 3 * n_blocks,
            *blockA = blockP + n_blocks, *block_carry = blockA + n_blocks;
     hipStream_t s = (hipStream_t)stream;
-    k_gae_summary<T><<<dim3(n_blocks), dim3(256), 0, s>>>(r, mk, v, n, gamma, gamma * tau, chunkP, chunkA, blockP, blockA);
+    constexpr size_t lds = (size_t)GAE_LDS_DOUBLES * sizeof(double);          // the block's (delta, c) pairs, padded (132 KiB)
+    static const hipError_t attr = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gae_summary<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gae_replay<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }();
+    if (attr != hipSuccess) { set_error("hipFuncSetAttribute(k_gae_*, %zu B of LDS): %s", lds, hipGetErrorString(attr)); return EGP_E_HIP; }
+    k_gae_summary<T><<<dim3(n_blocks), dim3(256), lds, s>>>(r, mk, v, n, gamma, gamma * tau, chunkP, chunkA, blockP, blockA);
     k_gae_scan<<<dim3(1), dim3(1024), 0, s>>>(n_blocks, blockP, blockA, block_carry);
-    k_gae_replay<T><<<dim3(n_blocks), dim3(256), 0, s>>>(r, mk, v, n, gamma, gamma * tau, chunkP, chunkA, block_carry, adv, ret, part);
+    k_gae_replay<T><<<dim3(n_blocks), dim3(256), lds, s>>>(r, mk, v, n, gamma, gamma * tau, chunkP, chunkA, block_carry, adv, ret, part);
     k_gae_stats<<<dim3(1), dim3(256), 0, s>>>(n_blocks, part, stats);
     return after_launch("k_gae_*");
 }
