@@ -1283,6 +1283,58 @@ int egp_rollout_tick_post(const egp_rollout_tick *d, int32_t group, int32_t a, i
     return EGP_OK;
 }
 
+namespace {
+// video-context rows of freshly reset slots: block (j, y) copies its share of ctx_rows[j] into v_out[ids[j]]; the id list is
+// read in place from pinned memory
+__global__ __launch_bounds__(256) void k_ctx_rows_scatter(const int *__restrict__ ids, const float *__restrict__ src, long row_elems,
+                                                          float *__restrict__ v_out, long v_stride, int vec4) {
+    const int j = blockIdx.x;
+    const float *s = src + (long)j * row_elems;
+    float *o = v_out + (long)ids[j] * v_stride;
+    const long step = (long)gridDim.y * blockDim.x;
+    if (vec4) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(s);
+        float4 *o4 = reinterpret_cast<float4 *>(o);
+        for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < row_elems / 4; i += step) o4[i] = s4[i];
+    } else {
+        for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < row_elems; i += step) o[i] = s[i];
+    }
+}
+}  // namespace
+
+int egp_rollout_reset(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, const int32_t *ids, int32_t n,
+                      const int64_t *e_ind, const int64_t *s_ind, const int64_t *frame_rows, const double *qpos, const double *qvel,
+                      const float *ctx_rows, const double *zf_cur, double *zf_new) {
+    EGP_REQUIRE(d && d->ctx && d->eng && d->reset_scratch && ids && e_ind && s_ind && frame_rows && qpos && qvel && ctx_rows, "NULL pointer");
+    EGP_REQUIRE(0 <= a && a < b && b <= d->n_env && b - a <= d->nmax && k >= 0 && n > 0 && n <= b - a, "slot range / tick out of range");
+    for (int j = 0; j < n; ++j) EGP_REQUIRE(ids[j] >= a && ids[j] < b, "reset slot outside its group");
+    hipStream_t s = (hipStream_t)d->stream;
+    int rc = egp_engine_reset(d->eng, ids, n, qpos, qvel, d->stream);       // also checks that the ids increase strictly
+    if (rc != EGP_OK) return rc;
+    const int nmax = d->nmax, ng = b - a;
+    // slot k & 1: its previous readers (tick k - 2 of this group) finished before that tick's env-step started
+    int32_t *list = d->reset_scratch + (size_t)(group * 2 + (k & 1)) * 2 * nmax, *mask = list + nmax;
+    memset(mask, 0, sizeof(int32_t) * ng);
+    for (int j = 0; j < n; ++j) {
+        const int e = ids[j];
+        list[j] = e;
+        mask[e - a] = 1;
+        d->e_ind[e] = e_ind[j];
+        d->s_ind[e] = s_ind[j];
+        d->frame_base[e] = frame_rows[j];
+        d->cur_t[e] = 0;
+    }
+    const long row_elems = (long)d->ctx_T * d->ctx_dim;
+    const int vec4 = (row_elems % 4 == 0 && d->v_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(ctx_rows) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(d->v_out) & 15) == 0) ? 1 : 0;
+    const int per_row = (int)std::min<long>(64, std::max<long>(1, row_elems / (vec4 ? 4096 : 1024)));
+    k_ctx_rows_scatter<<<dim3(n, per_row), dim3(256), 0, s>>>(list, ctx_rows, row_elems, const_cast<float *>(d->v_out), d->v_stride, vec4);
+    EGP_HIP_CHECK(hipGetLastError());
+    // fresh episodes: their first observation goes through the filter and replaces the policy input of tick k + 1
+    return egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, mask, ng, zf_cur, zf_new, d->zf_clip,
+                               d->states + ((size_t)(k + 1) * d->n_env + a) * d->obs_dim, nullptr, 1, d->zf_workspace, d->stream);
+}
+
 double egp_engine_event_overhead_ms(egp_engine *E) {
     double a = 0.0;
     if (E && !E->groups.empty()) { for (auto &G : E->groups) a += G.ev_overhead_ms; a /= E->groups.size(); }

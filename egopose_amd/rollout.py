@@ -128,6 +128,7 @@ class LockstepRollout:
         self.reward_kind = "quat_v3"        # which entry of the reward registry the rollout evaluates (Agent sets it)
         self.pool_batch = max(256, self.N // 2)
         self._pool, self._pool_pos = None, 0
+        self._reset_scratch = None
 
     # ------------------------------------------------------------------ helpers
     def _net_dtype(self):
@@ -179,6 +180,31 @@ class LockstepRollout:
         if self._s_hc is not None:               # fresh episodes start the state LSTM from zero
             self._s_hc[0][ids_d] = 0
             self._s_hc[1][ids_d] = 0
+
+    def _reset_slots_native(self, tickd_ref, g, a, b, k, ids, zf_p):
+        """_reset_slots + the masked first-observation filter of slots `ids` (inside group g = [a, b)) in one library call."""
+        cfg, ex = self.cfg, self.experts
+        e_ind, s_ind, ctx_rows = self._draw_episodes(len(ids))
+        rows = ex.take_offset[e_ind] + s_ind
+        qpos = ex.qpos[rows]                         # fancy indexing copies
+        qvel = ex.qvel[rows]
+        if cfg.env_init_noise > 0:
+            qpos[:, 7:] += self.env.np_random.normal(0.0, cfg.env_init_noise, size=(len(ids), qpos.shape[1] - 7))
+        if ctx_rows.dtype != torch.float32 or not ctx_rows.is_contiguous():
+            ctx_rows = ctx_rows.to(torch.float32).contiguous()
+        ids32 = np.ascontiguousarray(ids, dtype=np.int32)
+        e64, s64, r64 = (np.ascontiguousarray(x, dtype=np.int64) for x in (e_ind, s_ind, rows))
+        if zf_p is not None:                         # same ping-pong as _obs_filter
+            new_t, new, cur = self._zf_bufs[self._zf_flip], zf_p[self._zf_flip], self.zf_state.data_ptr()
+            self._zf_flip ^= 1
+        else:
+            new_t, new, cur = None, None, None
+        rc = self.engine.lib.egp_rollout_reset(tickd_ref, g, a, b, k, ids32.ctypes.data, len(ids32), e64.ctypes.data, s64.ctypes.data,
+                                               r64.ctypes.data, qpos.ctypes.data, qvel.ctypes.data, ctx_rows.data_ptr(), cur, new)
+        if rc != 0:
+            _lib.check(rc, "egp_rollout_reset")
+        if new_t is not None:
+            self.zf_state = new_t
 
     def _obs_filter(self, a, b, out, out2=None, active=None, write_only_active=False):
         """K3+K6 fused for slots [a,b): filtered observation of the engine state -> out (and out2)."""
@@ -512,6 +538,9 @@ class LockstepRollout:
             td.slab_host, td.slab_dev = slab_hp, slab_dp
             td.qpos, td.qvel, td.prev_qpos, td.ee = qpos_p, qvel_p, prev_p, ee_p
             td.zf_workspace = ws_p
+            if self._reset_scratch is None or self._reset_scratch.numel() != len(self.groups) * 4 * nmax:
+                self._reset_scratch = torch.zeros(len(self.groups) * 4 * nmax, dtype=torch.int32).pin_memory()
+            td.reset_scratch = self._reset_scratch.data_ptr()
             ok = (all(x.dtype == np.int64 and x.flags.c_contiguous for x in (self.cur_t, self.frame_base, self.e_ind, self.s_ind, steps_done))
                   and active.dtype == np.bool_ and eng.head_z.dtype == np.float64 and host["valid"].dtype == np.bool_ and host["done"].dtype == np.bool_
                   and host["e_ind"].dtype == np.int64 and host["s_ind"].dtype == np.int64 and rec["cinfo"].shape[2] == 5)
@@ -520,6 +549,11 @@ class LockstepRollout:
                     for e_ in pair:
                         e_.record()
                 tickd = (td, ctypes.byref(td), keep, ctypes.c_int32(0), ctypes.c_double(0.0))
+
+        # in-tick resets through one native call (egp_rollout_reset) instead of _reset_slots + a masked _obs_filter: the same
+        # launches minus the id / mask uploads and the index_put (EGP_RESET_NATIVE=0: the torch form)
+        native_reset = (tickd is not None and self._s_hc is None and self.v_out.dtype == torch.float32 and self.v_out.is_contiguous()
+                        and os.environ.get("EGP_RESET_NATIVE", "1") != "0")
 
         def pre_native(g):
             a, b = self.groups[g]
@@ -554,7 +588,9 @@ class LockstepRollout:
                 finished = slot_finished(ids)
                 active[ids[finished]] = False
                 again = ids[~finished]
-                if len(again):
+                if len(again) and native_reset:
+                    self._reset_slots_native(tickd[1], g, a, b, k, again, zf_p)
+                elif len(again):
                     self._reset_slots(again)
                     mask = np.zeros(b - a, np.int32)
                     mask[again - a] = 1

@@ -588,10 +588,20 @@ typedef struct egp_rollout_tick {
     uint8_t *slab_host, *slab_dev;               /* [n_groups][2][24 * nmax] flags + context-row slabs (pinned / device) */
     const double *qpos, *qvel, *prev_qpos, *ee;  /* the engine's device state */
     void *zf_workspace;
+    int32_t *reset_scratch;                      /* [n_groups][2][2 * nmax] pinned, device-visible: ids | group mask of egp_rollout_reset */
 } egp_rollout_tick;
 int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, void *ready_event);
 int egp_rollout_tick_post(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, const double *zf_cur, double *zf_new,
                           int32_t *n_done, double *wait_s);
+/* HumanoidEnv.reset_model + the first observation of the new episodes (ego_pose/envs/humanoid_v1.py:201-226, core/agent.py:35-38)
+ * for the slots `ids` (n of them, strictly increasing, all inside [a, b)) whose episode ended in tick k, called right behind
+ * egp_rollout_tick_post: physics reset to (qpos, qvel) rows [n][nq] / [n][nv] (host), slot bookkeeping (take, start frame, expert
+ * row of frame 0, cur_t = 0), the slots' video-context rows `ctx_rows` (device, [n][ctx_T][ctx_dim] float32) into v_out, and K3 + K6
+ * over the group with only those slots active: their filtered observation replaces states[k + 1] (the running filter advances
+ * zf_cur -> zf_new exactly as one more egp_obs_zfilter_f64 call). Uses reset_scratch slot k & 1 of the group. */
+int egp_rollout_reset(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, const int32_t *ids, int32_t n,
+                      const int64_t *e_ind, const int64_t *s_ind, const int64_t *frame_rows, const double *qpos, const double *qvel,
+                      const float *ctx_rows, const double *zf_cur, double *zf_new);
 
 /* Resident-K1 mode only: hand the NEXT egp_engine_step_async of `group` its reward launch. The flag arrays (device
  * memory, group-local: t / frame / end / active of the state the step will produce) must be ready by the step's
