@@ -117,7 +117,8 @@ class RolloutTick(C.Structure):
                 ("layers", vp), ("n_layers", C.c_int32), ("activation", C.c_int32), ("log_std", vp),
                 ("slab_host", vp), ("slab_dev", vp),
                 ("qpos", vp), ("qvel", vp), ("prev_qpos", vp), ("ee", vp),
-                ("zf_workspace", vp), ("reset_scratch", vp)]
+                ("zf_workspace", vp), ("reset_scratch", vp),
+                ("group_streams", C.c_int32), ("post_fused", C.c_int32)]
 
 
 class EngineDesc(C.Structure):
@@ -188,7 +189,8 @@ SIGNATURES = {
     "egp_lstm_group_bwd_f32": (C.c_int, [C.POINTER(C.c_void_p), _i32, vp, vp, vp, _i32, _i32, _i32, _i32, _i32, vp, vp, vp]),
     "egp_rollout_tick_pre": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp]),
     "egp_rollout_tick_post": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp]),
-    "egp_rollout_reset": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, _i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "egp_rollout_reset": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, _i32, vp, vp, vp, vp, vp, vp, _i32, vp, vp]),
+    "egp_engine_group_stream": (vp, [vp, _i32]),
     "egp_lstm_group_fwd_len_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_void_p), _i32, vp, vp, vp, vp, _i32, vp]),
     "egp_lstm_group_bwd_len_f32": (C.c_int, [C.POINTER(C.c_void_p), _i32, vp, vp, vp, _i32, _i32, _i32, _i32, _i32, vp, vp, vp, vp, _i32, vp]),
     "egp_upload_async": (C.c_int, [vp, vp, C.c_int64, vp]),

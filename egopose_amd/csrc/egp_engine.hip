@@ -152,6 +152,8 @@ struct Group {
     int n_threads = 1;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;                // recorded after the last upload of an env-step
+    hipEvent_t chain_done = nullptr;          // group-stream ticks: recorded behind the group's last filter launch (the running
+    bool chain_recorded = false;              //  statistics pass from group to group in host order)
     hipEvent_t reward_done = nullptr;         // recorded behind the reward job's kernel (it reads d_qpos / d_prev_qpos / d_ee rows
     bool reward_in_flight = false;            //  that a reset on the caller's stream overwrites): egp_engine_reset waits for it
     std::vector<hipEvent_t> k_beg, k_end;     // per substep, when profiling K1
@@ -231,6 +233,7 @@ struct egp_engine {
     int *h_reset_list = nullptr, *hd_reset_list = nullptr;   // pinned (env, qM_changed) pairs of the reset in flight
     hipEvent_t reset_done = nullptr;                          // recorded behind the scatter kernel of the last reset
     bool reset_pending = false;
+    hipEvent_t setup_ev = nullptr;                            // group-stream ticks: the caller's stream -> a group's stream
 };
 
 namespace {
@@ -886,6 +889,7 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
         E_TRY(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
         E_TRY(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
         E_TRY(hipEventCreateWithFlags(&G.reward_done, hipEventDisableTiming));
+        E_TRY(hipEventCreateWithFlags(&G.chain_done, hipEventDisableTiming));
         E_TRY(hipMalloc((void **)&G.d_done, sizeof(unsigned)));
         E_TRY(hipMemset(G.d_done, 0, sizeof(unsigned)));
         E_TRY(hipHostMalloc((void **)&G.h_flag, sizeof(unsigned long long), hipHostMallocDefault));
@@ -1033,12 +1037,14 @@ int egp_engine_destroy(egp_engine *E) {
         if (G.stream) (void)hipStreamDestroy(G.stream);
         if (G.done) (void)hipEventDestroy(G.done);
         if (G.reward_done) (void)hipEventDestroy(G.reward_done);
+        if (G.chain_done) (void)hipEventDestroy(G.chain_done);
         for (auto ev : G.k_beg) (void)hipEventDestroy(ev);
         for (auto ev : G.k_end) (void)hipEventDestroy(ev);
     }
     void *dev[] = {E->d_state, E->d_qM, E->d_prev_qpos, E->d_qpos, E->d_qvel, E->d_torque, E->d_ee, E->d_bias};
     for (void *p : dev) if (p) (void)hipFree(p);
     if (E->reset_done) (void)hipEventDestroy(E->reset_done);
+    if (E->setup_ev) (void)hipEventDestroy(E->setup_ev);
     void *host[] = {E->h_state, E->h_qM, E->h_qpos, E->h_qvel, E->h_torque, E->h_ee, E->h_headz, E->h_xpos, E->h_reset_list};
     for (void *p : host) if (p) (void)hipHostFree(p);
     delete E;
@@ -1191,14 +1197,43 @@ int egp_engine_wait(egp_engine *E, int32_t group, void *stream) {
         egp::set_error("rollout group %d: %s", group, G.err);
         return G.status.load();
     }
-    EGP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, G.done, 0));
+    // (a caller that works on the group's own stream is already ordered behind the env-step's kernel)
+    if ((hipStream_t)stream != G.stream) EGP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, G.done, 0));
     return EGP_OK;
 }
 
+void *egp_engine_group_stream(egp_engine *E, int32_t group) {
+    if (!E || group < 0 || group >= E->n_groups) return nullptr;
+    return E->groups[group].stream;
+}
+
+namespace {
+// The stream a group's tick runs on. group_streams: the group's own engine stream, so that policy -> env-step kernel ->
+// filter -> policy is one in-order queue (a dependency between two streams costs ~20 us on this platform, one inside a
+// stream ~3 us: tools/probes/stream_hop.py); else the caller's stream with an event either side of the env-step.
+inline hipStream_t tick_stream(const egp_rollout_tick *d, int group) {
+    return d->group_streams ? d->eng->groups[group].stream : (hipStream_t)d->stream;
+}
+// order a group's stream behind what the caller's stream holds now (rollout set-up, a freshly computed episode pool)
+inline hipError_t follow_caller_stream(const egp_rollout_tick *d, hipStream_t s) {
+    egp_engine *E = d->eng;
+    if (!E->setup_ev) { hipError_t e = hipEventCreateWithFlags(&E->setup_ev, hipEventDisableTiming); if (e != hipSuccess) return e; }
+    hipError_t e = hipEventRecord(E->setup_ev, (hipStream_t)d->stream);
+    return e != hipSuccess ? e : hipStreamWaitEvent(s, E->setup_ev, 0);
+}
+}  // namespace
+
 int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, void *ready_event) {
-    EGP_REQUIRE(d && d->ctx && d->eng && ready_event, "NULL pointer");
+    EGP_REQUIRE(d && d->ctx && d->eng && (ready_event || d->group_streams), "NULL pointer");
+    EGP_REQUIRE(group >= 0 && group < d->eng->n_groups, "group out of range");
     EGP_REQUIRE(0 <= a && a < b && b <= d->n_env && b - a <= d->nmax && k >= 0, "slot range / tick out of range");
+    EGP_REQUIRE(!d->group_streams || !d->reward_job, "group-stream ticks compute the reward in the filter's launch (post_fused)");
     const int n = b - a, nmax = d->nmax, N = d->n_env;
+    hipStream_t ts = tick_stream(d, group);
+    if (d->group_streams && k == 0) {              // a rollout begins: the slots' first state / observation were set up on the caller's stream
+        EGP_HIP_CHECK(follow_caller_stream(d, ts));
+        d->eng->groups[group].chain_recorded = false;
+    }
     const size_t soff = (size_t)(group * 2 + (k & 1)) * 24 * nmax;
     int32_t *fl = reinterpret_cast<int32_t *>(d->slab_host + soff);
     int64_t *ti = reinterpret_cast<int64_t *>(d->slab_host + soff + 16 * (size_t)nmax);
@@ -1223,15 +1258,16 @@ int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, in
                                             reinterpret_cast<const int64_t *>(d->slab_host + soff + 16 * (size_t)nmax),
                                             d->states + row * d->obs_dim, d->obs_dim, n, d->layers, d->n_layers, d->activation, d->log_std,
                                             d->noise ? d->noise + row * d->nu : nullptr, d->actions + row * d->nu, nullptr,
-                                            d->slab_host + soff, fbase, 24 * (int64_t)nmax, d->stream);
+                                            d->slab_host + soff, fbase, 24 * (int64_t)nmax, ts);
     } else {
-        if (d->flags_upload && (rc = egp_upload_async(fbase, d->slab_host + soff, 24 * (int64_t)nmax, d->stream)) != EGP_OK) return rc;
+        if (d->flags_upload && (rc = egp_upload_async(fbase, d->slab_host + soff, 24 * (int64_t)nmax, ts)) != EGP_OK) return rc;
         rc = egp_policy_gaussian_f32(d->v_out + (size_t)a * d->v_stride, d->v_stride, d->ctx_dim, reinterpret_cast<const int64_t *>(fbase + 16 * (size_t)nmax),
                                      d->states + row * d->obs_dim, d->obs_dim, n, d->layers, d->n_layers, d->activation, d->log_std,
-                                     d->noise ? d->noise + row * d->nu : nullptr, d->actions + row * d->nu, nullptr, d->stream);
+                                     d->noise ? d->noise + row * d->nu : nullptr, d->actions + row * d->nu, nullptr, ts);
     }
     if (rc != EGP_OK) return rc;
-    EGP_HIP_CHECK(hipEventRecord((hipEvent_t)ready_event, (hipStream_t)d->stream));
+    if (d->group_streams) ready_event = nullptr;       // the env-step's kernel queues right behind the policy step
+    else EGP_HIP_CHECK(hipEventRecord((hipEvent_t)ready_event, ts));
     if (d->reward_job) {      // K2 rides behind this env-step's kernel on the engine's stream
         const int32_t *f32 = reinterpret_cast<const int32_t *>(fbase);
         rc = egp_engine_set_reward_job(d->eng, group, f32, f32 + nmax, f32 + 2 * nmax, f32 + 3 * nmax, d->end_reward, d->rewards + row,
@@ -1246,22 +1282,39 @@ int egp_rollout_tick_post(const egp_rollout_tick *d, int32_t group, int32_t a, i
                           int32_t *n_done, double *wait_s) {
     EGP_REQUIRE(d && d->ctx && d->eng && n_done, "NULL pointer");
     EGP_REQUIRE(0 <= a && a < b && b <= d->n_env && b - a <= d->nmax && k >= 0, "slot range / tick out of range");
+    EGP_REQUIRE(group >= 0 && group < d->eng->n_groups, "group out of range");
     const auto t0 = clk::now();
-    int rc = egp_engine_wait(d->eng, group, d->stream);
+    hipStream_t ts = tick_stream(d, group);
+    int rc = egp_engine_wait(d->eng, group, ts);
     if (wait_s) *wait_s = secs(t0, clk::now());
     if (rc != EGP_OK) return rc;
+    if (d->group_streams)          // the running filter statistics: behind the filter launches the other groups issued before this call
+        for (int g2 = 0; g2 < d->eng->n_groups; ++g2)
+            if (g2 != group && d->eng->groups[g2].chain_recorded) EGP_HIP_CHECK(hipStreamWaitEvent(ts, d->eng->groups[g2].chain_done, 0));
     const int n = b - a, nmax = d->nmax, N = d->n_env;
     const size_t soff = (size_t)(group * 2 + (k & 1)) * 24 * nmax;
     const int32_t *f32 = reinterpret_cast<const int32_t *>(d->slab_dev + soff);          // the flags `pre` staged for this env-step
     const size_t row = (size_t)k * N + a;
     // the filter -> policy chain of the next tick starts here: K3 + K6 (-> next_states[k] and states[k + 1]) and K2 before the bookkeeping
-    rc = egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, f32 + 3 * nmax, n, zf_cur, zf_new, d->zf_clip,
-                             d->next_states + row * d->obs_dim, d->states + (row + N) * d->obs_dim, 0, d->zf_workspace, d->stream);
-    if (rc != EGP_OK) return rc;
-    if (!d->reward_job) {
-        rc = egp_reward_quat_v3_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->prev_qpos + (size_t)a * d->nq, d->ee + (size_t)a * 15, f32, f32 + nmax,
-                                    f32 + 2 * nmax, f32 + 3 * nmax, d->end_reward, n, d->rewards + row, d->cinfo + row * 5, d->stream);
+    if (d->post_fused && !d->reward_job) {      // K2's workgroups ride in the filter's first launch
+        rc = egp_post_step_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, d->prev_qpos + (size_t)a * d->nq,
+                               d->ee + (size_t)a * 15, f32, f32 + nmax, f32 + 2 * nmax, f32 + 3 * nmax, n, zf_cur, zf_new, d->zf_clip,
+                               d->next_states + row * d->obs_dim, d->states + (row + N) * d->obs_dim, d->zf_workspace, d->end_reward,
+                               d->rewards + row, d->cinfo + row * 5, ts);
         if (rc != EGP_OK) return rc;
+    } else {
+        rc = egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, f32 + 3 * nmax, n, zf_cur, zf_new, d->zf_clip,
+                                 d->next_states + row * d->obs_dim, d->states + (row + N) * d->obs_dim, 0, d->zf_workspace, ts);
+        if (rc != EGP_OK) return rc;
+        if (!d->reward_job) {
+            rc = egp_reward_quat_v3_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->prev_qpos + (size_t)a * d->nq, d->ee + (size_t)a * 15, f32, f32 + nmax,
+                                        f32 + 2 * nmax, f32 + 3 * nmax, d->end_reward, n, d->rewards + row, d->cinfo + row * 5, ts);
+            if (rc != EGP_OK) return rc;
+        }
+    }
+    if (d->group_streams) {
+        EGP_HIP_CHECK(hipEventRecord(d->eng->groups[group].chain_done, ts));
+        d->eng->groups[group].chain_recorded = true;
     }
     int nd = 0;
     for (int i = 0; i < n; ++i) {
@@ -1304,12 +1357,14 @@ __global__ __launch_bounds__(256) void k_ctx_rows_scatter(const int *__restrict_
 
 int egp_rollout_reset(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, const int32_t *ids, int32_t n,
                       const int64_t *e_ind, const int64_t *s_ind, const int64_t *frame_rows, const double *qpos, const double *qvel,
-                      const float *ctx_rows, const double *zf_cur, double *zf_new) {
+                      const float *ctx_rows, int32_t ctx_rows_fresh, const double *zf_cur, double *zf_new) {
     EGP_REQUIRE(d && d->ctx && d->eng && d->reset_scratch && ids && e_ind && s_ind && frame_rows && qpos && qvel && ctx_rows, "NULL pointer");
     EGP_REQUIRE(0 <= a && a < b && b <= d->n_env && b - a <= d->nmax && k >= 0 && n > 0 && n <= b - a, "slot range / tick out of range");
     for (int j = 0; j < n; ++j) EGP_REQUIRE(ids[j] >= a && ids[j] < b, "reset slot outside its group");
-    hipStream_t s = (hipStream_t)d->stream;
-    int rc = egp_engine_reset(d->eng, ids, n, qpos, qvel, d->stream);       // also checks that the ids increase strictly
+    EGP_REQUIRE(group >= 0 && group < d->eng->n_groups, "group out of range");
+    hipStream_t s = tick_stream(d, group);
+    if (d->group_streams && ctx_rows_fresh) EGP_HIP_CHECK(follow_caller_stream(d, s));     // ctx_rows were computed on the caller's stream
+    int rc = egp_engine_reset(d->eng, ids, n, qpos, qvel, s);               // also checks that the ids increase strictly
     if (rc != EGP_OK) return rc;
     const int nmax = d->nmax, ng = b - a;
     // slot k & 1: its previous readers (tick k - 2 of this group) finished before that tick's env-step started
@@ -1331,8 +1386,10 @@ int egp_rollout_reset(const egp_rollout_tick *d, int32_t group, int32_t a, int32
     k_ctx_rows_scatter<<<dim3(n, per_row), dim3(256), 0, s>>>(list, ctx_rows, row_elems, const_cast<float *>(d->v_out), d->v_stride, vec4);
     EGP_HIP_CHECK(hipGetLastError());
     // fresh episodes: their first observation goes through the filter and replaces the policy input of tick k + 1
-    return egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, mask, ng, zf_cur, zf_new, d->zf_clip,
-                               d->states + ((size_t)(k + 1) * d->n_env + a) * d->obs_dim, nullptr, 1, d->zf_workspace, d->stream);
+    rc = egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, mask, ng, zf_cur, zf_new, d->zf_clip,
+                             d->states + ((size_t)(k + 1) * d->n_env + a) * d->obs_dim, nullptr, 1, d->zf_workspace, s);
+    if (rc == EGP_OK && d->group_streams) EGP_HIP_CHECK(hipEventRecord(d->eng->groups[group].chain_done, s));
+    return rc;
 }
 
 double egp_engine_event_overhead_ms(egp_engine *E) {

@@ -129,6 +129,7 @@ class LockstepRollout:
         self.pool_batch = max(256, self.N // 2)
         self._pool, self._pool_pos = None, 0
         self._reset_scratch = None
+        self._pool_prev, self._pool_fresh, self._ctx_keep = None, True, None
 
     # ------------------------------------------------------------------ helpers
     def _net_dtype(self):
@@ -151,7 +152,9 @@ class LockstepRollout:
                 else:
                     win = self.policy_vs_net.window_features(e_d, s_d, self.T_ep)
                     ctx = self.policy_vs_net.forward_v_net(win)[self.margin:-self.margin].transpose(0, 1).contiguous()   # (m, T, H)
+                self._pool_prev = self._pool             # (a kernel on a group stream may still be reading rows of the old pool)
                 self._pool, self._pool_pos = (e_ind, s_ind, ctx), 0
+                self._pool_fresh = True
             e_ind, s_ind, ctx = self._pool
             k = min(need, len(e_ind) - self._pool_pos)
             sl = slice(self._pool_pos, self._pool_pos + k)
@@ -199,8 +202,12 @@ class LockstepRollout:
             self._zf_flip ^= 1
         else:
             new_t, new, cur = None, None, None
+        # (group-stream ticks read ctx_rows from another stream than the one torch made them on: the library orders itself behind
+        # a fresh pool, and the rows stay referenced until the next two resets have been issued)
+        self._ctx_keep = (ctx_rows, self._ctx_keep[0] if self._ctx_keep else None)
         rc = self.engine.lib.egp_rollout_reset(tickd_ref, g, a, b, k, ids32.ctypes.data, len(ids32), e64.ctypes.data, s64.ctypes.data,
-                                               r64.ctypes.data, qpos.ctypes.data, qvel.ctypes.data, ctx_rows.data_ptr(), cur, new)
+                                               r64.ctypes.data, qpos.ctypes.data, qvel.ctypes.data, ctx_rows.data_ptr(),
+                                               1 if self._pool_fresh else 0, cur, new)
         if rc != 0:
             _lib.check(rc, "egp_rollout_reset")
         if new_t is not None:
@@ -519,6 +526,15 @@ class LockstepRollout:
             # EGP_TICK_FLAGS: 'kernel' (default: the policy kernel stages the tick's flag slab itself), 'upload' (a copy-engine
             # transfer in front of it, round 2's form), 'zerocopy' (every kernel reads the pinned slab over PCIe)
             stage_mode = os.environ.get("EGP_TICK_FLAGS", "kernel")
+            # EGP_TICK_STREAMS: 'shared' (default) = the ticks of all groups on the caller's stream, an event either side of every
+            # env-step; 'group' = each group's tick on its engine stream, one in-order queue policy -> env-step kernel -> filter
+            # (+ reward) -> policy. Measured (round 3, tools/probes/chain_gaps.py): the policy -> K1 gap goes 12.8 -> 0 us, but
+            # the reward has to ride in the filter's first launch (15.5 -> 31.6 us) and K1's end -> filter stays 22 us, so
+            # T_sample does not move; the fused filter also merges its statistics in another order (1-ulp differences)
+            group_streams = (eng.substeps_per_launch > 1 and os.environ.get("EGP_TICK_STREAMS", "shared") == "group")
+            if group_streams:
+                reward_job = False
+            td.group_streams, td.post_fused = int(group_streams), int(group_streams or post_fused)
             td.reward_job, td.flags_upload = int(bool(reward_job)), (0 if not flags_upload else (2 if stage_mode == "kernel" else 1))
             td.has_fix_head_lb = int(self.env.fix_head_lb is not None)
             td.fix_head_lb = float(self.env.fix_head_lb) if self.env.fix_head_lb is not None else 0.0
@@ -590,6 +606,7 @@ class LockstepRollout:
                 again = ids[~finished]
                 if len(again) and native_reset:
                     self._reset_slots_native(tickd[1], g, a, b, k, again, zf_p)
+                    self._pool_fresh = False
                 elif len(again):
                     self._reset_slots(again)
                     mask = np.zeros(b - a, np.int32)

@@ -589,6 +589,9 @@ typedef struct egp_rollout_tick {
     const double *qpos, *qvel, *prev_qpos, *ee;  /* the engine's device state */
     void *zf_workspace;
     int32_t *reset_scratch;                      /* [n_groups][2][2 * nmax] pinned, device-visible: ids | group mask of egp_rollout_reset */
+    int32_t group_streams;                       /* 1: a group's tick is enqueued on its engine stream (egp_engine_group_stream), `stream` only
+                                                  * carries the rollout's set-up; needs reward_job == 0 */
+    int32_t post_fused;                          /* 1 (and reward_job == 0): K3 + K6 + K2 through egp_post_step_f64 */
 } egp_rollout_tick;
 int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, void *ready_event);
 int egp_rollout_tick_post(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, const double *zf_cur, double *zf_new,
@@ -598,10 +601,13 @@ int egp_rollout_tick_post(const egp_rollout_tick *d, int32_t group, int32_t a, i
  * egp_rollout_tick_post: physics reset to (qpos, qvel) rows [n][nq] / [n][nv] (host), slot bookkeeping (take, start frame, expert
  * row of frame 0, cur_t = 0), the slots' video-context rows `ctx_rows` (device, [n][ctx_T][ctx_dim] float32) into v_out, and K3 + K6
  * over the group with only those slots active: their filtered observation replaces states[k + 1] (the running filter advances
- * zf_cur -> zf_new exactly as one more egp_obs_zfilter_f64 call). Uses reset_scratch slot k & 1 of the group. */
+ * zf_cur -> zf_new exactly as one more egp_obs_zfilter_f64 call). Uses reset_scratch slot k & 1 of the group.
+ * ctx_rows_fresh != 0: ctx_rows were produced on `stream` since the last call (group-stream ticks order themselves behind it). */
 int egp_rollout_reset(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, const int32_t *ids, int32_t n,
                       const int64_t *e_ind, const int64_t *s_ind, const int64_t *frame_rows, const double *qpos, const double *qvel,
-                      const float *ctx_rows, const double *zf_cur, double *zf_new);
+                      const float *ctx_rows, int32_t ctx_rows_fresh, const double *zf_cur, double *zf_new);
+/* the stream group g's env-step kernels are launched on (owned by the engine) */
+void *egp_engine_group_stream(egp_engine *e, int32_t group);
 
 /* Resident-K1 mode only: hand the NEXT egp_engine_step_async of `group` its reward launch. The flag arrays (device
  * memory, group-local: t / frame / end / active of the state the step will produce) must be ready by the step's
