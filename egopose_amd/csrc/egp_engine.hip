@@ -1227,7 +1227,7 @@ int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, in
     EGP_REQUIRE(d && d->ctx && d->eng && (ready_event || d->group_streams), "NULL pointer");
     EGP_REQUIRE(group >= 0 && group < d->eng->n_groups, "group out of range");
     EGP_REQUIRE(0 <= a && a < b && b <= d->n_env && b - a <= d->nmax && k >= 0, "slot range / tick out of range");
-    EGP_REQUIRE(!d->group_streams || !d->reward_job, "group-stream ticks compute the reward in the filter's launch (post_fused)");
+    EGP_REQUIRE(!d->group_streams || !d->reward_job, "group-stream ticks launch the reward themselves (reward_job = 0)");
     const int n = b - a, nmax = d->nmax, N = d->n_env;
     hipStream_t ts = tick_stream(d, group);
     if (d->group_streams && k == 0) {              // a rollout begins: the slots' first state / observation were set up on the caller's stream
@@ -1266,8 +1266,14 @@ int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, in
                                      d->noise ? d->noise + row * d->nu : nullptr, d->actions + row * d->nu, nullptr, ts);
     }
     if (rc != EGP_OK) return rc;
-    if (d->group_streams) ready_event = nullptr;       // the env-step's kernel queues right behind the policy step
-    else EGP_HIP_CHECK(hipEventRecord((hipEvent_t)ready_event, ts));
+    if (d->group_streams) {
+        // the env-step's kernel queues right behind the policy step; the one thing it must not overtake is the reward of the
+        // previous env-step (on the caller's stream, reading the rows this kernel's epilogue rewrites): long finished by then
+        Group &G = d->eng->groups[group];
+        ready_event = (k > 0 && G.reward_in_flight) ? (void *)G.reward_done : nullptr;
+    } else {
+        EGP_HIP_CHECK(hipEventRecord((hipEvent_t)ready_event, ts));
+    }
     if (d->reward_job) {      // K2 rides behind this env-step's kernel on the engine's stream
         const int32_t *f32 = reinterpret_cast<const int32_t *>(fbase);
         rc = egp_engine_set_reward_job(d->eng, group, f32, f32 + nmax, f32 + 2 * nmax, f32 + 3 * nmax, d->end_reward, d->rewards + row,
@@ -1307,9 +1313,18 @@ int egp_rollout_tick_post(const egp_rollout_tick *d, int32_t group, int32_t a, i
                                  d->next_states + row * d->obs_dim, d->states + (row + N) * d->obs_dim, 0, d->zf_workspace, ts);
         if (rc != EGP_OK) return rc;
         if (!d->reward_job) {
+            // group-stream ticks: K2 leaves the group's queue (nothing of the next tick depends on it) for the caller's
+            // stream, behind this env-step's kernel; egp_engine_reset and the next env-step order themselves behind reward_done
+            hipStream_t rs = d->group_streams ? (hipStream_t)d->stream : ts;
+            Group &G = d->eng->groups[group];
+            if (d->group_streams) EGP_HIP_CHECK(hipStreamWaitEvent(rs, G.done, 0));
             rc = egp_reward_quat_v3_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->prev_qpos + (size_t)a * d->nq, d->ee + (size_t)a * 15, f32, f32 + nmax,
-                                        f32 + 2 * nmax, f32 + 3 * nmax, d->end_reward, n, d->rewards + row, d->cinfo + row * 5, ts);
+                                        f32 + 2 * nmax, f32 + 3 * nmax, d->end_reward, n, d->rewards + row, d->cinfo + row * 5, rs);
             if (rc != EGP_OK) return rc;
+            if (d->group_streams) {
+                EGP_HIP_CHECK(hipEventRecord(G.reward_done, rs));
+                G.reward_in_flight = true;
+            }
         }
     }
     if (d->group_streams) {

@@ -534,7 +534,7 @@ class LockstepRollout:
             group_streams = (eng.substeps_per_launch > 1 and os.environ.get("EGP_TICK_STREAMS", "shared") == "group")
             if group_streams:
                 reward_job = False
-            td.group_streams, td.post_fused = int(group_streams), int(group_streams or post_fused)
+            td.group_streams, td.post_fused = int(group_streams), int(post_fused)
             td.reward_job, td.flags_upload = int(bool(reward_job)), (0 if not flags_upload else (2 if stage_mode == "kernel" else 1))
             td.has_fix_head_lb = int(self.env.fix_head_lb is not None)
             td.fix_head_lb = float(self.env.fix_head_lb) if self.env.fix_head_lb is not None else 0.0

@@ -589,8 +589,8 @@ typedef struct egp_rollout_tick {
     const double *qpos, *qvel, *prev_qpos, *ee;  /* the engine's device state */
     void *zf_workspace;
     int32_t *reset_scratch;                      /* [n_groups][2][2 * nmax] pinned, device-visible: ids | group mask of egp_rollout_reset */
-    int32_t group_streams;                       /* 1: a group's tick is enqueued on its engine stream (egp_engine_group_stream), `stream` only
-                                                  * carries the rollout's set-up; needs reward_job == 0 */
+    int32_t group_streams;                       /* 1: a group's tick is enqueued on its engine stream (egp_engine_group_stream); `stream` carries
+                                                  * the rollout's set-up and the reward launches (event-ordered); needs reward_job == 0 */
     int32_t post_fused;                          /* 1 (and reward_job == 0): K3 + K6 + K2 through egp_post_step_f64 */
 } egp_rollout_tick;
 int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, void *ready_event);
