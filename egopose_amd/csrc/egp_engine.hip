@@ -1298,6 +1298,10 @@ int egp_rollout_tick_post(const egp_rollout_tick *d, int32_t group, int32_t a, i
         for (int g2 = 0; g2 < d->eng->n_groups; ++g2)
             if (g2 != group && d->eng->groups[g2].chain_recorded) EGP_HIP_CHECK(hipStreamWaitEvent(ts, d->eng->groups[g2].chain_done, 0));
     const int n = b - a, nmax = d->nmax, N = d->n_env;
+    {   // diagnostic (EGP_CHAIN_DELAY_US): hold the filter -> policy chain back to measure what a microsecond of it costs the rollout
+        static const int delay_us = [] { const char *e = getenv("EGP_CHAIN_DELAY_US"); return e ? atoi(e) : 0; }();
+        if (delay_us > 0) k_engine_spin<<<dim3(1), dim3(1), 0, ts>>>((long long)delay_us);
+    }
     const size_t soff = (size_t)(group * 2 + (k & 1)) * 24 * nmax;
     const int32_t *f32 = reinterpret_cast<const int32_t *>(d->slab_dev + soff);          // the flags `pre` staged for this env-step
     const size_t row = (size_t)k * N + a;
