@@ -605,13 +605,22 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &ph, un
 }
 
 // staged registers -> the three LDS images: v[8 u + j] = (row r_first + ROW_STEP u, k = 8 panel + j), one 16-byte store per image
-template <int R, int ROW_STEP>
+template <int R, int ROW_STEP, bool FAKE = false>
 __device__ __forceinline__ void ws_store(const float (&v)[R / 8], __bf16 *dst, int img, int panel, int r_first) {
 #pragma unroll
     for (int u = 0; u < R / 64; ++u) {
         unsigned q[3][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) split3_pair(v[8 * u + 2 * j], v[8 * u + 2 * j + 1], q[0][j], q[1][j], q[2][j]);
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (FAKE) {       // timing probe only (-DEGP_FAKE_SPLIT=1: B, 2: A and B; wrong numerics): what pre-split operands would
+                                        // save. Round 3, in-lease A/B/C (tools/probes/ab3.sh): B's conversion gone = T_update 50.8 -> 49.5 ms, i.e.
+                                        // keeping the weights as three bf16 planes is worth 1.3 ms -- not built
+                q[0][j] = __builtin_amdgcn_perm(__float_as_uint(v[8 * u + 2 * j + 1]), __float_as_uint(v[8 * u + 2 * j]), 0x07060302u);
+                q[1][j] = q[0][j] ^ 0x00010001u; q[2][j] = q[0][j] ^ 0x00020002u;
+            } else {
+                split3_pair(v[8 * u + 2 * j], v[8 * u + 2 * j + 1], q[0][j], q[1][j], q[2][j]);
+            }
+        }
         const int off = panel * panel_el(R) + (r_first + ROW_STEP * u) * 8;
 #pragma unroll
         for (int c = 0; c < 3; ++c) *(uint4 *)(dst + c * img + off) = make_uint4(q[c][0], q[c][1], q[c][2], q[c][3]);
@@ -748,9 +757,12 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
                 ws_zero_head<BN>(vb, zrel[SET], pb_panel);
             }
             __bf16 *pa = base + buf * BUF_EL, *pb = pa + NIMG * A_EL;
-            ws_store<BM, SA::ROW_STEP>(va, pa, A_EL, pa_panel, pa_row);
+#ifndef EGP_FAKE_SPLIT
+#define EGP_FAKE_SPLIT 0
+#endif
+            ws_store<BM, SA::ROW_STEP, (EGP_FAKE_SPLIT >= 2)>(va, pa, A_EL, pa_panel, pa_row);
             EGP_TRW(1, 34);
-            ws_store<BN, SB::ROW_STEP>(vb, pb, B_EL, pb_panel, pb_row);
+            ws_store<BN, SB::ROW_STEP, (EGP_FAKE_SPLIT >= 1)>(vb, pb, B_EL, pb_panel, pb_row);
         };
         prefetch(); issue(S0); prefetch(); issue(S1); prefetch(); issue(S2); prefetch(); issue(S3);      // k-tiles 0..3 in flight
         prefetch();
