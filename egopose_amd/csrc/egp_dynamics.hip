@@ -32,11 +32,17 @@ namespace {
 
 using namespace egp_dyn;
 
-__global__ __launch_bounds__(256) void k_dynamics(const DynTables *__restrict__ tab_g, const double *__restrict__ qpos,
+// One wavefront per env and the env's intermediates in LDS: at large batches the kernel's rate is (envs a CU holds) / (latency of
+// one env), and the first factor is LDS capacity. 7 envs per workgroup: 7 x 9.8 kB + the 5 kB of tree tables = 74 kB, two
+// workgroups per CU = 14 envs (round 2: 4 x 16.9 + 5 = 73 kB, two workgroups = 8 envs): 787 -> 653 us at 65 536 envs. Small
+// batches (a rollout group) keep 4 envs per workgroup: spread over more CUs, one wave per SIMD (1 024 envs: 22 us against 27).
+
+template <int DYN_ENVS_PER_BLOCK>
+__global__ __launch_bounds__(DYN_ENVS_PER_BLOCK * 64) void k_dynamics(const DynTables *__restrict__ tab_g, const double *__restrict__ qpos,
                                                   const double *__restrict__ qvel, int n, long ld_q, long ld_v, double *__restrict__ qM,
-                                                  long ld_m, double *__restrict__ bias, long ld_b, double *__restrict__ xpos) {
+                                                  long ld_m, double *__restrict__ bias, long ld_b, double *__restrict__ xpos, int env_doubles) {
     __shared__ DynTables tb;
-    extern __shared__ double s_env[];            // 4 x DY_ENV_DOUBLES
+    extern __shared__ double s_env[];            // (blockDim / 64) x env_doubles
     {
         const int words = sizeof(DynTables) / 4;
         const int *src = reinterpret_cast<const int *>(tab_g);
@@ -44,11 +50,11 @@ __global__ __launch_bounds__(256) void k_dynamics(const DynTables *__restrict__ 
         for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long env = (long)blockIdx.x * 4 + wave;
+    const long env = (long)blockIdx.x * DYN_ENVS_PER_BLOCK + wave;
     const bool valid = env < n;
     const long e = valid ? env : 0;              // out-of-range waves shadow env 0 and write nothing
     __syncthreads();
-    dynamics_wave(tb, s_env + wave * DY_ENV_DOUBLES, qpos + e * ld_q, qvel + e * ld_v, lane, valid, qM ? qM + env * ld_m : nullptr,
+    dynamics_wave(tb, s_env + wave * env_doubles, qpos + e * ld_q, qvel + e * ld_v, lane, valid, qM ? qM + env * ld_m : nullptr,
                   bias ? bias + env * ld_b : nullptr, xpos ? xpos + env * tb.nb * 3 : nullptr);
 }
 
@@ -58,9 +64,14 @@ __global__ __launch_bounds__(256) void k_dynamics(const DynTables *__restrict__ 
 int egp_launch_dynamics_strided(egp_ctx *ctx, const double *qpos, long ld_q, const double *qvel, long ld_v, int32_t n, double *qM,
                                 long ld_m, double *bias, long ld_b, double *xpos, hipStream_t stream) {
     if (!ctx->dyn_tables) { egp::set_error("egp_set_dynamics_model must be called before egp_dynamics"); return EGP_E_STATE; }
-    const size_t lds = (size_t)4 * DY_ENV_DOUBLES * sizeof(double);
-    k_dynamics<<<dim3((n + 3) / 4), dim3(256), lds, stream>>>((const DynTables *)ctx->dyn_tables, qpos, qvel, n, ld_q, ld_v, qM, ld_m, bias,
-                                                              ld_b, xpos);
+    const int env_doubles = dy_env_doubles(ctx->dm.nbody, ctx->dm.nv - 6, ctx->dm.nv);
+    static const hipError_t attr = hipFuncSetAttribute((const void *)k_dynamics<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    const bool wide = n >= 4096;
+    const size_t lds = (size_t)(wide ? 7 : 4) * env_doubles * sizeof(double);
+    if (attr != hipSuccess || lds > (wide ? 100 : 64) * 1024) { egp::set_error("k_dynamics: LDS budget (%zu bytes)", lds); return EGP_E_HIP; }
+    const DynTables *tab = (const DynTables *)ctx->dyn_tables;
+    if (wide) k_dynamics<7><<<dim3((n + 6) / 7), dim3(448), lds, stream>>>(tab, qpos, qvel, n, ld_q, ld_v, qM, ld_m, bias, ld_b, xpos, env_doubles);
+    else k_dynamics<4><<<dim3((n + 3) / 4), dim3(256), lds, stream>>>(tab, qpos, qvel, n, ld_q, ld_v, qM, ld_m, bias, ld_b, xpos, env_doubles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { egp::set_error("k_dynamics launch failed: %s", hipGetErrorString(e)); return EGP_E_HIP; }
     return EGP_OK;

@@ -72,8 +72,18 @@ __device__ __forceinline__ Sp inertia_apply(const double *in10, Sp s) {
 __device__ __forceinline__ void st_sp(double *p, Sp s) { p[0] = s.w.x; p[1] = s.w.y; p[2] = s.w.z; p[3] = s.v.x; p[4] = s.v.y; p[5] = s.v.z; }
 __device__ __forceinline__ Sp ld_sp(const double *p) { return {{p[0], p[1], p[2]}, {p[3], p[4], p[5]}}; }
 
-// per-env LDS (doubles): local chain transforms, world frames, joint motion vectors, inertias, velocities, forces
-constexpr int DY_ENV_DOUBLES = DY_MAXB * 12 * 2 + DY_MAXJ * 6 + DY_MAXV * 6 * 2 + DY_MAXB * 10 + DY_MAXB * 6;
+// per-env LDS (doubles), sized by the model (nb bodies, nj hinges, nv dofs):
+//   R1  [nb][12] local transforms + [nj][6] local hinge axis / anchor (phases A-C), reused from phase D on as
+//       [nb][10] own spatial inertias + [nb][6] body forces  (16 nb <= 12 nb + 6 nj whenever nj >= nb: every body but the root has a hinge)
+//   sW  [nb][12] world frames,  sS [nv][6] joint motion vectors,  sQ [nv] the env's qvel
+// (round 3: 16.9 kB -> 9.8 kB per env for the humanoid -- the number of envs a CU holds at once is what bounds this kernel at
+//  large batches -- by the aliasing, by sizing to the model instead of the table maxima, and by dropping the S_d * qvel_d
+//  copy: phase D forms the product. Keeping the copy (12.1 kB, 12 envs per CU) measured 674 us at 65 536 envs against 653.)
+__host__ __device__ inline int dy_env_doubles(int nb, int nj, int nv) {
+    const int r1a = nb * 12 + nj * 6, r1b = nb * 16;
+    return (r1a > r1b ? r1a : r1b) + nb * 12 + nv * 6 + nv;
+}
+constexpr int DY_ENV_DOUBLES = DY_MAXB * 12 + DY_MAXJ * 6 + DY_MAXB * 12 + DY_MAXV * 6 + DY_MAXV;      // the same for the table maxima
 
 // Every env is owned by ONE wavefront, so the phases only need the wave's own LDS writes to have landed before its
 // next reads: LDS operations of a wave complete in order; the fences keep the compiler from moving accesses across.
@@ -109,15 +119,17 @@ __device__ __forceinline__ void st_v3(double *p, V3 v) { p[0] = v.x; p[1] = v.y;
 // xpos_out [nb][3]. `valid` = false makes the wave compute on its inputs and write nothing.
 __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base, const double *q, const double *qd, int lane, bool valid,
                                               double *qM_out, double *bias_out, double *xpos_out) {
-    double *sLoc = base;                                 // [nb][12]  local transform in the parent frame: Rl (9), tl (3)
-    double *sW = sLoc + DY_MAXB * 12;                    // [nb][12]  world frame: R (9), p (3)
-    double *sJl = sW + DY_MAXB * 12;                     // [nj][6]   hinge axis (3) and anchor (3) in the parent frame of its body
-    double *sS = sJl + DY_MAXJ * 6;                      // [nv][6]   joint motion vectors (world)
-    double *sSq = sS + DY_MAXV * 6;                      // [nv][6]   S_d * qvel_d
-    double *sIb = sSq + DY_MAXV * 6;                     // [nb][10]  own spatial inertia about the world origin
-    double *sF = sIb + DY_MAXB * 10;                     // [nb][6]   body force
-    const int nb = tb.nb, nv = tb.nv;
+    const int nb = tb.nb, nv = tb.nv, nj = tb.nj;
+    double *sLoc = base;                                 // [nb][12]  local transform in the parent frame: Rl (9), tl (3)       (A, B)
+    double *sJl = sLoc + nb * 12;                        // [nj][6]   hinge axis (3) and anchor (3) in the parent frame of its body (A, C)
+    double *sIb = base;                                  // [nb][10]  own spatial inertia about the world origin        (D, F: over sLoc / sJl)
+    double *sF = sIb + nb * 10;                          // [nb][6]   body force                                        (D, F)
+    const int r1 = nb * 12 + nj * 6 > nb * 16 ? nb * 12 + nj * 6 : nb * 16;
+    double *sW = base + r1;                              // [nb][12]  world frame: R (9), p (3)
+    double *sS = sW + nb * 12;                           // [nv][6]   joint motion vectors (world)
+    double *sQ = sS + nv * 6;                            // [nv]      qvel
     const int b = lane;
+    if (lane < nv) sQ[lane] = qd[lane];
     // ---- A: own hinge chain in the parent frame
     if (b < nb) {
         M3 Rl;
@@ -185,7 +197,6 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
             S = {a_w, cross(r_w, a_w)};
         }
         st_sp(sS + d * 6, S);
-        st_sp(sSq + d * 6, qd[d] * S);
     }
     wave_sync();
     // ---- D: velocity, bias acceleration, own inertia, body force
@@ -196,7 +207,7 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
         Sp hinge_suffix = suffix;                     // the same without the root's rotational dofs
         Sp a = {{0, 0, 0}, {-tb.g[0], -tb.g[1], -tb.g[2]}};
         for (int d = tb.last_dof[b]; d >= 0; d = tb.dof_parent[d]) {
-            const Sp sq = ld_sp(sSq + d * 6);
+            const Sp sq = sQ[d] * ld_sp(sS + d * 6);
             const bool root_rot = d >= 3 && d < 6;
             a = a + cross_m(sq, root_rot ? hinge_suffix : suffix);
             suffix = suffix + sq;
