@@ -702,7 +702,12 @@ __device__ __forceinline__ void body_feature(const T *cq, const T *pq, int s, in
     const Q4<T> dv = qmul(*qc, qinv(qp));
     V3<T> ax; T ang;
     rot_axis_angle<T>(dv, &ax, &ang);
-    omega->x = ax.x * ang / dt; omega->y = ax.y * ang / dt; omega->z = ax.z * ang / dt;
+    if (sizeof(T) == 8) {          // (float64: one division instead of three, see qinv)
+        const T rate = ang / dt;
+        omega->x = ax.x * rate; omega->y = ax.y * rate; omega->z = ax.z * rate;
+    } else {
+        omega->x = ax.x * ang / dt; omega->y = ax.y * ang / dt; omega->z = ax.z * ang / dt;
+    }
 }
 
 // root lane: get_qvel_fd(prev, cur, dt) root part (utils/math.py:20-35): world-frame linear velocity `v`,
@@ -737,101 +742,154 @@ __device__ __forceinline__ V3<T> ee_local(const T *cq, const T *wp, bool root_fr
     return coord_vec(rc, rel, root_frame);
 }
 
-template <typename T>
+// Work split (round 3). A wavefront used to carry two envs, lane = body, with lane 0 doing the root terms and five lanes the end
+// effectors: three divergent branches that run one after the other, the ~1 000-instruction root branch with ONE lane per env
+// active (the kernel is float64-VALU bound: VALUBusy 87 %, 18.6 % of HBM peak at 65 536 envs). Now a workgroup owns a tile of
+// envs and works in two phases: (1) lane = (env, body): pose and angular-velocity terms of every body into LDS; (2) lane = env
+// for the root terms, lane = (env, end effector) on the other waves, then lane = env adds up the bodies' terms and combines the
+// five parts. With multi-pass tiles (PASSES = 5: 60 envs for the humanoid, large batches) the root branch runs once per tile
+// with nearly every lane busy instead of once per two envs; rollout-sized batches keep one-pass tiles (12 envs: the latency of
+// a tick's reward is unchanged).
+// Phase 1 packs as many envs into a wavefront as its 64 lanes hold bodies (three for the humanoid's 20 non-root bodies, 60 of
+// 64 lanes busy instead of 40): a pass of the workgroup covers 4 * (64 / (nbody - 1)) envs, the per-body terms go to LDS and
+// phase 2's env lane adds them up in body order.
+__host__ __device__ inline int reward_envs_per_wave(int nbody) { return nbody > 1 ? (64 / (nbody - 1) > 0 ? 64 / (nbody - 1) : 1) : 1; }
+__host__ __device__ inline int reward_tile_envs(int nbody, int passes) {
+    const int t = 4 * reward_envs_per_wave(nbody) * passes, cap = passes == 1 ? 16 : 64;     // (cap = the tile arrays' capacity)
+    return t < cap ? t : cap;
+}
+template <typename T, int PASSES>
 __device__ __forceinline__ void reward_body(const DevModel &m, const RewardW &w, const T *__restrict__ expert_rows,
                                             const T *__restrict__ cur_qpos, const T *__restrict__ prev_qpos,
                                             const T *__restrict__ ee_wpos, const int *__restrict__ tcur,
                                             const int *__restrict__ frame, const int *__restrict__ endf,
                                             const int *__restrict__ active, T end_reward, int n,
                                             T *__restrict__ reward, T *__restrict__ cinfo, int block_id) {
+    constexpr int ENVS = PASSES == 1 ? 16 : 64;                    // capacity of the tile arrays; the tile itself: reward_tile_envs
     __shared__ int s_start[EGP_MAX_BODY], s_ndof[EGP_MAX_BODY];
     __shared__ double s_bw[EGP_MAX_BODY];
+    __shared__ T s_bp[ENVS][EGP_MAX_BODY], s_bv[ENVS][EGP_MAX_BODY];      // per-body pose / angular-velocity terms
+    __shared__ T s_rp[ENVS], s_rv[ENVS], s_ee[ENVS][5];
     if (threadIdx.x < m.nbody) {
         s_start[threadIdx.x] = m.body_qpos_start[threadIdx.x];
         s_ndof[threadIdx.x] = m.body_ndof[threadIdx.x];
         s_bw[threadIdx.x] = threadIdx.x > 0 ? m.b_diffw[threadIdx.x - 1] : 0.0;
     }
     __syncthreads();
-    const long env = ((long)block_id * blockDim.x + threadIdx.x) >> 5;
-    const int l = threadIdx.x & 31;
-    if (env >= n) return;
-    if (active && !active[env]) {
-        if (l == 0) {
-            reward[env] = T(0);
-            for (int k = 0; k < 5; ++k) cinfo[env * 5 + k] = T(0);
-        }
-        return;
-    }
-    const T *cq = cur_qpos + env * m.nq;
-    const T *pq = prev_qpos + env * m.nq;
-    const T *er = expert_rows + (long)frame[env] * EGP_EXPERT_ROW;
+    const int per = m.nbody - 1, epw = reward_envs_per_wave(m.nbody), tile = reward_tile_envs(m.nbody, PASSES);
+    const long env0 = (long)block_id * tile;
     const T dt = (T)m.dt;
-    T pose_sq = T(0), vel_acc = T(0), ee_sq = T(0);
-    T rp_r = T(0), rv_r = T(0);
-    if (l >= 1 && l < m.nbody) {
-        Q4<T> qc; V3<T> om;
-        body_feature<T>(cq, pq, s_start[l], s_ndof[l], dt, &qc, &om);
-        const T *eb = er + ER_BQ + 4 * (l - 1);
-        const Q4<T> qe{eb[0], eb[1], eb[2], eb[3]};
-        const T pd = half_angle<T>(qmul(qc, qinv(qe))) * (T)s_bw[l];
-        pose_sq = pd * pd;
-        const T *ev = er + ER_BAV + 3 * (l - 1);
-        const T dx = om.x - ev[0], dy = om.y - ev[1], dz = om.z - ev[2];
-        if (w.v_ord == 2.0) {
-            vel_acc = dx * dx + dy * dy + dz * dz;
-        } else {
-            const T p = (T)w.v_ord;
-            vel_acc = t_pow<T>(fabs(dx), p) + t_pow<T>(fabs(dy), p) + t_pow<T>(fabs(dz), p);
+    // ---- phase 1: lane = (env of the wavefront, body)
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int sub = lane / per, bl = lane - sub * per;
+#pragma unroll 1
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int el = (ps * 4 + wv) * epw + sub;
+            const long env = env0 + el;
+            if (sub >= epw || el >= tile) continue;
+            T pose_sq = T(0), vel_acc = T(0);
+            if (env < n && (!active || active[env])) {
+                const int l = 1 + bl;
+                const T *cq = cur_qpos + env * m.nq;
+                const T *pq = prev_qpos + env * m.nq;
+                const T *er = expert_rows + (long)frame[env] * EGP_EXPERT_ROW;
+                Q4<T> qc; V3<T> om;
+                body_feature<T>(cq, pq, s_start[l], s_ndof[l], dt, &qc, &om);
+                const T *eb = er + ER_BQ + 4 * (l - 1);
+                const Q4<T> qe{eb[0], eb[1], eb[2], eb[3]};
+                const T pd = half_angle<T>(qmul(qc, qinv(qe))) * (T)s_bw[l];
+                pose_sq = pd * pd;
+                const T *ev = er + ER_BAV + 3 * (l - 1);
+                const T dx = om.x - ev[0], dy = om.y - ev[1], dz = om.z - ev[2];
+                if (w.v_ord == 2.0) {
+                    vel_acc = dx * dx + dy * dy + dz * dz;
+                } else {
+                    const T p = (T)w.v_ord;
+                    vel_acc = t_pow<T>(fabs(dx), p) + t_pow<T>(fabs(dy), p) + t_pow<T>(fabs(dz), p);
+                }
+            }
+            s_bp[el][bl] = pose_sq;
+            s_bv[el][bl] = vel_acc;
         }
-    } else if (l == 0) {
-        V3<T> v, rv;
-        root_velocity<T>(cq, pq, dt, &v, &rv);
-        const Q4<T> rp{pq[3], pq[4], pq[5], pq[6]};
-        // learner: get_qvel_fd(prev, cur, dt, cfg.obs_coord) (reward_function.py:19): frame of the PREVIOUS root quat
-        const V3<T> vl = coord_vec(rp, v, m.obs_root != 0);
-        const T dl = (vl.x - er[ER_RLINV]) * (vl.x - er[ER_RLINV]) + (vl.y - er[ER_RLINV + 1]) * (vl.y - er[ER_RLINV + 1]) +
-                     (vl.z - er[ER_RLINV + 2]) * (vl.z - er[ER_RLINV + 2]);
-        const T da = (rv.x - er[ER_RANGV]) * (rv.x - er[ER_RANGV]) + (rv.y - er[ER_RANGV + 1]) * (rv.y - er[ER_RANGV + 1]) +
-                     (rv.z - er[ER_RANGV + 2]) * (rv.z - er[ER_RANGV + 2]);
-        rv_r = t_exp<T>(-(T)w.k_rl * dl - (T)w.k_ra * da);
-        const Q4<T> rc{cq[3], cq[4], cq[5], cq[6]};
-        const Q4<T> rq = de_heading(rc);
-        const Q4<T> erq{er[ER_RQ], er[ER_RQ + 1], er[ER_RQ + 2], er[ER_RQ + 3]};
-        const T dq = half_angle<T>(qmul(rq, qinv(erq)));
-        const T dh = cq[2] - er[ER_Z];
-        rp_r = t_exp<T>(-(T)w.k_rh * dh * dh - (T)w.k_rq * dq * dq);
-    } else if (l < m.nbody + 5) {
-        const int k = l - m.nbody;
-        const V3<T> o = ee_local<T>(cq, ee_wpos + env * 15 + 3 * k, m.obs_root != 0);
-        const T *ee = er + ER_EE + 3 * k;
-        ee_sq = (o.x - ee[0]) * (o.x - ee[0]) + (o.y - ee[1]) * (o.y - ee[1]) + (o.z - ee[2]) * (o.z - ee[2]);
     }
-    pose_sq = half_wave_sum<T>(pose_sq);
-    vel_acc = half_wave_sum<T>(vel_acc);
-    ee_sq = half_wave_sum<T>(ee_sq);
-    if (l == 0) {
-        const T pose_r = t_exp<T>(-(T)w.k_p * pose_sq);
-        T vel_sq = vel_acc;
-        if (w.v_ord != 2.0) vel_sq = t_pow<T>(vel_acc, T(2) / (T)w.v_ord);
+    __syncthreads();
+    // ---- phase 2: lane = env (root terms, threads [0, ENVS)), lane = (env, end effector) (threads [64, 256))
+    if (threadIdx.x < tile) {
+        const long env = env0 + threadIdx.x;
+        T rp_r = T(0), rv_r = T(0);
+        if (env < n && (!active || active[env])) {
+            const T *cq = cur_qpos + env * m.nq;
+            const T *pq = prev_qpos + env * m.nq;
+            const T *er = expert_rows + (long)frame[env] * EGP_EXPERT_ROW;
+            V3<T> v, rv;
+            root_velocity<T>(cq, pq, dt, &v, &rv);
+            const Q4<T> rp{pq[3], pq[4], pq[5], pq[6]};
+            // learner: get_qvel_fd(prev, cur, dt, cfg.obs_coord) (reward_function.py:19): frame of the PREVIOUS root quat
+            const V3<T> vl = coord_vec(rp, v, m.obs_root != 0);
+            const T dl = (vl.x - er[ER_RLINV]) * (vl.x - er[ER_RLINV]) + (vl.y - er[ER_RLINV + 1]) * (vl.y - er[ER_RLINV + 1]) +
+                         (vl.z - er[ER_RLINV + 2]) * (vl.z - er[ER_RLINV + 2]);
+            const T da = (rv.x - er[ER_RANGV]) * (rv.x - er[ER_RANGV]) + (rv.y - er[ER_RANGV + 1]) * (rv.y - er[ER_RANGV + 1]) +
+                         (rv.z - er[ER_RANGV + 2]) * (rv.z - er[ER_RANGV + 2]);
+            rv_r = t_exp<T>(-(T)w.k_rl * dl - (T)w.k_ra * da);
+            const Q4<T> rc{cq[3], cq[4], cq[5], cq[6]};
+            const Q4<T> rq = de_heading(rc);
+            const Q4<T> erq{er[ER_RQ], er[ER_RQ + 1], er[ER_RQ + 2], er[ER_RQ + 3]};
+            const T dq = half_angle<T>(qmul(rq, qinv(erq)));
+            const T dh = cq[2] - er[ER_Z];
+            rp_r = t_exp<T>(-(T)w.k_rh * dh * dh - (T)w.k_rq * dq * dq);
+        }
+        s_rp[threadIdx.x] = rp_r;
+        s_rv[threadIdx.x] = rv_r;
+    } else if (threadIdx.x >= 64) {
+        for (int i = threadIdx.x - 64; i < 5 * tile; i += 192) {
+            const int el = i / 5, k = i - 5 * el;
+            const long env = env0 + el;
+            T ee_sq = T(0);
+            if (env < n && (!active || active[env])) {
+                const T *cq = cur_qpos + env * m.nq;
+                const T *er = expert_rows + (long)frame[env] * EGP_EXPERT_ROW;
+                const V3<T> o = ee_local<T>(cq, ee_wpos + env * 15 + 3 * k, m.obs_root != 0);
+                const T *ee = er + ER_EE + 3 * k;
+                ee_sq = (o.x - ee[0]) * (o.x - ee[0]) + (o.y - ee[1]) * (o.y - ee[1]) + (o.z - ee[2]) * (o.z - ee[2]);
+            }
+            s_ee[el][k] = ee_sq;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < tile) {
+        const long env = env0 + threadIdx.x;
+        if (env >= n) return;
+        T *ci = cinfo + env * 5;
+        if (active && !active[env]) {
+            reward[env] = T(0);
+            for (int k = 0; k < 5; ++k) ci[k] = T(0);
+            return;
+        }
+        const T ee_sq = (((s_ee[threadIdx.x][0] + s_ee[threadIdx.x][1]) + s_ee[threadIdx.x][2]) + s_ee[threadIdx.x][3]) + s_ee[threadIdx.x][4];
+        T pose_sum = T(0), vel_sq = T(0);
+        for (int bl = 0; bl < per; ++bl) { pose_sum += s_bp[threadIdx.x][bl]; vel_sq += s_bv[threadIdx.x][bl]; }
+        const T pose_r = t_exp<T>(-(T)w.k_p * pose_sum);
+        if (w.v_ord != 2.0) vel_sq = t_pow<T>(vel_sq, T(2) / (T)w.v_ord);
         const T vel_r = t_exp<T>(-(T)w.k_v * vel_sq);
         const T ee_r = t_exp<T>(-(T)w.k_e * ee_sq);
+        const T rp_r = s_rp[threadIdx.x], rv_r = s_rv[threadIdx.x];
         T r = ((T)w.w_p * pose_r + (T)w.w_v * vel_r + (T)w.w_e * ee_r + (T)w.w_rp * rp_r + (T)w.w_rv * rv_r) / (T)w.w_sum;
         if (w.decay) r *= T(1) - (T)tcur[env] / (T)w.episode_len;
         if (endf[env]) r += end_reward;
         reward[env] = r;
-        T *ci = cinfo + env * 5;
         ci[0] = pose_r; ci[1] = vel_r; ci[2] = ee_r; ci[3] = rp_r; ci[4] = rv_r;
     }
 }
 
-template <typename T>
+template <typename T, int PASSES>
 __global__ __launch_bounds__(256) void k_reward_quat_v3(DevModel m, RewardW w, const T *__restrict__ expert_rows,
                                                         const T *__restrict__ cur_qpos, const T *__restrict__ prev_qpos,
                                                         const T *__restrict__ ee_wpos, const int *__restrict__ tcur,
                                                         const int *__restrict__ frame, const int *__restrict__ endf,
                                                         const int *__restrict__ active, T end_reward, int n,
                                                         T *__restrict__ reward, T *__restrict__ cinfo) {
-    reward_body<T>(m, w, expert_rows, cur_qpos, prev_qpos, ee_wpos, tcur, frame, endf, active, end_reward, n, reward, cinfo, blockIdx.x);
+    reward_body<T, PASSES>(m, w, expert_rows, cur_qpos, prev_qpos, ee_wpos, tcur, frame, endf, active, end_reward, n, reward, cinfo, blockIdx.x);
 }
 
 // ============================================================================================ K7
@@ -1000,7 +1058,7 @@ __global__ __launch_bounds__(256) void k_post_step(ZfSrc<T> src, const int *__re
     if ((int)blockIdx.x < n_tiles)
         zf_partial_body<T>(src, zf_active, n, dim, rows_per_tile, ws, blockIdx.x);
     else
-        reward_body<T>(m, w, expert_rows, src.qpos, prev_qpos, ee_wpos, tcur, frame, endf, zf_active, end_reward, n, reward, cinfo,
+        reward_body<T, 1>(m, w, expert_rows, src.qpos, prev_qpos, ee_wpos, tcur, frame, endf, zf_active, end_reward, n, reward, cinfo,
                        (int)blockIdx.x - n_tiles);
 }
 
@@ -1746,9 +1804,17 @@ static int launch_reward(egp_ctx *ctx, const T *expert_rows, const T *cur_qpos, 
     if (!expert_rows) { set_error("egp_upload_experts must be called before the reward kernel"); return EGP_E_STATE; }
     if (n == 0) return EGP_OK;
     EGP_REQUIRE(cur_qpos && prev_qpos && ee_wpos && t && frame && endf && reward && cinfo, "NULL pointer");
-    const long threads = (long)n * 32;
-    k_reward_quat_v3<T><<<dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
-        ctx->dm, ctx->rw, expert_rows, cur_qpos, prev_qpos, ee_wpos, t, frame, endf, active, (T)end_reward, n, reward, cinfo);
+    // multi-pass tiles (60 envs for the humanoid) once the launch fills the chip several times over, one-pass tiles for
+    // rollout-sized batches
+    if (n >= 16384) {
+        const int tile = reward_tile_envs(ctx->dm.nbody, 5);
+        k_reward_quat_v3<T, 5><<<dim3((n + tile - 1) / tile), dim3(256), 0, (hipStream_t)stream>>>(
+            ctx->dm, ctx->rw, expert_rows, cur_qpos, prev_qpos, ee_wpos, t, frame, endf, active, (T)end_reward, n, reward, cinfo);
+    } else {
+        const int tile = reward_tile_envs(ctx->dm.nbody, 1);
+        k_reward_quat_v3<T, 1><<<dim3((n + tile - 1) / tile), dim3(256), 0, (hipStream_t)stream>>>(
+            ctx->dm, ctx->rw, expert_rows, cur_qpos, prev_qpos, ee_wpos, t, frame, endf, active, (T)end_reward, n, reward, cinfo);
+    }
     return after_launch("k_reward_quat_v3");
 }
 
@@ -1840,7 +1906,8 @@ static int launch_post_step(egp_ctx *ctx, const double *qpos, const double *qvel
     hipStream_t s = (hipStream_t)stream;
     int rpt = 0, nt = 0;
     if (!identity) zf_tiling(n, &rpt, &nt);
-    const int reward_blocks = (int)(((long)n * 32 + 255) / 256);
+    const int rtile = reward_tile_envs(ctx->dm.nbody, 1);
+    const int reward_blocks = (n + rtile - 1) / rtile;
     k_post_step<double><<<dim3(nt + reward_blocks), dim3(256), 0, s>>>(src, active, n, dim, rpt, (double *)ws, nt, ctx->dm, ctx->rw,
                                                                        ctx->expert_rows_f64, prev_qpos, ee_wpos, tcur, frame, endf,
                                                                        end_reward, reward, cinfo);

@@ -23,7 +23,28 @@ template <> __device__ __forceinline__ float t_pow<float>(float a, float b) { re
 template <> __device__ __forceinline__ double t_pow<double>(double a, double b) { return pow(a, b); }
 template <typename T> __device__ __forceinline__ void t_sincos(T v, T *s, T *c);
 template <> __device__ __forceinline__ void t_sincos<float>(float v, float *s, float *c) { sincosf(v, s, c); }
-template <> __device__ __forceinline__ void t_sincos<double>(double v, double *s, double *c) { sincos(v, s, c); }
+// float64 sincos for the kernels' joint angles and half-angles: Cody-Waite reduction by pi/2 in two FMAs (exact enough while
+// |n| < 2^18) and the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4] (< 1 ulp each) -- ~35 instructions where the
+// library routine, which also carries a Payne-Hanek path for huge arguments, runs ~120. The reward kernel is float64-VALU
+// bound (VALUBusy 87 %) and spends 12 of these per body lane. Arguments beyond 2^18 (and NaN / inf) take the library routine.
+__device__ __forceinline__ void egp_sincos_f64(double x, double *s, double *c) {
+    if (!(fabs(x) < 262144.0)) { sincos(x, s, c); return; }
+    const double n = rint(x * 6.36619772367581382433e-01);                 // x * 2 / pi
+    double r = fma(-n, 1.57079632679489655800e+00, x);                      // pi/2 = hi + lo
+    r = fma(-n, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                 -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+    const double sr = fma(r * z, fma(z, ps, -1.66666666666666324348e-01), r);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                        2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double cr = 1.0 - fma(0.5, z, -(z * z) * pc);
+    const int q = (int)n & 3;
+    const double a = (q & 1) ? cr : sr, b = (q & 1) ? sr : cr;
+    *s = (q & 2) ? -a : a;
+    *c = ((q + 1) & 2) ? -b : b;
+}
+template <> __device__ __forceinline__ void t_sincos<double>(double v, double *s, double *c) { egp_sincos_f64(v, s, c); }
 
 // quaternion_multiply  (utils/transformation.py:1379-1393)
 template <typename T> __device__ __forceinline__ Q4<T> qmul(const Q4<T> &a, const Q4<T> &b) {
@@ -36,10 +57,17 @@ template <typename T> __device__ __forceinline__ Q4<T> qmul(const Q4<T> &a, cons
 }
 
 // quaternion_inverse: conjugate / (q.q)  (utils/transformation.py:1410-1421)
+// (one division and four products instead of four divisions -- a float64 division is ~15 instructions around a quarter-rate
+//  v_rcp_f64, and the reward kernel, float64-VALU bound, inverted two quaternions per body lane; <= 1 ulp from the quotient)
 template <typename T> __device__ __forceinline__ Q4<T> qinv(const Q4<T> &q) {
     const T n = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
     Q4<T> r;
-    r.w = q.w / n; r.x = -q.x / n; r.y = -q.y / n; r.z = -q.z / n;
+    if (sizeof(T) == 8) {
+        const T inv = T(1) / n;
+        r.w = q.w * inv; r.x = -q.x * inv; r.y = -q.y * inv; r.z = -q.z * inv;
+    } else {                       // float32: the quotient itself (a float32 division is cheap, and the product costs a second rounding)
+        r.w = q.w / n; r.x = -q.x / n; r.y = -q.y / n; r.z = -q.z / n;
+    }
     return r;
 }
 
@@ -96,8 +124,8 @@ template <typename T> __device__ __forceinline__ void rot_axis_angle(const Q4<T>
         axis->x = T(1); axis->y = T(0); axis->z = T(0);
         *angle = T(0);
     } else if (sizeof(T) == 8) {
-        const T s = t_sqrt<T>(T(1) - q.w * q.w);
-        axis->x = q.x / s; axis->y = q.y / s; axis->z = q.z / s;
+        const T inv = T(1) / t_sqrt<T>(T(1) - q.w * q.w);
+        axis->x = q.x * inv; axis->y = q.y * inv; axis->z = q.z * inv;
         *angle = T(2) * t_acos<T>(q.w);
     } else {
         // float32 variant: sqrt(1-w^2) and acos(w) lose all digits for small rotations; for a unit
