@@ -1095,10 +1095,17 @@ __device__ __forceinline__ void zf_merge_column(int dim, int n_tiles, const doub
 // one block: the merged state of a batch with many tiles (few tiles: k_zf_apply merges them itself). 8 tile groups x 128
 // columns: group g merges its contiguous eighth of the tiles in order, then group 0 merges the eight results in order
 // through LDS -- eight times fewer dependent rounds of loads than one pass over all tiles (90 -> 15 us for 512 tiles).
-__global__ __launch_bounds__(1024) void k_zf_merge(int dim, int n_tiles, const double *__restrict__ ws,
-                                                   const double *__restrict__ st_in, double *__restrict__ st_out) {
+// Large batches (round 3): ONE block merging 512 partials took 31 of K6's 70 us at 65 536 rows. Now gridDim.x blocks each
+// merge a contiguous share of the tiles into a partial record of their own (st_in == nullptr: block b writes record b of
+// st_out, layout as ws) and the apply kernel merges those <= 16 records into the running state itself, as it does for small batches.
+__global__ __launch_bounds__(1024) void k_zf_merge(int dim, int n_tiles_all, const double *__restrict__ ws_all,
+                                                   const double *__restrict__ st_in, double *__restrict__ st_out_all) {
     __shared__ double s_n[8], s_mean[8][128], s_S[8][128];
     const int g = threadIdx.x >> 7, lc = threadIdx.x & 127;
+    const int share = (n_tiles_all + gridDim.x - 1) / gridDim.x;
+    const int t0 = blockIdx.x * share, n_tiles = max(0, min(n_tiles_all, t0 + share) - t0);
+    const double *ws = ws_all + (long)t0 * (1 + 2 * dim);
+    double *st_out = st_out_all + (st_in ? 0 : (long)blockIdx.x * (1 + 2 * dim));
     const int per = (n_tiles + 7) / 8, q0 = g * per, q1 = min(n_tiles, q0 + per);
     for (int cb = 0; cb < dim; cb += 128) {
         const int c = cb + lc;
@@ -1133,7 +1140,7 @@ __global__ __launch_bounds__(1024) void k_zf_merge(int dim, int n_tiles, const d
         if (lc == 0 && cb == 0) s_n[g] = cnt;            // (the count is the same for every column)
         __syncthreads();
         if (g == 0 && c < dim) {
-            double C = st_in[0], M = st_in[1 + c], SS = st_in[1 + dim + c];
+            double C = st_in ? st_in[0] : 0.0, M = st_in ? st_in[1 + c] : 0.0, SS = st_in ? st_in[1 + dim + c] : 0.0;
             for (int j = 0; j < 8; ++j) {
                 const double nb = s_n[j];
                 if (nb > 0.0) {
@@ -1855,18 +1862,31 @@ static int launch_zfilter_src(const ZfSrc<T> &src, const int *active, int n, int
     }
     int rpt, nt;
     zf_tiling(n, &rpt, &nt);
-    const bool fused = update && nt <= ZF_FUSED_TILES;
+    // <= 16 tiles: the apply kernel merges them itself (2 launches). Up to 256 tiles: one block merges them into the new state
+    // (a few rounds of loads). Beyond (>= 32 k rows): 16 blocks reduce the tiles to 16 records, which the apply kernel's
+    // (16-row) blocks merge themselves -- the single block took 31 of K6's 70 us at 65 536 rows.
+    const bool direct = update && nt <= ZF_FUSED_TILES;
+    const bool two_level = update && nt > 256;
+    const double *records = nullptr;                            // what the apply kernel merges into the running state, if anything
+    int n_records = 0;
     if (update) {
         // (1 024 threads = one round of loads per thread: in the rollout 16.9 us per call against 20.1 with 512 and 33.6 with 256)
         k_zf_partial<T><<<dim3(nt), dim3(1024), 0, (hipStream_t)stream>>>(src, active, n, dim, rpt, (double *)ws);
-        if (!fused) k_zf_merge<<<dim3(1), dim3(1024), 0, (hipStream_t)stream>>>(dim, nt, (const double *)ws, st_in, st_out);
+        if (direct) {
+            records = (const double *)ws; n_records = nt;
+        } else if (two_level) {
+            double *lvl1 = (double *)ws + (size_t)nt * (1 + 2 * dim);            // behind the tiles in the workspace
+            k_zf_merge<<<dim3(ZF_FUSED_TILES), dim3(1024), 0, (hipStream_t)stream>>>(dim, nt, (const double *)ws, nullptr, lvl1);
+            records = lvl1; n_records = ZF_FUSED_TILES;
+        } else {
+            k_zf_merge<<<dim3(1), dim3(1024), 0, (hipStream_t)stream>>>(dim, nt, (const double *)ws, st_in, st_out);
+        }
         int rc = after_launch("k_zf_partial/merge");
         if (rc != EGP_OK) return rc;
     }
-    const int rows_per_block = fused ? 8 : (n <= 8192 ? 2 : 16);     // small batches: enough blocks to cover the latency
+    const int rows_per_block = direct ? 8 : (n <= 8192 ? 2 : 16);     // small batches: enough blocks to cover the latency
     k_zf_apply<T><<<dim3((n + rows_per_block - 1) / rows_per_block), dim3(128), 2 * dim * sizeof(double), (hipStream_t)stream>>>(
-        src, n, dim, rows_per_block, update && !fused ? st_out : st_in, clip, y, y2, write_mask, identity,
-        fused ? (const double *)ws : nullptr, nt, st_out);
+        src, n, dim, rows_per_block, update && !records ? st_out : st_in, clip, y, y2, write_mask, identity, records, n_records, st_out);
     return after_launch("k_zf_apply");
 }
 
@@ -2010,7 +2030,7 @@ int egp_pose_features_f32(egp_ctx *c, const float *cur, const float *prev, const
 int64_t egp_zfilter_workspace_bytes(int32_t n, int32_t dim) {
     int rpt, nt;
     zf_tiling(n > 0 ? n : 1, &rpt, &nt);
-    return (int64_t)nt * (1 + 2 * (int64_t)dim) * sizeof(double);
+    return ((int64_t)nt + ZF_FUSED_TILES) * (1 + 2 * (int64_t)dim) * sizeof(double);      // the tiles + the level-1 records
 }
 int egp_zfilter_f64(const double *x, const int32_t *active, int32_t n, int32_t dim, const double *si, double *so,
                     int32_t update, double clip, double *y, void *ws, void *s) {
