@@ -1206,7 +1206,9 @@ __global__ __launch_bounds__(128) void k_zf_apply(ZfSrc<T> src, int n, int dim, 
 // estimate_advantages (core/common.py:5-25):  a_i = delta_i + (gamma*tau*m_i) a_{i+1},
 // delta_i = r_i + gamma*m_i*v_{i+1} - v_i   (v_N = a_N = 0; one reverse sweep over the flat batch).
 // Affine recurrence -> chunk summaries (P, A) -> block scan over chunks -> per-chunk replay.
-constexpr int GAE_CHUNK = 32;
+// (round 3: 8 samples per thread instead of 32 -- a workgroup then covers 2 048 samples and keeps 33 kB of LDS, so a 1.6 M-sample
+//  batch is 800 workgroups, four per CU, instead of 200 on 256 CUs, and the update's 135 k samples 66 instead of 17)
+constexpr int GAE_CHUNK = 8;
 
 template <typename T>
 __device__ __forceinline__ void gae_coeffs(const T *r, const T *mk, const T *v, int i, int n, double gamma, double gt,
@@ -1217,14 +1219,14 @@ __device__ __forceinline__ void gae_coeffs(const T *r, const T *mk, const T *v, 
     c = gt * mi;
 }
 
-// Staging. A thread owns a chunk of 32 CONSECUTIVE samples (the recurrence is sequential), so its own loads and stores would
-// touch 64 different 128-byte lines per wave instruction. The block's 8 192 samples therefore pass through LDS: coalesced
-// loads form (delta_i, c_i) straight away -- element e of the block at s[e + (e >> 5)], one pad word per chunk so that the
-// 64 lanes of a wave, 33 words apart, hit different banks -- and the replay's results leave the same way (round 3: K5 at
-// 1.6 M samples 142 -> see DESIGN section 4; same arithmetic in the same order, bit for bit).
+// Staging. A thread owns a chunk of GAE_CHUNK CONSECUTIVE samples (the recurrence is sequential), so its own loads and stores
+// would touch 64 different cache lines per wave instruction. The block's samples therefore pass through LDS: coalesced
+// loads form (delta_i, c_i) straight away -- element e of the block at s[e + e / GAE_CHUNK], one pad word per chunk so that the
+// lanes of a wave, GAE_CHUNK + 1 words apart, spread over the banks -- and the replay's results leave the same way (round 3: K5
+// at 1.6 M samples 142 -> see DESIGN section 4).
 constexpr int GAE_BLOCK_ELEMS = 256 * GAE_CHUNK;
-constexpr int GAE_LDS_DOUBLES = 2 * (GAE_BLOCK_ELEMS + GAE_BLOCK_ELEMS / 32);
-__device__ __forceinline__ int gae_pad(int e) { return e + (e >> 5); }
+constexpr int GAE_LDS_DOUBLES = 2 * (GAE_BLOCK_ELEMS + GAE_BLOCK_ELEMS / GAE_CHUNK);
+__device__ __forceinline__ int gae_pad(int e) { return e + e / GAE_CHUNK; }      // one pad word per chunk: lanes GAE_CHUNK + 1 words apart
 
 template <typename T>
 __device__ __forceinline__ void gae_stage(const T *__restrict__ r, const T *__restrict__ mk, const T *__restrict__ v, int n, double gamma,
@@ -1947,12 +1949,12 @@ static int launch_gae(const T *r, const T *mk, const T *v, int n, double gamma, 
     EGP_REQUIRE(n > 0, "n must be positive");
     const int n_chunks = (n + GAE_CHUNK - 1) / GAE_CHUNK;
     const int n_blocks = (n_chunks + 255) / 256;
-    // three levels: 32-sample chunks (one thread each) -> blocks of 256 chunks (composed / scanned in LDS) -> ONE block over the
+    // three levels: GAE_CHUNK-sample chunks (one thread each) -> blocks of 256 chunks (composed / scanned in LDS) -> ONE block over the
     // block maps. (Two levels with one block scanning all chunks took 177 of 364 us at 1.6 M samples.)
     double *chunkP = (double *)ws, *chunkA = chunkP + n_chunks, *part = chunkA + n_chunks, *blockP = part + 3 * n_blocks,
            *blockA = blockP + n_blocks, *block_carry = blockA + n_blocks;
     hipStream_t s = (hipStream_t)stream;
-    constexpr size_t lds = (size_t)GAE_LDS_DOUBLES * sizeof(double);          // the block's (delta, c) pairs, padded (132 KiB)
+    constexpr size_t lds = (size_t)GAE_LDS_DOUBLES * sizeof(double);          // the block's (delta, c) pairs, padded
     static const hipError_t attr = [] {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gae_summary<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gae_replay<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
