@@ -40,6 +40,27 @@ def test_body_quat_and_obs_golden(ctx, dtype, tol):
     np.testing.assert_allclose(obs, g["obs"], rtol=tol, atol=tol * 10)
 
 
+def test_body_quat_angle_range(ctx, skel):
+    """The kernels' own float64 sincos (two-FMA Cody-Waite reduction, egp_quat.hpp) against the oracle's libm over the whole
+    range it serves -- many turns, the reduction's quadrant boundaries -- and beyond 2^18 rad, where it hands over to the
+    library routine."""
+    rng = np.random.RandomState(3)
+    n = 4096
+    qpos = np.zeros((n, 59))
+    qpos[:, 3] = 1.0
+    ang = np.concatenate([rng.uniform(-1e3, 1e3, (n // 4, 52)), rng.uniform(-2.5e5, 2.5e5, (n // 4, 52)),
+                          (rng.randint(-4000, 4000, (n // 4, 52)) + rng.choice([0.0, 1e-9, -1e-9, 0.5], (n // 4, 52))) * (np.pi / 2),
+                          rng.uniform(-3e6, 3e6, (n // 4, 52))])
+    qpos[:, 7:] = ang
+    want = H.body_quat(qpos, skel.body_qpos_start, skel.body_ndof)
+    got = ctx.body_quat(dev(qpos, torch.float64)).cpu().numpy()
+    # half-angles up to 1.5e6 rad: one ulp of the ARGUMENT is 2e-10 there, the small ranges must hold 1e-12
+    np.testing.assert_allclose(got[: n // 4], want[: n // 4], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(got[n // 4: 3 * n // 4], want[n // 4: 3 * n // 4], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(got[3 * n // 4:], want[3 * n // 4:], rtol=0, atol=2e-9)
+    np.testing.assert_allclose(np.linalg.norm(got.reshape(n, 21, 4), axis=2), 1.0, rtol=0, atol=1e-12)
+
+
 def test_obs_and_body_quat_edge_sizes(ctx):
     g = load_golden("body_quat_obs.npz")
     assert ctx.body_quat(dev(g["qpos"][:0])).shape == (0, 84)          # empty batch is a no-op
