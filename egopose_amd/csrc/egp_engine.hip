@@ -247,6 +247,17 @@ __global__ void k_engine_spin(long long us) {
     while (wall_clock64() - t0 < us * 100) __builtin_amdgcn_s_sleep(32);
 }
 
+// diagnostic (egp_debug_burn): keep `gridDim.x` workgroups arithmetically busy for `us` microseconds
+__global__ __launch_bounds__(256) void k_engine_burn(long long us, float *sink) {
+    const long long t0 = wall_clock64();
+    float a = threadIdx.x * 1e-3f, b = 1.0001f;
+    while (wall_clock64() - t0 < us * 100) {
+#pragma unroll
+        for (int i = 0; i < 256; ++i) a = fmaf(a, b, 1e-7f);
+    }
+    if (a == 123.456f) *sink = a;
+}
+
 __global__ __launch_bounds__(256) void k_engine_reset_scatter(const int *__restrict__ list, const double *__restrict__ h_state, int ld_s,
                                                               int off_qpos, int off_qvel, const double *__restrict__ h_ee,
                                                               const double *__restrict__ h_qM, int ld_m, int nM, int nq, int nv,
@@ -1409,6 +1420,13 @@ int egp_rollout_reset(const egp_rollout_tick *d, int32_t group, int32_t a, int32
                              d->states + ((size_t)(k + 1) * d->n_env + a) * d->obs_dim, nullptr, 1, d->zf_workspace, s);
     if (rc == EGP_OK && d->group_streams) EGP_HIP_CHECK(hipEventRecord(d->eng->groups[group].chain_done, s));
     return rc;
+}
+
+int egp_debug_burn(int64_t us, int32_t blocks, float *sink, void *stream) {
+    EGP_REQUIRE(us > 0 && blocks > 0 && sink, "bad arguments");
+    k_engine_burn<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>((long long)us, sink);
+    EGP_HIP_CHECK(hipGetLastError());
+    return EGP_OK;
 }
 
 double egp_engine_event_overhead_ms(egp_engine *E) {

@@ -616,6 +616,9 @@ void *egp_engine_group_stream(egp_engine *e, int32_t group);
  * must synchronise with the device before reading `reward` / `cinfo`. */
 int egp_engine_set_reward_job(egp_engine *e, int32_t group, const int32_t *t, const int32_t *frame, const int32_t *end,
                               const int32_t *active, double end_reward, double *reward, double *cinfo);
+/* diagnostic: `blocks` workgroups of arithmetic for `us` microseconds on `stream` (does a busy GPU clock the rollout's short
+ * kernels differently? tools/probes/burn_probe.py); `sink` = any device float */
+int egp_debug_burn(int64_t us, int32_t blocks, float *sink, void *stream);
 int egp_engine_launches_per_substep(egp_engine *e);
 /* substeps one K1 launch serves: frame_skip when the engine runs the resident K1 (one launch per env-step that
  * trades go/done words with the physics threads through pinned memory; EGP_SERVER=0 turns it off), else 1 */
