@@ -262,6 +262,29 @@ def test_zfilter_blocks_match_sequential_reference(ctx, dtype, tol):
     np.testing.assert_allclose(ys[-1].cpu().numpy()[-1], g["Y"][-1], rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("n", [16385, 40000])
+def test_zfilter_two_level_merge_continues_a_running_state(ctx, n):
+    """More than 256 statistics tiles (> 16 384 rows): 16 workgroups reduce the tiles to 16 records and the apply kernel merges
+    those into the running state itself. Against the oracle's sequential merge, starting from a non-empty state, with a mask."""
+    rng = np.random.RandomState(n)
+    dim = 115
+    X0 = rng.normal(size=(3000, dim)) * 2 - 0.5
+    X = rng.normal(size=(n, dim)) * np.linspace(0.5, 4.0, dim) + np.linspace(-2, 2, dim)
+    act = (rng.uniform(size=n) < 0.8).astype(np.int32)
+    st0 = torch.zeros(1 + 2 * dim, dtype=torch.float64, device="cuda")
+    st1, st2 = torch.empty_like(st0), torch.empty_like(st0)
+    ctx.zfilter(dev(X0), st0, st1, update=True, clip=5.0)
+    y = ctx.zfilter(dev(X), st1, st2, update=True, clip=5.0, active=torch.as_tensor(act, device="cuda")).cpu().numpy()
+    rs = Z.RunningStatOracle(dim)
+    rs.merge_block(X0)
+    rs.merge_block(X[act == 1])
+    s = st2.cpu().numpy()
+    assert s[0] == 3000 + act.sum()
+    np.testing.assert_allclose(s[1:1 + dim], rs.mean, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(s[1 + dim:], rs.S, rtol=1e-10)
+    np.testing.assert_allclose(y, Z.zfilter_apply(X, rs.mean, rs.std, 5.0), rtol=1e-10, atol=1e-10)
+
+
 def test_zfilter_active_mask_and_large(ctx):
     rng = np.random.RandomState(0)
     n, dim = 5000, 115
