@@ -211,7 +211,11 @@ struct egp_engine {
     double *hd_state = nullptr, *hd_torque = nullptr, *hd_qM = nullptr, *hd_ee = nullptr;   // device-side aliases of h_state / h_torque / h_qM
     // Resident-K1 mode: the slices' go words live in FINE-GRAINED DEVICE memory that the host threads write through the PCIe
     // BAR (posted stores); the resident waves then poll HBM instead of host memory -- one PCIe read round trip less per
-    // substep. Opt-in (EGP_BAR_GO=1): T_sample -1 .. -3 ms on two boxes, nothing on a third, i.e. within the spread.
+    // substep. Opt-in (EGP_BAR_GO=1). Round 2: -1 .. -3 ms on two boxes, nothing on a third. Round 3, in-lease A/B
+    // (tools/probes/ab_env.sh): seven alternating pairs of nine rollouts on two boxes, median T_sample 94.5 against 99.9 ms -- but
+    // a heavier tail (single rollouts of 136 / 165 / 228 ms, the pulled form's worst were 121 / 127 / 135), and under bench.py
+    // (three iterations per run, tools/probes/ab_bench_bar.sh) 880 / 664 / 925 k against 840 / 895 / 839 k env-steps/s: a better
+    // median bought with rare long stalls of the host's posted stores. Left off: a three-step bench pays for one stall with 20 %.
     // The state rows stay in pinned host memory in any case: mirroring them the same
     // way was built and measured (tools/probes/bar_pingpong.hip: 4.7 instead of 8.1 us per round trip for ONE wave's four
     // rows), but a host thread's write-combined stores move ~0.4 us per env and substep one after the other where the
@@ -875,7 +879,7 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     memset(E->h_state, 0, N * E->ld_s * sizeof(double));
     {
         const char *bg = getenv("EGP_BAR_GO");
-        E->bar_go = E->zero_copy && E->hd_state && bg && atoi(bg) != 0;       // opt-in: within the run-to-run spread (see the field)
+        E->bar_go = E->zero_copy && E->hd_state && bg && atoi(bg) != 0;       // opt-in (see the field)
     }
     memset(E->h_qM, 0, N * E->ld_m * sizeof(double));
     memset(E->h_headz, 0, N * sizeof(double));
