@@ -733,6 +733,7 @@ class LockstepRollout:
 
         if fast:
             pre_step, post_step = (pre_native, post_native) if tickd is not None else (pre_fast, post_fast)
+        tm["setup"] = time.time() - t_start          # tables, record arrays, first reset of every slot, noise (host time: launches are asynchronous)
         for g in range(len(self.groups)):
             pre_step(g)
         live = [True] * len(self.groups)
@@ -749,6 +750,7 @@ class LockstepRollout:
                     live[g] = False
 
         # ---- episode-major batch: slot by slot, each slot's ticks in order
+        t_loop_end = time.time()
         torch.cuda.synchronize(dev)              # reward launches of the last env-steps live on the engine's streams
         T_used = max(tick)
         valid = host["valid"][:T_used]                                  # (T, N)
@@ -769,6 +771,7 @@ class LockstepRollout:
         if self.running_state is not None:
             self.running_state.from_device_state(self.zf_state)
         torch.cuda.synchronize(dev)
+        tm["assemble"] = time.time() - t_loop_end     # episode-major gather of the record, logger totals, filter state back to the host
         log.sample_time = time.time() - t_start
         tm.update(ticks=T_used, quota=quota, step_budget=budget, policy_graph=self._graphs is not None, **eng.timing())
         self.timing = tm

@@ -20,6 +20,7 @@ tm = tr.agent._get_rollout().timing
 print("T_sample ms: median %.2f  min %.2f  max %.2f  (%d steps, %d ticks; wait %.1f policy %.1f post %.1f reset %.1f ms; small ticks %d / %.1f ms)" % (
     ts[len(ts) // 2], ts[0], ts[-1], ns[-1], tm["ticks"], tm["wait"] * 1e3, tm["policy"] * 1e3, tm["post"] * 1e3, tm["reset"] * 1e3,
     tm["small_group_ticks"], tm["small_group_tick_s"] * 1e3))
+print("   outside the tick loop: set-up %.1f ms, batch assembly %.1f ms" % (tm.get("setup", 0) * 1e3, tm.get("assemble", 0) * 1e3))
 print("   engine: phys %.1f ms  gpu_wait %.1f ms (timekeeper threads, summed over groups), k1 %.1f ms / %d launches" % (
     tm.get("phys_s", 0) * 1e3, tm.get("gpu_wait_s", 0) * 1e3, tm.get("k1_ms", 0), tm.get("k1_launches", 0)))
 tr.close()
