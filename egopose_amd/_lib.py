@@ -118,7 +118,7 @@ class RolloutTick(C.Structure):
                 ("slab_host", vp), ("slab_dev", vp),
                 ("qpos", vp), ("qvel", vp), ("prev_qpos", vp), ("ee", vp),
                 ("zf_workspace", vp), ("reset_scratch", vp),
-                ("group_streams", C.c_int32), ("post_fused", C.c_int32)]
+                ("group_streams", C.c_int32), ("post_fused", C.c_int32), ("defer_apply", C.c_int32)]
 
 
 class EngineDesc(C.Structure):
@@ -187,7 +187,13 @@ SIGNATURES = {
     "egp_lstm_bwd_f32": (C.c_int, [vp, vp, vp, vp, _i32, _i32, _i32, _i32, vp, vp]),
     "egp_lstm_group_fwd_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_void_p), _i32, vp, vp, vp]),
     "egp_lstm_group_bwd_f32": (C.c_int, [C.POINTER(C.c_void_p), _i32, vp, vp, vp, _i32, _i32, _i32, _i32, _i32, vp, vp, vp]),
-    "egp_rollout_tick_pre": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp]),
+    "egp_rollout_tick_pre": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, _i32, vp, vp]),
+    "egp_rollout_tick_apply": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, vp]),
+    "egp_obs_zfilter_split_max_rows": (C.c_int32, []),
+    "egp_obs_zfilter_stats_f64": (C.c_int, [vp, vp, vp, vp, _i32, vp, vp]),
+    "egp_obs_zfilter_apply_f64": (C.c_int, [vp, vp, vp, _i32, vp, vp, C.c_double, vp, vp, vp, vp]),
+    "egp_policy_gaussian_filter_f32": (C.c_int, [vp, vp, C.c_int64, _i32, vp, vp, vp, _i32, vp, vp, C.c_double, vp, vp, vp,
+                                                vp, _i32, _i32, vp, vp, vp, vp, vp, vp, C.c_int64, vp]),
     "egp_rollout_tick_post": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp]),
     "egp_rollout_reset": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, _i32, vp, vp, vp, vp, vp, vp, _i32, vp, vp]),
     "egp_engine_group_stream": (vp, [vp, _i32]),

@@ -1238,8 +1238,10 @@ inline hipError_t follow_caller_stream(const egp_rollout_tick *d, hipStream_t s)
 }
 }  // namespace
 
-int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, void *ready_event) {
+int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, void *ready_event,
+                         int32_t apply_pending, const double *zf_cur, double *zf_new) {
     EGP_REQUIRE(d && d->ctx && d->eng && (ready_event || d->group_streams), "NULL pointer");
+    EGP_REQUIRE(!apply_pending || (d->defer_apply && k > 0 && zf_cur && zf_new), "a pending apply pass needs defer_apply, k > 0 and the filter states");
     EGP_REQUIRE(group >= 0 && group < d->eng->n_groups, "group out of range");
     EGP_REQUIRE(0 <= a && a < b && b <= d->n_env && b - a <= d->nmax && k >= 0, "slot range / tick out of range");
     EGP_REQUIRE(!d->group_streams || !d->reward_job, "group-stream ticks launch the reward themselves (reward_job = 0)");
@@ -1268,7 +1270,19 @@ int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, in
     const size_t row = (size_t)k * N + a;
     // flags_upload: 1 = a copy-engine transfer in front of the policy step; 2 (default) = the policy kernel moves the slab
     // itself and reads its context-row indices straight from the pinned copy (one dependent operation less per tick)
-    if (d->flags_upload == 2) {
+    if (apply_pending) {
+        // the apply pass of the previous env-step's filter (its statistics pass ran in `post`) rides in this policy step:
+        // next_states[k - 1] and states[k] are written on the way into the MLP
+        if (d->flags_upload == 1 && (rc = egp_upload_async(fbase, d->slab_host + soff, 24 * (int64_t)nmax, ts)) != EGP_OK) return rc;
+        const bool staged = d->flags_upload == 2;
+        rc = egp_policy_gaussian_filter_f32(d->ctx, d->v_out + (size_t)a * d->v_stride, d->v_stride, d->ctx_dim,
+                                            reinterpret_cast<const int64_t *>((staged ? d->slab_host : d->slab_dev) + soff + 16 * (size_t)nmax),
+                                            d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, n, zf_cur, zf_new, d->zf_clip,
+                                            d->next_states + (row - N) * d->obs_dim, d->states + row * d->obs_dim, d->zf_workspace,
+                                            d->layers, d->n_layers, d->activation, d->log_std,
+                                            d->noise ? d->noise + row * d->nu : nullptr, d->actions + row * d->nu, nullptr,
+                                            staged ? d->slab_host + soff : nullptr, staged ? fbase : nullptr, staged ? 24 * (int64_t)nmax : 0, ts);
+    } else if (d->flags_upload == 2) {
         rc = egp_policy_gaussian_staged_f32(d->v_out + (size_t)a * d->v_stride, d->v_stride, d->ctx_dim,
                                             reinterpret_cast<const int64_t *>(d->slab_host + soff + 16 * (size_t)nmax),
                                             d->states + row * d->obs_dim, d->obs_dim, n, d->layers, d->n_layers, d->activation, d->log_std,
@@ -1328,8 +1342,11 @@ int egp_rollout_tick_post(const egp_rollout_tick *d, int32_t group, int32_t a, i
                                d->rewards + row, d->cinfo + row * 5, ts);
         if (rc != EGP_OK) return rc;
     } else {
-        rc = egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, f32 + 3 * nmax, n, zf_cur, zf_new, d->zf_clip,
-                                 d->next_states + row * d->obs_dim, d->states + (row + N) * d->obs_dim, 0, d->zf_workspace, ts);
+        if (d->defer_apply)     // statistics pass only: the apply pass is egp_rollout_tick_apply or the next tick's policy step
+            rc = egp_obs_zfilter_stats_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, f32 + 3 * nmax, n, d->zf_workspace, ts);
+        else
+            rc = egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, f32 + 3 * nmax, n, zf_cur, zf_new, d->zf_clip,
+                                     d->next_states + row * d->obs_dim, d->states + (row + N) * d->obs_dim, 0, d->zf_workspace, ts);
         if (rc != EGP_OK) return rc;
         if (!d->reward_job) {
             // group-stream ticks: K2 leaves the group's queue (nothing of the next tick depends on it) for the caller's
@@ -1431,6 +1448,18 @@ int egp_debug_burn(int64_t us, int32_t blocks, float *sink, void *stream) {
     k_engine_burn<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>((long long)us, sink);
     EGP_HIP_CHECK(hipGetLastError());
     return EGP_OK;
+}
+
+// defer_apply: the apply pass of tick k's filter on its own (a tick with in-batch resets -- their masked pass needs the merged
+// statistics -- or a group's last tick); otherwise it rides in the next egp_rollout_tick_pre
+int egp_rollout_tick_apply(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, const double *zf_cur, double *zf_new) {
+    EGP_REQUIRE(d && d->ctx && d->eng && d->defer_apply && zf_cur && zf_new, "NULL pointer / defer_apply is off");
+    EGP_REQUIRE(group >= 0 && group < d->eng->n_groups, "group out of range");
+    EGP_REQUIRE(0 <= a && a < b && b <= d->n_env && b - a <= d->nmax && k >= 0, "slot range / tick out of range");
+    const size_t row = (size_t)k * d->n_env + a;
+    return egp_obs_zfilter_apply_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, b - a, zf_cur, zf_new, d->zf_clip,
+                                     d->next_states + row * d->obs_dim, d->states + (row + d->n_env) * d->obs_dim, d->zf_workspace,
+                                     tick_stream(d, group));
 }
 
 double egp_engine_event_overhead_ms(egp_engine *E) {

@@ -24,6 +24,7 @@
 #include "egp_internal.hpp"
 #include "egp_dynamics_dev.hpp"
 #include "egp_quat.hpp"
+#include "egp_filter_dev.hpp"
 
 namespace egp {
 
@@ -63,48 +64,7 @@ __global__ __launch_bounds__(256) void k_body_quat(DevModel m, const T *__restri
 }
 
 // ============================================================================================ K3
-// get_full_obs (ego_pose/envs/humanoid_v1.py:73-96): obs = [qpos[2:] (root quat de-headed), qvel
-// (root linear velocity in the heading frame)]
-// Observation variants (cfg.obs_heading / root_deheading / obs_coord / obs_vel), all zero for every shipped config.
-struct ObsOpt { int heading, keep, root, vel, np, nv; };
-__host__ __device__ inline ObsOpt obs_opt_of(const DevModel &m) { return ObsOpt{m.obs_heading, m.obs_keep, m.obs_root, m.obs_vel, m.nq - 2, m.nv}; }
-__host__ __device__ inline int obs_width(int nq, int nv, int heading, int vel) {
-    return (heading ? 1 : 0) + (nq - 2) + (vel == 0 ? nv : (vel == 1 ? 6 : 0));
-}
-
-// one element of get_full_obs (humanoid_v1.py:73-96) for env row (q, v): column c of
-// [heading]? ++ qpos[2:] (root quat de-headed unless `keep`) ++ {qvel | qvel[:6] | -} (root linear velocity in the
-// heading frame, or in the root frame with `root`)
-template <typename T>
-__device__ __forceinline__ T obs_element(const T *q, const T *v, const ObsOpt &o, int c) {
-    if (o.heading) {
-        if (c == 0) {        // get_heading (utils/math.py:70-77): angle of the yaw-only quaternion, z made non-negative
-            T w = q[3], z = q[6];
-            if (z < T(0)) { w = -w; z = -z; }
-            if (sizeof(T) == 8) return T(2) * t_acos<T>(w / t_sqrt<T>(w * w + z * z));
-            return T(2) * (T)atan2f((float)z, (float)w);          // float32: acos loses its digits near w = 1
-        }
-        c -= 1;
-    }
-    const int np = o.np;
-    T out;
-    if (c >= 1 && c <= 4 && !o.keep) {
-        Q4<T> r{q[3], q[4], q[5], q[6]};
-        Q4<T> d = de_heading(r);
-        out = c == 1 ? d.w : (c == 2 ? d.x : (c == 3 ? d.y : d.z));
-    } else if (c < np) {
-        out = q[c + 2];
-    } else if (c < np + 3) {
-        Q4<T> r{q[3], q[4], q[5], q[6]};
-        V3<T> lv{v[0], v[1], v[2]};
-        V3<T> w = rotate_T(o.root ? r : heading_q(r), lv);
-        const int k = c - np;
-        out = k == 0 ? w.x : (k == 1 ? w.y : w.z);
-    } else {
-        out = v[c - np];
-    }
-    return out;
-}
+// (ObsOpt, obs_element: egp_filter_dev.hpp)
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_obs(DevModel m, const T *__restrict__ qpos, const T *__restrict__ qvel,
@@ -956,16 +916,7 @@ __global__ __launch_bounds__(256) void k_pose_features(DevModel m, const T *__re
 // ============================================================================================ K6
 // RunningStat / ZFilter (utils/zfilter.py:7-67), batched.
 // partial layout per tile p: ws[p*(1+2*dim)] = count, then mean[dim], then M2[dim]  (float64)
-// Source of the rows being filtered: a dense array x[n][dim], or (x == nullptr) the observation computed on the
-// fly from the drained state (K3 fused into K6: no intermediate raw-observation array)
-template <typename T>
-struct ZfSrc {
-    const T *x; const T *qpos; const T *qvel; int nq, nv, dim;
-    ObsOpt opt;
-    __device__ __forceinline__ T at(long r, int c) const {
-        return x ? x[r * dim + c] : obs_element<T>(qpos + r * nq, qvel + r * nv, opt, c);
-    }
-};
+// (ZfSrc, zf_merge_column: egp_filter_dev.hpp)
 
 // tile statistics: a workgroup is G = blockDim / 128 row groups x 128 columns. A thread takes its group's share of the
 // tile's rows in chunks of 8 (8 independent loads in flight, then an exact two-pass mean / M2 of the chunk, Chan-merged
@@ -1060,36 +1011,6 @@ __global__ __launch_bounds__(256) void k_post_step(ZfSrc<T> src, const int *__re
     else
         reward_body<T, 1>(m, w, expert_rows, src.qpos, prev_qpos, ee_wpos, tcur, frame, endf, zf_active, end_reward, n, reward, cinfo,
                        (int)blockIdx.x - n_tiles);
-}
-
-// Chan-merge of the tile partials of column c into the running state, fixed order (deterministic)
-__device__ __forceinline__ void zf_merge_column(int dim, int n_tiles, const double *__restrict__ ws, const double *__restrict__ st_in,
-                                                int c, double &cnt, double &mean, double &S) {
-    cnt = st_in[0]; mean = st_in[1 + c]; S = st_in[1 + dim + c];
-    for (int q0 = 0; q0 < n_tiles; q0 += 8) {
-        double nb[8], mb[8], Sb[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {          // 24 independent loads in flight, then the ordered merge
-            const int q = q0 + i;
-            const double *pp = ws + (long)(q < n_tiles ? q : 0) * (1 + 2 * dim);
-            nb[i] = q < n_tiles ? pp[0] : 0.0;
-            mb[i] = pp[1 + c];
-            Sb[i] = pp[1 + dim + c];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (nb[i] > 0.0) {
-                if (cnt == 0.0) {
-                    cnt = nb[i]; mean = mb[i]; S = Sb[i];
-                } else {
-                    const double d = mb[i] - mean, tot = cnt + nb[i];
-                    S = S + Sb[i] + d * d * (cnt * nb[i] / tot);
-                    mean = mean + d * (nb[i] / tot);
-                    cnt = tot;
-                }
-            }
-        }
-    }
 }
 
 // one block: the merged state of a batch with many tiles (few tiles: k_zf_apply merges them itself). 8 tile groups x 128
@@ -1840,16 +1761,6 @@ static int launch_features(egp_ctx *ctx, const T *cur, const T *prev, const T *e
     return after_launch("k_pose_features");
 }
 
-// 64-row tiles (8 rows per thread of a 1 024-thread workgroup) while that gives <= 512 partials, larger tiles beyond.
-// Up to ZF_FUSED_TILES partials the apply kernel merges them itself (two launches per update), beyond that k_zf_merge does.
-constexpr int ZF_FUSED_TILES = 16;
-static inline void zf_tiling(int n, int *rows_per_tile, int *n_tiles) {
-    int rpt = 64;
-    while ((n + rpt - 1) / rpt > 512) rpt *= 2;
-    *rows_per_tile = rpt;
-    *n_tiles = n > 0 ? (n + rpt - 1) / rpt : 1;
-}
-
 template <typename T>
 static int launch_zfilter_src(const ZfSrc<T> &src, const int *active, int n, int dim, const double *st_in, double *st_out, int update,
                               double clip, T *y, T *y2, const int *write_mask, void *ws, void *stream) {
@@ -2053,6 +1964,32 @@ int egp_obs_zfilter_f64(egp_ctx *c, const double *qpos, const double *qvel, cons
 int egp_obs_zfilter_f32(egp_ctx *c, const float *qpos, const float *qvel, const int32_t *active, int32_t n, const double *si,
                         double *so, double clip, float *y, float *y2, int32_t write_only_active, void *ws, void *s) {
     return launch_obs_zfilter<float>(c, qpos, qvel, active, n, si, so, clip, y, y2, write_only_active, ws, s);
+}
+// egp_obs_zfilter_f64 in two calls, for batches of at most egp_obs_zfilter_split_max_rows() rows (the apply pass merges the tile
+// statistics itself there): _stats = the first launch, _apply = the second, same kernels with the same arguments. Whoever runs
+// the apply pass may instead be the policy step of the next tick (egp_policy_gaussian_filter_f32).
+int32_t egp_obs_zfilter_split_max_rows(void) { return 64 * ZF_FUSED_TILES; }
+int egp_obs_zfilter_stats_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const int32_t *active, int32_t n, void *ws, void *stream) {
+    EGP_REQUIRE(ctx && ws, "NULL pointer");
+    EGP_REQUIRE(n > 0 && n <= 64 * ZF_FUSED_TILES && qpos && qvel, "1 .. egp_obs_zfilter_split_max_rows() rows");
+    const int dim = ctx->dm.obs_dim;
+    ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm)};
+    int rpt, nt;
+    zf_tiling(n, &rpt, &nt);
+    k_zf_partial<double><<<dim3(nt), dim3(1024), 0, (hipStream_t)stream>>>(src, active, n, dim, rpt, (double *)ws);
+    return after_launch("k_zf_partial");
+}
+int egp_obs_zfilter_apply_f64(egp_ctx *ctx, const double *qpos, const double *qvel, int32_t n, const double *st_in, double *st_out,
+                              double clip, double *y, double *y2, void *ws, void *stream) {
+    EGP_REQUIRE(ctx && ws && st_in && st_out && st_in != st_out && y, "NULL pointer / state_out must differ from state_in");
+    EGP_REQUIRE(n > 0 && n <= 64 * ZF_FUSED_TILES && qpos && qvel, "1 .. egp_obs_zfilter_split_max_rows() rows");
+    const int dim = ctx->dm.obs_dim;
+    ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm)};
+    int rpt, nt;
+    zf_tiling(n, &rpt, &nt);
+    k_zf_apply<double><<<dim3((n + 7) / 8), dim3(128), 2 * dim * sizeof(double), (hipStream_t)stream>>>(
+        src, n, dim, 8, st_in, clip, y, y2, nullptr, 0, (const double *)ws, nt, st_out);
+    return after_launch("k_zf_apply");
 }
 
 int egp_upload_async(void *dst_device, const void *src_pinned, int64_t bytes, void *stream) {

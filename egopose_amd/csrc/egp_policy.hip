@@ -11,8 +11,21 @@
 #include <stdlib.h>
 
 #include "egp_internal.hpp"
+#include "egp_filter_dev.hpp"
 
 namespace {
+
+// The filter's apply pass folded into the policy step (egp_policy_gaussian_filter_f32): the observation rows of the tile are
+// formed, normalised with the running statistics merged from the tick's tile partials (exactly k_zf_apply's arithmetic: same
+// merge order, same expression, float64) and written to next_states[k] / states[k + 1] on their way into the MLP's input -- one
+// launch and its dependent memory round trips less on the chain filter -> policy -> env-step of every tick without a reset.
+struct PolFilter {
+    egp::ZfSrc<double> src;          // rows of the group: observation from (qpos, qvel)
+    const double *st_in; double *st_out;
+    const double *ws; int n_tiles;
+    double clip;
+    double *y, *y2;                  // [n][dim] each (y2 may be NULL)
+};
 
 constexpr int POL_ROWS = 4;          // rows per workgroup
 constexpr int POL_MAX_LAYERS = 8;
@@ -37,13 +50,31 @@ __device__ __forceinline__ float pol_act(float v, int kind) {
 // on the chain filter -> policy -> env-step of every tick) the workgroups copy the slab to its device copy themselves -- the
 // kernels that run after the env-step (reward, filter) read it there -- and take their own rows' indices (`t_idx`, which then
 // points into the pinned slab) with ONE load per row.
+template <bool FILTER>
 __global__ void k_policy_gaussian(const float *__restrict__ ctx_rows, long ctx_row_stride, int ctx_dim,
                                   const long long *__restrict__ t_idx, const double *__restrict__ state, int state_dim, int n,
                                   PolLayers L, int act_kind, int kmax, int part_elems, const float *__restrict__ log_std,
                                   const float *__restrict__ noise, double *__restrict__ action, float *__restrict__ mean_out,
-                                  const unsigned *__restrict__ stage_src, unsigned *__restrict__ stage_dst, int stage_words) {
-    extern __shared__ float4 s_act[];     // cur[kmax] | nxt[kmax] | part[part_elems]   (one float per row of the tile)
+                                  const unsigned *__restrict__ stage_src, unsigned *__restrict__ stage_dst, int stage_words,
+                                  PolFilter F) {
+    extern __shared__ float4 s_act[];     // cur[kmax] | nxt[kmax] | part[part_elems]   (one float per row of the tile) [| mean, inv: 2 dim doubles]
     __shared__ long long s_ti[POL_ROWS];
+    double *s_ms = reinterpret_cast<double *>(s_act + 2 * kmax + part_elems);
+    if constexpr (FILTER) {               // k_zf_apply's first phase: the merged statistics, every workgroup for itself
+        const int dim = state_dim;
+        for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+            double cnt, mean, S;
+            egp::zf_merge_column(dim, F.n_tiles, F.ws, F.st_in, c, cnt, mean, S);
+            if (blockIdx.x == 0) {
+                F.st_out[1 + c] = mean;
+                F.st_out[1 + dim + c] = S;
+                if (c == 0) F.st_out[0] = cnt;
+            }
+            const double var = cnt > 1.0 ? S / (cnt - 1.0) : mean * mean;
+            s_ms[c] = mean;
+            s_ms[dim + c] = 1.0 / (sqrt(var) + 1e-8);
+        }
+    }
     float4 *cur = s_act, *nxt = s_act + kmax, *part = s_act + 2 * kmax;
     const int r0 = blockIdx.x * POL_ROWS;
     const int in0 = ctx_dim + state_dim;
@@ -57,8 +88,19 @@ __global__ void k_policy_gaussian(const float *__restrict__ ctx_rows, long ctx_r
         for (int r = 0; r < POL_ROWS; ++r) {
             const int row = r0 + r;
             if (row >= n) { v[r] = 0.0f; continue; }
-            v[r] = k < ctx_dim ? ctx_rows[(long)row * ctx_row_stride + (long)s_ti[r] * ctx_dim + k]
-                               : (float)state[(long)row * state_dim + (k - ctx_dim)];
+            if (k < ctx_dim) {
+                v[r] = ctx_rows[(long)row * ctx_row_stride + (long)s_ti[r] * ctx_dim + k];
+            } else if constexpr (FILTER) {            // k_zf_apply's second phase for this element
+                const int c = k - ctx_dim;
+                double x = ((double)F.src.at(row, c) - s_ms[c]) * s_ms[state_dim + c];
+                if (F.clip > 0.0) x = fmin(fmax(x, -F.clip), F.clip);
+                const long e = (long)row * state_dim + c;
+                F.y[e] = x;
+                if (F.y2) F.y2[e] = x;
+                v[r] = (float)x;
+            } else {
+                v[r] = (float)state[(long)row * state_dim + (k - ctx_dim)];
+            }
         }
         cur[k] = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -145,11 +187,12 @@ __global__ void k_policy_gaussian(const float *__restrict__ ctx_rows, long ctx_r
 static int policy_launch(const float *ctx_rows, int64_t ctx_row_stride, int32_t ctx_dim, const int64_t *t_idx,
                          const double *state, int32_t state_dim, int32_t n, const egp_mlp_layer *layers,
                          int32_t n_layers, int32_t activation, const float *log_std, const float *noise,
-                         double *action, float *mean_out, const void *stage_src, void *stage_dst, int64_t stage_bytes, void *stream) {
+                         double *action, float *mean_out, const void *stage_src, void *stage_dst, int64_t stage_bytes, void *stream,
+                         const PolFilter *flt = nullptr) {
     EGP_REQUIRE(n >= 0, "n < 0");
     EGP_REQUIRE(stage_bytes >= 0 && stage_bytes % 4 == 0 && stage_bytes < (1ll << 31) && (stage_bytes == 0 || (stage_src && stage_dst)), "bad staging slab");
     if (n == 0) return EGP_OK;
-    EGP_REQUIRE(ctx_rows && t_idx && state && layers && action, "NULL pointer");
+    EGP_REQUIRE(ctx_rows && t_idx && (state || flt) && layers && action, "NULL pointer");
     EGP_REQUIRE(!noise || log_std, "noise needs log_std");
     EGP_REQUIRE(n_layers >= 1 && n_layers <= POL_MAX_LAYERS, "1..8 layers (hidden layers + output layer)");
     EGP_REQUIRE(activation >= 0 && activation <= 2, "activation: 0 tanh, 1 relu, 2 sigmoid");
@@ -175,11 +218,17 @@ static int policy_launch(const float *ctx_rows, int64_t ctx_row_stride, int32_t 
         const int e = G * ncol * 4;
         if (e > part_elems) part_elems = e;
     }
-    const size_t lds = ((size_t)2 * kmax + part_elems) * sizeof(float4);
+    const size_t lds = ((size_t)2 * kmax + part_elems) * sizeof(float4) + (flt ? (size_t)2 * state_dim * sizeof(double) : 0);
     EGP_REQUIRE(lds <= 150 * 1024, "layers too wide for the LDS tile");
-    k_policy_gaussian<<<dim3((n + POL_ROWS - 1) / POL_ROWS), dim3(threads), lds, (hipStream_t)stream>>>(
-        ctx_rows, (long)ctx_row_stride, ctx_dim, (const long long *)t_idx, state, state_dim, n, L, activation, kmax, part_elems,
-        log_std, noise, action, mean_out, stage_bytes ? (const unsigned *)stage_src : nullptr, (unsigned *)stage_dst, (int)(stage_bytes / 4));
+    const dim3 grid((n + POL_ROWS - 1) / POL_ROWS), block(threads);
+    if (flt)
+        k_policy_gaussian<true><<<grid, block, lds, (hipStream_t)stream>>>(
+            ctx_rows, (long)ctx_row_stride, ctx_dim, (const long long *)t_idx, state, state_dim, n, L, activation, kmax, part_elems,
+            log_std, noise, action, mean_out, stage_bytes ? (const unsigned *)stage_src : nullptr, (unsigned *)stage_dst, (int)(stage_bytes / 4), *flt);
+    else
+        k_policy_gaussian<false><<<grid, block, lds, (hipStream_t)stream>>>(
+            ctx_rows, (long)ctx_row_stride, ctx_dim, (const long long *)t_idx, state, state_dim, n, L, activation, kmax, part_elems,
+            log_std, noise, action, mean_out, stage_bytes ? (const unsigned *)stage_src : nullptr, (unsigned *)stage_dst, (int)(stage_bytes / 4), PolFilter{});
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { egp::set_error("k_policy_gaussian launch failed: %s", hipGetErrorString(e)); return EGP_E_HIP; }
     return EGP_OK;
@@ -200,4 +249,26 @@ extern "C" int egp_policy_gaussian_staged_f32(const float *ctx_rows, int64_t ctx
                                               void *stream) {
     return policy_launch(ctx_rows, ctx_row_stride, ctx_dim, t_idx, state, state_dim, n, layers, n_layers, activation, log_std, noise, action,
                          mean_out, stage_src, stage_dst, stage_bytes, stream);
+}
+
+// egp_policy_gaussian_staged_f32 with the filter's apply pass in front (see PolFilter): the policy input's state columns are the
+// filtered observations of (qpos, qvel) -- the group's n rows -- normalised with `zf_in` merged with the tile statistics that
+// egp_obs_zfilter_stats_f64 left in `zf_workspace`; they are also written to y (and y2), and the merged statistics to zf_out:
+// together exactly what egp_obs_zfilter_apply_f64 followed by egp_policy_gaussian_staged_f32 on y2 computes, in one launch.
+extern "C" int egp_policy_gaussian_filter_f32(egp_ctx *ctx, const float *ctx_rows, int64_t ctx_row_stride, int32_t ctx_dim, const int64_t *t_idx,
+                                              const double *qpos, const double *qvel, int32_t n, const double *zf_in, double *zf_out,
+                                              double clip, double *y, double *y2, const void *zf_workspace,
+                                              const egp_mlp_layer *layers, int32_t n_layers, int32_t activation, const float *log_std,
+                                              const float *noise, double *action, float *mean_out, const void *stage_src, void *stage_dst,
+                                              int64_t stage_bytes, void *stream) {
+    EGP_REQUIRE(ctx && qpos && qvel && zf_in && zf_out && zf_in != zf_out && y && zf_workspace, "NULL pointer / zf_out must differ from zf_in");
+    EGP_REQUIRE(n > 0 && n <= 64 * egp::ZF_FUSED_TILES, "1 .. egp_obs_zfilter_split_max_rows() rows");
+    const int dim = ctx->dm.obs_dim;
+    int rpt, nt;
+    egp::zf_tiling(n, &rpt, &nt);
+    PolFilter f;
+    f.src = egp::ZfSrc<double>{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, egp::obs_opt_of(ctx->dm)};
+    f.st_in = zf_in; f.st_out = zf_out; f.ws = (const double *)zf_workspace; f.n_tiles = nt; f.clip = clip; f.y = y; f.y2 = y2;
+    return policy_launch(ctx_rows, ctx_row_stride, ctx_dim, t_idx, nullptr, dim, n, layers, n_layers, activation, log_std, noise, action, mean_out,
+                         stage_src, stage_dst, stage_bytes, stream, &f);
 }

@@ -376,6 +376,19 @@ class EgpContext:
                    _ptr(out), _ptr(out2), 1 if write_only_active else 0, _ptr(ws), _stream()), "egp_obs_zfilter")
         return out
 
+    def obs_zfilter_stats(self, qpos, qvel, workspace, active=None):
+        """First launch of obs_zfilter on its own (`egp_obs_zfilter_stats_f64`): tile statistics into `workspace`."""
+        n = qpos.shape[0]
+        L.check(self.lib.egp_obs_zfilter_stats_f64(self.handle, _ptr(qpos), _ptr(qvel), _ptr(active), n, _ptr(workspace), _stream()),
+                "egp_obs_zfilter_stats_f64")
+
+    def obs_zfilter_apply(self, qpos, qvel, state_in, state_out, clip, out, out2, workspace):
+        """Second launch of obs_zfilter on its own (`egp_obs_zfilter_apply_f64`)."""
+        n = qpos.shape[0]
+        L.check(self.lib.egp_obs_zfilter_apply_f64(self.handle, _ptr(qpos), _ptr(qvel), n, _ptr(state_in), _ptr(state_out), float(clip or 0.0),
+                                                   _ptr(out), _ptr(out2), _ptr(workspace), _stream()), "egp_obs_zfilter_apply_f64")
+        return out
+
     def gae(self, rewards, masks, values, gamma, tau):
         """-> (adv_raw (n,), returns (n,), stats float64[3] = {n, mean, M2}) all on device."""
         n, dt = rewards.shape[0], rewards.dtype

@@ -535,6 +535,12 @@ class LockstepRollout:
             if group_streams:
                 reward_job = False
             td.group_streams, td.post_fused = int(group_streams), int(post_fused)
+            # EGP_DEFER_APPLY (default on): a tick's `post` runs only the filter's statistics pass; the apply pass rides in the next
+            # tick's policy step (one launch and its dependent round trips less on the chain filter -> policy -> env-step, ~14 us
+            # per tick), except in ticks with in-batch resets and in a group's last tick (egp_rollout_tick_apply)
+            defer_apply = (self.zf_state is not None and not post_fused and not group_streams
+                           and nmax <= int(ctx.lib.egp_obs_zfilter_split_max_rows()) and os.environ.get("EGP_DEFER_APPLY", "1") != "0")
+            td.defer_apply = int(defer_apply)
             td.reward_job, td.flags_upload = int(bool(reward_job)), (0 if not flags_upload else (2 if stage_mode == "kernel" else 1))
             td.has_fix_head_lb = int(self.env.fix_head_lb is not None)
             td.fix_head_lb = float(self.env.fix_head_lb) if self.env.fix_head_lb is not None else 0.0
@@ -571,13 +577,26 @@ class LockstepRollout:
         native_reset = (tickd is not None and self._s_hc is None and self.v_out.dtype == torch.float32 and self.v_out.is_contiguous()
                         and os.environ.get("EGP_RESET_NATIVE", "1") != "0")
 
+        pending_apply = [None] * len(self.groups)     # per group: (zf_cur, zf_new) pointers of a filter whose apply pass is still due
+
+        def flush_apply(g, k):                       # the apply pass of tick k's filter on its own
+            pa = pending_apply[g]
+            if pa is not None:
+                a, b = self.groups[g]
+                rc = eng.lib.egp_rollout_tick_apply(tickd[1], g, a, b, k, pa[0], pa[1])
+                if rc != 0:
+                    _lib.check(rc, "egp_rollout_tick_apply")
+                pending_apply[g] = None
+
         def pre_native(g):
             a, b = self.groups[g]
             t0 = time.time()
             k = tick[g]
             ev = ev_ring[g][k & 1]
             self._events[g] = ev
-            rc = eng.lib.egp_rollout_tick_pre(tickd[1], g, a, b, k, ev.cuda_event)
+            pa = pending_apply[g]
+            pending_apply[g] = None
+            rc = eng.lib.egp_rollout_tick_pre(tickd[1], g, a, b, k, ev.cuda_event, 1 if pa else 0, pa[0] if pa else None, pa[1] if pa else None)
             if rc != 0:
                 _lib.check(rc, "egp_rollout_tick_pre")
             tm["policy"] += time.time() - t0
@@ -597,6 +616,8 @@ class LockstepRollout:
                 _lib.check(rc, "egp_rollout_tick_post")
             if new_t is not None:
                 self.zf_state = new_t
+                if tickd[0].defer_apply:
+                    pending_apply[g] = (cur, new)
             t2 = time.time()
             if n_done.value:
                 ids = np.nonzero(host["done"][k, a:b])[0] + a
@@ -604,6 +625,8 @@ class LockstepRollout:
                 finished = slot_finished(ids)
                 active[ids[finished]] = False
                 again = ids[~finished]
+                if len(again):
+                    flush_apply(g, k)            # the resets' masked filter pass continues from the merged statistics
                 if len(again) and native_reset:
                     self._reset_slots_native(tickd[1], g, a, b, k, again, zf_p)
                     self._pool_fresh = False
@@ -612,6 +635,8 @@ class LockstepRollout:
                     mask = np.zeros(b - a, np.int32)
                     mask[again - a] = 1
                     self._obs_filter(a, b, rec["states"][k + 1, a:b], active=self.up(mask).to(torch.int32), write_only_active=True)
+            if not active[a:b].any():
+                flush_apply(g, k)                # the group's last tick: no policy step follows
             tick[g] = k + 1
             t3 = time.time()
             tm["wait"] += wait_s.value

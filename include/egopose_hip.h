@@ -222,6 +222,15 @@ int egp_obs_zfilter_f64(egp_ctx *ctx, const double *qpos, const double *qvel, co
 int egp_obs_zfilter_f32(egp_ctx *ctx, const float *qpos, const float *qvel, const int32_t *active, int32_t n,
                         const double *state_in, double *state_out, double clip, float *y, float *y2,
                         int32_t write_only_active, void *workspace, void *stream);
+/* egp_obs_zfilter_f64 (all rows written, no write mask) in two calls, for batches of at most egp_obs_zfilter_split_max_rows() rows:
+ * _stats = its first launch (tile statistics of the rows with active != 0 into `workspace`), _apply = its second (merge into
+ * state_in -> state_out, normalise, clip, write y / y2): the same kernels with the same arguments, bit-identical results.
+ * The apply pass can instead ride in the policy step that consumes y2 (egp_policy_gaussian_filter_f32). */
+int32_t egp_obs_zfilter_split_max_rows(void);
+int egp_obs_zfilter_stats_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const int32_t *active, int32_t n, void *workspace,
+                              void *stream);
+int egp_obs_zfilter_apply_f64(egp_ctx *ctx, const double *qpos, const double *qvel, int32_t n, const double *state_in, double *state_out,
+                              double clip, double *y, double *y2, void *workspace, void *stream);
 /* hipMemcpyAsync host (pinned) -> device on `stream`: the per-tick integer flags of the rollout driver (kernels that
  * re-read a flag array must not read it from pinned memory: every access would cross PCIe) */
 int egp_upload_async(void *dst_device, const void *src_pinned, int64_t bytes, void *stream);
@@ -461,6 +470,17 @@ int egp_policy_gaussian_staged_f32(const float *ctx_rows, int64_t ctx_row_stride
                                    int32_t n_layers, int32_t activation, const float *log_std, const float *noise,
                                    double *action, float *mean_out, const void *stage_src, void *stage_dst, int64_t stage_bytes,
                                    void *stream);
+/* ... with the observation filter's apply pass in front (agents/agent.py:50-51 followed by :42-46 of the next step: the filtered
+ * next state IS the policy's next input): the state columns of the policy input are the observations of (qpos, qvel) -- the
+ * group's n rows, n <= egp_obs_zfilter_split_max_rows() -- normalised with `zf_in` merged with the tile statistics that
+ * egp_obs_zfilter_stats_f64 left in `zf_workspace`; they are written to y (and y2) and the merged statistics to zf_out. One launch
+ * computes exactly what egp_obs_zfilter_apply_f64 followed by egp_policy_gaussian_staged_f32 on y2 computes (bit-identical). */
+int egp_policy_gaussian_filter_f32(egp_ctx *ctx, const float *ctx_rows, int64_t ctx_row_stride, int32_t ctx_dim, const int64_t *t_idx,
+                                   const double *qpos, const double *qvel, int32_t n, const double *zf_in, double *zf_out,
+                                   double clip, double *y, double *y2, const void *zf_workspace,
+                                   const egp_mlp_layer *layers, int32_t n_layers, int32_t activation, const float *log_std,
+                                   const float *noise, double *action, float *mean_out, const void *stage_src, void *stage_dst,
+                                   int64_t stage_bytes, void *stream);
 
 /* ----------------------------------------------------------------------------------------
  * Host physics boundary (replaces mujoco_py's MjSim inside HumanoidEnv: envs/common/mujoco_env.py:84-105,
@@ -592,8 +612,14 @@ typedef struct egp_rollout_tick {
     int32_t group_streams;                       /* 1: a group's tick is enqueued on its engine stream (egp_engine_group_stream); `stream` carries
                                                   * the rollout's set-up and the reward launches (event-ordered); needs reward_job == 0 */
     int32_t post_fused;                          /* 1 (and reward_job == 0): K3 + K6 + K2 through egp_post_step_f64 */
+    int32_t defer_apply;                         /* 1 (needs a filter, post_fused == 0, groups of at most egp_obs_zfilter_split_max_rows() slots):
+                                                  * `post` runs the filter's statistics pass only; its apply pass rides in the next tick's policy
+                                                  * step (egp_rollout_tick_pre with apply_pending = 1 and the same zf_cur / zf_new) or, in a tick with
+                                                  * in-batch resets and in a group's last tick, is run by egp_rollout_tick_apply */
 } egp_rollout_tick;
-int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, void *ready_event);
+int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, void *ready_event,
+                         int32_t apply_pending, const double *zf_cur, double *zf_new);
+int egp_rollout_tick_apply(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, const double *zf_cur, double *zf_new);
 int egp_rollout_tick_post(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, const double *zf_cur, double *zf_new,
                           int32_t *n_done, double *wait_s);
 /* HumanoidEnv.reset_model + the first observation of the new episodes (ego_pose/envs/humanoid_v1.py:201-226, core/agent.py:35-38)

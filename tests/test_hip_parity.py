@@ -728,3 +728,49 @@ def test_constant_and_pose_dist_rewards_on_device(skel):
     ctx.reward_simple("pose_dist", qpos, frame, end, 0.0, active=active, reward_out=keep)
     assert (keep[::3] == -7.0).all() and (keep[1::3] != -7.0).all()
     ctx.close()
+
+
+@pytest.mark.parametrize("n", [512, 37, 1024])
+def test_filter_apply_in_the_policy_step_is_bit_identical_to_the_two_launches(ctx, n):
+    """egp_obs_zfilter_stats_f64 + egp_policy_gaussian_filter_f32 against egp_obs_zfilter_f64 + egp_policy_gaussian_f32 (what a
+    rollout tick without resets runs, rollout.py EGP_DEFER_APPLY): filtered observations, running statistics and actions equal
+    bit for bit; so does the split pair stats + apply."""
+    from egopose_amd.nets import MLP, PolicyGaussian
+    from egopose_amd import policy_step
+    torch.manual_seed(11)
+    rng = np.random.RandomState(n)
+    H, S, T, nu = 128, 115, 7, 52
+    pol = PolicyGaussian(MLP(H + S, (300, 200), "relu"), nu, log_std=-2.3).cuda()
+    fp = policy_step.FusedGaussianPolicy(pol, torch.device("cuda"))
+    qpos = rng.normal(size=(n, 59)) * 0.4
+    qpos[:, 3:7] = rng.normal(size=(n, 4)); qpos[:, 3:7] /= np.linalg.norm(qpos[:, 3:7], axis=1, keepdims=True)
+    qvel = rng.normal(size=(n, 58))
+    qp, qv = dev(qpos), dev(qvel)
+    act = torch.as_tensor((rng.uniform(size=n) < 0.8).astype(np.int32), device="cuda")
+    st0 = torch.zeros(1 + 2 * S, dtype=torch.float64, device="cuda")
+    st_a, st_b = torch.empty_like(st0), torch.empty_like(st0)
+    ctx.obs_zfilter(dev(rng.normal(size=(300, 59)) * 0.3 + np.r_[0, 0, 1, 1, 0, 0, 0, np.zeros(52)]), dev(rng.normal(size=(300, 58))), st0, st_a, 5.0,
+                    torch.empty(300, S, dtype=torch.float64, device="cuda"))          # a non-trivial running state to continue from
+    v_out = torch.randn(n, T, H, device="cuda")
+    t_idx = torch.randint(0, T, (n,), device="cuda")
+    noise = torch.randn(n, nu, device="cuda")
+    # reference: two filter launches, then the policy step on the filtered rows
+    y_ref, y2_ref = torch.empty(n, S, dtype=torch.float64, device="cuda"), torch.empty(n, S, dtype=torch.float64, device="cuda")
+    ctx.obs_zfilter(qp, qv, st_a, st_b, 5.0, y_ref, y2_ref, active=act)
+    a_ref = torch.empty(n, nu, dtype=torch.float64, device="cuda")
+    fp(v_out, t_idx, y2_ref, a_ref, noise=noise)
+    ws = torch.empty(int(ctx.lib.egp_zfilter_workspace_bytes(n, S)) // 8, dtype=torch.float64, device="cuda")
+    # split pair
+    st_c = torch.empty_like(st0)
+    y1, y2 = torch.empty_like(y_ref), torch.empty_like(y_ref)
+    ctx.obs_zfilter_stats(qp, qv, ws, active=act)
+    ctx.obs_zfilter_apply(qp, qv, st_a, st_c, 5.0, y1, y2, ws)
+    assert torch.equal(st_c, st_b) and torch.equal(y1, y_ref) and torch.equal(y2, y2_ref)
+    # apply pass inside the policy step
+    st_d = torch.empty_like(st0)
+    y1.zero_(); y2.zero_()
+    a_f = torch.empty_like(a_ref)
+    ctx.obs_zfilter_stats(qp, qv, ws, active=act)
+    fp.with_filter(ctx, v_out, t_idx, qp, qv, st_a, st_d, 5.0, y1, y2, ws, a_f, noise=noise)
+    assert torch.equal(st_d, st_b) and torch.equal(y1, y_ref) and torch.equal(y2, y2_ref)
+    assert torch.equal(a_f, a_ref)
