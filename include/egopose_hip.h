@@ -489,6 +489,8 @@ int egp_policy_gaussian_filter_f32(egp_ctx *ctx, const float *ctx_rows, int64_t 
  *   reset(user, env, qpos[nq], qvel[nv])                      set_state + forward
  *   step (user, env, ctrl[nu])                                data.ctrl = ctrl; mj_step
  *   drain(user, env, qpos, qvel, qM[nM], qfrc_bias[nv], xpos[nbody*3])   copy out mjData fields (qM / xpos may be NULL)
+ * Threading: the engine calls reset / step / drain of DIFFERENT envs concurrently from its host threads (an env is only ever
+ * touched by one thread at a time): a backend keeps per-env state apart (MuJoCo: one mjData per env over a shared mjModel).
  * A MuJoCo adapter fills this from mj_step / mjData; the built-in surrogate is egp_physics_create_surrogate. */
 typedef struct egp_physics_vtable {
     void *user;
