@@ -214,7 +214,7 @@ struct egp_engine {
     // substep. Opt-in (EGP_BAR_GO=1). Round 2: -1 .. -3 ms on two boxes, nothing on a third. Round 3, in-lease A/B
     // (tools/probes/ab_env.sh): seven alternating pairs of nine rollouts on two boxes, median T_sample 94.5 against 99.9 ms -- but
     // a heavier tail (single rollouts of 136 / 165 / 228 ms, the pulled form's worst were 121 / 127 / 135), and under bench.py
-    // (three iterations per run, tools/probes/ab_bench_bar.sh) 880 / 664 / 925 k against 840 / 895 / 839 k env-steps/s: a better
+    // (three iterations per run, tools/probes/ab_bench_env.sh) 880 / 664 / 925 k against 840 / 895 / 839 k env-steps/s: a better
     // median bought with rare long stalls of the host's posted stores. Left off: a three-step bench pays for one stall with 20 %.
     // The state rows stay in pinned host memory in any case: mirroring them the same
     // way was built and measured (tools/probes/bar_pingpong.hip: 4.7 instead of 8.1 us per round trip for ONE wave's four
@@ -227,7 +227,11 @@ struct egp_engine {
     bool device_dynamics = false;             // K8 supplies qM / qfrc_bias from the drained (qpos, qvel) each substep
     double *d_bias = nullptr;                 // [n_env][nv] K8's bias (device-dynamics mode)
     int reward_delay_us = 0;                  // EGP_REWARD_JOB_DELAY_US (tests): a spin kernel ahead of the reward job's kernel
-    int spin_us = 0;                          // EGP_SPIN_US: poll this long for the next env-step before sleeping (off: measured no gain)
+    int spin_us = 150;                        // EGP_SPIN_US: the engine's threads (and a caller in egp_engine_wait, 4 x as long) poll this long for
+                                              // the next env-step / its end before sleeping on a condition variable. Round 2 measured no gain and left
+                                              // it at 0; round 3's in-lease A/B (tools/probes/ab_env.sh, four alternating pairs): 99.3 against
+                                              // 101.2 ms of T_sample, every pair better (150 vs 500: equal) -- a futex wake-up per env-step and
+                                              // thread is ~2 % of the rollout. Between rollouts the threads sleep after 150 us.
     double *d_state = nullptr, *d_qM = nullptr, *d_prev_qpos = nullptr, *d_qpos = nullptr, *d_qvel = nullptr, *d_torque = nullptr, *d_ee = nullptr;
     double *h_state = nullptr, *h_qM = nullptr, *h_qpos = nullptr, *h_qvel = nullptr, *h_torque = nullptr, *h_ee = nullptr,
            *h_headz = nullptr, *h_xpos = nullptr;
