@@ -9,7 +9,7 @@ from egopose_amd.train import Trainer
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 root = tempfile.mkdtemp(prefix="egp_st_"); write_synthetic_dataset(root, "subject_03", device_index=0); os.chdir(root)
 cfg = Config("subject_03", create_dirs=False)
-tr = Trainer(cfg, dev, torch.float32, num_envs=1024, num_threads=max(2, default_threads()), num_groups=int(os.environ.get("EGP_PROBE_GROUPS", "2")))
+tr = Trainer(cfg, dev, torch.float32, num_envs=1024, num_threads=int(os.environ.get("EGP_PROBE_THREADS", "0")) or max(2, default_threads()), num_groups=int(os.environ.get("EGP_PROBE_GROUPS", "2")))
 tr.iteration(0, cfg.min_batch_size)
 ts, ns = [], []
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 7):
