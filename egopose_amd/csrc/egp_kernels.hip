@@ -428,6 +428,9 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
     const int act = row >= 6 ? row - 6 : 0;
     const int slice = sv.block_slice[blockIdx.x];
     const bool live = valid && (!sv.active || sv.active[env] != 0);
+    // a workgroup none of whose envs is stepped (finished slots: most of the grid in a rollout's tail) has nothing to solve, nothing
+    // to hand back in the epilogue and nobody waiting for it: leave, instead of polling its slice's go word over PCIe for 15 substeps
+    if (__syncthreads_or(live ? 1 : 0) == 0) return;
     const double r_a = valid ? action[env * ld.action + act] : 0.0;
     const double c_kp = row >= 6 ? m.jkp[act] : 0.0, c_kd = row >= 6 ? m.jkd[act] : 0.0;
     const double c_ref = m.a_ref[act], c_scale = m.a_scale[act], c_lim = m.torque_lim[act];
