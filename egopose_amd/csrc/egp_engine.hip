@@ -46,6 +46,22 @@ inline void cpu_relax() {
 #endif
 }
 
+// A go word of the resident kernel. In pinned host memory a release store is all it takes (the waves read it over PCIe). In
+// fine-grained DEVICE memory (EGP_BAR_GO) the host's mapping is write-combining: without a store fence the word can sit in a
+// write-combining buffer until something else evicts it -- usually microseconds, occasionally the rest of a time slice, which
+// is what the "heavier tail" of the pushed form was (single rollouts of 136 / 165 / 228 ms): the fence pushes it out now.
+// (And a write-combining store is not ordered behind the ordinary stores that filled the state rows: a fence in front keeps the
+//  rows globally visible before the word that announces them.)
+inline void store_go(unsigned long long *word, unsigned long long value, bool in_vram) {
+#if defined(__x86_64__)
+    if (in_vram) _mm_sfence();
+#endif
+    __atomic_store_n(word, value, __ATOMIC_RELEASE);
+#if defined(__x86_64__)
+    if (in_vram) _mm_sfence();
+#endif
+}
+
 // sense-reversing spin barrier for the threads of one group
 struct SpinBarrier {
     std::atomic<int> count{0};
@@ -211,11 +227,12 @@ struct egp_engine {
     double *hd_state = nullptr, *hd_torque = nullptr, *hd_qM = nullptr, *hd_ee = nullptr;   // device-side aliases of h_state / h_torque / h_qM
     // Resident-K1 mode: the slices' go words live in FINE-GRAINED DEVICE memory that the host threads write through the PCIe
     // BAR (posted stores); the resident waves then poll HBM instead of host memory -- one PCIe read round trip less per
-    // substep. Opt-in (EGP_BAR_GO=1). Round 2: -1 .. -3 ms on two boxes, nothing on a third. Round 3, in-lease A/B
-    // (tools/probes/ab_env.sh): seven alternating pairs of nine rollouts on two boxes, median T_sample 94.5 against 99.9 ms -- but
-    // a heavier tail (single rollouts of 136 / 165 / 228 ms, the pulled form's worst were 121 / 127 / 135), and under bench.py
-    // (three iterations per run, tools/probes/ab_bench_env.sh) 880 / 664 / 925 k against 840 / 895 / 839 k env-steps/s: a better
-    // median bought with rare long stalls of the host's posted stores. Left off: a three-step bench pays for one stall with 20 %.
+    // substep. Default since the end of round 3 (EGP_BAR_GO=0: pinned go words; a failed fine-grained allocation falls back to
+    // them too). History: round 2 measured -1 .. -3 ms on two boxes and nothing on a third; round 3's in-lease A/B found a better
+    // median (94.5 against 99.9 ms) but single rollouts of 136 / 165 / 228 ms -- the host's mapping of that memory is
+    // write-combining and the go word was a plain store: it could sit in a write-combining buffer until something evicted it. With
+    // a store fence either side of it (store_go) the stalls are gone: four alternating pairs of 15 rollouts, medians 94.2 against
+    // 97.3 ms, worst rollout 101 against 107.5; under bench.py (tools/probes/ab_bench_env.sh) 906 / 921 / 918 k against 907 / 903 / 905 k.
     // The state rows stay in pinned host memory in any case: mirroring them the same
     // way was built and measured (tools/probes/bar_pingpong.hip: 4.7 instead of 8.1 us per round trip for ONE wave's four
     // rows), but a host thread's write-combined stores move ~0.4 us per env and substep one after the other where the
@@ -488,7 +505,7 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
     for (int h = h0; h < h1; ++h) {
         const int sl = S.order[h];
         arm_slice(E, G, S.e0[sl], S.e1[sl], nu, sstride);
-        __atomic_store_n(S.h_go + sl * 8, (base << 1) | (unsigned long long)S.dirty[sl].exchange(0), __ATOMIC_RELEASE);
+        store_go(S.h_go + sl * 8, (base << 1) | (unsigned long long)S.dirty[sl].exchange(0), S.go_in_vram);
     }
     if (tid == 0) {
         G.prof_now = E->profile_k1.load(std::memory_order_relaxed) && !G.k_beg.empty() && (G.job % E->profile_every == 0);
@@ -562,15 +579,14 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
                 ++n_stepped;
             }
             if (G.status.load(std::memory_order_relaxed) != EGP_OK) {
-                __atomic_store_n(S.h_go + sl * 8, drain_all, __ATOMIC_RELEASE);       // let the kernel run out
+                store_go(S.h_go + sl * 8, drain_all, S.go_in_vram);       // let the kernel run out
             } else if (!last) {
                 arm_slice(E, G, S.e0[sl], S.e1[sl], nu, sstride);
-                __atomic_store_n(S.h_go + sl * 8, ((base + (unsigned long long)s + 1ull) << 1) | (unsigned long long)S.dirty[sl].exchange(0),
-                                 __ATOMIC_RELEASE);
+                store_go(S.h_go + sl * 8, ((base + (unsigned long long)s + 1ull) << 1) | (unsigned long long)S.dirty[sl].exchange(0), S.go_in_vram);
             } else {
                 // final state of the slice is drained: let the kernel's epilogue move it to HBM (a pending qM refresh
                 // stays flagged for the next env-step)
-                __atomic_store_n(S.h_go + sl * 8, (base + (unsigned long long)FS) << 1, __ATOMIC_RELEASE);
+                store_go(S.h_go + sl * 8, (base + (unsigned long long)FS) << 1, S.go_in_vram);
             }
             if (tr) S.host_trace[s * 4 + 2] = secs(t_job, clk::now()) * 1e6;
             if (timekeeper) {
@@ -596,7 +612,7 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
         S.host_trace[3 * 4 + 3] = secs(t_job, clk::now()) * 1e6;                                       // kernel (epilogue) done
     }
     if (G.status.load() != EGP_OK) {
-        for (int sl = 0; sl < S.n_slices; ++sl) __atomic_store_n(S.h_go + sl * 8, drain_all, __ATOMIC_RELEASE);
+        for (int sl = 0; sl < S.n_slices; ++sl) store_go(S.h_go + sl * 8, drain_all, S.go_in_vram);
         (void)hipStreamSynchronize(G.stream);
         return;
     }
@@ -883,7 +899,7 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     memset(E->h_state, 0, N * E->ld_s * sizeof(double));
     {
         const char *bg = getenv("EGP_BAR_GO");
-        E->bar_go = E->zero_copy && E->hd_state && bg && atoi(bg) != 0;       // opt-in (see the field)
+        E->bar_go = E->zero_copy && E->hd_state && !(bg && atoi(bg) == 0);    // default on since the stores are fenced (see the field)
     }
     memset(E->h_qM, 0, N * E->ld_m * sizeof(double));
     memset(E->h_headz, 0, N * sizeof(double));
