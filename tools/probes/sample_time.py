@@ -1,6 +1,10 @@
 """T_sample of the bench workload (median over n rollouts) under the current environment switches -- for in-lease A/B runs."""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+if os.environ.get("EGP_PROBE_SPIN_SYNC") == "1":        # hipDeviceScheduleSpin before the runtime creates its context
+    import ctypes
+    _hip = ctypes.CDLL("libamdhip64.so")
+    print("hipSetDeviceFlags(spin) ->", _hip.hipSetDeviceFlags(1))
 import torch
 from egopose_amd.bench_support import write_synthetic_dataset
 from egopose_amd.config import Config
