@@ -344,7 +344,8 @@ def test_gae_sizes_vs_oracle(ctx):
 
 # ------------------------------------------------------------------------------------------------ engine
 ENGINE_MODES = {                     # env switches read by egp_engine_create -> (launches/substep, substeps/launch)
-    "resident": ({}, None),
+    "resident": ({}, None),                                        # (go words in HBM, pushed by the host with fenced stores: the default)
+    "resident-pinned-go": ({"EGP_BAR_GO": "0"}, None),             # go words in pinned host memory, pulled by the waves
     "pipelined": ({"EGP_SERVER": "0", "EGP_CHUNKS": "2"}, None),
     "barrier": ({"EGP_SERVER": "0", "EGP_CHUNKS": "1"}, (1, 1)),
     "copies": ({"EGP_SERVER": "0", "EGP_ZERO_COPY": "0"}, (1, 1)),
@@ -368,7 +369,7 @@ def test_engine_step_matches_host_loop(ctx, skel, mode, monkeypatch):
     for n_groups, n_threads in [(1, 3), (2, 4)]:
         ph = SurrogatePhysics(skel, n)
         eng = RolloutEngine(ctx, ph, n, n_threads=n_threads, n_groups=n_groups)
-        if mode == "resident":
+        if mode.startswith("resident"):
             assert (eng.launches_per_substep, eng.substeps_per_launch) == (1, 15)
         elif ENGINE_MODES[mode][1]:
             assert (eng.launches_per_substep, eng.substeps_per_launch) == ENGINE_MODES[mode][1]
