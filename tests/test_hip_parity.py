@@ -775,3 +775,42 @@ def test_filter_apply_in_the_policy_step_is_bit_identical_to_the_two_launches(ct
     fp.with_filter(ctx, v_out, t_idx, qp, qv, st_a, st_d, 5.0, y1, y2, ws, a_f, noise=noise)
     assert torch.equal(st_d, st_b) and torch.equal(y1, y_ref) and torch.equal(y2, y2_ref)
     assert torch.equal(a_f, a_ref)
+
+
+def test_large_batch_kernel_variants_equal_the_small_batch_ones(ctx, skel):
+    """K2 switches to multi-pass 60-env tiles at >= 16 384 envs and K8 to 7-env workgroups at >= 4 096: the same arithmetic per
+    env, so one large call must equal the same rows pushed through in small calls bit for bit (and the golden cases, tiled up
+    to that size with varied frames / masks, keep their reference values: the small variants are pinned to them above)."""
+    g = load_golden("reward.npz")
+    _upload_golden_expert(ctx, g)
+    wsets = [yaml.safe_load(str(s)) for s in g["wset_json"]]
+    ctx.set_reward_weights(wsets[0])
+    sel = np.where(g["wset"] == 0)[0]
+    n = 16384 + 77
+    rng = np.random.RandomState(5)
+    pick = sel[rng.randint(0, len(sel), n)]
+    i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32, device="cuda")
+    cur, prev, ee = dev(g["cur_qpos"][pick]), dev(g["prev_qpos"][pick]), dev(g["ee_wpos"][pick])
+    t, fr, en = i32(g["t"][pick]), i32(g["start_ind"][pick] + g["t"][pick]), i32(g["end"][pick])
+    act = i32((rng.uniform(size=n) < 0.9).astype(np.int32))
+    r_big, c_big = ctx.reward(cur, prev, ee, t, fr, en, 0.3, active=act)
+    r_parts, c_parts = [], []
+    for a in range(0, n, 5000):                      # 5 000-env calls: the one-pass variant
+        b = min(n, a + 5000)
+        r, c = ctx.reward(cur[a:b], prev[a:b], ee[a:b], t[a:b], fr[a:b], en[a:b], 0.3, active=act[a:b])
+        r_parts.append(r); c_parts.append(c)
+    assert torch.equal(r_big, torch.cat(r_parts)) and torch.equal(c_big, torch.cat(c_parts))
+    on = act.cpu().numpy() == 1
+    want = g["reward"][pick] - np.where(g["end"][pick], g["end_reward"][pick], 0.0) + np.where(g["end"][pick], 0.3, 0.0)
+    np.testing.assert_allclose(r_big.cpu().numpy()[on], want[on], rtol=1e-10, atol=5e-10)
+    assert float(r_big.cpu().numpy()[~on].max(initial=0.0)) == 0.0
+    # K8
+    m = 4096 + 13
+    qpos = np.tile(g["cur_qpos"][sel][:64], (m // 64 + 1, 1))[:m] + rng.normal(size=(m, 59)) * 0.01
+    qpos[:, 3:7] /= np.linalg.norm(qpos[:, 3:7], axis=1, keepdims=True)
+    qvel = rng.normal(size=(m, 58)) * 0.5
+    qp, qv = dev(qpos), dev(qvel)
+    big = ctx.dynamics(qp, qv, want_xpos=True)
+    parts = [ctx.dynamics(qp[a:a + 1500], qv[a:a + 1500], want_xpos=True) for a in range(0, m, 1500)]
+    for key in ("qM", "bias", "xpos"):
+        assert torch.equal(big[key], torch.cat([p[key] for p in parts])), key
