@@ -319,7 +319,9 @@ def test_gae_golden(ctx, dtype, tol):
 
 def test_gae_sizes_vs_oracle(ctx):
     rng = np.random.RandomState(3)
-    for n in (1, 2, 31, 32, 33, 1000, 204800):      # chunk edges (32) and the config-2 sweep size
+    # chunk edges (8 samples per thread), block edges (2 048 per workgroup), the config-2 sweep size, and more than 1 024 blocks
+    # (the single-block scan of the block maps then takes several per thread)
+    for n in (1, 2, 7, 8, 9, 31, 32, 33, 1000, 2047, 2048, 2049, 204800, 2048 * 1024 + 5):
         r = rng.uniform(0, 1.2, size=n)
         m = (rng.uniform(size=n) > 0.02).astype(float)
         v = rng.normal(size=n) * 2
