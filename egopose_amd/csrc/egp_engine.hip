@@ -900,6 +900,13 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     {
         const char *bg = getenv("EGP_BAR_GO");
         E->bar_go = E->zero_copy && E->hd_state && !(bg && atoi(bg) == 0);    // default on since the stores are fenced (see the field)
+        if (E->bar_go) {       // the host stores straight into device memory: only where the whole of it is mapped through the PCIe BAR
+            int large_bar = 0;
+            if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) != hipSuccess || !large_bar) {
+                (void)hipGetLastError();
+                E->bar_go = false;
+            }
+        }
     }
     memset(E->h_qM, 0, N * E->ld_m * sizeof(double));
     memset(E->h_headz, 0, N * sizeof(double));
