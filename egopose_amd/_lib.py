@@ -204,6 +204,8 @@ SIGNATURES = {
     "egp_post_step_f64": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, _i32, vp, vp, _f64, vp, vp, vp, _f64, vp, vp, vp]),
     "egp_set_dynamics_model": (C.c_int, [vp, C.POINTER(DynamicsDesc)]),
     "egp_dynamics_f64": (C.c_int, [vp, vp, vp, _i32, vp, C.c_int64, vp, vp, vp]),
+    "egp_mlp_pack_floats": (C.c_int64, [_i32, _i32]),
+    "egp_mlp_pack_f32": (C.c_int, [vp, C.c_int64, _i32, _i32, vp, vp]),
     "egp_policy_gaussian_f32": (C.c_int, [vp, C.c_int64, _i32, vp, vp, _i32, _i32, C.POINTER(MlpLayer), _i32, _i32, vp, vp, vp, vp, vp]),
     "egp_policy_gaussian_staged_f32": (C.c_int, [vp, C.c_int64, _i32, vp, vp, _i32, _i32, C.POINTER(MlpLayer), _i32, _i32, vp, vp, vp, vp, vp, vp,
                                                  C.c_int64, vp]),

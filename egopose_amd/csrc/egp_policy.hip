@@ -3,17 +3,31 @@
 //   -> action_mean (Linear) -> action = mean + exp(log_std) * noise  (float32 arithmetic, stored as float64 for
 //   the engine), i.e. PolicyGaussian.select_action of models/policy_gaussian.py:19-27 over models/mlp.py:5-25 with
 //   the VideoStateNet concatenation of models/video_state_net.py:37-43, for all envs of a group at once.
-// During a rollout this chain is ~13 launch-bound torch ops per tick (3 GEMMs of 512 rows, gather, cat, casts);
-// here a 4-row tile walks the layers through LDS while the transposed weights stream from L2.
+// During a rollout this chain is ~13 launch-bound torch ops per tick (3 GEMMs of 512 rows, gather, cat, casts).
+//
+// Round 4: the layer products run on the matrix cores in exact float32 (v_mfma_f32_4x4x1_16b_f32: 16 independent 4 x 4
+// outer products per instruction = 4 batch rows x 64 output columns x one input feature; an fmaf chain, bit for bit).
+// A workgroup owns R = 4 or 8 batch rows and walks the layers with the activations in LDS. Its NW waves split a layer's
+// input features (k) between them; every wave streams its k range of the PACKED weights (egp_mlp_pack_f32: for each
+// group of 64 output columns and each quad of input features one 1-KiB block, lane l's 16 bytes = column l at the four
+// k of the quad -> one coalesced global_load_dwordx4 per wave and block, PF blocks in flight per column group) and
+// reads the rows' activations as broadcast ds_read_b128; the per-wave partial sums meet in LDS, where bias and
+// activation are applied in a fixed order (deterministic, independent of the row's position in the batch).
+// The weights of the next pass are requested BEFORE the partial sums are written and reduced (they do not depend on the
+// activations), and the first layer's before the input rows are gathered: the dependent global round trips of a tick
+// (context-row index -> context row, tile statistics -> filtered observation) overlap the weight stream.
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "egp_internal.hpp"
 #include "egp_filter_dev.hpp"
 
 namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // The filter's apply pass folded into the policy step (egp_policy_gaussian_filter_f32): the observation rows of the tile are
 // formed, normalised with the running statistics merged from the tick's tile partials (exactly k_zf_apply's arithmetic: same
@@ -27,11 +41,11 @@ struct PolFilter {
     double *y, *y2;                  // [n][dim] each (y2 may be NULL)
 };
 
-constexpr int POL_ROWS = 4;          // rows per workgroup
 constexpr int POL_MAX_LAYERS = 8;
+constexpr int POL_GC = 5;            // column groups (64 outputs each) a pass accumulates in registers: 320 >= the 300-wide layer
 
 struct PolLayers {
-    const float *wt[POL_MAX_LAYERS];     // W^T, [in][round_up(out, 4)] row-major, 16-byte aligned
+    const float *wp[POL_MAX_LAYERS];     // packed weights (egp_mlp_pack_f32)
     const float *bias[POL_MAX_LAYERS];
     int in_dim[POL_MAX_LAYERS], out_dim[POL_MAX_LAYERS];
     int n;                                // hidden layers + the output layer
@@ -43,26 +57,112 @@ __device__ __forceinline__ float pol_act(float v, int kind) {
     return tanhf(v);                                      // tanh
 }
 
-// Thread t of a layer pass owns 4 consecutive outputs (one 16-byte weight load per input feature) for one slice of
-// the input features; the slices' partial sums meet in LDS. With 512 threads: 300 outputs -> 75 columns x 6 slices.
+// nn.Linear weight W[out][in] (row stride ldw) -> packed[(g * nkq + kq) * 64 + lane][kk] = W[64 g + lane][4 kq + kk], zero outside
+__global__ void k_mlp_pack(const float *__restrict__ W, long ldw, int in_dim, int out_dim, float *__restrict__ dst, long total) {
+    const int nkq = (in_dim + 3) >> 2;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int kk = (int)(e & 3), lane = (int)((e >> 2) & 63);
+        const long blk = e >> 8;
+        const int kq = (int)(blk % nkq), g = (int)(blk / nkq);
+        const int o = 64 * g + lane, i = 4 * kq + kk;
+        dst[e] = (o < out_dim && i < in_dim) ? W[(long)o * ldw + i] : 0.0f;
+    }
+}
+
+// The wave's weight blocks of one pass: PF quads x up to POL_GC column groups in flight.
+template <int PF>
+struct PolStage {
+    f32x4 w[PF][POL_GC];
+};
+
+// request the blocks of quads kq .. kq + PF - 1 (clamped into the wave's range) of column groups g0 .. g0 + ng - 1 (clamped)
+template <int PF>
+__device__ __forceinline__ void pol_preload(PolStage<PF> &st, const float *__restrict__ wl, int nkq, int g0, int ng, int kq0, int kq1, int lane) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+        const int k = min(kq0 + s, kq1 - 1);
+#pragma unroll
+        for (int g = 0; g < POL_GC; ++g) {
+            const int gg = g0 + min(g, ng - 1);
+            st.w[s][g] = *reinterpret_cast<const f32x4 *>(wl + (((long)gg * nkq + k) * 64 + lane) * 4);
+        }
+    }
+}
+
+// One pass: acc[g][h] += W[cols of group g0 + g][k range of the wave] * x[rows 4 h .. 4 h + 3][k range]. Straight-line loop body
+// (every load is unconditional with a clamped address, quads past the wave's range multiply zeros), so the compiler's
+// counted waits keep PF blocks per group in flight.
+template <int NG, int R, int PF>
+__device__ __forceinline__ void pol_pass(PolStage<PF> &st, const float *__restrict__ wl, int nkq, int g0, int kq0, int kq1, const float *x, int xs,
+                                         int lane, f32x4 (&acc)[POL_GC][R / 4]) {
+    const float *xr = x + (lane & 3) * xs;
+    const float *wb = wl + (((long)g0 * nkq) * 64 + lane) * 4;
+    const long gstride = (long)nkq * 256;
+    for (int kq = kq0; kq < kq1; kq += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int k = kq + s;
+            const bool live = k < kq1;
+            const int kc = live ? k : kq1 - 1;
+            f32x4 b[R / 4];
+#pragma unroll
+            for (int h = 0; h < R / 4; ++h) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + 4 * h * xs + 4 * kc);
+                b[h][0] = live ? v[0] : 0.0f; b[h][1] = live ? v[1] : 0.0f; b[h][2] = live ? v[2] : 0.0f; b[h][3] = live ? v[3] : 0.0f;
+            }
+            f32x4 w[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) w[g] = st.w[s][g];
+            const int kn = min(k + PF, kq1 - 1);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) st.w[s][g] = *reinterpret_cast<const f32x4 *>(wb + g * gstride + (long)kn * 256);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int h = 0; h < R / 4; ++h)
+                        acc[g][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[g][kk], b[h][kk], acc[g][h], 0, 0, 0);
+        }
+    }
+}
+
 // `stage_src` / `stage_dst` (optional): the tick's flag slab. The rollout stages the integer flags and context-row indices of a
 // tick in pinned host memory; instead of a copy-engine transfer in front of this kernel (one more dependent operation, ~6 us,
 // on the chain filter -> policy -> env-step of every tick) the workgroups copy the slab to its device copy themselves -- the
 // kernels that run after the env-step (reward, filter) read it there -- and take their own rows' indices (`t_idx`, which then
 // points into the pinned slab) with ONE load per row.
-template <bool FILTER>
-__global__ void k_policy_gaussian(const float *__restrict__ ctx_rows, long ctx_row_stride, int ctx_dim,
+template <int R, int NW, int PF, bool FILTER>
+// Register budget: a resident K1 workgroup keeps one 344-register wave on every SIMD for the length of an env-step; a policy
+// workgroup must fit beside it (168 registers per SIMD left), or it can only be placed on CUs without one.
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3 * NW / 4, 3 * NW / 4))) void k_policy_gaussian(const float *__restrict__ ctx_rows, long ctx_row_stride, int ctx_dim,
                                   const long long *__restrict__ t_idx, const double *__restrict__ state, int state_dim, int n,
-                                  PolLayers L, int act_kind, int kmax, int part_elems, const float *__restrict__ log_std,
+                                  PolLayers L, int act_kind, int xs, const float *__restrict__ log_std,
                                   const float *__restrict__ noise, double *__restrict__ action, float *__restrict__ mean_out,
                                   const unsigned *__restrict__ stage_src, unsigned *__restrict__ stage_dst, int stage_words,
                                   PolFilter F) {
-    extern __shared__ float4 s_act[];     // cur[kmax] | nxt[kmax] | part[part_elems]   (one float per row of the tile) [| mean, inv: 2 dim doubles]
-    __shared__ long long s_ti[POL_ROWS];
-    double *s_ms = reinterpret_cast<double *>(s_act + 2 * kmax + part_elems);
+    constexpr int T = NW * 64;
+    constexpr int PS = POL_GC * 64 + 4;              // row stride of a wave's partial sums (floats)
+    extern __shared__ __attribute__((aligned(16))) float s_f[];     // cur[R][xs] | nxt[R][xs] | part[NW][R][PS] [| mean, 1/std: 2 dim doubles]
+    __shared__ long long s_ti[R];
+    float *cur = s_f, *nxt = s_f + R * xs, *part = s_f + 2 * R * xs;
+    double *s_ms = reinterpret_cast<double *>(part + NW * R * PS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: the k loops' bounds live in SGPRs)
+    const int r0 = blockIdx.x * R;
+    const int in0 = ctx_dim + state_dim;
+
+    // the first layer's weights are on their way before anything else
+    PolStage<PF> st;
+    int nkq = (L.in_dim[0] + 3) >> 2;
+    int kq0 = wave * nkq / NW, kq1 = (wave + 1) * nkq / NW;
+    {
+        const int ng_all = (L.out_dim[0] + 63) >> 6;
+        pol_preload<PF>(st, L.wp[0], nkq, 0, min(ng_all, POL_GC), kq0, max(kq1, kq0 + 1), lane);
+    }
+
     if constexpr (FILTER) {               // k_zf_apply's first phase: the merged statistics, every workgroup for itself
         const int dim = state_dim;
-        for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+        for (int c = tid; c < dim; c += T) {
             double cnt, mean, S;
             egp::zf_merge_column(dim, F.n_tiles, F.ws, F.st_in, c, cnt, mean, S);
             if (blockIdx.x == 0) {
@@ -75,114 +175,159 @@ __global__ void k_policy_gaussian(const float *__restrict__ ctx_rows, long ctx_r
             s_ms[dim + c] = 1.0 / (sqrt(var) + 1e-8);
         }
     }
-    float4 *cur = s_act, *nxt = s_act + kmax, *part = s_act + 2 * kmax;
-    const int r0 = blockIdx.x * POL_ROWS;
-    const int in0 = ctx_dim + state_dim;
-    if (threadIdx.x < POL_ROWS) s_ti[threadIdx.x] = r0 + (int)threadIdx.x < n ? t_idx[r0 + threadIdx.x] : 0;
+    if (tid < R) s_ti[tid] = r0 + tid < n ? t_idx[r0 + tid] : 0;
     if (stage_src)
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < stage_words; i += gridDim.x * blockDim.x) stage_dst[i] = stage_src[i];
+        for (int i = blockIdx.x * T + tid; i < stage_words; i += gridDim.x * T) stage_dst[i] = stage_src[i];
     __syncthreads();
-    for (int k = threadIdx.x; k < in0; k += blockDim.x) {
-        float v[POL_ROWS];
+    const int in0p = (in0 + 3) & ~3;
+    for (int k = tid; k < in0p; k += T) {
 #pragma unroll
-        for (int r = 0; r < POL_ROWS; ++r) {
+        for (int r = 0; r < R; ++r) {
             const int row = r0 + r;
-            if (row >= n) { v[r] = 0.0f; continue; }
-            if (k < ctx_dim) {
-                v[r] = ctx_rows[(long)row * ctx_row_stride + (long)s_ti[r] * ctx_dim + k];
-            } else if constexpr (FILTER) {            // k_zf_apply's second phase for this element
-                const int c = k - ctx_dim;
-                double x = ((double)F.src.at(row, c) - s_ms[c]) * s_ms[state_dim + c];
-                if (F.clip > 0.0) x = fmin(fmax(x, -F.clip), F.clip);
-                const long e = (long)row * state_dim + c;
-                F.y[e] = x;
-                if (F.y2) F.y2[e] = x;
-                v[r] = (float)x;
-            } else {
-                v[r] = (float)state[(long)row * state_dim + (k - ctx_dim)];
+            float v = 0.0f;
+            if (row < n && k < in0) {
+                if (k < ctx_dim) {
+                    v = ctx_rows[(long)row * ctx_row_stride + (long)s_ti[r] * ctx_dim + k];
+                } else if constexpr (FILTER) {            // k_zf_apply's second phase for this element
+                    const int c = k - ctx_dim;
+                    double x = ((double)F.src.at(row, c) - s_ms[c]) * s_ms[state_dim + c];
+                    if (F.clip > 0.0) x = fmin(fmax(x, -F.clip), F.clip);
+                    const long e = (long)row * state_dim + c;
+                    F.y[e] = x;
+                    if (F.y2) F.y2[e] = x;
+                    v = (float)x;
+                } else {
+                    v = (float)state[(long)row * state_dim + (k - ctx_dim)];
+                }
             }
+            cur[r * xs + k] = v;
         }
-        cur[k] = make_float4(v[0], v[1], v[2], v[3]);
     }
     __syncthreads();
+
     for (int l = 0; l < L.n; ++l) {
-        const int in = L.in_dim[l], out = L.out_dim[l];
-        const int ldw = (out + 3) & ~3;                      // weight rows are padded to 4 floats
-        const int ncol = ldw >> 2;
-        const float4 *__restrict__ wt = reinterpret_cast<const float4 *>(L.wt[l]);
+        const int out = L.out_dim[l];
+        const int ng_all = (out + 63) >> 6;
         const bool last = l == L.n - 1;
-        const int cols = ncol < (int)blockDim.x ? ncol : (int)blockDim.x;
-        const int G = blockDim.x / cols;                     // input-feature slices
-        const int kc = (in + G - 1) / G;
-        const int col_l = threadIdx.x % cols, grp = threadIdx.x / cols;
-        for (int c0 = 0; c0 < ncol; c0 += cols) {
-            const int col = c0 + col_l;
-            if (grp < G && col < ncol) {
-                float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;      // a_o = output o of the column, .xyzw = rows
-                const int k0 = grp * kc, k1 = min(in, k0 + kc);
-                int k = k0;
-#define POL_FMA(W, X)                                                                                                     \
-    a0.x = fmaf(W.x, X.x, a0.x); a0.y = fmaf(W.x, X.y, a0.y); a0.z = fmaf(W.x, X.z, a0.z); a0.w = fmaf(W.x, X.w, a0.w);   \
-    a1.x = fmaf(W.y, X.x, a1.x); a1.y = fmaf(W.y, X.y, a1.y); a1.z = fmaf(W.y, X.z, a1.z); a1.w = fmaf(W.y, X.w, a1.w);   \
-    a2.x = fmaf(W.z, X.x, a2.x); a2.y = fmaf(W.z, X.y, a2.y); a2.z = fmaf(W.z, X.z, a2.z); a2.w = fmaf(W.z, X.w, a2.w);   \
-    a3.x = fmaf(W.w, X.x, a3.x); a3.y = fmaf(W.w, X.y, a3.y); a3.z = fmaf(W.w, X.z, a3.z); a3.w = fmaf(W.w, X.w, a3.w);
-                // eight weight rows in flight per round (sixteen: no further gain): the pass is a chain of L2 round trips (one workgroup streams every
-                // layer's weights), so the depth of each round is what its time is made of; same summation order as before
-                for (; k + 8 <= k1; k += 8) {
-                    float4 w[8];
+        const float *wl = L.wp[l];
+        for (int g0 = 0; g0 < ng_all; g0 += POL_GC) {
+            const int ng = min(POL_GC, ng_all - g0);
+            f32x4 acc[POL_GC][R / 4];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) w[u] = wt[(long)(k + u) * ncol + col];
+            for (int g = 0; g < POL_GC; ++g)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const float4 x = cur[k + u];
-                        POL_FMA(w[u], x)
+                for (int h = 0; h < R / 4; ++h) acc[g][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kq1 > kq0) {
+                switch (ng) {
+                    case 1: pol_pass<1, R, PF>(st, wl, nkq, g0, kq0, kq1, cur, xs, lane, acc); break;
+                    case 2: pol_pass<2, R, PF>(st, wl, nkq, g0, kq0, kq1, cur, xs, lane, acc); break;
+                    case 3: pol_pass<3, R, PF>(st, wl, nkq, g0, kq0, kq1, cur, xs, lane, acc); break;
+                    case 4: pol_pass<4, R, PF>(st, wl, nkq, g0, kq0, kq1, cur, xs, lane, acc); break;
+                    default: pol_pass<5, R, PF>(st, wl, nkq, g0, kq0, kq1, cur, xs, lane, acc); break;
+                }
+            }
+            // the next pass's first blocks: same layer's next column chunk, or the next layer
+            {
+                int nl = l, ng0 = g0 + POL_GC;
+                if (ng0 >= ng_all) { nl = l + 1; ng0 = 0; }
+                if (nl < L.n) {
+                    const int nkq_n = (L.in_dim[nl] + 3) >> 2;
+                    const int a = wave * nkq_n / NW, b = (wave + 1) * nkq_n / NW;
+                    const int ng_n = min(POL_GC, ((L.out_dim[nl] + 63) >> 6) - ng0);
+                    pol_preload<PF>(st, L.wp[nl], nkq_n, ng0, ng_n, a, max(b, a + 1), lane);
+                }
+            }
+            // partial sums -> LDS: register i of lane 4 b + j = out[row 4 h + j][column 64 g + 4 b + i]
+#pragma unroll
+            for (int g = 0; g < POL_GC; ++g)
+                if (g < ng) {
+#pragma unroll
+                    for (int h = 0; h < R / 4; ++h)
+                        *reinterpret_cast<f32x4 *>(part + ((wave * R) + 4 * h + (lane & 3)) * PS + 64 * g + (lane & ~3)) = acc[g][h];
+                }
+            __syncthreads();
+            const int c_base = 64 * g0;
+            const int cw = min(out - c_base, POL_GC * 64);               // real columns of this chunk
+            const int cw4 = last ? cw : min((cw + 3) & ~3, ng * 64);      // hidden layers: the pad columns of the last quad become zeros
+            for (int c = tid; c < cw4; c += T) {
+                const int col = c_base + c;
+                const bool real = c < cw;
+                const float bv = real ? L.bias[l][col] : 0.0f;
+                float v[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[r] = bv;
+#pragma unroll
+                for (int w = 0; w < NW; ++w)                         // fixed order: deterministic
+#pragma unroll
+                    for (int r = 0; r < R; ++r) v[r] += part[(w * R + r) * PS + c];
+                if (!last) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) nxt[r * xs + col] = real ? pol_act(v[r], act_kind) : 0.0f;
+                } else {
+                    const float sd = noise ? expf(log_std[col]) : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int row = r0 + r;
+                        if (row >= n) continue;
+                        const float a = noise ? fmaf(sd, noise[(long)row * out + col], v[r]) : v[r];
+                        action[(long)row * out + col] = (double)a;
+                        if (mean_out) mean_out[(long)row * out + col] = v[r];
                     }
                 }
-                for (; k + 4 <= k1; k += 4) {
-                    const float4 w0 = wt[(long)(k + 0) * ncol + col], w1 = wt[(long)(k + 1) * ncol + col];
-                    const float4 w2 = wt[(long)(k + 2) * ncol + col], w3 = wt[(long)(k + 3) * ncol + col];
-                    const float4 x0 = cur[k], x1 = cur[k + 1], x2 = cur[k + 2], x3 = cur[k + 3];
-                    POL_FMA(w0, x0) POL_FMA(w1, x1) POL_FMA(w2, x2) POL_FMA(w3, x3)
-                }
-                for (; k < k1; ++k) {
-                    const float4 w = wt[(long)k * ncol + col];
-                    const float4 x = cur[k];
-                    POL_FMA(w, x)
-                }
-#undef POL_FMA
-                float4 *pp = part + ((long)grp * ncol + col) * 4;
-                pp[0] = a0; pp[1] = a1; pp[2] = a2; pp[3] = a3;
             }
+            __syncthreads();
         }
-        __syncthreads();
-        for (int j = threadIdx.x; j < out; j += blockDim.x) {
-            const float b = L.bias[l][j];
-            float4 acc = make_float4(b, b, b, b);
-            for (int g = 0; g < G; ++g) {                   // fixed order: deterministic
-                const float4 p = part[((long)g * ncol + (j >> 2)) * 4 + (j & 3)];
-                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
-            }
-            if (!last) {
-                nxt[j] = make_float4(pol_act(acc.x, act_kind), pol_act(acc.y, act_kind), pol_act(acc.z, act_kind), pol_act(acc.w, act_kind));
-            } else {
-                const float m[POL_ROWS] = {acc.x, acc.y, acc.z, acc.w};
-                const float sd = noise ? expf(log_std[j]) : 0.0f;
-#pragma unroll
-                for (int r = 0; r < POL_ROWS; ++r) {
-                    const int row = r0 + r;
-                    if (row >= n) continue;
-                    const float a = noise ? fmaf(sd, noise[(long)row * out + j], m[r]) : m[r];
-                    action[(long)row * out + j] = (double)a;
-                    if (mean_out) mean_out[(long)row * out + j] = m[r];
-                }
-            }
+        if (!last) {
+            nkq = (L.in_dim[l + 1] + 3) >> 2;
+            kq0 = wave * nkq / NW; kq1 = (wave + 1) * nkq / NW;
+            float *t = cur; cur = nxt; nxt = t;
         }
-        __syncthreads();
-        float4 *t = cur; cur = nxt; nxt = t;
     }
 }
 
 }  // namespace
+
+// Packed form of an nn.Linear weight for the policy step: egp_mlp_pack_floats(in, out) floats.
+extern "C" int64_t egp_mlp_pack_floats(int32_t in_dim, int32_t out_dim) {
+    if (in_dim <= 0 || out_dim <= 0) return 0;
+    return (int64_t)((out_dim + 63) / 64) * ((in_dim + 3) / 4) * 256;
+}
+
+extern "C" int egp_mlp_pack_f32(const float *weight, int64_t ldw, int32_t in_dim, int32_t out_dim, float *packed, void *stream) {
+    EGP_REQUIRE(weight && packed && in_dim > 0 && out_dim > 0 && ldw >= in_dim, "bad weight");
+    const long total = (long)egp_mlp_pack_floats(in_dim, out_dim);
+    const int threads = 256;
+    const long blocks = (total + threads - 1) / threads;
+    k_mlp_pack<<<dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(threads), 0, (hipStream_t)stream>>>(weight, (long)ldw, in_dim, out_dim, packed, total);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { egp::set_error("k_mlp_pack launch failed: %s", hipGetErrorString(e)); return EGP_E_HIP; }
+    return EGP_OK;
+}
+
+// tile of the policy step: rows per workgroup x waves x weight blocks in flight per column group (EGP_POLICY_TILE="RxNWxPF")
+static void policy_tile(int *R, int *NW, int *PF) {
+    static int r = 0, nw = 0, pf = 0;
+    if (!r) {
+        int a = 8, b = 4, c = 4;
+        const char *e = getenv("EGP_POLICY_TILE");
+        if (e && sscanf(e, "%dx%dx%d", &a, &b, &c) != 3) { a = 8; b = 4; c = 4; }
+        r = a; nw = b; pf = c;
+    }
+    *R = r; *NW = nw; *PF = pf;
+}
+
+template <int R, int NW, int PF>
+static void policy_launch_t(bool flt, dim3 grid, size_t lds, hipStream_t s, const float *ctx_rows, long ctx_row_stride, int ctx_dim,
+                            const long long *t_idx, const double *state, int state_dim, int n, const PolLayers &L, int act, int xs,
+                            const float *log_std, const float *noise, double *action, float *mean_out, const unsigned *ssrc, unsigned *sdst,
+                            int swords, const PolFilter &F) {
+    if (flt)
+        k_policy_gaussian<R, NW, PF, true><<<grid, dim3(NW * 64), lds, s>>>(ctx_rows, ctx_row_stride, ctx_dim, t_idx, state, state_dim, n, L, act, xs,
+                                                                            log_std, noise, action, mean_out, ssrc, sdst, swords, F);
+    else
+        k_policy_gaussian<R, NW, PF, false><<<grid, dim3(NW * 64), lds, s>>>(ctx_rows, ctx_row_stride, ctx_dim, t_idx, state, state_dim, n, L, act, xs,
+                                                                             log_std, noise, action, mean_out, ssrc, sdst, swords, F);
+}
 
 static int policy_launch(const float *ctx_rows, int64_t ctx_row_stride, int32_t ctx_dim, const int64_t *t_idx,
                          const double *state, int32_t state_dim, int32_t n, const egp_mlp_layer *layers,
@@ -201,34 +346,32 @@ static int policy_launch(const float *ctx_rows, int64_t ctx_row_stride, int32_t 
     int kmax = ctx_dim + state_dim, prev = ctx_dim + state_dim;
     for (int l = 0; l < n_layers; ++l) {
         EGP_REQUIRE(layers[l].wt && layers[l].bias, "NULL layer");
+        EGP_REQUIRE(((uintptr_t)layers[l].wt & 15) == 0, "packed weights must be 16-byte aligned");
         EGP_REQUIRE(layers[l].in_dim == prev && layers[l].out_dim > 0, "layer dims do not chain");
-        L.wt[l] = layers[l].wt; L.bias[l] = layers[l].bias;
+        L.wp[l] = layers[l].wt; L.bias[l] = layers[l].bias;
         L.in_dim[l] = layers[l].in_dim; L.out_dim[l] = layers[l].out_dim;
         prev = layers[l].out_dim;
         if (prev > kmax) kmax = prev;
     }
     L.n = n_layers;
     EGP_REQUIRE(kmax <= 2048, "layer wider than 2048");
-    const int threads = 512;            // (320 .. 960 measured in the rollout: 20.9 / 19.2 (512) / 19.8 (640) / 21.1 us)
-    int part_elems = 0;                 // float4 slots for the partial sums: slices x padded outputs
-    for (int l = 0; l < n_layers; ++l) {
-        const int ncol = (layers[l].out_dim + 3) / 4;
-        const int cols = ncol < threads ? ncol : threads;
-        const int G = threads / cols;
-        const int e = G * ncol * 4;
-        if (e > part_elems) part_elems = e;
-    }
-    const size_t lds = ((size_t)2 * kmax + part_elems) * sizeof(float4) + (flt ? (size_t)2 * state_dim * sizeof(double) : 0);
+    int R, NW, PF;
+    policy_tile(&R, &NW, &PF);
+    const int xs = ((kmax + 31) & ~31) + 4;          // activation row stride: rows 0..3 of a broadcast read sit on different banks
+    const size_t lds = ((size_t)2 * R * xs + (size_t)NW * R * (POL_GC * 64 + 4)) * sizeof(float) + (flt ? (size_t)2 * state_dim * sizeof(double) : 0);
     EGP_REQUIRE(lds <= 150 * 1024, "layers too wide for the LDS tile");
-    const dim3 grid((n + POL_ROWS - 1) / POL_ROWS), block(threads);
-    if (flt)
-        k_policy_gaussian<true><<<grid, block, lds, (hipStream_t)stream>>>(
-            ctx_rows, (long)ctx_row_stride, ctx_dim, (const long long *)t_idx, state, state_dim, n, L, activation, kmax, part_elems,
-            log_std, noise, action, mean_out, stage_bytes ? (const unsigned *)stage_src : nullptr, (unsigned *)stage_dst, (int)(stage_bytes / 4), *flt);
-    else
-        k_policy_gaussian<false><<<grid, block, lds, (hipStream_t)stream>>>(
-            ctx_rows, (long)ctx_row_stride, ctx_dim, (const long long *)t_idx, state, state_dim, n, L, activation, kmax, part_elems,
-            log_std, noise, action, mean_out, stage_bytes ? (const unsigned *)stage_src : nullptr, (unsigned *)stage_dst, (int)(stage_bytes / 4), PolFilter{});
+    const dim3 grid((n + R - 1) / R);
+    const PolFilter F = flt ? *flt : PolFilter{};
+    const unsigned *ssrc = stage_bytes ? (const unsigned *)stage_src : nullptr;
+#define POL_CASE(r, w, p)                                                                                                              \
+    if (R == r && NW == w && PF == p) {                                                                                                \
+        policy_launch_t<r, w, p>(flt != nullptr, grid, lds, (hipStream_t)stream, ctx_rows, (long)ctx_row_stride, ctx_dim, (const long long *)t_idx, \
+                                 state, state_dim, n, L, activation, xs, log_std, noise, action, mean_out, ssrc, (unsigned *)stage_dst,  \
+                                 (int)(stage_bytes / 4), F);                                                                            \
+    } else
+    POL_CASE(8, 4, 4) POL_CASE(8, 4, 2) POL_CASE(8, 8, 2) POL_CASE(4, 4, 4) POL_CASE(4, 8, 2) POL_CASE(4, 8, 4) POL_CASE(8, 8, 1)
+    { egp::set_error("EGP_POLICY_TILE %dx%dx%d is not built", R, NW, PF); return EGP_E_INVALID; }
+#undef POL_CASE
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { egp::set_error("k_policy_gaussian launch failed: %s", hipGetErrorString(e)); return EGP_E_HIP; }
     return EGP_OK;

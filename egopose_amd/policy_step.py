@@ -1,7 +1,8 @@
 """Rollout-time policy step through `egp_policy_gaussian_f32` (csrc/egp_policy.hip): the VideoStateNet concat, the MLP
 and the Gaussian head of the reference's `policy_net.select_action` (core/agent.py:38-44, models/policy_gaussian.py:
 19-27, models/mlp.py:5-25) for a whole env group in one launch. The module keeps transposed float32 copies of the
-weights in persistent buffers (`refresh()` re-reads the live parameters, addresses stay fixed for hipGraphs)."""
+weights, packed for the kernel's matrix-core tiles, in persistent buffers (`refresh()` re-reads the live parameters,
+addresses stay fixed for hipGraphs)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -31,8 +32,9 @@ class FusedGaussianPolicy:
         self.net = policy_net
         self.layers = list(policy_net.net.affine_layers) + [policy_net.action_mean]
         self.act = _ACT_CODE[policy_net.net.activation]
-        pad4 = lambda v: (v + 3) // 4 * 4          # the kernel reads weight rows as float4
-        self.wt = [torch.zeros(l.in_features, pad4(l.out_features), dtype=torch.float32, device=device) for l in self.layers]
+        # the kernel's packed weight form (include/egopose_hip.h: egp_mlp_layer): one 64-column x 4-feature block per wave load
+        self.wt = [torch.zeros(int(self.lib.egp_mlp_pack_floats(l.in_features, l.out_features)), dtype=torch.float32, device=device)
+                   for l in self.layers]
         self.bias = [torch.empty(l.out_features, dtype=torch.float32, device=device) for l in self.layers]
         self.log_std = torch.empty(self.layers[-1].out_features, dtype=torch.float32, device=device)
         self.desc = (L.MlpLayer * len(self.layers))()
@@ -46,9 +48,12 @@ class FusedGaussianPolicy:
 
     @torch.no_grad()
     def refresh(self):
-        """Copy the live parameters into the transposed buffers (call once per rollout, after the optimiser step)."""
+        """Pack the live parameters into the kernel's buffers (call once per rollout, after the optimiser step)."""
+        stream = L.current_stream()
         for l, wt, b in zip(self.layers, self.wt, self.bias):
-            wt[:, :l.out_features].copy_(l.weight.t())
+            w = l.weight if l.weight.stride(1) == 1 else l.weight.contiguous()
+            L.check(self.lib.egp_mlp_pack_f32(C.c_void_p(w.data_ptr()), int(w.stride(0)), l.in_features, l.out_features,
+                                              C.c_void_p(wt.data_ptr()), stream), "egp_mlp_pack_f32")
             b.copy_(l.bias)
         self.log_std.copy_(self.net.action_log_std.reshape(-1))
 

@@ -81,6 +81,25 @@ class _Uploader:
         return out
 
 
+def global_budget(steps_done, cur_t, active, ids, a, b, t_eff, min_batch_size):
+    """EGP_STEP_BUDGET=global, decided when the episodes of slots `ids` (all inside group [a, b), still flagged active) have
+    ended: (park, rearm). park: the batch is covered by the steps collected plus what the OTHER running episodes deliver if
+    they reach their end -- the slots stop. Otherwise they restart, and if even their next episodes leave a shortfall (the
+    running episodes of an earlier decision ended early), `rearm` lists parked slots of the group to bring back: one per
+    t_eff missing steps."""
+    running = active.copy()
+    running[ids] = False
+    in_flight = int(np.maximum(t_eff - cur_t[running], 0).sum())
+    short = int(min_batch_size) - (int(steps_done.sum()) + in_flight)
+    if short <= 0:
+        return True, np.zeros(0, np.int64)
+    short -= len(ids) * int(t_eff)
+    if short <= 0:
+        return False, np.zeros(0, np.int64)
+    parked = np.nonzero(~active[a:b])[0] + a
+    return False, parked[:-(-short // int(t_eff))].astype(np.int64)
+
+
 class LockstepRollout:
 
     def __init__(self, sim, policy_net, policy_vs_net, running_state=None, noise_rate=1.0, mean_action=False,
@@ -320,14 +339,15 @@ class LockstepRollout:
         # 'global' (EGP_STEP_BUDGET / self.step_budget): when the batch as a whole is covered -- the same loop condition applied to all
         # slots together, counting what the running episodes can still deliver: a slot starts a new episode only while
         # (steps collected) + (steps the episodes in flight have left if they run to their end) < min_batch_size. The batch
-        # still reaches min_batch_size (when the episodes in flight fall short, restarts resume). With 1 024 slots and
+        # still reaches min_batch_size (when the episodes in flight fall short, restarts resume and parked slots of the group
+        # come back: `slot_finished`; checked before the batch is returned). With 1 024 slots and
         # 200-step episodes the per-slot rule restarts every episode that fails before its 48th step and the rollout ends
         # with ~45 ticks that step a few dozen envs; the global rule ends with the longest first episode (bench.py leg).
         budget = getattr(self, "step_budget", None) or os.environ.get("EGP_STEP_BUDGET", "slot")
         if budget not in ("slot", "global"):
             raise ValueError("step budget must be 'slot' or 'global', got %r" % (budget,))
         if budget == "global":
-            T_max = quota + 2 * T_ep          # (a slot may start another episode late, when the ones in flight fell short)
+            T_max = quota + 3 * T_ep          # (slots may start another episode late, when the ones in flight fell short)
         H = self.policy_vs_net.v_hdim
         self.policy_vs_net.attach_feature_table(self.experts.cnn_table(dev, ndt), self.experts.cnn_offset)
         self._pool, self._pool_pos = None, 0          # contexts depend on this iteration's weights
@@ -350,15 +370,29 @@ class LockstepRollout:
         steps_done = np.zeros(N, np.int64)
         active = np.ones(N, bool)
 
-        def slot_finished(ids):
+        def slot_finished(ids, a, b):
+            """Which of the slots `ids` (group [a, b)) whose episode has just ended stop for good, and which parked slots of the
+            group come back. 'global' budget: a slot parks while the steps collected plus what the running episodes can still
+            deliver cover the batch; when episodes in flight end early and leave a shortfall, the slots that have just ended go
+            on AND as many parked slots of this group as the shortfall needs are re-armed (they are reset with the others), so the
+            remainder is not left to a handful of slots one step per tick."""
             done_ = steps_done[ids] >= quota
+            rearm = np.zeros(0, np.int64)
             if budget == "global":
-                running = active.copy()
-                running[ids] = False                  # the episodes that have just ended deliver nothing more
                 t_eff = T_ep if self.env.fix_len is None else self.env.fix_len
-                in_flight = int(np.maximum(t_eff - self.cur_t[running], 0).sum())
-                done_[:] = int(steps_done.sum()) + in_flight >= min_batch_size
-            return done_
+                park, rearm = global_budget(steps_done, self.cur_t, active, ids, a, b, t_eff, min_batch_size)
+                done_[:] = park
+            return done_, rearm
+
+        def after_episodes(ids, a, b):
+            """Bookkeeping of the slots whose episode ended in this tick; returns the (sorted) slots to reset now."""
+            finished, rearm = slot_finished(ids, a, b)
+            active[ids[finished]] = False
+            again = ids[~finished]
+            if len(rearm):
+                active[rearm] = True
+                again = np.sort(np.concatenate([again, rearm]))
+            return again
         if self.running_state is not None:
             rs = self.running_state.rs
             self.zf_delta_base = (float(rs._n), np.array(rs._M, float).ravel().copy(), np.array(rs._S, float).ravel().copy())
@@ -454,9 +488,7 @@ class LockstepRollout:
             if done.any():
                 ids = np.nonzero(done)[0] + a
                 ep_lens.extend(self.cur_t[ids].tolist())
-                finished = slot_finished(ids)
-                active[ids[finished]] = False
-                again = ids[~finished]
+                again = after_episodes(ids, a, b)
                 if len(again):
                     self._reset_slots(again)
                     mask = np.zeros(b - a, np.int32)
@@ -623,9 +655,7 @@ class LockstepRollout:
             if n_done.value:
                 ids = np.nonzero(host["done"][k, a:b])[0] + a
                 ep_lens.extend(self.cur_t[ids].tolist())
-                finished = slot_finished(ids)
-                active[ids[finished]] = False
-                again = ids[~finished]
+                again = after_episodes(ids, a, b)
                 if len(again):
                     flush_apply(g, k)            # the resets' masked filter pass continues from the merged statistics
                 if len(again) and native_reset:
@@ -740,9 +770,7 @@ class LockstepRollout:
             if done.any():
                 ids = np.nonzero(done)[0] + a
                 ep_lens.extend(self.cur_t[ids].tolist())
-                finished = slot_finished(ids)
-                active[ids[finished]] = False
-                again = ids[~finished]
+                again = after_episodes(ids, a, b)
                 if len(again):
                     self._reset_slots(again)
                     mask = np.zeros(b - a, np.int32)
@@ -803,6 +831,8 @@ class LockstepRollout:
         ci = pick(rec["cinfo"])
         stats = torch.cat([r.sum().view(1), r.min().view(1), r.max().view(1), ci.sum(0)]).cpu().numpy()
         n_steps = int(r.shape[0])
+        if budget == "global" and n_steps < min_batch_size:
+            raise RuntimeError("rollout ended with %d steps, fewer than min_batch_size %d" % (n_steps, min_batch_size))
         ep = np.asarray(ep_lens, float)
         log = LoggerRL.from_totals(n_steps, len(ep), float(n_steps), ep.min(), ep.max(), stats[0], stats[1], stats[2], stats[3:])
         if self.running_state is not None:

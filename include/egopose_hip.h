@@ -450,13 +450,19 @@ int egp_dynamics_f64(egp_ctx *ctx, const double *qpos, const double *qvel, int32
  *   x[r] = [ctx_rows[r*ctx_row_stride + t_idx[r]*ctx_dim ...] (float32) | state[r] (float64 -> float32)]
  *   hidden layers with `activation` (0 tanh, 1 relu, 2 sigmoid), last layer = action_mean (no activation)
  *   action[r] = mean + exp(log_std) * noise[r]   (noise == NULL: action = mean), float32 arithmetic, stored float64
- * `layers[l].wt` is the TRANSPOSED weight, [in_dim][round_up(out_dim, 4)] row-major (zero padded, 16-byte aligned).
+ * The layer products run on the matrix cores in exact float32 (v_mfma_f32_4x4x1_16b_f32).
+ * `layers[l].wt` is the weight in the kernel's PACKED form (egp_mlp_pack_f32, 16-byte aligned): for each group g of 64 output
+ * columns and each quad kq of input features one block of 64 x 4 floats, packed[((g * ceil(in/4) + kq) * 64 + c) * 4 + kk] =
+ * W[64 g + c][4 kq + kk] (zero outside the matrix) -- a wave loads a block with one coalesced 16-byte load per lane.
  * mean_out (float32) may be NULL. */
 typedef struct egp_mlp_layer {
     const float *wt;
     const float *bias;
     int32_t in_dim, out_dim;
 } egp_mlp_layer;
+/* nn.Linear weight W[out_dim][in_dim] (device, row stride ldw floats) -> packed (device, egp_mlp_pack_floats(in_dim, out_dim) floats) */
+int64_t egp_mlp_pack_floats(int32_t in_dim, int32_t out_dim);
+int egp_mlp_pack_f32(const float *weight, int64_t ldw, int32_t in_dim, int32_t out_dim, float *packed, void *stream);
 int egp_policy_gaussian_f32(const float *ctx_rows, int64_t ctx_row_stride, int32_t ctx_dim, const int64_t *t_idx,
                             const double *state, int32_t state_dim, int32_t n, const egp_mlp_layer *layers,
                             int32_t n_layers, int32_t activation, const float *log_std, const float *noise,

@@ -432,3 +432,49 @@ def test_running_state_pickles_under_the_reference_module_path(tmp_path):
         out = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0 and "REF_LOADED 7" in out.stdout, out.stdout + out.stderr
         assert float(out.stdout.split()[-1]) == pytest.approx(float(zf(np.zeros(5), update=False).sum()), rel=1e-12)
+
+
+def test_global_step_budget_rearms_parked_slots_when_running_episodes_end_early():
+    """rollout.global_budget (EGP_STEP_BUDGET=global): slots park while collected + in-flight steps cover the batch; when the
+    episodes in flight then fail early, the decision at their end restarts them AND brings parked slots of the group back, so
+    that the batch is covered within a bounded number of ticks instead of by one slot stepping alone. A lockstep simulation of
+    two groups in which every episode after the first fails on its second step."""
+    from egopose_amd.rollout import global_budget
+    N, T_ep, min_batch = 32, 40, 32 * 12
+    groups = [(0, 16), (16, 32)]
+    steps_done, cur_t, active = np.zeros(N, np.int64), np.zeros(N, np.int64), np.ones(N, bool)
+    ep_no = np.zeros(N, np.int64)
+    # first episodes: group 0 fails at step 3 and parks (group 1's sixteen episodes would cover the batch), then group 1's episodes
+    # fail one after the other at steps 5, 6, ... 20: each parks in turn, and the last one ends with a shortfall of > 1 episode
+    fail_at = np.where(np.arange(N) < 16, 3, 5 + np.arange(N) - 16)
+    ticks, parked_seen, rearmed = 0, False, 0
+    while active.any():
+        ticks += 1
+        assert ticks <= 12 + 3 * T_ep, "the batch was left to too few slots"
+        for a, b in groups:
+            act = active[a:b].copy()
+            cur_t[a:b] += act
+            steps_done[a:b] += act
+            done = act & ((cur_t[a:b] >= fail_at[a:b]) | (cur_t[a:b] >= T_ep))
+            if done.any():
+                ids = np.nonzero(done)[0] + a
+                park, rearm = global_budget(steps_done, cur_t, active, ids, a, b, T_ep, min_batch)
+                assert set(rearm.tolist()).isdisjoint(ids.tolist()) and all(not active[r] for r in rearm)
+                if park:
+                    active[ids] = False
+                    parked_seen = True
+                restart = rearm if park else np.concatenate([ids, rearm])
+                active[restart] = True
+                cur_t[restart] = 0
+                ep_no[restart] += 1
+                fail_at[restart] = 2                      # every later episode fails on its second step
+                rearmed += len(rearm)
+    assert steps_done.sum() >= min_batch and parked_seen
+    # the re-arm rule itself: one slot ends, everything else is parked, 284 steps are missing -> that slot restarts and
+    # ceil((284 - 40) / 40) = 7 parked slots of ITS group come back (none of the other group's)
+    steps_done = np.full(N, 3, np.int64); steps_done[31] = 7          # 100 steps collected
+    active = np.zeros(N, bool); active[31] = True
+    park, rearm = global_budget(steps_done, np.zeros(N, np.int64), active, np.array([31]), 16, 32, T_ep, min_batch)
+    assert not park and rearm.tolist() == list(range(16, 23))
+    park, rearm = global_budget(steps_done + 10, np.zeros(N, np.int64), active, np.array([31]), 16, 32, T_ep, min_batch)
+    assert park and len(rearm) == 0                                    # 420 steps collected: covered

@@ -656,6 +656,14 @@ def test_global_step_budget_covers_the_batch_without_the_tail(workspace, skel, m
             assert len(batch.masks) >= min_batch and tr.agent._get_rollout().timing["step_budget"] == mode
             sizes[(mode, min_batch)] = (len(batch.masks), n_ep)
             _replay_episodes(tr, cfg, skel, batch, range(0, min(6, n_ep)), 0.3)
+        if mode == "global":
+            # every episode fails on its first step: the first group parks on the strength of the second group's episodes, which
+            # then deliver one step each -- the rollout must still cover the batch (restarts + re-armed slots), in bounded ticks
+            tr.env.fix_head_lb = 10.0
+            batch, log = tr.agent.sample(32 * 5)
+            assert len(batch.masks) >= 32 * 5 and int((batch.masks == 0).sum()) == len(batch.masks)
+            assert tr.agent._get_rollout().timing["ticks"] <= 5 + 3 * 12
+            tr.env.fix_head_lb = None
         tr.close()
     for min_batch in (32 * 5, 32 * 30):
         assert sizes[("global", min_batch)][0] <= sizes[("slot", min_batch)][0]
