@@ -340,6 +340,7 @@ def main():
         updater.time_collectives = True
     thr0 = cgroup_throttle()
     barrier()
+    D.COLLECTIVES["count"] = 0                    # (after the barrier: only the timed iterations' collectives are counted)
     t0 = time.time()
     steps_local, t_sample, t_update, per_iter = 0, 0.0, 0.0, []
     for _ in range(args.steps):
@@ -349,6 +350,7 @@ def main():
         t_update += tu
         per_iter.append((round(ts * 1e3, 1), round(tu * 1e3, 1)))
         it += 1
+    n_collectives = D.COLLECTIVES["count"]
     barrier()
     elapsed = time.time() - t0
     thr1 = cgroup_throttle()
@@ -383,8 +385,10 @@ def main():
             res["collectives"] = {"backend": torch.distributed.get_backend(), "ranks": world,
                                   "allreduce_ms_per_epoch": (sum(ar_ms) / len(ar_ms)) if ar_ms else None, "allreduces_timed": len(ar_ms),
                                   "allreduce_floats": int(updater.numel) if updater is not None else None,
-                                  "per_update": "1 MAX (padded window length) + 1 SUM (advantage moments + sample counts, 5 x float64) + "
-                                                "%d gradient all-reduces" % cfg.num_optim_epoch}
+                                  "collectives_per_iteration": n_collectives / max(1, args.steps),
+                                  "per_iteration": "sampling pass: 1 all-gather (LoggerRL totals + observation-filter deltas, merged on the "
+                                                   "device); update: 1 MAX (padded window length) + 1 all-gather (advantage moments + sample "
+                                                   "counts, 5 x float64, Chan-merged on the device) + %d gradient all-reduces" % cfg.num_optim_epoch}
     tr.close()
     if world > 1:
         torch.distributed.barrier()

@@ -218,10 +218,8 @@ class Agent:
         with to_test(*self.sample_modules):
             per_rank = int(math.ceil(min_batch_size / D.world_size()))
             batch, log = ro.sample(per_rank, end_reward=float(self.env.end_reward))
-        if D.world_size() > 1:
-            log = D.merge_loggers(log, self.device)
-            if self.running_state is not None:
-                D.merge_running_state(self.running_state, ro.zf_delta_base, self.device)
+        if D.world_size() > 1:      # logger totals + filter deltas: one all-gather, merged on the device (scalars beside the update's collectives)
+            log = D.merge_sampling_pass(log, self.running_state, ro.zf_delta_base if self.running_state is not None else None, self.device)
         log.sample_time = time.time() - t0
         return batch, log
 

@@ -35,7 +35,7 @@ def _obj_stale(src, force):
 
 
 def _compile(src, verbose):
-    cmd = [_hipcc()] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", _obj_of(src)]
+    cmd = [_hipcc()] + FLAGS + os.environ.get("EGP_BUILD_DEFS", "").split() + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", _obj_of(src)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

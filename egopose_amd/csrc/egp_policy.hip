@@ -41,6 +41,14 @@ struct PolFilter {
     double *y, *y2;                  // [n][dim] each (y2 may be NULL)
 };
 
+// EGP_POLICY_TRACE (tools/probes/policy_trace.py builds the library with it): wall_clock64 stamps (100 MHz) of thread 0 of one workgroup
+#ifdef EGP_POLICY_TRACE
+__device__ long long g_pol_trace[64];
+#define POL_TR(i) do { if (blockIdx.x == EGP_POLICY_TRACE && threadIdx.x == 0) g_pol_trace[i] = wall_clock64(); } while (0)
+#else
+#define POL_TR(i) do { } while (0)
+#endif
+
 constexpr int POL_MAX_LAYERS = 8;
 constexpr int POL_GC = 5;            // column groups (64 outputs each) a pass accumulates in registers: 320 >= the 300-wide layer
 
@@ -49,6 +57,8 @@ struct PolLayers {
     const float *bias[POL_MAX_LAYERS];
     int in_dim[POL_MAX_LAYERS], out_dim[POL_MAX_LAYERS];
     int n;                                // hidden layers + the output layer
+    int sum_out4;                         // sum of the output widths, each rounded up to 4 (the LDS copy of the biases)
+    int warm_lines;                       // 128-byte lines of the packed weights when the layers' buffers follow each other in memory, else 0
 };
 
 __device__ __forceinline__ float pol_act(float v, int kind) {
@@ -110,19 +120,16 @@ __device__ __forceinline__ void pol_pass(PolStage<PF> &st, const float *__restri
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + 4 * h * xs + 4 * kc);
                 b[h][0] = live ? v[0] : 0.0f; b[h][1] = live ? v[1] : 0.0f; b[h][2] = live ? v[2] : 0.0f; b[h][3] = live ? v[3] : 0.0f;
             }
-            f32x4 w[NG];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) w[g] = st.w[s][g];
-            const int kn = min(k + PF, kq1 - 1);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) st.w[s][g] = *reinterpret_cast<const f32x4 *>(wb + g * gstride + (long)kn * 256);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
 #pragma unroll
                     for (int h = 0; h < R / 4; ++h)
-                        acc[g][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[g][kk], b[h][kk], acc[g][h], 0, 0, 0);
+                        acc[g][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(st.w[s][g][kk], b[h][kk], acc[g][h], 0, 0, 0);
+            const int kn = min(k + PF, kq1 - 1);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) st.w[s][g] = *reinterpret_cast<const f32x4 *>(wb + g * gstride + (long)kn * 256);
         }
     }
 }
@@ -133,25 +140,46 @@ __device__ __forceinline__ void pol_pass(PolStage<PF> &st, const float *__restri
 // kernels that run after the env-step (reward, filter) read it there -- and take their own rows' indices (`t_idx`, which then
 // points into the pinned slab) with ONE load per row.
 template <int R, int NW, int PF, bool FILTER>
-// Register budget: a resident K1 workgroup keeps one 344-register wave on every SIMD for the length of an env-step; a policy
-// workgroup must fit beside it (168 registers per SIMD left), or it can only be placed on CUs without one.
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3 * NW / 4, 3 * NW / 4))) void k_policy_gaussian(const float *__restrict__ ctx_rows, long ctx_row_stride, int ctx_dim,
+__device__ __forceinline__ void policy_body(const float *__restrict__ ctx_rows, long ctx_row_stride, int ctx_dim,
                                   const long long *__restrict__ t_idx, const double *__restrict__ state, int state_dim, int n,
-                                  PolLayers L, int act_kind, int xs, const float *__restrict__ log_std,
+                                  const PolLayers &L, int act_kind, int xs, const float *__restrict__ log_std,
                                   const float *__restrict__ noise, double *__restrict__ action, float *__restrict__ mean_out,
                                   const unsigned *__restrict__ stage_src, unsigned *__restrict__ stage_dst, int stage_words,
-                                  PolFilter F) {
+                                  const PolFilter &F) {
     constexpr int T = NW * 64;
     constexpr int PS = POL_GC * 64 + 4;              // row stride of a wave's partial sums (floats)
     extern __shared__ __attribute__((aligned(16))) float s_f[];     // cur[R][xs] | nxt[R][xs] | part[NW][R][PS] [| mean, 1/std: 2 dim doubles]
-    __shared__ long long s_ti[R];
     float *cur = s_f, *nxt = s_f + R * xs, *part = s_f + 2 * R * xs;
-    double *s_ms = reinterpret_cast<double *>(part + NW * R * PS);
+    // small operands of the epilogues, fetched once in the prologue (a global load in an epilogue is a cold round trip on the chain):
+    // every layer's bias | exp(log_std) | the rows' noise
+    float *s_bias = part + NW * R * PS;
+    const int out_last = L.out_dim[L.n - 1];
+    float *s_sd = s_bias + L.sum_out4, *s_noise = s_sd + ((out_last + 3) & ~3);
+    double *s_ms = reinterpret_cast<double *>(s_noise + R * ((out_last + 3) & ~3) + ((R * ((out_last + 3) & ~3)) & 1));
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: the k loops' bounds live in SGPRs)
     const int r0 = blockIdx.x * R;
     const int in0 = ctx_dim + state_dim;
 
-    // the first layer's weights are on their way before anything else
+    POL_TR(0);
+    // L2 warm-up. A kernel starts with a cold L2 on every XCD (the per-XCD L2s are invalidated at kernel boundaries), so the
+    // first touch of a weight line costs a trip to the memory side (~0.7 us) and a wave's PF x POL_GC KiB in flight turn the
+    // weight stream into a chain of such trips. The workgroups of one XCD (round-robin dispatch: blockIdx & 7) therefore each
+    // touch a DIFFERENT slice of the packed weights right away -- one dword per 128-byte line, all requests in flight at once --
+    // while the input rows are gathered; by the time the k loops start, the XCD's L2 holds every layer and the stream runs at
+    // L2-hit latency. (Pure prefetch: results are never used; up to POL_WARM x T lines per workgroup; needs the layers' packed
+    // buffers back to back in memory -- FusedGaussianPolicy allocates them so -- else warm_lines = 0 and one line is touched.)
+    constexpr int POL_WARM = 8;
+    float warm[POL_WARM];
+    {
+        const int per_xcd = (gridDim.x + 7) >> 3, me = blockIdx.x >> 3;
+        const int lo = (int)((long)L.warm_lines * me / per_xcd), hi = (int)((long)L.warm_lines * (me + 1) / per_xcd);
+#pragma unroll
+        for (int u = 0; u < POL_WARM; ++u) {
+            const int i = min(lo + tid + u * T, max(hi - 1, 0));
+            warm[u] = L.wp[0][(long)i * 32];
+        }
+    }
+    // the first layer's own first blocks
     PolStage<PF> st;
     int nkq = (L.in_dim[0] + 3) >> 2;
     int kq0 = wave * nkq / NW, kq1 = (wave + 1) * nkq / NW;
@@ -175,10 +203,27 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3 * NW 
             s_ms[dim + c] = 1.0 / (sqrt(var) + 1e-8);
         }
     }
-    if (tid < R) s_ti[tid] = r0 + tid < n ? t_idx[r0 + tid] : 0;
+    POL_TR(1);
+    {
+        int off = 0;
+        for (int l = 0; l < L.n; ++l) {
+            for (int j = tid; j < L.out_dim[l]; j += T) s_bias[off + j] = L.bias[l][j];
+            off += (L.out_dim[l] + 3) & ~3;
+        }
+        if (noise) {
+            for (int j = tid; j < out_last; j += T) s_sd[j] = expf(log_std[j]);
+            for (int e = tid; e < R * out_last; e += T) {
+                const int r = e / out_last, j = e - r * out_last;
+                s_noise[e] = r0 + r < n ? noise[(long)(r0 + r) * out_last + j] : 0.0f;
+            }
+        }
+    }
+    long ctx_off[R];                      // every thread resolves its rows' context offsets itself: no LDS hop + barrier between the two dependent loads
+#pragma unroll
+    for (int r = 0; r < R; ++r) ctx_off[r] = (long)min(r0 + r, n - 1) * ctx_row_stride + (long)t_idx[min(r0 + r, n - 1)] * ctx_dim;
     if (stage_src)
         for (int i = blockIdx.x * T + tid; i < stage_words; i += gridDim.x * T) stage_dst[i] = stage_src[i];
-    __syncthreads();
+    if constexpr (FILTER) __syncthreads();            // the merged statistics (s_ms) are read by the staging loop below
     const int in0p = (in0 + 3) & ~3;
     for (int k = tid; k < in0p; k += T) {
 #pragma unroll
@@ -187,7 +232,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3 * NW 
             float v = 0.0f;
             if (row < n && k < in0) {
                 if (k < ctx_dim) {
-                    v = ctx_rows[(long)row * ctx_row_stride + (long)s_ti[r] * ctx_dim + k];
+                    v = ctx_rows[ctx_off[r] + k];
                 } else if constexpr (FILTER) {            // k_zf_apply's second phase for this element
                     const int c = k - ctx_dim;
                     double x = ((double)F.src.at(row, c) - s_ms[c]) * s_ms[state_dim + c];
@@ -204,7 +249,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3 * NW 
         }
     }
     __syncthreads();
+    {   // the warm-up loads have long landed; their registers are free from here on
+        float sink = 0.0f;
+#pragma unroll
+        for (int u = 0; u < POL_WARM; ++u) sink += warm[u];
+        asm volatile("" ::"v"(sink));
+    }
+    POL_TR(2);
 
+    int bias_off = 0;
     for (int l = 0; l < L.n; ++l) {
         const int out = L.out_dim[l];
         const int ng_all = (out + 63) >> 6;
@@ -226,6 +279,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3 * NW 
                     default: pol_pass<5, R, PF>(st, wl, nkq, g0, kq0, kq1, cur, xs, lane, acc); break;
                 }
             }
+            POL_TR(3 + 4 * l);
             // the next pass's first blocks: same layer's next column chunk, or the next layer
             {
                 int nl = l, ng0 = g0 + POL_GC;
@@ -245,14 +299,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3 * NW 
                     for (int h = 0; h < R / 4; ++h)
                         *reinterpret_cast<f32x4 *>(part + ((wave * R) + 4 * h + (lane & 3)) * PS + 64 * g + (lane & ~3)) = acc[g][h];
                 }
+            POL_TR(4 + 4 * l);
             __syncthreads();
+            POL_TR(5 + 4 * l);
             const int c_base = 64 * g0;
             const int cw = min(out - c_base, POL_GC * 64);               // real columns of this chunk
             const int cw4 = last ? cw : min((cw + 3) & ~3, ng * 64);      // hidden layers: the pad columns of the last quad become zeros
             for (int c = tid; c < cw4; c += T) {
                 const int col = c_base + c;
                 const bool real = c < cw;
-                const float bv = real ? L.bias[l][col] : 0.0f;
+                const float bv = real ? s_bias[bias_off + col] : 0.0f;
                 float v[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) v[r] = bv;
@@ -264,19 +320,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3 * NW 
 #pragma unroll
                     for (int r = 0; r < R; ++r) nxt[r * xs + col] = real ? pol_act(v[r], act_kind) : 0.0f;
                 } else {
-                    const float sd = noise ? expf(log_std[col]) : 0.0f;
+                    const float sd = noise ? s_sd[col] : 0.0f;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const int row = r0 + r;
                         if (row >= n) continue;
-                        const float a = noise ? fmaf(sd, noise[(long)row * out + col], v[r]) : v[r];
+                        const float a = noise ? fmaf(sd, s_noise[r * out + col], v[r]) : v[r];
                         action[(long)row * out + col] = (double)a;
                         if (mean_out) mean_out[(long)row * out + col] = v[r];
                     }
                 }
             }
             __syncthreads();
+            POL_TR(6 + 4 * l);
         }
+        bias_off += (out + 3) & ~3;
         if (!last) {
             nkq = (L.in_dim[l + 1] + 3) >> 2;
             kq0 = wave * nkq / NW; kq1 = (wave + 1) * nkq / NW;
@@ -285,7 +343,32 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3 * NW 
     }
 }
 
+// Registers: no cap. A resident K1 workgroup keeps one 346-register wave on every SIMD of its CU for the length of an env-step
+// (160 left); with 2 groups the OTHER group's K1 occupies half the CUs while this group's policy step runs. A policy workgroup
+// that needs more than 160 registers per SIMD cannot be placed beside a K1 wave and goes to the K1-free CUs -- which is where it
+// runs fastest anyway (no polling waves competing for issue slots), so the prefetch depth is chosen for speed, not for fitting.
+#define POL_KERNEL_ARGS                                                                                                          \
+    const float *__restrict__ ctx_rows, long ctx_row_stride, int ctx_dim, const long long *__restrict__ t_idx,                     \
+        const double *__restrict__ state, int state_dim, int n, PolLayers L, int act_kind, int xs, const float *__restrict__ log_std, \
+        const float *__restrict__ noise, double *__restrict__ action, float *__restrict__ mean_out,                               \
+        const unsigned *__restrict__ stage_src, unsigned *__restrict__ stage_dst, int stage_words, PolFilter F
+#define POL_KERNEL_PASS ctx_rows, ctx_row_stride, ctx_dim, t_idx, state, state_dim, n, L, act_kind, xs, log_std, noise, action, mean_out, stage_src, stage_dst, stage_words, F
+template <int R, int PF, bool FILTER>
+__global__ __launch_bounds__(256) void k_policy_gaussian_w4(POL_KERNEL_ARGS) {
+    policy_body<R, 4, PF, FILTER>(POL_KERNEL_PASS);
+}
+template <int R, int PF, bool FILTER>
+__global__ __launch_bounds__(512) void k_policy_gaussian_w8(POL_KERNEL_ARGS) {
+    policy_body<R, 8, PF, FILTER>(POL_KERNEL_PASS);
+}
+
 }  // namespace
+
+#ifdef EGP_POLICY_TRACE
+extern "C" int egp_policy_trace_read(long long *out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_pol_trace), sizeof(long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // Packed form of an nn.Linear weight for the policy step: egp_mlp_pack_floats(in, out) floats.
 extern "C" int64_t egp_mlp_pack_floats(int32_t in_dim, int32_t out_dim) {
@@ -304,13 +387,15 @@ extern "C" int egp_mlp_pack_f32(const float *weight, int64_t ldw, int32_t in_dim
     return EGP_OK;
 }
 
-// tile of the policy step: rows per workgroup x waves x weight blocks in flight per column group (EGP_POLICY_TILE="RxNWxPF")
+// tile of the policy step: rows per workgroup x waves x weight blocks in flight per column group (EGP_POLICY_TILE="RxNWxPF").
+// Round-4 sweep on the MI355X (tools/probes/policy_tile_sweep.sh; 512 rows, bench workload): 4x4x2 15.2 us per launch and the
+// lowest / least scattered T_sample; 4x8x2 14.9 us; 8-row tiles 19-21 us (twice the MFMAs per workgroup on half the CUs).
 static void policy_tile(int *R, int *NW, int *PF) {
     static int r = 0, nw = 0, pf = 0;
     if (!r) {
-        int a = 8, b = 4, c = 4;
+        int a = 4, b = 4, c = 2;
         const char *e = getenv("EGP_POLICY_TILE");
-        if (e && sscanf(e, "%dx%dx%d", &a, &b, &c) != 3) { a = 8; b = 4; c = 4; }
+        if (e && sscanf(e, "%dx%dx%d", &a, &b, &c) != 3) { a = 4; b = 4; c = 2; }
         r = a; nw = b; pf = c;
     }
     *R = r; *NW = nw; *PF = pf;
@@ -321,12 +406,11 @@ static void policy_launch_t(bool flt, dim3 grid, size_t lds, hipStream_t s, cons
                             const long long *t_idx, const double *state, int state_dim, int n, const PolLayers &L, int act, int xs,
                             const float *log_std, const float *noise, double *action, float *mean_out, const unsigned *ssrc, unsigned *sdst,
                             int swords, const PolFilter &F) {
-    if (flt)
-        k_policy_gaussian<R, NW, PF, true><<<grid, dim3(NW * 64), lds, s>>>(ctx_rows, ctx_row_stride, ctx_dim, t_idx, state, state_dim, n, L, act, xs,
-                                                                            log_std, noise, action, mean_out, ssrc, sdst, swords, F);
-    else
-        k_policy_gaussian<R, NW, PF, false><<<grid, dim3(NW * 64), lds, s>>>(ctx_rows, ctx_row_stride, ctx_dim, t_idx, state, state_dim, n, L, act, xs,
-                                                                             log_std, noise, action, mean_out, ssrc, sdst, swords, F);
+#define POL_GO(KERN, FLT) KERN<R, PF, FLT><<<grid, dim3(NW * 64), lds, s>>>(ctx_rows, ctx_row_stride, ctx_dim, t_idx, state, state_dim, n, L, act, xs, \
+                                                                            log_std, noise, action, mean_out, ssrc, sdst, swords, F)
+    if constexpr (NW == 4) { if (flt) POL_GO(k_policy_gaussian_w4, true); else POL_GO(k_policy_gaussian_w4, false); }
+    else { if (flt) POL_GO(k_policy_gaussian_w8, true); else POL_GO(k_policy_gaussian_w8, false); }
+#undef POL_GO
 }
 
 static int policy_launch(const float *ctx_rows, int64_t ctx_row_stride, int32_t ctx_dim, const int64_t *t_idx,
@@ -355,10 +439,23 @@ static int policy_launch(const float *ctx_rows, int64_t ctx_row_stride, int32_t 
     }
     L.n = n_layers;
     EGP_REQUIRE(kmax <= 2048, "layer wider than 2048");
+    L.sum_out4 = 0;
+    long lines = 0;
+    bool contiguous = true;
+    for (int l = 0; l < n_layers; ++l) {
+        L.sum_out4 += (layers[l].out_dim + 3) & ~3;
+        if (l > 0 && layers[l].wt != layers[l - 1].wt + egp_mlp_pack_floats(layers[l - 1].in_dim, layers[l - 1].out_dim)) contiguous = false;
+        lines += egp_mlp_pack_floats(layers[l].in_dim, layers[l].out_dim) / 32;
+    }
+    L.warm_lines = contiguous && lines < (1l << 30) ? (int)lines : 0;
     int R, NW, PF;
     policy_tile(&R, &NW, &PF);
     const int xs = ((kmax + 31) & ~31) + 4;          // activation row stride: rows 0..3 of a broadcast read sit on different banks
-    const size_t lds = ((size_t)2 * R * xs + (size_t)NW * R * (POL_GC * 64 + 4)) * sizeof(float) + (flt ? (size_t)2 * state_dim * sizeof(double) : 0);
+    size_t small = 0;                                 // biases | exp(log_std) | noise rows (floats, see the kernel's carve-up)
+    for (int l = 0; l < n_layers; ++l) small += (size_t)((layers[l].out_dim + 3) & ~3);
+    const size_t out4 = (size_t)((layers[n_layers - 1].out_dim + 3) & ~3);
+    small += out4 + (size_t)R * out4 + 1;
+    const size_t lds = ((size_t)2 * R * xs + (size_t)NW * R * (POL_GC * 64 + 4) + small) * sizeof(float) + (flt ? (size_t)2 * state_dim * sizeof(double) : 0);
     EGP_REQUIRE(lds <= 150 * 1024, "layers too wide for the LDS tile");
     const dim3 grid((n + R - 1) / R);
     const PolFilter F = flt ? *flt : PolFilter{};
@@ -369,7 +466,7 @@ static int policy_launch(const float *ctx_rows, int64_t ctx_row_stride, int32_t 
                                  state, state_dim, n, L, activation, xs, log_std, noise, action, mean_out, ssrc, (unsigned *)stage_dst,  \
                                  (int)(stage_bytes / 4), F);                                                                            \
     } else
-    POL_CASE(8, 4, 4) POL_CASE(8, 4, 2) POL_CASE(8, 8, 2) POL_CASE(4, 4, 4) POL_CASE(4, 8, 2) POL_CASE(4, 8, 4) POL_CASE(8, 8, 1)
+    POL_CASE(8, 4, 2) POL_CASE(4, 4, 2) POL_CASE(4, 4, 4) POL_CASE(4, 8, 2) POL_CASE(4, 8, 4) POL_CASE(8, 8, 2)
     { egp::set_error("EGP_POLICY_TILE %dx%dx%d is not built", R, NW, PF); return EGP_E_INVALID; }
 #undef POL_CASE
     hipError_t e = hipGetLastError();

@@ -230,6 +230,7 @@ class FlatUpdater:
         if self.time_collectives:           # HIP events around the collective (bench.py --gpus N: allreduce_ms_per_epoch)
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        D._note()
         if dev == G.device:
             torch.distributed.all_reduce(G)
         else:

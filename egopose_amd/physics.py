@@ -292,25 +292,14 @@ _RANKS_ON_HOST = None
 
 
 def ranks_on_host():
-    """Processes sharing this host's cores: torchrun's LOCAL_WORLD_SIZE; without it, the ranks of an initialised process group
-    that report this host's name (one all-gather, cached -- a multi-node launch without torchrun must not divide the host's
-    cores by the GLOBAL rank count); a single-node WORLD_SIZE as the last resort; else 1."""
-    global _RANKS_ON_HOST
+    """Processes sharing this host's cores: torchrun's LOCAL_WORLD_SIZE; else what `dist.count_ranks_on_host()` found when the
+    process group was set up (a collective every rank passes there -- this function only reads the cached value, it never
+    communicates); a single-node WORLD_SIZE as the last resort; else 1."""
     v = os.environ.get("LOCAL_WORLD_SIZE")
     if v and v.isdigit() and int(v) > 0:
         return int(v)
     if _RANKS_ON_HOST is not None:
         return _RANKS_ON_HOST
-    try:
-        import socket
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            names = [None] * dist.get_world_size()
-            dist.all_gather_object(names, socket.gethostname())
-            _RANKS_ON_HOST = max(1, sum(1 for n in names if n == socket.gethostname()))
-            return _RANKS_ON_HOST
-    except Exception:
-        pass
     v = os.environ.get("WORLD_SIZE")
     if v and v.isdigit() and int(v) > 0:
         return int(v)

@@ -33,8 +33,10 @@ class FusedGaussianPolicy:
         self.layers = list(policy_net.net.affine_layers) + [policy_net.action_mean]
         self.act = _ACT_CODE[policy_net.net.activation]
         # the kernel's packed weight form (include/egopose_hip.h: egp_mlp_layer): one 64-column x 4-feature block per wave load
-        self.wt = [torch.zeros(int(self.lib.egp_mlp_pack_floats(l.in_features, l.out_features)), dtype=torch.float32, device=device)
-                   for l in self.layers]
+        # (ONE buffer, layer after layer: the kernel's L2 warm-up walks it as a single range)
+        sizes = [int(self.lib.egp_mlp_pack_floats(l.in_features, l.out_features)) for l in self.layers]
+        self.wt_all = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+        self.wt = list(torch.split(self.wt_all, sizes))
         self.bias = [torch.empty(l.out_features, dtype=torch.float32, device=device) for l in self.layers]
         self.log_std = torch.empty(self.layers[-1].out_features, dtype=torch.float32, device=device)
         self.desc = (L.MlpLayer * len(self.layers))()

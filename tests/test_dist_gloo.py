@@ -59,7 +59,6 @@ def _worker(rank, world, port, out_dir):
     # scalar exchanges
     lg = LoggerRL.from_totals(10 + rank, 2 + rank, 10.0 + rank, 3 + rank, 7 + rank, 4.5 * (rank + 1), 0.1 * (rank + 1), 0.9 - 0.1 * rank,
                               np.arange(5.0) * (rank + 1))
-    merged = D.merge_loggers(lg, "cpu")
     rng = np.random.RandomState(7)
     X = rng.normal(size=(60, 5)) * 2 + 1
     zf = ZFilter((5,), clip=5)
@@ -68,11 +67,23 @@ def _worker(rank, world, port, out_dir):
     base = (float(zf.rs._n), zf.rs._M.copy(), zf.rs._S.copy())
     mine = X[10:35] if rank == 0 else X[35:]
     zf.rs.merge(len(mine), mine.mean(0), ((mine - mine.mean(0)) ** 2).sum(0))
-    D.merge_running_state(zf, base, "cpu")
+    before = D.COLLECTIVES["count"]
+    merged = D.merge_sampling_pass(lg, zf, base, "cpu")           # logger totals + filter deltas: ONE collective
+    n_coll = D.COLLECTIVES["count"] - before
+    # the two single-purpose wrappers give the same numbers
+    merged_b = D.merge_loggers(lg, "cpu")
+    assert merged_b.num_steps == merged.num_steps and merged_b.min_c_reward == merged.min_c_reward
+    # advantage moments: |mean| >> std and a rank without samples whose mean is NaN (raw sums cancel / poison)
+    big = torch.tensor([4.0, 1.0e9 + rank, 2.0], dtype=torch.float64) if rank == 0 else torch.tensor([0.0, float("nan"), float("nan")], dtype=torch.float64)
+    gm, cnt = D.merge_moments_and_counts(big, (3 + rank, 1))
+    assert cnt == [7, 2]
+    np.testing.assert_array_equal(gm.numpy(), [4.0, 1.0e9, 2.0])  # the empty rank changes nothing, nothing cancels
+    two = torch.tensor([3.0, 1.0e8 + 1.0, 2.0], dtype=torch.float64) if rank == 0 else torch.tensor([2.0, 1.0e8 + 3.5, 0.5], dtype=torch.float64)
+    gm2 = D.merge_moments(two)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), n_steps=merged.num_steps, avg_c=merged.avg_c_reward,
              min_c=merged.min_c_reward, max_ep=merged.max_episode_reward, avg_ci=merged.avg_c_info,
              zf_n=zf.rs.n, zf_mean=zf.rs.mean, zf_std=zf.rs.std, count=D.global_count(3 + rank, "cpu"),
-             gmax=D.global_max(5 + 2 * rank), **final)
+             gmax=D.global_max(5 + 2 * rank), n_coll=n_coll, gm2=gm2.numpy(), **final)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -93,6 +104,10 @@ def test_two_rank_ppo_update_equals_single_process_reference(tmp_path):
     np.testing.assert_allclose(r0["avg_c"], (4.5 + 9.0) / 21)
     np.testing.assert_allclose(r0["min_c"], 0.1)
     np.testing.assert_allclose(r0["avg_ci"], np.arange(5.0) * 3 / 21)
+    assert int(r0["n_coll"]) == 1 and int(r1["n_coll"]) == 1                  # one collective per sampling pass
+    # Chan merge of {3, 1e8+1, 2} and {2, 1e8+3.5, 0.5}: d = 2.5, M2 = 2.5 + 6.25 * 6/5 = 10 (raw sums would lose it at 1e16)
+    np.testing.assert_allclose(r0["gm2"], [5.0, 1.0e8 + 2.0, 10.0], rtol=1e-14)
+    np.testing.assert_array_equal(r0["gm2"], r1["gm2"])
     # observation filter: merged moments == pushing all 60 rows sequentially
     from egopose_amd.zfilter import ZFilter
     rng = np.random.RandomState(7)

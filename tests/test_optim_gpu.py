@@ -259,5 +259,24 @@ def test_rccl_single_rank_process_group_runs_the_update_collectives():
         assert zf.rs.n == 30
         np.testing.assert_allclose(zf.rs.mean, mean, rtol=1e-12)
         np.testing.assert_allclose(zf.rs.std, std, rtol=1e-10)
+        # the sampling pass's single collective: logger totals + filter deltas in one all-gather, merged on the GPU
+        zf2 = ZFilter((5,), clip=5)
+        for x in X[:10]:
+            zf2(x)
+        base2 = (float(zf2.rs._n), zf2.rs._M.copy(), zf2.rs._S.copy())
+        for x in X[10:]:
+            zf2(x)
+        c0 = D.COLLECTIVES["count"]
+        merged2 = D.merge_sampling_pass(lg, zf2, base2, "cuda:0")
+        assert D.COLLECTIVES["count"] - c0 == 1
+        assert merged2.num_steps == 10 and merged2.min_c_reward == 0.1 and merged2.max_c_reward == 0.9
+        np.testing.assert_allclose(merged2.avg_c_info, np.arange(5.0) / 10)
+        assert zf2.rs.n == 30
+        np.testing.assert_allclose(zf2.rs.mean, mean, rtol=1e-12)
+        np.testing.assert_allclose(zf2.rs.std, std, rtol=1e-10)
+        # Chan merge on the device ignores a NaN mean of an empty contribution
+        rows = torch.tensor([[0.0, float("nan"), float("nan")], [4.0, 1.0e9, 2.0]], dtype=torch.float64, device="cuda")
+        n_, m_, s_ = D.chan_merge_rows(rows, 1)
+        assert float(n_) == 4.0 and float(m_[0]) == 1.0e9 and float(s_[0]) == 2.0
     finally:
         dist.destroy_process_group()
