@@ -32,7 +32,7 @@ class ModelDesc(C.Structure):
         ("k_rl", C.c_double), ("k_ra", C.c_double),
         ("v_ord", C.c_double), ("decay", C.c_int32),
         ("obs_heading", C.c_int32), ("obs_keep_root_heading", C.c_int32), ("obs_coord_root", C.c_int32), ("obs_vel", C.c_int32),
-        ("action_torque", C.c_int32),
+        ("action_torque", C.c_int32), ("obs_phase", C.c_int32),
     ]
 
 
@@ -154,8 +154,8 @@ SIGNATURES = {
     "egp_quat_op_f32": (C.c_int, [_i32, vp, vp, _i32, vp, vp]),
     "egp_body_quat_f64": (C.c_int, [vp, vp, _i32, vp, vp]),
     "egp_body_quat_f32": (C.c_int, [vp, vp, _i32, vp, vp]),
-    "egp_obs_f64": (C.c_int, [vp, vp, vp, _i32, vp, vp]),
-    "egp_obs_f32": (C.c_int, [vp, vp, vp, _i32, vp, vp]),
+    "egp_obs_f64": (C.c_int, [vp, vp, vp, vp, _i32, vp, vp]),
+    "egp_obs_f32": (C.c_int, [vp, vp, vp, vp, _i32, vp, vp]),
     "egp_pd_torque_f64": (C.c_int, [vp, vp, vp, vp, vp, vp, _i32, vp, vp, vp]),
     "egp_pd_torque_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, _i32, vp, vp, vp]),
     "egp_reward_quat_v3_f64": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, _f64, _i32, vp, vp, vp]),
@@ -165,8 +165,8 @@ SIGNATURES = {
     "egp_zfilter_workspace_bytes": (_i64, [_i32, _i32]),
     "egp_zfilter_f64": (C.c_int, [vp, vp, _i32, _i32, vp, vp, _i32, _f64, vp, vp, vp]),
     "egp_zfilter_f32": (C.c_int, [vp, vp, _i32, _i32, vp, vp, _i32, _f64, vp, vp, vp]),
-    "egp_obs_zfilter_f64": (C.c_int, [vp, vp, vp, vp, _i32, vp, vp, _f64, vp, vp, _i32, vp, vp]),
-    "egp_obs_zfilter_f32": (C.c_int, [vp, vp, vp, vp, _i32, vp, vp, _f64, vp, vp, _i32, vp, vp]),
+    "egp_obs_zfilter_f64": (C.c_int, [vp, vp, vp, vp, vp, _i32, vp, vp, _f64, vp, vp, _i32, vp, vp]),
+    "egp_obs_zfilter_f32": (C.c_int, [vp, vp, vp, vp, vp, _i32, vp, vp, _f64, vp, vp, _i32, vp, vp]),
     "egp_gae_workspace_bytes": (_i64, [_i32]),
     "egp_gae_f64": (C.c_int, [vp, vp, vp, _i32, _f64, _f64, vp, vp, vp, vp, vp]),
     "egp_gae_f32": (C.c_int, [vp, vp, vp, _i32, _f64, _f64, vp, vp, vp, vp, vp]),
@@ -190,12 +190,12 @@ SIGNATURES = {
     "egp_rollout_tick_pre": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, _i32, vp, vp]),
     "egp_rollout_tick_apply": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, vp]),
     "egp_obs_zfilter_split_max_rows": (C.c_int32, []),
-    "egp_obs_zfilter_stats_f64": (C.c_int, [vp, vp, vp, vp, _i32, vp, vp]),
-    "egp_obs_zfilter_apply_f64": (C.c_int, [vp, vp, vp, _i32, vp, vp, C.c_double, vp, vp, vp, vp]),
-    "egp_policy_gaussian_filter_f32": (C.c_int, [vp, vp, C.c_int64, _i32, vp, vp, vp, _i32, vp, vp, C.c_double, vp, vp, vp,
+    "egp_obs_zfilter_stats_f64": (C.c_int, [vp, vp, vp, vp, vp, _i32, vp, vp]),
+    "egp_obs_zfilter_apply_f64": (C.c_int, [vp, vp, vp, vp, _i32, vp, vp, C.c_double, vp, vp, vp, vp]),
+    "egp_policy_gaussian_filter_f32": (C.c_int, [vp, vp, C.c_int64, _i32, vp, vp, vp, vp, _i32, vp, vp, C.c_double, vp, vp, vp,
                                                 vp, _i32, _i32, vp, vp, vp, vp, vp, vp, C.c_int64, vp]),
     "egp_rollout_tick_post": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp]),
-    "egp_rollout_reset": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, _i32, vp, vp, vp, vp, vp, vp, _i32, vp, vp]),
+    "egp_rollout_reset": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, _i32, vp, vp, vp, vp, vp, vp, vp, _i32, vp, vp]),
     "egp_engine_group_stream": (vp, [vp, _i32]),
     "egp_debug_burn": (C.c_int, [C.c_int64, _i32, vp, vp]),
     "egp_lstm_group_fwd_len_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_void_p), _i32, vp, vp, vp, vp, _i32, vp]),

@@ -1304,7 +1304,10 @@ int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, in
         const bool staged = d->flags_upload == 2;
         rc = egp_policy_gaussian_filter_f32(d->ctx, d->v_out + (size_t)a * d->v_stride, d->v_stride, d->ctx_dim,
                                             reinterpret_cast<const int64_t *>((staged ? d->slab_host : d->slab_dev) + soff + 16 * (size_t)nmax),
-                                            d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, n, zf_cur, zf_new, d->zf_clip,
+                                            d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv,
+                                            // (obs_phase: cur_t of the state = the step counter staged for the PREVIOUS env-step, slab slot (k - 1) & 1)
+                                            reinterpret_cast<const int32_t *>(d->slab_dev + (size_t)(group * 2 + ((k - 1) & 1)) * 24 * nmax),
+                                            n, zf_cur, zf_new, d->zf_clip,
                                             d->next_states + (row - N) * d->obs_dim, d->states + row * d->obs_dim, d->zf_workspace,
                                             d->layers, d->n_layers, d->activation, d->log_std,
                                             d->noise ? d->noise + row * d->nu : nullptr, d->actions + row * d->nu, nullptr,
@@ -1370,9 +1373,9 @@ int egp_rollout_tick_post(const egp_rollout_tick *d, int32_t group, int32_t a, i
         if (rc != EGP_OK) return rc;
     } else {
         if (d->defer_apply)     // statistics pass only: the apply pass is egp_rollout_tick_apply or the next tick's policy step
-            rc = egp_obs_zfilter_stats_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, f32 + 3 * nmax, n, d->zf_workspace, ts);
+            rc = egp_obs_zfilter_stats_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, f32, f32 + 3 * nmax, n, d->zf_workspace, ts);
         else
-            rc = egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, f32 + 3 * nmax, n, zf_cur, zf_new, d->zf_clip,
+            rc = egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, f32, f32 + 3 * nmax, n, zf_cur, zf_new, d->zf_clip,
                                      d->next_states + row * d->obs_dim, d->states + (row + N) * d->obs_dim, 0, d->zf_workspace, ts);
         if (rc != EGP_OK) return rc;
         if (!d->reward_job) {
@@ -1434,7 +1437,7 @@ __global__ __launch_bounds__(256) void k_ctx_rows_scatter(const int *__restrict_
 }  // namespace
 
 int egp_rollout_reset(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, const int32_t *ids, int32_t n,
-                      const int64_t *e_ind, const int64_t *s_ind, const int64_t *frame_rows, const double *qpos, const double *qvel,
+                      const int64_t *e_ind, const int64_t *s_ind, const int64_t *frame_rows, const int64_t *cur_t0, const double *qpos, const double *qvel,
                       const float *ctx_rows, int32_t ctx_rows_fresh, const double *zf_cur, double *zf_new) {
     EGP_REQUIRE(d && d->ctx && d->eng && d->reset_scratch && ids && e_ind && s_ind && frame_rows && qpos && qvel && ctx_rows, "NULL pointer");
     EGP_REQUIRE(0 <= a && a < b && b <= d->n_env && b - a <= d->nmax && k >= 0 && n > 0 && n <= b - a, "slot range / tick out of range");
@@ -1446,7 +1449,7 @@ int egp_rollout_reset(const egp_rollout_tick *d, int32_t group, int32_t a, int32
     if (rc != EGP_OK) return rc;
     const int nmax = d->nmax, ng = b - a;
     // slot k & 1: its previous readers (tick k - 2 of this group) finished before that tick's env-step started
-    int32_t *list = d->reset_scratch + (size_t)(group * 2 + (k & 1)) * 2 * nmax, *mask = list + nmax;
+    int32_t *list = d->reset_scratch + (size_t)(group * 2 + (k & 1)) * 3 * nmax, *mask = list + nmax, *tcur = mask + nmax;
     memset(mask, 0, sizeof(int32_t) * ng);
     for (int j = 0; j < n; ++j) {
         const int e = ids[j];
@@ -1455,8 +1458,9 @@ int egp_rollout_reset(const egp_rollout_tick *d, int32_t group, int32_t a, int32
         d->e_ind[e] = e_ind[j];
         d->s_ind[e] = s_ind[j];
         d->frame_base[e] = frame_rows[j];
-        d->cur_t[e] = 0;
+        d->cur_t[e] = cur_t0 ? cur_t0[j] : 0;          // cfg.random_cur_t (humanoid_v1.py:218-220): the episode starts at step cur_t0 of its window
     }
+    for (int i = 0; i < ng; ++i) tcur[i] = (int32_t)d->cur_t[a + i];      // obs_phase: cur_t of the group's rows (only the masked ones are read)
     const long row_elems = (long)d->ctx_T * d->ctx_dim;
     const int vec4 = (row_elems % 4 == 0 && d->v_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(ctx_rows) & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(d->v_out) & 15) == 0) ? 1 : 0;
@@ -1464,7 +1468,7 @@ int egp_rollout_reset(const egp_rollout_tick *d, int32_t group, int32_t a, int32
     k_ctx_rows_scatter<<<dim3(n, per_row), dim3(256), 0, s>>>(list, ctx_rows, row_elems, const_cast<float *>(d->v_out), d->v_stride, vec4);
     EGP_HIP_CHECK(hipGetLastError());
     // fresh episodes: their first observation goes through the filter and replaces the policy input of tick k + 1
-    rc = egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, mask, ng, zf_cur, zf_new, d->zf_clip,
+    rc = egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, tcur, mask, ng, zf_cur, zf_new, d->zf_clip,
                              d->states + ((size_t)(k + 1) * d->n_env + a) * d->obs_dim, nullptr, 1, d->zf_workspace, s);
     if (rc == EGP_OK && d->group_streams) EGP_HIP_CHECK(hipEventRecord(d->eng->groups[group].chain_done, s));
     return rc;
@@ -1484,7 +1488,9 @@ int egp_rollout_tick_apply(const egp_rollout_tick *d, int32_t group, int32_t a, 
     EGP_REQUIRE(group >= 0 && group < d->eng->n_groups, "group out of range");
     EGP_REQUIRE(0 <= a && a < b && b <= d->n_env && b - a <= d->nmax && k >= 0, "slot range / tick out of range");
     const size_t row = (size_t)k * d->n_env + a;
-    return egp_obs_zfilter_apply_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, b - a, zf_cur, zf_new, d->zf_clip,
+    return egp_obs_zfilter_apply_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv,
+                                     reinterpret_cast<const int32_t *>(d->slab_dev + (size_t)(group * 2 + (k & 1)) * 24 * d->nmax),      // tick k's step counter
+                                     b - a, zf_cur, zf_new, d->zf_clip,
                                      d->next_states + row * d->obs_dim, d->states + (row + d->n_env) * d->obs_dim, d->zf_workspace,
                                      tick_stream(d, group));
 }

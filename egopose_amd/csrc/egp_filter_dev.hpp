@@ -13,17 +13,24 @@ namespace egp {
 // get_full_obs (ego_pose/envs/humanoid_v1.py:73-96): obs = [qpos[2:] (root quat de-headed), qvel
 // (root linear velocity in the heading frame)]
 // Observation variants (cfg.obs_heading / root_deheading / obs_coord / obs_vel), all zero for every shipped config.
-struct ObsOpt { int heading, keep, root, vel, np, nv; };
-__host__ __device__ inline ObsOpt obs_opt_of(const DevModel &m) { return ObsOpt{m.obs_heading, m.obs_keep, m.obs_root, m.obs_vel, m.nq - 2, m.nv}; }
-__host__ __device__ inline int obs_width(int nq, int nv, int heading, int vel) {
-    return (heading ? 1 : 0) + (nq - 2) + (vel == 0 ? nv : (vel == 1 ? 6 : 0));
+struct ObsOpt { int heading, keep, root, vel, np, nv, phase, episode_len; };
+__host__ __device__ inline ObsOpt obs_opt_of(const DevModel &m) {
+    return ObsOpt{m.obs_heading, m.obs_keep, m.obs_root, m.obs_vel, m.nq - 2, m.nv, m.obs_phase, m.episode_len};
+}
+__host__ __device__ inline int obs_width(int nq, int nv, int heading, int vel, int phase = 0) {
+    return (heading ? 1 : 0) + (nq - 2) + (vel == 0 ? nv : (vel == 1 ? 6 : 0)) + (phase ? 1 : 0);
 }
 
 // one element of get_full_obs (humanoid_v1.py:73-96) for env row (q, v): column c of
 // [heading]? ++ qpos[2:] (root quat de-headed unless `keep`) ++ {qvel | qvel[:6] | -} (root linear velocity in the
-// heading frame, or in the root frame with `root`)
+// heading frame, or in the root frame with `root`) ++ [phase]?
+// cfg.obs_phase (:92-94; ego_forecast only): one more column at the end, min(cur_t / env_episode_len, 1) -- `t` = the env's cur_t
 template <typename T>
-__device__ __forceinline__ T obs_element(const T *q, const T *v, const ObsOpt &o, int c) {
+__device__ __forceinline__ T obs_element(const T *q, const T *v, const ObsOpt &o, int c, int t = 0) {
+    if (o.phase && c == (o.heading ? 1 : 0) + o.np + (o.vel == 0 ? o.nv : (o.vel == 1 ? 6 : 0))) {
+        const T ph = T(t) / T(o.episode_len);
+        return ph < T(1) ? ph : T(1);
+    }
     if (o.heading) {
         if (c == 0) {        // get_heading (utils/math.py:70-77): angle of the yaw-only quaternion, z made non-negative
             T w = q[3], z = q[6];
@@ -62,8 +69,9 @@ template <typename T>
 struct ZfSrc {
     const T *x; const T *qpos; const T *qvel; int nq, nv, dim;
     ObsOpt opt;
+    const int *t;               // opt.phase: the rows' cur_t (egp_* `phase_t`); unused otherwise
     __device__ __forceinline__ T at(long r, int c) const {
-        return x ? x[r * dim + c] : obs_element<T>(qpos + r * nq, qvel + r * nv, opt, c);
+        return x ? x[r * dim + c] : obs_element<T>(qpos + r * nq, qvel + r * nv, opt, c, opt.phase ? t[r] : 0);
     }
 };
 

@@ -50,6 +50,7 @@ struct DevModel {
     double sub_dt;                // model timestep
     double dt;                    // env step = frame_skip * sub_dt
     int obs_heading, obs_keep, obs_root, obs_vel;   // observation variants (egp_model_desc), all 0 = the shipped configs
+    int obs_phase, episode_len;   // cfg.obs_phase: a last column min(cur_t / episode_len, 1)
     int obs_dim;                  // width of an observation row
     int action_torque;            // cfg.action_type == 'torque': torque = clip(a_ref + action * a_scale), K1 solves nothing
 };

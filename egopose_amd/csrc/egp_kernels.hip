@@ -68,12 +68,12 @@ __global__ __launch_bounds__(256) void k_body_quat(DevModel m, const T *__restri
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_obs(DevModel m, const T *__restrict__ qpos, const T *__restrict__ qvel,
-                                             int n, T *__restrict__ obs) {
+                                             const int *__restrict__ phase_t, int n, T *__restrict__ obs) {
     const int od = m.obs_dim;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)n * od) return;
     const int env = gid / od, c = gid % od;
-    obs[gid] = obs_element<T>(qpos + (long)env * m.nq, qvel + (long)env * m.nv, obs_opt_of(m), c);
+    obs[gid] = obs_element<T>(qpos + (long)env * m.nq, qvel + (long)env * m.nv, obs_opt_of(m), c, m.obs_phase ? phase_t[env] : 0);
 }
 
 // ============================================================================================ K1
@@ -1439,7 +1439,10 @@ int egp_create(const egp_model_desc *d, int device, egp_ctx **out) {
     m.obs_vel = d->obs_vel;
     m.action_torque = d->action_torque != 0;
     if (m.obs_vel < 0 || m.obs_vel > 2) { delete ctx; set_error("obs_vel must be 0 (full), 1 (root) or 2 (none)"); return EGP_E_INVALID; }
-    m.obs_dim = obs_width(d->nq, d->nv, m.obs_heading, m.obs_vel);
+    m.obs_phase = d->obs_phase != 0;
+    m.episode_len = d->episode_len;
+    if (m.obs_phase && d->episode_len <= 0) { delete ctx; set_error("obs_phase needs episode_len > 0"); return EGP_E_INVALID; }
+    m.obs_dim = obs_width(d->nq, d->nv, m.obs_heading, m.obs_vel, m.obs_phase);
     // sparse-inertia index tables from the dof tree (what mj_fullM walks)
     std::vector<int> rows(d->nM), cols(d->nM);
     std::vector<short> mmap((size_t)d->nv * d->nv, (short)-1);
@@ -1644,13 +1647,14 @@ __global__ __launch_bounds__(256) void k_reward_simple(int kind, int nq, const d
 }
 
 template <typename T>
-static int launch_obs(egp_ctx *ctx, const T *qpos, const T *qvel, int n, T *obs, void *stream) {
+static int launch_obs(egp_ctx *ctx, const T *qpos, const T *qvel, const int *phase_t, int n, T *obs, void *stream) {
     EGP_REQUIRE(ctx, "ctx is NULL");
     EGP_REQUIRE(n >= 0, "n < 0");
     if (n == 0) return EGP_OK;
     EGP_REQUIRE(qpos && qvel && obs, "NULL pointer");
+    EGP_REQUIRE(!ctx->dm.obs_phase || phase_t, "the model has obs_phase: phase_t (the rows' cur_t) is required");
     const long total = (long)n * ctx->dm.obs_dim;
-    k_obs<T><<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(ctx->dm, qpos, qvel, n, obs);
+    k_obs<T><<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(ctx->dm, qpos, qvel, phase_t, n, obs);
     return after_launch("k_obs");
 }
 
@@ -1815,13 +1819,14 @@ static int launch_zfilter(const T *x, const int *active, int n, int dim, const d
 }
 
 template <typename T>
-static int launch_obs_zfilter(egp_ctx *ctx, const T *qpos, const T *qvel, const int *active, int n, const double *st_in, double *st_out,
+static int launch_obs_zfilter(egp_ctx *ctx, const T *qpos, const T *qvel, const int *phase_t, const int *active, int n, const double *st_in, double *st_out,
                               double clip, T *y, T *y2, int write_only_active, void *ws, void *stream) {
     EGP_REQUIRE(ctx, "ctx is NULL");
     EGP_REQUIRE(n == 0 || (qpos && qvel), "NULL pointer");
     EGP_REQUIRE(!write_only_active || active, "write_only_active needs the active mask");
+    EGP_REQUIRE(n == 0 || !ctx->dm.obs_phase || phase_t, "the model has obs_phase: phase_t (the rows' cur_t) is required");
     const int dim = ctx->dm.obs_dim;
-    ZfSrc<T> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm)};
+    ZfSrc<T> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm), phase_t};
     return launch_zfilter_src<T>(src, active, n, dim, st_in, st_out, 1, clip, y, y2, write_only_active ? active : nullptr, ws, stream);
 }
 
@@ -1836,7 +1841,7 @@ static int launch_post_step(egp_ctx *ctx, const double *qpos, const double *qvel
     EGP_REQUIRE(qpos && qvel && prev_qpos && ee_wpos && tcur && frame && endf && y && reward && cinfo, "NULL pointer");
     if (!ctx->expert_rows_f64) { set_error("egp_upload_experts must be called before the reward kernel"); return EGP_E_STATE; }
     const int dim = ctx->dm.obs_dim;
-    ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm)};
+    ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm), tcur};      // (obs_phase: the step counter the reward reads too)
     const int identity = st_in == nullptr;
     EGP_REQUIRE(identity || (st_out && ws && st_out != st_in), "the filter update needs workspace and a distinct state_out");
     hipStream_t s = (hipStream_t)stream;
@@ -1907,8 +1912,8 @@ int egp_reward_simple_f64(egp_ctx *c, int32_t kind, const double *qpos, const in
 }
 int egp_quat_op_f64(int32_t op, const double *a, const double *b, int32_t n, double *o, void *s) { return launch_quat_op<double>(op, a, b, n, o, s); }
 int egp_quat_op_f32(int32_t op, const float *a, const float *b, int32_t n, float *o, void *s) { return launch_quat_op<float>(op, a, b, n, o, s); }
-int egp_obs_f64(egp_ctx *c, const double *q, const double *v, int32_t n, double *o, void *s) { return launch_obs<double>(c, q, v, n, o, s); }
-int egp_obs_f32(egp_ctx *c, const float *q, const float *v, int32_t n, float *o, void *s) { return launch_obs<float>(c, q, v, n, o, s); }
+int egp_obs_f64(egp_ctx *c, const double *q, const double *v, const int32_t *phase_t, int32_t n, double *o, void *s) { return launch_obs<double>(c, q, v, phase_t, n, o, s); }
+int egp_obs_f32(egp_ctx *c, const float *q, const float *v, const int32_t *phase_t, int32_t n, float *o, void *s) { return launch_obs<float>(c, q, v, phase_t, n, o, s); }
 
 int egp_pd_torque_f64(egp_ctx *c, const double *qpos, const double *qvel, const double *action, const double *qM,
                       const double *bias, int32_t n, double *torque, double *torque_raw, void *s) {
@@ -1960,34 +1965,36 @@ int egp_zfilter_f32(const float *x, const int32_t *active, int32_t n, int32_t di
 /* K3+K6 fused: observations of the drained state (get_full_obs) pushed through the running filter in one call.
  *   active [n] (optional): rows that update the statistics; write_only_active: only those rows are written.
  *   state_in == NULL: no filter (raw observations). y2 (optional) receives a second copy of the output. */
-int egp_obs_zfilter_f64(egp_ctx *c, const double *qpos, const double *qvel, const int32_t *active, int32_t n, const double *si,
+int egp_obs_zfilter_f64(egp_ctx *c, const double *qpos, const double *qvel, const int32_t *phase_t, const int32_t *active, int32_t n, const double *si,
                         double *so, double clip, double *y, double *y2, int32_t write_only_active, void *ws, void *s) {
-    return launch_obs_zfilter<double>(c, qpos, qvel, active, n, si, so, clip, y, y2, write_only_active, ws, s);
+    return launch_obs_zfilter<double>(c, qpos, qvel, phase_t, active, n, si, so, clip, y, y2, write_only_active, ws, s);
 }
-int egp_obs_zfilter_f32(egp_ctx *c, const float *qpos, const float *qvel, const int32_t *active, int32_t n, const double *si,
+int egp_obs_zfilter_f32(egp_ctx *c, const float *qpos, const float *qvel, const int32_t *phase_t, const int32_t *active, int32_t n, const double *si,
                         double *so, double clip, float *y, float *y2, int32_t write_only_active, void *ws, void *s) {
-    return launch_obs_zfilter<float>(c, qpos, qvel, active, n, si, so, clip, y, y2, write_only_active, ws, s);
+    return launch_obs_zfilter<float>(c, qpos, qvel, phase_t, active, n, si, so, clip, y, y2, write_only_active, ws, s);
 }
 // egp_obs_zfilter_f64 in two calls, for batches of at most egp_obs_zfilter_split_max_rows() rows (the apply pass merges the tile
 // statistics itself there): _stats = the first launch, _apply = the second, same kernels with the same arguments. Whoever runs
 // the apply pass may instead be the policy step of the next tick (egp_policy_gaussian_filter_f32).
 int32_t egp_obs_zfilter_split_max_rows(void) { return 64 * ZF_FUSED_TILES; }
-int egp_obs_zfilter_stats_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const int32_t *active, int32_t n, void *ws, void *stream) {
+int egp_obs_zfilter_stats_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const int32_t *phase_t, const int32_t *active, int32_t n, void *ws, void *stream) {
     EGP_REQUIRE(ctx && ws, "NULL pointer");
     EGP_REQUIRE(n > 0 && n <= 64 * ZF_FUSED_TILES && qpos && qvel, "1 .. egp_obs_zfilter_split_max_rows() rows");
+    EGP_REQUIRE(!ctx->dm.obs_phase || phase_t, "the model has obs_phase: phase_t (the rows' cur_t) is required");
     const int dim = ctx->dm.obs_dim;
-    ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm)};
+    ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm), phase_t};
     int rpt, nt;
     zf_tiling(n, &rpt, &nt);
     k_zf_partial<double><<<dim3(nt), dim3(1024), 0, (hipStream_t)stream>>>(src, active, n, dim, rpt, (double *)ws);
     return after_launch("k_zf_partial");
 }
-int egp_obs_zfilter_apply_f64(egp_ctx *ctx, const double *qpos, const double *qvel, int32_t n, const double *st_in, double *st_out,
+int egp_obs_zfilter_apply_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const int32_t *phase_t, int32_t n, const double *st_in, double *st_out,
                               double clip, double *y, double *y2, void *ws, void *stream) {
     EGP_REQUIRE(ctx && ws && st_in && st_out && st_in != st_out && y, "NULL pointer / state_out must differ from state_in");
     EGP_REQUIRE(n > 0 && n <= 64 * ZF_FUSED_TILES && qpos && qvel, "1 .. egp_obs_zfilter_split_max_rows() rows");
+    EGP_REQUIRE(!ctx->dm.obs_phase || phase_t, "the model has obs_phase: phase_t (the rows' cur_t) is required");
     const int dim = ctx->dm.obs_dim;
-    ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm)};
+    ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm), phase_t};
     int rpt, nt;
     zf_tiling(n, &rpt, &nt);
     k_zf_apply<double><<<dim3((n + 7) / 8), dim3(128), 2 * dim * sizeof(double), (hipStream_t)stream>>>(

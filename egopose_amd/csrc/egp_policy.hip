@@ -496,7 +496,7 @@ extern "C" int egp_policy_gaussian_staged_f32(const float *ctx_rows, int64_t ctx
 // egp_obs_zfilter_stats_f64 left in `zf_workspace`; they are also written to y (and y2), and the merged statistics to zf_out:
 // together exactly what egp_obs_zfilter_apply_f64 followed by egp_policy_gaussian_staged_f32 on y2 computes, in one launch.
 extern "C" int egp_policy_gaussian_filter_f32(egp_ctx *ctx, const float *ctx_rows, int64_t ctx_row_stride, int32_t ctx_dim, const int64_t *t_idx,
-                                              const double *qpos, const double *qvel, int32_t n, const double *zf_in, double *zf_out,
+                                              const double *qpos, const double *qvel, const int32_t *phase_t, int32_t n, const double *zf_in, double *zf_out,
                                               double clip, double *y, double *y2, const void *zf_workspace,
                                               const egp_mlp_layer *layers, int32_t n_layers, int32_t activation, const float *log_std,
                                               const float *noise, double *action, float *mean_out, const void *stage_src, void *stage_dst,
@@ -507,7 +507,8 @@ extern "C" int egp_policy_gaussian_filter_f32(egp_ctx *ctx, const float *ctx_row
     int rpt, nt;
     egp::zf_tiling(n, &rpt, &nt);
     PolFilter f;
-    f.src = egp::ZfSrc<double>{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, egp::obs_opt_of(ctx->dm)};
+    EGP_REQUIRE(!ctx->dm.obs_phase || phase_t, "the model has obs_phase: phase_t (the rows' cur_t) is required");
+    f.src = egp::ZfSrc<double>{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, egp::obs_opt_of(ctx->dm), phase_t};
     f.st_in = zf_in; f.st_out = zf_out; f.ws = (const double *)zf_workspace; f.n_tiles = nt; f.clip = clip; f.y = y; f.y2 = y2;
     return policy_launch(ctx_rows, ctx_row_stride, ctx_dim, t_idx, nullptr, dim, n, layers, n_layers, activation, log_std, noise, action, mean_out,
                          stage_src, stage_dst, stage_bytes, stream, &f);

@@ -258,7 +258,7 @@ def merge_running_state(running_state, base, device):
     if not is_on():
         return
     from .rl_core import LoggerRL
-    merge_sampling_pass(LoggerRL.from_totals(0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, np.zeros(1)), running_state, base, device)
+    merge_sampling_pass(LoggerRL.from_totals(1, 1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, np.zeros(1)), running_state, base, device)
 
 
 def init_from_env(device_index=None):

@@ -77,8 +77,8 @@ class HumanoidEnv:
             nq=sk.nq, nv=sk.nv, nu=sk.nu, opt=types.SimpleNamespace(timestep=sk.timestep),
             _body_name2id={n: i + 1 for i, n in enumerate(sk.body_names)})
         self.body_qposaddr = sk.body_qposaddr()
-        oo = obs_options_of(cfg)            # humanoid_v1.py:73-96: [heading]? ++ qpos[2:] ++ {qvel | qvel[:6] | -}
-        self.obs_dim = (1 if oo["obs_heading"] else 0) + sk.nq - 2 + {"full": sk.nv, "root": 6}.get(oo["obs_vel"], 0)
+        oo = obs_options_of(cfg)            # humanoid_v1.py:73-96: [heading]? ++ qpos[2:] ++ {qvel | qvel[:6] | -} ++ [phase]?
+        self.obs_dim = (1 if oo["obs_heading"] else 0) + sk.nq - 2 + {"full": sk.nv, "root": 6}.get(oo["obs_vel"], 0) + (1 if oo["obs_phase"] else 0)
         self.observation_space = _Space(self.obs_dim)
         self.action_space = _Space(sk.nu)
         self.end_reward = 0.0
@@ -186,11 +186,17 @@ class HumanoidEnv:
             e_ind, s_ind = self.sample_reset(1)
             self.set_expert(int(e_ind[0]))
             self.start_ind = int(s_ind[0])
-            qpos = self.expert["qpos"][self.start_ind].copy()
-            qvel = self.expert["qvel"][self.start_ind].copy()
+            ind = self.start_ind
+            self.cur_t = 0
+            if getattr(self.cfg, "random_cur_t", False):       # humanoid_v1.py:218-220 (the reference draws from the global numpy generator)
+                self.cur_t = int(self.np_random.randint(self.cfg.env_episode_len))
+                ind += self.cur_t
+            qpos = self.expert["qpos"][ind].copy()
+            qvel = self.expert["qvel"][ind].copy()
             if self.cfg.env_init_noise > 0:
                 qpos[7:] += self.np_random.normal(0.0, self.cfg.env_init_noise, size=self.skel.nq - 7)
-        self.cur_t = 0
+        if self.fix_start_state is not None:
+            self.cur_t = 0
         sim.engine.reset(np.array([0]), qpos[None], qvel[None])
         torch.cuda.synchronize()
         self.prev_qpos = None
@@ -232,8 +238,10 @@ class HumanoidEnv:
         return self.get_obs(), 1.0, bool(fail or end), {"fail": bool(fail), "end": bool(end)}
 
     def get_obs(self):
+        import torch
         sim = self._one()
-        return sim.ctx.obs(sim.engine.qpos, sim.engine.qvel).cpu().numpy()[0]
+        pt = torch.tensor([self.cur_t], dtype=torch.int32, device=sim.engine.qpos.device) if sim.ctx.obs_phase else None
+        return sim.ctx.obs(sim.engine.qpos, sim.engine.qvel, phase_t=pt).cpu().numpy()[0]
 
     get_full_obs = get_obs
 

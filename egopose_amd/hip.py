@@ -81,7 +81,7 @@ def obs_options_of(cfg):
         raise NotImplementedError("obs_type %r: the reference's get_obs only knows 'full' (humanoid_v1.py:68-71)" % cfg.obs_type)
     return dict(obs_heading=bool(getattr(cfg, "obs_heading", False)), root_deheading=bool(getattr(cfg, "root_deheading", True)),
                 obs_coord=getattr(cfg, "obs_coord", "heading"), obs_vel=getattr(cfg, "obs_vel", "full"),
-                action_type=getattr(cfg, "action_type", "position"))
+                action_type=getattr(cfg, "action_type", "position"), obs_phase=bool(getattr(cfg, "obs_phase", False)))
 
 
 class EgpContext:
@@ -97,7 +97,7 @@ class EgpContext:
         self.frame_skip = int(frame_skip)
         self.episode_len = int(episode_len)
         self.nq, self.nv, self.nu, self.nbody, self.nM = skel.nq, skel.nv, skel.nu, len(skel.body_names), skel.nM
-        oo = dict(obs_heading=False, root_deheading=True, obs_coord="heading", obs_vel="full", action_type="position")
+        oo = dict(obs_heading=False, root_deheading=True, obs_coord="heading", obs_vel="full", action_type="position", obs_phase=False)
         oo.update(obs_options or {})
         if oo["obs_coord"] not in ("heading", "root"):
             raise ValueError("obs_coord must be 'heading' or 'root', got %r" % (oo["obs_coord"],))      # transform_vec asserts
@@ -106,7 +106,8 @@ class EgpContext:
             raise ValueError("action_type must be 'position' or 'torque', got %r" % (oo["action_type"],))
         self.obs_options = oo
         self._obs_vel = {"full": 0, "root": 1}.get(oo["obs_vel"], 2)        # anything else: no velocity block (humanoid_v1.py:86-89)
-        self.obs_dim = (1 if oo["obs_heading"] else 0) + self.nq - 2 + (self.nv, 6, 0)[self._obs_vel]
+        self.obs_phase = bool(oo["obs_phase"])       # humanoid_v1.py:92-94: a last column min(cur_t / env_episode_len, 1); kernels then need the rows' cur_t
+        self.obs_dim = (1 if oo["obs_heading"] else 0) + self.nq - 2 + (self.nv, 6, 0)[self._obs_vel] + (1 if self.obs_phase else 0)
         self._keep = dict(
             bqs=_np_i32(skel.body_qpos_start), bnd=_np_i32(skel.body_ndof), dpar=_np_i32(skel.dof_parentid),
             madr=_np_i32(skel.dof_Madr), ee=_np_i32(skel.ee_body), jkp=_np_f64(jkp), jkd=_np_f64(jkd),
@@ -150,6 +151,7 @@ class EgpContext:
         d.obs_coord_root = 1 if oo["obs_coord"] == "root" else 0
         d.obs_vel = self._obs_vel
         d.action_torque = 1 if oo["action_type"] == "torque" else 0
+        d.obs_phase = 1 if oo["obs_phase"] else 0
         return d
 
     def close(self):
@@ -204,14 +206,15 @@ class EgpContext:
         L.check(fn(self.handle, _ptr(qpos), n, _ptr(out), _stream()), "egp_body_quat")
         return out
 
-    def obs(self, qpos, qvel, out=None):
+    def obs(self, qpos, qvel, out=None, phase_t=None):
         n = qpos.shape[0]
+        phase_t = self._phase_t(phase_t, n)
         _need(qpos, (n, self.nq), qpos.dtype, "qpos")
         _need(qvel, (n, self.nv), qpos.dtype, "qvel")
         out = torch.empty(n, self.obs_dim, dtype=qpos.dtype, device=qpos.device) if out is None else out
         _need(out, (n, self.obs_dim), qpos.dtype, "out")
         fn = getattr(self.lib, "egp_obs_" + self._sfx(qpos))
-        L.check(fn(self.handle, _ptr(qpos), _ptr(qvel), n, _ptr(out), _stream()), "egp_obs")
+        L.check(fn(self.handle, _ptr(qpos), _ptr(qvel), _ptr(phase_t), n, _ptr(out), _stream()), "egp_obs")
         return out
 
     def pd_torque(self, qpos, qvel, action, qM, bias, want_raw=False):
@@ -356,9 +359,19 @@ class EgpContext:
                    float(clip or 0.0), _ptr(y), _ptr(ws), _stream()), "egp_zfilter")
         return y
 
-    def obs_zfilter(self, qpos, qvel, state_in, state_out, clip, out, out2=None, active=None, write_only_active=False):
+    def _phase_t(self, phase_t, n):
+        """`phase_t`: int32 [n] cur_t of the rows, required when the model has obs_phase (ignored otherwise)."""
+        if not self.obs_phase:
+            return None
+        if phase_t is None:
+            raise ValueError("the model has obs_phase: pass phase_t (int32 cur_t of every row)")
+        _need(phase_t, (n,), torch.int32, "phase_t")
+        return phase_t
+
+    def obs_zfilter(self, qpos, qvel, state_in, state_out, clip, out, out2=None, active=None, write_only_active=False, phase_t=None):
         """K3+K6 fused: filtered observations of (qpos, qvel) written to ``out`` (and ``out2``); state_in None = raw."""
         n, dt = qpos.shape[0], qpos.dtype
+        phase_t = self._phase_t(phase_t, n)
         _need(qpos, (n, self.nq), dt, "qpos")
         _need(qvel, (n, self.nv), dt, "qvel")
         _need(out, (n, self.obs_dim), dt, "out")
@@ -372,20 +385,20 @@ class EgpContext:
             _need(state_out, (1 + 2 * self.obs_dim,), torch.float64, "state_out")
             ws = self._workspace("zf", self.lib.egp_zfilter_workspace_bytes(n, self.obs_dim), qpos.device)
         fn = getattr(self.lib, "egp_obs_zfilter_" + self._sfx(qpos))
-        L.check(fn(self.handle, _ptr(qpos), _ptr(qvel), _ptr(active), n, _ptr(state_in), _ptr(state_out), float(clip or 0.0),
+        L.check(fn(self.handle, _ptr(qpos), _ptr(qvel), _ptr(phase_t), _ptr(active), n, _ptr(state_in), _ptr(state_out), float(clip or 0.0),
                    _ptr(out), _ptr(out2), 1 if write_only_active else 0, _ptr(ws), _stream()), "egp_obs_zfilter")
         return out
 
-    def obs_zfilter_stats(self, qpos, qvel, workspace, active=None):
+    def obs_zfilter_stats(self, qpos, qvel, workspace, active=None, phase_t=None):
         """First launch of obs_zfilter on its own (`egp_obs_zfilter_stats_f64`): tile statistics into `workspace`."""
         n = qpos.shape[0]
-        L.check(self.lib.egp_obs_zfilter_stats_f64(self.handle, _ptr(qpos), _ptr(qvel), _ptr(active), n, _ptr(workspace), _stream()),
+        L.check(self.lib.egp_obs_zfilter_stats_f64(self.handle, _ptr(qpos), _ptr(qvel), _ptr(self._phase_t(phase_t, n)), _ptr(active), n, _ptr(workspace), _stream()),
                 "egp_obs_zfilter_stats_f64")
 
-    def obs_zfilter_apply(self, qpos, qvel, state_in, state_out, clip, out, out2, workspace):
+    def obs_zfilter_apply(self, qpos, qvel, state_in, state_out, clip, out, out2, workspace, phase_t=None):
         """Second launch of obs_zfilter on its own (`egp_obs_zfilter_apply_f64`)."""
         n = qpos.shape[0]
-        L.check(self.lib.egp_obs_zfilter_apply_f64(self.handle, _ptr(qpos), _ptr(qvel), n, _ptr(state_in), _ptr(state_out), float(clip or 0.0),
+        L.check(self.lib.egp_obs_zfilter_apply_f64(self.handle, _ptr(qpos), _ptr(qvel), _ptr(self._phase_t(phase_t, n)), n, _ptr(state_in), _ptr(state_out), float(clip or 0.0),
                                                    _ptr(out), _ptr(out2), _ptr(workspace), _stream()), "egp_obs_zfilter_apply_f64")
         return out
 

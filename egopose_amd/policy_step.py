@@ -79,13 +79,15 @@ class FusedGaussianPolicy:
                                                  L.current_stream()), "egp_policy_gaussian_f32")
         return action_out
 
-    def with_filter(self, ctx, ctx_rows, t_idx, qpos, qvel, zf_in, zf_out, clip, y, y2, workspace, action_out, noise=None, mean_out=None):
+    def with_filter(self, ctx, ctx_rows, t_idx, qpos, qvel, zf_in, zf_out, clip, y, y2, workspace, action_out, noise=None, mean_out=None,
+                    phase_t=None):
         """The filter's apply pass + the policy step in one launch (`egp_policy_gaussian_filter_f32`): the state columns are the
         observations of (qpos, qvel) normalised with `zf_in` merged with the tile statistics `ctx.obs_zfilter_stats` left in
         `workspace`; y / y2 receive them, `zf_out` the merged statistics. `ctx`: the EgpContext of the model."""
         n, T, H = ctx_rows.shape
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-        L.check(self.lib.egp_policy_gaussian_filter_f32(ctx.handle, p(ctx_rows), int(ctx_rows.stride(0)), H, p(t_idx), p(qpos), p(qvel), n,
+        L.check(self.lib.egp_policy_gaussian_filter_f32(ctx.handle, p(ctx_rows), int(ctx_rows.stride(0)), H, p(t_idx), p(qpos), p(qvel),
+                                                        p(ctx._phase_t(phase_t, n)), n,
                                                         p(zf_in), p(zf_out), float(clip or 0.0), p(y), p(y2), p(workspace),
                                                         C.cast(self.desc, C.c_void_p), len(self.layers), self.act, p(self.log_std), p(noise),
                                                         p(action_out), p(mean_out), None, None, 0, L.current_stream()),

@@ -120,8 +120,11 @@ class LockstepRollout:
         # ego_forecast front end (VideoForecastNet): one video context per episode + a state LSTM stepped per tick
         self.forecast = hasattr(policy_vs_net, "s_step")
         self.ctx_T = 1 if self.forecast else self.T_ep          # context rows per episode kept in v_out
-        if getattr(self.cfg, "obs_phase", False) or getattr(self.cfg, "random_cur_t", False):
-            raise NotImplementedError("obs_phase / random_cur_t are not implemented in the lockstep rollout")
+        # cfg.obs_phase (humanoid_v1.py:92-94): part of the kernel context (sim.ctx.obs_phase -- every K3 call gets the rows' cur_t);
+        # cfg.random_cur_t (:218-220): an episode starts at a random step cur_t0 of its window -- state = expert frame start + cur_t0,
+        # it ends when cur_t reaches the episode length. The video nets keep counting from the episode's first step, as the
+        # reference's do (VideoStateNet.t / the forecast net's state LSTM restart at `initialize`), which only the torch tick knows.
+        self.random_cur_t = bool(getattr(self.cfg, "random_cur_t", False))
         if getattr(self.cfg, "action_type", "position") == "torque" and hasattr(self.cfg, "j_stiff"):
             # humanoid_v1.py:56-58 writes cfg.j_stiff into the MuJoCo model's joint stiffness: a property of the physics
             # backend, which the built-in surrogate does not have
@@ -190,14 +193,16 @@ class LockstepRollout:
         cfg, ex = self.cfg, self.experts
         e_ind, s_ind, ctx_rows = self._draw_episodes(len(ids))
         rows = ex.take_offset[e_ind] + s_ind
-        qpos = ex.qpos[rows].copy()
-        qvel = ex.qvel[rows].copy()
+        t0 = self.env.np_random.randint(0, self.T_ep, size=len(ids)) if self.random_cur_t else np.zeros(len(ids), np.int64)
+        qpos = ex.qpos[rows + t0].copy()             # (humanoid_v1.py:219-222: ind += cur_t)
+        qvel = ex.qvel[rows + t0].copy()
         if cfg.env_init_noise > 0:
             qpos[:, 7:] += self.env.np_random.normal(0.0, cfg.env_init_noise, size=(len(ids), qpos.shape[1] - 7))
         self.engine.reset(ids, qpos, qvel)
         self.e_ind[ids], self.s_ind[ids] = e_ind, s_ind
         self.frame_base[ids] = rows
-        self.cur_t[ids] = 0
+        self.cur_t[ids] = t0
+        self.t0[ids] = t0
         ids_d = self.up(ids)
         self.v_out[ids_d] = ctx_rows
         if self._s_hc is not None:               # fresh episodes start the state LSTM from zero
@@ -226,21 +231,24 @@ class LockstepRollout:
         # a fresh pool, and the rows stay referenced until the next two resets have been issued)
         self._ctx_keep = (ctx_rows, self._ctx_keep[0] if self._ctx_keep else None)
         rc = self.engine.lib.egp_rollout_reset(tickd_ref, g, a, b, k, ids32.ctypes.data, len(ids32), e64.ctypes.data, s64.ctypes.data,
-                                               r64.ctypes.data, qpos.ctypes.data, qvel.ctypes.data, ctx_rows.data_ptr(),
+                                               r64.ctypes.data, None, qpos.ctypes.data, qvel.ctypes.data, ctx_rows.data_ptr(),
                                                1 if self._pool_fresh else 0, cur, new)
         if rc != 0:
             _lib.check(rc, "egp_rollout_reset")
         if new_t is not None:
             self.zf_state = new_t
 
-    def _obs_filter(self, a, b, out, out2=None, active=None, write_only_active=False):
-        """K3+K6 fused for slots [a,b): filtered observation of the engine state -> out (and out2)."""
+    def _obs_filter(self, a, b, out, out2=None, active=None, write_only_active=False, phase_t=None):
+        """K3+K6 fused for slots [a,b): filtered observation of the engine state -> out (and out2). obs_phase: `phase_t` = the
+        slots' cur_t on the device (int32), default: uploaded from the host counters."""
         eng = self.engine
+        if self.ctx.obs_phase and phase_t is None:
+            phase_t = self.up(self.cur_t[a:b]).to(torch.int32)
         if self.zf_state is None:
-            return self.ctx.obs_zfilter(eng.qpos[a:b], eng.qvel[a:b], None, None, 0.0, out, out2, active, write_only_active)
+            return self.ctx.obs_zfilter(eng.qpos[a:b], eng.qvel[a:b], None, None, 0.0, out, out2, active, write_only_active, phase_t=phase_t)
         new = self._zf_bufs[self._zf_flip]
         self._zf_flip ^= 1
-        self.ctx.obs_zfilter(eng.qpos[a:b], eng.qvel[a:b], self.zf_state, new, self.zf_clip, out, out2, active, write_only_active)
+        self.ctx.obs_zfilter(eng.qpos[a:b], eng.qvel[a:b], self.zf_state, new, self.zf_clip, out, out2, active, write_only_active, phase_t=phase_t)
         self.zf_state = new
         return out
 
@@ -362,8 +370,11 @@ class LockstepRollout:
             exps=torch.ones(T_max, N, dtype=torch.int64, device=dev))
         host = dict(valid=np.zeros((T_max, N), bool), done=np.zeros((T_max, N), bool),
                     e_ind=np.zeros((T_max, N), np.int64), s_ind=np.zeros((T_max, N), np.int64))
+        if self.random_cur_t:
+            host["t0"] = np.zeros((T_max, N), np.int64)
         self._ensure_static(ndt)
         self.cur_t = np.zeros(N, np.int64)
+        self.t0 = np.zeros(N, np.int64)               # cur_t at the episode's first step (random_cur_t; else 0)
         self.e_ind = np.zeros(N, np.int64)
         self.s_ind = np.zeros(N, np.int64)
         self.frame_base = np.zeros(N, np.int64)
@@ -432,7 +443,7 @@ class LockstepRollout:
             a, b = self.groups[g]
             t0 = time.time()
             k = tick[g]
-            t_idx = self.up(np.minimum(self.cur_t[a:b], self.ctx_T - 1))
+            t_idx = self.up(np.minimum(self.cur_t[a:b] - self.t0[a:b], self.ctx_T - 1))
             if plain_noise:
                 # static-buffer form (one hipGraph launch when captured)
                 self._g_tidx[g].copy_(t_idx)
@@ -479,8 +490,10 @@ class LockstepRollout:
             fl = self.rings[g].upload(flags)
             host["valid"][k, a:b], host["done"][k, a:b] = act_g, done
             host["e_ind"][k, a:b], host["s_ind"][k, a:b] = self.e_ind[a:b], self.s_ind[a:b]
+            if self.random_cur_t:
+                host["t0"][k, a:b] = self.t0[a:b]
             # K3+K6: filtered next observation -> next_states[k] and the policy input of tick k+1;  K2: reward
-            self._obs_filter(a, b, rec["next_states"][k, a:b], rec["states"][k + 1, a:b], active=fl[3])
+            self._obs_filter(a, b, rec["next_states"][k, a:b], rec["states"][k + 1, a:b], active=fl[3], phase_t=fl[0])
             ctx.reward(eng.qpos[a:b], eng.prev_qpos[a:b], eng.ee_wpos[a:b], fl[0], fl[1], fl[2], end_reward, active=fl[3],
                        reward_out=rec["rewards"][k, a:b], cinfo_out=rec["cinfo"][k, a:b], kind=self.reward_kind)
             steps_done[a:b] += act_g
@@ -508,7 +521,7 @@ class LockstepRollout:
         # rec.actions[k] directly.
         # (mean_action: the same kernel without a noise operand writes the mean; exps = 0 as agents/agent.py:45-46)
         # (the registry's two small rewards, constant / pose_dist, take the torch tick: their kernel is called from there)
-        fast = (self._fused is not None and (plain_noise or self.mean_action) and not self.forecast
+        fast = (self._fused is not None and (plain_noise or self.mean_action) and not self.forecast and not self.random_cur_t
                 and self.reward_kind == "quat_v3" and os.environ.get("EGP_FAST_TICK", "1") != "0")
         if fast:
             if self.mean_action:
@@ -593,8 +606,8 @@ class LockstepRollout:
             td.slab_host, td.slab_dev = slab_hp, slab_dp
             td.qpos, td.qvel, td.prev_qpos, td.ee = qpos_p, qvel_p, prev_p, ee_p
             td.zf_workspace = ws_p
-            if self._reset_scratch is None or self._reset_scratch.numel() != len(self.groups) * 4 * nmax:
-                self._reset_scratch = torch.zeros(len(self.groups) * 4 * nmax, dtype=torch.int32).pin_memory()
+            if self._reset_scratch is None or self._reset_scratch.numel() != len(self.groups) * 6 * nmax:
+                self._reset_scratch = torch.zeros(len(self.groups) * 6 * nmax, dtype=torch.int32).pin_memory()
             td.reset_scratch = self._reset_scratch.data_ptr()
             ok = (all(x.dtype == np.int64 and x.flags.c_contiguous for x in (self.cur_t, self.frame_base, self.e_ind, self.s_ind, steps_done))
                   and active.dtype == np.bool_ and eng.head_z.dtype == np.float64 and host["valid"].dtype == np.bool_ and host["done"].dtype == np.bool_
@@ -737,7 +750,7 @@ class LockstepRollout:
                 new_t, new, cur = None, None, None
             # K3+K6 (-> next_states[k] and states[k+1]) and K2 (-> rewards[k], cinfo[k]): three launches, one call
             if not post_fused:
-                rc = lib.egp_obs_zfilter_f64(hnd, qpos_p + a * ctx.nq * 8, qvel_p + a * ctx.nv * 8, fbase + 12 * nmax, n, cur, new, zclip,
+                rc = lib.egp_obs_zfilter_f64(hnd, qpos_p + a * ctx.nq * 8, qvel_p + a * ctx.nv * 8, fbase, fbase + 12 * nmax, n, cur, new, zclip,
                                              P["next_states"] + (k * N + a) * od * 8, P["states"] + ((k + 1) * N + a) * od * 8, 0, ws_p,
                                              cur_stream)
                 if rc == 0 and not reward_job:
@@ -827,6 +840,8 @@ class LockstepRollout:
             states=pick(rec["states"]), actions=pick(rec["actions"]), masks=hpick(~host["done"], np.int64),
             next_states=pick(rec["next_states"]), rewards=pick(rec["rewards"]), exps=pick(rec["exps"]),
             v_metas=torch.stack((hpick(host["e_ind"], np.int64), hpick(host["s_ind"], np.int64)), dim=1))
+        # cur_t of every batch row's episode start (random_cur_t; inspection / replay: v_meta carries only take and start frame)
+        self.batch_t0 = host["t0"][:T_used].reshape(T_used * N)[tk * N + slot] if self.random_cur_t else np.zeros(len(tk), np.int64)
         r = batch.device_column("rewards")
         ci = pick(rec["cinfo"])
         stats = torch.cat([r.sum().view(1), r.min().view(1), r.max().view(1), ci.sum(0)]).cpu().numpy()

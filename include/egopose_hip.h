@@ -73,6 +73,10 @@ typedef struct egp_model_desc {
      * solves the stable-PD system per substep; 1 'torque' -- torque = clip(a_ref + action * a_scale, +-torque_lim), the
      * same on every substep of the env-step, no solve (every K1 entry point and the engine follow this switch) */
     int32_t action_torque;
+    /* cfg.obs_phase (humanoid_v1.py:92-94, egoforecast_config.py:107): the observation ends with one more column,
+     * min(cur_t / episode_len, 1). Every entry point that forms observations from (qpos, qvel) then needs the rows' cur_t
+     * (`phase_t`, int32 per row, device or device-visible memory); with obs_phase == 0 that argument is ignored (NULL). */
+    int32_t obs_phase;
 } egp_model_desc;
 /* width of an observation row under those options (115 for the defaults) */
 int32_t egp_obs_dim(const egp_ctx *ctx);
@@ -143,8 +147,8 @@ int egp_body_quat_f32(egp_ctx *ctx, const float *qpos, int32_t n, float *bquat, 
 /* ---------------------------------------------------------------------------------------- K3
  * HumanoidEnv.get_full_obs (ego_pose/envs/humanoid_v1.py:73-96), obs_coord='heading',
  * root_deheading, obs_vel='full': obs[n][nq-2+nv] */
-int egp_obs_f64(egp_ctx *ctx, const double *qpos, const double *qvel, int32_t n, double *obs, void *stream);
-int egp_obs_f32(egp_ctx *ctx, const float *qpos, const float *qvel, int32_t n, float *obs, void *stream);
+int egp_obs_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const int32_t *phase_t, int32_t n, double *obs, void *stream);
+int egp_obs_f32(egp_ctx *ctx, const float *qpos, const float *qvel, const int32_t *phase_t, int32_t n, float *obs, void *stream);
 
 /* ---------------------------------------------------------------------------------------- K1
  * HumanoidEnv.compute_torque + compute_desired_accel + the target/clip lines of do_simulation
@@ -214,12 +218,13 @@ int egp_zfilter_f32(const float *x, const int32_t *active, int32_t n, int32_t di
 
 /* K3 + K6 fused (what the rollout calls every tick): get_full_obs of the drained state pushed through the
  * running filter without an intermediate raw-observation array.
+ *   phase_t [n]: the rows' cur_t when the model has obs_phase (egp_model_desc), else ignored
  *   active [n] (optional): rows that update the statistics; write_only_active != 0: only those rows are written
  *   state_in == NULL: no filter (y = raw observation);  y2 (optional): second copy of the output rows */
-int egp_obs_zfilter_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const int32_t *active, int32_t n,
+int egp_obs_zfilter_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const int32_t *phase_t, const int32_t *active, int32_t n,
                         const double *state_in, double *state_out, double clip, double *y, double *y2,
                         int32_t write_only_active, void *workspace, void *stream);
-int egp_obs_zfilter_f32(egp_ctx *ctx, const float *qpos, const float *qvel, const int32_t *active, int32_t n,
+int egp_obs_zfilter_f32(egp_ctx *ctx, const float *qpos, const float *qvel, const int32_t *phase_t, const int32_t *active, int32_t n,
                         const double *state_in, double *state_out, double clip, float *y, float *y2,
                         int32_t write_only_active, void *workspace, void *stream);
 /* egp_obs_zfilter_f64 (all rows written, no write mask) in two calls, for batches of at most egp_obs_zfilter_split_max_rows() rows:
@@ -227,9 +232,9 @@ int egp_obs_zfilter_f32(egp_ctx *ctx, const float *qpos, const float *qvel, cons
  * state_in -> state_out, normalise, clip, write y / y2): the same kernels with the same arguments, bit-identical results.
  * The apply pass can instead ride in the policy step that consumes y2 (egp_policy_gaussian_filter_f32). */
 int32_t egp_obs_zfilter_split_max_rows(void);
-int egp_obs_zfilter_stats_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const int32_t *active, int32_t n, void *workspace,
+int egp_obs_zfilter_stats_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const int32_t *phase_t, const int32_t *active, int32_t n, void *workspace,
                               void *stream);
-int egp_obs_zfilter_apply_f64(egp_ctx *ctx, const double *qpos, const double *qvel, int32_t n, const double *state_in, double *state_out,
+int egp_obs_zfilter_apply_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const int32_t *phase_t, int32_t n, const double *state_in, double *state_out,
                               double clip, double *y, double *y2, void *workspace, void *stream);
 /* hipMemcpyAsync host (pinned) -> device on `stream`: the per-tick integer flags of the rollout driver (kernels that
  * re-read a flag array must not read it from pinned memory: every access would cross PCIe) */
@@ -482,7 +487,7 @@ int egp_policy_gaussian_staged_f32(const float *ctx_rows, int64_t ctx_row_stride
  * egp_obs_zfilter_stats_f64 left in `zf_workspace`; they are written to y (and y2) and the merged statistics to zf_out. One launch
  * computes exactly what egp_obs_zfilter_apply_f64 followed by egp_policy_gaussian_staged_f32 on y2 computes (bit-identical). */
 int egp_policy_gaussian_filter_f32(egp_ctx *ctx, const float *ctx_rows, int64_t ctx_row_stride, int32_t ctx_dim, const int64_t *t_idx,
-                                   const double *qpos, const double *qvel, int32_t n, const double *zf_in, double *zf_out,
+                                   const double *qpos, const double *qvel, const int32_t *phase_t, int32_t n, const double *zf_in, double *zf_out,
                                    double clip, double *y, double *y2, const void *zf_workspace,
                                    const egp_mlp_layer *layers, int32_t n_layers, int32_t activation, const float *log_std,
                                    const float *noise, double *action, float *mean_out, const void *stage_src, void *stage_dst,
@@ -616,7 +621,7 @@ typedef struct egp_rollout_tick {
     uint8_t *slab_host, *slab_dev;               /* [n_groups][2][24 * nmax] flags + context-row slabs (pinned / device) */
     const double *qpos, *qvel, *prev_qpos, *ee;  /* the engine's device state */
     void *zf_workspace;
-    int32_t *reset_scratch;                      /* [n_groups][2][2 * nmax] pinned, device-visible: ids | group mask of egp_rollout_reset */
+    int32_t *reset_scratch;                      /* [n_groups][2][3 * nmax] pinned, device-visible: ids | group mask | cur_t of egp_rollout_reset */
     int32_t group_streams;                       /* 1: a group's tick is enqueued on its engine stream (egp_engine_group_stream); `stream` carries
                                                   * the rollout's set-up and the reward launches (event-ordered); needs reward_job == 0 */
     int32_t post_fused;                          /* 1 (and reward_job == 0): K3 + K6 + K2 through egp_post_step_f64 */
@@ -633,12 +638,13 @@ int egp_rollout_tick_post(const egp_rollout_tick *d, int32_t group, int32_t a, i
 /* HumanoidEnv.reset_model + the first observation of the new episodes (ego_pose/envs/humanoid_v1.py:201-226, core/agent.py:35-38)
  * for the slots `ids` (n of them, strictly increasing, all inside [a, b)) whose episode ended in tick k, called right behind
  * egp_rollout_tick_post: physics reset to (qpos, qvel) rows [n][nq] / [n][nv] (host), slot bookkeeping (take, start frame, expert
- * row of frame 0, cur_t = 0), the slots' video-context rows `ctx_rows` (device, [n][ctx_T][ctx_dim] float32) into v_out, and K3 + K6
+ * row of frame 0, cur_t = cur_t0[j] -- NULL: 0; cfg.random_cur_t, humanoid_v1.py:218-220: the state rows then are those of frame
+ * start + cur_t0), the slots' video-context rows `ctx_rows` (device, [n][ctx_T][ctx_dim] float32) into v_out, and K3 + K6
  * over the group with only those slots active: their filtered observation replaces states[k + 1] (the running filter advances
  * zf_cur -> zf_new exactly as one more egp_obs_zfilter_f64 call). Uses reset_scratch slot k & 1 of the group.
  * ctx_rows_fresh != 0: ctx_rows were produced on `stream` since the last call (group-stream ticks order themselves behind it). */
 int egp_rollout_reset(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, const int32_t *ids, int32_t n,
-                      const int64_t *e_ind, const int64_t *s_ind, const int64_t *frame_rows, const double *qpos, const double *qvel,
+                      const int64_t *e_ind, const int64_t *s_ind, const int64_t *frame_rows, const int64_t *cur_t0, const double *qpos, const double *qvel,
                       const float *ctx_rows, int32_t ctx_rows_fresh, const double *zf_cur, double *zf_new);
 /* the stream group g's env-step kernels are launched on (owned by the engine) */
 void *egp_engine_group_stream(egp_engine *e, int32_t group);

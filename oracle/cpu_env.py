@@ -50,7 +50,8 @@ class OracleHumanoidEnv:
     def _obs(self):
         c = self.cfg
         return H.full_obs(self.qpos, self.qvel, obs_heading=getattr(c, "obs_heading", False), root_deheading=getattr(c, "root_deheading", True),
-                          obs_coord=getattr(c, "obs_coord", "heading"), obs_vel=getattr(c, "obs_vel", "full"))[0]
+                          obs_coord=getattr(c, "obs_coord", "heading"), obs_vel=getattr(c, "obs_vel", "full"),
+                          phase=([self.cur_t], c.env_episode_len) if getattr(c, "obs_phase", False) else None)[0]
 
     def reset(self):
         cfg = self.cfg
@@ -58,7 +59,11 @@ class OracleHumanoidEnv:
         self.expert_ind = self.np_random.randint(len(self.expert_arr))
         e = self.expert_arr[self.expert_ind]
         self.start_ind = self.np_random.randint(cfg.fr_margin, e["len"] - cfg.env_episode_len - cfg.fr_margin)
-        self.phys.reset(self.slot, e["qpos"][self.start_ind], e["qvel"][self.start_ind])
+        ind = self.start_ind
+        if getattr(cfg, "random_cur_t", False):                 # humanoid_v1.py:218-220
+            self.cur_t = int(self.np_random.randint(cfg.env_episode_len))
+            ind += self.cur_t
+        self.phys.reset(self.slot, e["qpos"][ind], e["qvel"][ind])
         self._drain(True)
         self.bquat = H.body_quat(self.qpos, self.skel.body_qpos_start, self.skel.body_ndof)[0]
         return self._obs()

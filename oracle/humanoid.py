@@ -37,9 +37,10 @@ def body_quat(qpos, body_qpos_start, body_ndof):
     return out.reshape(B, nb * 4)
 
 
-def full_obs(qpos, qvel, obs_heading=False, root_deheading=True, obs_coord="heading", obs_vel="full"):
+def full_obs(qpos, qvel, obs_heading=False, root_deheading=True, obs_coord="heading", obs_vel="full", phase=None):
     """HumanoidEnv.get_full_obs (ego_pose/envs/humanoid_v1.py:73-96), batch-first. Defaults (every shipped config):
-    (B,59),(B,58) -> (B,115) = [qpos[2:] with de-headed root quat, qvel with heading-frame root lin-vel]."""
+    (B,59),(B,58) -> (B,115) = [qpos[2:] with de-headed root quat, qvel with heading-frame root lin-vel].
+    `phase` = (cur_t (B,), env_episode_len) under cfg.obs_phase: one more column min(cur_t / env_episode_len, 1) (:92-94)."""
     qpos = np.atleast_2d(np.asarray(qpos, float)).copy()
     qvel = np.atleast_2d(np.asarray(qvel, float)).copy()
     root_q = qpos[:, 3:7].copy()
@@ -54,6 +55,9 @@ def full_obs(qpos, qvel, obs_heading=False, root_deheading=True, obs_coord="head
         parts.append(qvel[:, :6])
     elif obs_vel == "full":
         parts.append(qvel)
+    if phase is not None:                                                              # :91-94
+        cur_t, ep_len = phase
+        parts.append(np.minimum(np.asarray(cur_t, float).reshape(-1, 1) / ep_len, 1.0))
     return np.concatenate(parts, axis=1)
 
 

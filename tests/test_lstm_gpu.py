@@ -426,3 +426,27 @@ def test_ragged_grouped_sweeps_match_the_full_ones_where_it_counts(T, B, with_ro
         a, b = grag[k].cpu().numpy(), gfull[k].cpu().numpy()
         scale = max(1.0, np.abs(b).max())
         np.testing.assert_allclose(a / scale, b / scale, rtol=0, atol=5e-6, err_msg=k)      # (other split-K partitions, zeros instead of tiny products)
+
+
+def test_state_regression_head_on_the_gpu_matches_the_reference():
+    """videoreg_head.npz: the reference's VideoRegNet(no_cnn=True) (models/video_reg_net.py:10-59) at the shipped widths -- bi-LSTM
+    128 -> 2 x 64, MLP [300, 200], Linear -> 115 -- evaluated in float64 by the reference on a (40, 3, 128) clip. The GPU module
+    runs it on the persistent HIP LSTM kernels (hidden 64) and the HIP GEMM head in float32 from the float32-rounded weights:
+    2e-5 relative to the output scale (float32 rounding of weights and input, float32 accumulation over 220-term sums)."""
+    from conftest import load_golden
+    from egopose_amd import lstm as LS
+    from egopose_amd.nets import VideoRegNet
+    g = load_golden("videoreg_head.npz")
+    net = VideoRegNet(115, 128, 128, no_cnn=True, mlp_dim=(300, 200))
+    net.load_state_dict({k[3:]: torch.as_tensor(g[k]) for k in g.files if k.startswith("sd_")}, strict=True)
+    net = net.cuda().eval()
+    x = torch.as_tensor(g["x"], device="cuda")
+    assert LS.available(x, net.v_net.rnn_f), "the clip must run on the HIP LSTM kernels"
+    with torch.no_grad():
+        y = net(x)
+    scale = float(np.abs(g["y"]).max())
+    assert y.shape == g["y"].shape
+    np.testing.assert_allclose(y.double().cpu().numpy(), g["y"], rtol=0, atol=2e-5 * max(1.0, scale))
+    # the autograd (training) form of the same module gives the same numbers
+    y2 = net.train()(x)
+    np.testing.assert_allclose(y2.detach().double().cpu().numpy(), g["y"], rtol=0, atol=2e-5 * max(1.0, scale))

@@ -284,6 +284,64 @@ def test_observation_variants():
         np.testing.assert_allclose(got, ref, **TOL)
 
 
+def test_phase_observation():
+    """cfg.obs_phase (humanoid_v1.py:92-94): the last column min(cur_t / env_episode_len, 1), cur_t below, at and beyond the length."""
+    g = load_golden("obs_phase.npz")
+    ph = (g["cur_t"], int(g["episode_len"]))
+    got = H.full_obs(g["qpos"], g["qvel"], phase=ph)
+    assert got.shape == g["obs_default"].shape == (20, 116)
+    np.testing.assert_allclose(got, g["obs_default"], **TOL)
+    np.testing.assert_array_equal(got[:, -1], g["obs_default"][:, -1])          # the division itself: bit for bit
+    got = H.full_obs(g["qpos"], g["qvel"], obs_heading=True, root_deheading=False, obs_coord="root", obs_vel="root", phase=ph)
+    np.testing.assert_allclose(got, g["obs_variant"], **TOL)
+
+
+def test_random_cur_t_reset_rule():
+    """cfg.random_cur_t (humanoid_v1.py:218-220) through the oracle env with a recording physics stand-in: the state set at reset is
+    the expert frame start_ind + cur_t, the episode ends after env_episode_len - cur_t steps, step i's expert index is
+    start_ind + cur_t, the phase column follows cur_t -- the reference's own reset / step on the same draws (random_cur_t.npz)."""
+    import types
+    from oracle.cpu_env import OracleHumanoidEnv
+    from egopose_amd.skeleton import load_skeleton
+    g = load_golden("random_cur_t.npz")
+    sk = load_skeleton()
+    L, ep_len = int(g["take_len"]), int(g["episode_len"])
+    takes = [{"qpos": g["takes_qpos"][k], "qvel": g["takes_qvel"][k], "len": L, "head_height_lb": -100.0} for k in range(g["takes_qpos"].shape[0])]
+    cfg = types.SimpleNamespace(fr_margin=int(g["fr_margin"]), env_episode_len=ep_len, random_cur_t=True, obs_phase=True, action_type="torque",
+                                jkp=np.ones(52), jkd=np.ones(52), a_ref=np.zeros(52), a_scale=np.ones(52), torque_lim=np.ones(52))
+
+    class Phys:                                   # reset / step / drain of the physics boundary: holds the state it was given
+        def reset(self, slot, q, v):
+            self.q, self.v = np.array(q), np.array(v)
+        def step(self, slot, tau):
+            pass
+        def drain(self, slot, want_xpos=True):
+            xpos = np.zeros((len(sk.body_names), 3)); xpos[:, 2] = 10.0
+            return self.q, self.v, np.zeros(sk.nM), np.zeros(sk.nv), xpos
+
+    class Draws:                                  # the oracle's three randint calls return the fixture's draws
+        def __init__(self, vals): self.vals = list(vals)
+        def randint(self, *a, **k): return self.vals.pop(0)
+
+    for ep in range(len(g["cur_t0"])):
+        ph = Phys()
+        env = OracleHumanoidEnv(sk, cfg, ph, takes, None)
+        env.np_random = Draws([g["expert_ind"][ep], g["start_ind"][ep], g["cur_t0"][ep]])
+        ob = env.reset()
+        assert (env.expert_ind, env.start_ind, env.cur_t) == (g["expert_ind"][ep], g["start_ind"][ep], g["cur_t0"][ep])
+        np.testing.assert_array_equal(ph.q, g["set_qpos"][ep]); np.testing.assert_array_equal(ph.v, g["set_qvel"][ep])
+        assert ob[-1] == g["first_phase"][ep]
+        n = 0
+        while True:
+            ob, _, done, info = env.step(np.zeros(52))
+            assert env.start_ind + env.cur_t == g["step_index"][ep][n] and ob[-1] == g["step_phase"][ep][n]
+            n += 1
+            if done:
+                assert info["end"] and not info["fail"]
+                break
+        assert n == g["n_steps"][ep] == ep_len - g["cur_t0"][ep]
+
+
 def test_constant_and_pose_dist_rewards():
     g = load_golden("reward_simple.npz")
     for i in range(len(g["frame"])):

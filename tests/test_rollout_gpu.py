@@ -378,6 +378,35 @@ def test_forecast_rollout_matches_train_mode_nets_and_oracle_env(workspace, skel
     tr.close()
 
 
+def test_forecast_rollout_with_phase_observation_and_random_cur_t(workspace, skel):
+    """The two ego_forecast env branches (egoforecast_config.py:107-108, humanoid_v1.py:92-94,218-220) together: state width 116
+    through the state LSTM, episodes starting inside their window; observations (the phase column included), the decayed reward
+    (its t is cur_t) and the episode ends replayed by the oracle env, whose branches are pinned to obs_phase.npz / random_cur_t.npz;
+    an update step runs on the batch."""
+    from egopose_amd.config import ForecastConfig
+    from egopose_amd.train import Trainer
+    os.chdir(workspace)
+    cfg = ForecastConfig("subject_03", create_dirs=False)
+    cfg.env_episode_len = 12
+    cfg.num_optim_epoch = 1
+    cfg.obs_phase, cfg.random_cur_t = True, True
+    tr = Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=16, num_threads=4, num_groups=2)
+    assert tr.env.observation_space.shape[0] == 116
+    tr.pre_iter_update(0)
+    tr.agent.running_state = None
+    batch, log = tr.agent.sample(16 * 20)
+    ro = tr.agent._get_rollout()
+    ends = np.where(batch.masks == 0)[0]
+    starts = np.r_[0, ends[:-1] + 1]
+    t0 = ro.batch_t0
+    np.testing.assert_allclose(batch.states[starts, -1], t0[starts] / 12.0, rtol=0, atol=1e-15)
+    assert (ends - starts + 1 <= 12 - t0[starts]).all() and len(set(t0[starts].tolist())) > 4
+    _replay_episodes(tr, cfg, skel, batch, range(0, 8), 0.0, t0=t0)
+    tr.agent.update_params(batch)
+    assert all(np.isfinite(tr.agent.update_stats["value_loss"]))
+    tr.close()
+
+
 def test_forecast_full_iteration(workspace):
     tr, cfg = _forecast_trainer(workspace, 32, 10, num_threads=4, num_groups=2)
     before = [p.detach().clone() for p in list(tr.policy_net.parameters()) + list(tr.policy_vs_net.parameters())]
@@ -503,7 +532,8 @@ def test_sampled_actions_are_policy_mean_plus_unit_noise(workspace):
     tr.close()
 
 
-def _replay_episodes(tr, cfg, skel, batch, episodes, end_reward, tol=1e-7):
+def _replay_episodes(tr, cfg, skel, batch, episodes, end_reward, tol=1e-7, t0=None):
+    """`t0`: cur_t at every batch row's episode start (cfg.random_cur_t; LockstepRollout.batch_t0), default 0."""
     from egopose_amd.physics import SurrogatePhysics
     from oracle.cpu_env import OracleHumanoidEnv
     from oracle import humanoid as H
@@ -516,9 +546,10 @@ def _replay_episodes(tr, cfg, skel, batch, episodes, end_reward, tol=1e-7):
         s, e = starts[j], ends[j]
         ei, si = batch.v_metas[s]
         assert (batch.v_metas[s:e + 1] == [ei, si]).all()
-        env.expert_ind, env.start_ind, env.cur_t = int(ei), int(si), 0
+        c0 = 0 if t0 is None else int(t0[s])
+        env.expert_ind, env.start_ind, env.cur_t = int(ei), int(si), c0
         ex = tr.env.expert_arr[ei]
-        ph.reset(0, ex["qpos"][si], ex["qvel"][si])
+        ph.reset(0, ex["qpos"][si + c0], ex["qvel"][si + c0])
         env._drain(True)
         env.bquat = H.body_quat(env.qpos, skel.body_qpos_start, skel.body_ndof)[0]
         np.testing.assert_allclose(batch.states[s], env._obs(), rtol=1e-9, atol=1e-9)
@@ -589,7 +620,7 @@ def test_cross_01_config_short_rollout(tmp_path_factory, skel):
 
 
 @pytest.mark.parametrize("option", [("obs_heading", True), ("obs_vel", "root"), ("root_deheading", False), ("obs_coord", "root"),
-                                    ("action_type", "torque")])
+                                    ("action_type", "torque"), ("obs_phase", True), ("random_cur_t", True)])
 def test_non_default_observation_options_in_the_rollout(workspace, skel, option):
     """The env switches of humanoid_v1.py:73-96,167-172 run through the whole rollout: state width follows the option, the
     recorded observations and rewards are the oracle env's (which evaluates the reference's branches -- obs_coord inside
@@ -603,13 +634,25 @@ def test_non_default_observation_options_in_the_rollout(workspace, skel, option)
     cfg.num_optim_epoch = 1
     setattr(cfg, *option)
     tr = Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=16, num_threads=2, num_groups=2)
-    want = 115 + (1 if option[0] == "obs_heading" else 0) - (52 if option[0] == "obs_vel" else 0)
+    want = 115 + (1 if option[0] in ("obs_heading", "obs_phase") else 0) - (52 if option[0] == "obs_vel" else 0)
     assert tr.env.observation_space.shape[0] == want and tr.policy_net.net.affine_layers[0].in_features == want + cfg.policy_v_hdim
     tr.agent.running_state = None
     tr.env.end_reward = 0.2
     batch, log = tr.agent.sample(16 * 12)
     assert batch.states.shape[1] == want
-    _replay_episodes(tr, cfg, skel, batch, range(0, 6), 0.2)
+    ro = tr.agent._get_rollout()
+    if option[0] == "obs_phase":          # (the native tick: the phase column comes from the tick's flag slab)
+        assert ro.ctx.obs_phase and ro.timing["ticks"] > 10
+        ends = np.where(batch.masks == 0)[0]
+        starts = np.r_[0, ends[:-1] + 1]
+        assert (batch.states[starts, -1] == 0).all() and np.allclose(batch.next_states[:, -1][ends[ends - starts == 9]], 1.0)
+    if option[0] == "random_cur_t":       # episodes start at step cur_t0 of their window and end when cur_t reaches the episode length
+        ends = np.where(batch.masks == 0)[0]
+        starts = np.r_[0, ends[:-1] + 1]
+        t0 = ro.batch_t0
+        assert len(set(t0[starts].tolist())) > 3 and t0.max() < 10 and (ends - starts + 1 <= 10 - t0[starts]).all()
+        assert (ends - starts + 1 == 10 - t0[starts]).sum() > len(starts) // 2       # (the others fell)
+    _replay_episodes(tr, cfg, skel, batch, range(0, 6), 0.2, t0=ro.batch_t0)
     tr.agent.update_params(batch)
     assert all(np.isfinite(tr.agent.update_stats["value_loss"]))
     tr.close()
@@ -618,8 +661,7 @@ def test_non_default_observation_options_in_the_rollout(workspace, skel, option)
         Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=8, num_threads=2, num_groups=1).agent.sample(8)
 
 
-@pytest.mark.parametrize("key,value,exc", [("obs_phase", True, NotImplementedError), ("random_cur_t", True, NotImplementedError),
-                                           ("action_type", "velocity", ValueError), ("obs_coord", "world", ValueError),
+@pytest.mark.parametrize("key,value,exc", [("action_type", "velocity", ValueError), ("obs_coord", "world", ValueError),
                                            ("obs_type", "partial", NotImplementedError), ("j_stiff", 5.0, NotImplementedError)])
 def test_unsupported_env_options_are_refused(workspace, key, value, exc):
     """Every env key of egomimic_config.py:82-105 / egoforecast_config.py:90-95 is honoured on the HIP path or refused loudly."""
