@@ -64,6 +64,16 @@ class MlpLayer(C.Structure):
     _fields_ = [("wt", vp), ("bias", vp), ("in_dim", C.c_int32), ("out_dim", C.c_int32)]
 
 
+class MlpChainDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("backward", C.c_int32),
+                ("src1", vp), ("ld1", C.c_int64), ("gather", vp), ("c1", C.c_int32),
+                ("src2", vp), ("ld2", C.c_int64), ("c2", C.c_int32),
+                ("packed", vp * 3), ("bias", vp * 3), ("dims", C.c_int32 * 4),
+                ("mask1", vp), ("mask2", vp),
+                ("inT", vp), ("o1T", vp), ("o2T", vp), ("ldT", C.c_int64),
+                ("out", vp), ("ld_out", C.c_int64), ("scatter", vp)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("A", vp), ("lda", C.c_int64), ("a_kcontig", C.c_int32),
@@ -204,6 +214,10 @@ SIGNATURES = {
     "egp_post_step_f64": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, _i32, vp, vp, _f64, vp, vp, vp, _f64, vp, vp, vp]),
     "egp_set_dynamics_model": (C.c_int, [vp, C.POINTER(DynamicsDesc)]),
     "egp_dynamics_f64": (C.c_int, [vp, vp, vp, _i32, vp, C.c_int64, vp, vp, vp]),
+    "egp_mlp_chain_ksteps": (_i32, [_i32]),
+    "egp_mlp_chain_pack_bytes": (C.c_int64, [_i32, _i32]),
+    "egp_mlp_chain_pack_f32": (C.c_int, [vp, C.c_int64, _i32, _i32, _i32, _i32, vp, vp]),
+    "egp_mlp_chain_f32": (C.c_int, [C.POINTER(MlpChainDesc), vp]),
     "egp_mlp_pack_floats": (C.c_int64, [_i32, _i32]),
     "egp_mlp_pack_f32": (C.c_int, [vp, C.c_int64, _i32, _i32, vp, vp]),
     "egp_policy_gaussian_f32": (C.c_int, [vp, C.c_int64, _i32, vp, vp, _i32, _i32, C.POINTER(MlpLayer), _i32, _i32, vp, vp, vp, vp, vp]),

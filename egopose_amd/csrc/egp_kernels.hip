@@ -1407,7 +1407,7 @@ int64_t egp_abi_sizeof(const char *name) {
     if (!name) return -1;
 #define EGP_ABI_SIZE(T) if (!strcmp(name, #T)) return (int64_t)sizeof(T);
     EGP_ABI_SIZE(egp_model_desc) EGP_ABI_SIZE(egp_expert_table) EGP_ABI_SIZE(egp_gemm_desc)
-    EGP_ABI_SIZE(egp_dynamics_desc) EGP_ABI_SIZE(egp_mlp_layer) EGP_ABI_SIZE(egp_physics_vtable)
+    EGP_ABI_SIZE(egp_dynamics_desc) EGP_ABI_SIZE(egp_mlp_layer) EGP_ABI_SIZE(egp_mlp_chain_desc) EGP_ABI_SIZE(egp_physics_vtable)
     EGP_ABI_SIZE(egp_surrogate_desc) EGP_ABI_SIZE(egp_engine_desc) EGP_ABI_SIZE(egp_rollout_tick)
     EGP_ABI_SIZE(egp_ppo_loss_desc) EGP_ABI_SIZE(egp_adam_segment)
 #undef EGP_ABI_SIZE

@@ -449,6 +449,38 @@ int egp_dynamics_f64(egp_ctx *ctx, const double *qpos, const double *qvel, int32
                      double *qfrc_bias, double *xpos, void *stream);
 
 /* ----------------------------------------------------------------------------------------
+ * The update's policy / value MLP as one launch per direction (csrc/egp_chain.hip): three chained products over 128-row tiles
+ * with the intermediate activations in registers, weights streamed through LDS from pre-split bf16 fragment streams.
+ *   forward  (models/mlp.py:22-25, core/policy_gaussian.py:19-24, core/critic.py:15-18):
+ *       in = [src1[gather[r]][0:c1] | src2[r][0:c2]]  ->  relu(W1 in + b1)  ->  relu(W2 . + b2)  ->  W3 . + b3  =  out[r]
+ *       optional saves for the backward pass, [feature][ldT] float32: inT (the input), o1T, o2T (the hidden activations)
+ *   backward (data gradients of the same layers): src1 = d out [n][dims[0]] (gather NULL, c2 = 0), packed = W3^T, W2^T, W1[:, :H]^T,
+ *       mask1 / mask2 = the saved o2T / o1T of the forward pass; o1T / o2T receive d z2^T / d z1^T, inT receives d out^T (the
+ *       operands of the weight gradients, k-contiguous for egp_gemm_f32), out = d ctx, row r written to out[scatter[r]].
+ * dims = {in, product-1 out, product-2 out, product-3 out}. Built shapes: 32-feature block counts (10, 7, 2 | 1) forward and
+ * (7, 10, 4) backward -- the shipped 243 -> 300 -> 200 -> 52 | 1 nets; anything else returns EGP_E_INVALID (callers keep the
+ * layer-per-launch path of egp_gemm_f32 for other widths). Products are the six-term three-piece bf16 products of egp_gemm_f32.
+ * Weights: egp_mlp_chain_pack_f32 turns an nn.Linear weight W[n_out][k_in] (or its transpose: the operand's element (i, k) is
+ * W[k][i], n_out = the operand's rows) into the fragment stream of one product; `chained` = the product is fed from the
+ * previous product's accumulators (products 2 and 3), else from memory (product 1). egp_mlp_chain_pack_bytes(rows, k) bytes. */
+typedef struct egp_mlp_chain_desc {
+    int32_t n, backward;
+    const float *src1; int64_t ld1; const int64_t *gather; int32_t c1;
+    const float *src2; int64_t ld2; int32_t c2;
+    const void *packed[3];
+    const float *bias[3];
+    int32_t dims[4];
+    const float *mask1, *mask2;
+    float *inT, *o1T, *o2T; int64_t ldT;
+    float *out; int64_t ld_out; const int64_t *scatter;
+} egp_mlp_chain_desc;
+int32_t egp_mlp_chain_ksteps(int32_t k_in);
+int64_t egp_mlp_chain_pack_bytes(int32_t n_out, int32_t k_in);
+int egp_mlp_chain_pack_f32(const float *weight, int64_t ldw, int32_t n_out, int32_t k_in, int32_t transpose, int32_t chained, void *packed,
+                           void *stream);
+int egp_mlp_chain_f32(const egp_mlp_chain_desc *desc, void *stream);
+
+/* ----------------------------------------------------------------------------------------
  * Rollout-time policy step in one launch (replaces, for all envs of a group at once, the chain
  * VideoStateNet.forward concat (models/video_state_net.py:37-43) -> MLP (models/mlp.py:5-25) ->
  * PolicyGaussian.forward / select_action (models/policy_gaussian.py:19-27, core/agent.py:38-44)):
