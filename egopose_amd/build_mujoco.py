@@ -28,21 +28,23 @@ def find_mujoco(root):
     raise SystemExit("no libmujoco*.so under %s/lib or %s/bin" % (root, root))
 
 
-def build(verbose=True):
+def build(verbose=True, out=None):
+    """`out`: where to write the plugin (default: egopose_amd/libegopose_mujoco.so, where physics.MujocoPhysics looks for it)."""
     root = os.environ.get("MUJOCO_DIR")
     if not root:
         raise SystemExit("set MUJOCO_DIR to a MuJoCo tree (include/ + lib/ or bin/); MuJoCo is not shipped with this package")
     from .build import build as build_main
     main_lib = build_main()
     inc, mj = find_mujoco(root)
-    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + inc, SRC, "-o", LIB,
+    lib_out = out or LIB
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + inc, SRC, "-o", lib_out,
            main_lib, mj, "-Wl,-rpath," + os.path.dirname(mj), "-Wl,-rpath," + HERE]
     if os.environ.get("EGP_MUJOCO_ACTIVATE") == "1":
         cmd.insert(1, "-DEGP_MUJOCO_ACTIVATE")
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB
+    return lib_out
 
 
 if __name__ == "__main__":

@@ -148,12 +148,14 @@ class MujocoPhysics(SurrogatePhysics):
     def available(cls):
         return os.path.exists(cls.PLUGIN)
 
-    def __init__(self, skel: Skeleton, n_env: int, mjcf_path: str):
+    def __init__(self, skel: Skeleton, n_env: int, mjcf_path: str, plugin: Optional[str] = None):
+        """`plugin`: path of the compiled plugin (default: EGP_MUJOCO_PLUGIN, else egopose_amd/libegopose_mujoco.so)."""
         self.lib = L.load()
-        if not self.available():
+        plugin = plugin or os.environ.get("EGP_MUJOCO_PLUGIN") or self.PLUGIN
+        if not os.path.exists(plugin):
             raise L.EgpError("the MuJoCo plugin %s is not built: MUJOCO_DIR=<mujoco tree> python -m egopose_amd.build_mujoco "
-                             "(MuJoCo does not ship with this package)" % self.PLUGIN)
-        self.plugin = C.CDLL(self.PLUGIN, mode=C.RTLD_GLOBAL)
+                             "(MuJoCo does not ship with this package)" % plugin)
+        self.plugin = C.CDLL(plugin, mode=C.RTLD_GLOBAL)
         fn = self.plugin.egp_physics_create_mujoco
         fn.restype, fn.argtypes = C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p), C.c_char_p, C.c_int32]
         self.skel, self.n_env = skel, int(n_env)
