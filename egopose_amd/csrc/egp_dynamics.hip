@@ -79,6 +79,10 @@ int egp_launch_dynamics_strided(egp_ctx *ctx, const double *qpos, long ld_q, con
 
 extern "C" {
 
+#ifdef EGP_DYN_TRACE
+int egp_dyn_trace_read(long long *out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dyn_trace), sizeof(long long) * 16) == hipSuccess ? 0 : -1; }
+#endif
+
 int egp_set_dynamics_model(egp_ctx *ctx, const egp_dynamics_desc *d) {
     EGP_REQUIRE(ctx && d, "NULL pointer");
     EGP_REQUIRE(d->nbody >= 1 && d->nbody <= DY_MAXB && d->njoint >= 0 && d->njoint <= DY_MAXJ - 6, "tree too large");
@@ -137,12 +141,35 @@ int egp_set_dynamics_model(egp_ctx *ctx, const egp_dynamics_desc *d) {
         t.subtree_end[b] = end;
     }
     EGP_REQUIRE(j == d->njoint, "body_ndof does not sum to njoint");
+    {   // ancestor jump tables of the dof tree (phase D's prefix sums) and the rounds the longest chain needs
+        int longest = 1;
+        for (int i = 0; i < t.nv; ++i) {
+            t.dof_anc[0][i] = (signed char)t.dof_parent[i];
+            int len = 0;
+            for (int k = i; k >= 0; k = t.dof_parent[k]) ++len;
+            if (len > longest) longest = len;
+        }
+        for (int k = 1; k < 6; ++k)
+            for (int i = 0; i < t.nv; ++i) {
+                const int h = t.dof_anc[k - 1][i];
+                t.dof_anc[k][i] = h >= 0 ? t.dof_anc[k - 1][h] : (signed char)-1;
+            }
+        t.scan_rounds = 0;
+        while ((1 << t.scan_rounds) < longest) ++t.scan_rounds;
+        EGP_REQUIRE(t.scan_rounds <= 6, "dof chain longer than 64");
+    }
     int adr = 0;
     for (int i = 0; i < t.nv; ++i) {
         t.dof_madr[i] = adr;
         for (int k = i; k >= 0; k = t.dof_parent[k]) ++adr;
     }
     EGP_REQUIRE(adr == ctx->dm.nM, "sparse inertia size differs from the context's model");
+    EGP_REQUIRE(adr <= 1024, "sparse inertia row longer than 1024 entries");
+    t.nM = adr;
+    for (int i = 0; i < t.nv; ++i) {                 // entry table of the row: dof i, then its ancestors (MuJoCo's legacy order)
+        int e = t.dof_madr[i];
+        for (int k = i; k >= 0; k = t.dof_parent[k], ++e) { t.ent_row[e] = (unsigned char)i; t.ent_col[e] = (unsigned char)k; }
+    }
     EGP_HIP_CHECK(hipSetDevice(ctx->device));
     if (!ctx->dyn_tables) {
         void *p = nullptr;

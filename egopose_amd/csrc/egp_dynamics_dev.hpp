@@ -4,6 +4,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// EGP_DYN_TRACE (tools/probes/dyn_trace.py): wall_clock64 stamps (100 MHz) of lane 0 of the first wave of workgroup 0 after each phase
+#ifdef EGP_DYN_TRACE
+__device__ long long g_dyn_trace[16];
+#define DY_TR(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dyn_trace[i] = wall_clock64(); } while (0)
+#else
+#define DY_TR(i) do { } while (0)
+#endif
+
 namespace egp_dyn {
 
 constexpr int DY_MAXB = 24;      // bodies
@@ -16,6 +24,10 @@ struct DynTables {               // device copy of the tree, laid out as the ker
     int parent[DY_MAXB], level[DY_MAXB], nchild[DY_MAXB], child[DY_MAXB][DY_MAXC], first_j[DY_MAXB], ndof[DY_MAXB];
     int dof_parent[DY_MAXV], dof_madr[DY_MAXV], dof_body[DY_MAXV];
     int last_dof[DY_MAXB];       // deepest dof of the body's chain (its own last hinge, or the nearest ancestor's)
+    signed char dof_anc[6][DY_MAXV];   // dof_anc[k][d]: the 2^k-th ancestor of dof d in the dof tree (-1: none) -- pointer jumping
+    int scan_rounds;             // ceil(log2(longest dof chain))
+    int nM;                      // entries of the sparse inertia row
+    unsigned char ent_row[1024], ent_col[1024];   // entry e of the row = M[ent_row[e]][ent_col[e]] (MuJoCo's order: dof d, then its ancestors)
     int subtree_end[DY_MAXB];    // bodies [b, subtree_end[b]) form b's subtree (depth-first body order)
     double off[DY_MAXB][3];      // body_pos - body_pos[parent]   (zero pose, global)
     double com_l[DY_MAXB][3];    // body_com - body_pos
@@ -44,8 +56,7 @@ __device__ __forceinline__ M3 mul(const M3 &A, const M3 &B) {
     return C;
 }
 // Rodrigues: I + sin K + (1 - cos) K^2
-__device__ __forceinline__ M3 axis_angle(V3 a, double ang) {
-    const double s = sin(ang), c1 = 1.0 - cos(ang);
+__device__ __forceinline__ M3 axis_angle(V3 a, double s, double c1) {
     M3 R;
     R.m[0] = 1.0 + c1 * (-a.y * a.y - a.z * a.z); R.m[1] = -s * a.z + c1 * a.x * a.y;          R.m[2] = s * a.y + c1 * a.x * a.z;
     R.m[3] = s * a.z + c1 * a.x * a.y;           R.m[4] = 1.0 + c1 * (-a.x * a.x - a.z * a.z); R.m[5] = -s * a.x + c1 * a.y * a.z;
@@ -129,7 +140,17 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
     double *sS = sW + nb * 12;                           // [nv][6]   joint motion vectors (world)
     double *sQ = sS + nv * 6;                            // [nv]      qvel
     const int b = lane;
+    DY_TR(0);
     if (lane < nv) sQ[lane] = qd[lane];
+    // ---- A0: lane = hinge: sin and 1 - cos of every hinge angle at once (a body's up to three hinges used to take their
+    //          double-precision sincos one after the other); parked in sS, which phase C fills later
+    if (lane < nj) {
+        double sn, cs;
+        sincos(q[7 + lane], &sn, &cs);
+        sS[2 * lane] = sn;
+        sS[2 * lane + 1] = 1.0 - cs;
+    }
+    wave_sync();
     // ---- A: own hinge chain in the parent frame
     if (b < nb) {
         M3 Rl;
@@ -155,7 +176,7 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
                 const V3 r_p = tl + mul(Rl, anc_loc);
                 st_v3(sJl + j * 6, a_p);
                 st_v3(sJl + j * 6 + 3, r_p);
-                Rl = mul(Rl, axis_angle(a_loc, q[7 + j]));
+                Rl = mul(Rl, axis_angle(a_loc, sS[2 * j], sS[2 * j + 1]));
                 tl = r_p - mul(Rl, anc_loc);
             }
         }
@@ -163,6 +184,7 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
         st_v3(sLoc + b * 12 + 9, tl);
     }
     wave_sync();
+    DY_TR(1);
     // ---- B: world frames (compose upwards: T_world = T_root o ... o T_parent o T_b)
     if (b < nb) {
         M3 R;
@@ -179,6 +201,7 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
         if (valid && xpos_out) st_v3(xpos_out + b * 3, t);
     }
     wave_sync();
+    DY_TR(2);
     // ---- C: joint motion vectors
     if (lane < nv) {
         const int d = lane;
@@ -199,21 +222,45 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
         st_sp(sS + d * 6, S);
     }
     wave_sync();
-    // ---- D: velocity, bias acceleration, own inertia, body force
-    if (b < nb) {
-        // a = a0 + sum over dof pairs d' < d of the chain of (S_d' qd_d') x (S_d qd_d), except pairs inside the root's three
-        // rotational dofs (their axes ride on the root itself: d/dt S = v_root x S, whose rot-rot part cancels).
-        Sp suffix = {{0, 0, 0}, {0, 0, 0}};          // sum of S_d qd_d over the dofs visited so far (below the current one)
-        Sp hinge_suffix = suffix;                     // the same without the root's rotational dofs
-        Sp a = {{0, 0, 0}, {-tb.g[0], -tb.g[1], -tb.g[2]}};
-        for (int d = tb.last_dof[b]; d >= 0; d = tb.dof_parent[d]) {
-            const Sp sq = sQ[d] * ld_sp(sS + d * 6);
-            const bool root_rot = d >= 3 && d < 6;
-            a = a + cross_m(sq, root_rot ? hinge_suffix : suffix);
-            suffix = suffix + sq;
-            if (!root_rot) hinge_suffix = hinge_suffix + sq;
+    DY_TR(3);
+    // ---- D: velocity, bias acceleration, own inertia, body force.
+    // v_b = sum of S_d qd_d over the body's dof chain; a_b = a0 + sum over pairs u above l of the chain of (S_u qd_u) x (S_l qd_l),
+    // except pairs inside the root's three rotational dofs (their axes ride on the root itself: d/dt S = v_root x S, whose rot-rot
+    // part cancels). Round 3 walked the chain per body (up to 28 dependent steps of LDS loads and cross products: 7 of the pass's
+    // 18 us). Both are sums over the ancestors of a dof: with P(d) = sum of S q over d and its ancestors,
+    //     a_b - a0 = sum over the chain's l of P'(parent l) x (S_l qd_l),    P' = P, but P(dof 2) for the root's rotational dofs,
+    // so two ancestor-prefix sums by pointer jumping (lane = dof, ceil(log2 28) = 5 rounds each) replace the walks.
+    double *sX = base;                                   // [nv][6] scan buffer: over sLoc / sJl (dead after C), under sIb / sF (written at the end of D)
+    Sp sq = {{0, 0, 0}, {0, 0, 0}};
+    if (lane < nv) sq = sQ[lane] * ld_sp(sS + lane * 6);
+    auto ancestor_sums = [&](Sp x) -> Sp {              // inclusive sum of x over the lane's dof and its ancestors; leaves the sums in sX
+        if (lane < nv) st_sp(sX + lane * 6, x);
+        wave_sync();
+        for (int k = 0; k < tb.scan_rounds; ++k) {
+            const int an = lane < nv ? tb.dof_anc[k][lane] : -1;
+            Sp up = {{0, 0, 0}, {0, 0, 0}};
+            if (an >= 0) up = ld_sp(sX + an * 6);
+            wave_sync();                                 // every lane has read round k's values
+            x = x + up;
+            if (an >= 0) st_sp(sX + lane * 6, x);
+            wave_sync();
         }
-        const Sp v = suffix;
+        return x;
+    };
+    ancestor_sums(sq);
+    Sp v = {{0, 0, 0}, {0, 0, 0}};
+    if (b < nb) v = ld_sp(sX + tb.last_dof[b] * 6);
+    Sp cterm = {{0, 0, 0}, {0, 0, 0}};
+    if (lane < nv) {
+        const int par = (lane >= 3 && lane < 6) ? 2 : tb.dof_parent[lane];
+        if (par >= 0) cterm = cross_m(ld_sp(sX + par * 6), sq);
+    }
+    wave_sync();                                         // P has been read; the buffer is reused
+    ancestor_sums(cterm);
+    Sp a = {{0, 0, 0}, {-tb.g[0], -tb.g[1], -tb.g[2]}};
+    if (b < nb) a = a + ld_sp(sX + tb.last_dof[b] * 6);
+    wave_sync();                                         // ... and again, by sIb / sF below
+    if (b < nb) {
         M3 R;
         ld_m3(sW + b * 12, R);
         const V3 p = ld_v3(sW + b * 12 + 9);
@@ -239,30 +286,86 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
         st_sp(sF + b * 6, inertia_apply(in10, a) + cross_f(v, inertia_apply(in10, v)));
     }
     wave_sync();
-    // ---- E + F: lane = dof. Composite inertia and subtree force of the dof's body = sums over its depth-first range.
-    if (valid && lane < nv) {
-        const int d = lane, bd = tb.dof_body[d];
-        double ic[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        Sp fc = {{0, 0, 0}, {0, 0, 0}};
-        for (int c = bd; c < tb.subtree_end[bd]; ++c) {
+    DY_TR(4);
+    // ---- E: composite inertia / subtree force of every body, in place. The bodies are listed depth first, so a subtree is the
+    //         contiguous range [b, subtree_end[b]): a suffix sum over the body index (lane = body, ceil(log2 nb) doubling rounds
+    //         through LDS) gives T[b] = sum of bodies >= b, and the subtree's sum is T[b] - T[subtree_end[b]]. (Round 3 let every
+    //         dof lane add up its body's range itself -- 21 bodies x 16 doubles for the root's dofs. The subtraction costs a few
+    //         ulps of the WHOLE tree's inertia about the world origin, which is what every entry of M is formed from anyway.)
+    {
+        double t16[16];
+        if (b < nb) {
 #pragma unroll
-            for (int i = 0; i < 10; ++i) ic[i] += sIb[c * 10 + i];
-            fc = fc + ld_sp(sF + c * 6);
+            for (int i = 0; i < 10; ++i) t16[i] = sIb[b * 10 + i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t16[10 + i] = sF[b * 6 + i];
         }
-        const Sp S = ld_sp(sS + d * 6);
-        if (qM_out) {
-            const Sp F = inertia_apply(ic, S);
-            double *out = qM_out + tb.dof_madr[d];
-            int i = d, k = 0;
-            while (i >= 0) {
-                double v = sdot(ld_sp(sS + i * 6), F);
-                if (i == d && d >= 6) v += tb.armature;
-                out[k++] = v;
-                i = tb.dof_parent[i];
+        for (int step = 1; step < nb; step <<= 1) {
+            const bool has = b < nb && b + step < nb;
+            double up[16];
+            if (has) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) up[i] = sIb[(b + step) * 10 + i];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) up[10 + i] = sF[(b + step) * 6 + i];
             }
+            wave_sync();
+            if (has) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t16[i] += up[i];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) sIb[b * 10 + i] = t16[i];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) sF[b * 6 + i] = t16[10 + i];
+            }
+            wave_sync();
         }
-        if (bias_out) bias_out[d] = sdot(S, fc);
+        const int end = b < nb ? tb.subtree_end[b] : nb;
+        double sub[16];
+        if (end < nb) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) sub[i] = sIb[end * 10 + i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) sub[10 + i] = sF[end * 6 + i];
+        }
+        wave_sync();
+        if (end < nb) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) sIb[b * 10 + i] = t16[i] - sub[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) sF[b * 6 + i] = t16[10 + i] - sub[10 + i];
+        }
+        wave_sync();
     }
+    DY_TR(6);
+    // ---- F: lane = dof: F_d = Ic(body of d) S_d, bias entry; then lane = ENTRY of the sparse row: M[d][i] = S_i . F_d for the 910
+    //         (dof, ancestor) pairs, 15 independent products per lane (round 3: every dof lane walked its own chain, up to 28
+    //         dependent steps of two LDS round trips each)
+    Sp Fd = {{0, 0, 0}, {0, 0, 0}};
+    if (lane < nv) {
+        const int d = lane, bd = tb.dof_body[d];
+        double ic[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) ic[i] = sIb[bd * 10 + i];
+        const Sp fc = ld_sp(sF + bd * 6);
+        const Sp S = ld_sp(sS + d * 6);
+        Fd = inertia_apply(ic, S);
+        if (valid && bias_out) bias_out[d] = sdot(S, fc);
+    }
+    wave_sync();                                         // the composites have been read: their place takes F
+    if (lane < nv) st_sp(sX + lane * 6, Fd);
+    wave_sync();
+    if (valid && qM_out) {
+#pragma unroll 4
+        for (int e = lane; e < tb.nM; e += 64) {
+            const int d = tb.ent_row[e], i = tb.ent_col[e];
+            double v = sdot(ld_sp(sS + i * 6), ld_sp(sX + d * 6));
+            if (i == d && d >= 6) v += tb.armature;
+            qM_out[e] = v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    DY_TR(5);
 }
 
 }  // namespace egp_dyn

@@ -94,8 +94,6 @@ def test_engine_steps_through_the_plugin(plugin, skel):
             eng.wait(0)
         torch.cuda.synchronize()
         out.append((eng.qpos.cpu().numpy().copy(), eng.qvel.cpu().numpy().copy(), eng.ee_wpos.cpu().numpy().copy(), eng.head_z.copy()))
-        if kind == "mujoco":
-            assert eng.inertia_uploads() > 0 if hasattr(eng, "inertia_uploads") else True
         eng.close(); ph.close(); ctx.close()
     for a, b, what in zip(out[0], out[1], ("qpos", "qvel", "ee_wpos", "head_z")):
         np.testing.assert_array_equal(a, b, err_msg=what)
