@@ -180,7 +180,7 @@ def k1_roofline(tim, envs_per_group, eng, every):
         pm = json.load(open(os.path.join(REPO, "profiles", "pmc_k1_traffic.json")))
         per = pm.get("hbm_bytes_per_stepped_env_substep") or pm["hbm_bytes_per_env_substep"]
         traffic = per * stepped_per_launch * sub_per_launch
-        traffic_src = "NOT measured in this run: committed profile, " + pm["source"] + "; " + pm["correction"]
+        traffic_src = ("NOT measured in this run: committed profile taken at commit %s, " % pm.get("commit", "?")) + pm["source"] + "; " + pm["correction"]
     except Exception:
         pass
     return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
@@ -435,6 +435,22 @@ def main():
             # the reference's loop condition applied to all slots together (no new episode once the batch is there) against the
             # per-slot quota of the default: what the rollout's latency-bound tail costs, and what it buys in batch size
             legs["step_budget_global"] = run_leg(mk32, args.leg_steps, 1, min_batch, ev, {"EGP_STEP_BUDGET": "global"})
+            # more env slots on the one GPU, same physics, the batch scaled with the slots (each slot keeps its 48-step quota): how far
+            # the fixed latencies of a tick amortise -- the basis of the weak-scaling claim (1 024 slots = the headline; the resident
+            # K1 serves up to 2 048 slots, beyond that the engine launches per substep)
+            sweep = {}
+            for n_slots in (2048, 4096):
+                mkn = lambda n_slots=n_slots: Trainer(cfg_cls(args.cfg, create_dirs=False), dev, torch.float32, num_envs=n_slots,
+                                                      num_threads=n_threads, num_groups=args.groups)
+                r = run_leg(mkn, max(1, args.leg_steps - 1), 1, min_batch * n_slots // args.envs, ev)
+                sweep[str(n_slots)] = {k: r.get(k) for k in ("env_steps_per_s", "rollout_only_env_steps_per_s", "t_sample_s", "t_update_s", "steps",
+                                                            "env_steps_per_iteration", "ticks", "substeps_per_launch", "error") if k in r}
+            legs["envs_per_gpu_sweep"] = {"slots_%s" % k: (v.get("env_steps_per_s") if "error" not in v else v["error"]) for k, v in sweep.items()}
+            for k, v in sweep.items():
+                legs["envs_per_gpu_sweep"]["slots_%s_rollout_only" % k] = v.get("rollout_only_env_steps_per_s")
+                legs["envs_per_gpu_sweep"]["slots_%s_ms_sample_update" % k] = (None if "error" in v else
+                    [round(1e3 * v["t_sample_s"] / v["steps"], 1), round(1e3 * v["t_update_s"] / v["steps"], 1)])
+                legs["envs_per_gpu_sweep"]["slots_%s_substeps_per_launch" % k] = v.get("substeps_per_launch")
             # BASELINE config 4: the state regressor's optimisation step (ResNet-18 encoder in bf16 on the matrix cores)
             try:
                 from egopose_amd.bench_support import statereg_config4
@@ -442,6 +458,7 @@ def main():
             except Exception as e:
                 legs["statereg_config4"] = {"error": repr(e)[:300]}
             res["legs"] = {k: {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items()} for k, v in legs.items()}
+            res["legs"]["envs_per_gpu_sweep"]["slots_%d" % args.envs] = res["value"]
             res["dropin_env_steps_per_s"] = legs["dropin_float64_driver"].get("env_steps_per_s")
         if not args.no_cpu_baseline:
             # BASELINE config 1 / B1: 2 sampling workers (+ the CPU update on a bounded part of their sample); B2: as many

@@ -54,7 +54,7 @@ if k1:
          "fetch_kib_per_launch": k1[2], "write_kib_per_launch": k1[3], "envs_per_launch": envs, "substeps_per_launch": 15,
          "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads -> bytes = (2*FETCH + WRITE) * 1024; the counters also see the state rows / torques in pinned host memory (zero-copy) and the go-word polls",
          "hbm_bytes_per_env_substep": (2 * k1[2] + k1[3]) * 1024 / (envs * 15),
-         "launches": k1[1], "env_steps_of_profiled_run": env_steps,
+         "launches": k1[1], "env_steps_of_profiled_run": env_steps, "commit": "${ROUND_COMMIT:-unknown}",
          "hbm_bytes_per_stepped_env_substep": (None if not env_steps else (2 * k1[2] + k1[3]) * 1024 * k1[1] / (env_steps * 15))}
     json.dump(d, open(OUT + "/pmc_k1_traffic.json", "w"), indent=1)
 print("\n".join(rows))

@@ -1,0 +1,41 @@
+#!/bin/bash
+# Round-4 profile set (run on the GPU box through gpurun): everything under gpurun_out/profiles_round4/, to be copied to profiles/r04_*.
+# ROUND_COMMIT=<git rev-parse --short HEAD of the tree that was sent> is stamped into every file's header / meta.
+#   r04_meta.json                                                                     commit, date, what ran
+#   r04_bench_n1_kernel_stats.csv / _kernel_classes.txt / _line_under_rocprof.json   rocprofv3 --kernel-trace --stats over bench.py (headline only)
+#   r04_pmc_bench_n1_fetch_write.csv, pmc_k1_traffic.json                            FETCH_SIZE / WRITE_SIZE passes over bench.py --steps 1
+#   r04_update_mfma_util.csv                                                          MfmaUtil / VALUBusy of the update's kernels and the policy step
+#   r04_microbench.jsonl                                                              K1-K6 / K8 with HBM-resident inputs (HIP events)
+#   r04_pmc_microbench_{65536,1024}_fetch_write.csv                                   FETCH_SIZE / WRITE_SIZE of the same kernels
+#   r04_pmc_{k1_grid58,k2_reward,k5_gae,k8_dynamics}_65536.txt                        VALUBusy / occupancy / SALUBusy of K1, K2, K5, K8
+#   r04_statereg_mfma_util.csv, r04_statereg_kernel_stats.csv                         config 4 (256 x 224 x 224, bf16 encoder)
+#   r04_phase_profile.txt                                                             one rollout and one update separately (torch profiler)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_round4
+rm -rf $OUT; mkdir -p $OUT
+C=${ROUND_COMMIT:-unknown}
+echo "{\"commit\": \"$C\", \"date\": \"$(date -u +%FT%TZ)\", \"script\": \"tools/profile_round4.sh\"}" > $OUT/r04_meta.json
+ROUND_TAG=r04 ROUND_COMMIT=$C bash tools/profile_round.sh > $OUT/profile_round.log 2>&1
+P=$GRAFT_REPO_ROOT/gpurun_out/profiles_round
+stamp() { { echo "# commit $C (tools/profile_round4.sh)"; cat "$1"; } > "$2"; }
+stamp $P/bench_kernel_stats.csv $OUT/r04_bench_n1_kernel_stats.csv
+cp $P/bench_line_under_rocprof.json $OUT/r04_bench_n1_line_under_rocprof.json
+stamp $P/pmc_bench_fetch_write.csv $OUT/r04_pmc_bench_n1_fetch_write.csv
+cp $P/pmc_k1_traffic.json $OUT/pmc_k1_traffic.json
+stamp $P/update_mfma_util.csv $OUT/r04_update_mfma_util.csv
+{ echo "# commit $C"; python tools/classify_kernel_stats.py $P/bench_kernel_stats.csv 5; } > $OUT/r04_bench_n1_kernel_classes.txt 2>&1
+python tools/microbench.py 1024 8192 65536 > $OUT/r04_microbench.jsonl 2> $OUT/microbench.err
+for n in 65536 1024; do
+  { echo "# commit $C"; bash tools/pmc_k1.sh $n; } > $OUT/r04_pmc_microbench_${n}_fetch_write.csv 2> $OUT/pmc_k1_$n.err
+done
+for kv in k1_grid58:k_pd_torque_grid58 k2_reward:k_reward_quat_v3 k5_gae:k_gae k8_dynamics:k_dynamics; do
+  tag=${kv%%:*}; kern=${kv##*:}
+  { echo "# commit $C  kernel $kern at 65 536 envs (tools/pmc_kernel.sh)"; bash tools/pmc_kernel.sh $kern 65536 VALUBusy MeanOccupancyPerCU SALUBusy FetchSize WriteSize; } > $OUT/r04_pmc_${tag}_65536.txt 2>&1
+done
+bash tools/prof_statereg.sh > $OUT/prof_statereg.log 2>&1
+stamp $GRAFT_REPO_ROOT/gpurun_out/prof_statereg/mfma_util.csv $OUT/r04_statereg_mfma_util.csv
+stamp $GRAFT_REPO_ROOT/gpurun_out/prof_statereg/kernel_stats.csv $OUT/r04_statereg_kernel_stats.csv
+tail -3 $GRAFT_REPO_ROOT/gpurun_out/prof_statereg/bench.log > $OUT/r04_statereg_bench_tail.txt
+python tools/phase_profile.py --out $OUT/r04_phase_profile.txt > $OUT/phase_profile.log 2>&1
+sed -i "1i # commit $C" $OUT/r04_phase_profile.txt
+ls -la $OUT
