@@ -439,18 +439,18 @@ def main():
             # the fixed latencies of a tick amortise -- the basis of the weak-scaling claim (1 024 slots = the headline; the resident
             # K1 serves up to 2 048 slots, beyond that the engine launches per substep)
             sweep = {}
-            for n_slots in (2048, 4096):
-                mkn = lambda n_slots=n_slots: Trainer(cfg_cls(args.cfg, create_dirs=False), dev, torch.float32, num_envs=n_slots,
-                                                      num_threads=n_threads, num_groups=args.groups)
+            for n_slots, n_groups in ((512, args.groups), (2048, args.groups), (2048, 2 * args.groups), (4096, 2 * args.groups)):
+                mkn = lambda n_slots=n_slots, n_groups=n_groups: Trainer(cfg_cls(args.cfg, create_dirs=False), dev, torch.float32, num_envs=n_slots,
+                                                                         num_threads=n_threads, num_groups=n_groups)
                 r = run_leg(mkn, max(1, args.leg_steps - 1), 1, min_batch * n_slots // args.envs, ev)
-                sweep[str(n_slots)] = {k: r.get(k) for k in ("env_steps_per_s", "rollout_only_env_steps_per_s", "t_sample_s", "t_update_s", "steps",
-                                                            "env_steps_per_iteration", "ticks", "substeps_per_launch", "error") if k in r}
-            legs["envs_per_gpu_sweep"] = {"slots_%s" % k: (v.get("env_steps_per_s") if "error" not in v else v["error"]) for k, v in sweep.items()}
-            for k, v in sweep.items():
-                legs["envs_per_gpu_sweep"]["slots_%s_rollout_only" % k] = v.get("rollout_only_env_steps_per_s")
-                legs["envs_per_gpu_sweep"]["slots_%s_ms_sample_update" % k] = (None if "error" in v else
-                    [round(1e3 * v["t_sample_s"] / v["steps"], 1), round(1e3 * v["t_update_s"] / v["steps"], 1)])
-                legs["envs_per_gpu_sweep"]["slots_%s_substeps_per_launch" % k] = v.get("substeps_per_launch")
+                key = "slots_%d_groups_%d" % (n_slots, n_groups)
+                if "error" in r:
+                    sweep[key] = {"error": r["error"]}
+                else:
+                    sweep[key] = {"env_steps_per_s": r["env_steps_per_s"], "rollout_only_env_steps_per_s": r["rollout_only_env_steps_per_s"],
+                                  "ms_sample_update": [round(1e3 * r["t_sample_s"] / r["steps"], 1), round(1e3 * r["t_update_s"] / r["steps"], 1)],
+                                  "env_steps_per_iteration": r["env_steps_per_iteration"], "substeps_per_launch": r["substeps_per_launch"]}
+            legs["envs_per_gpu_sweep"] = {k: json.dumps(v) for k, v in sweep.items()}
             # BASELINE config 4: the state regressor's optimisation step (ResNet-18 encoder in bf16 on the matrix cores)
             try:
                 from egopose_amd.bench_support import statereg_config4
@@ -458,7 +458,8 @@ def main():
             except Exception as e:
                 legs["statereg_config4"] = {"error": repr(e)[:300]}
             res["legs"] = {k: {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items()} for k, v in legs.items()}
-            res["legs"]["envs_per_gpu_sweep"]["slots_%d" % args.envs] = res["value"]
+            res["legs"]["envs_per_gpu_sweep"] = {k: json.loads(v) for k, v in res["legs"]["envs_per_gpu_sweep"].items()}
+            res["legs"]["envs_per_gpu_sweep"]["slots_%d_groups_%d" % (args.envs, args.groups)] = {"env_steps_per_s": res["value"], "headline": True}
             res["dropin_env_steps_per_s"] = legs["dropin_float64_driver"].get("env_steps_per_s")
         if not args.no_cpu_baseline:
             # BASELINE config 1 / B1: 2 sampling workers (+ the CPU update on a bounded part of their sample); B2: as many
