@@ -439,7 +439,7 @@ class AgentPPO(AgentPG):
         for epoch in range(self.opt_num_epochs):
             # critic and actor have disjoint parameters: both backward passes run before the single gradient
             # exchange; the value step precedes the policy step as in the reference. (Running the two passes on two
-            # HIP streams was faster and hung the GPU intermittently -- concurrent library GEMMs)
+            # HIP streams was faster and hung the GPU intermittently -- concurrent library GEMMs, docs/DESIGN_TRAIL.md section 2.)
             if first_pass is not None and epoch == 0:
                 v_loss = (pred0 - returns).pow(2).sum() / n_val
                 adv = advantages if ind is None else advantages[ind]

@@ -113,7 +113,7 @@ def kernel_microbench(sizes=(1024, 65536), device_index=0, variants=False, iters
     return out
 
 
-def statereg_config4(device_index=0, frames=256, steps=8, warmup=3, lr=1e-4):
+def statereg_config4(device_index=0, frames=256, steps=8, warmup=5, lr=1e-4):
     """BASELINE config 4 ("state_reg cross_01: ResNet-18 VideoRegNet bf16 on MFMA, batch 256, 1xMI355X") as a timed leg:
     optimisation steps of VideoRegNet (ResNet-18 -> bi-LSTM -> MLP[300,200] -> 115, models/video_reg_net.py:10-59,
     ego_pose/state_reg.py:60-95, config/statereg/cross_01.yml: fr_num 120-frame clips are the reference's unit; 256
@@ -143,16 +143,17 @@ def statereg_config4(device_index=0, frames=256, steps=8, warmup=3, lr=1e-4):
     for _ in range(warmup):
         l = step()
         first = l if first is None else first
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     torch.cuda.synchronize(dev)
-    a.record()
-    for _ in range(steps):
+    evs[0].record()
+    for i in range(steps):
         l = step()
-    b.record()
+        evs[i + 1].record()
     torch.cuda.synchronize(dev)
-    ms = a.elapsed_time(b) / steps
+    per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    ms = evs[0].elapsed_time(evs[steps]) / steps           # (the quoted rate: all timed steps; the per-step list shows what a cold box does to it)
     n_par = sum(p.numel() for p in net.parameters())
     return {"frames_per_s": frames / (ms * 1e-3), "ms_per_step": ms, "frames_per_step": frames, "frame_shape": [3, 224, 224], "steps": steps,
-            "warmup": warmup, "dtype": "bf16 ResNet-18 encoder on MFMA (float32 master weights) + f32 bi-LSTM / MLP",
+            "ms_per_step_all": [round(t, 2) for t in per_step], "warmup": warmup, "dtype": "bf16 ResNet-18 encoder on MFMA (float32 master weights) + f32 bi-LSTM / MLP",
             "parameters": int(n_par), "loss_first": float(first), "loss_last": float(l), "data": "synthetic frames resident in HBM",
             "config": "state_reg: VideoRegNet(out 115, v_hdim 128, cnn_fdim 128, mlp [300, 200]), Adam lr %g, one clip of %d frames per step" % (lr, frames)}

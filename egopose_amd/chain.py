@@ -14,7 +14,7 @@ tile): a 128-row tile takes 108 us where its 1 914 MFMAs alone take ~36 us (19 n
 chip sustains); 48 stage boundaries cost ~0.32 us each (barrier, B-fragment conversion, first LDS round trip), the epilogues'
 [feature][row] stores 18 us, the input gather and the LDS-DMA weight stream another ~28 us of stalls. The register chaining
 needs 440 VGPRs, i.e. ONE wave per SIMD, so nothing covers those stalls -- the layer-per-launch kernels run two waves per SIMD
-at 48 % matrix-pipe utilisation against this kernel's 26 %. What would have to change is in DESIGN.md (section 4).
+at 48 % matrix-pipe utilisation against this kernel's 26 %. What would have to change is in DESIGN.md (section 0, item 1).
 """
 from __future__ import annotations
 

@@ -10,6 +10,12 @@
 namespace egp {
 
 void set_error(const char *fmt, ...);
+// Dynamic LDS to request for one of the rollout tick's small launches (filter statistics / apply, reward, policy step), given what
+// the kernel itself needs. EGP_TICK_LDS_PAD=<bytes> adds a pad: a resident K1 workgroup holds 37.7 kB of a CU's 160 kB, so a
+// launch that asks for more than 122 kB cannot be placed beside one and runs on the CUs the other group's K1 does not occupy --
+// CU partitioning by resource request (CU masks cannot separate them: docs/DESIGN_TRAIL.md). The first call per kernel raises its
+// dynamic-LDS limit.
+size_t tick_lds(const void *kernel, size_t own_dynamic, size_t own_static);
 
 #define EGP_HIP_CHECK(expr)                                                                  \
     do {                                                                                     \

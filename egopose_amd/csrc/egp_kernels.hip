@@ -36,6 +36,25 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+size_t tick_lds(const void *kernel, size_t own_dynamic, size_t own_static) {
+    static const size_t pad = [] { const char *e = getenv("EGP_TICK_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+    if (pad == 0) return own_dynamic;
+    size_t want = own_dynamic + pad;
+    if (want + own_static > 160 * 1024) want = 160 * 1024 - own_static;
+    static const void *done[32];
+    static int n_done = 0;
+    bool seen = false;
+    for (int i = 0; i < n_done; ++i) seen = seen || done[i] == kernel;
+    if (!seen) {
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - own_static)) != hipSuccess) {
+            (void)hipGetLastError();
+            return own_dynamic;
+        }
+        if (n_done < 32) done[n_done++] = kernel;
+    }
+    return want;
+}
+
 // ============================================================================================ K4
 // get_body_quat (ego_pose/envs/humanoid_v1.py:113-125)
 template <typename T>
@@ -1147,7 +1166,7 @@ __device__ __forceinline__ void gae_coeffs(const T *r, const T *mk, const T *v, 
 // would touch 64 different cache lines per wave instruction. The block's samples therefore pass through LDS: coalesced
 // loads form (delta_i, c_i) straight away -- element e of the block at s[e + e / GAE_CHUNK], one pad word per chunk so that the
 // lanes of a wave, GAE_CHUNK + 1 words apart, spread over the banks -- and the replay's results leave the same way (round 3: K5
-// at 1.6 M samples 142 -> see DESIGN section 4).
+// at 1.6 M samples 142 -> see docs/DESIGN_TRAIL.md section 4).
 constexpr int GAE_BLOCK_ELEMS = 256 * GAE_CHUNK;
 constexpr int GAE_LDS_DOUBLES = 2 * (GAE_BLOCK_ELEMS + GAE_BLOCK_ELEMS / GAE_CHUNK);
 __device__ __forceinline__ int gae_pad(int e) { return e + e / GAE_CHUNK; }      // one pad word per chunk: lanes GAE_CHUNK + 1 words apart
@@ -1749,7 +1768,7 @@ static int launch_reward(egp_ctx *ctx, const T *expert_rows, const T *cur_qpos, 
             ctx->dm, ctx->rw, expert_rows, cur_qpos, prev_qpos, ee_wpos, t, frame, endf, active, (T)end_reward, n, reward, cinfo);
     } else {
         const int tile = reward_tile_envs(ctx->dm.nbody, 1);
-        k_reward_quat_v3<T, 1><<<dim3((n + tile - 1) / tile), dim3(256), 0, (hipStream_t)stream>>>(
+        k_reward_quat_v3<T, 1><<<dim3((n + tile - 1) / tile), dim3(256), tick_lds((const void *)&k_reward_quat_v3<T, 1>, 0, 10 * 1024), (hipStream_t)stream>>>(
             ctx->dm, ctx->rw, expert_rows, cur_qpos, prev_qpos, ee_wpos, t, frame, endf, active, (T)end_reward, n, reward, cinfo);
     }
     return after_launch("k_reward_quat_v3");
@@ -1791,7 +1810,7 @@ static int launch_zfilter_src(const ZfSrc<T> &src, const int *active, int n, int
     int n_records = 0;
     if (update) {
         // (1 024 threads = one round of loads per thread: in the rollout 16.9 us per call against 20.1 with 512 and 33.6 with 256)
-        k_zf_partial<T><<<dim3(nt), dim3(1024), 0, (hipStream_t)stream>>>(src, active, n, dim, rpt, (double *)ws);
+        k_zf_partial<T><<<dim3(nt), dim3(1024), tick_lds((const void *)&k_zf_partial<T>, 0, 17 * 1024), (hipStream_t)stream>>>(src, active, n, dim, rpt, (double *)ws);
         if (direct) {
             records = (const double *)ws; n_records = nt;
         } else if (two_level) {
@@ -1805,7 +1824,7 @@ static int launch_zfilter_src(const ZfSrc<T> &src, const int *active, int n, int
         if (rc != EGP_OK) return rc;
     }
     const int rows_per_block = direct ? 8 : (n <= 8192 ? 2 : 16);     // small batches: enough blocks to cover the latency
-    k_zf_apply<T><<<dim3((n + rows_per_block - 1) / rows_per_block), dim3(128), 2 * dim * sizeof(double), (hipStream_t)stream>>>(
+    k_zf_apply<T><<<dim3((n + rows_per_block - 1) / rows_per_block), dim3(128), tick_lds((const void *)&k_zf_apply<T>, 2 * dim * sizeof(double), 1024), (hipStream_t)stream>>>(
         src, n, dim, rows_per_block, update && !records ? st_out : st_in, clip, y, y2, write_mask, identity, records, n_records, st_out);
     return after_launch("k_zf_apply");
 }
@@ -1985,7 +2004,7 @@ int egp_obs_zfilter_stats_f64(egp_ctx *ctx, const double *qpos, const double *qv
     ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm), phase_t};
     int rpt, nt;
     zf_tiling(n, &rpt, &nt);
-    k_zf_partial<double><<<dim3(nt), dim3(1024), 0, (hipStream_t)stream>>>(src, active, n, dim, rpt, (double *)ws);
+    k_zf_partial<double><<<dim3(nt), dim3(1024), tick_lds((const void *)&k_zf_partial<double>, 0, 17 * 1024), (hipStream_t)stream>>>(src, active, n, dim, rpt, (double *)ws);
     return after_launch("k_zf_partial");
 }
 int egp_obs_zfilter_apply_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const int32_t *phase_t, int32_t n, const double *st_in, double *st_out,
@@ -1997,7 +2016,7 @@ int egp_obs_zfilter_apply_f64(egp_ctx *ctx, const double *qpos, const double *qv
     ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm), phase_t};
     int rpt, nt;
     zf_tiling(n, &rpt, &nt);
-    k_zf_apply<double><<<dim3((n + 7) / 8), dim3(128), 2 * dim * sizeof(double), (hipStream_t)stream>>>(
+    k_zf_apply<double><<<dim3((n + 7) / 8), dim3(128), tick_lds((const void *)&k_zf_apply<double>, 2 * dim * sizeof(double), 1024), (hipStream_t)stream>>>(
         src, n, dim, 8, st_in, clip, y, y2, nullptr, 0, (const double *)ws, nt, st_out);
     return after_launch("k_zf_apply");
 }

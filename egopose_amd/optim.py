@@ -25,10 +25,13 @@ _WS = {}
 
 
 def _zeroed_workspace(key, nbytes, device):
-    buf = _WS.get((key, str(device)))
+    """Partial-sum scratch of the loss kernels, one per (device, stream): two updates issued on different streams of one device
+    must not share it between k_ppo_loss and k_ppo_loss_final."""
+    k = (key, str(device), int(torch.cuda.current_stream(device).cuda_stream))
+    buf = _WS.get(k)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)        # (the loss kernel's arrival counter must start at zero)
-        _WS[(key, str(device))] = buf
+        buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        _WS[k] = buf
     return buf
 
 
@@ -151,7 +154,9 @@ class FlatUpdater:
         self.S = mk(torch.float32) if self.shadowed else None    # float32 compute copies of float64 masters
         self.steps = [0] * len(self.optimizers)
         self.time_collectives, self.collective_events = False, []
-        self.step_tensors = [torch.tensor(0.0) for _ in self.optimizers]       # what the optimizers' state shows as `step` (one per optimizer)
+        # what the optimizers' state shows as `step`: a tensor of its OWN per parameter (torch's optimizer.step() increments every
+        # state["step"] it finds -- one shared tensor per optimizer would be incremented once per parameter)
+        self.step_tensors = [torch.tensor(0.0) for _ in self.entries]
         self._views = lambda flat: [flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, masters)]
         self.p_views, self.m_views, self.v_views, self.g_views = (self._views(f) for f in (self.P, self.M, self.V, self.G))
         self.s_views = self._views(self.S) if self.shadowed else None
@@ -189,8 +194,8 @@ class FlatUpdater:
 
     def _publish_state(self):
         for k, (oi, gi, p, _, _) in enumerate(self.entries):
-            self.step_tensors[oi].fill_(float(self.steps[oi]))
-            self.optimizers[oi].state[p] = {"step": self.step_tensors[oi], "exp_avg": self.m_views[k], "exp_avg_sq": self.v_views[k]}
+            self.step_tensors[k].fill_(float(self.steps[oi]))
+            self.optimizers[oi].state[p] = {"step": self.step_tensors[k], "exp_avg": self.m_views[k], "exp_avg_sq": self.v_views[k]}
 
     # ---------------------------------------------------------------------------------------------- one epoch
     def zero_grad(self):
@@ -278,8 +283,9 @@ class FlatUpdater:
         else:
             rc = self.lib.egp_adam_step_f64g(n, segs, ptr(self.G), ptr(self.P), ptr(self.M), ptr(self.V), ptr(self.ws), ptr(self.norms), st)
         L.check(rc, "egp_adam_step")
-        for oi in which:
-            self.step_tensors[oi].fill_(float(self.steps[oi]))
+        for k, (oi, _, _, _, _) in enumerate(self.entries):
+            if oi in which:
+                self.step_tensors[k].fill_(float(self.steps[oi]))
 
 
 class _NotEligible(Exception):

@@ -11,7 +11,7 @@ Semantics kept from the reference: per-worker step quota ``floor(min_batch_size 
 episode boundaries (episodes are never truncated), ``mask = 0`` on the last step of an episode,
 ``exp = 1 - mean_action``, ``v_meta = (expert_ind, start_ind)``, reward computed on the state after the step,
 worker-ordered (here: slot-ordered), episode-contiguous batches, LoggerRL totals.
-Deviation (documented in DESIGN.md): the observation filter is updated with all slots' samples by block
+Deviation (documented in DESIGN.md section 5): the observation filter is updated with all slots' samples by block
 merges instead of sample-by-sample inside worker 0 only.
 """
 from __future__ import annotations

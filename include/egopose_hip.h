@@ -130,7 +130,7 @@ int egp_upload_experts(egp_ctx *ctx, const egp_expert_table *tbl);
  *   EGP_QUAT_TRANSFORM_VEC_HEADING  v [n][3]  q [n][4]  R(heading_q(q))^T v [n][3]
  *   EGP_QUAT_ROTATION               q [n][4]  -         axis[3] | angle [n][4]   (identity branch 1 - w < 1e-8; no clamp, no wrap)
  *   EGP_QUAT_DIFF_HALF_ANGLE        q1 [n][4] q0 [n][4] acos(clip(w(q1 * q0^-1))) [n]   (= multi_quat_norm(multi_quat_diff))
- * The float32 variant evaluates the two angle ops through atan2(|xyz|, w) (DESIGN.md, deviation iii). */
+ * The float32 variant evaluates the two angle ops through atan2(|xyz|, w) (DESIGN.md section 5, deviation iii). */
 enum {
     EGP_QUAT_MUL = 0, EGP_QUAT_INV = 1, EGP_QUAT_FROM_EULER_SXYZ = 2, EGP_QUAT_HEADING_Q = 3, EGP_QUAT_DE_HEADING = 4,
     EGP_QUAT_TRANSFORM_VEC_ROOT = 5, EGP_QUAT_TRANSFORM_VEC_HEADING = 6, EGP_QUAT_ROTATION = 7, EGP_QUAT_DIFF_HALF_ANGLE = 8,
