@@ -48,7 +48,7 @@ def _time_launches(fn, iters=50, warm=5, warm_s=0.03):
     return a.elapsed_time(b) / iters * 1e-3
 
 
-def kernel_microbench(sizes=(1024, 65536), device_index=0, variants=False, iters=50):
+def kernel_microbench(sizes=(1024, 65536), device_index=0, variants=False, iters=50, only=None):
     """K1-K6 / K8 with inputs resident in HBM (HIP events on the launch stream, float64): per (kernel, n) the time per
     call, the ALGORITHMIC bytes (SURVEY.md 8d / DESIGN.md section 4), achieved GB/s and the fraction of the 8 TB/s HBM
     peak. These are the numbers an HBM roofline can bind; the in-rollout K1 launch waits for host physics instead.
@@ -99,6 +99,8 @@ def kernel_microbench(sizes=(1024, 65536), device_index=0, variants=False, iters
                 ("K8_dynamics", lambda: ctx.dynamics(qpos, qvel, want_xpos=True, qM_out=qM_dyn), (59 + 58 + 910 + 58 + 63) * W, 1),
             ]
             for name, fn, bytes_per_unit, units_per_env in cases:
+                if only and name not in only:          # (PMC passes profile one kernel at a time: tools/pmc_kernel.sh)
+                    continue
                 todo = [(0, "_tree58")] + ([(3, "_tree58_rows"), (2, "_reg58"), (1, "_lds")] if variants else []) if name == "K1_pd_torque" else [(None, "")]
                 for variant, sfx in todo:
                     if variant is not None:

@@ -86,13 +86,15 @@ struct PolStage {
 };
 
 // request the blocks of quads kq .. kq + PF - 1 (clamped into the wave's range) of column groups g0 .. g0 + ng - 1 (clamped)
+// (a pass over ONE column group -- the output layer -- uses the POL_GC slots of a stage for POL_GC different quads: PF x POL_GC quads
+//  in flight instead of PF; with PF of them the 50 quads of the 200 -> 52 layer were a chain of L2 round trips, 1.8 of the step's 15 us)
 template <int PF>
 __device__ __forceinline__ void pol_preload(PolStage<PF> &st, const float *__restrict__ wl, int nkq, int g0, int ng, int kq0, int kq1, int lane) {
 #pragma unroll
     for (int s = 0; s < PF; ++s) {
-        const int k = min(kq0 + s, kq1 - 1);
 #pragma unroll
         for (int g = 0; g < POL_GC; ++g) {
+            const int k = min(ng == 1 ? kq0 + s * POL_GC + g : kq0 + s, kq1 - 1);
             const int gg = g0 + min(g, ng - 1);
             st.w[s][g] = *reinterpret_cast<const f32x4 *>(wl + (((long)gg * nkq + k) * 64 + lane) * 4);
         }
@@ -108,6 +110,33 @@ __device__ __forceinline__ void pol_pass(PolStage<PF> &st, const float *__restri
     const float *xr = x + (lane & 3) * xs;
     const float *wb = wl + (((long)g0 * nkq) * 64 + lane) * 4;
     const long gstride = (long)nkq * 256;
+    if constexpr (NG == 1) {                             // one column group: the stage's slots hold PF x POL_GC consecutive quads
+        constexpr int D = PF * POL_GC;
+        for (int kq = kq0; kq < kq1; kq += D) {
+#pragma unroll
+            for (int s = 0; s < PF; ++s)
+#pragma unroll
+                for (int g = 0; g < POL_GC; ++g) {
+                    const int k = kq + s * POL_GC + g;
+                    const bool live = k < kq1;
+                    const int kc = live ? k : kq1 - 1;
+                    f32x4 b[R / 4];
+#pragma unroll
+                    for (int h = 0; h < R / 4; ++h) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + 4 * h * xs + 4 * kc);
+                        b[h][0] = live ? v[0] : 0.0f; b[h][1] = live ? v[1] : 0.0f; b[h][2] = live ? v[2] : 0.0f; b[h][3] = live ? v[3] : 0.0f;
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int h = 0; h < R / 4; ++h)
+                            acc[0][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(st.w[s][g][kk], b[h][kk], acc[0][h], 0, 0, 0);
+                    const int kn = min(k + D, kq1 - 1);
+                    st.w[s][g] = *reinterpret_cast<const f32x4 *>(wb + (long)kn * 256);
+                }
+        }
+        return;
+    }
     for (int kq = kq0; kq < kq1; kq += PF) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) {

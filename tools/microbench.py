@@ -4,7 +4,7 @@ Prints one JSON line per (kernel, n): time per launch, algorithmic bytes (SURVEY
 achieved GB/s and fraction of the 8 TB/s HBM peak. (The measurement itself lives in
 egopose_amd/bench_support.py: bench.py reports the same table in its `kernels` block.)
 
-    python tools/microbench.py [n ...]        default: 1024 8192 65536
+    python tools/microbench.py [n ...] [--only K2_reward[,K8_dynamics...]] [--no-variants]       default sizes: 1024 8192 65536
 """
 import json
 import os
@@ -15,8 +15,16 @@ from egopose_amd.bench_support import kernel_microbench
 
 
 def main():
-    sizes = [int(s) for s in (sys.argv[1:] or ["1024", "8192", "65536"])]
-    for row in kernel_microbench(sizes, variants=True):
+    argv, only, variants = list(sys.argv[1:]), None, True
+    if "--only" in argv:
+        i = argv.index("--only")
+        only = set(argv[i + 1].split(","))
+        del argv[i:i + 2]
+    if "--no-variants" in argv:
+        argv.remove("--no-variants")
+        variants = False
+    sizes = [int(s) for s in (argv or ["1024", "8192", "65536"])]
+    for row in kernel_microbench(sizes, variants=variants, only=only):
         print(json.dumps(row))
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Derived counters of ONE kernel of the microbench: tools/pmc_kernel.sh <kernel-name substring> <n> <counter> [<counter> ...]
+# Derived counters of ONE kernel of the microbench: [ONLY=<microbench case, e.g. K2_reward>] tools/pmc_kernel.sh <kernel-name substring> <n> <counter> [<counter> ...]
 # (one rocprofv3 --pmc pass per counter group of <= 3; gpurun forbids mixing --pmc with trace domains other than kernel-trace)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 K=$1; N=$2; shift 2
@@ -8,7 +8,7 @@ rm -rf $OUT; mkdir -p $OUT
 i=0
 while [ $# -gt 0 ]; do
   grp="$1 ${2:-} ${3:-}"; shift; [ $# -gt 0 ] && shift; [ $# -gt 0 ] && shift
-  timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -o mb -- python tools/microbench.py $N > $OUT/p$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -o mb -- python tools/microbench.py $N ${ONLY:+--only $ONLY --no-variants} > $OUT/p$i.log 2>&1
   i=$((i+1))
 done
 python - <<PY

@@ -12,25 +12,31 @@
 #   r04_phase_profile.txt                                                             one rollout and one update separately (torch profiler)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_round4
-rm -rf $OUT; mkdir -p $OUT
 C=${ROUND_COMMIT:-unknown}
+stamp() { { echo "# commit $C (tools/profile_round4.sh)"; cat "$1"; } > "$2"; }
+if [ "${PART:-all}" = "2" ]; then      # PART=2: only the kernel PMC passes, config 4 and the phase profile (the bench passes ran in another call)
+  mkdir -p $OUT
+else
+rm -rf $OUT; mkdir -p $OUT
 echo "{\"commit\": \"$C\", \"date\": \"$(date -u +%FT%TZ)\", \"script\": \"tools/profile_round4.sh\"}" > $OUT/r04_meta.json
 ROUND_TAG=r04 ROUND_COMMIT=$C bash tools/profile_round.sh > $OUT/profile_round.log 2>&1
 P=$GRAFT_REPO_ROOT/gpurun_out/profiles_round
-stamp() { { echo "# commit $C (tools/profile_round4.sh)"; cat "$1"; } > "$2"; }
 stamp $P/bench_kernel_stats.csv $OUT/r04_bench_n1_kernel_stats.csv
 cp $P/bench_line_under_rocprof.json $OUT/r04_bench_n1_line_under_rocprof.json
 stamp $P/pmc_bench_fetch_write.csv $OUT/r04_pmc_bench_n1_fetch_write.csv
 cp $P/pmc_k1_traffic.json $OUT/pmc_k1_traffic.json
 stamp $P/update_mfma_util.csv $OUT/r04_update_mfma_util.csv
 { echo "# commit $C"; python tools/classify_kernel_stats.py $P/bench_kernel_stats.csv 5; } > $OUT/r04_bench_n1_kernel_classes.txt 2>&1
+if [ "${QUICK:-0}" = "1" ]; then ls -la $OUT; exit 0; fi      # QUICK=1: only the bench passes above (kernel stats, FETCH / WRITE, MfmaUtil)
 python tools/microbench.py 1024 8192 65536 > $OUT/r04_microbench.jsonl 2> $OUT/microbench.err
+fi
 for n in 65536 1024; do
+  [ "${PART:-all}" = "2" ] && break
   { echo "# commit $C"; bash tools/pmc_k1.sh $n; } > $OUT/r04_pmc_microbench_${n}_fetch_write.csv 2> $OUT/pmc_k1_$n.err
 done
-for kv in k1_grid58:k_pd_torque_grid58 k2_reward:k_reward_quat_v3 k5_gae:k_gae k8_dynamics:k_dynamics; do
-  tag=${kv%%:*}; kern=${kv##*:}
-  { echo "# commit $C  kernel $kern at 65 536 envs (tools/pmc_kernel.sh)"; bash tools/pmc_kernel.sh $kern 65536 VALUBusy MeanOccupancyPerCU SALUBusy FetchSize WriteSize; } > $OUT/r04_pmc_${tag}_65536.txt 2>&1
+for kv in k1_grid58:k_pd_torque_grid58:K1_pd_torque k2_reward:k_reward_quat_v3:K2_reward k5_gae:k_gae:K5_gae k8_dynamics:k_dynamics:K8_dynamics; do
+  tag=${kv%%:*}; rest=${kv#*:}; kern=${rest%%:*}; only=${rest##*:}
+  { echo "# commit $C  kernel $kern at 65 536 envs (tools/pmc_kernel.sh, microbench case $only alone)"; ONLY=$only bash tools/pmc_kernel.sh $kern 65536 VALUBusy MeanOccupancyPerCU SALUBusy FetchSize WriteSize; } > $OUT/r04_pmc_${tag}_65536.txt 2>&1
 done
 bash tools/prof_statereg.sh > $OUT/prof_statereg.log 2>&1
 stamp $GRAFT_REPO_ROOT/gpurun_out/prof_statereg/mfma_util.csv $OUT/r04_statereg_mfma_util.csv
