@@ -211,6 +211,9 @@ SIGNATURES = {
     "egp_lstm_group_fwd_len_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_void_p), _i32, vp, vp, vp, vp, _i32, vp]),
     "egp_lstm_group_bwd_len_f32": (C.c_int, [C.POINTER(C.c_void_p), _i32, vp, vp, vp, _i32, _i32, _i32, _i32, _i32, vp, vp, vp, vp, _i32, vp]),
     "egp_upload_async": (C.c_int, [vp, vp, C.c_int64, vp]),
+    "egp_hostvis_alloc": (C.c_int, [C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
+    "egp_hostvis_free": (C.c_int, [vp]),
+    "egp_host_store_fence": (None, []),
     "egp_post_step_f64": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, _i32, vp, vp, _f64, vp, vp, vp, _f64, vp, vp, vp]),
     "egp_set_dynamics_model": (C.c_int, [vp, C.POINTER(DynamicsDesc)]),
     "egp_dynamics_f64": (C.c_int, [vp, vp, vp, _i32, vp, C.c_int64, vp, vp, vp]),

@@ -1265,6 +1265,34 @@ inline hipError_t follow_caller_stream(const egp_rollout_tick *d, hipStream_t s)
 }
 }  // namespace
 
+// Host-visible DEVICE memory (fine-grained HBM, written by the host through the PCIe BAR): see include/egopose_hip.h.
+int egp_hostvis_alloc(int32_t device, int64_t bytes, void **ptr) {
+    EGP_REQUIRE(ptr && bytes > 0, "bad host-visible allocation");
+    *ptr = nullptr;
+    int large_bar = 0;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large_bar) {
+        (void)hipGetLastError();
+        return EGP_E_STATE;           // not every byte of device memory is reachable from the host on this system
+    }
+    void *p = nullptr;
+    EGP_HIP_CHECK(hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained));
+    EGP_HIP_CHECK(hipMemset(p, 0, (size_t)bytes));
+    EGP_HIP_CHECK(hipDeviceSynchronize());
+    *ptr = p;
+    return EGP_OK;
+}
+int egp_hostvis_free(void *ptr) {
+    if (ptr) EGP_HIP_CHECK(hipFree(ptr));
+    return EGP_OK;
+}
+void egp_host_store_fence(void) {
+#if defined(__x86_64__)
+    _mm_sfence();
+#else
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+}
+
 int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, void *ready_event,
                          int32_t apply_pending, const double *zf_cur, double *zf_new) {
     EGP_REQUIRE(d && d->ctx && d->eng && (ready_event || d->group_streams), "NULL pointer");
@@ -1292,6 +1320,7 @@ int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, in
         fl[3 * nmax + i] = act;
         ti[i] = d->cur_t[e] < d->ctx_T - 1 ? d->cur_t[e] : d->ctx_T - 1;
     }
+    if (d->flags_upload == 0) egp_host_store_fence();     // the slab may be write-combining device memory (egp_hostvis_alloc)
     uint8_t *fbase = d->slab_dev + soff;
     int rc = EGP_OK;
     const size_t row = (size_t)k * N + a;

@@ -945,7 +945,9 @@ __global__ __launch_bounds__(256) void k_pose_features(DevModel m, const T *__re
 // into the thread's running statistics); the groups' results meet in LDS and group 0 merges them in row order. With
 // 1 024 threads and 64-row tiles every thread has ONE round of loads and a 512-env tick leaves 8 partials -- few
 // enough for k_zf_apply to merge them itself (one launch and its memory round trips less on the tick's critical path).
-template <typename T>
+// ROWS: the source is the drained state (src.x == nullptr) and takes ZfSrc's rows form; else src.at() per element
+// (two instantiations, two kernels: one function with both paths needs more than the 128 registers of a 1 024-thread workgroup)
+template <typename T, bool ROWS>
 __device__ __forceinline__ void zf_partial_body(const ZfSrc<T> &src, const int *__restrict__ active, int n, int dim,
                                                 int rows_per_tile, double *__restrict__ ws, int p) {
     __shared__ double s_mean[8][128], s_m2[8][128], s_cnt[8];
@@ -957,16 +959,45 @@ __device__ __forceinline__ void zf_partial_body(const ZfSrc<T> &src, const int *
     for (int cb = 0; cb < dim; cb += 128) {
         const int c = cb + lc;
         double cnt = 0.0, mean = 0.0, m2 = 0.0;
-        if (c < dim)
+        // (rows of the drained state: every load of the chunk's 8 rows in flight at once and the rows' quaternion work shared
+        //  out over the wave's lanes -- ZfSrc::load_rows / finish_rows, wave-uniform here: a wave is 64 columns of ONE row group;
+        //  with src.at() per row the chunk was 8 dependent rounds of flag -> branch -> loads -> arithmetic)
+        if (ROWS || c < dim)
             for (int rb = g0; rb < g1; rb += 8) {
                 double v[8];
-                int on[8], k = 0;
+                unsigned on = 0;          // bit i: row rb + i counts
+                int k = 0;
+                if constexpr (ROWS) {
+                    // (two half-chunks of 4 rows: the 8-row form needs more than the 128 registers a thread of this workgroup has)
+                    const int cl = min(c, dim - 1);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int r = rb + i;
-                    on[i] = r < g1 && (!active || active[r]);
-                    v[i] = on[i] ? (double)src.at(r, c) : 0.0;
-                    k += on[i];
+                    for (int h = 0; h < 2; ++h) {
+                        typename ZfSrc<T>::template Rows<4> P = src.template load_rows<4>(rb + 4 * h, n, cl);
+                        int flag[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) flag[i] = 1;
+                        if (active) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) flag[i] = active[min(rb + 4 * h + i, n - 1)];
+                        }
+                        src.template finish_rows<4>(P, rb + 4 * h, n, cl);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const bool o_ = rb + 4 * h + i < g1 && flag[i] && c < dim;
+                            on |= (unsigned)o_ << (4 * h + i);
+                            v[4 * h + i] = o_ ? (double)P.own[i] : 0.0;
+                            k += o_;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int r = rb + i;
+                        const bool o_ = r < g1 && (!active || active[r]);
+                        on |= (unsigned)o_ << i;
+                        v[i] = o_ ? (double)src.at(r, c) : 0.0;
+                        k += o_;
+                    }
                 }
                 if (k == 0) continue;
                 double sum = 0.0;
@@ -975,7 +1006,7 @@ __device__ __forceinline__ void zf_partial_body(const ZfSrc<T> &src, const int *
                 const double mb = sum / k;
                 double sb = 0.0;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) sb += on[i] ? (v[i] - mb) * (v[i] - mb) : 0.0;
+                for (int i = 0; i < 8; ++i) sb += (on >> i) & 1 ? (v[i] - mb) * (v[i] - mb) : 0.0;
                 if (cnt == 0.0) {
                     cnt = k; mean = mb; m2 = sb;
                 } else {
@@ -1012,10 +1043,17 @@ __device__ __forceinline__ void zf_partial_body(const ZfSrc<T> &src, const int *
     }
 }
 
-template <typename T>
+template <typename T, bool ROWS>
 __global__ __launch_bounds__(1024) void k_zf_partial(ZfSrc<T> src, const int *__restrict__ active, int n, int dim,
                                                     int rows_per_tile, double *__restrict__ ws) {
-    zf_partial_body<T>(src, active, n, dim, rows_per_tile, ws, blockIdx.x);
+    zf_partial_body<T, ROWS>(src, active, n, dim, rows_per_tile, ws, blockIdx.x);
+}
+template <typename T>
+static void launch_zf_partial(const ZfSrc<T> &src, const int *active, int n, int dim, int rpt, int nt, double *ws, hipStream_t stream) {
+    if (src.x == nullptr)
+        k_zf_partial<T, true><<<dim3(nt), dim3(1024), tick_lds((const void *)&k_zf_partial<T, true>, 0, 17 * 1024), stream>>>(src, active, n, dim, rpt, ws);
+    else
+        k_zf_partial<T, false><<<dim3(nt), dim3(1024), tick_lds((const void *)&k_zf_partial<T, false>, 0, 17 * 1024), stream>>>(src, active, n, dim, rpt, ws);
 }
 
 // One launch for the two independent halves of a rollout tick's post-step: blocks [0, n_tiles) compute the observation
@@ -1029,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_post_step(ZfSrc<T> src, const int *__re
                                                    const int *__restrict__ frame, const int *__restrict__ endf, T end_reward,
                                                    T *__restrict__ reward, T *__restrict__ cinfo) {
     if ((int)blockIdx.x < n_tiles)
-        zf_partial_body<T>(src, zf_active, n, dim, rows_per_tile, ws, blockIdx.x);
+        zf_partial_body<T, true>(src, zf_active, n, dim, rows_per_tile, ws, blockIdx.x);      // (the post-step's source is always the drained state)
     else
         reward_body<T, 1>(m, w, expert_rows, src.qpos, prev_qpos, ee_wpos, tcur, frame, endf, zf_active, end_reward, n, reward, cinfo,
                        (int)blockIdx.x - n_tiles);
@@ -1810,7 +1848,7 @@ static int launch_zfilter_src(const ZfSrc<T> &src, const int *active, int n, int
     int n_records = 0;
     if (update) {
         // (1 024 threads = one round of loads per thread: in the rollout 16.9 us per call against 20.1 with 512 and 33.6 with 256)
-        k_zf_partial<T><<<dim3(nt), dim3(1024), tick_lds((const void *)&k_zf_partial<T>, 0, 17 * 1024), (hipStream_t)stream>>>(src, active, n, dim, rpt, (double *)ws);
+        launch_zf_partial<T>(src, active, n, dim, rpt, nt, (double *)ws, (hipStream_t)stream);
         if (direct) {
             records = (const double *)ws; n_records = nt;
         } else if (two_level) {
@@ -2004,7 +2042,7 @@ int egp_obs_zfilter_stats_f64(egp_ctx *ctx, const double *qpos, const double *qv
     ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm), phase_t};
     int rpt, nt;
     zf_tiling(n, &rpt, &nt);
-    k_zf_partial<double><<<dim3(nt), dim3(1024), tick_lds((const void *)&k_zf_partial<double>, 0, 17 * 1024), (hipStream_t)stream>>>(src, active, n, dim, rpt, (double *)ws);
+    launch_zf_partial<double>(src, active, n, dim, rpt, nt, (double *)ws, (hipStream_t)stream);
     return after_launch("k_zf_partial");
 }
 int egp_obs_zfilter_apply_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const int32_t *phase_t, int32_t n, const double *st_in, double *st_out,

@@ -45,8 +45,11 @@ struct PolFilter {
 #ifdef EGP_POLICY_TRACE
 __device__ long long g_pol_trace[64];
 #define POL_TR(i) do { if (blockIdx.x == EGP_POLICY_TRACE && threadIdx.x == 0) g_pol_trace[i] = wall_clock64(); } while (0)
+// (the prologue of a wave that holds state columns: stamps 32..39 of thread 128)
+#define POL_TR_S(i) do { if (blockIdx.x == EGP_POLICY_TRACE && threadIdx.x == 128) g_pol_trace[32 + (i)] = wall_clock64(); } while (0)
 #else
 #define POL_TR(i) do { } while (0)
+#define POL_TR_S(i) do { } while (0)
 #endif
 
 constexpr int POL_MAX_LAYERS = 8;
@@ -190,6 +193,30 @@ __device__ __forceinline__ void policy_body(const float *__restrict__ ctx_rows, 
     const int in0 = ctx_dim + state_dim;
 
     POL_TR(0);
+    // the rows' context-row indices first: the longest dependent chain of the prologue (index -> context row) starts here
+    long tix[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) tix[r] = (long)t_idx[min(r0 + r, n - 1)];
+    // One input column per thread (in0 <= T, the shipped 128 + 115 on 256 threads): the thread that normalises state column c
+    // merges that column's statistics itself -- no LDS hop and no barrier between the filter's two phases, and the waves that
+    // gather the context columns do not wait for the merge. (Waves hold context columns, state columns or straddle the
+    // boundary: `state_wave` is wave-uniform.)
+    const int in0p = (in0 + 3) & ~3;
+    const bool own_col = in0p <= T;
+    const bool state_wave = own_col && wave * 64 + 63 >= ctx_dim && wave * 64 < in0;
+    const bool mine = tid >= ctx_dim && tid < in0;
+    const int c_own = min(max(tid - ctx_dim, 0), state_dim - 1);
+    // ... and the filter's loads next, ahead of the weight traffic below in the memory queue (loads return in order): the
+    // statistics' tile partials and the rows' raw state, which do not depend on each other -- one cold round trip for both
+    egp::ZfWaveMerge M;
+    egp::ZfSrc<double>::Rows<R> pend;
+    if constexpr (FILTER) {
+        if (state_wave) {
+            M.begin(state_dim, F.st_in, c_own);
+            M.load(state_dim, F.n_tiles, F.ws, c_own, 0);
+            pend = F.src.template load_rows<R>(r0, n, c_own);
+        }
+    }
     // L2 warm-up. A kernel starts with a cold L2 on every XCD (the per-XCD L2s are invalidated at kernel boundaries), so the
     // first touch of a weight line costs a trip to the memory side (~0.7 us) and a wave's PF x POL_GC KiB in flight turn the
     // weight stream into a chain of such trips. The workgroups of one XCD (round-robin dispatch: blockIdx & 7) therefore each
@@ -216,8 +243,61 @@ __device__ __forceinline__ void policy_body(const float *__restrict__ ctx_rows, 
         const int ng_all = (L.out_dim[0] + 63) >> 6;
         pol_preload<PF>(st, L.wp[0], nkq, 0, min(ng_all, POL_GC), kq0, max(kq1, kq0 + 1), lane);
     }
+    // the context columns (waiting for the indices requested first; everything above stays in flight)
+    long ctx_off[R];                      // every thread resolves its rows' context offsets itself: no LDS hop + barrier between the two dependent loads
+#pragma unroll
+    for (int r = 0; r < R; ++r) ctx_off[r] = (long)min(r0 + r, n - 1) * ctx_row_stride + tix[r] * ctx_dim;
+    float v_in[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v_in[r] = 0.0f;
+    if (own_col && wave * 64 < ctx_dim) {
+        if (tid < ctx_dim) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (r0 + r < n) v_in[r] = ctx_rows[ctx_off[r] + tid];
+        }
+    }
+    // The small operands of the epilogues (every layer's bias | exp(log_std) | the rows' noise: one LDS range from s_bias on):
+    // requested here into registers and parked in LDS behind the inputs' barrier -- a load followed by its LDS store right
+    // here would stall every wave until the weight loads queued in front of it have landed.
+    constexpr int POL_SMALL = 4;
+    const int osd4 = (out_last + 3) & ~3;
+    const int small_n = L.sum_out4 + (noise ? osd4 + R * out_last : 0);
+    // (where LDS float f of the range comes from, without touching memory: 0 padding, 1 value, 2 exp(value), 3 zero)
+    auto small_source = [&](int f, const float *&src) -> int {
+        src = L.bias[0];
+        if (f >= small_n) return 0;
+        if (f < L.sum_out4) {
+            int off = 0, kind = 0;
+            for (int l = 0; l < L.n; ++l) {
+                const int j = f - off;
+                const bool hit = j >= 0 && j < L.out_dim[l];
+                src = hit ? L.bias[l] + j : src;
+                kind = hit ? 1 : kind;
+                off += (L.out_dim[l] + 3) & ~3;
+            }
+            return kind;
+        }
+        const int j = f - L.sum_out4;
+        if (j < osd4) {
+            src = j < out_last ? log_std + j : src;
+            return j < out_last ? 2 : 0;
+        }
+        const int e = j - osd4, r = e / out_last;
+        const bool live = r0 + r < n;
+        src = live ? noise + (long)(r0 + r) * out_last + (e - r * out_last) : src;
+        return live ? 1 : 3;
+    };
+    float small_v[POL_SMALL];
+    int small_kind[POL_SMALL];
+#pragma unroll
+    for (int u = 0; u < POL_SMALL; ++u) {
+        const float *src;
+        small_kind[u] = small_source(tid + u * T, src);
+        small_v[u] = *src;                        // (unconditional: a load under a branch is waited for at the branch's end)
+    }
 
-    if constexpr (FILTER) {               // k_zf_apply's first phase: the merged statistics, every workgroup for itself
+    if constexpr (FILTER) if (!own_col) {   // k_zf_apply's first phase: the merged statistics, every workgroup for itself
         const int dim = state_dim;
         for (int c = tid; c < dim; c += T) {
             double cnt, mean, S;
@@ -233,27 +313,61 @@ __device__ __forceinline__ void policy_body(const float *__restrict__ ctx_rows, 
         }
     }
     POL_TR(1);
-    {
-        int off = 0;
-        for (int l = 0; l < L.n; ++l) {
-            for (int j = tid; j < L.out_dim[l]; j += T) s_bias[off + j] = L.bias[l][j];
-            off += (L.out_dim[l] + 3) & ~3;
-        }
-        if (noise) {
-            for (int j = tid; j < out_last; j += T) s_sd[j] = expf(log_std[j]);
-            for (int e = tid; e < R * out_last; e += T) {
-                const int r = e / out_last, j = e - r * out_last;
-                s_noise[e] = r0 + r < n ? noise[(long)(r0 + r) * out_last + j] : 0.0f;
-            }
-        }
-    }
-    long ctx_off[R];                      // every thread resolves its rows' context offsets itself: no LDS hop + barrier between the two dependent loads
-#pragma unroll
-    for (int r = 0; r < R; ++r) ctx_off[r] = (long)min(r0 + r, n - 1) * ctx_row_stride + (long)t_idx[min(r0 + r, n - 1)] * ctx_dim;
     if (stage_src)
         for (int i = blockIdx.x * T + tid; i < stage_words; i += gridDim.x * T) stage_dst[i] = stage_src[i];
+    if (own_col) {
+        const int k = tid;
+        float (&v)[R] = v_in;
+        if (state_wave) {
+            const int c = c_own;
+            if constexpr (FILTER) {
+                POL_TR_S(0);
+                M.merge(F.n_tiles, 0);
+                POL_TR_S(1);
+                for (int q0 = 8; q0 < F.n_tiles; q0 += 8) {
+                    M.load(state_dim, F.n_tiles, F.ws, c, q0);
+                    M.merge(F.n_tiles, q0);
+                }
+                const double cnt = M.cnt, mean = M.mean, S = M.S;
+                if (blockIdx.x == 0 && mine) {
+                    F.st_out[1 + c] = mean;
+                    F.st_out[1 + state_dim + c] = S;
+                    if (c == 0) F.st_out[0] = cnt;
+                }
+                const double var = cnt > 1.0 ? S / (cnt - 1.0) : mean * mean;
+                const double istd = 1.0 / (sqrt(var) + 1e-8);
+                POL_TR_S(2);
+                F.src.template finish_rows<R>(pend, r0, n, c);
+                const double (&raw)[R] = pend.own;
+                POL_TR_S(3);
+                if (mine) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int row = r0 + r;
+                        if (row < n) {
+                            double x = (raw[r] - mean) * istd;
+                            if (F.clip > 0.0) x = fmin(fmax(x, -F.clip), F.clip);
+                            const long e = (long)row * state_dim + c;
+                            F.y[e] = x;
+                            if (F.y2) F.y2[e] = x;
+                            v[r] = (float)x;
+                        }
+                    }
+                }
+            } else if (mine) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (r0 + r < n) v[r] = (float)state[(long)(r0 + r) * state_dim + c];
+            }
+        }
+        POL_TR_S(4);
+        if (k < in0p) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) cur[r * xs + k] = v[r];
+        }
+        POL_TR_S(5);
+    } else {
     if constexpr (FILTER) __syncthreads();            // the merged statistics (s_ms) are read by the staging loop below
-    const int in0p = (in0 + 3) & ~3;
     for (int k = tid; k < in0p; k += T) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -277,7 +391,20 @@ __device__ __forceinline__ void policy_body(const float *__restrict__ ctx_rows, 
             cur[r * xs + k] = v;
         }
     }
-    __syncthreads();
+    }
+    // the small operands into LDS (their loads have landed with the inputs'); the rest of a range beyond POL_SMALL x T floats directly
+#pragma unroll
+    for (int u = 0; u < POL_SMALL; ++u)
+        if (small_kind[u]) s_bias[tid + u * T] = small_kind[u] == 2 ? expf(small_v[u]) : (small_kind[u] == 3 ? 0.0f : small_v[u]);
+    for (int f = tid + POL_SMALL * T; f < small_n; f += T) {
+        const float *src;
+        const int kind = small_source(f, src);
+        const float val = *src;
+        if (kind) s_bias[f] = kind == 2 ? expf(val) : (kind == 3 ? 0.0f : val);
+    }
+    // (the barrier for the staged inputs in LDS only: __syncthreads() would also wait for the acknowledgement of the filtered
+    //  rows' global stores above -- a trip to the memory side on the critical path; nothing in this kernel reads them back)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     {   // the warm-up loads have long landed; their registers are free from here on
         float sink = 0.0f;
 #pragma unroll

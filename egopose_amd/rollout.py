@@ -30,6 +30,35 @@ from . import policy_step
 from .rl_core import LoggerRL, TrajBatchEgo
 
 
+_DEFAULT_TICK_FLAGS = "kernel"
+
+
+class _HostVisible:
+    """A byte array in fine-grained device memory (egp_hostvis_alloc): the host's NumPy view writes through the PCIe BAR, kernels
+    read the same address in HBM. Never read through `array` on the host (uncached PCIe reads)."""
+
+    def __init__(self, lib, ptr, nbytes):
+        self.lib, self.ptr = lib, ptr
+        self.array = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(ptr))
+
+    @classmethod
+    def create(cls, lib, device, nbytes):
+        """None where the device's memory is not host-addressable (no large BAR)."""
+        p = ctypes.c_void_p()
+        index = torch.device(device).index
+        rc = lib.egp_hostvis_alloc(torch.cuda.current_device() if index is None else index, nbytes, ctypes.byref(p))
+        if rc == -3:                  # EGP_E_STATE
+            return None
+        _lib.check(rc, "egp_hostvis_alloc")
+        return cls(lib, p.value, nbytes)
+
+    def __del__(self):
+        if getattr(self, "ptr", None) and torch.cuda.is_available():
+            self.array = None
+            self.lib.egp_hostvis_free(ctypes.c_void_p(self.ptr))
+            self.ptr = None
+
+
 class _PinnedRing:
     """Small ring of pinned int32 staging buffers for per-tick host->device flag uploads."""
 
@@ -536,17 +565,31 @@ class LockstepRollout:
             v_out_p, v_stride = self.v_out.data_ptr(), self.v_out.stride(0)
             fz = self._fused
             nmax = max(b - a for a, b in self.groups)
-            if self._fast_bufs is None or self._fast_bufs[3] != nmax:
+            # EGP_TICK_FLAGS: where the tick's flag slab lives and how it reaches the kernels -- 'bar' (the host fills fine-grained
+            # device memory through the PCIe BAR, kernels read it in HBM), 'kernel' (pinned host memory, the policy kernel stages it),
+            # 'upload' (pinned, a copy-engine transfer in front of the policy step: round 2's form), 'zerocopy' (every kernel reads the
+            # pinned slab over PCIe)
+            stage_mode = os.environ.get("EGP_TICK_FLAGS", _DEFAULT_TICK_FLAGS)
+            if self._fast_bufs is None or self._fast_bufs[3] != nmax or self._fast_bufs[4] != stage_mode:
                 # per (group, slot) one 24*nmax-byte slab: 4 x nmax int32 flags (t | frame | end | active), then nmax int64 context rows
-                self._fast_bufs = (torch.zeros(len(self.groups), 2, 24 * nmax, dtype=torch.uint8).pin_memory(),
-                                   torch.zeros(len(self.groups), 2, 24 * nmax, dtype=torch.uint8, device=dev), None, nmax)
-            slab_h, slab_d, _, _ = self._fast_bufs
-            slab_np = slab_h.numpy()
+                shape = (len(self.groups), 2, 24 * nmax)
+                vis = _HostVisible.create(ctx.lib, dev, int(np.prod(shape))) if stage_mode == "bar" else None
+                if vis is not None:
+                    self._fast_bufs = (vis.array.reshape(shape), None, vis, nmax, stage_mode)
+                else:
+                    if stage_mode == "bar":
+                        stage_mode = "kernel"           # no large BAR on this system: pinned memory, staged by the policy kernel
+                    self._fast_bufs = (torch.zeros(shape, dtype=torch.uint8).pin_memory(),
+                                       torch.zeros(shape, dtype=torch.uint8, device=dev), None, nmax, stage_mode)
+            slab_h, slab_d, vis, _, stage_mode = self._fast_bufs
+            if vis is not None:
+                slab_np, slab_hp, slab_dp = slab_h, vis.ptr, vis.ptr       # one address for the host's stores and the kernels' loads
+            else:
+                slab_np, slab_hp, slab_dp = slab_h.numpy(), slab_h.data_ptr(), slab_d.data_ptr()
             fl_np = slab_np[:, :, :16 * nmax].view(np.int32)            # (G, 2, 4*nmax)
             ti_np = slab_np[:, :, 16 * nmax:].view(np.int64)            # (G, 2, nmax)
-            slab_hp, slab_dp = slab_h.data_ptr(), slab_d.data_ptr()
-            flags_upload = os.environ.get("EGP_TICK_FLAGS", "kernel") != "zerocopy"
-            if not flags_upload:       # kernels read the pinned slab in place (same address on the device): every access is a PCIe read
+            flags_upload = stage_mode not in ("zerocopy", "bar")
+            if stage_mode == "zerocopy":       # kernels read the pinned slab in place (same address on the device): every access is a PCIe read
                 slab_dp = slab_hp
             reward_job = eng.substeps_per_launch > 1 and os.environ.get("EGP_REWARD_JOB", "1") != "0"
             T_eff = T_ep if self.env.fix_len is None else self.env.fix_len
@@ -569,9 +612,6 @@ class LockstepRollout:
             td.ctx, td.eng, td.stream = hnd, eng.handle, cur_stream
             td.n_env, td.nmax, td.obs_dim, td.nu, td.nq, td.nv = N, nmax, od, nu, ctx.nq, ctx.nv
             td.ctx_dim, td.ctx_T, td.episode_len = H, self.ctx_T, int(T_eff)
-            # EGP_TICK_FLAGS: 'kernel' (default: the policy kernel stages the tick's flag slab itself), 'upload' (a copy-engine
-            # transfer in front of it, round 2's form), 'zerocopy' (every kernel reads the pinned slab over PCIe)
-            stage_mode = os.environ.get("EGP_TICK_FLAGS", "kernel")
             # EGP_TICK_STREAMS: 'shared' (default) = the ticks of all groups on the caller's stream, an event either side of every
             # env-step; 'group' = each group's tick on its engine stream, one in-order queue policy -> env-step kernel -> filter
             # (+ reward) -> policy. Measured (round 3, tools/probes/chain_gaps.py): the policy -> K1 gap goes 12.8 -> 0 us, but
@@ -708,6 +748,8 @@ class LockstepRollout:
             soff = (g * 2 + slot) * 24 * nmax
             if flags_upload:
                 lib.egp_upload_async(slab_dp + soff, slab_hp + soff, 24 * nmax, cur_stream)
+            else:
+                lib.egp_host_store_fence()          # (the 'bar' slab is write-combining memory)
             fbase = slab_dp + soff
             nz_p = None if self.mean_action else noise_p + (k * N + a) * nu * 4
             rc = lib.egp_policy_gaussian_f32(v_out_p + a * v_stride * 4, v_stride, H, fbase + 16 * nmax,

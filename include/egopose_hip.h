@@ -239,6 +239,15 @@ int egp_obs_zfilter_apply_f64(egp_ctx *ctx, const double *qpos, const double *qv
 /* hipMemcpyAsync host (pinned) -> device on `stream`: the per-tick integer flags of the rollout driver (kernels that
  * re-read a flag array must not read it from pinned memory: every access would cross PCIe) */
 int egp_upload_async(void *dst_device, const void *src_pinned, int64_t bytes, void *stream);
+/* Host-visible DEVICE memory: fine-grained HBM the host writes through the PCIe BAR (write-combining, posted stores) and
+ * kernels read at HBM latency -- for small tables the host refills every tick (the rollout driver's flag slab with
+ * egp_rollout_tick.flags_upload == 0), where a pinned host buffer costs every reading wave a PCIe round trip that queues
+ * behind the resident env-step kernel's state-row traffic. The host must not READ it (uncached PCIe reads) and must call
+ * egp_host_store_fence() between its last store and the launch that reads (egp_rollout_tick_pre does).
+ * EGP_E_STATE: the device's memory is not fully host-addressable (no large BAR) -- use pinned memory. */
+int egp_hostvis_alloc(int32_t device, int64_t bytes, void **ptr);
+int egp_hostvis_free(void *ptr);
+void egp_host_store_fence(void);
 /* One rollout tick's post-step in three launches: egp_obs_zfilter (all rows written to y / y2, rows with active != 0 update
  * the statistics; state_in == NULL: raw observations) + egp_reward_quat_v3 with the same mask; the reward's workgroups
  * ride in the launch of the filter's first pass. Same arithmetic as the two separate calls (bit-identical, tested). */
@@ -630,7 +639,8 @@ int egp_engine_group_range(egp_engine *e, int32_t group, int32_t *env_begin, int
  * Python (flags of the coming env-step, their upload, the fused policy step, the reward job, the env-step; then the wait,
  * K3 + K6, K2 and the termination flags of HumanoidEnv.step, ego_pose/envs/humanoid_v1.py:182-199). The driver fills the
  * descriptor once per rollout; the arrays are its own (NumPy / device tensors) and stay valid for the rollout.
- *   flags_upload: how the tick's flag slab reaches the device -- 0 kernels read slab_host in place (then slab_dev == slab_host),
+ *   flags_upload: how the tick's flag slab reaches the device -- 0 kernels read slab_host in place (then slab_dev == slab_host: pinned
+ *                 memory read over PCIe, or egp_hostvis_alloc memory the host fills through the BAR),
  *                 1 a copy-engine transfer in front of the policy step, 2 the policy kernel moves it (egp_policy_gaussian_staged_f32)
  *   pre : flags / context rows of tick k for slots [a, b) -> policy -> env-step (asynchronous)
  *   post: wait for the env-step, observation + filter into states[k + 1] / next_states[k], reward, cur_t / done / record rows;

@@ -798,16 +798,18 @@ def test_constant_and_pose_dist_rewards_on_device(skel):
     ctx.close()
 
 
-@pytest.mark.parametrize("n", [512, 37, 1024])
-def test_filter_apply_in_the_policy_step_is_bit_identical_to_the_two_launches(ctx, n):
+@pytest.mark.parametrize("n,H", [(512, 128), (37, 128), (1024, 128), (300, 192), (512, 40)])
+def test_filter_apply_in_the_policy_step_is_bit_identical_to_the_two_launches(ctx, n, H):
     """egp_obs_zfilter_stats_f64 + egp_policy_gaussian_filter_f32 against egp_obs_zfilter_f64 + egp_policy_gaussian_f32 (what a
     rollout tick without resets runs, rollout.py EGP_DEFER_APPLY): filtered observations, running statistics and actions equal
-    bit for bit; so does the split pair stats + apply."""
+    bit for bit; so does the split pair stats + apply. Context widths: 128 (shipped; one input column per thread, the thread
+    that normalises a state column merges its statistics -- with the merge coefficients shared across the wave), 192 (more
+    input columns than threads: the statistics go through LDS), 40 (state columns straddle a wave boundary)."""
     from egopose_amd.nets import MLP, PolicyGaussian
     from egopose_amd import policy_step
     torch.manual_seed(11)
     rng = np.random.RandomState(n)
-    H, S, T, nu = 128, 115, 7, 52
+    S, T, nu = 115, 7, 52
     pol = PolicyGaussian(MLP(H + S, (300, 200), "relu"), nu, log_std=-2.3).cuda()
     fp = policy_step.FusedGaussianPolicy(pol, torch.device("cuda"))
     qpos = rng.normal(size=(n, 59)) * 0.4

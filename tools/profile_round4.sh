@@ -36,7 +36,9 @@ for n in 65536 1024; do
 done
 for kv in k1_grid58:k_pd_torque_grid58:K1_pd_torque k2_reward:k_reward_quat_v3:K2_reward k5_gae:k_gae:K5_gae k8_dynamics:k_dynamics:K8_dynamics; do
   tag=${kv%%:*}; rest=${kv#*:}; kern=${rest%%:*}; only=${rest##*:}
-  { echo "# commit $C  kernel $kern at 65 536 envs (tools/pmc_kernel.sh, microbench case $only alone)"; ONLY=$only bash tools/pmc_kernel.sh $kern 65536 VALUBusy MeanOccupancyPerCU SALUBusy FetchSize WriteSize; } > $OUT/r04_pmc_${tag}_65536.txt 2>&1
+  grep -q VALUBusy $OUT/r04_pmc_${tag}_65536.txt 2>/dev/null && continue        # (PART=2 after a call that ran out of time: keep what is there)
+  # (one pass of three counters; the derived FetchSize / WriteSize do not finish on this stack -- FETCH_SIZE / WRITE_SIZE are in r04_pmc_microbench_*)
+  { echo "# commit $C  kernel $kern at 65 536 envs (tools/pmc_kernel.sh, microbench case $only alone)"; ONLY=$only bash tools/pmc_kernel.sh $kern 65536 VALUBusy MeanOccupancyPerCU SALUBusy; } > $OUT/r04_pmc_${tag}_65536.txt 2>&1
 done
 bash tools/prof_statereg.sh > $OUT/prof_statereg.log 2>&1
 stamp $GRAFT_REPO_ROOT/gpurun_out/prof_statereg/mfma_util.csv $OUT/r04_statereg_mfma_util.csv
