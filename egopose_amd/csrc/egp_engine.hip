@@ -244,6 +244,10 @@ struct egp_engine {
     bool device_dynamics = false;             // K8 supplies qM / qfrc_bias from the drained (qpos, qvel) each substep
     double *d_bias = nullptr;                 // [n_env][nv] K8's bias (device-dynamics mode)
     int reward_delay_us = 0;                  // EGP_REWARD_JOB_DELAY_US (tests): a spin kernel ahead of the reward job's kernel
+    // EGP_WAIT_QUERY=1: egp_engine_wait polls the env-step kernel's completion event on the host (hipEventQuery) and returns
+    // without putting an event wait on the caller's stream: what the caller launches next is ordered by the host instead of by
+    // a dependency between two hardware queues (~20 us on this platform, tools/probes/stream_hop.py)
+    bool wait_query = false;
     int spin_us = 150;                        // EGP_SPIN_US: the engine's threads (and a caller in egp_engine_wait, 4 x as long) poll this long for
                                               // the next env-step / its end before sleeping on a condition variable. Round 2 measured no gain and left
                                               // it at 0; round 3's in-lease A/B (tools/probes/ab_env.sh, four alternating pairs): 99.3 against
@@ -873,6 +877,7 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
         const char *zc = getenv("EGP_ZERO_COPY");
         E->zero_copy = !(zc && atoi(zc) == 0);
         if (const char *su = getenv("EGP_SPIN_US")) E->spin_us = atoi(su);
+        if (const char *wq = getenv("EGP_WAIT_QUERY")) E->wait_query = atoi(wq) != 0;
         if (const char *rd = getenv("EGP_REWARD_JOB_DELAY_US")) E->reward_delay_us = atoi(rd);
         const char *fp = getenv("EGP_FLAG_POLL");
         E->flag_poll = !(fp && atoi(fp) == 0);
@@ -1240,7 +1245,15 @@ int egp_engine_wait(egp_engine *E, int32_t group, void *stream) {
         return G.status.load();
     }
     // (a caller that works on the group's own stream is already ordered behind the env-step's kernel)
-    if ((hipStream_t)stream != G.stream) EGP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, G.done, 0));
+    if ((hipStream_t)stream != G.stream) {
+        if (E->wait_query) {
+            hipError_t q;
+            while ((q = hipEventQuery(G.done)) == hipErrorNotReady) cpu_relax();
+            EGP_HIP_CHECK(q);
+        } else {
+            EGP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, G.done, 0));
+        }
+    }
     return EGP_OK;
 }
 
