@@ -1187,6 +1187,9 @@ int egp_engine_step_async(egp_engine *E, int32_t group, const double *action, co
     if (G.status.load() != EGP_OK) { egp::set_error("group %d failed earlier: %s", group, G.err); return G.status.load(); }
     G.action = action;
     G.ready = (hipEvent_t)ready_event;
+    // a caller that hands over no event has ordered nothing behind its last egp_engine_reset: the env-step's kernel must not
+    // read the device rows (state, inertia) while that reset's scatter kernel is still writing them
+    if (!G.ready && E->reset_pending) G.ready = E->reset_done;
     G.has_active = active_host != nullptr;
     if (active_host) memcpy(G.active, active_host, E->n_env * sizeof(int));
     G.server_job = server_mode(E, G);

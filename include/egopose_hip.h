@@ -612,7 +612,9 @@ int egp_engine_reset(egp_engine *e, const int32_t *env_ids_host, int32_t n, cons
                      const double *qvel_host, void *stream);
 /* start one env-step (frame_skip substeps) for group g: `action` is a DEVICE pointer [n_env][nu];
  * `active_host` [n_env] (optional) marks the envs to step; `ready_event` (optional hipEvent_t) is waited
- * on by every worker stream before its first K1 launch (action produced on another stream). */
+ * on by every worker stream before its first K1 launch (action produced on another stream; the event must also cover the
+ * caller's last egp_engine_reset, i.e. be recorded on that reset's stream after it). Without an event the env-step orders
+ * itself behind the last reset's upload and nothing else. */
 int egp_engine_step_async(egp_engine *e, int32_t group, const double *action, const int32_t *active_host,
                           void *ready_event);
 /* block until group g finished; makes `stream` wait for the final uploads so kernels enqueued on it
