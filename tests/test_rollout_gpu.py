@@ -447,11 +447,15 @@ def test_fast_tick_path_is_bit_identical_to_the_torch_path(workspace, monkeypatc
     # "1": the tick's bookkeeping and launches in two native calls (egp_rollout_tick_pre / _post, the default);
     # "py": the same from Python, one ctypes call per kernel (EGP_TICK_NATIVE=0); "0": the torch-tensor tick
     # "group": the native tick with each group's launches on its engine stream (EGP_TICK_STREAMS=group), the reward on the
-    # caller's stream behind the env-step's kernel
-    for fast in ("0", "1", "group", "py"):
+    # caller's stream behind the env-step's kernel; "bar" / "py-bar": the tick's flag slab in host-visible device memory
+    # (EGP_TICK_FLAGS=bar: filled through the PCIe BAR, store fence in front of the launch) from the native and the Python tick;
+    # "query": the host polls the env-step's completion event instead of an event wait on the caller's stream (EGP_WAIT_QUERY=1)
+    for fast in ("0", "1", "group", "py", "bar", "py-bar", "query"):
         monkeypatch.setenv("EGP_FAST_TICK", "0" if fast == "0" else "1")
-        monkeypatch.setenv("EGP_TICK_NATIVE", "0" if fast == "py" else "1")
+        monkeypatch.setenv("EGP_TICK_NATIVE", "0" if fast.startswith("py") else "1")
         monkeypatch.setenv("EGP_TICK_STREAMS", "group" if fast == "group" else "shared")
+        monkeypatch.setenv("EGP_TICK_FLAGS", "bar" if fast.endswith("bar") else "kernel")
+        monkeypatch.setenv("EGP_WAIT_QUERY", "1" if fast == "query" else "0")
         monkeypatch.setenv("EGP_REWARD_JOB_DELAY_US", reward_delay_us if fast != "0" else "0")
         monkeypatch.setenv("EGP_POLICY_GRAPH", "0")          # eager noise draws in both runs (same generator stream)
         torch.manual_seed(123)
