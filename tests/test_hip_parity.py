@@ -883,3 +883,30 @@ def test_large_batch_kernel_variants_equal_the_small_batch_ones(ctx, skel):
     parts = [ctx.dynamics(qp[a:a + 1500], qv[a:a + 1500], want_xpos=True) for a in range(0, m, 1500)]
     for key in ("qM", "bias", "xpos"):
         assert torch.equal(big[key], torch.cat([p[key] for p in parts])), key
+
+
+def test_host_visible_device_memory_round_trip():
+    """egp_hostvis_alloc (include/egopose_hip.h): fine-grained device memory the host fills through the PCIe BAR -- what the
+    rollout's EGP_TICK_FLAGS=bar keeps the tick's flag slab in. Host stores + egp_host_store_fence, then a device-side copy
+    must see every byte; EGP_E_STATE (no large BAR) is the one accepted refusal."""
+    import ctypes as C
+    from egopose_amd import _lib as L
+    lib = L.load()
+    n = 24 * 512 + 40
+    p = C.c_void_p()
+    rc = lib.egp_hostvis_alloc(torch.cuda.current_device(), n, C.byref(p))
+    if rc == -3:
+        pytest.skip("device memory is not host-addressable on this system (no large BAR)")
+    assert rc == 0 and p.value
+    view = np.ctypeslib.as_array((C.c_uint8 * n).from_address(p.value))
+    want = np.random.RandomState(3).randint(0, 256, n).astype(np.uint8)
+    view[:] = want
+    lib.egp_host_store_fence()
+    out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(C.c_void_p(out.data_ptr()), p, n, 4) == 0            # hipMemcpyDefault: a device-side read of the allocation
+    assert np.array_equal(out.cpu().numpy(), want)
+    del view
+    assert lib.egp_hostvis_free(p) == 0
