@@ -1171,6 +1171,36 @@ __global__ __launch_bounds__(128) void k_zf_apply(ZfSrc<T> src, int n, int dim, 
     }
     __syncthreads();
     const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+    if (src.x == nullptr && dim <= (int)blockDim.x) {
+        // rows of the drained state, one column per thread: ZfSrc's rows form (every load of 4 rows in flight at once, the rows'
+        // quaternion work shared out over the wave's lanes) instead of one src.at() -- branch, loads, arithmetic -- per element
+        const int c = min((int)threadIdx.x, dim - 1);
+        const bool mine = (int)threadIdx.x < dim;
+        const double mean = s_ms[c], inv = s_ms[dim + c];
+        for (int rb = r0; rb < r1; rb += 4) {
+            typename ZfSrc<T>::template Rows<4> P = src.template load_rows<4>(rb, n, c);
+            int keep[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) keep[i] = 1;
+            if (write_mask) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) keep[i] = write_mask[min(rb + i, n - 1)];
+            }
+            src.template finish_rows<4>(P, rb, n, c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = rb + i;
+                if (r < r1 && mine && keep[i]) {
+                    double v = ((double)P.own[i] - mean) * inv;
+                    if (clip > 0.0 && !identity) v = fmin(fmax(v, -clip), clip);
+                    const long e = (long)r * dim + c;
+                    y[e] = (T)v;
+                    if (y2) y2[e] = (T)v;
+                }
+            }
+        }
+        return;
+    }
     const long e0 = (long)r0 * dim, e1 = (long)r1 * dim;
     for (long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
         const int c = e % dim;
