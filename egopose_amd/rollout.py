@@ -569,19 +569,19 @@ class LockstepRollout:
             # device memory through the PCIe BAR, kernels read it in HBM), 'kernel' (pinned host memory, the policy kernel stages it),
             # 'upload' (pinned, a copy-engine transfer in front of the policy step: round 2's form), 'zerocopy' (every kernel reads the
             # pinned slab over PCIe)
-            stage_mode = os.environ.get("EGP_TICK_FLAGS", _DEFAULT_TICK_FLAGS)
-            if self._fast_bufs is None or self._fast_bufs[3] != nmax or self._fast_bufs[4] != stage_mode:
+            stage_mode = wanted_mode = os.environ.get("EGP_TICK_FLAGS", _DEFAULT_TICK_FLAGS)
+            if self._fast_bufs is None or self._fast_bufs[3] != nmax or self._fast_bufs[5] != wanted_mode:
                 # per (group, slot) one 24*nmax-byte slab: 4 x nmax int32 flags (t | frame | end | active), then nmax int64 context rows
                 shape = (len(self.groups), 2, 24 * nmax)
                 vis = _HostVisible.create(ctx.lib, dev, int(np.prod(shape))) if stage_mode == "bar" else None
                 if vis is not None:
-                    self._fast_bufs = (vis.array.reshape(shape), None, vis, nmax, stage_mode)
+                    self._fast_bufs = (vis.array.reshape(shape), None, vis, nmax, stage_mode, wanted_mode)
                 else:
                     if stage_mode == "bar":
                         stage_mode = "kernel"           # no large BAR on this system: pinned memory, staged by the policy kernel
                     self._fast_bufs = (torch.zeros(shape, dtype=torch.uint8).pin_memory(),
-                                       torch.zeros(shape, dtype=torch.uint8, device=dev), None, nmax, stage_mode)
-            slab_h, slab_d, vis, _, stage_mode = self._fast_bufs
+                                       torch.zeros(shape, dtype=torch.uint8, device=dev), None, nmax, stage_mode, wanted_mode)
+            slab_h, slab_d, vis, _, stage_mode, _ = self._fast_bufs
             if vis is not None:
                 slab_np, slab_hp, slab_dp = slab_h, vis.ptr, vis.ptr       # one address for the host's stores and the kernels' loads
             else:
