@@ -410,6 +410,8 @@ struct PdServe {
     const int *active;                    // optional [n] (pinned host): envs with 0 are not stepped this env-step -- their waves
                                           // move no state, torque or epilogue rows (in a rollout's tail that is most of the PCIe traffic)
     const void *dyn;                      // DYN kernels: the egp_dyn::DynTables of the context (device)
+    int row_contig;                       // qpos | qvel | bias are ONE row of nq + 2 nv doubles (the engine's state rows): read it as a
+                                          // contiguous stream (see the substep loop)
 };
 
 // Poll a word of pinned host memory through the SCALAR memory path (s_load ... glc = always fetch from beyond the
@@ -529,6 +531,23 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
                 egp_dyn::dynamics_wave(*tb, s_scr, s_q, s_q + 64, lane, true, &s_qM[wave][0], s_q + 128, nullptr);
                 egp_dyn::wave_sync();
                 r_q = s_q[7 + act]; r_v = s_q[64 + row]; r_c = s_q[128 + row];
+            } else if (sv.row_contig) {
+                // The state row over PCIe, lane l taking doubles l, 64 + l, 128 + l: whole 64-byte lines, each once (22 for the
+                // humanoid's 175 doubles). As three lane = dof segments (qpos + 7.., qvel, bias) the same row costs ~25 line reads,
+                // the segments start mid-line -- tools/probes/pcie_read_probe.hip: 48 against 57 GB/s, and the full-activity
+                // env-step is bound by exactly this traffic. The lanes then fetch their dof's three values with ds_bpermute.
+                const double *rowp = qpos + env * ld.qpos;
+                const int tot = sv.nq + 2 * sv.nv;
+                const double c0 = lane < tot ? sys_load_f64(rowp + lane) : 0.0;
+                const double c1 = 64 + lane < tot ? sys_load_f64(rowp + 64 + lane) : 0.0;
+                const double c2 = 128 + lane < tot ? sys_load_f64(rowp + 128 + lane) : 0.0;
+                auto pick = [&](int i) {
+                    const double a0 = __shfl(c0, i & 63), a1 = __shfl(c1, i & 63), a2 = __shfl(c2, i & 63);
+                    return i < 64 ? a0 : (i < 128 ? a1 : a2);
+                };
+                r_q = pick(7 + act);
+                r_v = pick(sv.nq + row);
+                r_c = pick(sv.nq + sv.nv + row);
             } else {
                 r_q = sys_load_f64(qpos + env * ld.qpos + 7 + act);
                 r_v = sys_load_f64(qvel + env * ld.qvel + row);
@@ -1805,8 +1824,13 @@ int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const d
     EGP_REQUIRE(n > 0 && n_sub > 0, "n and n_sub must be positive");
     PdLd ld{ld_qpos, ld_qvel, ctx->dm.nu, ld_qM, ld_bias};
     static const int poll_sleep = [] { const char *e = getenv("EGP_SERVER_POLL_SLEEP"); return e ? atoi(e) : 2; }();
+    // EGP_SERVER_ROW_CONTIG=0: the three lane = dof loads of round 3 (the A/B switch of the contiguous row read)
+    static const int want_contig = [] { const char *e = getenv("EGP_SERVER_ROW_CONTIG"); return e ? atoi(e) : 1; }();
+    const int nq = ctx->dm.nq, nv = ctx->dm.nv;
+    const int row_contig = want_contig && !device_dynamics && qvel == qpos + nq && bias == qvel + nv && ld_qpos == ld_qvel &&
+                           ld_qvel == ld_bias && nq + 2 * nv <= 192 && ld_qpos >= nq + 2 * nv;
     PdServe sv{block_slice, go, base, n_sub, qM_host, const_cast<double *>(qM), err, (long long)(timeout_s * 100.0e6), trace,
-               ee_host, out_qpos, out_prev_qpos, out_qvel, out_ee, ctx->dm.nq, ctx->dm.nv, poll_sleep, active, ctx->dyn_tables};
+               ee_host, out_qpos, out_prev_qpos, out_qvel, out_ee, nq, nv, poll_sleep, active, ctx->dyn_tables, row_contig};
     if (device_dynamics) {
         const size_t lds = egp_pd_server_dyn_lds_bytes();
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pd_server_tree58<true>),
