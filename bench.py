@@ -164,6 +164,53 @@ def dry_run(args):
         torch.distributed.destroy_process_group()
 
 
+def _med(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return None if n == 0 else (xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2]))
+
+
+def explain(args, world, eng, ro, t_sample, t_update, per_iter, iter_ms, iter_steps, thr0, thr1, probe0, probe1, info):
+    """Everything that tells a slow run from a slow box, as plain numbers for the `config` dict (the record the driver keeps of
+    this line retains `config` / `roofline` / `cpu_baseline` and drops unknown top-level keys): the reference prints T_sample /
+    T_update per iteration (ego_pose/ego_mimic.py:115-126), this line carries them per iteration, with the median-iteration rate
+    and its spread, the engine mode actually taken, the host, and the probe (egp_host_probe) before and after the timed region."""
+    rates = [n * world / (ms * 1e-3) for n, ms in zip(iter_steps, iter_ms)]
+    out = {
+        "t_sample_s": round(t_sample, 4), "t_update_s": round(t_update, 4),
+        "t_sample_ms_per_iteration": [p[0] for p in per_iter], "t_update_ms_per_iteration": [p[1] for p in per_iter],
+        "t_sample_ms_median": _med([p[0] for p in per_iter]), "t_update_ms_median": _med([p[1] for p in per_iter]),
+        "iteration_ms": [round(x, 1) for x in iter_ms],
+        "rollout_only_env_steps_per_s": round(sum(iter_steps) * world / max(t_sample, 1e-9), 1),
+        "env_steps_per_s_median_iteration": round(_med(rates), 1), "env_steps_per_s_min_iteration": round(min(rates), 1),
+        "env_steps_per_s_max_iteration": round(max(rates), 1),
+        "value_is": "env-steps of the K timed iterations / their wall time (bench contract); the median / min / max iteration beside it",
+        "host_cgroup_throttled_events": (thr1[0] - thr0[0]) if (thr0 and thr1) else None,
+        "host_cgroup_throttled_ms_all_threads": round((thr1[1] - thr0[1]) * 1e-3, 1) if (thr0 and thr1) else None,
+        "engine_substeps_per_launch": eng.substeps_per_launch,
+        "engine_go_words": {1: "vram(BAR)", 0: "pinned", -1: "n/a"}.get(int(eng.lib.egp_engine_go_words_in_vram(eng.handle)), "?"),
+        "rollout_ticks": ro.timing.get("ticks"), "rollout_small_group_ticks": ro.timing.get("small_group_ticks"),
+        "rollout_wait_s": round(ro.timing.get("wait", 0.0), 4), "rollout_setup_s": round(ro.timing.get("setup", 0.0), 4),
+        "rollout_assemble_s": round(ro.timing.get("assemble", 0.0), 4),
+    }
+    out.update({"host_" + k: v for k, v in info.items()})
+    for tag, pr in (("probe", probe0), ("probe_after", probe1)):
+        if pr is None:
+            continue
+        if "error" in pr:
+            out[tag + "_error"] = pr["error"]
+            continue
+        out.update({tag + "_pcie_read_GBps": round(pr["pcie_read_gbps"], 2), tag + "_go_rtt_us_p50": round(pr["go_rtt_us_p50"], 2),
+                    tag + "_go_rtt_us_p99": round(pr["go_rtt_us_p99"], 2), tag + "_go_rtt_us_max": round(pr["go_rtt_us_max"], 1),
+                    tag + "_spin_gap_us_max": round(pr["spin_gap_us_max"], 1),
+                    tag + "_spin_gap_us_median_thread_max": round(pr["spin_gap_us_median_of_thread_max"], 1),
+                    tag + "_spin_lost_frac": round(pr["spin_lost_frac"], 5), tag + "_spin_gaps_over_5us": pr["spin_gaps_over_5us"]})
+        if tag == "probe":
+            out.update({"probe_large_bar": bool(pr["large_bar"]), "probe_go_in_vram": bool(pr["go_in_vram"]), "probe_spin_threads": pr["spin_threads"],
+                        "probe_what": "egp_host_probe: 1024 pinned state rows read K1's way; go word -> row back round trip; spinning threads' clock gaps"})
+    return out
+
+
 def k1_roofline(tim, envs_per_group, eng, every):
     """K1 roofline from the engine's event-bracketed launches (see the module docstring)."""
     if tim["k1_launches"] <= 0:
@@ -171,7 +218,7 @@ def k1_roofline(tim, envs_per_group, eng, every):
     total_s = tim["k1_ms"] * 1e-3
     avg_s = total_s / tim["k1_launches"]
     sub_per_launch = max(1, eng.substeps_per_launch)       # 15 when the resident K1 serves a whole env-step
-    slots_per_launch = envs_per_group / max(1, eng.launches_per_substep)
+    slots_per_launch = envs_per_group
     achieved = K1_BYTES_PER_ENV * tim["k1_env_substeps"] / total_s
     slot_based = K1_BYTES_PER_ENV * slots_per_launch * sub_per_launch / avg_s
     stepped_per_launch = tim["k1_env_substeps"] / float(sub_per_launch) / tim["k1_launches"]
@@ -216,18 +263,20 @@ def run_leg(make_trainer, steps, warmup, min_batch, every, env=None, default_dty
         eng.reset_timing()
         torch.cuda.synchronize()
         t0 = time.time()
-        n_steps, t_sample, t_update = 0, 0.0, 0.0
+        n_steps, t_sample, t_update, per_iter = 0, 0.0, 0.0, []
         for _ in range(steps):
             _, ts, tu, n = tr.iteration(it, min_batch)
             n_steps += n
             t_sample += ts
             t_update += tu
+            per_iter.append([round(ts * 1e3, 1), round(tu * 1e3, 1)])
             it += 1
         torch.cuda.synchronize()
         elapsed = time.time() - t0
         tim = eng.timing()
         out = {"env_steps_per_s": n_steps / elapsed, "rollout_only_env_steps_per_s": n_steps / max(t_sample, 1e-9),
-               "steps": steps, "warmup": warmup, "t_sample_s": t_sample, "t_update_s": t_update,
+               "steps": steps, "warmup": warmup, "t_sample_s": t_sample, "t_update_s": t_update, "per_iteration_ms_sample_update": per_iter,
+               "indicative": bool(steps < 3 or warmup < 2),      # fewer iterations than that is a smoke run, not a measurement
                "substeps_per_launch": eng.substeps_per_launch, "device_dynamics": bool(getattr(eng, "device_dynamics", False)),
                "inertia_uploads": int(eng.lib.egp_engine_inertia_uploads(eng.handle))}
         if tim["k1_launches"] > 0:
@@ -267,12 +316,14 @@ def main():
     ap.add_argument("--cpu-update-steps", type=int, default=1500, help="steps of the CPU sample the CPU update leg runs on (~10 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-k1-events", action="store_true")
+    ap.add_argument("--no-host-probe", action="store_true", help="skip egp_host_probe around the timed region")
     ap.add_argument("--k1-event-every", type=int, default=8, help="bracket K1 with HIP events on every Nth env-step")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra 1-GPU legs (drop-in dtype, changing inertia)")
     ap.add_argument("--sim-cost-us", type=float, default=20.0,
                     help="per-substep physics cost of the `simulator_cost_per_substep` leg (busy wait inside the surrogate's step)")
     ap.add_argument("--no-kernels", action="store_true", help="skip the HBM-resident kernel microbenchmarks")
-    ap.add_argument("--leg-steps", type=int, default=2)
+    ap.add_argument("--leg-steps", type=int, default=3, help="timed iterations of every extra leg (after --leg-warmup untimed ones)")
+    ap.add_argument("--leg-warmup", type=int, default=3)
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous self-test: no GPU work (gloo on CPU)")
     args = ap.parse_args()
 
@@ -338,13 +389,25 @@ def main():
     if world > 1 and updater is not None:
         updater.collective_ms()                 # (drop the warm-up's)
         updater.time_collectives = True
+    # the box, measured right in front of the timed region and again behind it (rank 0; ~0.4 s each, the engine's threads asleep):
+    # two runs of one commit that differ in env-steps/s differ here too -- or the code is what moved
+    from egopose_amd.physics import host_info, host_probe
+    probe0 = probe1 = None
+    if rank == 0 and not args.no_host_probe:
+        try:
+            probe0 = host_probe(local, n_threads, 250)
+        except Exception as e:
+            probe0 = {"error": repr(e)[:200]}
     thr0 = cgroup_throttle()
     barrier()
     D.COLLECTIVES["count"] = 0                    # (after the barrier: only the timed iterations' collectives are counted)
     t0 = time.time()
-    steps_local, t_sample, t_update, per_iter = 0, 0.0, 0.0, []
+    steps_local, t_sample, t_update, per_iter, iter_ms, iter_steps = 0, 0.0, 0.0, [], [], []
     for _ in range(args.steps):
+        ti0 = time.time()
         log, ts, tu, n = tr.iteration(it, min_batch)
+        iter_ms.append((time.time() - ti0) * 1e3)
+        iter_steps.append(n)
         steps_local += n
         t_sample += ts
         t_update += tu
@@ -354,6 +417,11 @@ def main():
     barrier()
     elapsed = time.time() - t0
     thr1 = cgroup_throttle()
+    if rank == 0 and probe0 is not None and "error" not in probe0:
+        try:
+            probe1 = host_probe(local, n_threads, 250)
+        except Exception as e:
+            probe1 = {"error": repr(e)[:200]}
     tim = eng.timing()
     ar_ms = updater.collective_ms() if (world > 1 and updater is not None) else []
     total_steps, elapsed = aggregate(steps_local, elapsed, world, dev)
@@ -379,7 +447,12 @@ def main():
             "host_cgroup_throttled": None if not (thr0 and thr1) else {"events": thr1[0] - thr0[0], "usec_all_threads": thr1[1] - thr0[1]},
             "rollout_timing": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ro.timing.items()},
         })
+        res["config"].update(explain(args, world, eng, ro, t_sample, t_update, per_iter, iter_ms, iter_steps, thr0, thr1, probe0, probe1,
+                                     host_info(local)))
         res["roofline"] = k1_roofline(tim, args.envs / float(args.groups), eng, args.k1_event_every)
+        if res["roofline"] is not None:          # (the decomposition next to the kernel figure too: this dict is kept whole)
+            c = res["config"]
+            res["roofline"].update({"t_sample_ms_median": c["t_sample_ms_median"], "t_update_ms_median": c["t_update_ms_median"]})
         if world > 1:
             # SURVEY 8e / BASELINE.md G2: one fused gradient all-reduce per PPO epoch (476 109 floats), timed with HIP events on rank 0
             res["collectives"] = {"backend": torch.distributed.get_backend(), "ranks": world,
@@ -407,22 +480,22 @@ def main():
 
             mk64 = lambda: Trainer(cfg_cls(args.cfg, create_dirs=False), dev, torch.float64, num_envs=args.envs, num_threads=n_threads,
                                    num_groups=args.groups, plain_optim=True)
-            ev = args.k1_event_every
+            ev, lw = args.k1_event_every, args.leg_warmup
             legs = {
-                "dropin_float64_driver": run_leg(mk64, args.leg_steps, 1, min_batch, ev, default_dtype=torch.float64),
-                "changing_inertia_host_fed": run_leg(mk32, args.leg_steps, 1, min_batch, ev, {"EGP_SURROGATE_ALWAYS_DIRTY": "1"}),
-                "changing_inertia_device_dynamics": run_leg(mk32, args.leg_steps, 1, min_batch, ev,
+                "dropin_float64_driver": run_leg(mk64, args.leg_steps, lw, min_batch, ev, default_dtype=torch.float64),
+                "changing_inertia_host_fed": run_leg(mk32, args.leg_steps, lw, min_batch, ev, {"EGP_SURROGATE_ALWAYS_DIRTY": "1"}),
+                "changing_inertia_device_dynamics": run_leg(mk32, args.leg_steps, lw, min_batch, ev,
                                                             {"EGP_SURROGATE_ALWAYS_DIRTY": "1", "EGP_DEVICE_DYNAMICS": "1"}),
             }
             # BASELINE config 5's nets on this GPU's shard (1 of the 4 x 1 024 env slots): VideoForecastNet front ends,
             # per-tick state LSTM, 90-step episodes, decayed reward
             mkf = lambda: Trainer(ForecastConfig(args.cfg, create_dirs=False), dev, torch.float32, num_envs=args.envs,
                                   num_threads=n_threads, num_groups=args.groups)
-            legs["egoforecast_config5_shard"] = run_leg(mkf, args.leg_steps, 1, min_batch, ev)
+            legs["egoforecast_config5_shard"] = run_leg(mkf, args.leg_steps, lw, min_batch, ev)
             # the same pipeline when a physics substep costs what a real simulator's does (the surrogate's own is ~0.3 us;
             # an mj_step of this humanoid is tens of us): host-bound, and the CPU sampler beside it at the same cost
             cost = {"EGP_SURROGATE_SUBSTEP_US": str(args.sim_cost_us)}
-            leg = run_leg(mk32, 1, 1, min_batch, ev, cost)
+            leg = run_leg(mk32, args.leg_steps, min(2, lw), min_batch, ev, cost)
             if not args.no_cpu_baseline and "error" not in leg:
                 cb = cpu_baseline(root, max(200, args.cpu_steps // 6), 2, cost)
                 leg.update({"cpu_sampler_env_steps_per_s": cb["value"], "cpu_sampler_cores": cb["cores"], "cpu_sampler_sample": cb["sample"]})
@@ -434,7 +507,7 @@ def main():
             legs["simulator_cost_per_substep"] = leg
             # the reference's loop condition applied to all slots together (no new episode once the batch is there) against the
             # per-slot quota of the default: what the rollout's latency-bound tail costs, and what it buys in batch size
-            legs["step_budget_global"] = run_leg(mk32, args.leg_steps, 1, min_batch, ev, {"EGP_STEP_BUDGET": "global"})
+            legs["step_budget_global"] = run_leg(mk32, args.leg_steps, lw, min_batch, ev, {"EGP_STEP_BUDGET": "global"})
             # more env slots on the one GPU, same physics, the batch scaled with the slots (each slot keeps its 48-step quota): how far
             # the fixed latencies of a tick amortise -- the basis of the weak-scaling claim (1 024 slots = the headline; the resident
             # K1 serves up to 2 048 slots, beyond that the engine launches per substep)
@@ -442,13 +515,14 @@ def main():
             for n_slots, n_groups in ((512, args.groups), (2048, args.groups), (2048, 2 * args.groups), (4096, 2 * args.groups)):
                 mkn = lambda n_slots=n_slots, n_groups=n_groups: Trainer(cfg_cls(args.cfg, create_dirs=False), dev, torch.float32, num_envs=n_slots,
                                                                          num_threads=n_threads, num_groups=n_groups)
-                r = run_leg(mkn, max(1, args.leg_steps - 1), 1, min_batch * n_slots // args.envs, ev)
+                r = run_leg(mkn, args.leg_steps, lw, min_batch * n_slots // args.envs, ev)
                 key = "slots_%d_groups_%d" % (n_slots, n_groups)
                 if "error" in r:
                     sweep[key] = {"error": r["error"]}
                 else:
                     sweep[key] = {"env_steps_per_s": r["env_steps_per_s"], "rollout_only_env_steps_per_s": r["rollout_only_env_steps_per_s"],
                                   "ms_sample_update": [round(1e3 * r["t_sample_s"] / r["steps"], 1), round(1e3 * r["t_update_s"] / r["steps"], 1)],
+                                  "ms_sample_update_per_iteration": r.get("per_iteration_ms_sample_update"), "steps": r["steps"], "warmup": r["warmup"],
                                   "env_steps_per_iteration": r["env_steps_per_iteration"], "substeps_per_launch": r["substeps_per_launch"]}
             legs["envs_per_gpu_sweep"] = {k: json.dumps(v) for k, v in sweep.items()}
             # BASELINE config 4: the state regressor's optimisation step (ResNet-18 encoder in bf16 on the matrix cores)

@@ -64,16 +64,6 @@ class MlpLayer(C.Structure):
     _fields_ = [("wt", vp), ("bias", vp), ("in_dim", C.c_int32), ("out_dim", C.c_int32)]
 
 
-class MlpChainDesc(C.Structure):
-    _fields_ = [("n", C.c_int32), ("backward", C.c_int32),
-                ("src1", vp), ("ld1", C.c_int64), ("gather", vp), ("c1", C.c_int32),
-                ("src2", vp), ("ld2", C.c_int64), ("c2", C.c_int32),
-                ("packed", vp * 3), ("bias", vp * 3), ("dims", C.c_int32 * 4),
-                ("mask1", vp), ("mask2", vp),
-                ("inT", vp), ("o1T", vp), ("o2T", vp), ("ldT", C.c_int64),
-                ("out", vp), ("ld_out", C.c_int64), ("scatter", vp)]
-
-
 class GemmDesc(C.Structure):
     _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("A", vp), ("lda", C.c_int64), ("a_kcontig", C.c_int32),
@@ -117,7 +107,7 @@ class RolloutTick(C.Structure):
     _fields_ = [("ctx", vp), ("eng", vp), ("stream", vp),
                 ("n_env", C.c_int32), ("nmax", C.c_int32), ("obs_dim", C.c_int32), ("nu", C.c_int32), ("nq", C.c_int32), ("nv", C.c_int32),
                 ("ctx_dim", C.c_int32), ("ctx_T", C.c_int32), ("episode_len", C.c_int32), ("reward_job", C.c_int32),
-                ("flags_upload", C.c_int32), ("has_fix_head_lb", C.c_int32),
+                ("has_fix_head_lb", C.c_int32),
                 ("end_reward", C.c_double), ("zf_clip", C.c_double), ("fix_head_lb", C.c_double),
                 ("cur_t", vp), ("frame_base", vp), ("e_ind", vp), ("s_ind", vp), ("steps_done", vp),
                 ("active", vp), ("active_i32", vp), ("head_z", vp), ("head_lb", vp),
@@ -128,7 +118,14 @@ class RolloutTick(C.Structure):
                 ("slab_host", vp), ("slab_dev", vp),
                 ("qpos", vp), ("qvel", vp), ("prev_qpos", vp), ("ee", vp),
                 ("zf_workspace", vp), ("reset_scratch", vp),
-                ("group_streams", C.c_int32), ("post_fused", C.c_int32), ("defer_apply", C.c_int32)]
+                ("defer_apply", C.c_int32)]
+
+
+class HostProbeResult(C.Structure):
+    """egp_host_probe_result (include/egopose_hip.h)."""
+    _fields_ = [(k, C.c_double) for k in ("pcie_read_gbps", "pcie_read_us_per_pass", "go_rtt_us_p50", "go_rtt_us_p99", "go_rtt_us_max",
+                                          "spin_gap_us_max", "spin_gap_us_median_of_thread_max", "spin_lost_frac")] + \
+               [(k, C.c_int32) for k in ("pcie_read_rows", "go_rtt_n", "go_in_vram", "large_bar", "spin_threads", "spin_gaps_over_5us")]
 
 
 class EngineDesc(C.Structure):
@@ -205,22 +202,14 @@ SIGNATURES = {
     "egp_policy_gaussian_filter_f32": (C.c_int, [vp, vp, C.c_int64, _i32, vp, vp, vp, vp, _i32, vp, vp, C.c_double, vp, vp, vp,
                                                 vp, _i32, _i32, vp, vp, vp, vp, vp, vp, C.c_int64, vp]),
     "egp_rollout_tick_post": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, vp, vp, vp]),
-    "egp_rollout_reset": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, _i32, vp, vp, vp, vp, vp, vp, vp, _i32, vp, vp]),
+    "egp_rollout_reset": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, _i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "egp_engine_group_stream": (vp, [vp, _i32]),
     "egp_debug_burn": (C.c_int, [C.c_int64, _i32, vp, vp]),
     "egp_lstm_group_fwd_len_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_void_p), _i32, vp, vp, vp, vp, _i32, vp]),
     "egp_lstm_group_bwd_len_f32": (C.c_int, [C.POINTER(C.c_void_p), _i32, vp, vp, vp, _i32, _i32, _i32, _i32, _i32, vp, vp, vp, vp, _i32, vp]),
     "egp_upload_async": (C.c_int, [vp, vp, C.c_int64, vp]),
-    "egp_hostvis_alloc": (C.c_int, [C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
-    "egp_hostvis_free": (C.c_int, [vp]),
-    "egp_host_store_fence": (None, []),
-    "egp_post_step_f64": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, _i32, vp, vp, _f64, vp, vp, vp, _f64, vp, vp, vp]),
     "egp_set_dynamics_model": (C.c_int, [vp, C.POINTER(DynamicsDesc)]),
     "egp_dynamics_f64": (C.c_int, [vp, vp, vp, _i32, vp, C.c_int64, vp, vp, vp]),
-    "egp_mlp_chain_ksteps": (_i32, [_i32]),
-    "egp_mlp_chain_pack_bytes": (C.c_int64, [_i32, _i32]),
-    "egp_mlp_chain_pack_f32": (C.c_int, [vp, C.c_int64, _i32, _i32, _i32, _i32, vp, vp]),
-    "egp_mlp_chain_f32": (C.c_int, [C.POINTER(MlpChainDesc), vp]),
     "egp_mlp_pack_floats": (C.c_int64, [_i32, _i32]),
     "egp_mlp_pack_f32": (C.c_int, [vp, C.c_int64, _i32, _i32, vp, vp]),
     "egp_policy_gaussian_f32": (C.c_int, [vp, C.c_int64, _i32, vp, vp, _i32, _i32, C.POINTER(MlpLayer), _i32, _i32, vp, vp, vp, vp, vp]),
@@ -249,9 +238,10 @@ SIGNATURES = {
     "egp_engine_layout": (C.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p]),
     "egp_engine_group_range": (C.c_int, [vp, _i32, c_int_p, c_int_p]),
     "egp_engine_set_reward_job": (C.c_int, [vp, _i32, vp, vp, vp, vp, _f64, vp, vp]),
-    "egp_engine_launches_per_substep": (C.c_int, [vp]),
     "egp_engine_substeps_per_launch": (C.c_int, [vp]),
     "egp_engine_server_trace": (C.c_int, [vp, _i32, vp, vp]),
+    "egp_engine_go_words_in_vram": (_i32, [vp]),
+    "egp_host_probe": (C.c_int, [_i32, _i32, _i32, C.POINTER(HostProbeResult)]),
 }
 
 _lib = None

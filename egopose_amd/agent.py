@@ -197,8 +197,10 @@ class Agent:
                 raise RuntimeError("egopose_amd samples on an MI355X only: device=%s has no HIP path (no CPU fallback)" % (dev,))
             idx = dev.index if dev.index is not None else torch.cuda.current_device()
             reward_id = getattr(self.env.cfg, "reward_id", "quat_v3")
-            kind = "quat_v3" if self.custom_reward is None else getattr(self.custom_reward, "egp_kernel", None)
-            if kind not in ("quat_v3", "constant", "pose_dist"):
+            # custom_reward=None (agents/agent.py:53-58): the batch trains on the ENV's reward (HumanoidEnv.step returns 1.0 per
+            # step, humanoid_v1.py:188) and the logger sees c_reward = 0, c_info = [0] -- kind 'env', never a silent quat_v3
+            kind = "env" if self.custom_reward is None else getattr(self.custom_reward, "egp_kernel", None)
+            if kind not in ("env", "quat_v3", "constant", "pose_dist"):
                 raise NotImplementedError("custom_reward %r has no HIP kernel (the registry's quat_v3 / constant / pose_dist "
                                           "do; reward_id=%s)" % (self.custom_reward, reward_id))
             n_threads = None if self.num_threads in (None, 0) else int(self.num_threads)

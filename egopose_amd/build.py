@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libegopose_hip.so")
-SOURCES = ["egp_kernels.hip", "egp_lstm.hip", "egp_policy.hip", "egp_gemm.hip", "egp_chain.hip", "egp_dynamics.hip", "egp_engine.hip", "egp_update.hip",
+SOURCES = ["egp_kernels.hip", "egp_lstm.hip", "egp_policy.hip", "egp_gemm.hip", "egp_dynamics.hip", "egp_engine.hip", "egp_update.hip", "egp_probe.hip",
            "egp_physics.cpp"]
 HEADERS = ["egp_internal.hpp", "egp_quat.hpp", "egp_filter_dev.hpp", "egp_dynamics_dev.hpp", "egp_tree58.inc", "egp_pd_grid.hpp", os.path.join("..", "..", "include", "egopose_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wno-unused-result", "-Xarch_host", "-mavx2", "-Xarch_host", "-mfma"]

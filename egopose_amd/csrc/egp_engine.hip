@@ -2,15 +2,18 @@
 // (ego_pose/envs/humanoid_v1.py:158-177: 15 x {compute_torque; clip; data.ctrl = torque; sim.step()})
 // for all envs of a GPU at once.
 //
-//   * envs are partitioned into `n_groups` contiguous groups; a group advances one env-step as 15 substeps of
-//        K1 over the whole group (ONE launch on the group's stream) -> one D2H copy of the clipped torques
-//        -> physics of the group's envs on the group's host threads (egp_physics vtable, env-parallel)
-//        -> ONE H2D copy of the group's state rows [qpos | qvel | qfrc_bias | pad] (176 doubles/env), plus
-//           ONE copy of its inertia rows qM (912 doubles/env) when the backend reports that some qM changed
-//     so the GPU sees a few large launches/copies per substep instead of many tiny ones (HIP streams beyond
-//     the handful of hardware queues serialise);
-//   * a group's threads meet at spin barriers inside the substep loop (phases are tens of microseconds);
-//     thread 0 of the group is its leader and owns every HIP call of the group;
+//   * envs are partitioned into `n_groups` contiguous groups with their own host threads and HIP stream; state rows
+//     [qpos | qvel | qfrc_bias | pad] (176 doubles/env), inertia rows qM (912 doubles/env) and torque rows live in pinned host
+//     memory that the kernels read / write in place over PCIe (zero-copy);
+//   * TWO forms of the env-step (docs/DESIGN_TRAIL.md section 2 has the forms that were measured and dropped):
+//        resident   ONE launch of k_pd_server_tree58 serves all 15 substeps: its workgroups wait for the go word of their
+//                   slice, pull the slice's state rows, solve, write torques; every host thread owns a few slices and steps an
+//                   env the moment its torque row has arrived (run_step_server). The default -- whenever every workgroup of
+//                   every group fits on the chip at the same time (they wait on the host: a workgroup that is not resident
+//                   while its slice's owner waits for it would stall the env-step until another group's kernel ends).
+//        per-substep  one K1 launch per substep over the whole group, the leader polls the kernel's completion flag, the
+//                   group's threads meet at spin barriers (run_step). The fallback: other dof trees / K1 variants, more
+//                   slots than the chip holds resident workgroups for, EGP_SERVER=0.
 //   * different groups run independently: while one group's rows are on the PCIe link / in K1, another
 //     group's threads do physics, and the caller's GPU work for a finished group (reward / observation
 //     kernels, policy inference) overlaps the other groups' stepping.
@@ -82,19 +85,6 @@ struct SpinBarrier {
     }
 };
 
-// A slice of a group with its own K1 launch, completion counter and pinned completion flag (pipelined mode)
-struct Chunk {
-    int e0 = 0, e1 = 0;
-    unsigned *d_done = nullptr;
-    unsigned long long *h_flag = nullptr, *hd_flag = nullptr;
-    hipStream_t stream = nullptr;             // own launch stream (EGP_CHUNK_STREAMS=1) or the group's
-    bool own_stream = false;
-    unsigned long long seq = 0;               // sequence number of the last launch
-    unsigned long long base = 0;              // seq when the current env-step was posted
-    alignas(64) std::atomic<long> phys_done{0};   // worker completions of this env-step (cumulative over substeps)
-    std::atomic<int> qM_dirty{0};
-};
-
 // Resident-K1 mode: the group's envs as a few slices per host thread (whole 4-env blocks each), each with the `go`
 // word its owner raises after a substep of physics; torques come back through sentinel-filled pinned rows
 struct Server {
@@ -116,7 +106,6 @@ struct Server {
     // per env-substep (an mj_step-like cost) the rollout gains 7 %; with the 0.3 us surrogate it LOSES 10 % (measured both
     // ways). So the engine measures what a substep costs and deals only above `balance_min_ns`.
     std::vector<int> order, first;
-    int balance = -1;                         // EGP_SERVER_BALANCE: 0 = fixed ownership, 1 = always deal, unset = by measured cost
     std::atomic<long long> substep_ns{0};     // running estimate of one env-substep on a host thread (step + drain)
     long long balance_min_ns = 2000;
     bool can_balance = true;
@@ -127,8 +116,7 @@ inline void assign_slices(Server &S, int n_threads, const int *active) {
     const int ns = S.n_slices, K = S.per_thread;
     S.order.resize(ns);
     S.first.resize(n_threads + 1);
-    const bool deal = active && S.can_balance &&
-                      (S.balance == 1 || (S.balance < 0 && S.substep_ns.load(std::memory_order_relaxed) >= S.balance_min_ns));
+    const bool deal = active && S.can_balance && S.substep_ns.load(std::memory_order_relaxed) >= S.balance_min_ns;
     if (!deal) {
         for (int sl = 0; sl < ns; ++sl) S.order[sl] = sl;
         for (int t = 0; t <= n_threads; ++t) S.first[t] = K * t;
@@ -163,13 +151,9 @@ inline void assign_slices(Server &S, int n_threads, const int *active) {
 struct Group {
     int e0 = 0, e1 = 0;                       // env range [e0, e1)
     Server srv;
-    std::unique_ptr<Chunk[]> chunks;          // pipelined mode: n_chunks >= 2 slices, else unused
-    int n_chunks = 0;
     int n_threads = 1;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;                // recorded after the last upload of an env-step
-    hipEvent_t chain_done = nullptr;          // group-stream ticks: recorded behind the group's last filter launch (the running
-    bool chain_recorded = false;              //  statistics pass from group to group in host order)
     hipEvent_t reward_done = nullptr;         // recorded behind the reward job's kernel (it reads d_qpos / d_prev_qpos / d_ee rows
     bool reward_in_flight = false;            //  that a reset on the caller's stream overwrites): egp_engine_reset waits for it
     std::vector<hipEvent_t> k_beg, k_end;     // per substep, when profiling K1
@@ -201,8 +185,7 @@ struct Group {
     unsigned long long seq = 0;
     bool polled = false;                      // the launch in flight publishes to h_flag
     bool prof_now = false;                    // this env-step brackets its K1 launches with events
-    bool pipelined_job = false;               // mode of the env-step in flight (fixed when it is posted)
-    bool server_job = false;
+    bool server_job = false;                  // form of the env-step in flight (fixed when it is posted)
     char err[256] = "";
     // timing (leader only)
     double phys_s = 0.0, wait_s = 0.0, k1_ms = 0.0, ev_overhead_ms = 0.0;
@@ -222,8 +205,6 @@ struct egp_engine {
     int ld_s = 0, ld_m = 0, off_qpos = 0, off_qvel = 0, off_bias = 0;   // state / inertia row strides (doubles)
     std::atomic<bool> profile_k1{false};
     int profile_every = 1;                    // bracket K1 with events on every Nth env-step of a group
-    bool zero_copy = false;                   // K1 reads state rows / writes torques in pinned host memory directly
-    bool flag_poll = false;                   // leader polls a pinned completion flag instead of hipStreamSynchronize
     double *hd_state = nullptr, *hd_torque = nullptr, *hd_qM = nullptr, *hd_ee = nullptr;   // device-side aliases of h_state / h_torque / h_qM
     // Resident-K1 mode: the slices' go words live in FINE-GRAINED DEVICE memory that the host threads write through the PCIe
     // BAR (posted stores); the resident waves then poll HBM instead of host memory -- one PCIe read round trip less per
@@ -244,25 +225,19 @@ struct egp_engine {
     bool device_dynamics = false;             // K8 supplies qM / qfrc_bias from the drained (qpos, qvel) each substep
     double *d_bias = nullptr;                 // [n_env][nv] K8's bias (device-dynamics mode)
     int reward_delay_us = 0;                  // EGP_REWARD_JOB_DELAY_US (tests): a spin kernel ahead of the reward job's kernel
-    // EGP_WAIT_QUERY=1: egp_engine_wait polls the env-step kernel's completion event on the host (hipEventQuery) and returns
-    // without putting an event wait on the caller's stream: what the caller launches next is ordered by the host instead of by
-    // a dependency between two hardware queues (~20 us on this platform, tools/probes/stream_hop.py)
-    bool wait_query = false;
-    int spin_us = 150;                        // EGP_SPIN_US: the engine's threads (and a caller in egp_engine_wait, 4 x as long) poll this long for
-                                              // the next env-step / its end before sleeping on a condition variable. Round 2 measured no gain and left
-                                              // it at 0; round 3's in-lease A/B (tools/probes/ab_env.sh, four alternating pairs): 99.3 against
-                                              // 101.2 ms of T_sample, every pair better (150 vs 500: equal) -- a futex wake-up per env-step and
-                                              // thread is ~2 % of the rollout. Between rollouts the threads sleep after 150 us.
+    // The engine's threads (and a caller in egp_engine_wait, 4 x as long) poll this long for the next env-step / its end before
+    // sleeping on a condition variable: a futex wake-up per env-step and thread is ~2 % of the rollout (round 3's in-lease A/B,
+    // 99.3 against 101.2 ms of T_sample; 150 vs 500 us: equal). Between rollouts the threads sleep after 150 us.
+    static constexpr int spin_us = 150;
     double *d_state = nullptr, *d_qM = nullptr, *d_prev_qpos = nullptr, *d_qpos = nullptr, *d_qvel = nullptr, *d_torque = nullptr, *d_ee = nullptr;
     double *h_state = nullptr, *h_qM = nullptr, *h_qpos = nullptr, *h_qvel = nullptr, *h_torque = nullptr, *h_ee = nullptr,
            *h_headz = nullptr, *h_xpos = nullptr;
     std::vector<Group> groups;
     std::vector<int64_t> epoch;               // last drained inertia epoch per env (-1 = never)
-    std::vector<int> env_group, env_chunk, env_slice;
+    std::vector<int> env_group, env_slice;
     int *h_reset_list = nullptr, *hd_reset_list = nullptr;   // pinned (env, qM_changed) pairs of the reset in flight
     hipEvent_t reset_done = nullptr;                          // recorded behind the scatter kernel of the last reset
     bool reset_pending = false;
-    hipEvent_t setup_ev = nullptr;                            // group-stream ticks: the caller's stream -> a group's stream
 };
 
 namespace {
@@ -305,7 +280,7 @@ __global__ __launch_bounds__(256) void k_engine_reset_scatter(const int *__restr
         for (int c = threadIdx.x; c < nM; c += blockDim.x) d_qM[(long)e * ld_m + c] = h_qM[(long)e * ld_m + c];
 }
 
-// mark_dirty: flag the env's group / chunk / slice for an inertia upload (the substep loop); egp_engine_reset
+// mark_dirty: flag the env's group / slice for an inertia upload (the substep loop); egp_engine_reset
 // uploads the rows it drained itself and must leave the flags of its neighbours alone
 int drain_env(egp_engine *E, int env, bool with_xpos, bool mark_dirty = true) {
     double *row = E->h_state + (size_t)env * E->ld_s;
@@ -321,7 +296,6 @@ int drain_env(egp_engine *E, int env, bool with_xpos, bool mark_dirty = true) {
     if (qM && mark_dirty) {
         Group &G = E->groups[E->env_group[env]];
         G.qM_dirty.store(1, std::memory_order_relaxed);
-        if (G.n_chunks) G.chunks[E->env_chunk[env]].qM_dirty.store(1, std::memory_order_relaxed);
         if (G.srv.n_slices) G.srv.dirty[E->env_slice[env]].store(1, std::memory_order_relaxed);
     }
     if (with_xpos) {
@@ -347,13 +321,13 @@ void fail(Group &G, int code, const char *what, const char *detail) {
         if (_e != hipSuccess) fail(G, EGP_E_HIP, #expr, hipGetErrorString(_e)); \
     } while (0)
 
-// leader only: K1 over the whole group + torque download
+// leader only (per-substep form): K1 over the whole group, state rows read and torques written in pinned host memory
 void enqueue_k1(egp_engine *E, Group &G, int substep) {
     const int m = G.e1 - G.e0;
     const bool prof = G.prof_now;
     if (prof) G_HIP(hipEventRecord(G.k_beg[substep], G.stream));
-    const double *st = (E->zero_copy ? E->hd_state : E->d_state) + (size_t)G.e0 * E->ld_s;
-    double *tq = (E->zero_copy ? E->hd_torque : E->d_torque) + (size_t)G.e0 * E->nu;
+    const double *st = E->hd_state + (size_t)G.e0 * E->ld_s;
+    double *tq = E->hd_torque + (size_t)G.e0 * E->nu;
     const double *bias = st + E->off_bias;
     long ld_bias = E->ld_s;
     if (E->device_dynamics) {        // K8: inertia and bias force of the state just drained, straight into HBM
@@ -369,9 +343,6 @@ void enqueue_k1(egp_engine *E, Group &G, int substep) {
                                           G.polled ? G.d_done : nullptr, G.hd_flag, G.polled ? ++G.seq : 0);
     if (rc != EGP_OK) fail(G, rc, "K1 launch", egp_last_error());
     if (prof) G_HIP(hipEventRecord(G.k_end[substep], G.stream));
-    if (!E->zero_copy)
-        G_HIP(hipMemcpyAsync(E->h_torque + (size_t)G.e0 * E->nu, E->d_torque + (size_t)G.e0 * E->nu, (size_t)m * E->nu * sizeof(double),
-                             hipMemcpyDeviceToHost, G.stream));
 }
 
 // envs of the group this env-step advances (finished slots of a rollout's tail are skipped)
@@ -390,7 +361,7 @@ void run_step(egp_engine *E, Group &G, int tid) {
     if (leader) {
         G.prof_now = E->profile_k1.load(std::memory_order_relaxed) && !G.k_beg.empty() && (G.job % E->profile_every == 0);
         if (G.prof_now) G.k1_env_substeps += stepped_envs(G) * (long)E->frame_skip;
-        G.polled = E->flag_poll && E->zero_copy && E->ctx->pd_variant == 0;
+        G.polled = E->ctx->pd_variant == 0;          // (the tree kernels publish a completion flag; the others: hipStreamSynchronize)
         if (G.ready) G_HIP(hipStreamWaitEvent(G.stream, G.ready, 0));
         // env.prev_qpos = data.qpos.copy() (humanoid_v1.py:182): kept on the device for the reward kernel
         G_HIP(hipMemcpyAsync(E->d_prev_qpos + (size_t)G.e0 * E->nq, E->d_qpos + (size_t)G.e0 * E->nq, (size_t)m * E->nq * sizeof(double),
@@ -432,11 +403,7 @@ void run_step(egp_engine *E, Group &G, int tid) {
         if (leader) {
             G.phys_s += secs(t1, clk::now());
             if (G.status.load() == EGP_OK) {
-                if (!E->zero_copy)
-                    G_HIP(hipMemcpyAsync(E->d_state + (size_t)G.e0 * E->ld_s, E->h_state + (size_t)G.e0 * E->ld_s,
-                                         (size_t)m * E->ld_s * sizeof(double), hipMemcpyHostToDevice, G.stream));
                 if (G.qM_dirty.exchange(0)) {
-                    for (int c = 0; c < G.n_chunks; ++c) G.chunks[c].qM_dirty.store(0, std::memory_order_relaxed);
                     G_HIP(hipMemcpyAsync(E->d_qM + (size_t)G.e0 * E->ld_m, E->h_qM + (size_t)G.e0 * E->ld_m,
                                          (size_t)m * E->ld_m * sizeof(double), hipMemcpyHostToDevice, G.stream));
                     G.qM_uploads += 1;
@@ -468,8 +435,7 @@ void run_step(egp_engine *E, Group &G, int tid) {
 }
 
 inline bool server_mode(const egp_engine *E, const Group &G) {
-    return (!E->device_dynamics || E->server_dyn_ok) && E->server_ok && G.srv.n_slices > 0 && E->flag_poll && E->zero_copy &&
-           E->ctx->pd_variant == 0 && E->ctx->tree58;
+    return (!E->device_dynamics || E->server_dyn_ok) && E->server_ok && G.srv.n_slices > 0 && E->ctx->pd_variant == 0 && E->ctx->tree58;
 }
 
 // Resident-K1 env-step: one launch of k_pd_server_tree58 serves all substeps. Every host thread owns a few slices
@@ -621,7 +587,6 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
         return;
     }
     G.qM_dirty.store(0, std::memory_order_relaxed);
-    for (int c = 0; c < G.n_chunks; ++c) G.chunks[c].qM_dirty.store(0, std::memory_order_relaxed);
     if (G.prof_now) {
         G_HIP(hipStreamSynchronize(G.stream));
         float ms = 0.f;
@@ -632,135 +597,6 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
     }
 }
 
-inline bool pipelined_mode(const egp_engine *E, const Group &G) {
-    return !E->device_dynamics && G.n_chunks >= 2 && G.n_threads >= 3 && E->flag_poll && E->zero_copy && E->ctx->pd_variant == 0;
-}
-
-// Pipelined env-step: the group is cut into chunks, each with its own K1 launch and completion flag.
-//   leader (tid 0): owns the stream. Launches K1(chunk, s+1) as soon as every worker has finished the physics of
-//                   (chunk, s) -- no physics of its own, so a launch never waits behind a slice of envs.
-//   workers:        walk the chunks in order; for (chunk, s) spin on the chunk's pinned flag until the torques of
-//                   substep s have landed, advance their slice of the chunk, bump the chunk's counter.
-// While K1 of one chunk is in flight (launch + PCIe reads + solve + flag write, ~30 us whatever the size) the
-// workers are inside the other chunks, so the fixed K1 latency is hidden behind physics instead of added to it.
-void run_step_pipelined(egp_engine *E, Group &G, int tid) {
-    const int FS = E->frame_skip;
-    const int NC = G.n_chunks;
-    const int W = G.n_threads - 1;
-    auto launch = [&](Chunk &C, int substep, int ci) {
-        const bool prof = G.prof_now;
-        const int ev = substep * NC + ci;
-        if (prof) G_HIP(hipEventRecord(G.k_beg[ev], C.stream));
-        const double *st = E->hd_state + (size_t)C.e0 * E->ld_s;
-        int rc = egp_launch_pd_torque_strided(E->ctx, st + E->off_qpos, E->ld_s, st + E->off_qvel, E->ld_s, st + E->off_bias, E->ld_s,
-                                              E->d_qM + (size_t)C.e0 * E->ld_m, E->ld_m, G.action + (size_t)C.e0 * E->nu, C.e1 - C.e0,
-                                              E->hd_torque + (size_t)C.e0 * E->nu, C.stream, C.d_done, C.hd_flag, ++C.seq);
-        if (rc != EGP_OK) fail(G, rc, "K1 launch", egp_last_error());
-        if (prof) G_HIP(hipEventRecord(G.k_end[ev], C.stream));
-    };
-    if (tid == 0) {
-        G.prof_now = E->profile_k1.load(std::memory_order_relaxed) && (int)G.k_beg.size() >= FS * NC && (G.job % E->profile_every == 0);
-        if (G.prof_now) G.k1_env_substeps += stepped_envs(G) * (long)E->frame_skip;
-        if (G.ready) G_HIP(hipStreamWaitEvent(G.stream, G.ready, 0));
-        G_HIP(hipMemcpyAsync(E->d_prev_qpos + (size_t)G.e0 * E->nq, E->d_qpos + (size_t)G.e0 * E->nq,
-                             (size_t)(G.e1 - G.e0) * E->nq * sizeof(double), hipMemcpyDeviceToDevice, G.stream));
-        for (int c = 0; c < NC; ++c) {
-            if (G.chunks[c].own_stream && G.ready) G_HIP(hipStreamWaitEvent(G.chunks[c].stream, G.ready, 0));
-            launch(G.chunks[c], 0, c);
-        }
-        for (int s = 0; s < FS; ++s) {
-            const bool last = s == FS - 1;
-            for (int c = 0; c < NC; ++c) {
-                Chunk &C = G.chunks[c];
-                const long want = (long)W * (s + 1);
-                int spins = 0;
-                while (C.phys_done.load(std::memory_order_acquire) < want) {
-                    if (++spins < 4096) cpu_relax();
-                    else std::this_thread::yield();
-                }
-                if (G.status.load(std::memory_order_relaxed) != EGP_OK) continue;
-                if (C.qM_dirty.exchange(0)) {
-                    G_HIP(hipMemcpyAsync(E->d_qM + (size_t)C.e0 * E->ld_m, E->h_qM + (size_t)C.e0 * E->ld_m,
-                                         (size_t)(C.e1 - C.e0) * E->ld_m * sizeof(double), hipMemcpyHostToDevice, C.stream));
-                    G.qM_uploads += 1;
-                }
-                if (!last) launch(C, s + 1, c);
-            }
-        }
-        G.qM_dirty.store(0, std::memory_order_relaxed);
-        if (G.status.load() == EGP_OK) {
-            const int m = G.e1 - G.e0;
-            G_HIP(hipMemcpyAsync(E->d_qpos + (size_t)G.e0 * E->nq, E->h_qpos + (size_t)G.e0 * E->nq, (size_t)m * E->nq * sizeof(double),
-                                 hipMemcpyHostToDevice, G.stream));
-            G_HIP(hipMemcpyAsync(E->d_qvel + (size_t)G.e0 * E->nv, E->h_qvel + (size_t)G.e0 * E->nv, (size_t)m * E->nv * sizeof(double),
-                                 hipMemcpyHostToDevice, G.stream));
-            G_HIP(hipMemcpyAsync(E->d_ee + (size_t)G.e0 * 15, E->h_ee + (size_t)G.e0 * 15, (size_t)m * 15 * sizeof(double),
-                                 hipMemcpyHostToDevice, G.stream));
-            G_HIP(hipEventRecord(G.done, G.stream));
-        }
-        if (G.prof_now && G.status.load() == EGP_OK) {
-            G_HIP(hipStreamSynchronize(G.stream));
-            for (int c = 0; c < NC; ++c)
-                if (G.chunks[c].own_stream) G_HIP(hipStreamSynchronize(G.chunks[c].stream));
-            for (int i = 0; i < FS * NC; ++i) {
-                float ms = 0.f;
-                if (hipEventElapsedTime(&ms, G.k_beg[i], G.k_end[i]) == hipSuccess) {
-                    G.k1_ms += ms > G.ev_overhead_ms ? ms - G.ev_overhead_ms : 0.0;
-                    G.k1_launches += 1;
-                }
-            }
-        }
-        return;
-    }
-    const int w = tid - 1;
-    const bool timekeeper = w == 0;
-    double t_wait = 0.0, t_phys = 0.0;
-    for (int s = 0; s < FS; ++s) {
-        const bool last = s == FS - 1;
-        for (int c = 0; c < NC; ++c) {
-            Chunk &C = G.chunks[c];
-            const unsigned long long want = C.base + (unsigned long long)s + 1ull;
-            auto t0 = clk::now();
-            {
-                const auto deadline = t0 + std::chrono::seconds(5);
-                long spins = 0;
-                while (__atomic_load_n(C.h_flag, __ATOMIC_ACQUIRE) < want) {
-                    cpu_relax();
-                    if ((++spins & 0x3FFF) == 0) {
-                        if (G.status.load(std::memory_order_relaxed) != EGP_OK) break;
-                        if (clk::now() > deadline) {       // ask the runtime; a flag that is still behind is an error
-                            (void)hipStreamSynchronize(C.stream);
-                            if (__atomic_load_n(C.h_flag, __ATOMIC_ACQUIRE) < want) fail(G, EGP_E_HIP, "K1 completion flag", "timed out");
-                            break;
-                        }
-                    }
-                }
-            }
-            auto t1 = clk::now();
-            if (G.status.load(std::memory_order_relaxed) == EGP_OK) {
-                const int mc = C.e1 - C.e0;
-                const int my0 = C.e0 + (int)((long)mc * w / W), my1 = C.e0 + (int)((long)mc * (w + 1) / W);
-                for (int e = my0; e < my1; ++e) {
-                    if (G.has_active && !G.active[e]) continue;
-                    if (E->vt->step(E->vt->user, e, E->h_torque + (size_t)e * E->nu) != 0 || drain_env(E, e, last) != EGP_OK) {
-                        char msg[64];
-                        snprintf(msg, sizeof(msg), "env %d", e);
-                        fail(G, EGP_E_PHYSICS, "physics backend failed", msg);
-                        break;
-                    }
-                }
-            }
-            C.phys_done.fetch_add(1, std::memory_order_acq_rel);
-            if (timekeeper) {
-                auto t2 = clk::now();
-                t_wait += secs(t0, t1);
-                t_phys += secs(t1, t2);
-            }
-        }
-    }
-    if (timekeeper) { G.wait_s += t_wait; G.phys_s += t_phys; }
-}
-
 void thread_main(egp_engine *E, int gi, int tid) {
     Group &G = E->groups[gi];
     (void)hipSetDevice(E->ctx->device);
@@ -769,8 +605,8 @@ void thread_main(egp_engine *E, int gi, int tid) {
         // the next env-step of a group usually arrives within a few hundred microseconds (the caller's reward /
         // observation / policy launches): spin that long before going to sleep on the condition variable
         bool got = false;
-        if (E->spin_us > 0) {
-            const auto until = clk::now() + std::chrono::microseconds(E->spin_us);
+        {
+            const auto until = clk::now() + std::chrono::microseconds(egp_engine::spin_us);
             int n = 0;
             while (!(got = G.job_pub.load(std::memory_order_acquire) != seen)) {
                 cpu_relax();
@@ -786,7 +622,6 @@ void thread_main(egp_engine *E, int gi, int tid) {
             seen = G.job;
         }
         if (G.server_job) run_step_server(E, G, tid);
-        else if (G.pipelined_job) run_step_pipelined(E, G, tid);
         else run_step(E, G, tid);
         {
             std::lock_guard<std::mutex> lk(G.mu);
@@ -801,7 +636,7 @@ void thread_main(egp_engine *E, int gi, int tid) {
 int make_profile_events(egp_engine *E) {
     for (auto &G : E->groups) {
         if (!G.k_beg.empty()) continue;
-        const int n_ev = E->frame_skip * std::max(1, G.n_chunks);
+        const int n_ev = E->frame_skip;
         G.k_beg.resize(n_ev);
         G.k_end.resize(n_ev);
         for (int s = 0; s < n_ev; ++s) {
@@ -850,7 +685,6 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     E->ld_m = ((E->nM + 15) / 16) * 16;
     E->epoch.assign(d->n_env, -1);
     E->env_group.assign(d->n_env, 0);
-    E->env_chunk.assign(d->n_env, 0);
     E->env_slice.assign(d->n_env, 0);
     const size_t N = (size_t)E->n_env;
 #define E_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { egp::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); egp_engine_destroy(E); return EGP_E_HIP; } } while (0)
@@ -874,37 +708,23 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     E_TRY(hipHostMalloc((void **)&E->h_headz, N * sizeof(double), hipHostMallocDefault));
     E_TRY(hipHostMalloc((void **)&E->h_xpos, N * E->nbody * 3 * sizeof(double), hipHostMallocDefault));
     {
-        const char *zc = getenv("EGP_ZERO_COPY");
-        E->zero_copy = !(zc && atoi(zc) == 0);
-        if (const char *su = getenv("EGP_SPIN_US")) E->spin_us = atoi(su);
-        if (const char *wq = getenv("EGP_WAIT_QUERY")) E->wait_query = atoi(wq) != 0;
+        // zero-copy is the engine's only form: the kernels address the pinned rows directly
+        void *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr, *p5 = nullptr;
+        E_TRY(hipHostGetDevicePointer(&p1, E->h_state, 0));
+        E_TRY(hipHostGetDevicePointer(&p2, E->h_torque, 0));
+        E_TRY(hipHostGetDevicePointer(&p3, E->h_qM, 0));
+        E_TRY(hipHostGetDevicePointer(&p4, E->h_ee, 0));
+        E->hd_state = (double *)p1; E->hd_torque = (double *)p2; E->hd_qM = (double *)p3; E->hd_ee = (double *)p4;
+        E_TRY(hipHostMalloc((void **)&E->h_reset_list, N * 2 * sizeof(int), hipHostMallocDefault));
+        E_TRY(hipHostGetDevicePointer(&p5, E->h_reset_list, 0));
+        E->hd_reset_list = (int *)p5;
+        E_TRY(hipEventCreateWithFlags(&E->reset_done, hipEventDisableTiming));
         if (const char *rd = getenv("EGP_REWARD_JOB_DELAY_US")) E->reward_delay_us = atoi(rd);
-        const char *fp = getenv("EGP_FLAG_POLL");
-        E->flag_poll = !(fp && atoi(fp) == 0);
-        void *p1 = nullptr, *p2 = nullptr;
-        if (E->zero_copy && hipHostGetDevicePointer(&p1, E->h_state, 0) == hipSuccess &&
-            hipHostGetDevicePointer(&p2, E->h_torque, 0) == hipSuccess) {
-            E->hd_state = (double *)p1;
-            E->hd_torque = (double *)p2;
-            void *p3 = nullptr;
-            if (hipHostGetDevicePointer(&p3, E->h_qM, 0) == hipSuccess) E->hd_qM = (double *)p3;
-            void *p4 = nullptr;
-            if (hipHostGetDevicePointer(&p4, E->h_ee, 0) == hipSuccess) E->hd_ee = (double *)p4;
-        } else {
-            E->zero_copy = false;
-        }
-    }
-    if (E->zero_copy && E->hd_qM && E->hd_ee) {
-        void *p = nullptr;
-        if (hipHostMalloc((void **)&E->h_reset_list, N * 2 * sizeof(int), hipHostMallocDefault) == hipSuccess &&
-            hipHostGetDevicePointer(&p, E->h_reset_list, 0) == hipSuccess &&
-            hipEventCreateWithFlags(&E->reset_done, hipEventDisableTiming) == hipSuccess)
-            E->hd_reset_list = (int *)p;
     }
     memset(E->h_state, 0, N * E->ld_s * sizeof(double));
     {
         const char *bg = getenv("EGP_BAR_GO");
-        E->bar_go = E->zero_copy && E->hd_state && !(bg && atoi(bg) == 0);    // default on since the stores are fenced (see the field)
+        E->bar_go = !(bg && atoi(bg) == 0);    // default on since the stores are fenced (see the field)
         if (E->bar_go) {       // the host stores straight into device memory: only where the whole of it is mapped through the PCIe BAR
             int large_bar = 0;
             if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) != hipSuccess || !large_bar) {
@@ -936,7 +756,6 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
         E_TRY(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
         E_TRY(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
         E_TRY(hipEventCreateWithFlags(&G.reward_done, hipEventDisableTiming));
-        E_TRY(hipEventCreateWithFlags(&G.chain_done, hipEventDisableTiming));
         E_TRY(hipMalloc((void **)&G.d_done, sizeof(unsigned)));
         E_TRY(hipMemset(G.d_done, 0, sizeof(unsigned)));
         E_TRY(hipHostMalloc((void **)&G.h_flag, sizeof(unsigned long long), hipHostMallocDefault));
@@ -946,48 +765,18 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
             E_TRY(hipHostGetDevicePointer(&p, G.h_flag, 0));
             G.hd_flag = (unsigned long long *)p;
         }
-        // pipelined mode: cut the group into chunks (EGP_CHUNKS, default 2; every chunk keeps >= 8 envs)
-        int want_chunks = 2;
-        if (const char *ck = getenv("EGP_CHUNKS")) want_chunks = atoi(ck);
-        const int m = G.e1 - G.e0;
-        const int nc = std::min(want_chunks, m / 8);
-        if (nc >= 2 && G.n_threads >= 3) {
-            G.n_chunks = nc;
-            G.chunks.reset(new Chunk[nc]);
-            for (int c = 0; c < nc; ++c) {
-                Chunk &C = G.chunks[c];
-                C.e0 = G.e0 + (int)((long)m * c / nc);
-                C.e1 = G.e0 + (int)((long)m * (c + 1) / nc);
-                for (int e = C.e0; e < C.e1; ++e) E->env_chunk[e] = c;
-                E_TRY(hipMalloc((void **)&C.d_done, sizeof(unsigned)));
-                E_TRY(hipMemset(C.d_done, 0, sizeof(unsigned)));
-                E_TRY(hipHostMalloc((void **)&C.h_flag, sizeof(unsigned long long), hipHostMallocDefault));
-                *C.h_flag = 0;
-                void *p = nullptr;
-                E_TRY(hipHostGetDevicePointer(&p, C.h_flag, 0));
-                C.hd_flag = (unsigned long long *)p;
-                C.stream = G.stream;
-                const char *cs = getenv("EGP_CHUNK_STREAMS");
-                if (cs && atoi(cs) != 0 && c > 0) {
-                    E_TRY(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
-                    C.own_stream = true;
-                }
-            }
-        }
-        // resident-K1 mode: EGP_SERVER_SLICES (default 8) slices per thread, whole 4-env blocks each
+        // resident K1: 8 slices per thread (fewer for small groups), whole 4-env blocks each
         {
             Server &S = G.srv;
             const int m = G.e1 - G.e0;
             const int nb = (m + 3) / 4;
             int per_thread = 8;
-            if (const char *sp = getenv("EGP_SERVER_SLICES")) per_thread = std::max(1, atoi(sp));
             while (per_thread > 1 && nb < per_thread * G.n_threads) per_thread /= 2;
             const int ns = per_thread * G.n_threads;
-            if (nb >= ns && E->hd_qM && E->hd_ee) {
+            if (nb >= ns) {
                 S.n_slices = ns;
                 S.n_blocks = nb;
                 S.per_thread = per_thread;
-                if (const char *bl = getenv("EGP_SERVER_BALANCE")) S.balance = atoi(bl) != 0;
                 S.can_balance = ns <= 512 && G.n_threads <= 64;
                 S.e0.resize(ns);
                 S.e1.resize(ns);
@@ -1033,23 +822,16 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
         }
     }
     {
-        // the resident kernel's blocks wait on the host, so all of them (every group's) must fit on the chip at once
-        int max_blocks = 512;
-        if (const char *mb = getenv("EGP_SERVER_MAX_BLOCKS")) max_blocks = atoi(mb);
+        // The resident kernel's workgroups wait on the host, so ALL of them (every group's) must be resident at the same time: a
+        // workgroup that waits for a CU while its slice's owner waits for its torques stalls the env-step until another group's
+        // kernel ends -- with 2 x 256 workgroups on 256 CUs (2 048 slots in two groups; one 346-VGPR workgroup fits a CU) that
+        // went as far as the kernel-side timeout. The bound is what the occupancy calculator says the chip holds.
         const char *sv = getenv("EGP_SERVER");
-        E->server_ok = all_groups_sliced && total_server_blocks <= max_blocks && !(sv && atoi(sv) == 0);
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
-            E->server_dyn_ok = total_server_blocks <= prop.multiProcessorCount &&
-                               egp_pd_server_dyn_lds_bytes() + 48 * 1024 <= (size_t)prop.maxSharedMemoryPerMultiProcessor;
+        const int cap = egp_pd_server_resident_blocks(ctx->device, false), cap_dyn = egp_pd_server_resident_blocks(ctx->device, true);
+        E->server_ok = all_groups_sliced && total_server_blocks <= cap && !(sv && atoi(sv) == 0);
+        E->server_dyn_ok = total_server_blocks <= cap_dyn;
     }
 #undef E_TRY
-    const char *prof = getenv("EGP_PROFILE_K1");
-    if (prof && atoi(prof) != 0) {
-        int rc = make_profile_events(E);
-        if (rc != EGP_OK) { egp_engine_destroy(E); return rc; }
-        E->profile_k1 = true;
-    }
     for (int g = 0; g < E->n_groups; ++g)
         for (int t = 0; t < E->groups[g].n_threads; ++t) E->groups[g].threads.emplace_back(thread_main, E, g, t);
     *out = E;
@@ -1066,11 +848,6 @@ int egp_engine_destroy(egp_engine *E) {
         }
         for (auto &t : G.threads)
             if (t.joinable()) t.join();
-        for (int c = 0; c < G.n_chunks; ++c) {
-            if (G.chunks[c].d_done) (void)hipFree(G.chunks[c].d_done);
-            if (G.chunks[c].h_flag) (void)hipHostFree(G.chunks[c].h_flag);
-            if (G.chunks[c].own_stream) (void)hipStreamDestroy(G.chunks[c].stream);
-        }
         {
             Server &S = G.srv;
             void *dv[] = {S.d_block_slice, S.d_trace};
@@ -1084,14 +861,12 @@ int egp_engine_destroy(egp_engine *E) {
         if (G.stream) (void)hipStreamDestroy(G.stream);
         if (G.done) (void)hipEventDestroy(G.done);
         if (G.reward_done) (void)hipEventDestroy(G.reward_done);
-        if (G.chain_done) (void)hipEventDestroy(G.chain_done);
         for (auto ev : G.k_beg) (void)hipEventDestroy(ev);
         for (auto ev : G.k_end) (void)hipEventDestroy(ev);
     }
     void *dev[] = {E->d_state, E->d_qM, E->d_prev_qpos, E->d_qpos, E->d_qvel, E->d_torque, E->d_ee, E->d_bias};
     for (void *p : dev) if (p) (void)hipFree(p);
     if (E->reset_done) (void)hipEventDestroy(E->reset_done);
-    if (E->setup_ev) (void)hipEventDestroy(E->setup_ev);
     void *host[] = {E->h_state, E->h_qM, E->h_qpos, E->h_qvel, E->h_torque, E->h_ee, E->h_headz, E->h_xpos, E->h_reset_list};
     for (void *p : host) if (p) (void)hipHostFree(p);
     delete E;
@@ -1151,7 +926,7 @@ int egp_engine_reset(egp_engine *E, const int32_t *ids, int32_t n, const double 
         }
         new_qM[k] = !E->vt->inertia_epoch || E->epoch[e] != before;
     }
-    if (E->hd_reset_list && n > 0) {
+    if (n > 0) {
         for (int k = 0; k < n; ++k) { E->h_reset_list[2 * k] = ids[k]; E->h_reset_list[2 * k + 1] = new_qM[k]; }
         k_engine_reset_scatter<<<dim3(n), dim3(256), 0, s>>>(E->hd_reset_list, E->hd_state, E->ld_s, E->off_qpos, E->off_qvel, E->hd_ee,
                                                               E->hd_qM, E->ld_m, E->nM, E->nq, E->nv, E->d_state, E->d_qpos, E->d_qvel,
@@ -1159,21 +934,6 @@ int egp_engine_reset(egp_engine *E, const int32_t *ids, int32_t n, const double 
         EGP_HIP_CHECK(hipGetLastError());
         EGP_HIP_CHECK(hipEventRecord(E->reset_done, s));
         E->reset_pending = true;
-        return EGP_OK;
-    }
-    int k = 0;
-    while (k < n) {                  // upload maximal runs of consecutive env ids
-        int j = k;
-        bool any_qM = new_qM[k];
-        while (j + 1 < n && ids[j + 1] == ids[j] + 1) { ++j; any_qM = any_qM || new_qM[j]; }
-        const size_t e0 = ids[k], m = (size_t)(j - k + 1);
-        EGP_HIP_CHECK(hipMemcpyAsync(E->d_state + e0 * E->ld_s, E->h_state + e0 * E->ld_s, m * E->ld_s * sizeof(double), hipMemcpyHostToDevice, s));
-        if (any_qM)
-            EGP_HIP_CHECK(hipMemcpyAsync(E->d_qM + e0 * E->ld_m, E->h_qM + e0 * E->ld_m, m * E->ld_m * sizeof(double), hipMemcpyHostToDevice, s));
-        EGP_HIP_CHECK(hipMemcpyAsync(E->d_qpos + e0 * E->nq, E->h_qpos + e0 * E->nq, m * E->nq * sizeof(double), hipMemcpyHostToDevice, s));
-        EGP_HIP_CHECK(hipMemcpyAsync(E->d_qvel + e0 * E->nv, E->h_qvel + e0 * E->nv, m * E->nv * sizeof(double), hipMemcpyHostToDevice, s));
-        EGP_HIP_CHECK(hipMemcpyAsync(E->d_ee + e0 * 15, E->h_ee + e0 * 15, m * 15 * sizeof(double), hipMemcpyHostToDevice, s));
-        k = j + 1;
     }
     return EGP_OK;
 }
@@ -1198,12 +958,6 @@ int egp_engine_step_async(egp_engine *E, int32_t group, const double *action, co
         G.srv.base = G.srv.seq;
         G.srv.seq += (unsigned long long)E->frame_skip + 1ull;
     }
-    G.pipelined_job = !G.server_job && pipelined_mode(E, G);
-    if (G.pipelined_job)
-        for (int c = 0; c < G.n_chunks; ++c) {
-            G.chunks[c].base = G.chunks[c].seq;
-            G.chunks[c].phys_done.store(0, std::memory_order_relaxed);
-        }
     G.pending = G.n_threads;
     G.pending_pub.store(G.n_threads, std::memory_order_relaxed);
     G.job += 1;
@@ -1231,8 +985,8 @@ int egp_engine_wait(egp_engine *E, int32_t group, void *stream) {
     EGP_REQUIRE(group >= 0 && group < E->n_groups, "group out of range");
     Group &G = E->groups[group];
     bool done = false;
-    if (E->spin_us > 0) {               // an env-step takes a few hundred microseconds: poll before sleeping
-        const auto until = clk::now() + std::chrono::microseconds(4 * E->spin_us);
+    {                                   // an env-step takes a few hundred microseconds: poll before sleeping
+        const auto until = clk::now() + std::chrono::microseconds(4 * egp_engine::spin_us);
         int n = 0;
         while (!(done = G.pending_pub.load(std::memory_order_acquire) == 0)) {
             cpu_relax();
@@ -1248,15 +1002,7 @@ int egp_engine_wait(egp_engine *E, int32_t group, void *stream) {
         return G.status.load();
     }
     // (a caller that works on the group's own stream is already ordered behind the env-step's kernel)
-    if ((hipStream_t)stream != G.stream) {
-        if (E->wait_query) {
-            hipError_t q;
-            while ((q = hipEventQuery(G.done)) == hipErrorNotReady) cpu_relax();
-            EGP_HIP_CHECK(q);
-        } else {
-            EGP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, G.done, 0));
-        }
-    }
+    if ((hipStream_t)stream != G.stream) EGP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, G.done, 0));
     return EGP_OK;
 }
 
@@ -1265,63 +1011,14 @@ void *egp_engine_group_stream(egp_engine *E, int32_t group) {
     return E->groups[group].stream;
 }
 
-namespace {
-// The stream a group's tick runs on. group_streams: the group's own engine stream, so that policy -> env-step kernel ->
-// filter -> policy is one in-order queue (a dependency between two streams costs ~20 us on this platform, one inside a
-// stream ~3 us: tools/probes/stream_hop.py); else the caller's stream with an event either side of the env-step.
-inline hipStream_t tick_stream(const egp_rollout_tick *d, int group) {
-    return d->group_streams ? d->eng->groups[group].stream : (hipStream_t)d->stream;
-}
-// order a group's stream behind what the caller's stream holds now (rollout set-up, a freshly computed episode pool)
-inline hipError_t follow_caller_stream(const egp_rollout_tick *d, hipStream_t s) {
-    egp_engine *E = d->eng;
-    if (!E->setup_ev) { hipError_t e = hipEventCreateWithFlags(&E->setup_ev, hipEventDisableTiming); if (e != hipSuccess) return e; }
-    hipError_t e = hipEventRecord(E->setup_ev, (hipStream_t)d->stream);
-    return e != hipSuccess ? e : hipStreamWaitEvent(s, E->setup_ev, 0);
-}
-}  // namespace
-
-// Host-visible DEVICE memory (fine-grained HBM, written by the host through the PCIe BAR): see include/egopose_hip.h.
-int egp_hostvis_alloc(int32_t device, int64_t bytes, void **ptr) {
-    EGP_REQUIRE(ptr && bytes > 0, "bad host-visible allocation");
-    *ptr = nullptr;
-    int large_bar = 0;
-    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large_bar) {
-        (void)hipGetLastError();
-        return EGP_E_STATE;           // not every byte of device memory is reachable from the host on this system
-    }
-    void *p = nullptr;
-    EGP_HIP_CHECK(hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained));
-    EGP_HIP_CHECK(hipMemset(p, 0, (size_t)bytes));
-    EGP_HIP_CHECK(hipDeviceSynchronize());
-    *ptr = p;
-    return EGP_OK;
-}
-int egp_hostvis_free(void *ptr) {
-    if (ptr) EGP_HIP_CHECK(hipFree(ptr));
-    return EGP_OK;
-}
-void egp_host_store_fence(void) {
-#if defined(__x86_64__)
-    _mm_sfence();
-#else
-    __atomic_thread_fence(__ATOMIC_SEQ_CST);
-#endif
-}
-
 int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, void *ready_event,
                          int32_t apply_pending, const double *zf_cur, double *zf_new) {
-    EGP_REQUIRE(d && d->ctx && d->eng && (ready_event || d->group_streams), "NULL pointer");
+    EGP_REQUIRE(d && d->ctx && d->eng && ready_event, "NULL pointer");
     EGP_REQUIRE(!apply_pending || (d->defer_apply && k > 0 && zf_cur && zf_new), "a pending apply pass needs defer_apply, k > 0 and the filter states");
     EGP_REQUIRE(group >= 0 && group < d->eng->n_groups, "group out of range");
     EGP_REQUIRE(0 <= a && a < b && b <= d->n_env && b - a <= d->nmax && k >= 0, "slot range / tick out of range");
-    EGP_REQUIRE(!d->group_streams || !d->reward_job, "group-stream ticks launch the reward themselves (reward_job = 0)");
     const int n = b - a, nmax = d->nmax, N = d->n_env;
-    hipStream_t ts = tick_stream(d, group);
-    if (d->group_streams && k == 0) {              // a rollout begins: the slots' first state / observation were set up on the caller's stream
-        EGP_HIP_CHECK(follow_caller_stream(d, ts));
-        d->eng->groups[group].chain_recorded = false;
-    }
+    hipStream_t ts = (hipStream_t)d->stream;
     const size_t soff = (size_t)(group * 2 + (k & 1)) * 24 * nmax;
     int32_t *fl = reinterpret_cast<int32_t *>(d->slab_host + soff);
     int64_t *ti = reinterpret_cast<int64_t *>(d->slab_host + soff + 16 * (size_t)nmax);
@@ -1336,19 +1033,16 @@ int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, in
         fl[3 * nmax + i] = act;
         ti[i] = d->cur_t[e] < d->ctx_T - 1 ? d->cur_t[e] : d->ctx_T - 1;
     }
-    if (d->flags_upload == 0) egp_host_store_fence();     // the slab may be write-combining device memory (egp_hostvis_alloc)
     uint8_t *fbase = d->slab_dev + soff;
     int rc = EGP_OK;
     const size_t row = (size_t)k * N + a;
-    // flags_upload: 1 = a copy-engine transfer in front of the policy step; 2 (default) = the policy kernel moves the slab
-    // itself and reads its context-row indices straight from the pinned copy (one dependent operation less per tick)
+    // The policy kernel moves the flag slab to its device copy itself and reads its context-row indices straight from the pinned
+    // one (one dependent operation less per tick than a copy-engine transfer in front of it).
     if (apply_pending) {
         // the apply pass of the previous env-step's filter (its statistics pass ran in `post`) rides in this policy step:
         // next_states[k - 1] and states[k] are written on the way into the MLP
-        if (d->flags_upload == 1 && (rc = egp_upload_async(fbase, d->slab_host + soff, 24 * (int64_t)nmax, ts)) != EGP_OK) return rc;
-        const bool staged = d->flags_upload == 2;
         rc = egp_policy_gaussian_filter_f32(d->ctx, d->v_out + (size_t)a * d->v_stride, d->v_stride, d->ctx_dim,
-                                            reinterpret_cast<const int64_t *>((staged ? d->slab_host : d->slab_dev) + soff + 16 * (size_t)nmax),
+                                            reinterpret_cast<const int64_t *>(d->slab_host + soff + 16 * (size_t)nmax),
                                             d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv,
                                             // (obs_phase: cur_t of the state = the step counter staged for the PREVIOUS env-step, slab slot (k - 1) & 1)
                                             reinterpret_cast<const int32_t *>(d->slab_dev + (size_t)(group * 2 + ((k - 1) & 1)) * 24 * nmax),
@@ -1356,28 +1050,16 @@ int egp_rollout_tick_pre(const egp_rollout_tick *d, int32_t group, int32_t a, in
                                             d->next_states + (row - N) * d->obs_dim, d->states + row * d->obs_dim, d->zf_workspace,
                                             d->layers, d->n_layers, d->activation, d->log_std,
                                             d->noise ? d->noise + row * d->nu : nullptr, d->actions + row * d->nu, nullptr,
-                                            staged ? d->slab_host + soff : nullptr, staged ? fbase : nullptr, staged ? 24 * (int64_t)nmax : 0, ts);
-    } else if (d->flags_upload == 2) {
+                                            d->slab_host + soff, fbase, 24 * (int64_t)nmax, ts);
+    } else {
         rc = egp_policy_gaussian_staged_f32(d->v_out + (size_t)a * d->v_stride, d->v_stride, d->ctx_dim,
                                             reinterpret_cast<const int64_t *>(d->slab_host + soff + 16 * (size_t)nmax),
                                             d->states + row * d->obs_dim, d->obs_dim, n, d->layers, d->n_layers, d->activation, d->log_std,
                                             d->noise ? d->noise + row * d->nu : nullptr, d->actions + row * d->nu, nullptr,
                                             d->slab_host + soff, fbase, 24 * (int64_t)nmax, ts);
-    } else {
-        if (d->flags_upload && (rc = egp_upload_async(fbase, d->slab_host + soff, 24 * (int64_t)nmax, ts)) != EGP_OK) return rc;
-        rc = egp_policy_gaussian_f32(d->v_out + (size_t)a * d->v_stride, d->v_stride, d->ctx_dim, reinterpret_cast<const int64_t *>(fbase + 16 * (size_t)nmax),
-                                     d->states + row * d->obs_dim, d->obs_dim, n, d->layers, d->n_layers, d->activation, d->log_std,
-                                     d->noise ? d->noise + row * d->nu : nullptr, d->actions + row * d->nu, nullptr, ts);
     }
     if (rc != EGP_OK) return rc;
-    if (d->group_streams) {
-        // the env-step's kernel queues right behind the policy step; the one thing it must not overtake is the reward of the
-        // previous env-step (on the caller's stream, reading the rows this kernel's epilogue rewrites): long finished by then
-        Group &G = d->eng->groups[group];
-        ready_event = (k > 0 && G.reward_in_flight) ? (void *)G.reward_done : nullptr;
-    } else {
-        EGP_HIP_CHECK(hipEventRecord((hipEvent_t)ready_event, ts));
-    }
+    EGP_HIP_CHECK(hipEventRecord((hipEvent_t)ready_event, ts));
     if (d->reward_job) {      // K2 rides behind this env-step's kernel on the engine's stream
         const int32_t *f32 = reinterpret_cast<const int32_t *>(fbase);
         rc = egp_engine_set_reward_job(d->eng, group, f32, f32 + nmax, f32 + 2 * nmax, f32 + 3 * nmax, d->end_reward, d->rewards + row,
@@ -1394,53 +1076,25 @@ int egp_rollout_tick_post(const egp_rollout_tick *d, int32_t group, int32_t a, i
     EGP_REQUIRE(0 <= a && a < b && b <= d->n_env && b - a <= d->nmax && k >= 0, "slot range / tick out of range");
     EGP_REQUIRE(group >= 0 && group < d->eng->n_groups, "group out of range");
     const auto t0 = clk::now();
-    hipStream_t ts = tick_stream(d, group);
+    hipStream_t ts = (hipStream_t)d->stream;
     int rc = egp_engine_wait(d->eng, group, ts);
     if (wait_s) *wait_s = secs(t0, clk::now());
     if (rc != EGP_OK) return rc;
-    if (d->group_streams)          // the running filter statistics: behind the filter launches the other groups issued before this call
-        for (int g2 = 0; g2 < d->eng->n_groups; ++g2)
-            if (g2 != group && d->eng->groups[g2].chain_recorded) EGP_HIP_CHECK(hipStreamWaitEvent(ts, d->eng->groups[g2].chain_done, 0));
     const int n = b - a, nmax = d->nmax, N = d->n_env;
-    {   // diagnostic (EGP_CHAIN_DELAY_US): hold the filter -> policy chain back to measure what a microsecond of it costs the rollout
-        static const int delay_us = [] { const char *e = getenv("EGP_CHAIN_DELAY_US"); return e ? atoi(e) : 0; }();
-        if (delay_us > 0) k_engine_spin<<<dim3(1), dim3(1), 0, ts>>>((long long)delay_us);
-    }
     const size_t soff = (size_t)(group * 2 + (k & 1)) * 24 * nmax;
     const int32_t *f32 = reinterpret_cast<const int32_t *>(d->slab_dev + soff);          // the flags `pre` staged for this env-step
     const size_t row = (size_t)k * N + a;
     // the filter -> policy chain of the next tick starts here: K3 + K6 (-> next_states[k] and states[k + 1]) and K2 before the bookkeeping
-    if (d->post_fused && !d->reward_job) {      // K2's workgroups ride in the filter's first launch
-        rc = egp_post_step_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, d->prev_qpos + (size_t)a * d->nq,
-                               d->ee + (size_t)a * 15, f32, f32 + nmax, f32 + 2 * nmax, f32 + 3 * nmax, n, zf_cur, zf_new, d->zf_clip,
-                               d->next_states + row * d->obs_dim, d->states + (row + N) * d->obs_dim, d->zf_workspace, d->end_reward,
-                               d->rewards + row, d->cinfo + row * 5, ts);
+    if (d->defer_apply)     // statistics pass only: the apply pass is egp_rollout_tick_apply or the next tick's policy step
+        rc = egp_obs_zfilter_stats_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, f32, f32 + 3 * nmax, n, d->zf_workspace, ts);
+    else
+        rc = egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, f32, f32 + 3 * nmax, n, zf_cur, zf_new, d->zf_clip,
+                                 d->next_states + row * d->obs_dim, d->states + (row + N) * d->obs_dim, 0, d->zf_workspace, ts);
+    if (rc != EGP_OK) return rc;
+    if (!d->reward_job) {
+        rc = egp_reward_quat_v3_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->prev_qpos + (size_t)a * d->nq, d->ee + (size_t)a * 15, f32, f32 + nmax,
+                                    f32 + 2 * nmax, f32 + 3 * nmax, d->end_reward, n, d->rewards + row, d->cinfo + row * 5, ts);
         if (rc != EGP_OK) return rc;
-    } else {
-        if (d->defer_apply)     // statistics pass only: the apply pass is egp_rollout_tick_apply or the next tick's policy step
-            rc = egp_obs_zfilter_stats_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, f32, f32 + 3 * nmax, n, d->zf_workspace, ts);
-        else
-            rc = egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, f32, f32 + 3 * nmax, n, zf_cur, zf_new, d->zf_clip,
-                                     d->next_states + row * d->obs_dim, d->states + (row + N) * d->obs_dim, 0, d->zf_workspace, ts);
-        if (rc != EGP_OK) return rc;
-        if (!d->reward_job) {
-            // group-stream ticks: K2 leaves the group's queue (nothing of the next tick depends on it) for the caller's
-            // stream, behind this env-step's kernel; egp_engine_reset and the next env-step order themselves behind reward_done
-            hipStream_t rs = d->group_streams ? (hipStream_t)d->stream : ts;
-            Group &G = d->eng->groups[group];
-            if (d->group_streams) EGP_HIP_CHECK(hipStreamWaitEvent(rs, G.done, 0));
-            rc = egp_reward_quat_v3_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->prev_qpos + (size_t)a * d->nq, d->ee + (size_t)a * 15, f32, f32 + nmax,
-                                        f32 + 2 * nmax, f32 + 3 * nmax, d->end_reward, n, d->rewards + row, d->cinfo + row * 5, rs);
-            if (rc != EGP_OK) return rc;
-            if (d->group_streams) {
-                EGP_HIP_CHECK(hipEventRecord(G.reward_done, rs));
-                G.reward_in_flight = true;
-            }
-        }
-    }
-    if (d->group_streams) {
-        EGP_HIP_CHECK(hipEventRecord(d->eng->groups[group].chain_done, ts));
-        d->eng->groups[group].chain_recorded = true;
     }
     int nd = 0;
     for (int i = 0; i < n; ++i) {
@@ -1483,13 +1137,12 @@ __global__ __launch_bounds__(256) void k_ctx_rows_scatter(const int *__restrict_
 
 int egp_rollout_reset(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, const int32_t *ids, int32_t n,
                       const int64_t *e_ind, const int64_t *s_ind, const int64_t *frame_rows, const int64_t *cur_t0, const double *qpos, const double *qvel,
-                      const float *ctx_rows, int32_t ctx_rows_fresh, const double *zf_cur, double *zf_new) {
+                      const float *ctx_rows, const double *zf_cur, double *zf_new) {
     EGP_REQUIRE(d && d->ctx && d->eng && d->reset_scratch && ids && e_ind && s_ind && frame_rows && qpos && qvel && ctx_rows, "NULL pointer");
     EGP_REQUIRE(0 <= a && a < b && b <= d->n_env && b - a <= d->nmax && k >= 0 && n > 0 && n <= b - a, "slot range / tick out of range");
     for (int j = 0; j < n; ++j) EGP_REQUIRE(ids[j] >= a && ids[j] < b, "reset slot outside its group");
     EGP_REQUIRE(group >= 0 && group < d->eng->n_groups, "group out of range");
-    hipStream_t s = tick_stream(d, group);
-    if (d->group_streams && ctx_rows_fresh) EGP_HIP_CHECK(follow_caller_stream(d, s));     // ctx_rows were computed on the caller's stream
+    hipStream_t s = (hipStream_t)d->stream;
     int rc = egp_engine_reset(d->eng, ids, n, qpos, qvel, s);               // also checks that the ids increase strictly
     if (rc != EGP_OK) return rc;
     const int nmax = d->nmax, ng = b - a;
@@ -1513,10 +1166,8 @@ int egp_rollout_reset(const egp_rollout_tick *d, int32_t group, int32_t a, int32
     k_ctx_rows_scatter<<<dim3(n, per_row), dim3(256), 0, s>>>(list, ctx_rows, row_elems, const_cast<float *>(d->v_out), d->v_stride, vec4);
     EGP_HIP_CHECK(hipGetLastError());
     // fresh episodes: their first observation goes through the filter and replaces the policy input of tick k + 1
-    rc = egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, tcur, mask, ng, zf_cur, zf_new, d->zf_clip,
-                             d->states + ((size_t)(k + 1) * d->n_env + a) * d->obs_dim, nullptr, 1, d->zf_workspace, s);
-    if (rc == EGP_OK && d->group_streams) EGP_HIP_CHECK(hipEventRecord(d->eng->groups[group].chain_done, s));
-    return rc;
+    return egp_obs_zfilter_f64(d->ctx, d->qpos + (size_t)a * d->nq, d->qvel + (size_t)a * d->nv, tcur, mask, ng, zf_cur, zf_new, d->zf_clip,
+                               d->states + ((size_t)(k + 1) * d->n_env + a) * d->obs_dim, nullptr, 1, d->zf_workspace, s);
 }
 
 int egp_debug_burn(int64_t us, int32_t blocks, float *sink, void *stream) {
@@ -1537,7 +1188,7 @@ int egp_rollout_tick_apply(const egp_rollout_tick *d, int32_t group, int32_t a, 
                                      reinterpret_cast<const int32_t *>(d->slab_dev + (size_t)(group * 2 + (k & 1)) * 24 * d->nmax),      // tick k's step counter
                                      b - a, zf_cur, zf_new, d->zf_clip,
                                      d->next_states + row * d->obs_dim, d->states + (row + d->n_env) * d->obs_dim, d->zf_workspace,
-                                     tick_stream(d, group));
+                                     (hipStream_t)d->stream);
 }
 
 double egp_engine_event_overhead_ms(egp_engine *E) {
@@ -1598,13 +1249,6 @@ int egp_engine_layout(egp_engine *E, int32_t *pack_ld, int32_t *n_env, int32_t *
     return EGP_OK;
 }
 
-int egp_engine_launches_per_substep(egp_engine *E) {
-    if (!E || E->groups.empty()) return 0;
-    const Group &G = E->groups[0];
-    if (server_mode(E, G)) return 1;
-    return pipelined_mode(E, G) ? G.n_chunks : 1;
-}
-
 int egp_engine_server_trace(egp_engine *E, int32_t group, int64_t *device_ticks, double *host_us) {
     EGP_REQUIRE(E && device_ticks && host_us, "NULL pointer");
     EGP_REQUIRE(group >= 0 && group < E->n_groups, "group out of range");
@@ -1618,6 +1262,11 @@ int egp_engine_server_trace(egp_engine *E, int32_t group, int64_t *device_ticks,
 int egp_engine_substeps_per_launch(egp_engine *E) {
     if (!E || E->groups.empty()) return 0;
     return server_mode(E, E->groups[0]) ? E->frame_skip : 1;
+}
+
+int32_t egp_engine_go_words_in_vram(egp_engine *E) {
+    if (!E || E->groups.empty() || !server_mode(E, E->groups[0])) return -1;
+    return E->groups[0].srv.go_in_vram ? 1 : 0;
 }
 
 int egp_engine_group_range(egp_engine *E, int32_t group, int32_t *e0, int32_t *e1) {

@@ -10,13 +10,6 @@
 namespace egp {
 
 void set_error(const char *fmt, ...);
-// Dynamic LDS to request for one of the rollout tick's small launches (filter statistics / apply, reward, policy step), given what
-// the kernel itself needs. EGP_TICK_LDS_PAD=<bytes> adds a pad: a resident K1 workgroup holds 37.7 kB of a CU's 160 kB, so a
-// launch that asks for more than 122 kB cannot be placed beside one and runs on the CUs the other group's K1 does not occupy --
-// CU partitioning by resource request (CU masks cannot separate them: docs/DESIGN_TRAIL.md). The first call per kernel raises its
-// dynamic-LDS limit.
-size_t tick_lds(const void *kernel, size_t own_dynamic, size_t own_static);
-
 #define EGP_HIP_CHECK(expr)                                                                  \
     do {                                                                                     \
         hipError_t _e = (expr);                                                              \
@@ -93,6 +86,7 @@ int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const d
                          unsigned long long base, int n_sub, int *err, double timeout_s, long long *trace, const double *ee_host,
                          double *out_qpos, double *out_prev_qpos, double *out_qvel, double *out_ee, const int *active, bool device_dynamics);
 size_t egp_pd_server_dyn_lds_bytes();
+int egp_pd_server_resident_blocks(int device, bool device_dynamics);
 int egp_launch_dynamics_strided(egp_ctx *ctx, const double *qpos, long ld_q, const double *qvel, long ld_v, int32_t n, double *qM,
                                 long ld_m, double *bias, long ld_b, double *xpos, hipStream_t stream);
 // bit pattern the engine pre-fills pinned torque rows with in resident-K1 mode (a quiet NaN no clipped torque can equal)

@@ -36,25 +36,6 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-size_t tick_lds(const void *kernel, size_t own_dynamic, size_t own_static) {
-    static const size_t pad = [] { const char *e = getenv("EGP_TICK_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
-    if (pad == 0) return own_dynamic;
-    size_t want = own_dynamic + pad;
-    if (want + own_static > 160 * 1024) want = 160 * 1024 - own_static;
-    static const void *done[32];
-    static int n_done = 0;
-    bool seen = false;
-    for (int i = 0; i < n_done; ++i) seen = seen || done[i] == kernel;
-    if (!seen) {
-        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - own_static)) != hipSuccess) {
-            (void)hipGetLastError();
-            return own_dynamic;
-        }
-        if (n_done < 32) done[n_done++] = kernel;
-    }
-    return want;
-}
-
 // ============================================================================================ K4
 // get_body_quat (ego_pose/envs/humanoid_v1.py:113-125)
 template <typename T>
@@ -1070,26 +1051,9 @@ __global__ __launch_bounds__(1024) void k_zf_partial(ZfSrc<T> src, const int *__
 template <typename T>
 static void launch_zf_partial(const ZfSrc<T> &src, const int *active, int n, int dim, int rpt, int nt, double *ws, hipStream_t stream) {
     if (src.x == nullptr)
-        k_zf_partial<T, true><<<dim3(nt), dim3(1024), tick_lds((const void *)&k_zf_partial<T, true>, 0, 17 * 1024), stream>>>(src, active, n, dim, rpt, ws);
+        k_zf_partial<T, true><<<dim3(nt), dim3(1024), 0, stream>>>(src, active, n, dim, rpt, ws);
     else
-        k_zf_partial<T, false><<<dim3(nt), dim3(1024), tick_lds((const void *)&k_zf_partial<T, false>, 0, 17 * 1024), stream>>>(src, active, n, dim, rpt, ws);
-}
-
-// One launch for the two independent halves of a rollout tick's post-step: blocks [0, n_tiles) compute the observation
-// filter's tile statistics (K6, first pass), the remaining blocks the imitation reward (K2). The reward then costs no
-// launch and no time of its own on the tick's critical path (filter -> policy -> next env-step).
-template <typename T>
-__global__ __launch_bounds__(256) void k_post_step(ZfSrc<T> src, const int *__restrict__ zf_active, int n, int dim, int rows_per_tile,
-                                                   double *__restrict__ ws, int n_tiles, DevModel m, RewardW w,
-                                                   const T *__restrict__ expert_rows, const T *__restrict__ prev_qpos,
-                                                   const T *__restrict__ ee_wpos, const int *__restrict__ tcur,
-                                                   const int *__restrict__ frame, const int *__restrict__ endf, T end_reward,
-                                                   T *__restrict__ reward, T *__restrict__ cinfo) {
-    if ((int)blockIdx.x < n_tiles)
-        zf_partial_body<T, true>(src, zf_active, n, dim, rows_per_tile, ws, blockIdx.x);      // (the post-step's source is always the drained state)
-    else
-        reward_body<T, 1>(m, w, expert_rows, src.qpos, prev_qpos, ee_wpos, tcur, frame, endf, zf_active, end_reward, n, reward, cinfo,
-                       (int)blockIdx.x - n_tiles);
+        k_zf_partial<T, false><<<dim3(nt), dim3(1024), 0, stream>>>(src, active, n, dim, rpt, ws);
 }
 
 // one block: the merged state of a batch with many tiles (few tiles: k_zf_apply merges them itself). 8 tile groups x 128
@@ -1513,9 +1477,9 @@ int64_t egp_abi_sizeof(const char *name) {
     if (!name) return -1;
 #define EGP_ABI_SIZE(T) if (!strcmp(name, #T)) return (int64_t)sizeof(T);
     EGP_ABI_SIZE(egp_model_desc) EGP_ABI_SIZE(egp_expert_table) EGP_ABI_SIZE(egp_gemm_desc)
-    EGP_ABI_SIZE(egp_dynamics_desc) EGP_ABI_SIZE(egp_mlp_layer) EGP_ABI_SIZE(egp_mlp_chain_desc) EGP_ABI_SIZE(egp_physics_vtable)
+    EGP_ABI_SIZE(egp_dynamics_desc) EGP_ABI_SIZE(egp_mlp_layer) EGP_ABI_SIZE(egp_physics_vtable)
     EGP_ABI_SIZE(egp_surrogate_desc) EGP_ABI_SIZE(egp_engine_desc) EGP_ABI_SIZE(egp_rollout_tick)
-    EGP_ABI_SIZE(egp_ppo_loss_desc) EGP_ABI_SIZE(egp_adam_segment)
+    EGP_ABI_SIZE(egp_ppo_loss_desc) EGP_ABI_SIZE(egp_adam_segment) EGP_ABI_SIZE(egp_host_probe_result)
 #undef EGP_ABI_SIZE
     return -1;
 }
@@ -1593,12 +1557,6 @@ int egp_create(const egp_model_desc *d, int device, egp_ctx **out) {
         ctx->pd_grid = true;
     }
     ctx->pd_variant = tree_ok ? 0 : (d->nv == PD_NV ? 2 : 1);
-    const char *v = getenv("EGP_PD_VARIANT");
-    if (v) {
-        const int want = atoi(v);
-        if (want == 1 || (want == 2 && d->nv == PD_NV) || (want == 0 && tree_ok)) ctx->pd_variant = want;
-        if (want == 3 && tree_ok) ctx->pd_grid = false;
-    }
     *out = ctx;
     return EGP_OK;
 }
@@ -1810,6 +1768,28 @@ size_t egp_pd_server_dyn_lds_bytes() {
     return ((sizeof(egp_dyn::DynTables) + 7) / 8 + 4 * (size_t)egp_dyn::DY_ENV_DOUBLES + 4 * 192) * sizeof(double);
 }
 
+// How many workgroups of the resident K1 the chip holds at once (the occupancy calculator's figure x the CUs): the engine runs the
+// resident form only when every workgroup of every group is resident at the same time -- they wait on the host, and a workgroup
+// that is not resident cannot answer its slice's go word. 0 when the kernel cannot run at all (device dynamics without its LDS).
+int egp_pd_server_resident_blocks(int device, bool device_dynamics) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int per_cu = 0;
+    hipError_t e;
+    if (device_dynamics) {
+        const size_t lds = egp_pd_server_dyn_lds_bytes();
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pd_server_tree58<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pd_server_tree58<true>, 256, lds);
+    } else {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pd_server_tree58<false>, 256, 0);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return per_cu * prop.multiProcessorCount;
+}
+
 // engine entry for the resident K1 (see k_pd_server_tree58); all flag arrays are device-visible addresses
 int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const double *qvel, long ld_qvel, const double *bias,
                          long ld_bias, const double *qM, long ld_qM, const double *qM_host, const double *action, int32_t n,
@@ -1823,11 +1803,10 @@ int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const d
     EGP_REQUIRE(qpos && qvel && bias && qM && qM_host && action && torque && block_slice && go && err, "NULL pointer");
     EGP_REQUIRE(n > 0 && n_sub > 0, "n and n_sub must be positive");
     PdLd ld{ld_qpos, ld_qvel, ctx->dm.nu, ld_qM, ld_bias};
-    static const int poll_sleep = [] { const char *e = getenv("EGP_SERVER_POLL_SLEEP"); return e ? atoi(e) : 2; }();
-    // EGP_SERVER_ROW_CONTIG=0: the three lane = dof loads of round 3 (the A/B switch of the contiguous row read)
-    static const int want_contig = [] { const char *e = getenv("EGP_SERVER_ROW_CONTIG"); return e ? atoi(e) : 1; }();
+    const int poll_sleep = 2;          // s_sleep(1) repeats between two polls of a go word
     const int nq = ctx->dm.nq, nv = ctx->dm.nv;
-    const int row_contig = want_contig && !device_dynamics && qvel == qpos + nq && bias == qvel + nv && ld_qpos == ld_qvel &&
+    // (the engine's state rows are qpos | qvel | bias back to back: read as one contiguous stream; separate arrays: three segments)
+    const int row_contig = !device_dynamics && qvel == qpos + nq && bias == qvel + nv && ld_qpos == ld_qvel &&
                            ld_qvel == ld_bias && nq + 2 * nv <= 192 && ld_qpos >= nq + 2 * nv;
     PdServe sv{block_slice, go, base, n_sub, qM_host, const_cast<double *>(qM), err, (long long)(timeout_s * 100.0e6), trace,
                ee_host, out_qpos, out_prev_qpos, out_qvel, out_ee, nq, nv, poll_sleep, active, ctx->dyn_tables, row_contig};
@@ -1860,7 +1839,7 @@ static int launch_reward(egp_ctx *ctx, const T *expert_rows, const T *cur_qpos, 
             ctx->dm, ctx->rw, expert_rows, cur_qpos, prev_qpos, ee_wpos, t, frame, endf, active, (T)end_reward, n, reward, cinfo);
     } else {
         const int tile = reward_tile_envs(ctx->dm.nbody, 1);
-        k_reward_quat_v3<T, 1><<<dim3((n + tile - 1) / tile), dim3(256), tick_lds((const void *)&k_reward_quat_v3<T, 1>, 0, 10 * 1024), (hipStream_t)stream>>>(
+        k_reward_quat_v3<T, 1><<<dim3((n + tile - 1) / tile), dim3(256), 0, (hipStream_t)stream>>>(
             ctx->dm, ctx->rw, expert_rows, cur_qpos, prev_qpos, ee_wpos, t, frame, endf, active, (T)end_reward, n, reward, cinfo);
     }
     return after_launch("k_reward_quat_v3");
@@ -1916,7 +1895,7 @@ static int launch_zfilter_src(const ZfSrc<T> &src, const int *active, int n, int
         if (rc != EGP_OK) return rc;
     }
     const int rows_per_block = direct ? 8 : (n <= 8192 ? 2 : 16);     // small batches: enough blocks to cover the latency
-    k_zf_apply<T><<<dim3((n + rows_per_block - 1) / rows_per_block), dim3(128), tick_lds((const void *)&k_zf_apply<T>, 2 * dim * sizeof(double), 1024), (hipStream_t)stream>>>(
+    k_zf_apply<T><<<dim3((n + rows_per_block - 1) / rows_per_block), dim3(128), 2 * dim * sizeof(double), (hipStream_t)stream>>>(
         src, n, dim, rows_per_block, update && !records ? st_out : st_in, clip, y, y2, write_mask, identity, records, n_records, st_out);
     return after_launch("k_zf_apply");
 }
@@ -1939,37 +1918,6 @@ static int launch_obs_zfilter(egp_ctx *ctx, const T *qpos, const T *qvel, const 
     const int dim = ctx->dm.obs_dim;
     ZfSrc<T> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm), phase_t};
     return launch_zfilter_src<T>(src, active, n, dim, st_in, st_out, 1, clip, y, y2, write_only_active ? active : nullptr, ws, stream);
-}
-
-// K3+K6 (filtered observation -> y, y2; statistics updated) and K2 (reward) of one rollout tick in three launches
-static int launch_post_step(egp_ctx *ctx, const double *qpos, const double *qvel, const double *prev_qpos, const double *ee_wpos,
-                            const int *tcur, const int *frame, const int *endf, const int *active, int n, const double *st_in,
-                            double *st_out, double clip, double *y, double *y2, void *ws, double end_reward, double *reward,
-                            double *cinfo, void *stream) {
-    EGP_REQUIRE(ctx, "ctx is NULL");
-    EGP_REQUIRE(n >= 0, "n < 0");
-    if (n == 0) return EGP_OK;
-    EGP_REQUIRE(qpos && qvel && prev_qpos && ee_wpos && tcur && frame && endf && y && reward && cinfo, "NULL pointer");
-    if (!ctx->expert_rows_f64) { set_error("egp_upload_experts must be called before the reward kernel"); return EGP_E_STATE; }
-    const int dim = ctx->dm.obs_dim;
-    ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm), tcur};      // (obs_phase: the step counter the reward reads too)
-    const int identity = st_in == nullptr;
-    EGP_REQUIRE(identity || (st_out && ws && st_out != st_in), "the filter update needs workspace and a distinct state_out");
-    hipStream_t s = (hipStream_t)stream;
-    int rpt = 0, nt = 0;
-    if (!identity) zf_tiling(n, &rpt, &nt);
-    const int rtile = reward_tile_envs(ctx->dm.nbody, 1);
-    const int reward_blocks = (n + rtile - 1) / rtile;
-    k_post_step<double><<<dim3(nt + reward_blocks), dim3(256), 0, s>>>(src, active, n, dim, rpt, (double *)ws, nt, ctx->dm, ctx->rw,
-                                                                       ctx->expert_rows_f64, prev_qpos, ee_wpos, tcur, frame, endf,
-                                                                       end_reward, reward, cinfo);
-    const bool fused = !identity && nt <= ZF_FUSED_TILES;
-    if (!identity && !fused) k_zf_merge<<<dim3(1), dim3(1024), 0, s>>>(dim, nt, (const double *)ws, st_in, st_out);
-    const int rows_per_block = fused ? 8 : (n <= 8192 ? 2 : 16);
-    k_zf_apply<double><<<dim3((n + rows_per_block - 1) / rows_per_block), dim3(128), 2 * dim * sizeof(double), s>>>(
-        src, n, dim, rows_per_block, identity || fused ? st_in : st_out, clip, y, y2, nullptr, identity,
-        fused ? (const double *)ws : nullptr, nt, st_out);
-    return after_launch("k_post_step / k_zf_merge / k_zf_apply");
 }
 
 template <typename T>
@@ -2108,7 +2056,7 @@ int egp_obs_zfilter_apply_f64(egp_ctx *ctx, const double *qpos, const double *qv
     ZfSrc<double> src{nullptr, qpos, qvel, ctx->dm.nq, ctx->dm.nv, dim, obs_opt_of(ctx->dm), phase_t};
     int rpt, nt;
     zf_tiling(n, &rpt, &nt);
-    k_zf_apply<double><<<dim3((n + 7) / 8), dim3(128), tick_lds((const void *)&k_zf_apply<double>, 2 * dim * sizeof(double), 1024), (hipStream_t)stream>>>(
+    k_zf_apply<double><<<dim3((n + 7) / 8), dim3(128), 2 * dim * sizeof(double), (hipStream_t)stream>>>(
         src, n, dim, 8, st_in, clip, y, y2, nullptr, 0, (const double *)ws, nt, st_out);
     return after_launch("k_zf_apply");
 }
@@ -2118,14 +2066,6 @@ int egp_upload_async(void *dst_device, const void *src_pinned, int64_t bytes, vo
     if (bytes == 0) return EGP_OK;
     EGP_HIP_CHECK(hipMemcpyAsync(dst_device, src_pinned, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     return EGP_OK;
-}
-
-int egp_post_step_f64(egp_ctx *c, const double *qpos, const double *qvel, const double *prev_qpos, const double *ee_wpos,
-                      const int32_t *t, const int32_t *frame, const int32_t *end, const int32_t *active, int32_t n, const double *si,
-                      double *so, double clip, double *y, double *y2, void *ws, double end_reward, double *reward, double *cinfo,
-                      void *s) {
-    return launch_post_step(c, qpos, qvel, prev_qpos, ee_wpos, t, frame, end, active, n, si, so, clip, y, y2, ws, end_reward, reward,
-                            cinfo, s);
 }
 
 int64_t egp_gae_workspace_bytes(int32_t n) {

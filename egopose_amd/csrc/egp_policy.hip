@@ -562,7 +562,7 @@ static void policy_launch_t(bool flt, dim3 grid, size_t lds, hipStream_t s, cons
                             const long long *t_idx, const double *state, int state_dim, int n, const PolLayers &L, int act, int xs,
                             const float *log_std, const float *noise, double *action, float *mean_out, const unsigned *ssrc, unsigned *sdst,
                             int swords, const PolFilter &F) {
-#define POL_GO(KERN, FLT) KERN<R, PF, FLT><<<grid, dim3(NW * 64), egp::tick_lds((const void *)&KERN<R, PF, FLT>, lds, 0), s>>>(ctx_rows, ctx_row_stride, ctx_dim, t_idx, state, state_dim, n, L, act, xs, \
+#define POL_GO(KERN, FLT) KERN<R, PF, FLT><<<grid, dim3(NW * 64), lds, s>>>(ctx_rows, ctx_row_stride, ctx_dim, t_idx, state, state_dim, n, L, act, xs, \
                                                                             log_std, noise, action, mean_out, ssrc, sdst, swords, F)
     if constexpr (NW == 4) { if (flt) POL_GO(k_policy_gaussian_w4, true); else POL_GO(k_policy_gaussian_w4, false); }
     else { if (flt) POL_GO(k_policy_gaussian_w8, true); else POL_GO(k_policy_gaussian_w8, false); }

@@ -185,10 +185,12 @@ def _logger_row(log):
 
 def _merge_logger_rows(rows):
     """LoggerRL.merge (core/logger_rl.py:44-59) over the rows of a (W, 8 + n_cinfo) tensor: sums of the totals, min / max of
-    the extremes -- one row out, computed where the rows are."""
+    the extremes -- one row out, computed where the rows are. min_episode_reward (column 3) is the MAX of the per-worker
+    minima: the reference's merge does that (core/logger_rl.py:52) and rl_core.LoggerRL.merge keeps it, so a multi-rank log
+    equals the reference's merge of the same per-rank loggers."""
     sums, mins, maxs = rows.sum(0), rows.min(0).values, rows.max(0).values
     out = sums.clone()
-    out[3], out[6] = mins[3], mins[6]
+    out[3], out[6] = maxs[3], mins[6]
     out[4], out[7] = maxs[4], maxs[7]
     return out
 

@@ -310,15 +310,7 @@ class GatherMlpHead(torch.autograd.Function):
 
 
 def gather_mlp_head(gi, layers, head):
-    """head(relu-MLP([ctx2d[idx] | x])): the chained launches of csrc/egp_chain.hip when the call has their shape (chain.py),
-    else one launch per layer (GatherMlpHead)."""
-    from . import chain as _chain
-    if _chain.available(gi, layers, head):
-        return _chain.chain_mlp_head(gi, layers, head)
-    return gather_mlp_head_layers(gi, layers, head)
-
-
-def gather_mlp_head_layers(gi, layers, head):
+    """head(relu-MLP([ctx2d[idx] | x])), one launch per layer and direction (GatherMlpHead)."""
     params = []
     for l in list(layers) + [head]:
         params += [l.weight, l.bias]

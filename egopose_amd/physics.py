@@ -290,6 +290,64 @@ def default_threads(share=1, device_index=None):
     return max(1, min(budget - 2, 64))
 
 
+def _pin_to_gpu_node(device_index, n_threads):
+    """Narrow this thread's affinity to the physical cores of the GPU's NUMA node when they can hold n_threads + 1 threads (what
+    `RolloutEngine` does around egp_engine_create). Returns (saved mask or None, sorted cores or None)."""
+    if os.environ.get("EGP_PIN_NUMA", "1") == "0":
+        return None, None
+    node = gpu_numa_node(device_index)
+    cores = numa_physical_cpus(node) if node is not None else set()
+    if len(cores) < n_threads + 1:
+        return None, None
+    try:
+        saved = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, cores)
+        return saved, sorted(cores)
+    except OSError:
+        return None, None
+
+
+def host_info(device_index=0):
+    """What the box is, as far as sysfs / procfs tell: CPU model, frequency governor, the GPU's NUMA node, SMT, load average."""
+    info = {"cpu_model": None, "cpu_governor": None, "gpu_numa_node": gpu_numa_node(device_index), "loadavg_1m": None, "smt": None}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                info["cpu_model"] = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    try:
+        info["cpu_governor"] = _read("/sys/devices/system/cpu/cpu0/cpufreq/scaling_governor")
+    except Exception:
+        pass
+    try:
+        info["loadavg_1m"] = float(_read("/proc/loadavg").split()[0])
+    except Exception:
+        pass
+    try:
+        info["smt"] = _read("/sys/devices/system/cpu/smt/active") == "1"
+    except Exception:
+        pass
+    return info
+
+
+def host_probe(device_index=0, n_threads=0, millis=300):
+    """egp_host_probe (include/egopose_hip.h) with the spinning threads confined as the engine's are: PCIe read rate of pinned state
+    rows, go-word round trip, and whether spinning threads keep their cores. A dict of plain numbers."""
+    lib = L.load()
+    res = L.HostProbeResult()
+    saved, cores = _pin_to_gpu_node(device_index, n_threads)
+    try:
+        L.check(lib.egp_host_probe(int(device_index), int(n_threads), int(millis), C.byref(res)), "egp_host_probe")
+    finally:
+        if saved is not None:
+            os.sched_setaffinity(0, saved)
+    out = {k: getattr(res, k) for k, _ in res._fields_}
+    out["spin_cpus_pinned"] = len(cores) if cores else None
+    return out
+
+
 _RANKS_ON_HOST = None
 
 
@@ -327,18 +385,7 @@ class RolloutEngine:
         # the engine's threads inherit the creating thread's affinity mask: narrow it to the physical cores of the GPU's
         # NUMA node (when they can hold all of them) for the duration of the call only -- the caller's own mask, and with
         # it every thread pool it creates later (OpenMP, the oracle in the tests, the CPU baseline), stays as it was
-        self.pinned_cpus = None
-        saved = None
-        if os.environ.get("EGP_PIN_NUMA", "1") != "0":
-            node = gpu_numa_node(ctx.device)
-            cores = numa_physical_cpus(node) if node is not None else set()
-            if len(cores) >= n_threads + 1:
-                try:
-                    saved = os.sched_getaffinity(0)
-                    os.sched_setaffinity(0, cores)
-                    self.pinned_cpus = sorted(cores)
-                except OSError:
-                    saved = None
+        saved, self.pinned_cpus = _pin_to_gpu_node(ctx.device, n_threads)
         try:
             L.check(self.lib.egp_engine_create(ctx.handle, physics.handle, C.byref(d), C.byref(h)), "egp_engine_create")
         finally:
@@ -361,11 +408,6 @@ class RolloutEngine:
         a, b = C.c_int32(), C.c_int32()
         L.check(self.lib.egp_engine_group_range(self.handle, int(g), C.byref(a), C.byref(b)), "egp_engine_group_range")
         return a.value, b.value
-
-    @property
-    def launches_per_substep(self):
-        """K1 launches per group per substep (number of chunks when the group runs pipelined, else 1)."""
-        return int(self.lib.egp_engine_launches_per_substep(self.handle))
 
     @property
     def substeps_per_launch(self):

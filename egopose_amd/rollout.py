@@ -30,35 +30,6 @@ from . import policy_step
 from .rl_core import LoggerRL, TrajBatchEgo
 
 
-_DEFAULT_TICK_FLAGS = "kernel"
-
-
-class _HostVisible:
-    """A byte array in fine-grained device memory (egp_hostvis_alloc): the host's NumPy view writes through the PCIe BAR, kernels
-    read the same address in HBM. Never read through `array` on the host (uncached PCIe reads)."""
-
-    def __init__(self, lib, ptr, nbytes):
-        self.lib, self.ptr = lib, ptr
-        self.array = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(ptr))
-
-    @classmethod
-    def create(cls, lib, device, nbytes):
-        """None where the device's memory is not host-addressable (no large BAR)."""
-        p = ctypes.c_void_p()
-        index = torch.device(device).index
-        rc = lib.egp_hostvis_alloc(torch.cuda.current_device() if index is None else index, nbytes, ctypes.byref(p))
-        if rc == -3:                  # EGP_E_STATE
-            return None
-        _lib.check(rc, "egp_hostvis_alloc")
-        return cls(lib, p.value, nbytes)
-
-    def __del__(self):
-        if getattr(self, "ptr", None) and torch.cuda.is_available():
-            self.array = None
-            self.lib.egp_hostvis_free(ctypes.c_void_p(self.ptr))
-            self.ptr = None
-
-
 class _PinnedRing:
     """Small ring of pinned int32 staging buffers for per-tick host->device flag uploads."""
 
@@ -170,8 +141,9 @@ class LockstepRollout:
         self.timing = {}
         self._events = [None] * len(self.groups)
         self.up = _Uploader(self.dev, max(4096, self.N))
-        self.use_graphs = os.environ.get("EGP_POLICY_GRAPH", "1") != "0"
-        self.use_fused = os.environ.get("EGP_POLICY_FUSED", "1") != "0"     # HIP policy step (float32 PolicyGaussian over an MLP)
+        self.use_graphs = True              # torch tick: capture the policy step of a group in a hipGraph (eager when capture fails)
+        self.use_fused = True               # HIP policy step (float32 PolicyGaussian over an MLP) wherever the nets allow it
+        self.trace_ticks = False            # tools/tick_trace.py: record (group, tick, stepped envs, wait, post, reset) per env-step
         self._fused = None
         self._s_hc = None
         self._fast_bufs = None              # pinned per-tick flag / index slots of the fast tick path
@@ -260,8 +232,7 @@ class LockstepRollout:
         # a fresh pool, and the rows stay referenced until the next two resets have been issued)
         self._ctx_keep = (ctx_rows, self._ctx_keep[0] if self._ctx_keep else None)
         rc = self.engine.lib.egp_rollout_reset(tickd_ref, g, a, b, k, ids32.ctypes.data, len(ids32), e64.ctypes.data, s64.ctypes.data,
-                                               r64.ctypes.data, None, qpos.ctypes.data, qvel.ctypes.data, ctx_rows.data_ptr(),
-                                               1 if self._pool_fresh else 0, cur, new)
+                                               r64.ctypes.data, None, qpos.ctypes.data, qvel.ctypes.data, ctx_rows.data_ptr(), cur, new)
         if rc != 0:
             _lib.check(rc, "egp_rollout_reset")
         if new_t is not None:
@@ -390,12 +361,15 @@ class LockstepRollout:
         self._pool, self._pool_pos = None, 0          # contexts depend on this iteration's weights
         od, nu = ctx.obs_dim, ctx.nu
         f64 = torch.float64
+        # reward_kind 'env' (custom_reward=None, agents/agent.py:56-58): the batch's reward is env_reward = 1.0 per step
+        # (humanoid_v1.py:188) -- the registry's constant kernel writes exactly that -- and the logger's c_reward / c_info are 0
+        reward_kernel = "constant" if self.reward_kind == "env" else self.reward_kind
         # time-major record in HBM. rec["states"][k] IS the policy input of tick k: the filtered observation of
         # tick k-1 is written straight into row k (and into next_states[k-1]) by the fused kernel.
         rec = dict(
             states=torch.empty(T_max + 1, N, od, dtype=f64, device=dev), next_states=torch.empty(T_max, N, od, dtype=f64, device=dev),
             actions=torch.zeros(T_max, N, nu, dtype=f64, device=dev), rewards=torch.zeros(T_max, N, dtype=f64, device=dev),
-            cinfo=torch.zeros(T_max, N, ctx.reward_cinfo_dim(self.reward_kind), dtype=f64, device=dev),
+            cinfo=torch.zeros(T_max, N, ctx.reward_cinfo_dim(reward_kernel), dtype=f64, device=dev),
             exps=torch.ones(T_max, N, dtype=torch.int64, device=dev))
         host = dict(valid=np.zeros((T_max, N), bool), done=np.zeros((T_max, N), bool),
                     e_ind=np.zeros((T_max, N), np.int64), s_ind=np.zeros((T_max, N), np.int64))
@@ -456,7 +430,7 @@ class LockstepRollout:
                 tm["small_group_ticks"] += 1
                 tm["small_group_tick_s"] += now - last_post[g]
             last_post[g] = now
-        trace = [] if os.environ.get("EGP_TICK_TRACE") else None
+        trace = [] if self.trace_ticks else None
 
         # ---- initial reset of every slot; group g's first state goes to rec["states"][0, a:b]
         self._reset_slots(np.arange(N))
@@ -524,12 +498,12 @@ class LockstepRollout:
             # K3+K6: filtered next observation -> next_states[k] and the policy input of tick k+1;  K2: reward
             self._obs_filter(a, b, rec["next_states"][k, a:b], rec["states"][k + 1, a:b], active=fl[3], phase_t=fl[0])
             ctx.reward(eng.qpos[a:b], eng.prev_qpos[a:b], eng.ee_wpos[a:b], fl[0], fl[1], fl[2], end_reward, active=fl[3],
-                       reward_out=rec["rewards"][k, a:b], cinfo_out=rec["cinfo"][k, a:b], kind=self.reward_kind)
+                       reward_out=rec["rewards"][k, a:b], cinfo_out=rec["cinfo"][k, a:b], kind=reward_kernel)
             steps_done[a:b] += act_g
             t2 = time.time()
             if done.any():
                 ids = np.nonzero(done)[0] + a
-                ep_lens.extend(self.cur_t[ids].tolist())
+                ep_lens.extend((self.cur_t[ids] - self.t0[ids]).tolist())     # steps taken (random_cur_t: the episode began at t0)
                 again = after_episodes(ids, a, b)
                 if len(again):
                     self._reset_slots(again)
@@ -543,20 +517,20 @@ class LockstepRollout:
             tm["post"] += t2 - t1
             tm["reset"] += t3 - t2
 
-        # ---- fast tick: the same per-tick work with no torch views, no uploads and one ctypes call per kernel.
-        # The integer flags / context row indices of a tick live in pinned buffers the kernels read in place (two slots
-        # per group: a slot is reused two ticks later, after the env-step that was ordered behind its readers), every
-        # tensor argument is a precomputed address, and the fused policy kernel reads rec.states[k] / writes
+        # ---- native tick: the same per-tick work with no torch views, no uploads and two library calls per env-step.
+        # The integer flags / context row indices of a tick live in a pinned slab (two slots per group: a slot is reused two
+        # ticks later, after the env-step that was ordered behind its readers) that the policy kernel copies to its device
+        # twin; every tensor argument is a precomputed address; the fused policy kernel reads rec.states[k] / writes
         # rec.actions[k] directly.
         # (mean_action: the same kernel without a noise operand writes the mean; exps = 0 as agents/agent.py:45-46)
-        # (the registry's two small rewards, constant / pose_dist, take the torch tick: their kernel is called from there)
+        # (the registry's two small rewards, constant / pose_dist, the forecast nets and random_cur_t take the torch tick;
+        #  EGP_FAST_TICK=0 forces it: the tests replay both forms against each other)
         fast = (self._fused is not None and (plain_noise or self.mean_action) and not self.forecast and not self.random_cur_t
                 and self.reward_kind == "quat_v3" and os.environ.get("EGP_FAST_TICK", "1") != "0")
         if fast:
             if self.mean_action:
                 rec["exps"].zero_()
-            lib, hnd = ctx.lib, ctx.handle
-            vp = ctypes.c_void_p
+            hnd = ctx.handle
             P = {k: v.data_ptr() for k, v in rec.items()}
             qpos_p, qvel_p, prev_p, ee_p = eng.qpos.data_ptr(), eng.qvel.data_ptr(), eng.prev_qpos.data_ptr(), eng.ee_wpos.data_ptr()
             zf_p = [b_.data_ptr() for b_ in self._zf_bufs] if self.zf_state is not None else None
@@ -565,69 +539,33 @@ class LockstepRollout:
             v_out_p, v_stride = self.v_out.data_ptr(), self.v_out.stride(0)
             fz = self._fused
             nmax = max(b - a for a, b in self.groups)
-            # EGP_TICK_FLAGS: where the tick's flag slab lives and how it reaches the kernels -- 'bar' (the host fills fine-grained
-            # device memory through the PCIe BAR, kernels read it in HBM), 'kernel' (pinned host memory, the policy kernel stages it),
-            # 'upload' (pinned, a copy-engine transfer in front of the policy step: round 2's form), 'zerocopy' (every kernel reads the
-            # pinned slab over PCIe)
-            stage_mode = wanted_mode = os.environ.get("EGP_TICK_FLAGS", _DEFAULT_TICK_FLAGS)
-            if self._fast_bufs is None or self._fast_bufs[3] != nmax or self._fast_bufs[5] != wanted_mode:
+            if self._fast_bufs is None or self._fast_bufs[2] != nmax:
                 # per (group, slot) one 24*nmax-byte slab: 4 x nmax int32 flags (t | frame | end | active), then nmax int64 context rows
                 shape = (len(self.groups), 2, 24 * nmax)
-                vis = _HostVisible.create(ctx.lib, dev, int(np.prod(shape))) if stage_mode == "bar" else None
-                if vis is not None:
-                    self._fast_bufs = (vis.array.reshape(shape), None, vis, nmax, stage_mode, wanted_mode)
-                else:
-                    if stage_mode == "bar":
-                        stage_mode = "kernel"           # no large BAR on this system: pinned memory, staged by the policy kernel
-                    self._fast_bufs = (torch.zeros(shape, dtype=torch.uint8).pin_memory(),
-                                       torch.zeros(shape, dtype=torch.uint8, device=dev), None, nmax, stage_mode, wanted_mode)
-            slab_h, slab_d, vis, _, stage_mode, _ = self._fast_bufs
-            if vis is not None:
-                slab_np, slab_hp, slab_dp = slab_h, vis.ptr, vis.ptr       # one address for the host's stores and the kernels' loads
-            else:
-                slab_np, slab_hp, slab_dp = slab_h.numpy(), slab_h.data_ptr(), slab_d.data_ptr()
-            fl_np = slab_np[:, :, :16 * nmax].view(np.int32)            # (G, 2, 4*nmax)
-            ti_np = slab_np[:, :, 16 * nmax:].view(np.int64)            # (G, 2, nmax)
-            flags_upload = stage_mode not in ("zerocopy", "bar")
-            if stage_mode == "zerocopy":       # kernels read the pinned slab in place (same address on the device): every access is a PCIe read
-                slab_dp = slab_hp
-            reward_job = eng.substeps_per_launch > 1 and os.environ.get("EGP_REWARD_JOB", "1") != "0"
+                self._fast_bufs = (torch.zeros(shape, dtype=torch.uint8).pin_memory(), torch.zeros(shape, dtype=torch.uint8, device=dev), nmax)
+            slab_hp, slab_dp = self._fast_bufs[0].data_ptr(), self._fast_bufs[1].data_ptr()
+            reward_job = eng.substeps_per_launch > 1          # K2 rides behind the resident K1 on the engine's stream
             T_eff = T_ep if self.env.fix_len is None else self.env.fix_len
             end_r = float(end_reward)
             zclip = float(self.zf_clip) if self.zf_state is not None else 0.0
             act_i32 = np.ones(N, np.int32)
-            # egp_post_step (reward workgroups riding in the filter's first launch) is bit-identical but measured no faster
-            # than the two separate calls (the merge still waits for the slower half): opt-in
-            post_fused = os.environ.get("EGP_POST_FUSED", "0") == "1" and not reward_job
 
         cur_stream = _lib.current_stream()           # the rollout stays on one torch stream
         ev_ring = [[torch.cuda.Event(), torch.cuda.Event()] for _ in self.groups]
 
-        # The tick's bookkeeping and its six library calls in TWO native calls (egp_rollout_tick_pre / _post,
-        # include/egopose_hip.h): same launches with the same arguments in the same order as pre_fast / post_fast below
-        # (EGP_TICK_NATIVE=0: these), ~35 us less interpreter time per group and env-step.
+        # The tick's bookkeeping and its library calls in TWO native calls (egp_rollout_tick_pre / _post, include/egopose_hip.h).
         tickd = None
-        if fast and os.environ.get("EGP_TICK_NATIVE", "1") != "0":
+        if fast:
             td = _lib.RolloutTick()
             td.ctx, td.eng, td.stream = hnd, eng.handle, cur_stream
             td.n_env, td.nmax, td.obs_dim, td.nu, td.nq, td.nv = N, nmax, od, nu, ctx.nq, ctx.nv
             td.ctx_dim, td.ctx_T, td.episode_len = H, self.ctx_T, int(T_eff)
-            # EGP_TICK_STREAMS: 'shared' (default) = the ticks of all groups on the caller's stream, an event either side of every
-            # env-step; 'group' = each group's tick on its engine stream, one in-order queue policy -> env-step kernel -> filter
-            # (+ reward) -> policy. Measured (round 3, tools/probes/chain_gaps.py): the policy -> K1 gap goes 12.8 -> 0 us, but
-            # the reward has to ride in the filter's first launch (15.5 -> 31.6 us) and K1's end -> filter stays 22 us, so
-            # T_sample does not move; the fused filter also merges its statistics in another order (1-ulp differences)
-            group_streams = (eng.substeps_per_launch > 1 and os.environ.get("EGP_TICK_STREAMS", "shared") == "group")
-            if group_streams:
-                reward_job = False
-            td.group_streams, td.post_fused = int(group_streams), int(post_fused)
-            # EGP_DEFER_APPLY (default on): a tick's `post` runs only the filter's statistics pass; the apply pass rides in the next
-            # tick's policy step (one launch and its dependent round trips less on the chain filter -> policy -> env-step, ~14 us
-            # per tick), except in ticks with in-batch resets and in a group's last tick (egp_rollout_tick_apply)
-            defer_apply = (self.zf_state is not None and not post_fused and not group_streams
-                           and nmax <= int(ctx.lib.egp_obs_zfilter_split_max_rows()) and os.environ.get("EGP_DEFER_APPLY", "1") != "0")
+            # A tick's `post` runs only the filter's statistics pass; the apply pass rides in the next tick's policy step (one launch
+            # and its dependent round trips less on the chain filter -> policy -> env-step, ~14 us per tick), except in ticks with
+            # in-batch resets and in a group's last tick (egp_rollout_tick_apply)
+            defer_apply = self.zf_state is not None and nmax <= int(ctx.lib.egp_obs_zfilter_split_max_rows())
             td.defer_apply = int(defer_apply)
-            td.reward_job, td.flags_upload = int(bool(reward_job)), (0 if not flags_upload else (2 if stage_mode == "kernel" else 1))
+            td.reward_job = int(bool(reward_job))
             td.has_fix_head_lb = int(self.env.fix_head_lb is not None)
             td.fix_head_lb = float(self.env.fix_head_lb) if self.env.fix_head_lb is not None else 0.0
             td.end_reward, td.zf_clip = end_r, zclip
@@ -659,9 +597,8 @@ class LockstepRollout:
                 tickd = (td, ctypes.byref(td), keep, ctypes.c_int32(0), ctypes.c_double(0.0))
 
         # in-tick resets through one native call (egp_rollout_reset) instead of _reset_slots + a masked _obs_filter: the same
-        # launches minus the id / mask uploads and the index_put (EGP_RESET_NATIVE=0: the torch form)
-        native_reset = (tickd is not None and self._s_hc is None and self.v_out.dtype == torch.float32 and self.v_out.is_contiguous()
-                        and os.environ.get("EGP_RESET_NATIVE", "1") != "0")
+        # launches minus the id / mask uploads and the index_put
+        native_reset = tickd is not None and self._s_hc is None and self.v_out.dtype == torch.float32 and self.v_out.is_contiguous()
 
         pending_apply = [None] * len(self.groups)     # per group: (zf_cur, zf_new) pointers of a filter whose apply pass is still due
 
@@ -707,7 +644,7 @@ class LockstepRollout:
             t2 = time.time()
             if n_done.value:
                 ids = np.nonzero(host["done"][k, a:b])[0] + a
-                ep_lens.extend(self.cur_t[ids].tolist())
+                ep_lens.extend((self.cur_t[ids] - self.t0[ids]).tolist())     # steps taken (random_cur_t: the episode began at t0)
                 again = after_episodes(ids, a, b)
                 if len(again):
                     flush_apply(g, k)            # the resets' masked filter pass continues from the merged statistics
@@ -730,124 +667,14 @@ class LockstepRollout:
             if trace is not None:
                 trace.append((g, k, int(host["valid"][k, a:b].sum()), wait_s.value, t2 - t0 - wait_s.value, t3 - t2))
 
-        def pre_fast(g):
-            a, b = self.groups[g]
-            n = b - a
-            t0 = time.time()
-            k = tick[g]
-            slot = k & 1
-            # flags of the state this env-step will produce (they do not depend on its outcome) + context rows of this tick
-            act_g = active[a:b]
-            fl = fl_np[g, slot].reshape(4, nmax)
-            t_next = self.cur_t[a:b] + act_g
-            fl[0, :n] = t_next
-            fl[1, :n] = self.frame_base[a:b] + t_next
-            fl[2, :n] = (t_next >= T_eff) & act_g
-            fl[3, :n] = act_g
-            np.minimum(self.cur_t[a:b], self.ctx_T - 1, out=ti_np[g, slot, :n])
-            soff = (g * 2 + slot) * 24 * nmax
-            if flags_upload:
-                lib.egp_upload_async(slab_dp + soff, slab_hp + soff, 24 * nmax, cur_stream)
-            else:
-                lib.egp_host_store_fence()          # (the 'bar' slab is write-combining memory)
-            fbase = slab_dp + soff
-            nz_p = None if self.mean_action else noise_p + (k * N + a) * nu * 4
-            rc = lib.egp_policy_gaussian_f32(v_out_p + a * v_stride * 4, v_stride, H, fbase + 16 * nmax,
-                                             P["states"] + (k * N + a) * od * 8, od, n, fz.desc, len(fz.layers), fz.act,
-                                             fz.log_std.data_ptr(), nz_p, P["actions"] + (k * N + a) * nu * 8, None,
-                                             cur_stream)
-            if rc != 0:
-                _lib.check(rc, "egp_policy_gaussian_f32")
-            ev = ev_ring[g][slot]           # the env-step that waited on it two ticks ago has long finished
-            ev.record()
-            self._events[g] = ev
-            if reward_job:      # K2 rides behind this env-step's kernel on the engine's stream
-                rc = eng.lib.egp_engine_set_reward_job(eng.handle, g, fbase, fbase + 4 * nmax, fbase + 8 * nmax, fbase + 12 * nmax, end_r,
-                                                       P["rewards"] + (k * N + a) * 8, P["cinfo"] + (k * N + a) * 5 * 8)
-                if rc != 0:
-                    _lib.check(rc, "egp_engine_set_reward_job")
-            np.copyto(act_i32, active, casting="unsafe")
-            rc = eng.lib.egp_engine_step_async(eng.handle, g, P["actions"] + k * N * nu * 8, act_i32.ctypes.data, ev.cuda_event)
-            if rc != 0:
-                _lib.check(rc, "egp_engine_step_async")
-            tm["policy"] += time.time() - t0
-
-        def post_fast(g):
-            a, b = self.groups[g]
-            n = b - a
-            t0 = time.time()
-            rc = eng.lib.egp_engine_wait(eng.handle, g, cur_stream)
-            if rc != 0:
-                _lib.check(rc, "egp_engine_wait")
-            t1 = time.time()
-            k = tick[g]
-            slot = k & 1
-            # the filter -> policy chain of the next tick starts here: launch K3+K6 (and K2) before the host bookkeeping;
-            # everything they read was staged before the env-step (flags) or is on the device (state, ping-pong filter)
-            fbase = slab_dp + (g * 2 + slot) * 24 * nmax          # the flags pre_fast staged for this env-step
-            if zf_p is not None:                 # same ping-pong as _obs_filter
-                new_t, new, cur = self._zf_bufs[self._zf_flip], zf_p[self._zf_flip], self.zf_state.data_ptr()
-                self._zf_flip ^= 1
-            else:                                # raw observations (no running_state)
-                new_t, new, cur = None, None, None
-            # K3+K6 (-> next_states[k] and states[k+1]) and K2 (-> rewards[k], cinfo[k]): three launches, one call
-            if not post_fused:
-                rc = lib.egp_obs_zfilter_f64(hnd, qpos_p + a * ctx.nq * 8, qvel_p + a * ctx.nv * 8, fbase, fbase + 12 * nmax, n, cur, new, zclip,
-                                             P["next_states"] + (k * N + a) * od * 8, P["states"] + ((k + 1) * N + a) * od * 8, 0, ws_p,
-                                             cur_stream)
-                if rc == 0 and not reward_job:
-                    rc = lib.egp_reward_quat_v3_f64(hnd, qpos_p + a * ctx.nq * 8, prev_p + a * ctx.nq * 8, ee_p + a * 15 * 8, fbase,
-                                                    fbase + 4 * nmax, fbase + 8 * nmax, fbase + 12 * nmax, end_r, n,
-                                                    P["rewards"] + (k * N + a) * 8, P["cinfo"] + (k * N + a) * 5 * 8, cur_stream)
-            else:
-                rc = lib.egp_post_step_f64(hnd, qpos_p + a * ctx.nq * 8, qvel_p + a * ctx.nv * 8, prev_p + a * ctx.nq * 8, ee_p + a * 15 * 8,
-                                           fbase, fbase + 4 * nmax, fbase + 8 * nmax, fbase + 12 * nmax, n, cur, new, zclip,
-                                           P["next_states"] + (k * N + a) * od * 8, P["states"] + ((k + 1) * N + a) * od * 8, ws_p, end_r,
-                                           P["rewards"] + (k * N + a) * 8, P["cinfo"] + (k * N + a) * 5 * 8, cur_stream)
-            if rc != 0:
-                _lib.check(rc, "egp_post_step")
-            if new_t is not None:
-                self.zf_state = new_t
-            act_g = active[a:b]
-            self.cur_t[a:b] += act_g
-            ct = self.cur_t[a:b]
-            head_z = eng.head_z[a:b]
-            if self.env.fix_head_lb is not None:
-                fail = head_z < self.env.fix_head_lb
-            else:
-                fail = head_z < lb[self.e_ind[a:b]] - 0.1
-            end = ct >= (T_ep if self.env.fix_len is None else self.env.fix_len)
-            done = (fail | end) & act_g
-            host["valid"][k, a:b], host["done"][k, a:b] = act_g, done
-            host["e_ind"][k, a:b], host["s_ind"][k, a:b] = self.e_ind[a:b], self.s_ind[a:b]
-            steps_done[a:b] += act_g
-            t2 = time.time()
-            if done.any():
-                ids = np.nonzero(done)[0] + a
-                ep_lens.extend(self.cur_t[ids].tolist())
-                again = after_episodes(ids, a, b)
-                if len(again):
-                    self._reset_slots(again)
-                    mask = np.zeros(b - a, np.int32)
-                    mask[again - a] = 1
-                    self._obs_filter(a, b, rec["states"][k + 1, a:b], active=self.up(mask).to(torch.int32), write_only_active=True)
-            tick[g] = k + 1
-            t3 = time.time()
-            tm["wait"] += t1 - t0
-            tm["post"] += t2 - t1
-            tm["reset"] += t3 - t2
-            note_tick(g, int(act_g.sum()), t3)
-            if trace is not None:           # EGP_TICK_TRACE: (group, tick, stepped envs, wait, post, reset) per env-step
-                trace.append((g, k, int(act_g.sum()), t1 - t0, t2 - t1, t3 - t2))
-
-        if fast:
-            pre_step, post_step = (pre_native, post_native) if tickd is not None else (pre_fast, post_fast)
+        if tickd is not None:
+            pre_step, post_step = pre_native, post_native
         tm["setup"] = time.time() - t_start          # tables, record arrays, first reset of every slot, noise (host time: launches are asynchronous)
         # the tick loop is a latency chain (the Python thread hands a group its next env-step ~25 us after the last one ended): keep
         # the cyclic garbage collector out of it and let it run afterwards -- a generation-0 pass costs 50-200 us, a full one tens
         # of ms. It trims rare pauses, not the typical rollout (tools/probes/outlier_probe.py, 60 rollouts each way: mean 99.5
-        # against 101.0 ms, worst 110 against 131; the medians of an alternating A/B are equal). EGP_GC_IN_TICKS=1 leaves it on.
-        gc_was_on = gc.isenabled() and os.environ.get("EGP_GC_IN_TICKS", "0") != "1"
+        # against 101.0 ms, worst 110 against 131; the medians of an alternating A/B are equal).
+        gc_was_on = gc.isenabled()
         if gc_was_on:
             gc.disable()
         try:
@@ -891,6 +718,8 @@ class LockstepRollout:
         if budget == "global" and n_steps < min_batch_size:
             raise RuntimeError("rollout ended with %d steps, fewer than min_batch_size %d" % (n_steps, min_batch_size))
         ep = np.asarray(ep_lens, float)
+        if self.reward_kind == "env":          # c_reward = 0.0, c_info = [0.0] on every step (agents/agent.py:57)
+            stats = np.zeros(4)
         log = LoggerRL.from_totals(n_steps, len(ep), float(n_steps), ep.min(), ep.max(), stats[0], stats[1], stats[2], stats[3:])
         if self.running_state is not None:
             self.running_state.from_device_state(self.zf_state)

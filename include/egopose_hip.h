@@ -239,22 +239,6 @@ int egp_obs_zfilter_apply_f64(egp_ctx *ctx, const double *qpos, const double *qv
 /* hipMemcpyAsync host (pinned) -> device on `stream`: the per-tick integer flags of the rollout driver (kernels that
  * re-read a flag array must not read it from pinned memory: every access would cross PCIe) */
 int egp_upload_async(void *dst_device, const void *src_pinned, int64_t bytes, void *stream);
-/* Host-visible DEVICE memory: fine-grained HBM the host writes through the PCIe BAR (write-combining, posted stores) and
- * kernels read at HBM latency -- for small tables the host refills every tick (the rollout driver's flag slab with
- * egp_rollout_tick.flags_upload == 0), where a pinned host buffer costs every reading wave a PCIe round trip that queues
- * behind the resident env-step kernel's state-row traffic. The host must not READ it (uncached PCIe reads) and must call
- * egp_host_store_fence() between its last store and the launch that reads (egp_rollout_tick_pre does).
- * EGP_E_STATE: the device's memory is not fully host-addressable (no large BAR) -- use pinned memory. */
-int egp_hostvis_alloc(int32_t device, int64_t bytes, void **ptr);
-int egp_hostvis_free(void *ptr);
-void egp_host_store_fence(void);
-/* One rollout tick's post-step in three launches: egp_obs_zfilter (all rows written to y / y2, rows with active != 0 update
- * the statistics; state_in == NULL: raw observations) + egp_reward_quat_v3 with the same mask; the reward's workgroups
- * ride in the launch of the filter's first pass. Same arithmetic as the two separate calls (bit-identical, tested). */
-int egp_post_step_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const double *prev_qpos, const double *ee_wpos,
-                      const int32_t *t, const int32_t *frame, const int32_t *end, const int32_t *active, int32_t n,
-                      const double *state_in, double *state_out, double clip, double *y, double *y2, void *workspace,
-                      double end_reward, double *reward, double *cinfo, void *stream);
 
 /* ---------------------------------------------------------------------------------------- K5
  * estimate_advantages (core/common.py:5-25) over the flat concatenated batch.
@@ -457,37 +441,6 @@ int egp_set_dynamics_model(egp_ctx *ctx, const egp_dynamics_desc *desc);
 int egp_dynamics_f64(egp_ctx *ctx, const double *qpos, const double *qvel, int32_t n, double *qM, int64_t ld_m,
                      double *qfrc_bias, double *xpos, void *stream);
 
-/* ----------------------------------------------------------------------------------------
- * The update's policy / value MLP as one launch per direction (csrc/egp_chain.hip): three chained products over 128-row tiles
- * with the intermediate activations in registers, weights streamed through LDS from pre-split bf16 fragment streams.
- *   forward  (models/mlp.py:22-25, core/policy_gaussian.py:19-24, core/critic.py:15-18):
- *       in = [src1[gather[r]][0:c1] | src2[r][0:c2]]  ->  relu(W1 in + b1)  ->  relu(W2 . + b2)  ->  W3 . + b3  =  out[r]
- *       optional saves for the backward pass, [feature][ldT] float32: inT (the input), o1T, o2T (the hidden activations)
- *   backward (data gradients of the same layers): src1 = d out [n][dims[0]] (gather NULL, c2 = 0), packed = W3^T, W2^T, W1[:, :H]^T,
- *       mask1 / mask2 = the saved o2T / o1T of the forward pass; o1T / o2T receive d z2^T / d z1^T, inT receives d out^T (the
- *       operands of the weight gradients, k-contiguous for egp_gemm_f32), out = d ctx, row r written to out[scatter[r]].
- * dims = {in, product-1 out, product-2 out, product-3 out}. Built shapes: 32-feature block counts (10, 7, 2 | 1) forward and
- * (7, 10, 4) backward -- the shipped 243 -> 300 -> 200 -> 52 | 1 nets; anything else returns EGP_E_INVALID (callers keep the
- * layer-per-launch path of egp_gemm_f32 for other widths). Products are the six-term three-piece bf16 products of egp_gemm_f32.
- * Weights: egp_mlp_chain_pack_f32 turns an nn.Linear weight W[n_out][k_in] (or its transpose: the operand's element (i, k) is
- * W[k][i], n_out = the operand's rows) into the fragment stream of one product; `chained` = the product is fed from the
- * previous product's accumulators (products 2 and 3), else from memory (product 1). egp_mlp_chain_pack_bytes(rows, k) bytes. */
-typedef struct egp_mlp_chain_desc {
-    int32_t n, backward;
-    const float *src1; int64_t ld1; const int64_t *gather; int32_t c1;
-    const float *src2; int64_t ld2; int32_t c2;
-    const void *packed[3];
-    const float *bias[3];
-    int32_t dims[4];
-    const float *mask1, *mask2;
-    float *inT, *o1T, *o2T; int64_t ldT;
-    float *out; int64_t ld_out; const int64_t *scatter;
-} egp_mlp_chain_desc;
-int32_t egp_mlp_chain_ksteps(int32_t k_in);
-int64_t egp_mlp_chain_pack_bytes(int32_t n_out, int32_t k_in);
-int egp_mlp_chain_pack_f32(const float *weight, int64_t ldw, int32_t n_out, int32_t k_in, int32_t transpose, int32_t chained, void *packed,
-                           void *stream);
-int egp_mlp_chain_f32(const egp_mlp_chain_desc *desc, void *stream);
 
 /* ----------------------------------------------------------------------------------------
  * Rollout-time policy step in one launch (replaces, for all envs of a group at once, the chain
@@ -588,7 +541,10 @@ int egp_physics_drain_host(egp_physics *p, int32_t env, double *qpos_host, doubl
  * Lockstep rollout engine: n_env envs advance one env-step (frame_skip substeps of
  * {K1 on the GPU <-> physics on host threads}) per egp_engine_step. Replaces the 15x
  * compute_torque/sim.step loop of do_simulation (ego_pose/envs/humanoid_v1.py:158-177) for all
- * envs at once; state is staged through pinned buffers with hipMemcpyAsync on per-worker streams. */
+ * envs at once. State, inertia and torque rows live in pinned host memory the kernels address in place (zero-copy). Two forms of the
+ * env-step: RESIDENT (default: one K1 launch serves all frame_skip substeps, trading go words / torque rows with the physics threads;
+ * taken when every workgroup of every group fits on the chip at once) and PER-SUBSTEP (one K1 launch per substep; the fallback for other
+ * dof trees / K1 variants, more slots than the chip holds resident workgroups for, or EGP_SERVER=0). */
 typedef struct egp_engine_desc {
     int32_t n_env;
     int32_t n_threads;       /* host physics worker threads (reference: --num-threads samplers) */
@@ -633,23 +589,19 @@ double egp_engine_event_overhead_ms(egp_engine *e);   /* calibrated cost of an e
 int egp_engine_set_profile(egp_engine *e, int on);   /* 0 off; 1: HIP events around every K1 launch; N>1: on every Nth env-step */
 int egp_engine_layout(egp_engine *e, int32_t *pack_ld, int32_t *n_env, int32_t *n_threads, int32_t *n_groups);
 int egp_engine_group_range(egp_engine *e, int32_t group, int32_t *env_begin, int32_t *env_end);
-/* K1 launches a group issues per substep: 1, or the number of chunks when the group runs pipelined
- * (>= 3 threads, >= 16 envs, polled zero-copy mode; EGP_CHUNKS, default 2) */
 /* ----------------------------------------------------------------------------------------
  * One tick of the lockstep sampler (Agent.sample_worker's loop body, core/agent.py:31-66, for every slot of an env group
  * at once) on the native side: the per-slot bookkeeping and the calls the rollout driver otherwise makes one by one from
  * Python (flags of the coming env-step, their upload, the fused policy step, the reward job, the env-step; then the wait,
  * K3 + K6, K2 and the termination flags of HumanoidEnv.step, ego_pose/envs/humanoid_v1.py:182-199). The driver fills the
  * descriptor once per rollout; the arrays are its own (NumPy / device tensors) and stay valid for the rollout.
- *   flags_upload: how the tick's flag slab reaches the device -- 0 kernels read slab_host in place (then slab_dev == slab_host: pinned
- *                 memory read over PCIe, or egp_hostvis_alloc memory the host fills through the BAR),
- *                 1 a copy-engine transfer in front of the policy step, 2 the policy kernel moves it (egp_policy_gaussian_staged_f32)
+ *   the tick's flag slab (pinned) reaches its device copy inside the policy step (egp_policy_gaussian_staged_f32 / _filter_f32)
  *   pre : flags / context rows of tick k for slots [a, b) -> policy -> env-step (asynchronous)
  *   post: wait for the env-step, observation + filter into states[k + 1] / next_states[k], reward, cur_t / done / record rows;
  *         *n_done = slots whose episode ended, *wait_s = seconds blocked on the env-step */
 typedef struct egp_rollout_tick {
     egp_ctx *ctx; egp_engine *eng; void *stream;
-    int32_t n_env, nmax, obs_dim, nu, nq, nv, ctx_dim, ctx_T, episode_len, reward_job, flags_upload, has_fix_head_lb;
+    int32_t n_env, nmax, obs_dim, nu, nq, nv, ctx_dim, ctx_T, episode_len, reward_job, has_fix_head_lb;
     double end_reward, zf_clip, fix_head_lb;
     /* host state of the env slots */
     int64_t *cur_t, *frame_base, *e_ind, *s_ind, *steps_done;
@@ -666,10 +618,7 @@ typedef struct egp_rollout_tick {
     const double *qpos, *qvel, *prev_qpos, *ee;  /* the engine's device state */
     void *zf_workspace;
     int32_t *reset_scratch;                      /* [n_groups][2][3 * nmax] pinned, device-visible: ids | group mask | cur_t of egp_rollout_reset */
-    int32_t group_streams;                       /* 1: a group's tick is enqueued on its engine stream (egp_engine_group_stream); `stream` carries
-                                                  * the rollout's set-up and the reward launches (event-ordered); needs reward_job == 0 */
-    int32_t post_fused;                          /* 1 (and reward_job == 0): K3 + K6 + K2 through egp_post_step_f64 */
-    int32_t defer_apply;                         /* 1 (needs a filter, post_fused == 0, groups of at most egp_obs_zfilter_split_max_rows() slots):
+    int32_t defer_apply;                         /* 1 (needs a filter, groups of at most egp_obs_zfilter_split_max_rows() slots):
                                                   * `post` runs the filter's statistics pass only; its apply pass rides in the next tick's policy
                                                   * step (egp_rollout_tick_pre with apply_pending = 1 and the same zf_cur / zf_new) or, in a tick with
                                                   * in-batch resets and in a group's last tick, is run by egp_rollout_tick_apply */
@@ -685,11 +634,10 @@ int egp_rollout_tick_post(const egp_rollout_tick *d, int32_t group, int32_t a, i
  * row of frame 0, cur_t = cur_t0[j] -- NULL: 0; cfg.random_cur_t, humanoid_v1.py:218-220: the state rows then are those of frame
  * start + cur_t0), the slots' video-context rows `ctx_rows` (device, [n][ctx_T][ctx_dim] float32) into v_out, and K3 + K6
  * over the group with only those slots active: their filtered observation replaces states[k + 1] (the running filter advances
- * zf_cur -> zf_new exactly as one more egp_obs_zfilter_f64 call). Uses reset_scratch slot k & 1 of the group.
- * ctx_rows_fresh != 0: ctx_rows were produced on `stream` since the last call (group-stream ticks order themselves behind it). */
+ * zf_cur -> zf_new exactly as one more egp_obs_zfilter_f64 call). Uses reset_scratch slot k & 1 of the group. */
 int egp_rollout_reset(const egp_rollout_tick *d, int32_t group, int32_t a, int32_t b, int32_t k, const int32_t *ids, int32_t n,
                       const int64_t *e_ind, const int64_t *s_ind, const int64_t *frame_rows, const int64_t *cur_t0, const double *qpos, const double *qvel,
-                      const float *ctx_rows, int32_t ctx_rows_fresh, const double *zf_cur, double *zf_new);
+                      const float *ctx_rows, const double *zf_cur, double *zf_new);
 /* the stream group g's env-step kernels are launched on (owned by the engine) */
 void *egp_engine_group_stream(egp_engine *e, int32_t group);
 
@@ -703,15 +651,34 @@ int egp_engine_set_reward_job(egp_engine *e, int32_t group, const int32_t *t, co
 /* diagnostic: `blocks` workgroups of arithmetic for `us` microseconds on `stream` (does a busy GPU clock the rollout's short
  * kernels differently? tools/probes/burn_probe.py); `sink` = any device float */
 int egp_debug_burn(int64_t us, int32_t blocks, float *sink, void *stream);
-int egp_engine_launches_per_substep(egp_engine *e);
 /* substeps one K1 launch serves: frame_skip when the engine runs the resident K1 (one launch per env-step that
  * trades go/done words with the physics threads through pinned memory; EGP_SERVER=0 turns it off), else 1 */
 int egp_engine_substeps_per_launch(egp_engine *e);
+/* where the resident K1's go words live: 1 = fine-grained device memory the host writes through the PCIe BAR (large-BAR systems),
+ * 0 = pinned host memory the waves poll over PCIe, -1 = the engine does not run the resident K1 */
+int32_t egp_engine_go_words_in_vram(egp_engine *e);
 /* diagnostics (engine created with EGP_SERVER_TRACE=1): the last env-step of `group` as seen by block 0 of the
  * resident K1 -- device_ticks[frame_skip*8], 100 MHz wall_clock64 stamps per substep: poll start, go seen, state
  * loaded, solved, torques stored -- and by the owner of slice 0 -- host_us[frame_skip*4], microseconds since the
  * step was posted: wait start, first torque row in, go written */
 int egp_engine_server_trace(egp_engine *e, int32_t group, int64_t *device_ticks, double *host_us);
+/* Host probe (egp_probe.hip): ~2 s of measurements of what the rollout's env-step depends on OUTSIDE this library's code -- the box.
+ * The env-step is a latency chain through the host (per substep: go word host -> GPU, state rows GPU <- pinned memory over PCIe,
+ * torque rows GPU -> pinned memory; host threads spinning on those rows): the reference has no such path (its sampler is
+ * CPU-only, agents/agent.py:29-111), so this has no counterpart there; bench.py reports the numbers next to T_sample (the
+ * reference prints T_sample / T_update per iteration, ego_pose/ego_mimic.py:115-126) so that a slow run can be told from a slow box.
+ *   pcie_read_*   1 024 pinned state rows (176 doubles) read by one wave per row with the resident K1's access shape
+ *   go_rtt_*      microseconds from the host's go-word store to the arrival of the 52-double row a resident wave writes back after
+ *                 reading one state row (one substep's round trip without the solve); go_in_vram: the go word lived in fine-grained
+ *                 device memory behind a large BAR, as the engine's do by default
+ *   spin_*        n_threads threads spin on the clock for `millis` ms: gaps between two reads = time a spinning thread was not running */
+typedef struct egp_host_probe_result {
+    double pcie_read_gbps, pcie_read_us_per_pass;
+    double go_rtt_us_p50, go_rtt_us_p99, go_rtt_us_max;
+    double spin_gap_us_max, spin_gap_us_median_of_thread_max, spin_lost_frac;
+    int32_t pcie_read_rows, go_rtt_n, go_in_vram, large_bar, spin_threads, spin_gaps_over_5us;
+} egp_host_probe_result;
+int egp_host_probe(int32_t device, int32_t n_threads, int32_t millis, egp_host_probe_result *out);
 int32_t egp_physics_n_env(const egp_physics *p);
 
 #ifdef __cplusplus

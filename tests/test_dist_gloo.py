@@ -81,7 +81,7 @@ def _worker(rank, world, port, out_dir):
     two = torch.tensor([3.0, 1.0e8 + 1.0, 2.0], dtype=torch.float64) if rank == 0 else torch.tensor([2.0, 1.0e8 + 3.5, 0.5], dtype=torch.float64)
     gm2 = D.merge_moments(two)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), n_steps=merged.num_steps, avg_c=merged.avg_c_reward,
-             min_c=merged.min_c_reward, max_ep=merged.max_episode_reward, avg_ci=merged.avg_c_info,
+             min_c=merged.min_c_reward, max_ep=merged.max_episode_reward, min_ep=merged.min_episode_reward, avg_ci=merged.avg_c_info,
              zf_n=zf.rs.n, zf_mean=zf.rs.mean, zf_std=zf.rs.std, count=D.global_count(3 + rank, "cpu"),
              gmax=D.global_max(5 + 2 * rank), n_coll=n_coll, gm2=gm2.numpy(), **final)
     dist.barrier()
@@ -103,6 +103,8 @@ def test_two_rank_ppo_update_equals_single_process_reference(tmp_path):
     assert int(r0["n_steps"]) == 21 and int(r0["count"]) == 7 and int(r0["gmax"]) == 7
     np.testing.assert_allclose(r0["avg_c"], (4.5 + 9.0) / 21)
     np.testing.assert_allclose(r0["min_c"], 0.1)
+    # per-rank minima 3 and 4, maxima 7 and 8: the reference's merge takes max() of the MINIMA too (core/logger_rl.py:52)
+    assert float(r0["min_ep"]) == 4.0 and float(r0["max_ep"]) == 8.0 and float(r1["min_ep"]) == 4.0
     np.testing.assert_allclose(r0["avg_ci"], np.arange(5.0) * 3 / 21)
     assert int(r0["n_coll"]) == 1 and int(r1["n_coll"]) == 1                  # one collective per sampling pass
     # Chan merge of {3, 1e8+1, 2} and {2, 1e8+3.5, 0.5}: d = 2.5, M2 = 2.5 + 6.25 * 6/5 = 10 (raw sums would lose it at 1e16)

@@ -344,13 +344,34 @@ def test_gae_sizes_vs_oracle(ctx):
             np.testing.assert_allclose(adv.cpu().numpy(), a_ref.ravel(), rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("n", [134656, 204800])
+def test_gae_f32_at_update_batch_size_vs_oracle(ctx, n):
+    """north_star: "returns/advantages within 1e-4 fp32 given identical trajectories" at the batch sizes the update really runs
+    the float32 kernel on (k_gae_replay<float>: ~134 k rows per iteration of config 2, 204 800 = the slot sweep's), against the
+    oracle's reverse sweep (core/common.py:5-25) on episodes of the rollout's shape: rewards in [0, 1.2], 30-200-step episodes."""
+    rng = np.random.RandomState(n)
+    r = rng.uniform(0, 1.2, size=n)
+    m = np.ones(n)
+    ends = np.cumsum(rng.randint(30, 201, size=n // 30 + 1))
+    m[ends[ends < n] - 1] = 0.0
+    m[-1] = 0.0
+    v = rng.normal(size=n) * 2 + 5
+    a_ref, r_ref, raw_ref = G.estimate_advantages(r, m, v, 0.95, 0.95)
+    f32 = torch.float32
+    adv, ret, stats = ctx.gae(dev(r, f32), dev(m, f32), dev(v, f32), 0.95, 0.95)
+    np.testing.assert_allclose(ret.cpu().numpy(), r_ref.ravel(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(adv.cpu().numpy(), raw_ref.ravel(), rtol=1e-4, atol=1e-4)
+    ctx.gae_standardize(adv, stats)
+    np.testing.assert_allclose(adv.cpu().numpy(), a_ref.ravel(), rtol=1e-4, atol=1e-4)
+    s = stats.cpu().numpy()
+    np.testing.assert_allclose([s[0], s[1]], [n, raw_ref.mean()], rtol=1e-4)
+
+
 # ------------------------------------------------------------------------------------------------ engine
-ENGINE_MODES = {                     # env switches read by egp_engine_create -> (launches/substep, substeps/launch)
-    "resident": ({}, None),                                        # (go words in HBM, pushed by the host with fenced stores: the default)
-    "resident-pinned-go": ({"EGP_BAR_GO": "0"}, None),             # go words in pinned host memory, pulled by the waves
-    "pipelined": ({"EGP_SERVER": "0", "EGP_CHUNKS": "2"}, None),
-    "barrier": ({"EGP_SERVER": "0", "EGP_CHUNKS": "1"}, (1, 1)),
-    "copies": ({"EGP_SERVER": "0", "EGP_ZERO_COPY": "0"}, (1, 1)),
+ENGINE_MODES = {                     # env switches read by egp_engine_create -> substeps per K1 launch
+    "resident": ({}, 15),                                          # (go words in HBM, pushed by the host with fenced stores: the default)
+    "resident-pinned-go": ({"EGP_BAR_GO": "0"}, 15),               # go words in pinned host memory, pulled by the waves
+    "per-substep": ({"EGP_SERVER": "0"}, 1),                       # the fallback: one K1 launch per substep, completion flag polled
 }
 
 
@@ -371,10 +392,7 @@ def test_engine_step_matches_host_loop(ctx, skel, mode, monkeypatch):
     for n_groups, n_threads in [(1, 3), (2, 4)]:
         ph = SurrogatePhysics(skel, n)
         eng = RolloutEngine(ctx, ph, n, n_threads=n_threads, n_groups=n_groups)
-        if mode.startswith("resident"):
-            assert (eng.launches_per_substep, eng.substeps_per_launch) == (1, 15)
-        elif ENGINE_MODES[mode][1]:
-            assert (eng.launches_per_substep, eng.substeps_per_launch) == ENGINE_MODES[mode][1]
+        assert eng.substeps_per_launch == ENGINE_MODES[mode][1]
         eng.reset(np.arange(n), qpos0, qvel0)
         act_d = dev(action)
         torch.cuda.synchronize()
@@ -404,7 +422,7 @@ def test_engine_step_matches_host_loop(ctx, skel, mode, monkeypatch):
         ref.close()
 
 
-@pytest.mark.parametrize("mode", ["resident", "pipelined", "barrier", "copies"])
+@pytest.mark.parametrize("mode", ["resident", "per-substep"])
 def test_engine_step_with_torque_actions(skel, mode, monkeypatch):
     """cfg.action_type = 'torque' through the engine: every substep applies clip(a_ref + a * a_scale) (humanoid_v1.py:167-172),
     no PD solve -- against the host loop with the oracle's control law, in every mode of the substep loop."""
@@ -447,9 +465,9 @@ def test_engine_step_with_torque_actions(skel, mode, monkeypatch):
 
 
 def test_resident_engine_dealt_slices_are_bit_identical(ctx, skel, monkeypatch):
-    """With an active mask the resident engine may deal its slices out to the host threads per env-step
-    (EGP_SERVER_BALANCE: 1 = always, 0 = never, unset = when a substep of physics is expensive enough): who steps an env
-    changes, the env's numbers do not, and an inactive env is never touched."""
+    """With an active mask the resident engine deals its slices out to the host threads per env-step once a substep of physics
+    is expensive enough (2 us per env-substep; the free surrogate stays with fixed ownership): who steps an env changes, the
+    env's numbers do not, and an inactive env is never touched."""
     from egopose_amd.physics import SurrogatePhysics, RolloutEngine
     g = load_golden("body_quat_obs.npz")
     n = 203
@@ -460,12 +478,9 @@ def test_resident_engine_dealt_slices_are_bit_identical(ctx, skel, monkeypatch):
     masks = [(rng.rand(n) < p).astype(np.int32) for p in (0.6, 0.5, 0.15, 0.03)]
     masks[3][:8] = 1                                   # a crowded first slice: the case dealing is for
     out = {}
-    for bal in ("0", "1", "by-cost"):
-        if bal == "by-cost":            # the default rule, with a physics step slow enough (3 us) for it to start dealing
-            monkeypatch.delenv("EGP_SERVER_BALANCE")
-            monkeypatch.setenv("EGP_SURROGATE_SUBSTEP_US", "3")
-        else:
-            monkeypatch.setenv("EGP_SERVER_BALANCE", bal)
+    for bal in ("fixed", "by-cost", "by-cost-8us"):
+        if bal != "fixed":              # a physics step slow enough (3 / 8 us) for the engine to start dealing
+            monkeypatch.setenv("EGP_SURROGATE_SUBSTEP_US", "3" if bal == "by-cost" else "8")
         ph = SurrogatePhysics(skel, n)
         eng = RolloutEngine(ctx, ph, n, n_threads=6, n_groups=2)
         assert eng.substeps_per_launch == 15
@@ -480,13 +495,13 @@ def test_resident_engine_dealt_slices_are_bit_identical(ctx, skel, monkeypatch):
         out[bal] = (eng.qpos.cpu().numpy().copy(), eng.qvel.cpu().numpy().copy(), eng.ee_wpos.cpu().numpy().copy())
         eng.close()
         ph.close()
-    for other in ("1", "by-cost"):
-        for a, b in zip(out["0"], out[other]):
+    for other in ("by-cost", "by-cost-8us"):
+        for a, b in zip(out["fixed"], out[other]):
             np.testing.assert_array_equal(a, b)
     never = (masks[0] | masks[1] | masks[2] | masks[3]) == 0
     assert never.any()
-    np.testing.assert_array_equal(out["1"][0][never], qpos0[never])
-    assert np.abs(out["1"][0][~never] - qpos0[~never]).max() > 0
+    np.testing.assert_array_equal(out["by-cost"][0][never], qpos0[never])
+    assert np.abs(out["by-cost"][0][~never] - qpos0[~never]).max() > 0
 
 
 def test_surrogate_always_dirty_changes_traffic_not_numbers(ctx, skel, monkeypatch):
@@ -518,7 +533,55 @@ def test_surrogate_always_dirty_changes_traffic_not_numbers(ctx, skel, monkeypat
         np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("mode", ["resident", "pipelined", "barrier"])
+def _changing_inertia_env_steps(eng, be, qpos0, qvel0, seed=4):
+    """reset all envs -> env-step -> re-seat envs 3, 4, 17 -> env-step on a VaryingInertiaBackend engine; returns the actions,
+    the final qpos and every torque row the backend was handed, per env."""
+    n = be.n_env
+    rng = np.random.RandomState(seed)
+    be.torques = [[] for _ in range(n)]
+    eng.reset(np.arange(n), qpos0, qvel0)
+    actions = []
+    for step in range(2):
+        a = rng.normal(size=(n, 52)) * 0.2
+        actions.append(a)
+        act_d = dev(a)
+        torch.cuda.synchronize()
+        eng.step_async(0, act_d)
+        eng.wait(0)
+        if step == 0:                                  # re-seat a few envs between the two env-steps (ordered by the engine, no sync)
+            ids = np.array([3, 4, 17])
+            eng.reset(ids, qpos0[ids], qvel0[ids])
+    torch.cuda.synchronize()
+    assert not be.physics.errors
+    return actions, eng.qpos.cpu().numpy(), [np.array(t) for t in be.torques]
+
+
+@pytest.mark.parametrize("mode", ["resident", "per-substep"])
+def test_engine_changing_inertia_repeats_bit_identically(ctx, skel, mode, monkeypatch):
+    """Stress of the inertia path's orderings (K1 once read inertia rows a reset's scatter kernel was still
+    writing -- found by one flaky run): the reset / env-step / partial reset / env-step sequence 50 times on one engine, no host
+    synchronisation between a reset and the env-step behind it; every torque row and the final state bit-identical to the first run."""
+    from conftest import VaryingInertiaBackend
+    from egopose_amd.physics import RolloutEngine
+    for k, v in ENGINE_MODES[mode][0].items():
+        monkeypatch.setenv(k, v)
+    g = load_golden("body_quat_obs.npz")
+    n = 26
+    qpos0, qvel0 = g["qpos"][:n], g["qvel"][:n] * 0.2
+    be = VaryingInertiaBackend(skel, n)
+    eng = RolloutEngine(ctx, be, n, n_threads=3, n_groups=1)
+    assert eng.substeps_per_launch == ENGINE_MODES[mode][1]
+    _, q0, t0 = _changing_inertia_env_steps(eng, be, qpos0, qvel0)
+    for rep in range(49):
+        _, q, t = _changing_inertia_env_steps(eng, be, qpos0, qvel0)
+        np.testing.assert_array_equal(q, q0, err_msg="repeat %d" % rep)
+        for e in range(n):
+            np.testing.assert_array_equal(t[e], t0[e], err_msg="repeat %d env %d" % (rep, e))
+    eng.close()
+    be.close()
+
+
+@pytest.mark.parametrize("mode", list(ENGINE_MODES))
 def test_engine_follows_changing_inertia(ctx, skel, mode, monkeypatch):
     """A backend whose qM changes on every step (what a MuJoCo adapter looks like): every torque row the engine
     hands to step() must come from the inertia drained just before it, over two env-steps and a partial reset."""
@@ -529,27 +592,10 @@ def test_engine_follows_changing_inertia(ctx, skel, mode, monkeypatch):
     c = load_golden("config_subject_03.npz")
     g = load_golden("body_quat_obs.npz")
     n = 26
-    rng = np.random.RandomState(4)
     qpos0, qvel0 = g["qpos"][:n], g["qvel"][:n] * 0.2
     be = VaryingInertiaBackend(skel, n)
     eng = RolloutEngine(ctx, be, n, n_threads=3, n_groups=1)
-    eng.reset(np.arange(n), qpos0, qvel0)
-    actions = []
-    for step in range(2):
-        a = rng.normal(size=(n, 52)) * 0.2
-        actions.append(a)
-        act_d = dev(a)
-        torch.cuda.synchronize()
-        eng.step_async(0, act_d)
-        eng.wait(0)
-        torch.cuda.synchronize()
-        if step == 0:                                  # re-seat a few envs between the two env-steps
-            ids = np.array([3, 4, 17])
-            eng.reset(ids, qpos0[ids], qvel0[ids])
-            torch.cuda.synchronize()
-    assert not be.physics.errors
-    got_q = eng.qpos.cpu().numpy()
-    logged = [np.array(t) for t in be.torques]
+    actions, got_q, logged = _changing_inertia_env_steps(eng, be, qpos0, qvel0)
     eng.close()
     # replay on the host with the oracle's stable PD and the same per-step inertia
     from egopose_amd.physics import SurrogatePhysics
@@ -643,7 +689,7 @@ def test_fused_policy_step_matches_the_reference_policy_vectors():
     np.testing.assert_allclose(act.cpu().numpy(), g["a"], rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("mode", ["resident", "pipelined", "barrier"])
+@pytest.mark.parametrize("mode", ["resident", "per-substep"])
 def test_engine_reports_backend_failure_instead_of_hanging(ctx, skel, mode, monkeypatch):
     """A physics callback that fails in the middle of an env-step: every engine mode must come back with an error
     (the resident K1 is drained through its go words, nothing is left spinning on the GPU), stay failed for further
@@ -801,7 +847,7 @@ def test_constant_and_pose_dist_rewards_on_device(skel):
 @pytest.mark.parametrize("n,H", [(512, 128), (37, 128), (1024, 128), (300, 192), (512, 40)])
 def test_filter_apply_in_the_policy_step_is_bit_identical_to_the_two_launches(ctx, n, H):
     """egp_obs_zfilter_stats_f64 + egp_policy_gaussian_filter_f32 against egp_obs_zfilter_f64 + egp_policy_gaussian_f32 (what a
-    rollout tick without resets runs, rollout.py EGP_DEFER_APPLY): filtered observations, running statistics and actions equal
+    rollout tick without resets runs, rollout.py defer_apply): filtered observations, running statistics and actions equal
     bit for bit; so does the split pair stats + apply. Context widths: 128 (shipped; one input column per thread, the thread
     that normalises a state column merges its statistics -- with the merge coefficients shared across the wave), 192 (more
     input columns than threads: the statistics go through LDS), 40 (state columns straddle a wave boundary)."""
@@ -883,30 +929,3 @@ def test_large_batch_kernel_variants_equal_the_small_batch_ones(ctx, skel):
     parts = [ctx.dynamics(qp[a:a + 1500], qv[a:a + 1500], want_xpos=True) for a in range(0, m, 1500)]
     for key in ("qM", "bias", "xpos"):
         assert torch.equal(big[key], torch.cat([p[key] for p in parts])), key
-
-
-def test_host_visible_device_memory_round_trip():
-    """egp_hostvis_alloc (include/egopose_hip.h): fine-grained device memory the host fills through the PCIe BAR -- what the
-    rollout's EGP_TICK_FLAGS=bar keeps the tick's flag slab in. Host stores + egp_host_store_fence, then a device-side copy
-    must see every byte; EGP_E_STATE (no large BAR) is the one accepted refusal."""
-    import ctypes as C
-    from egopose_amd import _lib as L
-    lib = L.load()
-    n = 24 * 512 + 40
-    p = C.c_void_p()
-    rc = lib.egp_hostvis_alloc(torch.cuda.current_device(), n, C.byref(p))
-    if rc == -3:
-        pytest.skip("device memory is not host-addressable on this system (no large BAR)")
-    assert rc == 0 and p.value
-    view = np.ctypeslib.as_array((C.c_uint8 * n).from_address(p.value))
-    want = np.random.RandomState(3).randint(0, 256, n).astype(np.uint8)
-    view[:] = want
-    lib.egp_host_store_fence()
-    out = torch.zeros(n, dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    assert hip.hipMemcpy(C.c_void_p(out.data_ptr()), p, n, 4) == 0            # hipMemcpyDefault: a device-side read of the allocation
-    assert np.array_equal(out.cpu().numpy(), want)
-    del view
-    assert lib.egp_hostvis_free(p) == 0

@@ -119,6 +119,47 @@ def test_unmodified_reference_driver_runs_on_the_compat_packages(tmp_path, skel)
     assert len(origins) == 9 and all(o.startswith(os.path.join(REPO, "egopose_amd", "compat")) for o in origins), origins
 
 
+REF_FORECAST_DRIVER = "/root/reference/ego_pose/ego_forecast.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_FORECAST_DRIVER), reason="the reference tree only exists in the build container")
+def test_unmodified_forecast_driver_runs_on_the_compat_packages(tmp_path, skel, monkeypatch):
+    """Row f2 through row (b): `python <reference>/ego_pose/ego_forecast.py --cfg subject_03` executed AS IS on egopose_amd/compat
+    with max_iter_num 0 -- its imports (models.video_forecast_net, ego_pose.utils.egoforecast_config + egomimic_config), the warm
+    start from an ego_mimic checkpoint written in the reference's container (plain pickle.load, filter_state_dict of the first
+    affine layer because policy_s_net is 'lstm', load_state_dict(strict=False); ego_forecast.py:60-68), the two VideoForecastNets,
+    optimizers, AgentEgo and an empty main_loop. The iterations themselves run on the GPU (tests/test_rollout_gpu.py forecast tests)."""
+    from egopose_amd.config import Config, _ASSET_CFG
+    from egopose_amd.train import Trainer
+    root = _workspace(tmp_path, skel, n_frames=150)
+    monkeypatch.chdir(root)
+    # the ego_mimic checkpoint the forecast driver starts from (iter 1: a checkpoint of this package, in the reference's format)
+    tr = Trainer(Config("subject_03", create_dirs=True), torch.device("cpu"), torch.float64, num_envs=2, num_threads=1, num_groups=1)
+    tr.save("results/egomimic/subject_03/models/iter_0001.p")
+    tr.close()
+    os.makedirs(os.path.join(root, "config", "egoforecast"))
+    y = yaml.safe_load(open(os.path.join(os.path.dirname(_ASSET_CFG), "egoforecast", "subject_03.yml")))
+    y["max_iter_num"], y["ego_mimic_iter"] = 0, 1
+    yaml.safe_dump(y, open(os.path.join(root, "config", "egoforecast", "subject_03.yml"), "w"))
+    out = subprocess.run([sys.executable, REF_FORECAST_DRIVER, "--cfg", "subject_03", "--num-threads", "2"], cwd=root, env=_driver_env(),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    log = open(os.path.join(root, "results/egoforecast/subject_03/log/log.txt")).read()
+    assert "loading model from ego mimic checkpoint: results/egomimic/subject_03/models/iter_0001.p" in log and "training done!" in log
+    probe = ("import runpy, sys; sys.argv = [%r, '--cfg', 'subject_03']; ns = runpy.run_path(%r, run_name='__main__'); "
+             "mods = ['models.video_forecast_net', 'ego_pose.utils.egoforecast_config', 'ego_pose.utils.egomimic_config', "
+             "'ego_pose.core.agent_ego', 'ego_pose.envs.humanoid_v1']; "
+             "print('ORIGINS', [sys.modules[m].__file__ for m in mods]); "
+             "print('SHAPES', [ns['policy_vs_net'].out_dim, ns['policy_net'].net.affine_layers[0].in_features, "
+             "type(ns['policy_vs_net']).__module__, ns['cfg'].env_episode_len, ns['cfg'].fr_margin])" % (REF_FORECAST_DRIVER, REF_FORECAST_DRIVER))
+    out = subprocess.run([sys.executable, "-c", probe], cwd=root, env=_driver_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    origins = eval(out.stdout.split("ORIGINS", 1)[1].strip().splitlines()[0])
+    assert len(origins) == 5 and all(o.startswith(os.path.join(REPO, "egopose_amd", "compat")) for o in origins), origins
+    shapes = eval(out.stdout.split("SHAPES", 1)[1].strip().splitlines()[0])
+    assert shapes[0] == shapes[1] == 128 + 128 and shapes[2] == "egopose_amd.nets" and shapes[3:] == [90, 30], shapes   # v_hdim + s_hdim (lstm state net)
+
+
 def test_compat_packages_expose_the_driver_surface(tmp_path, skel):
     """The names ego_pose/ego_mimic.py:8-16 imports and the calls it makes on them (:29-99), resolved through
     egopose_amd/compat -- runs everywhere (the test above needs the reference tree). Sampling without an MI355X must

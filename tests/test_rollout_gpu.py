@@ -436,46 +436,77 @@ def test_forecast_full_iteration(workspace):
     tr.close()
 
 
+def _seeded_sample(tr, min_batch, end_reward=0.21):
+    """One rollout from a fixed seed state (host + device generators, env sampling stream, a fresh observation filter) on a
+    trainer that may have sampled before: everything a bit-equality comparison of two rollouts needs."""
+    from egopose_amd.zfilter import ZFilter
+    torch.manual_seed(123)
+    np.random.seed(5)
+    tr.env.seed(77)
+    tr.pre_iter_update(0)
+    tr.env.end_reward = end_reward
+    tr.running_state = tr.agent.running_state = ZFilter((tr.env.observation_space.shape[0],), clip=5)
+    ro = tr.agent._get_rollout()
+    ro.running_state = tr.running_state
+    ro.use_graphs = False                  # (torch tick: eager launches in every run)
+    ro.gen.manual_seed(4242)
+    ro._pool, ro._pool_pos = None, 0
+    torch.cuda.manual_seed(999)
+    batch, log = tr.agent.sample(min_batch)
+    rs = tr.running_state.rs
+    return dict(states=batch.states.copy(), actions=batch.actions.copy(), rewards=batch.rewards.copy(), masks=batch.masks.copy(),
+                next_states=batch.next_states.copy(), v_metas=batch.v_metas.copy(), n=rs.n, mean=np.array(rs.mean).copy(),
+                std=np.array(rs.std).copy(), steps=log.num_steps, eps=log.num_episodes, r=log.avg_c_reward)
+
+
+def _assert_same_rollout(a, b, what=""):
+    assert a["steps"] == b["steps"] and a["eps"] == b["eps"] and a["n"] == b["n"] and a["r"] == b["r"], what
+    for k in ("states", "actions", "rewards", "masks", "next_states", "v_metas", "mean", "std"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg="%s %s" % (what, k))
+
+
 @pytest.mark.parametrize("reward_delay_us", ["0", "500"])
-def test_fast_tick_path_is_bit_identical_to_the_torch_path(workspace, monkeypatch, reward_delay_us):
-    """The pointer-level tick (pinned flag slots read in place, one ctypes call per kernel) against the torch-tensor tick
-    with the same seeds: identical batches, filter statistics and logger totals. With `reward_delay_us` the reward
-    kernel that rides behind the env-step on the engine's stream is held back (EGP_REWARD_JOB_DELAY_US) so that an
-    in-batch reset on the caller's stream would overtake it unless egp_engine_reset is ordered behind it: terminal
-    rewards (incl. the end bonus) must still equal the torch tick's."""
-    outs = []
-    # "1": the tick's bookkeeping and launches in two native calls (egp_rollout_tick_pre / _post, the default);
-    # "py": the same from Python, one ctypes call per kernel (EGP_TICK_NATIVE=0); "0": the torch-tensor tick
-    # "group": the native tick with each group's launches on its engine stream (EGP_TICK_STREAMS=group), the reward on the
-    # caller's stream behind the env-step's kernel; "bar" / "py-bar": the tick's flag slab in host-visible device memory
-    # (EGP_TICK_FLAGS=bar: filled through the PCIe BAR, store fence in front of the launch) from the native and the Python tick;
-    # "query": the host polls the env-step's completion event instead of an event wait on the caller's stream (EGP_WAIT_QUERY=1)
-    for fast in ("0", "1", "group", "py", "bar", "py-bar", "query"):
-        monkeypatch.setenv("EGP_FAST_TICK", "0" if fast == "0" else "1")
-        monkeypatch.setenv("EGP_TICK_NATIVE", "0" if fast.startswith("py") else "1")
-        monkeypatch.setenv("EGP_TICK_STREAMS", "group" if fast == "group" else "shared")
-        monkeypatch.setenv("EGP_TICK_FLAGS", "bar" if fast.endswith("bar") else "kernel")
-        monkeypatch.setenv("EGP_WAIT_QUERY", "1" if fast == "query" else "0")
+def test_native_tick_is_bit_identical_to_the_torch_tick(workspace, monkeypatch, reward_delay_us):
+    """The native tick (pinned flag slabs staged by the policy kernel, two library calls per env-step, the reward riding behind
+    the resident K1, the filter's apply pass folded into the next policy step) against the torch-tensor tick with the same
+    seeds: identical batches, filter statistics and logger totals. With `reward_delay_us` the reward kernel that rides behind
+    the env-step on the engine's stream is held back (EGP_REWARD_JOB_DELAY_US) so that an in-batch reset on the caller's stream
+    would overtake it unless egp_engine_reset is ordered behind it: terminal rewards (incl. the end bonus) must still equal the
+    torch tick's. Also in the engine's per-substep form (EGP_SERVER=0: the reward is then launched by the tick itself)."""
+    outs = {}
+    for fast, server in (("0", "1"), ("1", "1"), ("0", "0"), ("1", "0")):
+        monkeypatch.setenv("EGP_FAST_TICK", fast)
+        monkeypatch.setenv("EGP_SERVER", server)
         monkeypatch.setenv("EGP_REWARD_JOB_DELAY_US", reward_delay_us if fast != "0" else "0")
-        monkeypatch.setenv("EGP_POLICY_GRAPH", "0")          # eager noise draws in both runs (same generator stream)
-        torch.manual_seed(123)
-        np.random.seed(5)
         tr, cfg = _trainer(workspace, 48, 14, num_threads=4, num_groups=2)
-        tr.env.seed(77)
-        tr.pre_iter_update(0)
-        tr.env.end_reward = 0.21
-        torch.cuda.manual_seed(999)
-        batch, log = tr.agent.sample(48 * 25)
-        rs = tr.running_state.rs
-        outs.append(dict(states=batch.states.copy(), actions=batch.actions.copy(), rewards=batch.rewards.copy(), masks=batch.masks.copy(),
-                         next_states=batch.next_states.copy(), v_metas=batch.v_metas.copy(), n=rs.n, mean=np.array(rs.mean).copy(),
-                         std=np.array(rs.std).copy(), steps=log.num_steps, eps=log.num_episodes, r=log.avg_c_reward))
+        outs[(fast, server)] = _seeded_sample(tr, 48 * 25)
+        assert tr.agent._get_rollout().engine.substeps_per_launch == (15 if server == "1" else 1)
         tr.close()
-    a = outs[0]
-    for b in outs[1:]:
-        assert a["steps"] == b["steps"] and a["eps"] == b["eps"] and a["n"] == b["n"] and a["r"] == b["r"]
-        for k in ("states", "actions", "rewards", "masks", "next_states", "v_metas", "mean", "std"):
-            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    # (the two forms of the env-step run different K1 kernels -- one lane per matrix row / a lane grid -- whose sums differ in the
+    #  last bits: each tick form is compared within one engine form)
+    _assert_same_rollout(outs[("0", "1")], outs[("1", "1")], "resident")
+    _assert_same_rollout(outs[("0", "0")], outs[("1", "0")], "per-substep")
+    assert abs(outs[("0", "1")]["r"] - outs[("0", "0")]["r"]) < 1e-6
+
+
+@pytest.mark.parametrize("server", ["1", "0"])
+def test_rollout_repeats_bit_identically_under_resets_on_every_tick(workspace, monkeypatch, server):
+    """Stress of the concurrency the rollout depends on (a cross-stream race was once found by a single
+    bit-equality run): 50 rollouts of 96 slots with 6-step episodes -- in-batch resets in nearly every tick of both groups, each
+    with its scatter kernel on the caller's stream, the env-step kernel and the reward job on the group's stream, host threads
+    re-arming torque rows -- from the same seed state on ONE engine, every one bit-identical to the first; resident and
+    per-substep form of the env-step. The reward job is held back 30 us so that orderings that only hold by luck fail."""
+    monkeypatch.setenv("EGP_SERVER", server)
+    monkeypatch.setenv("EGP_REWARD_JOB_DELAY_US", "30")
+    tr, cfg = _trainer(workspace, 96, 6, num_threads=4, num_groups=2)
+    first = _seeded_sample(tr, 96 * 18)
+    ro = tr.agent._get_rollout()
+    assert ro.engine.substeps_per_launch == (15 if server == "1" else 1)
+    ends = np.where(first["masks"] == 0)[0]
+    assert len(ends) >= 3 * 96 and ro.timing["ticks"] >= 18          # every slot restarted at least twice
+    for rep in range(49):
+        _assert_same_rollout(first, _seeded_sample(tr, 96 * 18), "repeat %d" % rep)
+    tr.close()
 
 
 def _train_mode_policy_mean(tr, ro, batch):
@@ -743,4 +774,64 @@ def test_rollout_with_the_small_rewards(workspace, skel, reward_id):
     else:
         assert batch.rewards.max() < 5.0 + 0.6 and np.isclose(log.avg_c_info[0], (5.0 - (batch.rewards - 0.6 * (batch.masks == 0))).mean() / 3.0)
     _replay_episodes(tr, cfg, skel, batch, range(0, 6), 0.6)
+    tr.close()
+
+
+def test_custom_reward_none_trains_on_the_env_reward(workspace, skel):
+    """agents/agent.py:53-58: with custom_reward=None the memory gets env_reward (HumanoidEnv.step: 1.0 per step,
+    humanoid_v1.py:188), the logger c_reward = 0.0 and c_info = [0.0] on every step -- never a silent quat_v3."""
+    tr, cfg = _trainer(workspace, 16, 9, num_threads=2, num_groups=2)
+    tr.agent.custom_reward = None
+    tr.agent._rollout = None
+    tr.agent.running_state = None
+    tr.env.end_reward = 0.6                       # (would show up in a quat_v3 / pose_dist reward; the env's reward has no bonus)
+    batch, log = tr.agent.sample(16 * 12)
+    assert tr.agent._get_rollout().reward_kind == "env"
+    assert (batch.rewards == 1.0).all()
+    assert log.avg_c_reward == 0.0 and log.min_c_reward == 0.0 and log.max_c_reward == 0.0
+    np.testing.assert_array_equal(np.asarray(log.avg_c_info), [0.0])
+    ends = np.where(batch.masks == 0)[0]
+    starts = np.r_[0, ends[:-1] + 1]
+    assert log.num_episodes == len(ends) and np.isclose(log.avg_episode_reward, (ends - starts + 1).mean())    # episode_reward = steps x 1.0
+    tr.agent.update_params(batch)
+    assert all(np.isfinite(tr.agent.update_stats["value_loss"]))
+    tr.close()
+    # a callable with no HIP kernel behind it is refused, not replaced
+    tr, cfg = _trainer(workspace, 8, 9, num_threads=2, num_groups=1)
+    tr.agent.custom_reward = lambda env, state, action, info: (0.5, np.zeros(1))
+    tr.agent._rollout = None
+    with pytest.raises(NotImplementedError):
+        tr.agent.sample(8)
+    tr.close()
+
+
+def test_cross_01_at_1024_slots_replayed_by_oracle_env(tmp_path_factory, skel):
+    """BASELINE config 3's per-GPU shard at full size: cross_01 (its own meta / take list, 40 takes) on 1 024 env slots, 2 groups,
+    the resident K1 engine, 200-step episodes, min batch 50 000 -- replayed on a sample of episodes by the oracle's CPU env."""
+    from egopose_amd.bench_support import write_synthetic_dataset
+    from egopose_amd.config import Config
+    from egopose_amd.physics import default_threads
+    from egopose_amd.train import Trainer
+    root = str(tmp_path_factory.mktemp("egp_cross01_full"))
+    write_synthetic_dataset(root, "cross_01", n_takes=40, n_frames=420, seed=11)
+    os.chdir(root)
+    cfg = Config("cross_01", create_dirs=False)
+    assert len(cfg.takes["train"]) == 40
+    cfg.num_optim_epoch = 1
+    n_threads = max(2, default_threads(share=1, device_index=0))
+    tr = Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=1024, num_threads=n_threads, num_groups=2)
+    tr.pre_iter_update(0)
+    tr.agent.running_state = None
+    tr.env.end_reward = 0.9
+    batch, log = tr.agent.sample(cfg.min_batch_size)
+    eng = tr.agent._get_rollout().engine
+    assert eng.substeps_per_launch == 15 and eng.n_groups == 2
+    N = len(batch)
+    ends = np.where(batch.masks == 0)[0]
+    assert N >= cfg.min_batch_size and ends[-1] == N - 1 and log.num_steps == N
+    assert len(np.unique(batch.v_metas[:, 0])) >= 35                       # the takes of the cross-subject list are all drawn from
+    n_ep = len(ends)
+    sample = sorted({0, 1, n_ep // 3, n_ep // 2 - 1, n_ep // 2, 2 * n_ep // 3, n_ep - 2, n_ep - 1})
+    starts, _ = _replay_episodes(tr, cfg, skel, batch, sample, 0.9)
+    assert (ends - starts + 1).max() <= cfg.env_episode_len
     tr.close()

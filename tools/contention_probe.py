@@ -44,7 +44,7 @@ def measure(tag):
 measure("engine idle   ")
 th = threading.Thread(target=stepper); th.start()
 time.sleep(0.2)
-measure("engine running (mode: launches/substep %d, substeps/launch %d)" % (eng.launches_per_substep, eng.substeps_per_launch))
+measure("engine running (substeps per K1 launch: %d)" % eng.substeps_per_launch)
 stop = True; th.join()
 torch.cuda.synchronize()
 eng.close(); ph.close(); ctx.close()

@@ -19,7 +19,7 @@ eng.reset(np.arange(N), q0, np.zeros((N, 58)))
 act = torch.zeros(N, 52, dtype=torch.float64, device="cuda")
 torch.cuda.synchronize()
 rng = np.random.RandomState(0)
-print("threads", eng.n_threads, "mode", eng.launches_per_substep, eng.substeps_per_launch)
+print("threads", eng.n_threads, "substeps per K1 launch", eng.substeps_per_launch)
 for n_active in (1024, 512, 256, 64, 16, 2):
     mask = np.zeros(N, np.int32)
     mask[rng.choice(N, n_active, replace=False)] = 1

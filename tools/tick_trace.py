@@ -1,8 +1,7 @@
 """Per-tick timeline of one rollout of the bench workload: stepped envs and the Python thread's wait per env-step.
-Usage: EGP_TICK_TRACE=1 python tools/tick_trace.py [envs]"""
+Usage: python tools/tick_trace.py [envs]"""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("EGP_TICK_TRACE", "1")
 import numpy as np, torch
 from egopose_amd.bench_support import write_synthetic_dataset
 from egopose_amd.config import Config
@@ -14,6 +13,8 @@ root = tempfile.mkdtemp(prefix="egp_trace_"); write_synthetic_dataset(root, "sub
 cfg = Config("subject_03", create_dirs=False)
 tr = Trainer(cfg, dev, torch.float32, num_envs=envs, num_threads=max(2, default_threads()), num_groups=2)
 for it in range(3):
+    if it == 2:
+        tr.agent._get_rollout().trace_ticks = True
     log, ts, tu, n = tr.iteration(it, cfg.min_batch_size)
 ro = tr.agent._get_rollout()
 t = np.array(ro.tick_trace)
