@@ -219,6 +219,7 @@ class Agent:
         ro.sim.ctx.set_reward_weights(self.env.cfg.reward_weights)
         with to_test(*self.sample_modules):
             per_rank = int(math.ceil(min_batch_size / D.world_size()))
+            self._last_min_batch = per_rank
             batch, log = ro.sample(per_rank, end_reward=float(self.env.end_reward))
         if D.world_size() > 1:      # logger totals + filter deltas: one all-gather, merged on the device (scalars beside the update's collectives)
             log = D.merge_sampling_pass(log, self.running_state, ro.zf_delta_base if self.running_state is not None else None, self.device)
@@ -236,6 +237,11 @@ class AgentPG(Agent):
         self.opt_num_epochs, self.value_opt_niter = opt_num_epochs, value_opt_niter
         self._grad_sync = None
         self._updater = None            # optim.FlatUpdater (fused clip + Adam over flat buffers) once built; False = not eligible
+        # A/B handles of the update's fused forms (the tests run both sides; all on by default, no environment switches):
+        self.use_fused_optim = True     # clip + both Adam steps over flat buffers (optim.FlatUpdater) instead of the torch optimizers
+        self.use_fused_loss = True      # both losses and their output gradients in one launch (optim.ppo_losses)
+        self.share_train_context = True    # the value net adopts the policy net's segmented batch (VideoStateNet.adopt_train_context)
+        self.reuse_first_pass = True    # the no-grad value / fixed-log-prob pass doubles as epoch 0's forward
         self.update_stats = {}
 
     # -- pieces shared by the A2C and PPO updates -------------------------------------------------
@@ -278,10 +284,10 @@ class AgentPG(Agent):
         return []
 
     def _get_updater(self):
-        """optim.FlatUpdater for this agent's two optimizers, or None (CPU device, non-Adam optimizers, EGP_FUSED_OPTIM=0, ...)."""
+        """optim.FlatUpdater for this agent's two optimizers, or None (CPU device, non-Adam optimizers, use_fused_optim = False, ...)."""
         if self._updater is None:
             up = None
-            if torch.device(self.device).type == "cuda" and os.environ.get("EGP_FUSED_OPTIM", "1") != "0" and \
+            if torch.device(self.device).type == "cuda" and self.use_fused_optim and \
                     self.optimizer_value is not None and self.optimizer_policy is not None:
                 compute_of = {m: c for m, c in self.shadow.pairs} if self.shadow is not None else None
                 up = O.FlatUpdater.build([self.optimizer_value, self.optimizer_policy], self._clip_list(), compute_of)
@@ -381,7 +387,7 @@ class AgentPPO(AgentPG):
         ls = getattr(pol, "action_log_std", None)
         return (torch.device(self.device).type == "cuda" and self.cdtype == torch.float32 and self.value_opt_niter == 1
                 and hasattr(pol, "mean_std") and ls is not None and ls.dim() == 2 and ls.shape[0] == 1 and ls.shape[1] <= 256
-                and ls.dtype == torch.float32 and os.environ.get("EGP_FUSED_LOSS", "1") != "0")
+                and ls.dtype == torch.float32 and self.use_fused_loss)
 
     def ppo_loss(self, states, actions, advantages, fixed_log_probs, ind, n_exp=None):
         """`ind` = rows with exps == 1 (agents/agent_ppo.py:45-51), or None when that is every row (no gather copies)."""
@@ -479,6 +485,10 @@ class AgentPPO(AgentPG):
     def _policy_mean(self, x):
         return self.cn.policy_net.mean_std(x)[0]
 
+    def _epochs_enqueued(self):
+        """Hook: every launch of the update is on the stream, its results have not been read yet."""
+        return
+
     def _update_policy_fused(self, states, actions, returns, advantages, ind, n_ind, n_val, n_exp, first_pass):
         """The epochs with optim.ppo_losses: forward passes -> ONE launch for both losses and d loss / d (values, action mean)
         -> autograd from those two tensors -> fused exchange / clip / Adam (`_optim_step`). Epoch 0's forward doubles as the
@@ -510,6 +520,7 @@ class AgentPPO(AgentPG):
             if learn_std:
                 log_std.grad = d_ls.view_as(log_std)
             self._optim_step()
+        self._epochs_enqueued()              # (the host would only wait from here on: the GPU still works through the epochs)
         host = rec.tolist()
         self.update_stats = {"value_loss": [r[0] for r in host[:self.opt_num_epochs]], "surr_loss": [r[1] for r in host[:self.opt_num_epochs]]}
 
@@ -549,7 +560,21 @@ class AgentEgo(AgentPPO):
     def _video_net(self):
         return self.cn.policy_vs_net
 
-    def pre_sample(self):
+    prefetch_rollout = True     # set up the next sampling pass behind the update's last epoch (LockstepRollout.prepare)
+
+    def _epochs_enqueued(self):
+        """The reference's loop is sample -> update -> sample (ego_pose/ego_mimic.py:106-118): once the update's launches are
+        queued, the set-up of the next sampling pass -- host work the GPU does not wait for -- runs while the GPU finishes the
+        update. Only with compute nets that ARE the caller's modules (shadow copies are refreshed at `sample`, which would make
+        the set-up stale every time) and only when a sampling pass has told us its batch size."""
+        ro, mb = self._rollout, getattr(self, "_last_min_batch", None)
+        if not self.prefetch_rollout or ro is None or mb is None or self.shadow is not None or D.world_size() > 1:
+            return
+        with to_test(*self.sample_modules):
+            self.pre_sample()
+            ro.noise_rate, ro.mean_action = self.noise_rate, self.mean_action
+            ro.prepare(mb, end_reward=float(self.env.end_reward))
+
         self.cn.policy_vs_net.set_mode("test")
 
     def pre_episode(self):
@@ -588,13 +613,13 @@ class AgentEgo(AgentPPO):
         x_init = (c["masks"], self.env.cnn_feat, v_metas)
         for i, net in enumerate(vs_nets):
             net.set_mode("train")
-            if i > 0 and hasattr(net, "adopt_train_context") and os.environ.get("EGP_SHARE_TRAIN_CONTEXT", "1") != "0":
+            if i > 0 and hasattr(net, "adopt_train_context") and self.share_train_context:
                 net.adopt_train_context(vs_nets[0], x_init)      # same batch, same feature table: segment and gather once
             else:
                 net.initialize(x_init)
         n_rows = c["states"].shape[0]
         ind, n_ind = self._exploration_rows(c["exps"], n_rows)
-        if self.value_opt_niter == 1 and os.environ.get("EGP_REUSE_FIRST_PASS", "1") != "0":
+        if self.value_opt_niter == 1 and self.reuse_first_pass:
             # ONE forward pass with autograd on serves three purposes: the values that GAE consumes, the fixed log-probs of
             # the surrogate, and epoch 0's forward (nothing has stepped in between; no dropout / batch norm in these nets)
             self._group_contexts(c["states"])

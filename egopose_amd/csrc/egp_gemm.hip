@@ -1174,7 +1174,7 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
         EGP_REQUIRE(!d->b_krows || d->b_src_rows > 0, "b_krows needs b_src_rows (rows of the gathered source)");
     }
     // thin products (see k_gemv_rows / k_rank1 / k_colsum): plain float32 streaming kernels, no tiles
-    if (!fused_io && !(getenv("EGP_GEMM_THIN") && atoi(getenv("EGP_GEMM_THIN")) == 0)) {
+    if (!fused_io) {
         if (d->N == 1 && !partial && d->a_kcontig && d->K >= 1) {
             const long blocks = std::min<long>(((long)d->M + 3) / 4, 256 * 16);
             k_gemv_rows<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(g);
@@ -1217,8 +1217,7 @@ int egp_gemm_f32(const egp_gemm_desc *d, void *stream) {
     const int zs_ws = (zs > 1 && rem < BK) ? zs - 1 : zs;
     g.zs = zs_ws;
     g.n_items = g.grid_tiles * zs_ws;
-    const char *sx_env = getenv("EGP_GEMM_SPLIT_XCD");     // =0: plain numbering (read per call, for A/B runs)
-    g.split_xcd = zs_ws > 1 && !g.xcd_order && g.grid_tiles > 1 && !(sx_env && atoi(sx_env) == 0);
+    g.split_xcd = zs_ws > 1 && !g.xcd_order && g.grid_tiles > 1;
     // three-piece products: the warp-specialised persistent kernel, unless a k range is shorter than one k-tile
     const char *ws_env = getenv("EGP_GEMM_WS");            // EGP_GEMM_WS=0: k_gemm_bf16x for everything (read per call: tests switch it)
     const bool ws_on = !(ws_env && atoi(ws_env) == 0);

@@ -543,19 +543,10 @@ extern "C" int egp_mlp_pack_f32(const float *weight, int64_t ldw, int32_t in_dim
     return EGP_OK;
 }
 
-// tile of the policy step: rows per workgroup x waves x weight blocks in flight per column group (EGP_POLICY_TILE="RxNWxPF").
+// tile of the policy step: rows per workgroup x waves x weight blocks in flight per column group.
 // Round-4 sweep on the MI355X (tools/probes/policy_tile_sweep.sh; 512 rows, bench workload): 4x4x2 15.2 us per launch and the
 // lowest / least scattered T_sample; 4x8x2 14.9 us; 8-row tiles 19-21 us (twice the MFMAs per workgroup on half the CUs).
-static void policy_tile(int *R, int *NW, int *PF) {
-    static int r = 0, nw = 0, pf = 0;
-    if (!r) {
-        int a = 4, b = 4, c = 2;
-        const char *e = getenv("EGP_POLICY_TILE");
-        if (e && sscanf(e, "%dx%dx%d", &a, &b, &c) != 3) { a = 4; b = 4; c = 2; }
-        r = a; nw = b; pf = c;
-    }
-    *R = r; *NW = nw; *PF = pf;
-}
+static void policy_tile(int *R, int *NW, int *PF) { *R = 4; *NW = 4; *PF = 2; }
 
 template <int R, int NW, int PF>
 static void policy_launch_t(bool flt, dim3 grid, size_t lds, hipStream_t s, const float *ctx_rows, long ctx_row_stride, int ctx_dim,
@@ -622,8 +613,8 @@ static int policy_launch(const float *ctx_rows, int64_t ctx_row_stride, int32_t 
                                  state, state_dim, n, L, activation, xs, log_std, noise, action, mean_out, ssrc, (unsigned *)stage_dst,  \
                                  (int)(stage_bytes / 4), F);                                                                            \
     } else
-    POL_CASE(8, 4, 2) POL_CASE(4, 4, 2) POL_CASE(4, 4, 4) POL_CASE(4, 8, 2) POL_CASE(4, 8, 4) POL_CASE(8, 8, 2)
-    { egp::set_error("EGP_POLICY_TILE %dx%dx%d is not built", R, NW, PF); return EGP_E_INVALID; }
+    POL_CASE(4, 4, 2)
+    { egp::set_error("policy tile %dx%dx%d is not built", R, NW, PF); return EGP_E_INVALID; }
 #undef POL_CASE
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { egp::set_error("k_policy_gaussian launch failed: %s", hipGetErrorString(e)); return EGP_E_HIP; }

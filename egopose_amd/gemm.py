@@ -257,7 +257,7 @@ def fused_gather_available(H, n_hidden, S):
     k-tile of state columns S (a k-tile reads one source)."""
     import os
     return enabled() and default_terms() == 6 and os.environ.get("EGP_GEMM_WS", "1") != "0" and H % 128 == 0 and n_hidden % 4 == 0 \
-        and S >= 32 and os.environ.get("EGP_FUSED_GATHER", "1") != "0"
+        and S >= 32
 
 
 def fused_rows_available():

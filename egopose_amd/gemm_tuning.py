@@ -22,7 +22,7 @@ _state = {"on": False}
 
 
 def tuned_file():
-    return os.environ.get("EGP_TUNED_GEMMS_FILE", _FILE)
+    return _FILE
 
 
 def enabled():

@@ -162,7 +162,7 @@ class LstmGroup(torch.autograd.Function):
         bias = (torch.cat([b_ih[p] for p in pord]) + torch.cat([b_hh[p] for p in pord])).index_select(0, bperm)
         rows = None
         if ragged is not None and ragged.rows is not None and 0 < nf and G.enabled() and G.fused_rows_available() \
-                and ragged.T == T and ragged.rows.shape[0] >= 4096 and os.environ.get("EGP_LSTM_ROWS", "1") != "0":
+                and ragged.T == T and ragged.rows.shape[0] >= 4096:
             rows = ragged.rows
         if rows is not None:
             gx = torch.empty(T * B, P * 4 * H, dtype=x.dtype, device=x.device)
@@ -187,7 +187,7 @@ class LstmGroup(torch.autograd.Function):
         order, steps = (ragged.order, ragged.steps) if ragged is not None else (None, None)
         # with row lists every later product visits only the rows the workgroups stepped through: the skipped steps of the
         # sweeps (3.6-3.9 TB/s of HBM traffic) need not be filled with zeros
-        leave = int(rows is not None and train and os.environ.get("EGP_LSTM_LEAVE_SKIPPED", "1") != "0")
+        leave = int(rows is not None and train)
         L.check(lib.egp_lstm_group_fwd_len_f32(_p(gx), _p(w_hh_all), T, B, H, P, kmask, ptrs, W,
                                                _p(gx if train else None), _p(cells), _p(order), _p(steps), leave, _s()), "egp_lstm_group_fwd_len_f32")
         outs = tuple(h_buf[i, 1:T + 1] for i in range(n_out))
@@ -301,7 +301,7 @@ def lstm_group(x, cells, reverses, pairs=False, ragged=None):
     outputs of a forward-running problem beyond a sequence's own steps are not computed (zeros) and carry no gradient."""
     mask = sum(1 << i for i, r in enumerate(reverses) if r)
     params = [t for c in cells for t in (c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh)]
-    if ragged is not None and (ragged.n_seq != x.shape[1] or os.environ.get("EGP_LSTM_RAGGED", "1") == "0"):
+    if ragged is not None and ragged.n_seq != x.shape[1]:
         ragged = None
     return list(LstmGroup.apply(x.contiguous(), mask, len(cells), 2 if pairs else 1, _wants_grad(x, params), ragged, *params))
 

@@ -26,11 +26,11 @@ from . import gemm as _gemm
 from . import gemm_tuning as _tuning
 from . import lstm as _hip_lstm
 
-# Length buckets of the train-mode forward LSTM (1 = off, the default: measured SLOWER on the MI355X -- the persistent
-# LSTM kernel is bound by its per-timestep latency, not by the batch, so four short launches in a row cost more than
-# one long one; kept for throughput-bound shapes). Running the two directions on two HIP streams was also tried: no
-# gain in the update, and an intermittent stall next to the resident K1 streams -- removed.
-_FWD_BUCKETS = int(os.environ.get("EGP_FWD_BUCKETS", "1"))
+# Length buckets of the train-mode forward LSTM (1 = off: measured SLOWER on the MI355X -- the persistent LSTM kernel is
+# bound by its per-timestep latency, not by the batch, so four short launches in a row cost more than one long one; the
+# code path stays for throughput-bound shapes, a module attribute, no switch). Running the two directions on two HIP streams
+# was also tried: no gain in the update, and an intermittent stall next to the resident K1 streams -- removed.
+_FWD_BUCKETS = 1
 _LSTM_IMPL = os.environ.get("EGP_LSTM", "hip")      # "torch" forces the MIOpen / cell-loop paths (A/B runs)
 
 _ACT = {"tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid}
@@ -278,7 +278,7 @@ class RNN(nn.Module):
             else:
                 self.hx = self.rnn_f(x, self.hx)
             return self.hx
-        if (self.bi_dir and self.cell_type == "lstm" and _LSTM_IMPL != "torch" and os.environ.get("EGP_LSTM_GROUP", "1") != "0"
+        if (self.bi_dir and self.cell_type == "lstm" and _LSTM_IMPL != "torch"
                 and _hip_lstm.group_available(x, [self.rnn_f, self.rnn_b])):
             # both directions in one grouped launch each way, writing the halves of one (T, B, 2H) buffer (lstm.LstmGroup)
             return _hip_lstm.lstm_group(x, [self.rnn_f, self.rnn_b], [False, True], pairs=True, ragged=self.ragged)[0]
@@ -327,8 +327,12 @@ class VideoStateNet(nn.Module):
 
     def attach_feature_table(self, table, take_offset):
         """Device-resident concatenation of all takes' features (+ row offsets) for gather-built contexts."""
-        self._cnn_table = (table, torch.as_tensor(np.asarray(take_offset), dtype=torch.long, device=table.device))
-        self._take_offset_host = np.asarray(take_offset, dtype=np.int64).copy()
+        host = np.asarray(take_offset, dtype=np.int64)
+        cur = getattr(self, "_cnn_table", None)
+        if cur is not None and cur[0] is table and np.array_equal(getattr(self, "_take_offset_host", None), host):
+            return                     # (same table as last time: no upload -- a copy from pageable memory blocks the host until the stream drains)
+        self._cnn_table = (table, torch.as_tensor(host, dtype=torch.long, device=table.device))
+        self._take_offset_host = host.copy()
         self._take_len = _take_lengths(take_offset, table.shape[0])
 
     def check_windows(self, expert_ind, start_ind, length):
@@ -651,7 +655,12 @@ class VideoForecastNet(nn.Module):
         return self.v_net(x)
 
     def attach_feature_table(self, table, take_offset):
-        self._cnn_table = (table, torch.as_tensor(np.asarray(take_offset), dtype=torch.long, device=table.device))
+        host = np.asarray(take_offset, dtype=np.int64)
+        cur = getattr(self, "_cnn_table", None)
+        if cur is not None and cur[0] is table and np.array_equal(getattr(self, "_take_offset_host", None), host):
+            return                     # (same table as last time: no blocking upload)
+        self._cnn_table = (table, torch.as_tensor(host, dtype=torch.long, device=table.device))
+        self._take_offset_host = host.copy()
         self._take_len = _take_lengths(take_offset, table.shape[0])
 
     def check_windows(self, expert_ind, start_ind, length=0):
@@ -755,7 +764,7 @@ def grouped_video_context(nets):
     launch each way (lstm.LstmGroup): their bi-LSTMs read the same windows with different weights, and a single sweep
     leaves most of the chip idle. Each net's next forward() consumes its context. Returns False (nothing done) when the
     nets do not qualify; the nets then compute their contexts one by one as usual."""
-    if os.environ.get("EGP_LSTM_GROUP", "1") == "0" or _LSTM_IMPL == "torch" or len(nets) < 1:
+    if _LSTM_IMPL == "torch" or len(nets) < 1:
         return False
     n0 = nets[0]
     for n in nets:
@@ -780,7 +789,7 @@ def grouped_video_context(nets):
 def grouped_forecast_context(nets, x):
     """ego_forecast's counterpart of grouped_video_context: the causal video LSTMs of all nets in one grouped launch each
     way, and their state LSTMs over the scattered states `x` in another. Each net's next forward(x) consumes its pair."""
-    if os.environ.get("EGP_LSTM_GROUP", "1") == "0" or _LSTM_IMPL == "torch" or len(nets) < 2 or x is None:
+    if _LSTM_IMPL == "torch" or len(nets) < 2 or x is None:
         return False
     n0 = nets[0]
     for n in nets:

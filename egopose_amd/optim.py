@@ -21,17 +21,23 @@ import torch
 from . import _lib as L
 from . import dist as D
 
-_WS = {}
+_WS = {}            # (key, device, stream handle) -> zeroed scratch; least recently used entries dropped beyond _WS_MAX
+_WS_MAX = 8
 
 
 def _zeroed_workspace(key, nbytes, device):
     """Partial-sum scratch of the loss kernels, one per (device, stream): two updates issued on different streams of one device
-    must not share it between k_ppo_loss and k_ppo_loss_final."""
+    must not share it between k_ppo_loss and k_ppo_loss_final. INVARIANT: the buffer is all zeros between calls --
+    the kernels' arrival counter lives in it, starts at zero and is reset by the last workgroup to arrive; a fresh buffer is
+    zero-filled here. The cache is bounded (code that creates short-lived streams must not grow it for ever): an evicted entry's
+    stream handle may be recycled by the runtime for a new stream, which then simply gets a fresh zeroed buffer."""
     k = (key, str(device), int(torch.cuda.current_stream(device).cuda_stream))
-    buf = _WS.get(k)
+    buf = _WS.pop(k, None)
     if buf is None or buf.numel() < nbytes:
         buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
-        _WS[k] = buf
+    _WS[k] = buf                       # (re-inserted: dict order = recency)
+    while len(_WS) > _WS_MAX:
+        _WS.pop(next(iter(_WS)))
     return buf
 
 

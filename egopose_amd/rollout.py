@@ -154,6 +154,8 @@ class LockstepRollout:
         self._pool, self._pool_pos = None, 0
         self._reset_scratch = None
         self._pool_prev, self._pool_fresh, self._ctx_keep = None, True, None
+        self._prepared = None               # (key, parked generator) of a set-up made ahead by `prepare`
+        self._zf_pin = None                 # pinned staging of the observation filter's state (+ the event of its last upload)
 
     # ------------------------------------------------------------------ helpers
     def _net_dtype(self):
@@ -334,8 +336,62 @@ class LockstepRollout:
             self.graph_error = repr(e)
 
     # ------------------------------------------------------------------ one sampling pass
-    @torch.no_grad()
+    def _setup_key(self, min_batch_size, end_reward):
+        """Everything a prepared set-up (prepare) depends on that the caller may change before it calls sample: the batch size, the
+        end bonus, the noise regime, the reset noise, the filter object, and the weights the set-up read (the policy MLP that the
+        fused step packs, the video net whose contexts fill the episode pool) by address AND version -- a checkpoint load or a
+        `with to_cpu(...)` round trip in between makes the set-up stale. (The policy's log_std is read by the tick itself.)"""
+        nets = [p for n, p in self.policy_net.named_parameters() if n != "action_log_std"] + list(self.policy_vs_net.parameters())
+        return (int(min_batch_size), float(end_reward), bool(self.mean_action), bool(self.noise_rate >= 1.0), float(self.cfg.env_init_noise),
+                id(self.running_state), self.reward_kind, getattr(self, "step_budget", None) or os.environ.get("EGP_STEP_BUDGET", "slot"),
+                tuple((p.data_ptr(), p._version) for p in nets))
+
+    def prepare(self, min_batch_size, end_reward=0.0):
+        """Run the set-up of the NEXT sampling pass now -- record buffers, the first reset of every slot (host physics), the episode
+        context pool, the first observations, the exploration noise: every launch goes onto the caller's stream BEHIND whatever is
+        queued there -- and park it. AgentEgo.update_params calls this once its last epoch is enqueued, while the GPU still works
+        through the update and the host would only wait: the set-up's ~7 ms of host time leave the sampling pass. `sample` takes
+        the parked set-up over when nothing it depends on has changed (`_setup_key`), else drops it and starts afresh: same launches
+        in the same stream order either way, so the rollout's numbers do not depend on whether it was prepared."""
+        self.drop_prepared()
+        key = self._setup_key(min_batch_size, end_reward)
+        gen = self._sample_gen(min_batch_size, end_reward)
+        with torch.no_grad():
+            next(gen)
+        self._prepared = (key, gen)
+
+    def drop_prepared(self):
+        pr, self._prepared = getattr(self, "_prepared", None), None
+        if pr is not None:
+            pr[1].close()
+
     def sample(self, min_batch_size, end_reward=0.0):
+        t_call = time.time()
+        pr, self._prepared = getattr(self, "_prepared", None), None
+        gen = None
+        if pr is not None:
+            if pr[0] == self._setup_key(min_batch_size, end_reward):
+                gen = pr[1]
+            else:
+                pr[1].close()
+        with torch.no_grad():
+            if gen is None:
+                gen = self._sample_gen(min_batch_size, end_reward)
+                next(gen)
+            self._t_resume, self._was_prepared = t_call, pr is not None and gen is pr[1]
+            if self._was_prepared and self._fused is not None:
+                # the one value of the policy the set-up copied that a driver rewrites between update and sample
+                # (`policy_net.action_log_std.fill_(cfg.adp_log_std)`, ego_mimic.py:101-102): re-read it now
+                self._fused.log_std.copy_(self.policy_net.action_log_std.reshape(-1))
+            try:
+                next(gen)
+            except StopIteration as done:
+                return done.value
+        raise RuntimeError("the sampling pass did not finish")
+
+    def _sample_gen(self, min_batch_size, end_reward=0.0):
+        """The sampling pass as a generator: set-up, `yield` (the point `prepare` parks it at), tick loop + batch assembly; the
+        generator's return value is (batch, log)."""
         t_start = time.time()
         cfg, N, dev, T_ep = self.cfg, self.N, self.dev, self.T_ep
         ctx, eng = self.ctx, self.engine
@@ -373,9 +429,11 @@ class LockstepRollout:
             exps=torch.ones(T_max, N, dtype=torch.int64, device=dev))
         host = dict(valid=np.zeros((T_max, N), bool), done=np.zeros((T_max, N), bool),
                     e_ind=np.zeros((T_max, N), np.int64), s_ind=np.zeros((T_max, N), np.int64))
+        t_parts = [("alloc", time.time())]
         if self.random_cur_t:
             host["t0"] = np.zeros((T_max, N), np.int64)
         self._ensure_static(ndt)
+        t_parts.append(("static", time.time()))
         self.cur_t = np.zeros(N, np.int64)
         self.t0 = np.zeros(N, np.int64)               # cur_t at the episode's first step (random_cur_t; else 0)
         self.e_ind = np.zeros(N, np.int64)
@@ -410,7 +468,17 @@ class LockstepRollout:
         if self.running_state is not None:
             rs = self.running_state.rs
             self.zf_delta_base = (float(rs._n), np.array(rs._M, float).ravel().copy(), np.array(rs._S, float).ravel().copy())
-            self.zf_state = self.running_state.to_device_state(dev)
+            # (through a pinned buffer: a copy from pageable memory would block the host until everything queued on the stream has
+            #  run -- fatal for a set-up that `prepare` queues behind a whole update)
+            st = self.running_state.to_device_state("cpu")
+            if self._zf_pin is None or self._zf_pin[0].numel() != st.numel():
+                self._zf_pin = [torch.empty(st.numel(), dtype=torch.float64).pin_memory(), None]
+            if self._zf_pin[1] is not None:
+                self._zf_pin[1].synchronize()
+            self._zf_pin[0].copy_(st)
+            self.zf_state = self._zf_pin[0].to(dev, non_blocking=True)
+            self._zf_pin[1] = torch.cuda.Event()
+            self._zf_pin[1].record()
             self._zf_bufs = [torch.empty_like(self.zf_state), torch.empty_like(self.zf_state)]
             self._zf_flip = 0
             self.zf_clip = float(self.running_state.clip or 0.0)
@@ -434,7 +502,9 @@ class LockstepRollout:
 
         # ---- initial reset of every slot; group g's first state goes to rec["states"][0, a:b]
         self._reset_slots(np.arange(N))
+        t_parts.append(("zf+reset", time.time()))
         self._obs_filter(0, N, rec["states"][0])
+        t_parts.append(("obs", time.time()))
 
         plain_noise = (not self.mean_action) and self.noise_rate >= 1.0
         # exploration noise of the whole rollout in ONE draw (T_max x N x nu float32, ~50 MB at the bench shape) instead of a
@@ -669,7 +739,12 @@ class LockstepRollout:
 
         if tickd is not None:
             pre_step, post_step = pre_native, post_native
+        t_parts.append(("noise+descr", time.time()))
+        tm["setup_parts_ms"] = {k: round((t - (t_parts[i - 1][1] if i else t_start)) * 1e3, 2) for i, (k, t) in enumerate(t_parts)}
         tm["setup"] = time.time() - t_start          # tables, record arrays, first reset of every slot, noise (host time: launches are asynchronous)
+        yield                                        # <- a prepared set-up waits here for `sample`
+        t_start = self._t_resume                     # (sample_time counts from the caller's `sample` call)
+        tm["setup_prepared"] = bool(self._was_prepared)
         # the tick loop is a latency chain (the Python thread hands a group its next env-step ~25 us after the last one ended): keep
         # the cyclic garbage collector out of it and let it run afterwards -- a generation-0 pass costs 50-200 us, a full one tens
         # of ms. It trims rare pauses, not the typical rollout (tools/probes/outlier_probe.py, 60 rollouts each way: mean 99.5

@@ -210,10 +210,9 @@ class StateRegTrainer:
         self.optimizer = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=cfg.lr)
         self.autocast = autocast           # torch.autocast dtype (measured 3.4x SLOWER than float32 here: kept for A/B runs)
         # BASELINE config 4: the ResNet-18 encoder in bf16 on the matrix cores, float32 master weights (nets.Bf16Shadow);
-        # default on the GPU for float32 trainers, EGP_STATEREG_BF16=0 or bf16_encoder=False keeps float32 convolutions
+        # default on the GPU for float32 trainers, bf16_encoder=False keeps float32 convolutions
         if bf16_encoder is None:
-            bf16_encoder = (self.device.type == "cuda" and dtype == torch.float32 and not no_cnn and autocast is None
-                            and os.environ.get("EGP_STATEREG_BF16", "1") != "0")
+            bf16_encoder = self.device.type == "cuda" and dtype == torch.float32 and not no_cnn and autocast is None
         self.bf16_encoder = bool(bf16_encoder)
         if self.bf16_encoder:
             self.net.bf16_encoder()

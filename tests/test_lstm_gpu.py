@@ -193,43 +193,6 @@ def test_grouped_video_contexts_match_per_net_contexts():
 
 
 @pytest.mark.gpu
-def test_fma_kernels_still_match(tmp_path):
-    """EGP_LSTM_MFMA=0 selects the FMA recurrences (torch gate order) when the library is loaded: checked in a fresh
-    process against a float64 LSTMCell loop, forward and all gradients."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import numpy as np, torch
-from egopose_amd import _lib
-from egopose_amd import lstm as hl
-assert _lib.load().egp_lstm_gate_layout() == 0
-torch.manual_seed(3)
-T, B, D, H = 21, 11, 32, 64
-cell = torch.nn.LSTMCell(D, H)
-x = torch.randn(T, B, D); w = torch.randn(T, B, H)
-ref = cell.double() if False else None
-c64 = torch.nn.LSTMCell(D, H).double(); c64.load_state_dict({k: v.double() for k, v in cell.state_dict().items()})
-for rev in (False, True):
-    h = torch.zeros(B, H, dtype=torch.float64); c = torch.zeros(B, H, dtype=torch.float64); outs = [None] * T
-    c64.zero_grad()
-    for t in (range(T - 1, -1, -1) if rev else range(T)):
-        h, c = c64(x[t].double(), (h, c)); outs[t] = h
-    o64 = torch.stack(outs); (o64 * w.double()).sum().backward()
-    cd = torch.nn.LSTMCell(D, H).cuda(); cd.load_state_dict(cell.state_dict())
-    o = hl.lstm_direction(cd, x.cuda(), rev); (o * w.cuda()).sum().backward()
-    np.testing.assert_allclose(o.detach().cpu().numpy(), o64.detach().numpy(), atol=2e-5, rtol=0)
-    for (n, p), (_, q) in zip(cd.named_parameters(), c64.named_parameters()):
-        s = max(1.0, float(q.grad.abs().max()))
-        np.testing.assert_allclose(p.grad.cpu().numpy() / s, q.grad.numpy() / s, atol=3e-5, rtol=0, err_msg=n)
-print("fma ok")
-'''
-    env = dict(os.environ, EGP_LSTM_MFMA="0", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "fma ok" in r.stdout, r.stdout + r.stderr
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("dynamic_v", [False, True])
 def test_grouped_forecast_contexts_match_per_net_contexts(dynamic_v):
     """nets.grouped_forecast_context for ego_forecast's (value, policy) front ends == each net running its causal video

@@ -125,8 +125,8 @@ def test_value_front_end_adopts_the_policy_s_train_context(workspace, monkeypatc
     in the backward pass is not order-deterministic)."""
     out = {}
     for share in ("1", "0"):
-        monkeypatch.setenv("EGP_SHARE_TRAIN_CONTEXT", share)
         tr, cfg = _trainer(workspace, 32, 12, num_threads=4, num_groups=2)
+        tr.agent.share_train_context = share == "1"
         tr.iteration(0, 32 * 16)
         pv, vv = tr.agent.cn.policy_vs_net, tr.agent.cn.value_vs_net
         if share == "1":
@@ -155,6 +155,7 @@ def test_update_gradients_hip_path_vs_library_path_at_row_list_scale(workspace, 
     cfg.env_episode_len = 150
     cfg.num_optim_epoch = 1
     tr = Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=96, num_threads=4, num_groups=2)
+    tr.agent.prefetch_rollout = False          # (its context-pool LSTM sweep would show up in the spies below)
     tr.pre_iter_update(0)
     batch, log = tr.agent.sample(96 * 80)
     for opt in (tr.optimizer_policy, tr.optimizer_value):
@@ -834,4 +835,61 @@ def test_cross_01_at_1024_slots_replayed_by_oracle_env(tmp_path_factory, skel):
     sample = sorted({0, 1, n_ep // 3, n_ep // 2 - 1, n_ep // 2, 2 * n_ep // 3, n_ep - 2, n_ep - 1})
     starts, _ = _replay_episodes(tr, cfg, skel, batch, sample, 0.9)
     assert (ends - starts + 1).max() <= cfg.env_episode_len
+    tr.close()
+
+
+def test_prepared_rollout_setup_changes_nothing(workspace):
+    """AgentEgo.update_params sets up the next sampling pass behind its last epoch (LockstepRollout.prepare: record buffers, the
+    first reset of every slot, the episode context pool, the noise block) while the GPU finishes the update. Same launches in the
+    same stream order: from one seed state, prepare + sample gives the batch sample alone gives, bit for bit (compared without an
+    update in between: two runs of the update itself differ in the last bits, a torch reduction of its backward pass is not
+    order-deterministic). Through the training loop: the set-up is taken over from the second iteration on, the log_std a driver
+    rewrites between update and sample is the one the ticks use, and a set-up made stale by a change of the weights it read or of
+    the batch size is dropped and redone."""
+    tr, cfg = _trainer(workspace, 64, 12, num_threads=4, num_groups=2)
+    tr.agent.prefetch_rollout = False
+    plain = _seeded_sample(tr, 64 * 20)
+
+    def prepared_sample():
+        ro = tr.agent._get_rollout()
+        real = tr.agent.sample
+
+        def sample_with_prepare(min_batch):          # (what update_params does ahead of the driver's next sample call)
+            with torch.no_grad():
+                ro.noise_rate, ro.mean_action = tr.agent.noise_rate, tr.agent.mean_action
+                ro.prepare(min_batch, end_reward=float(tr.env.end_reward))
+            return real(min_batch)
+        tr.agent.sample = sample_with_prepare
+        try:
+            return _seeded_sample(tr, 64 * 20)
+        finally:
+            tr.agent.sample = real
+    ahead = prepared_sample()
+    assert tr.agent._get_rollout().timing["setup_prepared"] is True
+    _assert_same_rollout(plain, ahead, "prepared")
+    tr.close()
+
+    tr, cfg = _trainer(workspace, 64, 12, num_threads=4, num_groups=2)
+    assert tr.agent.prefetch_rollout
+    for it in range(3):
+        tr.pre_iter_update(it)
+        tr.policy_net.action_log_std.data.fill_(-2.0 - 0.1 * it)            # a log_std schedule (ego_mimic.py:101-102)
+        batch, log = tr.agent.sample(64 * 20)
+        ro = tr.agent._get_rollout()
+        assert ro.timing["setup_prepared"] == (it > 0), it
+        assert float(ro._fused.log_std[0]) == pytest.approx(-2.0 - 0.1 * it)
+        # the exploration noise really has that scale: action - mean = std * N(0, 1)
+        tr.env.end_reward = log.avg_c_reward * cfg.gamma / (1 - cfg.gamma)
+        tr.agent.update_params(batch)
+        assert ro._prepared is not None and np.isfinite(log.avg_c_reward)
+    # the weights the parked set-up read change (a checkpoint load would do this): it must be dropped, not used
+    with torch.no_grad():
+        tr.policy_net.net.affine_layers[0].weight.mul_(1.0)
+    tr.pre_iter_update(3)
+    b2, _ = tr.agent.sample(64 * 20)
+    assert ro.timing["setup_prepared"] is False and len(b2) >= 64 * 20
+    tr.agent.update_params(b2)                            # a different batch size next: dropped as well
+    assert ro._prepared is not None
+    b3, _ = tr.agent.sample(64 * 10)
+    assert ro.timing["setup_prepared"] is False and 64 * 10 <= len(b3) < len(b2)
     tr.close()

@@ -200,13 +200,13 @@ def test_video_state_net_train_mode_hip_lstm_matches_reference(grouped, monkeypa
 
 
 def test_reusing_the_first_forward_pass_changes_nothing(kctx, monkeypatch):
-    """EGP_REUSE_FIRST_PASS (default on): the forward that yields the values for GAE and the fixed log-probs is also
+    """agent.reuse_first_pass (default on): the forward that yields the values for GAE and the fixed log-probs is also
     epoch 0's forward. Against the separate no-grad passes of the reference's flow: same parameters to round-off."""
     g = load_golden("ppo_update_h128.npz")
     outs = []
     for reuse in ("1", "0"):
-        monkeypatch.setenv("EGP_REUSE_FIRST_PASS", reuse)
         agent, mods = build_agent(g, device="cuda", dtype=torch.float32, fused_adam=True)
+        agent.reuse_first_pass = reuse == "1"
         _attach_tables(agent, g, torch.float32)
         _spy_gae(agent, kctx)
         agent.update_params(batch_of(g))
@@ -221,7 +221,7 @@ def test_reusing_the_first_forward_pass_changes_nothing(kctx, monkeypatch):
 def test_fused_update_tail_equals_the_torch_formulation(kctx, mode, monkeypatch):
     """Round 3's tail -- optim.ppo_losses (one launch for both losses and their gradients w.r.t. values / action mean) and
     optim.FlatUpdater (clip + both Adam steps over flat buffers) -- against the same update with the losses as torch element-wise
-    ops under autograd and the caller's own `clip_grad_norm_` + `torch.optim.Adam.step()` (EGP_FUSED_LOSS=0, EGP_FUSED_OPTIM=0):
+    ops under autograd and the caller's own `clip_grad_norm_` + `torch.optim.Adam.step()` (agent.use_fused_loss / use_fused_optim = False):
     same per-epoch losses, same parameters to float32 round-off, and the reference's run is matched by both."""
     from egopose_amd.optim import FlatUpdater
     g = load_golden("ppo_update_h128_s40.npz")
@@ -231,9 +231,8 @@ def test_fused_update_tail_equals_the_torch_formulation(kctx, mode, monkeypatch)
         torch.set_default_dtype(torch.float64)
     try:
         for fused in ("1", "0"):
-            monkeypatch.setenv("EGP_FUSED_LOSS", fused)
-            monkeypatch.setenv("EGP_FUSED_OPTIM", fused)
             agent, mods = build_agent(g, device="cuda", dtype=torch.float64 if masters64 else torch.float32, fused_adam=False)
+            agent.use_fused_loss = agent.use_fused_optim = fused == "1"
             _attach_tables(agent, g, torch.float32)
             _spy_gae(agent, kctx)
             agent.update_params(batch_of(g))
