@@ -893,3 +893,54 @@ def test_prepared_rollout_setup_changes_nothing(workspace):
     b3, _ = tr.agent.sample(64 * 10)
     assert ro.timing["setup_prepared"] is False and 64 * 10 <= len(b3) < len(b2)
     tr.close()
+
+
+def test_forecast_config5_shard_at_1024_slots_replayed_by_oracle_env(tmp_path_factory, skel):
+    """BASELINE config 5's per-GPU shard at full size: ego_forecast subject_03 (VideoForecastNet front ends, per-tick state LSTM,
+    90-step episodes, decayed reward, no end bonus) on 1 024 env slots, 2 groups, the resident K1 engine, min batch 50 000 --
+    physics, termination and the decayed reward of a sample of episodes replayed by the oracle's CPU env, and a PPO iteration on
+    the batch."""
+    from egopose_amd.bench_support import write_synthetic_dataset
+    from egopose_amd.config import ForecastConfig
+    from egopose_amd.physics import SurrogatePhysics, default_threads
+    from egopose_amd.train import Trainer
+    from oracle.cpu_env import OracleHumanoidEnv
+    from oracle import humanoid as H
+    root = str(tmp_path_factory.mktemp("egp_forecast_full"))
+    write_synthetic_dataset(root, "subject_03", n_takes=8, n_frames=600, seed=13)
+    os.chdir(root)
+    cfg = ForecastConfig("subject_03", create_dirs=False)
+    assert cfg.env_episode_len == 90 and cfg.fr_margin == 30 and cfg.policy_s_net == "lstm" and not cfg.end_reward
+    cfg.num_optim_epoch = 1
+    n_threads = max(2, default_threads(share=1, device_index=0))
+    tr = Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=1024, num_threads=n_threads, num_groups=2)
+    assert tr.forecast
+    tr.pre_iter_update(0)
+    batch, log = tr.agent.sample(cfg.min_batch_size)
+    eng = tr.agent._get_rollout().engine
+    assert eng.substeps_per_launch == 15 and eng.n_groups == 2
+    N = len(batch)
+    ends = np.where(batch.masks == 0)[0]
+    starts = np.r_[0, ends[:-1] + 1]
+    assert N >= cfg.min_batch_size and ends[-1] == N - 1 and (ends - starts + 1).max() <= 90 and log.num_steps == N
+    ph = SurrogatePhysics(skel, 1)
+    env = OracleHumanoidEnv(skel, cfg, ph, tr.env.expert_arr, tr.env.cnn_feat)
+    n_ep = len(ends)
+    for k in sorted({0, 1, n_ep // 3, n_ep // 2, 2 * n_ep // 3, n_ep - 2, n_ep - 1}):
+        s, e = starts[k], ends[k]
+        ei, si = batch.v_metas[s]
+        assert (batch.v_metas[s:e + 1] == [ei, si]).all()
+        env.expert_ind, env.start_ind, env.cur_t = int(ei), int(si), 0
+        ex = tr.env.expert_arr[ei]
+        ph.reset(0, ex["qpos"][si], ex["qvel"][si])
+        env._drain(True)
+        env.bquat = H.body_quat(env.qpos, skel.body_qpos_start, skel.body_ndof)[0]
+        for i in range(s, e + 1):
+            _, _, done, info = env.step(batch.actions[i])
+            r, _ = env.reward(None, None, info)
+            np.testing.assert_allclose(batch.rewards[i], r, rtol=1e-7, atol=1e-7, err_msg="episode %d reward @%d" % (k, i))
+            assert done == (batch.masks[i] == 0)
+    ph.close()
+    tr.agent.update_params(batch)
+    assert all(np.isfinite(tr.agent.update_stats["value_loss"])) and all(np.isfinite(tr.agent.update_stats["surr_loss"]))
+    tr.close()
