@@ -2061,12 +2061,6 @@ int egp_obs_zfilter_apply_f64(egp_ctx *ctx, const double *qpos, const double *qv
     return after_launch("k_zf_apply");
 }
 
-int egp_upload_async(void *dst_device, const void *src_pinned, int64_t bytes, void *stream) {
-    EGP_REQUIRE(bytes >= 0 && (bytes == 0 || (dst_device && src_pinned)), "bad upload");
-    if (bytes == 0) return EGP_OK;
-    EGP_HIP_CHECK(hipMemcpyAsync(dst_device, src_pinned, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
-    return EGP_OK;
-}
 
 int64_t egp_gae_workspace_bytes(int32_t n) {
     const int64_t n_chunks = ((int64_t)n + GAE_CHUNK - 1) / GAE_CHUNK;

@@ -236,9 +236,6 @@ int egp_obs_zfilter_stats_f64(egp_ctx *ctx, const double *qpos, const double *qv
                               void *stream);
 int egp_obs_zfilter_apply_f64(egp_ctx *ctx, const double *qpos, const double *qvel, const int32_t *phase_t, int32_t n, const double *state_in, double *state_out,
                               double clip, double *y, double *y2, void *workspace, void *stream);
-/* hipMemcpyAsync host (pinned) -> device on `stream`: the per-tick integer flags of the rollout driver (kernels that
- * re-read a flag array must not read it from pinned memory: every access would cross PCIe) */
-int egp_upload_async(void *dst_device, const void *src_pinned, int64_t bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------- K5
  * estimate_advantages (core/common.py:5-25) over the flat concatenated batch.

@@ -6,6 +6,7 @@ import sys
 
 
 def cls(n):
+    if "k_probe_" in n: return "host probe (egp_host_probe: outside the timed region)"
     if "k_pd_server" in n or "k_pd_torque" in n: return "K1 (stable PD)"
     if "k_lstm" in n: return "LSTM recurrences (HIP)"
     if "k_gemm" in n or "k_gemv_rows" in n or "k_rank1" in n or "k_colsum" in n: return "GEMM (HIP, split bf16 MFMA + thin float32 products)"
@@ -19,7 +20,7 @@ def cls(n):
 
 
 def main():
-    rows = list(csv.DictReader(open(sys.argv[1])))
+    rows = list(csv.DictReader(l for l in open(sys.argv[1]) if not l.startswith("#")))
     iters = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
     acc, calls = collections.Counter(), collections.Counter()
     for r in rows:
