@@ -140,6 +140,9 @@ class Trainer:
         self.value_net.load_state_dict(cp["value_dict"], strict=False)
 
     def close(self):
+        ro = getattr(self.agent, "_rollout", None)
+        if ro is not None:
+            ro.drop_prepared()            # a set-up parked by update_params holds the record buffers and the engine
         self.env.close()
 
 
