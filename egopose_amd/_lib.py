@@ -205,7 +205,7 @@ SIGNATURES = {
     "egp_rollout_reset": (C.c_int, [vp, _i32, _i32, _i32, _i32, vp, _i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "egp_engine_group_stream": (vp, [vp, _i32]),
     "egp_debug_burn": (C.c_int, [C.c_int64, _i32, vp, vp]),
-    "egp_lstm_group_fwd_len_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_void_p), _i32, vp, vp, vp, vp, _i32, vp]),
+    "egp_lstm_group_fwd_len_f32": (C.c_int, [vp, vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_void_p), _i32, vp, vp, vp, vp, _i32, vp, vp]),
     "egp_lstm_group_bwd_len_f32": (C.c_int, [C.POINTER(C.c_void_p), _i32, vp, vp, vp, _i32, _i32, _i32, _i32, _i32, vp, vp, vp, vp, _i32, vp]),
     "egp_set_dynamics_model": (C.c_int, [vp, C.POINTER(DynamicsDesc)]),
     "egp_dynamics_f64": (C.c_int, [vp, vp, vp, _i32, vp, C.c_int64, vp, vp, vp]),

@@ -71,6 +71,11 @@ struct LstmGroup {
     const int *order;
     const int *steps;
     int leave_skipped;     // the skipped steps' h_out / d_pre stay unwritten (the caller never reads those rows)
+    // optional (forward): the input projection as a table over the dataset's FRAMES instead of over the (t, b) rows of the padded
+    // windows. A sequence is a window of consecutive frames, so x[t][b] = frame (seq_base[b] + t) and its projection row is
+    // gates_x[seq_base[b] + t]: the projection GEMM runs over the unique frames once (16 k rows for the bench's dataset) instead
+    // of over every window row (154 k), and the sweeps read an L2-resident table instead of streaming 630 MB.
+    const int *seq_base;
 };
 
 // steps a forward-running workgroup has to make: the longest of its rows
@@ -141,6 +146,11 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
         const int pos = live[q] ? r0 + 4 * q + sub : B - 1;
         rowc[q] = grp.order ? grp.order[pos] : pos;
     }
+    // row of the projection a step reads: f_t * gmul + gadd[q] -- (t, b) rows of a dense buffer, or frames of a table
+    const long gmul = grp.seq_base ? 1 : B;
+    long gadd[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) gadd[q] = grp.seq_base ? (long)grp.seq_base[rowc[q]] : (long)rowc[q];
     const int Tp = lstm_group_steps<ROWS>(grp, reverse, r0, B, T);       // (wave-uniform)
     for (int i = threadIdx.x; i < 2 * ROWS * (LH + 4); i += 4 * LH) (&s_h[0][0][0])[i] = 0.f;
 
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
         const int f_s = (STEP) < T ? (STEP) : T - 1;                                                 \
         const int f_t = reverse ? T - 1 - f_s : f_s;                                                 \
         _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                               \
-            DST[q] = *reinterpret_cast<const f32x4 *>(gx + ((long)f_t * B + rowc[q]) * ld + 4 * u);  \
+            DST[q] = *reinterpret_cast<const f32x4 *>(gx + ((long)f_t * gmul + gadd[q]) * ld + 4 * u); \
     }
 
     // one timestep: products, cell update in registers, stores, barrier
@@ -494,13 +504,16 @@ int egp_lstm_bwd_f32(const float *dh_out, const float *gates_save, const float *
 
 int egp_lstm_group_fwd_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t B, int32_t hidden, int32_t n_problems,
                            int32_t reverse_mask, float *const *h_out, int32_t ld_h, float *gates_save, float *cells_save, void *stream) {
-    return egp_lstm_group_fwd_len_f32(gates_x, w_hh, T, B, hidden, n_problems, reverse_mask, h_out, ld_h, gates_save, cells_save, nullptr, nullptr, 0, stream);
+    return egp_lstm_group_fwd_len_f32(gates_x, w_hh, T, B, hidden, n_problems, reverse_mask, h_out, ld_h, gates_save, cells_save, nullptr, nullptr, 0,
+                                      nullptr, stream);
 }
 
 int egp_lstm_group_fwd_len_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t B, int32_t hidden, int32_t n_problems,
                                int32_t reverse_mask, float *const *h_out, int32_t ld_h, float *gates_save, float *cells_save,
-                               const int32_t *seq_order, const int32_t *seq_steps, int32_t leave_skipped, void *stream) {
+                               const int32_t *seq_order, const int32_t *seq_steps, int32_t leave_skipped, const int32_t *seq_base,
+                               void *stream) {
     EGP_REQUIRE((seq_order == nullptr) == (seq_steps == nullptr), "seq_order and seq_steps go together");
+    EGP_REQUIRE(!seq_base || !gates_save || gates_save != gates_x, "a frame table cannot double as the saved gates (rows are shared between sequences)");
     EGP_REQUIRE(hidden == 64 || hidden == 128, "egp_lstm kernels are built for hidden size 64 and 128");
     EGP_REQUIRE(n_problems >= 1 && n_problems <= 4, "1..4 problems per group");
     EGP_REQUIRE(T >= 0 && B >= 0, "negative size");
@@ -513,7 +526,7 @@ int egp_lstm_group_fwd_len_f32(const float *gates_x, const float *w_hh, int32_t 
         EGP_REQUIRE(h_out[p], "NULL h_out");
         g.h[p] = h_out[p];
     }
-    g.order = seq_order; g.steps = seq_steps; g.leave_skipped = seq_steps && leave_skipped;
+    g.order = seq_order; g.steps = seq_steps; g.leave_skipped = seq_steps && leave_skipped; g.seq_base = seq_base;
     launch_fwd_mfma(hidden, n_problems, gates_x, w_hh, T, B, g, gates_save, cells_save, (hipStream_t)stream);
     return lstm_launch_check("k_lstm_fwd_mfma (group)");
 }

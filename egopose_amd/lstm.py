@@ -143,9 +143,12 @@ class LstmGroup(torch.autograd.Function):
     problems is one batched GEMM against x, dW_hh one per problem against its own h_prev (no concatenated operands)."""
 
     @staticmethod
-    def forward(ctx, x, reverse_mask, P, width, train, ragged, *params):
+    def forward(ctx, x, reverse_mask, P, width, train, ragged, frames, *params):
         """`ragged` = None or (order, steps): int32 device tensors of B entries (include/egopose_hip.h,
-        egp_lstm_group_fwd_len_f32) -- forward-running problems stop at the longest sequence of their workgroup."""
+        egp_lstm_group_fwd_len_f32) -- forward-running problems stop at the longest sequence of their workgroup.
+        `frames` = None or (table (F, D), base int32 (B,)) with x[t, b] == table[base[b] + t]: the input projection then runs over
+        the table's F rows once and the sweeps read row base[b] + t of it (the reference evaluates W_ih x_t per window row,
+        models/rnn.py:45-61; windows of one take overlap, so most of those rows repeat)."""
         lib = L.load()
         T, B, D = x.shape
         w_ih, w_hh, b_ih, b_hh = params[0::4], params[1::4], params[2::4], params[3::4]
@@ -164,7 +167,12 @@ class LstmGroup(torch.autograd.Function):
         if ragged is not None and ragged.rows is not None and 0 < nf and G.enabled() and G.fused_rows_available() \
                 and ragged.T == T and ragged.rows.shape[0] >= 4096:
             rows = ragged.rows
-        if rows is not None:
+        seq_base, gates_buf = None, None
+        if frames is not None and G.enabled():
+            table, seq_base = frames
+            gx = G.linear_fwd(table, w_in, bias)                                            # (F, P*4H): one row per frame
+            gates_buf = torch.empty(T * B, P * 4 * H, dtype=x.dtype, device=x.device) if train else None
+        elif rows is not None:
             gx = torch.empty(T * B, P * 4 * H, dtype=x.dtype, device=x.device)
             nfc = nf * 4 * H
             G.gemm(x2, w_in[:nfc], True, True, bias=bias[:nfc], a_rows=rows, c_rows=rows, out=gx[:, :nfc])
@@ -188,11 +196,12 @@ class LstmGroup(torch.autograd.Function):
         # with row lists every later product visits only the rows the workgroups stepped through: the skipped steps of the
         # sweeps (3.6-3.9 TB/s of HBM traffic) need not be filled with zeros
         leave = int(rows is not None and train)
+        gates = gates_buf if seq_base is not None else (gx if train else None)             # (a dense projection doubles as the saved gates)
         L.check(lib.egp_lstm_group_fwd_len_f32(_p(gx), _p(w_hh_all), T, B, H, P, kmask, ptrs, W,
-                                               _p(gx if train else None), _p(cells), _p(order), _p(steps), leave, _s()), "egp_lstm_group_fwd_len_f32")
+                                               _p(gates), _p(cells), _p(order), _p(steps), leave, _p(seq_base), _s()), "egp_lstm_group_fwd_len_f32")
         outs = tuple(h_buf[i, 1:T + 1] for i in range(n_out))
         if train:
-            ctx.save_for_backward(x2, w_in, w_hh_all, h_buf, gx, cells)
+            ctx.save_for_backward(x2, w_in, w_hh_all, h_buf, gates, cells)
             ctx.meta = (T, B, D, H, P, width, reverse_mask)
             ctx.ragged, ctx.rows, ctx.pord, ctx.nf, ctx.kmask, ctx.leave = ragged, rows, pord, nf, kmask, leave
         return outs
@@ -247,7 +256,7 @@ class LstmGroup(torch.autograd.Function):
             d_b = db_t[q]
             grads[4 * p:4 * p + 4] = [dw_ih, dw_hh, d_b, d_b]
         d_x = dpre.mm(w_in).view(T, B, D) if ctx.needs_input_grad[0] else None
-        return (d_x, None, None, None, None, None, *grads)
+        return (d_x, None, None, None, None, None, None, *grads)
 
 
 def _wants_grad(x, params):
@@ -295,15 +304,23 @@ def ragged_order(seq_steps, device, T=None):
                   rows, B, T)
 
 
-def lstm_group(x, cells, reverses, pairs=False, ragged=None):
+def lstm_group(x, cells, reverses, pairs=False, ragged=None, frames=None):
     """P (cell, reverse) pairs over the same x (T,B,D), one grouped launch each way. Returns [(T,B,H)] * P, or with
     pairs=True [(T,B,2H)] * P/2 where problems 2i and 2i+1 fill the two halves of output i. `ragged` (ragged_order(...)):
-    outputs of a forward-running problem beyond a sequence's own steps are not computed (zeros) and carry no gradient."""
+    outputs of a forward-running problem beyond a sequence's own steps are not computed (zeros) and carry no gradient.
+    `frames` = (table (F, D), base int32 (B,)) when x[t, b] == table[base[b] + t] (windows of consecutive frames): the input
+    projection is then computed once per frame of the table (LstmGroup.forward); x itself still serves the weight gradient."""
     mask = sum(1 << i for i, r in enumerate(reverses) if r)
     params = [t for c in cells for t in (c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh)]
     if ragged is not None and ragged.n_seq != x.shape[1]:
         ragged = None
-    return list(LstmGroup.apply(x.contiguous(), mask, len(cells), 2 if pairs else 1, _wants_grad(x, params), ragged, *params))
+    if frames is not None:
+        table, base = frames
+        ok = (table.is_cuda and table.dtype == x.dtype and table.dim() == 2 and table.shape[1] == x.shape[2] and table.is_contiguous()
+              and base.dtype == torch.int32 and base.is_cuda and base.is_contiguous() and base.shape[0] == x.shape[1] and not x.requires_grad)
+        if not ok:
+            frames = None
+    return list(LstmGroup.apply(x.contiguous(), mask, len(cells), 2 if pairs else 1, _wants_grad(x, params), ragged, frames, *params))
 
 
 def lstm_direction(cell, x, reverse):

@@ -361,6 +361,7 @@ class VideoStateNet(nn.Module):
             return
         masks, cnn_feat, v_metas = x
         device, dtype = masks.device, masks.dtype
+        self._frames = None
         ends = torch.nonzero(masks == 0).flatten().cpu().numpy()
         n = masks.shape[0]
         starts = np.concatenate(([0], ends[:-1] + 1))
@@ -384,6 +385,14 @@ class VideoStateNet(nn.Module):
             e_ind = torch.as_tensor(meta[:, 0], device=device)
             s_ind = torch.as_tensor(meta[:, 1], device=device)
             self.cnn_feat_ctx = self.window_features(e_ind, s_ind, max_len).to(dtype)
+            # The windows are runs of consecutive rows of the feature table: window b starts at row base[b]. When the table is
+            # (much) smaller than the windows laid end to end -- the takes' frames are visited by many episodes -- the LSTMs'
+            # input projection is computed per frame of the table instead of per window row (lstm.LstmGroup, `frames`).
+            table = self._cnn_table[0]
+            n_rows = self.cnn_feat_ctx.shape[0] * self.cnn_feat_ctx.shape[1]
+            if table.dtype == dtype and table.is_contiguous() and 2 * table.shape[0] <= n_rows:
+                base = self._take_offset_host[meta[:, 0].astype(np.int64)] + meta[:, 1].astype(np.int64) - m
+                self._frames = (table, torch.as_tensor(base.astype(np.int32), device=device))
         else:
             ctx = np.zeros((max_len + 2 * m, len(ends), self.cnn_feat_dim))
             for e, (ei, si) in enumerate(meta):
@@ -424,7 +433,7 @@ class VideoStateNet(nn.Module):
             self._buckets = [(cuts[k], cuts[k + 1], int(m + lens_sorted[cuts[k]])) for k in range(_FWD_BUCKETS)]
 
     _TRAIN_CONTEXT = ("indices", "cnn_feat_ctx", "gather_indices", "_gather_tm", "_gather_unique", "_ctx_key", "_ragged",
-                      "_buckets", "_gather_sorted", "_ctx_sorted")
+                      "_buckets", "_gather_sorted", "_ctx_sorted", "_frames")
 
     def adopt_train_context(self, other, x):
         """``initialize(x)`` in train mode when ``other`` has just been initialised with the SAME ``x``: the episode
@@ -780,7 +789,8 @@ def grouped_video_context(nets):
     x = n0.cnn_feat_ctx                      # same episodes, same windows for every net (initialize() of the same batch)
     if not _hip_lstm.group_available(x, cells):
         return False
-    hs = _hip_lstm.lstm_group(x, cells, revs, pairs=n0.v_net.bi_dir, ragged=n0._ragged)     # bi-directional: (T, B, 2H) per net, no concatenation
+    hs = _hip_lstm.lstm_group(x, cells, revs, pairs=n0.v_net.bi_dir, ragged=n0._ragged,     # bi-directional: (T, B, 2H) per net, no concatenation
+                              frames=getattr(n0, "_frames", None))
     for i, n in enumerate(nets):
         n._v_ctx = (hs[i], torch.is_grad_enabled())
     return True

@@ -406,10 +406,15 @@ int egp_lstm_group_bwd_f32(const float *const *dh_out, int32_t ld_dh, const floa
  * written as zeros; with leave_skipped != 0 only up to the longest sequence of the ALIGNED GROUP OF 8 POSITIONS and not at
  * all beyond: the sweeps move 3.6-3.9 TB/s, and a caller whose products visit only the rows t < that maximum of each group
  * of 8 -- row lists, egp_gemm_desc.a_rows / a_krows -- saves a tenth of their bytes);
- * problems that run backward in time go through all T steps. NULL / NULL = the plain functions. */
+ * problems that run backward in time go through all T steps. NULL / NULL = the plain functions.
+ * seq_base (forward, optional; device, B entries): the sequences are windows of consecutive FRAMES of one table -- x[t][b] = frame
+ * seq_base[b] + t, as VideoStateNet's windows cnn_feat[take][start - m : start + len + m] are (models/video_state_net.py:52-55) --
+ * and gates_x is the projection of that table, [frames][P * 4H]: row seq_base[b] + t is read for (t, b). The projection then runs
+ * once per unique frame instead of once per window row. gates_save must be a buffer of its own ([T * B][P * 4H]) in that case. */
 int egp_lstm_group_fwd_len_f32(const float *gates_x, const float *w_hh, int32_t T, int32_t B, int32_t hidden, int32_t n_problems,
                                int32_t reverse_mask, float *const *h_out, int32_t ld_h, float *gates_save, float *cells_save,
-                               const int32_t *seq_order, const int32_t *seq_steps, int32_t leave_skipped, void *stream);
+                               const int32_t *seq_order, const int32_t *seq_steps, int32_t leave_skipped, const int32_t *seq_base,
+                               void *stream);
 int egp_lstm_group_bwd_len_f32(const float *const *dh_out, int32_t ld_dh, const float *gates_save, const float *cells_save, const float *w_hh,
                                int32_t T, int32_t B, int32_t hidden, int32_t n_problems, int32_t reverse_mask, float *d_pre, float *d_bias,
                                const int32_t *seq_order, const int32_t *seq_steps, int32_t leave_skipped, void *stream);

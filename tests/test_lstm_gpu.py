@@ -182,6 +182,7 @@ def test_grouped_video_contexts_match_per_net_contexts():
             n.set_mode("train")
             n.initialize((masks, cnn, metas))
         if grouped:
+            assert nets[0]._frames is not None             # 300 table rows against 45 x 40 window rows: projection per frame
             assert grouped_video_context(nets)
         ys = [n(states) for n in nets]
         sum((y * w).sum() for y in ys).backward()          # one backward over both nets, as the PPO update does
@@ -389,6 +390,50 @@ def test_ragged_grouped_sweeps_match_the_full_ones_where_it_counts(T, B, with_ro
         a, b = grag[k].cpu().numpy(), gfull[k].cpu().numpy()
         scale = max(1.0, np.abs(b).max())
         np.testing.assert_allclose(a / scale, b / scale, rtol=0, atol=5e-6, err_msg=k)      # (other split-K partitions, zeros instead of tiny products)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+@pytest.mark.parametrize("T,B,F", [(40, 37, 300), (150, 200, 2000), (9, 4, 9)])
+def test_frame_table_projection_matches_the_per_window_one(T, B, F, ragged):
+    """lstm.LstmGroup `frames`: when x[t, b] = table[base[b] + t] (overlapping windows of consecutive frames, as the video
+    context's are) the input projection is computed once per table row and the sweeps fetch row base[b] + t of it. Same
+    products, same order within a row -> the same outputs and parameter gradients as the per-window projection."""
+    from egopose_amd import lstm as lstm_mod
+    torch.manual_seed(T + B + F)
+    rng = np.random.RandomState(F)
+    table = torch.randn(F, 128, device="cuda")
+    base = rng.randint(0, F - T + 1, size=B).astype(np.int32)
+    base_t = torch.as_tensor(base, device="cuda")
+    x = table[(base_t.long().unsqueeze(0) + torch.arange(T, device="cuda").unsqueeze(1))]        # (T, B, D)
+    steps = rng.randint(0, T + 1, size=B)
+    steps[0] = T
+    rg = lstm_mod.ragged_order(steps, torch.device("cuda"), T=T) if ragged else None
+    inside = (torch.arange(T).unsqueeze(1) < torch.as_tensor(steps if ragged else np.full(B, T)).unsqueeze(0)).unsqueeze(2).cuda()
+    keep = lambda o: torch.where(inside, o, torch.zeros_like(o))      # (rows beyond a sequence's steps may be left unwritten)
+    dys = [keep(torch.randn(T, B, 128, device="cuda")) for _ in range(2)]
+    res = []
+    for frames in (None, (table, base_t)):
+        torch.manual_seed(5)
+        cells = [torch.nn.LSTMCell(128, 64).cuda() for _ in range(4)]
+        for rows_ in (T * B, (T + 2) * B, F):
+            for width in (128, 512, 1024):
+                junk = torch.full((rows_, width), float("nan"), device="cuda")
+                del junk
+        outs = lstm_mod.lstm_group(x, cells, [False, True, False, True], pairs=True, ragged=rg, frames=frames)
+        torch.autograd.backward(outs, dys)
+        res.append(([keep(o.detach()) for o in outs], [p.grad.clone() for c in cells for p in c.parameters()]))
+    (o_d, g_d), (o_f, g_f) = res
+    for a, b in zip(o_f, o_d):
+        np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    for a, b in zip(g_f, g_d):
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        scale = max(1.0, np.abs(b).max())
+        np.testing.assert_allclose(a / scale, b / scale, rtol=0, atol=2e-6)       # (split-K partial sums meet in any order)
+    # and the no-grad form (the value net's passes, the rollout's context): no gates buffer at all
+    with torch.no_grad():
+        o_n = lstm_mod.lstm_group(x, cells, [False, True, False, True], pairs=True, ragged=rg, frames=(table, base_t))
+    for a, b in zip(o_n, o_f):
+        np.testing.assert_allclose(keep(a).cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-6)
 
 
 def test_state_regression_head_on_the_gpu_matches_the_reference():
