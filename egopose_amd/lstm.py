@@ -1,9 +1,8 @@
 """One LSTM direction with the persistent HIP recurrence (csrc/egp_lstm.hip) behind torch autograd.
 
 Split of the work:
-  egp_gemm (MFMA): the input projection  X W_ih^T + b  for all T*B rows (or all frames of the feature table) at once, and
-                   in backward the weight-gradient reductions  dW_ih = dPre^T X,  dW_hh = dPre^T H_prev  (db = sum dPre
-                   comes out of the recurrence kernel);
+  rocBLAS (MFMA):  the input projection  X W_ih^T + b  for all T*B rows at once, and in backward the three
+                   weight-gradient reductions  dW_ih = dPre^T X,  dW_hh = dPre^T H_prev,  db = sum dPre;
   HIP kernels:     the sequential part -- T steps of h W_hh^T + gate non-linearities (forward) and the
                    backward-through-time recurrence producing dPre.
 Parameters are those of ``nn.LSTMCell`` (weight_ih [4H,D], weight_hh [4H,H], bias_ih, bias_hh), hidden size 64,
@@ -11,7 +10,6 @@ float32, zero initial state: exactly what ``RNN.batch_forward`` of the reference
 """
 from __future__ import annotations
 
-import contextlib
 import ctypes as C
 import os
 
@@ -31,17 +29,6 @@ def available(x, cell):
 
 def _s():
     return L.current_stream()
-
-
-WGRAD_SIDE_STREAMS = True     # LstmGroup.backward: the recurrent-weight gradients of the P problems on two side streams
-_SIDE = {}
-
-
-def _side_streams(device):
-    key = str(device)
-    if key not in _SIDE:
-        _SIDE[key] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
-    return _SIDE[key]
 
 
 def _p(t):
@@ -253,14 +240,7 @@ class LstmGroup(torch.autograd.Function):
         _, binv = _stacked_perm(H, P, x2.device)
         dw_ih_t = dw_ih_all.index_select(0, binv)                                           # torch row order, P blocks at once
         db_t = db.reshape(-1).index_select(0, binv).view(P, 4 * H)
-        # the P recurrent-weight gradients are independent split-K products over the same d_pre: dealt over two side streams
-        # their launch gaps, first k-steps and reductions overlap (each is a full-chip persistent launch of ~80 us)
-        main = torch.cuda.current_stream(x2.device) if (use_g and WGRAD_SIDE_STREAMS and P > 1) else None
-        side = _side_streams(x2.device) if main is not None else ()
-        for s in side:
-            s.wait_stream(main)
         for q, p in enumerate(pord):          # q: the problem's place in the kernels' order, p: in the caller's
-          with (torch.cuda.stream(side[q % len(side)]) if side else contextlib.nullcontext()):
             rev = (kmask >> q) & 1
             slab = h_buf[p // width, 2:] if rev else h_buf[p // width, :T]
             h_prev = slab[:, :, (p % width) * H:(p % width + 1) * H]
@@ -275,8 +255,6 @@ class LstmGroup(torch.autograd.Function):
             dw_ih = dw_ih_t[q * 4 * H:(q + 1) * 4 * H]
             d_b = db_t[q]
             grads[4 * p:4 * p + 4] = [dw_ih, dw_hh, d_b, d_b]
-        for s in side:
-            main.wait_stream(s)
         d_x = dpre.mm(w_in).view(T, B, D) if ctx.needs_input_grad[0] else None
         return (d_x, None, None, None, None, None, None, *grads)
 
