@@ -485,34 +485,6 @@ class AgentPPO(AgentPG):
     def _policy_mean(self, x):
         return self.cn.policy_net.mean_std(x)[0]
 
-    two_stream_heads = True     # the critic's and the actor's heads on two HIP streams (forward, and so backward)
-
-    def _heads_forward(self, states, ind):
-        """(values, action mean) of one training forward pass. The two nets share nothing after the grouped recurrences
-        (`_group_contexts`, on the caller's stream), so the critic's head runs on one side stream and the actor's on another:
-        autograd replays each backward node on its forward's stream, and a product's launch gap, cold first k-steps and
-        last-tile tail -- a third of a product's time at these shapes -- fill with the other net's product instead of
-        idling the chip. Same kernels on the same operands: the numbers do not depend on the interleaving."""
-        self._group_contexts(states)
-        if not (self.two_stream_heads and states.is_cuda):
-            pred = self.cn.value_net(self.trans_value(states))
-            x = self.trans_policy(states)
-            return pred, self._policy_mean(x if ind is None else x[ind])
-        main = torch.cuda.current_stream(states.device)
-        side = getattr(self, "_head_streams", None)
-        if side is None or side[0].device != states.device:
-            side = self._head_streams = (torch.cuda.Stream(states.device), torch.cuda.Stream(states.device))
-        for s in side:
-            s.wait_stream(main)
-        with torch.cuda.stream(side[0]):
-            pred = self.cn.value_net(self.trans_value(states))
-        with torch.cuda.stream(side[1]):
-            x = self.trans_policy(states)
-            mean = self._policy_mean(x if ind is None else x[ind])
-        for s in side:
-            main.wait_stream(s)
-        return pred, mean
-
     def _epochs_enqueued(self):
         """Hook: every launch of the update is on the stream, its results have not been read yet."""
         return
@@ -536,7 +508,10 @@ class AgentPPO(AgentPG):
             if first_pass is not None and epoch == 0:
                 pred, mean = first_pass[0], first_pass[1]
             else:
-                pred, mean = self._heads_forward(states, ind)
+                self._group_contexts(states)
+                pred = self.cn.value_net(self.trans_value(states))
+                x = self.trans_policy(states)
+                mean = self._policy_mean(x if ind is None else x[ind])
             self._zero_grads()
             _, _, _, d_ls = O.ppo_losses(pred.detach(), returns, mean.detach(), act, log_std.detach(), advantages, fixed, epoch == 0,
                                          self.clip_epsilon, n_val, n_exp, rows=ind, d_pred=d_pred, d_mean=d_mean,
@@ -647,13 +622,13 @@ class AgentEgo(AgentPPO):
         if self.value_opt_niter == 1 and self.reuse_first_pass:
             # ONE forward pass with autograd on serves three purposes: the values that GAE consumes, the fixed log-probs of
             # the surrogate, and epoch 0's forward (nothing has stepped in between; no dropout / batch norm in these nets)
+            self._group_contexts(c["states"])
+            pred0 = self.cn.value_net(self.trans_value(c["states"]))
+            x = self.trans_policy(c["states"])
+            xs = x if ind is None else x[ind]
             if self._fused_losses():
-                pred0, head0 = self._heads_forward(c["states"], ind)     # the loss kernel forms the log-probabilities itself
+                head0 = self._policy_mean(xs)           # the loss kernel forms the log-probabilities itself
             else:
-                self._group_contexts(c["states"])
-                pred0 = self.cn.value_net(self.trans_value(c["states"]))
-                x = self.trans_policy(c["states"])
-                xs = x if ind is None else x[ind]
                 head0 = self.cn.policy_net.get_log_prob(xs, c["actions"] if ind is None else c["actions"][ind])
             advantages, returns, counts = self._advantages_with_counts(c["rewards"], c["masks"], pred0.detach(), (n_rows, n_ind))
             self.update_policy(c["states"], c["actions"], returns, advantages, c["exps"], first_pass=(pred0, head0, ind), counts=counts)

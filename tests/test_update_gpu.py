@@ -217,31 +217,6 @@ def test_reusing_the_first_forward_pass_changes_nothing(kctx, monkeypatch):
         np.testing.assert_allclose(p1[k].cpu().numpy(), p0[k].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
 
 
-def test_heads_on_two_streams_change_nothing(kctx):
-    """agent.two_stream_heads (default on): the critic's and the actor's heads run forward -- and therefore backward -- on
-    two side streams between the grouped recurrences. Same kernels on the same operands with per-stream scratch: the updated
-    parameters equal the one-stream update's (the only order that may differ is the atomics' inside the LSTM bias
-    gradient, as between any two runs), five times over with allocator blocks handed back dirty in between."""
-    g = load_golden("ppo_update_h128.npz")
-    ref = None
-    for rep, two in enumerate([False, True, True, True, True, True]):
-        agent, mods = build_agent(g, device="cuda", dtype=torch.float32, fused_adam=True)
-        agent.two_stream_heads = two
-        _attach_tables(agent, g, torch.float32)
-        _spy_gae(agent, kctx)
-        for width in (128, 300, 1024):
-            junk = torch.full((20000, width), float("nan"), device="cuda")
-            del junk
-        agent.update_params(batch_of(g))
-        assert (getattr(agent, "_head_streams", None) is not None) == two
-        p = {k: v.detach().cpu().numpy().copy() for m in mods.values() for k, v in m.state_dict().items()}
-        if ref is None:
-            ref = p
-            continue
-        for k in ref:
-            np.testing.assert_allclose(p[k], ref[k], rtol=2e-6, atol=2e-7, err_msg="%s (repeat %d)" % (k, rep))
-
-
 @pytest.mark.parametrize("mode", ["float32", "float64-masters"])
 def test_fused_update_tail_equals_the_torch_formulation(kctx, mode, monkeypatch):
     """Round 3's tail -- optim.ppo_losses (one launch for both losses and their gradients w.r.t. values / action mean) and
