@@ -37,7 +37,7 @@ def default_terms():
 
 
 def _workspace(n_floats, device):
-    key = str(device)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)      # (products on two streams must not share scratch)
     buf = _WS.get(key)
     if buf is None or buf.numel() < n_floats:
         buf = torch.empty(max(int(n_floats), 1 << 20), dtype=torch.float32, device=device)
