@@ -36,12 +36,19 @@ def default_terms():
     return int(t)
 
 
+_WS_MAX = 8
+
+
 def _workspace(n_floats, device):
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)      # (products on two streams must not share scratch)
-    buf = _WS.get(key)
+    """Split-K / bias-gradient scratch, one per (device, stream): products issued on two streams must not share it. Bounded,
+    least recently used first out (as optim._zeroed_workspace): callers with short-lived streams must not grow it for ever."""
+    key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
+    buf = _WS.pop(key, None)
     if buf is None or buf.numel() < n_floats:
         buf = torch.empty(max(int(n_floats), 1 << 20), dtype=torch.float32, device=device)
-        _WS[key] = buf
+    _WS[key] = buf                     # (re-inserted: dict order = recency)
+    while len(_WS) > _WS_MAX:
+        _WS.pop(next(iter(_WS)))
     return buf
 
 
