@@ -76,6 +76,55 @@ __global__ __launch_bounds__(256) void k_obs(DevModel m, const T *__restrict__ q
     obs[gid] = obs_element<T>(qpos + (long)env * m.nq, qvel + (long)env * m.nv, obs_opt_of(m), c, m.obs_phase ? phase_t[env] : 0);
 }
 
+// Large batches (the HBM-resident form): with one thread per element the wave that holds a row's root quaternion columns pays the
+// whole de-heading (two float64 divisions, a square root) and the one with the root velocity columns the rotation -- ~600 cycles
+// of divergent float64 work per wave for 1 KiB of traffic: 65 536 rows took 47 us at 32 % of the HBM roofline, vector-ALU bound (now 23 us, 65 %; 262 144 rows, beyond the 256 MB cache: 52 %).
+// Here a workgroup takes 64 rows. First the columns that need arithmetic (heading, de-headed quaternion, root velocity, phase:
+// at most 9): one wave per column, one lane per row, obs_element itself (same bits) into LDS -- every lane of the wave works.
+// Then the rows stream through: 128 threads per row, 8-byte loads and stores of consecutive columns, the special ones from LDS.
+constexpr int OBS_ROWS = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void k_obs_rows(DevModel m, const T *__restrict__ qpos, const T *__restrict__ qvel,
+                                                  const int *__restrict__ phase_t, int n, T *__restrict__ obs) {
+    __shared__ T s_spec[9][OBS_ROWS];
+    const ObsOpt o = obs_opt_of(m);
+    const int od = m.obs_dim, h = o.heading ? 1 : 0;
+    const int n_vel = o.vel == 0 ? o.nv : (o.vel == 1 ? 6 : 0);
+    // special column s -> its index in the row (-1: not present)
+    auto spec_col = [&](int s) {
+        if (s == 0) return o.heading ? 0 : -1;
+        if (s <= 4) return o.keep ? -1 : h + s;
+        if (s <= 7) return n_vel >= 3 ? h + o.np + (s - 5) : -1;
+        return o.phase ? h + o.np + n_vel : -1;
+    };
+    const long r0 = (long)blockIdx.x * OBS_ROWS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int s = wave; s < 9; s += 4) {                       // (wave-uniform: one column per wave and round)
+        const int c = spec_col(s);
+        if (c < 0) continue;
+        const long r = min(r0 + lane, (long)n - 1);
+        s_spec[s][lane] = obs_element<T>(qpos + r * m.nq, qvel + r * m.nv, o, c, o.phase ? phase_t[r] : 0);
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
+    if (c >= od) return;
+    int sp = -1;
+#pragma unroll
+    for (int s = 0; s < 9; ++s) sp = spec_col(s) == c ? s : sp;
+    const int cc = c - h;
+    const bool from_q = cc < o.np;
+    const int src = from_q ? cc + 2 : cc - o.np;             // (unused for special columns)
+#pragma unroll 4
+    for (int e = half; e < OBS_ROWS; e += 2) {
+        const long r = r0 + e;
+        if (r >= n) break;
+        T v;
+        if (sp >= 0) v = s_spec[sp][e];
+        else v = from_q ? qpos[r * m.nq + src] : qvel[r * m.nv + src];
+        obs[r * od + c] = v;
+    }
+}
+
 // ============================================================================================ K1
 // compute_torque / compute_desired_accel (ego_pose/envs/humanoid_v1.py:130-156) + clip (:172)
 __device__ __forceinline__ double readlane_f64(double v, int l) {
@@ -1718,6 +1767,10 @@ static int launch_obs(egp_ctx *ctx, const T *qpos, const T *qvel, const int *pha
     EGP_REQUIRE(qpos && qvel && obs, "NULL pointer");
     EGP_REQUIRE(!ctx->dm.obs_phase || phase_t, "the model has obs_phase: phase_t (the rows' cur_t) is required");
     const long total = (long)n * ctx->dm.obs_dim;
+    if (n >= 32768 && ctx->dm.obs_dim <= 128) {        // whole rounds of the chip: the row-streaming form (k_obs_rows); below, launch-bound either way
+        k_obs_rows<T><<<dim3((n + OBS_ROWS - 1) / OBS_ROWS), dim3(256), 0, (hipStream_t)stream>>>(ctx->dm, qpos, qvel, phase_t, n, obs);
+        return after_launch("k_obs_rows");
+    }
     k_obs<T><<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(ctx->dm, qpos, qvel, phase_t, n, obs);
     return after_launch("k_obs");
 }

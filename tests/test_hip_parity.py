@@ -779,6 +779,36 @@ def test_observation_variants_on_device(skel, dtype, tol):
         EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"], obs_options=dict(obs_coord="bogus"))
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_large_batch_observation_kernel_equals_the_element_kernel(skel, dtype):
+    """K3 from 32 768 rows on streams whole rows through a workgroup (k_obs_rows: the columns that need quaternion arithmetic one
+    wave per column, one lane per row); below that one thread per element (k_obs). Same obs_element on the same values: the
+    large batch must equal its own chunks run through the small form bit for bit -- ragged size (a last workgroup of 37
+    rows), every observation switch incl. the phase column."""
+    from egopose_amd.hip import EgpContext
+    c = load_golden("config_subject_03.npz")
+    g = load_golden("obs_variants.npz")
+    n = 32768 + 3 * 64 + 37
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    qpos = torch.randn(n, 59, dtype=dtype, device="cuda", generator=gen) * 0.4
+    qvel = torch.randn(n, 58, dtype=dtype, device="cuda", generator=gen)
+    k = min(n, g["qpos"].shape[0])
+    qpos[:k] = torch.as_tensor(g["qpos"][:k], dtype=dtype, device="cuda")              # the reference's rows lead the batch
+    qvel[:k] = torch.as_tensor(g["qvel"][:k], dtype=dtype, device="cuda")
+    t = torch.randint(0, 300, (n,), dtype=torch.int32, device="cuda", generator=gen)
+    combos = [tuple(int(v) for v in cmb) + (0,) for cmb in g["combos"]] + [(0, 1, 0, 0, 1), (1, 0, 1, 1, 1), (1, 1, 0, 2, 1)]
+    for oh, deheading, root, vel, phase in combos:
+        opts = dict(obs_heading=bool(oh), root_deheading=bool(deheading), obs_coord="root" if root else "heading", obs_vel=["full", "root", "no"][vel],
+                    obs_phase=bool(phase))
+        ctx = EgpContext(skel, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], c["b_diffw"], episode_len=120, obs_options=opts)
+        kw = (lambda a, b: dict(phase_t=t[a:b])) if phase else (lambda a, b: {})
+        big = ctx.obs(qpos, qvel, **kw(0, n))
+        parts = torch.cat([ctx.obs(qpos[a:a + 9000], qvel[a:a + 9000], **kw(a, a + 9000)) for a in range(0, n, 9000)], 0)
+        assert big.shape == (n, ctx.obs_dim)
+        np.testing.assert_array_equal(big.cpu().numpy(), parts.cpu().numpy(), err_msg=str(opts))
+        ctx.close()
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 3e-6)])
 def test_phase_observation_on_device(skel, dtype, tol):
     """cfg.obs_phase (humanoid_v1.py:92-94): K3's extra column from the rows' cur_t against the reference's get_full_obs
