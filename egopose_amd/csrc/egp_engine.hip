@@ -447,6 +447,15 @@ inline bool server_mode(const egp_engine *E, const Group &G) {
 // is enough both to arm a row and to see that all of it has arrived; otherwise every word is used.
 inline int sentinel_stride(int nu) { return nu % 4 == 0 ? 4 : 1; }
 
+inline void prefetch_row(const double *row, int nu) {
+#if defined(__x86_64__)
+    const char *p = reinterpret_cast<const char *>(row);
+    for (int b = 0; b < nu * (int)sizeof(double); b += 64) _mm_prefetch(p + b, _MM_HINT_T0);
+#else
+    (void)row; (void)nu;
+#endif
+}
+
 inline bool row_arrived(const double *row, int nu, int stride) {
     const unsigned long long *u = reinterpret_cast<const unsigned long long *>(row);
     bool ok = true;
@@ -540,6 +549,9 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
                     if (G.status.load(std::memory_order_relaxed) != EGP_OK) break;
                 }
                 if (tr && first) { S.host_trace[s * 4 + 1] = secs(t_job, clk::now()) * 1e6; first = false; }
+                // the GPU's writes left the next env's torque row out of every cache: request its lines now, so that the miss
+                // (a trip to memory per line) runs under this env's physics step instead of in front of the next one
+                if (e + 1 < S.e1[sl]) prefetch_row(row + nu, nu);
                 if (E->vt->step(E->vt->user, e, row) != 0 || drain_env(E, e, last) != EGP_OK) {
                     char msg[64];
                     snprintf(msg, sizeof(msg), "env %d", e);
