@@ -123,7 +123,12 @@ template <int NQ, int LH, bool FULL, bool TRAIN>
 __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restrict__ gx, const float *__restrict__ w_hh, int T, int B,
                                                           LstmGroup grp, float *__restrict__ gates_out, float *__restrict__ c_out) {
     constexpr int LG = 4 * LH, ROWS = 4 * NQ;
-    const int prob = blockIdx.y, reverse = (grp.rev_mask >> prob) & 1, ld = grp.ld_g, ld_h = grp.ld_h;
+    // Workgroups are dispatched x first, then y, and a grouped launch is a few rounds of the chip (1 100 workgroups on 768 / 512
+    // slots at the update's shapes): the LAST problems' workgroups form the tail. The callers put the forward-running problems
+    // (ragged: short) first and the backward-running ones (every step) last, so the y index is walked downwards -- the long
+    // workgroups start first and the short ones fill the tail (longest-processing-time-first): 0.508 -> 0.493 ms forward,
+    // 0.573 -> 0.555 ms backward per grouped sweep of the update
+    const int prob = (int)(gridDim.y - 1 - blockIdx.y), reverse = (grp.rev_mask >> prob) & 1, ld = grp.ld_g, ld_h = grp.ld_h;
     float *__restrict__ h_out = grp.h[prob];
     gx += prob * LG; w_hh += (long)prob * LG * LH;
     if (TRAIN) { gates_out += prob * LG; c_out += prob * grp.c_stride; }
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
                                                           const float *__restrict__ w_hh, int T, int B, LstmGroup grp,
                                                           float *__restrict__ dpre) {
     constexpr int LG = 4 * LH, NT = 4 * LH, ROWS = 4 * NQ, UH = LH / 64;
-    const int prob = blockIdx.y, reverse = (grp.rev_mask >> prob) & 1, ld = grp.ld_g, ld_dh = grp.ld_dh;
+    const int prob = (int)(gridDim.y - 1 - blockIdx.y), reverse = (grp.rev_mask >> prob) & 1, ld = grp.ld_g, ld_dh = grp.ld_dh;     // (as in the forward kernel)
     const float *__restrict__ dh_out = grp.dh[prob];
     gates += prob * LG; dpre += prob * LG; cells += prob * grp.c_stride; w_hh += (long)prob * LG * LH;
     constexpr int NP = (ROWS * LH + NT - 1) / NT;     // = NQ: (row, unit) pairs per thread in the pointwise phase
