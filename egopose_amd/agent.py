@@ -575,6 +575,8 @@ class AgentEgo(AgentPPO):
             ro.noise_rate, ro.mean_action = self.noise_rate, self.mean_action
             ro.prepare(mb, end_reward=float(self.env.end_reward))
 
+    def pre_sample(self):
+        # ego_pose/core/agent_ego.py:18-19: the video net leaves the update in 'train' mode; every sampling pass starts in 'test'
         self.cn.policy_vs_net.set_mode("test")
 
     def pre_episode(self):

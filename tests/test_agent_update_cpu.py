@@ -41,6 +41,23 @@ def test_update_params_matches_reference_run(fixture):
         torch.set_default_dtype(torch.float32)
 
 
+def test_pre_sample_puts_the_video_net_back_into_test_mode_after_an_update():
+    """ego_pose/core/agent_ego.py:18-19: `pre_sample` switches `policy_vs_net` to 'test'; `update_params` leaves it in 'train'
+    (agent_ego.py:41-44). A host-side `pre_episode` after an update must find the test branch."""
+    g = load_golden("ppo_update.npz")
+    torch.set_default_dtype(torch.float64)
+    try:
+        agent, mods = build_agent(g)
+        _with_oracle_gae(agent)
+        agent.update_params(batch_of(g))
+        assert agent.cn.policy_vs_net.mode == "train"
+        assert "pre_sample" in type(agent).__dict__           # AgentEgo's own method, not the base no-op
+        agent.pre_sample()
+        assert agent.cn.policy_vs_net.mode == "test"
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
 def test_float64_masters_with_float32_shadows_follow_the_reference_run():
     """The drop-in precision scheme (agent.ShadowNets): float64 master modules owned by the caller and its optimizers,
     float32 compute copies. Final MASTER parameters stay within float32 round-off of the reference's float64 run, the
