@@ -37,10 +37,15 @@ using namespace egp_dyn;
 // workgroups per CU = 14 envs (round 2: 4 x 16.9 + 5 = 73 kB, two workgroups = 8 envs): 787 -> 653 us at 65 536 envs. Small
 // batches (a rollout group) keep 4 envs per workgroup: spread over more CUs, one wave per SIMD (1 024 envs: 22 us against 27).
 
+// `list` (optional): the launch covers the envs list[k * list_stride] instead of 0 .. n - 1 (the engine's reset: rows of the envs
+// being reset, = the reference's sim.forward() after set_state); an entry whose list[k * list_stride + 2] is non-zero writes to the
+// `_alt` outputs (the per-substep engine form keeps two generations of (qM, bias) rows, see egp_engine.hip).
 template <int DYN_ENVS_PER_BLOCK>
 __global__ __launch_bounds__(DYN_ENVS_PER_BLOCK * 64) void k_dynamics(const DynTables *__restrict__ tab_g, const double *__restrict__ qpos,
                                                   const double *__restrict__ qvel, int n, long ld_q, long ld_v, double *__restrict__ qM,
-                                                  long ld_m, double *__restrict__ bias, long ld_b, double *__restrict__ xpos, int env_doubles) {
+                                                  long ld_m, double *__restrict__ bias, long ld_b, double *__restrict__ xpos, int env_doubles,
+                                                  const int *__restrict__ list, int list_stride, double *__restrict__ qM_alt,
+                                                  double *__restrict__ bias_alt) {
     __shared__ DynTables tb;
     extern __shared__ double s_env[];            // (blockDim / 64) x env_doubles
     {
@@ -50,19 +55,21 @@ __global__ __launch_bounds__(DYN_ENVS_PER_BLOCK * 64) void k_dynamics(const DynT
         for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long env = (long)blockIdx.x * DYN_ENVS_PER_BLOCK + wave;
-    const bool valid = env < n;
-    const long e = valid ? env : 0;              // out-of-range waves shadow env 0 and write nothing
+    const long k = (long)blockIdx.x * DYN_ENVS_PER_BLOCK + wave;
+    const bool valid = k < n;
+    const long env = !valid ? 0 : (list ? (long)list[k * list_stride] : k);    // out-of-range waves shadow env 0 and write nothing
+    if (valid && list && list[k * list_stride + 2] != 0) { qM = qM_alt; bias = bias_alt; }
     __syncthreads();
-    dynamics_wave(tb, s_env + wave * env_doubles, qpos + e * ld_q, qvel + e * ld_v, lane, valid, qM ? qM + env * ld_m : nullptr,
+    dynamics_wave(tb, s_env + wave * env_doubles, qpos + env * ld_q, qvel + env * ld_v, lane, valid, qM ? qM + env * ld_m : nullptr,
                   bias ? bias + env * ld_b : nullptr, xpos ? xpos + env * tb.nb * 3 : nullptr);
 }
 
 }  // namespace
 
-// engine entry: state rows / outputs with arbitrary row strides (doubles)
+// engine entry: state rows / outputs with arbitrary row strides (doubles); `list` / `_alt`: see k_dynamics
 int egp_launch_dynamics_strided(egp_ctx *ctx, const double *qpos, long ld_q, const double *qvel, long ld_v, int32_t n, double *qM,
-                                long ld_m, double *bias, long ld_b, double *xpos, hipStream_t stream) {
+                                long ld_m, double *bias, long ld_b, double *xpos, hipStream_t stream, const int *list, int list_stride,
+                                double *qM_alt, double *bias_alt) {
     if (!ctx->dyn_tables) { egp::set_error("egp_set_dynamics_model must be called before egp_dynamics"); return EGP_E_STATE; }
     const int env_doubles = dy_env_doubles(ctx->dm.nbody, ctx->dm.nv - 6, ctx->dm.nv);
     static const hipError_t attr = hipFuncSetAttribute((const void *)k_dynamics<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
@@ -70,8 +77,12 @@ int egp_launch_dynamics_strided(egp_ctx *ctx, const double *qpos, long ld_q, con
     const size_t lds = (size_t)(wide ? 7 : 4) * env_doubles * sizeof(double);
     if (attr != hipSuccess || lds > (wide ? 100 : 64) * 1024) { egp::set_error("k_dynamics: LDS budget (%zu bytes)", lds); return EGP_E_HIP; }
     const DynTables *tab = (const DynTables *)ctx->dyn_tables;
-    if (wide) k_dynamics<7><<<dim3((n + 6) / 7), dim3(448), lds, stream>>>(tab, qpos, qvel, n, ld_q, ld_v, qM, ld_m, bias, ld_b, xpos, env_doubles);
-    else k_dynamics<4><<<dim3((n + 3) / 4), dim3(256), lds, stream>>>(tab, qpos, qvel, n, ld_q, ld_v, qM, ld_m, bias, ld_b, xpos, env_doubles);
+    if (wide)
+        k_dynamics<7><<<dim3((n + 6) / 7), dim3(448), lds, stream>>>(tab, qpos, qvel, n, ld_q, ld_v, qM, ld_m, bias, ld_b, xpos, env_doubles,
+                                                                     list, list_stride, qM_alt, bias_alt);
+    else
+        k_dynamics<4><<<dim3((n + 3) / 4), dim3(256), lds, stream>>>(tab, qpos, qvel, n, ld_q, ld_v, qM, ld_m, bias, ld_b, xpos, env_doubles,
+                                                                     list, list_stride, qM_alt, bias_alt);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { egp::set_error("k_dynamics launch failed: %s", hipGetErrorString(e)); return EGP_E_HIP; }
     return EGP_OK;

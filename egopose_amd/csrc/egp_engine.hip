@@ -183,6 +183,7 @@ struct Group {
     unsigned long long *h_flag = nullptr;     // K1 completion flag (pinned host), polled by the leader
     unsigned long long *hd_flag = nullptr;
     unsigned long long seq = 0;
+    int dyn_gen = 0;                          // device dynamics, per-substep form: which generation of (qM, bias) rows K1 reads next
     bool polled = false;                      // the launch in flight publishes to h_flag
     bool prof_now = false;                    // this env-step brackets its K1 launches with events
     bool server_job = false;                  // form of the env-step in flight (fixed when it is posted)
@@ -222,8 +223,14 @@ struct egp_engine {
     bool bar_go = false;
     bool server_ok = false;                   // resident-K1 mode allowed (EGP_SERVER, block budget)
     bool server_dyn_ok = false;               // ... also with device dynamics (its 110 kB of LDS: one workgroup per CU)
-    bool device_dynamics = false;             // K8 supplies qM / qfrc_bias from the drained (qpos, qvel) each substep
-    double *d_bias = nullptr;                 // [n_env][nv] K8's bias (device-dynamics mode)
+    // device-dynamics mode: qM / qfrc_bias come from K8 on the (qpos, qvel) rows the backend drains -- with the reference's timing
+    // (ego_pose/envs/humanoid_v1.py:130-144 reads data.qM / data.qfrc_bias as the previous mj_step left them): the torque of a
+    // substep is solved with M, C of the state the PREVIOUS substep started from; only a reset (sim.forward(),
+    // envs/common/mujoco_env.py:97-101) evaluates them at the current state. d_qM / d_bias hold what "the last mj_step left behind"
+    // per env; the per-substep form alternates between them and a second generation (K8 writes the next while K1 reads the current).
+    bool device_dynamics = false;
+    double *d_bias = nullptr;                 // [n_env][nv]
+    double *d_qM2 = nullptr, *d_bias2 = nullptr;   // second generation (per-substep form only)
     int reward_delay_us = 0;                  // EGP_REWARD_JOB_DELAY_US (tests): a spin kernel ahead of the reward job's kernel
     // The engine's threads (and a caller in egp_engine_wait, 4 x as long) poll this long for the next env-step / its end before
     // sleeping on a condition variable: a futex wake-up per env-step and thread is ~2 % of the rollout (round 3's in-lease A/B,
@@ -235,7 +242,7 @@ struct egp_engine {
     std::vector<Group> groups;
     std::vector<int64_t> epoch;               // last drained inertia epoch per env (-1 = never)
     std::vector<int> env_group, env_slice;
-    int *h_reset_list = nullptr, *hd_reset_list = nullptr;   // pinned (env, qM_changed) pairs of the reset in flight
+    int *h_reset_list = nullptr, *hd_reset_list = nullptr;   // pinned (env, qM_changed, dynamics generation) triples of the reset in flight
     hipEvent_t reset_done = nullptr;                          // recorded behind the scatter kernel of the last reset
     bool reset_pending = false;
 };
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256) void k_engine_reset_scatter(const int *__restr
                                                               const double *__restrict__ h_qM, int ld_m, int nM, int nq, int nv,
                                                               double *d_state, double *d_qpos, double *d_qvel, double *d_ee,
                                                               double *d_qM) {
-    const int e = list[2 * blockIdx.x], new_qM = list[2 * blockIdx.x + 1];
+    const int e = list[3 * blockIdx.x], new_qM = list[3 * blockIdx.x + 1];
     const double *row = h_state + (long)e * ld_s;
     for (int c = threadIdx.x; c < ld_s; c += blockDim.x) {
         const double v = row[c];
@@ -330,16 +337,24 @@ void enqueue_k1(egp_engine *E, Group &G, int substep) {
     double *tq = E->hd_torque + (size_t)G.e0 * E->nu;
     const double *bias = st + E->off_bias;
     long ld_bias = E->ld_s;
-    if (E->device_dynamics) {        // K8: inertia and bias force of the state just drained, straight into HBM
-        double *db = E->d_bias + (size_t)G.e0 * E->nv;
-        int rd = egp_launch_dynamics_strided(E->ctx, st + E->off_qpos, E->ld_s, st + E->off_qvel, E->ld_s, m,
-                                             E->d_qM + (size_t)G.e0 * E->ld_m, E->ld_m, db, E->nv, nullptr, G.stream);
+    const double *qM = E->d_qM + (size_t)G.e0 * E->ld_m;
+    if (E->device_dynamics) {
+        // K8 on the state just drained writes the NEXT generation (what this substep's mj_step will have left behind); K1 solves with
+        // the current one -- the previous substep's, or the reset's. (K8 has to read the pinned rows before the host may step, so it
+        // stays in front of K1 in the stream; the resident form runs it behind the torque store.)
+        double *qM_gen[2] = {E->d_qM + (size_t)G.e0 * E->ld_m, E->d_qM2 + (size_t)G.e0 * E->ld_m};
+        double *bias_gen[2] = {E->d_bias + (size_t)G.e0 * E->nv, E->d_bias2 + (size_t)G.e0 * E->nv};
+        const int cur = G.dyn_gen, nxt = cur ^ 1;
+        int rd = egp_launch_dynamics_strided(E->ctx, st + E->off_qpos, E->ld_s, st + E->off_qvel, E->ld_s, m, qM_gen[nxt], E->ld_m,
+                                             bias_gen[nxt], E->nv, nullptr, G.stream);
         if (rd != EGP_OK) fail(G, rd, "K8 launch", egp_last_error());
-        bias = db;
+        qM = qM_gen[cur];
+        bias = bias_gen[cur];
         ld_bias = E->nv;
+        G.dyn_gen = nxt;
     }
     int rc = egp_launch_pd_torque_strided(E->ctx, st + E->off_qpos, E->ld_s, st + E->off_qvel, E->ld_s, bias, ld_bias,
-                                          E->d_qM + (size_t)G.e0 * E->ld_m, E->ld_m, G.action + (size_t)G.e0 * E->nu, m, tq, G.stream,
+                                          qM, E->ld_m, G.action + (size_t)G.e0 * E->nu, m, tq, G.stream,
                                           G.polled ? G.d_done : nullptr, G.hd_flag, G.polled ? ++G.seq : 0);
     if (rc != EGP_OK) fail(G, rc, "K1 launch", egp_last_error());
     if (prof) G_HIP(hipEventRecord(G.k_end[substep], G.stream));
@@ -493,7 +508,8 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
         if (G.ready) G_HIP(hipStreamWaitEvent(G.stream, G.ready, 0));
         if (G.prof_now) G_HIP(hipEventRecord(G.k_beg[0], G.stream));
         const double *st = E->hd_state + (size_t)G.e0 * E->ld_s;
-        int rc = egp_launch_pd_server(E->ctx, st + E->off_qpos, E->ld_s, st + E->off_qvel, E->ld_s, st + E->off_bias, E->ld_s,
+        const double *bias = E->device_dynamics ? E->d_bias + (size_t)G.e0 * E->nv : st + E->off_bias;
+        int rc = egp_launch_pd_server(E->ctx, st + E->off_qpos, E->ld_s, st + E->off_qvel, E->ld_s, bias, E->device_dynamics ? E->nv : E->ld_s,
                                       E->d_qM + (size_t)G.e0 * E->ld_m, E->ld_m, E->hd_qM + (size_t)G.e0 * E->ld_m,
                                       G.action + (size_t)G.e0 * nu, m, E->hd_torque + (size_t)G.e0 * nu, G.stream, S.d_block_slice,
                                       S.hd_go, base, FS, S.hd_err, 2.0, S.d_trace, E->hd_ee + (size_t)G.e0 * 15,
@@ -708,7 +724,14 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     E_TRY(hipMalloc((void **)&E->d_qvel, N * E->nv * sizeof(double)));
     E_TRY(hipMalloc((void **)&E->d_torque, N * E->nu * sizeof(double)));
     E_TRY(hipMalloc((void **)&E->d_ee, N * 15 * sizeof(double)));
-    if (E->device_dynamics) E_TRY(hipMalloc((void **)&E->d_bias, N * E->nv * sizeof(double)));
+    if (E->device_dynamics) {
+        E_TRY(hipMalloc((void **)&E->d_bias, N * E->nv * sizeof(double)));
+        E_TRY(hipMalloc((void **)&E->d_bias2, N * E->nv * sizeof(double)));
+        E_TRY(hipMalloc((void **)&E->d_qM2, N * E->ld_m * sizeof(double)));
+        E_TRY(hipMemset(E->d_bias, 0, N * E->nv * sizeof(double)));
+        E_TRY(hipMemset(E->d_bias2, 0, N * E->nv * sizeof(double)));
+        E_TRY(hipMemset(E->d_qM2, 0, N * E->ld_m * sizeof(double)));
+    }
     E_TRY(hipMemset(E->d_state, 0, N * E->ld_s * sizeof(double)));
     E_TRY(hipMemset(E->d_qM, 0, N * E->ld_m * sizeof(double)));
     E_TRY(hipHostMalloc((void **)&E->h_state, N * E->ld_s * sizeof(double), hipHostMallocDefault));
@@ -727,7 +750,7 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
         E_TRY(hipHostGetDevicePointer(&p3, E->h_qM, 0));
         E_TRY(hipHostGetDevicePointer(&p4, E->h_ee, 0));
         E->hd_state = (double *)p1; E->hd_torque = (double *)p2; E->hd_qM = (double *)p3; E->hd_ee = (double *)p4;
-        E_TRY(hipHostMalloc((void **)&E->h_reset_list, N * 2 * sizeof(int), hipHostMallocDefault));
+        E_TRY(hipHostMalloc((void **)&E->h_reset_list, N * 3 * sizeof(int), hipHostMallocDefault));
         E_TRY(hipHostGetDevicePointer(&p5, E->h_reset_list, 0));
         E->hd_reset_list = (int *)p5;
         E_TRY(hipEventCreateWithFlags(&E->reset_done, hipEventDisableTiming));
@@ -876,7 +899,7 @@ int egp_engine_destroy(egp_engine *E) {
         for (auto ev : G.k_beg) (void)hipEventDestroy(ev);
         for (auto ev : G.k_end) (void)hipEventDestroy(ev);
     }
-    void *dev[] = {E->d_state, E->d_qM, E->d_prev_qpos, E->d_qpos, E->d_qvel, E->d_torque, E->d_ee, E->d_bias};
+    void *dev[] = {E->d_state, E->d_qM, E->d_prev_qpos, E->d_qpos, E->d_qvel, E->d_torque, E->d_ee, E->d_bias, E->d_bias2, E->d_qM2};
     for (void *p : dev) if (p) (void)hipFree(p);
     if (E->reset_done) (void)hipEventDestroy(E->reset_done);
     void *host[] = {E->h_state, E->h_qM, E->h_qpos, E->h_qvel, E->h_torque, E->h_ee, E->h_headz, E->h_xpos, E->h_reset_list};
@@ -936,14 +959,25 @@ int egp_engine_reset(egp_engine *E, const int32_t *ids, int32_t n, const double 
             egp::set_error("physics backend failed to reset env %d", e);
             return EGP_E_PHYSICS;
         }
-        new_qM[k] = !E->vt->inertia_epoch || E->epoch[e] != before;
+        new_qM[k] = !E->device_dynamics && (!E->vt->inertia_epoch || E->epoch[e] != before);
     }
     if (n > 0) {
-        for (int k = 0; k < n; ++k) { E->h_reset_list[2 * k] = ids[k]; E->h_reset_list[2 * k + 1] = new_qM[k]; }
+        for (int k = 0; k < n; ++k) {
+            E->h_reset_list[3 * k] = ids[k];
+            E->h_reset_list[3 * k + 1] = new_qM[k];
+            E->h_reset_list[3 * k + 2] = E->groups[E->env_group[ids[k]]].dyn_gen;
+        }
         k_engine_reset_scatter<<<dim3(n), dim3(256), 0, s>>>(E->hd_reset_list, E->hd_state, E->ld_s, E->off_qpos, E->off_qvel, E->hd_ee,
                                                               E->hd_qM, E->ld_m, E->nM, E->nq, E->nv, E->d_state, E->d_qpos, E->d_qvel,
                                                               E->d_ee, E->d_qM);
         EGP_HIP_CHECK(hipGetLastError());
+        if (E->device_dynamics) {
+            // sim.forward() of the reset (envs/common/mujoco_env.py:97-101): M, C at the reset state -- the only time compute_torque sees
+            // them fresh -- into the generation the env's group reads next
+            int rd = egp_launch_dynamics_strided(E->ctx, E->d_qpos, E->nq, E->d_qvel, E->nv, n, E->d_qM, E->ld_m, E->d_bias, E->nv, nullptr, s,
+                                                 E->hd_reset_list, 3, E->d_qM2, E->d_bias2);
+            if (rd != EGP_OK) return rd;
+        }
         EGP_HIP_CHECK(hipEventRecord(E->reset_done, s));
         E->reset_pending = true;
     }

@@ -88,7 +88,8 @@ int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const d
 size_t egp_pd_server_dyn_lds_bytes();
 int egp_pd_server_resident_blocks(int device, bool device_dynamics);
 int egp_launch_dynamics_strided(egp_ctx *ctx, const double *qpos, long ld_q, const double *qvel, long ld_v, int32_t n, double *qM,
-                                long ld_m, double *bias, long ld_b, double *xpos, hipStream_t stream);
+                                long ld_m, double *bias, long ld_b, double *xpos, hipStream_t stream, const int *list = nullptr,
+                                int list_stride = 0, double *qM_alt = nullptr, double *bias_alt = nullptr);
 // bit pattern the engine pre-fills pinned torque rows with in resident-K1 mode (a quiet NaN no clipped torque can equal)
 constexpr unsigned long long EGP_TORQUE_SENTINEL = 0x7FF8DEADBEEF0001ull;
 const egp_physics_vtable *egp_physics_vt(const egp_physics *p);

@@ -440,6 +440,7 @@ struct PdServe {
     const int *active;                    // optional [n] (pinned host): envs with 0 are not stepped this env-step -- their waves
                                           // move no state, torque or epilogue rows (in a rollout's tail that is most of the PCIe traffic)
     const void *dyn;                      // DYN kernels: the egp_dyn::DynTables of the context (device)
+    double *bias_dev;                     // DYN kernels: [n][nv] HBM bias rows -- with qM_dev what the env's last mj_step "left behind"
     int row_contig;                       // qpos | qvel | bias are ONE row of nq + 2 nv doubles (the engine's state rows): read it as a
                                           // contiguous stream (see the substep loop)
 };
@@ -459,10 +460,15 @@ __device__ __forceinline__ double sys_load_f64(const double *p) {
     return __longlong_as_double((long long)u);
 }
 
-// DYN (device_dynamics engines): the wave computes the inertia and the bias force itself from the (qpos, qvel) row it has
-// just read (K8's wave function: FK + CRBA + RNE, egp_dynamics_dev.hpp) instead of taking qM / qfrc_bias from the host --
-// a backend whose inertia changes with every substep (MuJoCo's does) then sends 117 doubles per env-substep, not 1 085,
-// at the price of a fresh factorisation per substep. Needs the dynamic LDS (tables + per-wave scratch).
+// DYN (device_dynamics engines): the wave computes the inertia and the bias force itself from the (qpos, qvel) rows it reads
+// (K8's wave function: FK + CRBA + RNE, egp_dynamics_dev.hpp) instead of taking qM / qfrc_bias from the host -- a backend whose
+// inertia changes with every substep (MuJoCo's does) then sends 117 doubles per env-substep, not 1 085.
+// With the reference's timing: compute_torque (ego_pose/envs/humanoid_v1.py:130-144) reads data.qM / data.qfrc_bias as the
+// PREVIOUS mj_step left them -- evaluated at the state that step started from -- and only a reset's sim.forward()
+// (envs/common/mujoco_env.py:97-101) makes them fresh. So substep k solves with the factors of M(q_{k-1}) and with C(q_{k-1}, v_{k-1})
+// it already holds, stores the torque, and only THEN runs K8 + the factorisation on the row it has just read, for substep k + 1
+// -- behind the host's physics step instead of in front of the torque. Across launches the env's (qM, bias) rows persist in
+// HBM (qM_dev / bias_dev: written after the last substep, and by the engine's reset = sim.forward()). Needs the dynamic LDS.
 template <bool DYN>
 __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, const double *qpos, const double *qvel,
                                                           const double *__restrict__ action, const double *qM, const double *C,
@@ -527,6 +533,24 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
     double a[PD_NV];
     double dinv = 0.0;
     const double kd_dt = c_kd * m.sub_dt;
+    double c_held = 0.0;                    // DYN: the bias entry of this lane's dof that the previous substep left behind
+    auto factor_from_lds = [&]() {
+#pragma unroll
+        for (int j = 0; j < PD_NV; ++j) {
+            const int id = s_map[row * PD_NV + j];
+            double v = id >= 0 ? s_qM[wave][id] : 0.0;
+            a[j] = v + (j == row ? kd_dt : 0.0);
+        }
+        tree_factor<PD_NV - 1>(a, dinv, row);
+    };
+    if constexpr (DYN) {
+        // what the last env-step's final mj_step (or the reset's forward) left in HBM: factor it before the first go word
+        __syncthreads();
+        if (live && !m.action_torque) {
+            c_held = C[env * ld.bias + row];
+            factor_from_lds();
+        }
+    }
     for (int sub = 0; sub < sv.n_sub; ++sub) {
         if (threadIdx.x == 0) {
             const unsigned long long want = sv.base + (unsigned long long)sub;
@@ -558,9 +582,7 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
                 if (lane < sv.nq) s_q[lane] = sys_load_f64(qpos + env * ld.qpos + lane);
                 if (lane < sv.nv) s_q[64 + lane] = sys_load_f64(qvel + env * ld.qvel + lane);
                 egp_dyn::wave_sync();
-                egp_dyn::dynamics_wave(*tb, s_scr, s_q, s_q + 64, lane, true, &s_qM[wave][0], s_q + 128, nullptr);
-                egp_dyn::wave_sync();
-                r_q = s_q[7 + act]; r_v = s_q[64 + row]; r_c = s_q[128 + row];
+                r_q = s_q[7 + act]; r_v = s_q[64 + row]; r_c = c_held;
             } else if (sv.row_contig) {
                 // The state row over PCIe, lane l taking doubles l, 64 + l, 128 + l: whole 64-byte lines, each once (22 for the
                 // humanoid's 175 doubles). As three lane = dof segments (qpos + 7.., qvel, bias) the same row costs ~25 line reads,
@@ -599,15 +621,7 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
                     if (i < m.nM) dst[i] = t_qM[k];
                 }
             }
-            if (sub == 0 || refresh) {          // (wave-uniform: the go word is per slice, the wave per env)
-#pragma unroll
-                for (int j = 0; j < PD_NV; ++j) {
-                    const int id = s_map[row * PD_NV + j];
-                    double v = id >= 0 ? s_qM[wave][id] : 0.0;
-                    a[j] = v + (j == row ? kd_dt : 0.0);
-                }
-                tree_factor<PD_NV - 1>(a, dinv, row);
-            }
+            if (!DYN && (sub == 0 || refresh)) factor_from_lds();      // (wave-uniform: the go word is per slice, the wave per env)
             const double kp = c_kp, kd = c_kd;
             const double eq = row >= 6 ? r_q - target : 0.0;
             const double qv = r_v;
@@ -625,6 +639,24 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
                                    __HIP_MEMORY_SCOPE_SYSTEM);
             }
             if (tracer) sv.trace[sub * 8 + 4] = wall_clock64();
+            if constexpr (DYN) {
+                // the torque is on its way and the host steps: now what that mj_step leaves behind for the NEXT compute_torque --
+                // M and C at the state just read -- and its factors
+                egp_dyn::dynamics_wave(*tb, s_scr, s_q, s_q + 64, lane, true, &s_qM[wave][0], s_q + 128, nullptr);
+                egp_dyn::wave_sync();
+                c_held = s_q[128 + row];
+                factor_from_lds();
+                if (sub == sv.n_sub - 1) {       // ... and across launches
+                    double *dst = sv.qM_dev + env * ld.qM;
+#pragma unroll
+                    for (int k = 0; k < QM_IT; ++k) {
+                        const int i = lane + 64 * k;
+                        if (i < m.nM) dst[i] = s_qM[wave][i];
+                    }
+                    if (lane < PD_NV) sv.bias_dev[env * ld.bias + row] = c_held;
+                }
+                if (tracer) sv.trace[sub * 8 + 5] = wall_clock64();
+            }
         }
     }
     // epilogue: prev_qpos <- qpos; qpos | qvel | ee_wpos <- the rows the owner drained after the last substep.
@@ -1862,7 +1894,8 @@ int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const d
     const int row_contig = !device_dynamics && qvel == qpos + nq && bias == qvel + nv && ld_qpos == ld_qvel &&
                            ld_qvel == ld_bias && nq + 2 * nv <= 192 && ld_qpos >= nq + 2 * nv;
     PdServe sv{block_slice, go, base, n_sub, qM_host, const_cast<double *>(qM), err, (long long)(timeout_s * 100.0e6), trace,
-               ee_host, out_qpos, out_prev_qpos, out_qvel, out_ee, nq, nv, poll_sleep, active, ctx->dyn_tables, row_contig};
+               ee_host, out_qpos, out_prev_qpos, out_qvel, out_ee, nq, nv, poll_sleep, active, ctx->dyn_tables,
+               device_dynamics ? const_cast<double *>(bias) : nullptr, row_contig};
     if (device_dynamics) {
         const size_t lds = egp_pd_server_dyn_lds_bytes();
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pd_server_tree58<true>),

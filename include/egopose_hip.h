@@ -553,7 +553,10 @@ typedef struct egp_engine_desc {
     int32_t n_groups;        /* env groups that can be stepped independently (policy/physics overlap) */
     int32_t device_dynamics; /* 1: qM and qfrc_bias of every substep come from K8 (egp_set_dynamics_model must have been
                               * called) instead of the backend's drain -- `drain` is then always called with qM == NULL and its
-                              * qfrc_bias is ignored; M and C belong to the CURRENT state (mj_step's are one step stale) */
+                              * qfrc_bias is ignored. Timing as in the reference (ego_pose/envs/humanoid_v1.py:130-144 reads
+                              * data.qM / data.qfrc_bias as the previous mj_step left them): a substep's torque is solved with
+                              * M, C of the state the PREVIOUS substep started from; egp_engine_reset evaluates them at the reset
+                              * state (sim.forward(), envs/common/mujoco_env.py:97-101) */
 } egp_engine_desc;
 
 int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *desc, egp_engine **out);

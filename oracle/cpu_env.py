@@ -29,8 +29,14 @@ from .zfilter import ZFilterOracle
 
 
 class OracleHumanoidEnv:
-    def __init__(self, skel, cfg, physics, expert_arr, cnn_feat, seed=0, env_slot=0):
+    def __init__(self, skel, cfg, physics, expert_arr, cnn_feat, seed=0, env_slot=0, device_dynamics=False):
+        """`device_dynamics`: qM / qfrc_bias are not taken from the backend's drain but evaluated by oracle/dynamics.py with the
+        timing MuJoCo gives the reference (humanoid_v1.py:130-144 reads data.qM / data.qfrc_bias as the previous mj_step left them,
+        i.e. at the state that step started from; sim.forward() makes them fresh after a reset, envs/common/mujoco_env.py:97-101):
+        what the engine's device-dynamics mode (K8) must reproduce."""
         self.skel, self.cfg, self.phys = skel, cfg, physics
+        self.device_dynamics = bool(device_dynamics)
+        self._held = None
         self.slot = env_slot
         self.expert_arr, self.cnn_feat = expert_arr, cnn_feat
         self.np_random = np.random.RandomState(seed)
@@ -46,6 +52,14 @@ class OracleHumanoidEnv:
         self.qpos, self.qvel, self.qM, self.bias = q, v, qM, bias
         if want_xpos:
             self.xpos = xpos
+
+    def forward(self):
+        """sim.forward() after set_state: drained state, and (device dynamics) M, C evaluated at it."""
+        self._drain(True)
+        if self.device_dynamics:
+            from . import dynamics as D
+            M, C, _ = D.crba_rne_spatial(self.skel, self.qpos, self.qvel)
+            self._held = (M, C)
 
     def _obs(self):
         c = self.cfg
@@ -64,7 +78,7 @@ class OracleHumanoidEnv:
             self.cur_t = int(self.np_random.randint(cfg.env_episode_len))
             ind += self.cur_t
         self.phys.reset(self.slot, e["qpos"][ind], e["qvel"][ind])
-        self._drain(True)
+        self.forward()
         self.bquat = H.body_quat(self.qpos, self.skel.body_qpos_start, self.skel.body_ndof)[0]
         return self._obs()
 
@@ -72,8 +86,14 @@ class OracleHumanoidEnv:
         cfg, sk = self.cfg, self.skel
         self.prev_qpos, self.prev_bquat = self.qpos.copy(), self.bquat.copy()
         for i in range(15):
-            M = H.full_from_sparse(self.qM, sk.dof_parentid, sk.dof_Madr)
-            _, tau = H.control_torque(getattr(cfg, "action_type", "position"), self.qpos, self.qvel, action, M, self.bias, cfg.jkp,
+            if self.device_dynamics:
+                from . import dynamics as D
+                M, bias = self._held                     # left behind by the previous mj_step (or the reset's forward)
+                Mn, Cn, _ = D.crba_rne_spatial(sk, self.qpos, self.qvel)
+                self._held = (Mn, Cn)                    # ... and by this one: evaluated at the state it starts from
+            else:
+                M, bias = H.full_from_sparse(self.qM, sk.dof_parentid, sk.dof_Madr), self.bias
+            _, tau = H.control_torque(getattr(cfg, "action_type", "position"), self.qpos, self.qvel, action, M, bias, cfg.jkp,
                                       cfg.jkd, cfg.a_ref, cfg.a_scale, cfg.torque_lim, sk.timestep)
             self.phys.step(self.slot, tau[0])
             self._drain(i == 14)

@@ -105,9 +105,12 @@ def test_dynamics_feeds_stable_pd(ctx, skel):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["resident", "per_substep"])
 def test_engine_device_dynamics_matches_host_loop(ctx, skel, mode, monkeypatch):
-    """Engine with device_dynamics: the backend is only asked for qpos / qvel (drain always gets qM == NULL), K8 feeds K1
-    every substep -- inside the resident kernel (one launch per env-step), or as a K8 + K1 launch pair per substep;
-    2 env-steps == the host loop with the oracle's stable PD on the oracle's M(q), C(q, qvel) of the CURRENT state."""
+    """Engine with device_dynamics: the backend is only asked for qpos / qvel (drain always gets qM == NULL), K8 feeds K1 -- inside
+    the resident kernel (one launch per env-step), or as a K8 + K1 launch pair per substep -- with the REFERENCE's timing
+    (ego_pose/envs/humanoid_v1.py:130-144: compute_torque reads data.qM / data.qfrc_bias as the previous mj_step left them, i.e.
+    evaluated at the state that step started from; fresh only after the reset's sim.forward(), envs/common/mujoco_env.py:97-101).
+    3 env-steps with a reset of some envs in between == the host loop with the oracle's stable PD fed the oracle's M, C of the
+    PREVIOUS substep's state."""
     if mode == "per_substep":
         monkeypatch.setenv("EGP_SERVER", "0")
     from conftest import load_golden, VaryingInertiaBackend
@@ -130,8 +133,12 @@ def test_engine_device_dynamics_matches_host_loop(ctx, skel, mode, monkeypatch):
     eng = RolloutEngine(ctx, be, n, n_threads=2, n_groups=1, device_dynamics=True)
     assert eng.substeps_per_launch == (15 if mode == "resident" else 1)
     eng.reset(np.arange(n), qpos0, qvel0)
-    acts = [rng.normal(size=(n, 52)) * 0.2 for _ in range(2)]
-    for a in acts:
+    acts = [rng.normal(size=(n, 52)) * 0.2 for _ in range(3)]
+    re_ids = np.array([0, 6, 9])                      # reset between env-steps 2 and 3: their M, C are fresh again, the others' stay stale
+    re_q, re_v = g["qpos"][n:n + 3], g["qvel"][n:n + 3] * 0.1
+    for k, a in enumerate(acts):
+        if k == 2:
+            eng.reset(re_ids, re_q, re_v)
         ad = torch.as_tensor(a, device="cuda")
         torch.cuda.synchronize()
         eng.step_async(0, ad)
@@ -142,19 +149,30 @@ def test_engine_device_dynamics_matches_host_loop(ctx, skel, mode, monkeypatch):
     logged = [np.array(t) for t in be.torques]
     eng.close()
     ref = SurrogatePhysics(skel, 1)
-    for e in range(0, n, 3):
+    fresh_err = 0.0
+    for e in [0, 3, 6, 9, 12]:
         ref.reset(0, qpos0[e], qvel0[e])
+        M, C, _ = D.crba_rne_spatial(skel, qpos0[e], qvel0[e])             # sim.forward() of the reset
         row = 0
-        for a in acts:
+        for k, a in enumerate(acts):
+            if k == 2 and e in re_ids:
+                j = int(np.where(re_ids == e)[0][0])
+                ref.reset(0, re_q[j], re_v[j])
+                M, C, _ = D.crba_rne_spatial(skel, re_q[j], re_v[j])
             for s in range(15):
                 q, v, _, _, _ = ref.drain(0, want_xpos=False)
-                M, C, _ = D.crba_rne_spatial(skel, q, v)
                 _, tc = H.pd_torque(q, v, a[e], M, C, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], skel.timestep)
-                np.testing.assert_allclose(logged[e][row], tc[0], rtol=1e-7, atol=1e-7, err_msg="env %d substep %d" % (e, row))
+                np.testing.assert_allclose(logged[e][row], tc[0], rtol=1e-9, atol=1e-9, err_msg="env %d substep %d" % (e, row))
+                M_now, C_now, _ = D.crba_rne_spatial(skel, q, v)          # what this substep's mj_step leaves behind
+                if row > 0:
+                    _, tf = H.pd_torque(q, v, a[e], M_now, C_now, c["jkp"], c["jkd"], c["a_ref"], c["a_scale"], c["torque_lim"], skel.timestep)
+                    fresh_err = max(fresh_err, float(np.abs(tf[0] - tc[0]).max()))
+                M, C = M_now, C_now
                 ref.step(0, tc[0])
                 row += 1
         q, *_ = ref.drain(0, want_xpos=False)
-        np.testing.assert_allclose(got_q[e], q, rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(got_q[e], q, rtol=1e-9, atol=1e-9)
+    assert fresh_err > 1e-6, "the test cannot tell stale from fresh M, C (%g)" % fresh_err
     ref.close()
     be.close()
 

@@ -568,15 +568,16 @@ def test_sampled_actions_are_policy_mean_plus_unit_noise(workspace):
     tr.close()
 
 
-def _replay_episodes(tr, cfg, skel, batch, episodes, end_reward, tol=1e-7, t0=None):
-    """`t0`: cur_t at every batch row's episode start (cfg.random_cur_t; LockstepRollout.batch_t0), default 0."""
+def _replay_episodes(tr, cfg, skel, batch, episodes, end_reward, tol=1e-7, t0=None, device_dynamics=False):
+    """`t0`: cur_t at every batch row's episode start (cfg.random_cur_t; LockstepRollout.batch_t0), default 0.
+    `device_dynamics`: the oracle env evaluates M, C itself with the reference's one-substep staleness (OracleHumanoidEnv)."""
     from egopose_amd.physics import SurrogatePhysics
     from oracle.cpu_env import OracleHumanoidEnv
     from oracle import humanoid as H
     ends = np.where(batch.masks == 0)[0]
     starts = np.r_[0, ends[:-1] + 1]
     ph = SurrogatePhysics(skel, 1)
-    env = OracleHumanoidEnv(skel, cfg, ph, tr.env.expert_arr, tr.env.cnn_feat)
+    env = OracleHumanoidEnv(skel, cfg, ph, tr.env.expert_arr, tr.env.cnn_feat, device_dynamics=device_dynamics)
     env.end_reward = end_reward
     for j in episodes:
         s, e = starts[j], ends[j]
@@ -586,7 +587,7 @@ def _replay_episodes(tr, cfg, skel, batch, episodes, end_reward, tol=1e-7, t0=No
         env.expert_ind, env.start_ind, env.cur_t = int(ei), int(si), c0
         ex = tr.env.expert_arr[ei]
         ph.reset(0, ex["qpos"][si + c0], ex["qvel"][si + c0])
-        env._drain(True)
+        env.forward()
         env.bquat = H.body_quat(env.qpos, skel.body_qpos_start, skel.body_ndof)[0]
         np.testing.assert_allclose(batch.states[s], env._obs(), rtol=1e-9, atol=1e-9)
         for i in range(s, e + 1):
@@ -628,6 +629,29 @@ def test_bench_shape_rollout_replayed_by_oracle_env(tmp_path_factory, skel):
     starts, _ = _replay_episodes(tr, cfg, skel, batch, sample, 1.7)
     lens = ends - starts + 1
     assert lens.max() <= cfg.env_episode_len and (lens[sample] > 1).all()
+    tr.close()
+
+
+@pytest.mark.parametrize("server", ["1", "0"])
+def test_device_dynamics_rollout_replayed_by_oracle_env(workspace, skel, monkeypatch, server):
+    """EGP_DEVICE_DYNAMICS=1: M, C of every substep from K8 on the device. The oracle env, which evaluates oracle/dynamics.py with the
+    reference's timing (previous substep's state; fresh after a reset), replays the episodes -- in-batch resets included -- in both
+    forms of the env-step; and the same episodes do NOT replay with the backend's own (constant) inertia, so the comparison can tell."""
+    monkeypatch.setenv("EGP_DEVICE_DYNAMICS", "1")
+    monkeypatch.setenv("EGP_SERVER", server)
+    tr, cfg = _trainer(workspace, 24, 6, num_threads=4, num_groups=2)
+    tr.agent.running_state = None
+    tr.env.end_reward = 0.37
+    batch, log = tr.agent.sample(24 * 14)
+    eng = tr.agent._get_rollout().engine
+    assert eng.device_dynamics and eng.substeps_per_launch == (15 if server == "1" else 1)
+    ends = np.where(batch.masks == 0)[0]
+    n_ep = len(ends)
+    assert n_ep >= 48, "every slot must have restarted at least once inside the batch"
+    sample = sorted({0, 1, n_ep // 2 - 1, n_ep // 2, n_ep - 2, n_ep - 1})
+    _replay_episodes(tr, cfg, skel, batch, sample, 0.37, device_dynamics=True)
+    with pytest.raises(AssertionError):
+        _replay_episodes(tr, cfg, skel, batch, sample[:1], 0.37, device_dynamics=False)
     tr.close()
 
 
