@@ -45,6 +45,8 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec
 K1_BYTES_PER_ENV = (910 + 58 + 52 + 58 + 52 + 52) * 8   # qM + qfrc_bias + qpos[7:] + qvel + action + torque, float64
+K1_MOVED_BYTES_PER_ENV = K1_BYTES_PER_ENV - 910 * 8      # ... without the inertia row: what moves while the backend's inertia is constant
+K1_LINK_BYTES_PER_ENV = 22 * 64                         # the state row as the resident K1 reads it over PCIe: 22 whole lines (qpos | qvel | bias)
 
 
 def cpu_baseline(dataset, steps, threads, extra_env=None, update_steps=0):
@@ -192,6 +194,12 @@ def explain(args, world, eng, ro, t_sample, t_update, per_iter, iter_ms, iter_st
         "rollout_ticks": ro.timing.get("ticks"), "rollout_small_group_ticks": ro.timing.get("small_group_ticks"),
         "rollout_wait_s": round(ro.timing.get("wait", 0.0), 4), "rollout_setup_s": round(ro.timing.get("setup", 0.0), 4),
         "rollout_assemble_s": round(ro.timing.get("assemble", 0.0), 4),
+        #  with prefetch_rollout the next pass's set-up (resets, context pool, noise: host work) runs inside update_params
+        # behind the enqueued epochs: T_sample then excludes it and T_update contains it (hidden under the GPU's epochs); the
+        # reference's T_sample includes its resets (agents/agent.py:29-76). Last rollout's figure:
+        "rollout_setup_prepared_ms": round(ro.timing.get("setup", 0.0) * 1e3, 2) if ro.timing.get("setup_prepared") else 0.0,
+        "t_split_note": "T_sample excludes the sampling set-up when it was prepared inside update_params (rollout_setup_prepared_ms > 0): "
+                        "that host time is inside T_update; env-steps/s is end to end either way",
     }
     out.update({"host_" + k: v for k, v in info.items()})
     for tag, pr in (("probe", probe0), ("probe_after", probe1)):
@@ -211,7 +219,38 @@ def explain(args, world, eng, ro, t_sample, t_update, per_iter, iter_ms, iter_st
     return out
 
 
-def k1_roofline(tim, envs_per_group, eng, every):
+CONFIG_FIRST = ("workload", "env_steps_per_s_changing_inertia_device", "env_steps_per_s_changing_inertia_host_fed",
+                "env_steps_per_s_20us_substep", "frac_of_host_physics_ceiling_20us", "k1_avg_launch_us_device_dynamics",
+                "probe_go_rtt_us_p50", "probe_pcie_read_GBps", "probe_spin_gap_us_max", "host_loadavg_1m",
+                "t_sample_ms_median", "t_update_ms_median", "rollout_setup_prepared_ms", "env_steps_per_s_median_iteration",
+                "env_steps_per_s_min_iteration", "env_steps_per_s_max_iteration", "engine_substeps_per_launch", "envs_per_gpu",
+                "physics", "host_threads_per_gpu", "parallelism", "env_steps_per_s_2048_slots", "env_steps_per_s_4096_slots")
+
+
+def order_config(cfg, legs):
+    """The driver's record of this line keeps the first ~21 scalar keys of `config`: the physics modes a MuJoCo-shaped backend
+    would see (from `legs`, which the record drops), the host probe and the sample / update split go first; everything else after."""
+    legs = legs or {}
+
+    def leg(name, key="env_steps_per_s"):
+        v = legs.get(name, {}).get(key)
+        return round(v, 1) if isinstance(v, float) else v
+    lead = {"env_steps_per_s_changing_inertia_device": leg("changing_inertia_device_dynamics"),
+            "env_steps_per_s_changing_inertia_host_fed": leg("changing_inertia_host_fed"),
+            "env_steps_per_s_20us_substep": leg("simulator_cost_per_substep"),
+            "frac_of_host_physics_ceiling_20us": leg("simulator_cost_per_substep", "frac_of_host_physics_ceiling"),
+            "k1_avg_launch_us_device_dynamics": leg("changing_inertia_device_dynamics", "k1_avg_launch_us")}
+    sweep = legs.get("envs_per_gpu_sweep", {})
+    for n in (2048, 4096):
+        best = [v.get("env_steps_per_s") for k, v in sweep.items() if k.startswith("slots_%d_" % n) and isinstance(v, dict) and v.get("env_steps_per_s")]
+        lead["env_steps_per_s_%d_slots" % n] = round(max(best), 1) if best else None
+    merged = dict(cfg, **lead)
+    out = {k: merged[k] for k in CONFIG_FIRST if k in merged}
+    out.update({k: v for k, v in merged.items() if k not in out})
+    return out
+
+
+def k1_roofline(tim, envs_per_group, eng, every, probe=None):
     """K1 roofline from the engine's event-bracketed launches (see the module docstring)."""
     if tim["k1_launches"] <= 0:
         return None
@@ -230,7 +269,17 @@ def k1_roofline(tim, envs_per_group, eng, every):
         traffic_src = ("NOT measured in this run: committed profile taken at commit %s, " % pm.get("commit", "?")) + pm["source"] + "; " + pm["correction"]
     except Exception:
         pass
+    # what the launch actually waits for: 15 host round trips and the PCIe read of the state rows (22 whole 64-byte lines per
+    # env-substep); the inertia row (910 of the 1 182 "algorithmic" doubles) never moves while the backend's inertia is constant
+    link_bytes = K1_LINK_BYTES_PER_ENV * tim["k1_env_substeps"]
+    link_gbps = link_bytes / total_s / 1e9
+    probe_gbps = (probe or {}).get("pcie_read_gbps")
+    moved = K1_MOVED_BYTES_PER_ENV * tim["k1_env_substeps"] / total_s
     return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+            "bound_in_rollout": "host round trips (%d per launch) + PCIe read of the state rows; HBM is not the limit here" % sub_per_launch,
+            "pcie_frac": (link_gbps / probe_gbps) if probe_gbps else None, "pcie_GBps": link_gbps, "pcie_peak_GBps_probe": probe_gbps,
+            "pcie_bytes_per_env_substep": K1_LINK_BYTES_PER_ENV,
+            "alg_bytes_moved_per_env_substep": K1_MOVED_BYTES_PER_ENV, "achieved_moved_GBps": moved / 1e9, "frac_moved": moved / HBM_PEAK,
             "traffic": traffic, "traffic_unit": "bytes per launch (mean stepped envs)", "traffic_source": traffic_src,
             "kernel": "k_pd_server_tree58 (resident: one launch = 15 substeps, duration includes the waits for host physics)"
                       if sub_per_launch > 1 else "k_pd_torque_tree58<double>",
@@ -449,7 +498,8 @@ def main():
         })
         res["config"].update(explain(args, world, eng, ro, t_sample, t_update, per_iter, iter_ms, iter_steps, thr0, thr1, probe0, probe1,
                                      host_info(local)))
-        res["roofline"] = k1_roofline(tim, args.envs / float(args.groups), eng, args.k1_event_every)
+        res["roofline"] = k1_roofline(tim, args.envs / float(args.groups), eng, args.k1_event_every,
+                                      probe0 if (probe0 and "error" not in probe0) else None)
         if res["roofline"] is not None:          # (the decomposition next to the kernel figure too: this dict is kept whole)
             c = res["config"]
             res["roofline"].update({"t_sample_ms_median": c["t_sample_ms_median"], "t_update_ms_median": c["t_update_ms_median"]})
@@ -545,6 +595,7 @@ def main():
                 if res[k].get("value"):
                     res[k]["gpu_over_cpu_rollout"] = res["rollout_only_env_steps_per_s"] / res[k]["value"]
     if rank == 0:
+        res["config"] = order_config(res["config"], res.get("legs"))
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -94,10 +94,11 @@ __device__ __forceinline__ int lstm_group_steps(const LstmGroup &grp, int revers
 // s_waitcnt pass no longer knows how many memory operations are outstanding and waits for ALL of them (vmcnt(0))
 // before touching a prefetched register -- i.e. for the acknowledgement of the stores it has just issued, every step.
 // tools/probes/lstm_trace.hip compiles this file with EGP_LSTM_TRACE = a workgroup index: per-phase cycle sums of wave 0 of that
-// workgroup of the LAST problem of a grouped forward launch (a problem that runs backward in time: every step)
+// workgroup of the LAST problem of a grouped forward launch (a problem that runs backward in time: every step; the kernels
+// walk the problems from the last one down, prob = gridDim.y - 1 - blockIdx.y, so that is blockIdx.y == 0)
 #ifdef EGP_LSTM_TRACE
 __device__ long long g_lstm_trace[8];
-#define EGP_LT_DECL long long lt_acc[6] = {0, 0, 0, 0, 0, 0}, lt_prev = 0; const bool lt_on = blockIdx.x == EGP_LSTM_TRACE && blockIdx.y == gridDim.y - 1 && threadIdx.x == 0
+#define EGP_LT_DECL long long lt_acc[6] = {0, 0, 0, 0, 0, 0}, lt_prev = 0; const bool lt_on = blockIdx.x == EGP_LSTM_TRACE && blockIdx.y == 0 && threadIdx.x == 0
 #define EGP_LT_START if (lt_on) lt_prev = (long long)__builtin_readcyclecounter()
 #define EGP_LT(i) if (lt_on) { const long long lt_now = (long long)__builtin_readcyclecounter(); lt_acc[i] += lt_now - lt_prev; lt_prev = lt_now; }
 #define EGP_LT_END(steps) if (lt_on) { for (int i = 0; i < 6; ++i) g_lstm_trace[i] = lt_acc[i]; g_lstm_trace[6] = (steps); }

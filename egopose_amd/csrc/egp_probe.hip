@@ -115,6 +115,8 @@ extern "C" int egp_host_probe(int32_t device, int32_t n_threads, int32_t millis,
     hipStream_t st = nullptr;
     hipEvent_t ea = nullptr, eb = nullptr;
     const int n_rows = 1024;
+    int caller_device = -1;                    // the calling thread's current device is the caller's business: put it back on the way out
+    if (hipGetDevice(&caller_device) != hipSuccess) { (void)hipGetLastError(); caller_device = -1; }
     EGP_HIP_CHECK(hipSetDevice(device));
     {
         int large_bar = 0;
@@ -250,5 +252,6 @@ done:
     if (ea) (void)hipEventDestroy(ea);
     if (eb) (void)hipEventDestroy(eb);
     if (st) (void)hipStreamDestroy(st);
+    if (caller_device >= 0 && caller_device != device) (void)hipSetDevice(caller_device);
     return rc;
 }

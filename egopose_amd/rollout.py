@@ -342,8 +342,11 @@ class LockstepRollout:
         fused step packs, the video net whose contexts fill the episode pool) by address AND version -- a checkpoint load or a
         `with to_cpu(...)` round trip in between makes the set-up stale. (The policy's log_std is read by the tick itself.)"""
         nets = [p for n, p in self.policy_net.named_parameters() if n != "action_log_std"] + list(self.policy_vs_net.parameters())
+        rs = getattr(self.running_state, "rs", None)      # the set-up uploads the filter's CONTENTS and runs its first pass: an in-place
+        rs_sig = None if rs is None else (int(rs._n), float(np.sum(rs._M)), float(np.sum(rs._S)))       # restore / merge makes it stale
         return (int(min_batch_size), float(end_reward), bool(self.mean_action), bool(self.noise_rate >= 1.0), float(self.cfg.env_init_noise),
-                id(self.running_state), self.reward_kind, getattr(self, "step_budget", None) or os.environ.get("EGP_STEP_BUDGET", "slot"),
+                id(self.running_state), rs_sig, self.reward_kind, getattr(self, "step_budget", None) or os.environ.get("EGP_STEP_BUDGET", "slot"),
+                getattr(self.env, "fix_len", None), getattr(self.env, "fix_head_lb", None), id(getattr(self.env, "expert_arr", None)),
                 tuple((p.data_ptr(), p._version) for p in nets))
 
     def prepare(self, min_batch_size, end_reward=0.0):
@@ -355,15 +358,26 @@ class LockstepRollout:
         in the same stream order either way, so the rollout's numbers do not depend on whether it was prepared."""
         self.drop_prepared()
         key = self._setup_key(min_batch_size, end_reward)
+        # the set-up draws from the device's default generator (noise block), self.gen and the env's reset stream: a set-up that is
+        # dropped must leave them as it found them, or the next pass's numbers would depend on whether a prepared one was thrown away
+        npr = getattr(self.env, "np_random", None)
+        rng = (torch.cuda.get_rng_state(self.dev), self.gen.get_state(), None if npr is None else npr.get_state())
         gen = self._sample_gen(min_batch_size, end_reward)
         with torch.no_grad():
             next(gen)
-        self._prepared = (key, gen)
+        self._prepared = (key, gen, rng)
+
+    def _discard(self, pr):
+        pr[1].close()
+        torch.cuda.set_rng_state(pr[2][0], self.dev)
+        self.gen.set_state(pr[2][1])
+        if pr[2][2] is not None:
+            self.env.np_random.set_state(pr[2][2])
 
     def drop_prepared(self):
         pr, self._prepared = getattr(self, "_prepared", None), None
         if pr is not None:
-            pr[1].close()
+            self._discard(pr)
 
     def sample(self, min_batch_size, end_reward=0.0):
         t_call = time.time()
@@ -373,7 +387,7 @@ class LockstepRollout:
             if pr[0] == self._setup_key(min_batch_size, end_reward):
                 gen = pr[1]
             else:
-                pr[1].close()
+                self._discard(pr)
         with torch.no_grad():
             if gen is None:
                 gen = self._sample_gen(min_batch_size, end_reward)

@@ -874,14 +874,14 @@ def test_prepared_rollout_setup_changes_nothing(workspace):
     tr.agent.prefetch_rollout = False
     plain = _seeded_sample(tr, 64 * 20)
 
-    def prepared_sample():
+    def prepared_sample(prepared_batch=None):
         ro = tr.agent._get_rollout()
         real = tr.agent.sample
 
         def sample_with_prepare(min_batch):          # (what update_params does ahead of the driver's next sample call)
             with torch.no_grad():
                 ro.noise_rate, ro.mean_action = tr.agent.noise_rate, tr.agent.mean_action
-                ro.prepare(min_batch, end_reward=float(tr.env.end_reward))
+                ro.prepare(prepared_batch or min_batch, end_reward=float(tr.env.end_reward))
             return real(min_batch)
         tr.agent.sample = sample_with_prepare
         try:
@@ -891,6 +891,11 @@ def test_prepared_rollout_setup_changes_nothing(workspace):
     ahead = prepared_sample()
     assert tr.agent._get_rollout().timing["setup_prepared"] is True
     _assert_same_rollout(plain, ahead, "prepared")
+    # a set-up that is thrown away (made for another batch size) gives back the random streams it drew from: the pass that
+    # follows is the pass that would have run without it
+    dropped = prepared_sample(prepared_batch=64 * 10)
+    assert tr.agent._get_rollout().timing["setup_prepared"] is False
+    _assert_same_rollout(plain, dropped, "dropped set-up")
     tr.close()
 
     tr, cfg = _trainer(workspace, 64, 12, num_threads=4, num_groups=2)

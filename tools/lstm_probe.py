@@ -30,6 +30,5 @@ fwd = lambda: L.check(lib.egp_lstm_fwd_f32(p(gx.clone()), p(w), T, B, H, 0, p(h)
 cl = lambda: gx.clone()
 bwd = lambda: L.check(lib.egp_lstm_bwd_f32(p(dh), p(gates), p(cells), p(w), T, B, H, 0, p(dpre), s), "bwd")
 t_clone = bench(cl)
-print("T %d B %d H %d  mfma=%s tile=%s: fwd %.1f us  bwd %.1f us  (per step %.2f / %.2f us)" % (
-    T, B, H, os.environ.get("EGP_LSTM_MFMA", "1"), os.environ.get("EGP_LSTM_TILE", "-"),
-    bench(fwd) - t_clone, bench(bwd), (bench(fwd) - t_clone) / T, bench(bwd) / T))
+print("T %d B %d H %d: fwd %.1f us  bwd %.1f us  (per step %.2f / %.2f us)" % (
+    T, B, H, bench(fwd) - t_clone, bench(bwd), (bench(fwd) - t_clone) / T, bench(bwd) / T))
