@@ -240,6 +240,7 @@ SIGNATURES = {
     "egp_engine_substeps_per_launch": (C.c_int, [vp]),
     "egp_engine_server_trace": (C.c_int, [vp, _i32, vp, vp]),
     "egp_engine_go_words_in_vram": (_i32, [vp]),
+    "egp_engine_envs_per_wave": (_i32, [vp, C.POINTER(C.c_int32)]),
     "egp_host_probe": (C.c_int, [_i32, _i32, _i32, C.POINTER(HostProbeResult)]),
 }
 

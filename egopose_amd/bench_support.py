@@ -48,11 +48,13 @@ def _time_launches(fn, iters=50, warm=5, warm_s=0.03):
     return a.elapsed_time(b) / iters * 1e-3
 
 
-def kernel_microbench(sizes=(1024, 65536), device_index=0, variants=False, iters=50, only=None):
+def kernel_microbench(sizes=(1024, 65536), device_index=0, variants=False, iters=50, only=None, rotate=None):
     """K1-K6 / K8 with inputs resident in HBM (HIP events on the launch stream, float64): per (kernel, n) the time per
     call, the ALGORITHMIC bytes (SURVEY.md 8d / DESIGN.md section 4), achieved GB/s and the fraction of the 8 TB/s HBM
     peak. These are the numbers an HBM roofline can bind; the in-rollout K1 launch waits for host physics instead.
-    `variants=True` also times the other K1 kernels (lane per row, dense order, generic LDS)."""
+    `variants=True` also times the other K1 kernels (lane per row, dense order, generic LDS). Every launch works on the next of
+    `rotating_sets` input / output sets, so that a size whose footprint fits the 256 MiB Infinity Cache is still read from HBM
+    (`beyond_mall`: the sets together exceed the cache; round 5's figures at 65 536 envs re-ran one set and were cache-resident)."""
     import numpy as np
     import torch
     from .hip import EgpContext
@@ -72,31 +74,61 @@ def kernel_microbench(sizes=(1024, 65536), device_index=0, variants=False, iters
                 bquat=rng.normal(size=(F, 84)), bangvel=rng.normal(size=(F, 63)), head_height_lb=1.0)
     ctx.upload_experts([take])
     out = []
+    MALL = 256 << 20                           # Infinity Cache (MI355X_MICROARCH.md): inputs re-read from it are not an HBM measurement
     try:
         for n in sizes:
-            g = lambda *s: torch.randn(*s, dtype=dt, device=dev)
-            qpos, qvel, act, C = g(n, 59) * 0.3, g(n, 58), g(n, 52) * 0.3, g(n, 58)
-            qpos[:, 3:7] = torch.nn.functional.normalize(g(n, 4), dim=1)
-            prev = qpos + g(n, 59) * 0.01
-            qM = torch.as_tensor(qM0, device=dev).repeat(n, 1).contiguous()
-            ee = g(n, 15)
-            t = torch.randint(1, 100, (n,), dtype=torch.int32, device=dev)
-            frame = torch.randint(0, F, (n,), dtype=torch.int32, device=dev)
-            end = torch.zeros(n, dtype=torch.int32, device=dev)
-            obs = g(n, 115)
-            qM_dyn = torch.empty(n, sk.nM, dtype=dt, device=dev)
-            st0 = torch.zeros(231, dtype=dt, device=dev)
-            st1 = torch.empty_like(st0)
             ns = n * 200 // 8
-            rew, msk, val = torch.rand(ns, dtype=dt, device=dev), torch.ones(ns, dtype=dt, device=dev), g(ns)
+            # `rot` input / output sets, visited round-robin: a launch only finds its lines in the 256 MiB cache if the sets between
+            # two visits of the same set are smaller than the cache. Sized on the smallest per-env footprint (K4: 1 144 B).
+            rot = rotate if rotate is not None else max(1, min(16, -(-2 * MALL // (n * 1144))))
+
+            def make_set():
+                g = lambda *s: torch.randn(*s, dtype=dt, device=dev)
+                d = dict(qpos=g(n, 59) * 0.3, qvel=g(n, 58), act=g(n, 52) * 0.3, C=g(n, 58), ee=g(n, 15), obs=g(n, 115))
+                d["qpos"][:, 3:7] = torch.nn.functional.normalize(g(n, 4), dim=1)
+                d["prev"] = d["qpos"] + g(n, 59) * 0.01
+                d["t"] = torch.randint(1, 100, (n,), dtype=torch.int32, device=dev)
+                d["frame"] = torch.randint(0, F, (n,), dtype=torch.int32, device=dev)
+                d["end"] = torch.zeros(n, dtype=torch.int32, device=dev)
+                d["st0"] = torch.zeros(231, dtype=dt, device=dev)
+                d["st1"] = torch.empty_like(d["st0"])
+                d["rew"], d["msk"], d["val"] = torch.rand(ns, dtype=dt, device=dev), torch.ones(ns, dtype=dt, device=dev), g(ns)
+                return d
+            sets = [make_set() for _ in range(rot)]
+            big = {}                                           # the 7.3 kB-per-env inertia rows: allocated for the kernels that touch them only
+
+            def need_big(key):
+                if key not in big:
+                    big[key] = [torch.as_tensor(qM0, device=dev).repeat(n, 1).contiguous() if key == "qM" else
+                                torch.empty(n, sk.nM, dtype=dt, device=dev) for _ in range(max(1, min(rot, -(-2 * MALL // (n * 7280)))))]
+                return big[key]
+            turn = [0]
+
+            def nxt():
+                turn[0] += 1
+                return sets[turn[0] % rot], turn[0]
+            def k1():
+                d, i = nxt(); qm = need_big("qM"); return ctx.pd_torque(d["qpos"], d["qvel"], d["act"], qm[i % len(qm)], d["C"])
+            def k2():
+                d, _ = nxt(); return ctx.reward(d["qpos"], d["prev"], d["ee"], d["t"], d["frame"], d["end"], 0.0)
+            def k3():
+                d, _ = nxt(); return ctx.obs(d["qpos"], d["qvel"])
+            def k4():
+                d, _ = nxt(); return ctx.body_quat(d["qpos"])
+            def k6():
+                d, _ = nxt(); return ctx.zfilter(d["obs"], d["st0"], d["st1"], update=True)
+            def k5():
+                d, _ = nxt(); return ctx.gae(d["rew"], d["msk"], d["val"], 0.95, 0.95)
+            def k8():
+                d, i = nxt(); qo = need_big("qM_dyn"); return ctx.dynamics(d["qpos"], d["qvel"], want_xpos=True, qM_out=qo[i % len(qo)])
             cases = [
-                ("K1_pd_torque", lambda: ctx.pd_torque(qpos, qvel, act, qM, C), (910 + 58 + 52 + 58 + 52 + 52) * W, 1),
-                ("K2_reward", lambda: ctx.reward(qpos, prev, ee, t, frame, end, 0.0), (59 + 59 + 15 + 166 + 6) * W, 1),
-                ("K3_obs", lambda: ctx.obs(qpos, qvel), (59 + 58 + 115) * W, 1),
-                ("K4_body_quat", lambda: ctx.body_quat(qpos), (59 + 84) * W, 1),
-                ("K6_zfilter", lambda: ctx.zfilter(obs, st0, st1, update=True), (115 + 115) * W, 1),
-                ("K5_gae", lambda: ctx.gae(rew, msk, val, 0.95, 0.95), 5 * W, ns / n),
-                ("K8_dynamics", lambda: ctx.dynamics(qpos, qvel, want_xpos=True, qM_out=qM_dyn), (59 + 58 + 910 + 58 + 63) * W, 1),
+                ("K1_pd_torque", k1, (910 + 58 + 52 + 58 + 52 + 52) * W, 1),
+                ("K2_reward", k2, (59 + 59 + 15 + 166 + 6) * W, 1),
+                ("K3_obs", k3, (59 + 58 + 115) * W, 1),
+                ("K4_body_quat", k4, (59 + 84) * W, 1),
+                ("K6_zfilter", k6, (115 + 115) * W, 1),
+                ("K5_gae", k5, 5 * W, ns / n),
+                ("K8_dynamics", k8, (59 + 58 + 910 + 58 + 63) * W, 1),
             ]
             for name, fn, bytes_per_unit, units_per_env in cases:
                 if only and name not in only:          # (PMC passes profile one kernel at a time: tools/pmc_kernel.sh)
@@ -105,11 +137,16 @@ def kernel_microbench(sizes=(1024, 65536), device_index=0, variants=False, iters
                 for variant, sfx in todo:
                     if variant is not None:
                         ctx.set_pd_variant(variant)
-                    s = _time_launches(fn, iters=min(iters, 20) if variant == 1 else iters)
                     ab = bytes_per_unit * n * units_per_env
-                    out.append(dict(kernel=name + sfx, n=n, us=s * 1e6, alg_bytes=ab, GBps=ab / s / 1e9, frac_hbm=ab / s / HBM_PEAK))
+                    its = min(iters, 20) if (variant == 1 or ab > (1 << 30)) else iters
+                    s = _time_launches(fn, iters=its)
+                    sets_k = len(big.get("qM" if name == "K1_pd_torque" else "qM_dyn", [])) if name in ("K1_pd_torque", "K8_dynamics") else rot
+                    out.append(dict(kernel=name + sfx, n=n, us=s * 1e6, alg_bytes=ab, GBps=ab / s / 1e9, frac_hbm=ab / s / HBM_PEAK,
+                                    rotating_sets=sets_k, beyond_mall=bool(ab * sets_k > 1.5 * MALL)))
                 if name == "K1_pd_torque":
                     ctx.set_pd_variant(0)
+            del sets, big
+            torch.cuda.empty_cache()
     finally:
         ctx.close()
     return out

@@ -119,7 +119,7 @@ inline void assign_slices(Server &S, int n_threads, const int *active) {
     const bool deal = active && S.can_balance && S.substep_ns.load(std::memory_order_relaxed) >= S.balance_min_ns;
     if (!deal) {
         for (int sl = 0; sl < ns; ++sl) S.order[sl] = sl;
-        for (int t = 0; t <= n_threads; ++t) S.first[t] = K * t;
+        for (int t = 0; t <= n_threads; ++t) S.first[t] = std::min(K * t, ns);      // (fewer workgroups than threads: the last threads idle)
         return;
     }
     // longest-processing-time-first: slices by falling number of active envs, each to the least loaded thread (ties:
@@ -221,8 +221,9 @@ struct egp_engine {
     // waves' PCIe reads run in parallel: T_sample 102 -> 118 ms with every row mirrored, and erratic (100 .. 270 ms)
     // when only env-steps with few running envs used the mirror.
     bool bar_go = false;
-    bool server_ok = false;                   // resident-K1 mode allowed (EGP_SERVER, block budget)
-    bool server_dyn_ok = false;               // ... also with device dynamics (its 110 kB of LDS: one workgroup per CU)
+    bool server_ok = false;                   // resident-K1 mode allowed (EGP_SERVER, every workgroup of every group fits the chip at once)
+    int server_ke = 1;                        // envs a resident wave serves in turn per substep (1: k_pd_server_tree58; 2 / 4: ..._multi)
+    int server_cap = 0;                       // workgroups of that kernel the chip holds at once (probed, egp_pd_server_resident_blocks)
     // device-dynamics mode: qM / qfrc_bias come from K8 on the (qpos, qvel) rows the backend drains -- with the reference's timing
     // (ego_pose/envs/humanoid_v1.py:130-144 reads data.qM / data.qfrc_bias as the previous mj_step left them): the torque of a
     // substep is solved with M, C of the state the PREVIOUS substep started from; only a reset (sim.forward(),
@@ -450,7 +451,7 @@ void run_step(egp_engine *E, Group &G, int tid) {
 }
 
 inline bool server_mode(const egp_engine *E, const Group &G) {
-    return (!E->device_dynamics || E->server_dyn_ok) && E->server_ok && G.srv.n_slices > 0 && E->ctx->pd_variant == 0 && E->ctx->tree58;
+    return E->server_ok && G.srv.n_slices > 0 && E->ctx->pd_variant == 0 && E->ctx->tree58;
 }
 
 // Resident-K1 env-step: one launch of k_pd_server_tree58 serves all substeps. Every host thread owns a few slices
@@ -515,7 +516,7 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
                                       S.hd_go, base, FS, S.hd_err, 2.0, S.d_trace, E->hd_ee + (size_t)G.e0 * 15,
                                       E->d_qpos + (size_t)G.e0 * E->nq, E->d_prev_qpos + (size_t)G.e0 * E->nq,
                                       E->d_qvel + (size_t)G.e0 * E->nv, E->d_ee + (size_t)G.e0 * 15,
-                                      G.has_active ? G.hd_active + G.e0 : nullptr, E->device_dynamics);
+                                      G.has_active ? G.hd_active + G.e0 : nullptr, E->device_dynamics, E->server_ke);
         if (rc != EGP_OK) fail(G, rc, "K1 server launch", egp_last_error());
         if (G.prof_now) G_HIP(hipEventRecord(G.k_end[0], G.stream));
         G_HIP(hipEventRecord(G.done, G.stream));      // the kernel's epilogue moves the final state to HBM
@@ -773,6 +774,32 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
     E->groups = std::vector<Group>(E->n_groups);
     int total_server_blocks = 0;
     bool all_groups_sliced = true;
+    {
+        // The resident kernel's workgroups wait on the host, so ALL of them (every group's) must be on the chip at the same time: a
+        // workgroup that waits for a CU while its slice's owner waits for its torques stalls the env-step until another group's kernel
+        // ends (2 x 256 one-env workgroups on 256 CUs went as far as the kernel-side timeout in round 4). One 350-register workgroup
+        // fits a CU: 4 envs per CU with one env per wave (1 024 slots on 256 CUs). Beyond that -- more slots, or fewer CUs to be had
+        // (a CU mask, a co-tenant, a smaller part) -- a wave serves 2 or 4 envs in turn (k_pd_server_tree58_multi): the smallest
+        // count whose grid the chip holds, by the kernel's own residency probe. Device dynamics (110 kB of LDS per workgroup) has the
+        // one-env form only. EGP_SERVER_KE forces a count (tests), EGP_SERVER=0 the per-substep form.
+        const char *sv = getenv("EGP_SERVER");
+        const char *fk = getenv("EGP_SERVER_KE");
+        const bool usable = ctx->tree58 && ctx->pd_variant == 0 && !(sv && atoi(sv) == 0);
+        const int choices[3] = {1, 2, 4};
+        E->server_ke = 0;
+        for (int c = 0; c < 3 && usable && E->server_ke == 0; ++c) {
+            const int ke = choices[c];
+            if (fk && atoi(fk) != ke) continue;
+            if (E->device_dynamics && ke != 1) continue;
+            long blocks = 0;
+            for (int g = 0; g < E->n_groups; ++g) {
+                const long m = (long)E->n_env * (g + 1) / E->n_groups - (long)E->n_env * g / E->n_groups;
+                blocks += (m + 4 * ke - 1) / (4 * ke);
+            }
+            const int cap = egp_pd_server_resident_blocks(ctx->device, E->device_dynamics, ke);
+            if (blocks <= cap) { E->server_ke = ke; E->server_cap = cap; }
+        }
+    }
     for (int g = 0; g < E->n_groups; ++g) {
         Group &G = E->groups[g];
         G.e0 = (int)((long)E->n_env * g / E->n_groups);
@@ -800,15 +827,16 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
             E_TRY(hipHostGetDevicePointer(&p, G.h_flag, 0));
             G.hd_flag = (unsigned long long *)p;
         }
-        // resident K1: 8 slices per thread (fewer for small groups), whole 4-env blocks each
-        {
+        // resident K1: 8 slices per thread (fewer for small groups), whole workgroups (4 waves x server_ke envs) each
+        if (E->server_ke > 0) {
             Server &S = G.srv;
             const int m = G.e1 - G.e0;
-            const int nb = (m + 3) / 4;
+            const int bw = 4 * E->server_ke;
+            const int nb = (m + bw - 1) / bw;
             int per_thread = 8;
             while (per_thread > 1 && nb < per_thread * G.n_threads) per_thread /= 2;
-            const int ns = per_thread * G.n_threads;
-            if (nb >= ns) {
+            const int ns = std::min(per_thread * G.n_threads, nb);       // a slice is at least one workgroup
+            if (nb >= 1) {
                 S.n_slices = ns;
                 S.n_blocks = nb;
                 S.per_thread = per_thread;
@@ -819,8 +847,8 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
                 std::vector<int> block_slice(nb);
                 for (int sl = 0; sl < ns; ++sl) {
                     const int b0 = (int)((long)nb * sl / ns), b1 = (int)((long)nb * (sl + 1) / ns);
-                    S.e0[sl] = G.e0 + 4 * b0;
-                    S.e1[sl] = std::min(G.e1, G.e0 + 4 * b1);
+                    S.e0[sl] = G.e0 + bw * b0;
+                    S.e1[sl] = std::min(G.e1, G.e0 + bw * b1);
                     S.dirty[sl].store(0);
                     for (int b = b0; b < b1; ++b) block_slice[b] = sl;
                     for (int e = S.e0[sl]; e < S.e1[sl]; ++e) E->env_slice[e] = sl;
@@ -856,16 +884,8 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
             }
         }
     }
-    {
-        // The resident kernel's workgroups wait on the host, so ALL of them (every group's) must be resident at the same time: a
-        // workgroup that waits for a CU while its slice's owner waits for its torques stalls the env-step until another group's
-        // kernel ends -- with 2 x 256 workgroups on 256 CUs (2 048 slots in two groups; one 346-VGPR workgroup fits a CU) that
-        // went as far as the kernel-side timeout. The bound is what the occupancy calculator says the chip holds.
-        const char *sv = getenv("EGP_SERVER");
-        const int cap = egp_pd_server_resident_blocks(ctx->device, false), cap_dyn = egp_pd_server_resident_blocks(ctx->device, true);
-        E->server_ok = all_groups_sliced && total_server_blocks <= cap && !(sv && atoi(sv) == 0);
-        E->server_dyn_ok = total_server_blocks <= cap_dyn;
-    }
+    E->server_ok = E->server_ke > 0 && all_groups_sliced && total_server_blocks <= E->server_cap;
+    if (E->server_ke == 0) E->server_ke = 1;
 #undef E_TRY
     for (int g = 0; g < E->n_groups; ++g)
         for (int t = 0; t < E->groups[g].n_threads; ++t) E->groups[g].threads.emplace_back(thread_main, E, g, t);
@@ -1308,6 +1328,12 @@ int egp_engine_server_trace(egp_engine *E, int32_t group, int64_t *device_ticks,
 int egp_engine_substeps_per_launch(egp_engine *E) {
     if (!E || E->groups.empty()) return 0;
     return server_mode(E, E->groups[0]) ? E->frame_skip : 1;
+}
+
+int32_t egp_engine_envs_per_wave(egp_engine *E, int32_t *resident_capacity) {
+    if (resident_capacity) *resident_capacity = E ? E->server_cap : 0;
+    if (!E || E->groups.empty() || !server_mode(E, E->groups[0])) return 0;
+    return E->server_ke;
 }
 
 int32_t egp_engine_go_words_in_vram(egp_engine *E) {

@@ -21,6 +21,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <map>
+#include <mutex>
+
 #include "egp_internal.hpp"
 #include "egp_dynamics_dev.hpp"
 #include "egp_quat.hpp"
@@ -441,6 +445,7 @@ struct PdServe {
                                           // move no state, torque or epilogue rows (in a rollout's tail that is most of the PCIe traffic)
     const void *dyn;                      // DYN kernels: the egp_dyn::DynTables of the context (device)
     double *bias_dev;                     // DYN kernels: [n][nv] HBM bias rows -- with qM_dev what the env's last mj_step "left behind"
+    unsigned *probe;                      // residency probe (egp_pd_server_resident_blocks): count the workgroups on the chip at once and leave
     int row_contig;                       // qpos | qvel | bias are ONE row of nq + 2 nv doubles (the engine's state rows): read it as a
                                           // contiguous stream (see the substep loop)
 };
@@ -458,6 +463,27 @@ __device__ __forceinline__ unsigned long long scalar_poll_u64(const unsigned lon
 __device__ __forceinline__ double sys_load_f64(const double *p) {
     const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return __longlong_as_double((long long)u);
+}
+
+// Residency probe: every workgroup that gets a place on the chip counts itself in, holds that place until all gridDim.x are there
+// (probe[2] is raised) or `timeout_ticks` have passed, and counts itself out; probe[1] ends up as the largest head count any of them
+// saw = the workgroups of THIS kernel (its registers, its LDS) the chip really holds at once -- under a CU mask, next to a co-tenant,
+// on a part with CUs fused off -- where the occupancy calculator only knows the data sheet. The resident env-step needs that number.
+__device__ __forceinline__ void server_residency_probe(const PdServe &sv) {
+    if (threadIdx.x == 0) {
+        unsigned present = atomicAdd(sv.probe, 1u) + 1u, best = present;
+        const long long t0 = wall_clock64();
+        for (;;) {
+            if (present >= gridDim.x) { atomicExch(sv.probe + 2, 1u); break; }
+            if (__hip_atomic_load(sv.probe + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            if (wall_clock64() - t0 > sv.timeout_ticks) break;
+            __builtin_amdgcn_s_sleep(8);
+            present = __hip_atomic_load(sv.probe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            best = present > best ? present : best;
+        }
+        atomicMax(sv.probe + 1, best);
+        atomicSub(sv.probe, 1u);
+    }
 }
 
 // DYN (device_dynamics engines): the wave computes the inertia and the bias force itself from the (qpos, qvel) rows it reads
@@ -478,6 +504,7 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
     __shared__ double s_qM[4][PD_NM_MAX];
     __shared__ unsigned long long s_go[2];
     __shared__ int s_abort;
+    if (sv.probe) { server_residency_probe(sv); return; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long env = (long)blockIdx.x * 4 + wave;
     const bool valid = env < n;
@@ -683,6 +710,218 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
         }
         if (live) {
             // the row base of qpos: `qpos` points at the state rows' qpos column (offset 0 of the row)
+            if (lane < sv.nq) {
+                const long d = env * sv.nq + lane;
+                const double q = sys_load_f64(qpos + env * ld.qpos + lane);
+                sv.out_prev_qpos[d] = sv.out_qpos[d];
+                sv.out_qpos[d] = q;
+            }
+            if (lane < sv.nv) sv.out_qvel[env * sv.nv + lane] = sys_load_f64(qvel + env * ld.qvel + lane);
+            if (lane < 15) sv.out_ee[env * 15 + lane] = sys_load_f64(sv.ee_host + env * 15 + lane);
+        }
+    }
+}
+
+// KE envs per wavefront ("multi" form of the resident K1): the grid must fit the chip at once -- one 350-register workgroup per
+// CU -- so beyond 4 envs per CU (1 024 slots on 256 CUs), or when fewer CUs are to be had, a wave serves its KE envs in turn in
+// every substep. The wave's registers hold ONE env's factors while it eliminates; what the solves need is then kept in LDS in
+// place of the env's inertia row, in the same sparse layout: entry (K, r), r an ancestor of K, holds the multiplier of pivot K in
+// row r -- L[K][r] of M + Kd dt = L^T D L (the tree elimination's upper multipliers ARE Featherstone's L) -- and the diagonal
+// entry 1 / D_K. A solve is two sweeps over those 852 + 58 numbers: leaves -> root through L^T, scale, root -> leaves through L
+// (the one-env kernel keeps both triangles' multipliers in registers and needs one sweep: the two forms agree to rounding).
+// All state rows of the wave's envs are requested before the first solve, so their PCIe round trips overlap.
+template <int KE>
+__global__ __launch_bounds__(256) void k_pd_server_tree58_multi(DevModel m, PdLd ld, const double *qpos, const double *qvel,
+                                                                const double *__restrict__ action, const double *qM, const double *C,
+                                                                int n, double *torque, PdServe sv) {
+    extern __shared__ double s_fac[];                  // [4 waves][KE][PD_NM_MAX]
+    __shared__ short s_map[PD_NV * PD_NV];
+    __shared__ unsigned long long s_go[2];
+    __shared__ int s_abort;
+    if (sv.probe) { server_residency_probe(sv); return; }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long env0 = ((long)blockIdx.x * 4 + wave) * KE;
+    const int row = lane < PD_NV ? lane : PD_NV - 1;
+    const int act = row >= 6 ? row - 6 : 0;
+    const int slice = sv.block_slice[blockIdx.x];
+    bool live[KE];
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < KE; ++e) {
+        live[e] = env0 + e < n && (!sv.active || sv.active[env0 + e] != 0);
+        any = any || live[e];
+    }
+    if (__syncthreads_or(any ? 1 : 0) == 0) return;
+    const double c_kp = row >= 6 ? m.jkp[act] : 0.0, c_kd = row >= 6 ? m.jkd[act] : 0.0;
+    const double c_ref = m.a_ref[act], c_scale = m.a_scale[act], c_lim = m.torque_lim[act];
+    const double kd_dt = c_kd * m.sub_dt;
+    double target[KE];
+#pragma unroll
+    for (int e = 0; e < KE; ++e) target[e] = c_ref + (live[e] ? action[(env0 + e) * ld.action + act] : 0.0) * c_scale;
+    constexpr int QM_IT = PD_NM_MAX / 64;
+    for (int i = threadIdx.x; i < PD_NV * PD_NV; i += 256) s_map[i] = m.m_map[i];
+#pragma unroll
+    for (int e = 0; e < KE; ++e) {
+        double *F = s_fac + (size_t)(wave * KE + e) * PD_NM_MAX;
+        const double *src = qM + (env0 + e) * ld.qM;
+#pragma unroll
+        for (int k = 0; k < QM_IT; ++k) {
+            const int i = lane + 64 * k;
+            F[i] = (live[e] && i < m.nM) ? src[i] : 0.0;
+        }
+    }
+    if (threadIdx.x == 0) s_abort = 0;
+    const int tot = sv.nq + 2 * sv.nv;
+    for (int sub = 0; sub < sv.n_sub; ++sub) {
+        if (threadIdx.x == 0) {
+            const unsigned long long want = sv.base + (unsigned long long)sub;
+            const long long t0 = wall_clock64();
+            unsigned long long v;
+            for (;;) {
+                v = scalar_poll_u64(sv.go + slice * 8);
+                if ((v >> 1) >= want) break;
+                for (int z = 0; z < sv.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > sv.timeout_ticks) { s_abort = 1; break; }
+            }
+            s_go[sub & 1] = v;
+        }
+        __syncthreads();
+        if (s_abort) {
+            if (threadIdx.x == 0) __hip_atomic_store(sv.err, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        const bool refresh = (s_go[sub & 1] & 1ull) != 0ull;
+        if (m.action_torque) {                  // action_type 'torque' (humanoid_v1.py:170-172): the clipped control itself
+#pragma unroll
+            for (int e = 0; e < KE; ++e)
+                if (live[e] && lane < PD_NV && row >= 6)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(torque + (env0 + e) * m.nu + act),
+                                       (unsigned long long)__double_as_longlong(fmin(fmax(target[e], -c_lim), c_lim)), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+            continue;
+        }
+        // every live env's state row first (whole 64-byte lines when the row is contiguous: see k_pd_server_tree58)
+        double c0[KE], c1[KE], c2[KE];
+#pragma unroll
+        for (int e = 0; e < KE; ++e) {
+            c0[e] = c1[e] = c2[e] = 0.0;
+            if (!live[e]) continue;
+            const long env = env0 + e;
+            if (sv.row_contig) {
+                const double *rowp = qpos + env * ld.qpos;
+                if (lane < tot) c0[e] = sys_load_f64(rowp + lane);
+                if (64 + lane < tot) c1[e] = sys_load_f64(rowp + 64 + lane);
+                if (128 + lane < tot) c2[e] = sys_load_f64(rowp + 128 + lane);
+            } else {
+                c0[e] = sys_load_f64(qpos + env * ld.qpos + 7 + act);
+                c1[e] = sys_load_f64(qvel + env * ld.qvel + row);
+                c2[e] = sys_load_f64(C + env * ld.bias + row);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < KE; ++e) {
+            if (!live[e]) continue;             // (wave-uniform)
+            const long env = env0 + e;
+            double *F = s_fac + (size_t)(wave * KE + e) * PD_NM_MAX;
+            double r_q = c0[e], r_v = c1[e], r_c = c2[e];
+            if (sv.row_contig) {
+                auto pick = [&](int i) {
+                    const double a0 = __shfl(c0[e], i & 63), a1 = __shfl(c1[e], i & 63), a2 = __shfl(c2[e], i & 63);
+                    return i < 64 ? a0 : (i < 128 ? a1 : a2);
+                };
+                r_q = pick(7 + act);
+                r_v = pick(sv.nq + row);
+                r_c = pick(sv.nq + sv.nv + row);
+            }
+            if (refresh) {                      // this env's inertia row changed on the host: LDS and HBM copies
+                const double *src = sv.qM_host + env * ld.qM;
+                double *dst = sv.qM_dev + env * ld.qM;
+                double t_qM[QM_IT];
+#pragma unroll
+                for (int k = 0; k < QM_IT; ++k) {
+                    const int i = lane + 64 * k;
+                    t_qM[k] = i < m.nM ? sys_load_f64(src + i) : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < QM_IT; ++k) {
+                    const int i = lane + 64 * k;
+                    F[i] = t_qM[k];
+                    if (i < m.nM) dst[i] = t_qM[k];
+                }
+                egp_dyn::wave_sync();
+            }
+            if (sub == 0 || refresh) {
+                double a[PD_NV];
+                double dinv = 0.0;
+#pragma unroll
+                for (int j = 0; j < PD_NV; ++j) {
+                    const int id = s_map[row * PD_NV + j];
+                    const double v = id >= 0 ? F[id] : 0.0;
+                    a[j] = v + (j == row ? kd_dt : 0.0);
+                }
+                tree_factor<PD_NV - 1>(a, dinv, row);
+                egp_dyn::wave_sync();           // every lane has its row: the inertia entries may go
+#pragma unroll
+                for (int K = 0; K < PD_NV; ++K) {
+                    const int id = s_map[row * PD_NV + K];
+                    if (lane < PD_NV && K >= row && id >= 0) F[id] = K == row ? dinv : a[K];
+                }
+                egp_dyn::wave_sync();
+            }
+            const double eq = row >= 6 ? r_q - target[e] : 0.0;
+            double b = -r_c - c_kp * eq - c_kd * r_v;
+            double d_own = 0.0;
+            // L^T y = b: leaves -> root
+#pragma unroll
+            for (int K = PD_NV - 1; K >= 0; --K) {
+                const int id = s_map[row * PD_NV + K];
+                const double cf = id >= 0 ? F[id] : 0.0;
+                const double bk = readlane_f64(b, K);
+                if (K == row) d_own = cf;
+                b = K > row ? fma(-cf, bk, b) : b;
+            }
+            b *= d_own;
+            // L x = z: root -> leaves
+#pragma unroll
+            for (int J = 0; J < PD_NV; ++J) {
+                const int id = s_map[row * PD_NV + J];
+                const double cf = id >= 0 ? F[id] : 0.0;
+                const double xj = readlane_f64(b, J);
+                b = J < row ? fma(-cf, xj, b) : b;
+            }
+            if (lane < PD_NV && row >= 6) {
+                const double ev = r_v + b * m.sub_dt;
+                const double tau = -c_kp * eq - c_kd * ev;
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(torque + env * m.nu + act),
+                                   (unsigned long long)__double_as_longlong(fmin(fmax(tau, -c_lim), c_lim)), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    // epilogue (see k_pd_server_tree58): the final state of the wave's envs to HBM once the slice's last step is drained
+    {
+        const int slot = sv.n_sub & 1;
+        if (threadIdx.x == 0) {
+            const unsigned long long want = sv.base + (unsigned long long)sv.n_sub;
+            const long long t0 = wall_clock64();
+            unsigned long long v;
+            for (;;) {
+                v = scalar_poll_u64(sv.go + slice * 8);
+                if ((v >> 1) >= want) break;
+                for (int z = 0; z < sv.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > sv.timeout_ticks) { s_abort = 1; break; }
+            }
+            s_go[slot] = v;
+        }
+        __syncthreads();
+        if (s_abort) {
+            if (threadIdx.x == 0) __hip_atomic_store(sv.err, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < KE; ++e) {
+            if (!live[e]) continue;
+            const long env = env0 + e;
             if (lane < sv.nq) {
                 const long d = env * sv.nq + lane;
                 const double q = sys_load_f64(qpos + env * ld.qpos + lane);
@@ -1853,40 +2092,101 @@ size_t egp_pd_server_dyn_lds_bytes() {
     return ((sizeof(egp_dyn::DynTables) + 7) / 8 + 4 * (size_t)egp_dyn::DY_ENV_DOUBLES + 4 * 192) * sizeof(double);
 }
 
-// How many workgroups of the resident K1 the chip holds at once (the occupancy calculator's figure x the CUs): the engine runs the
-// resident form only when every workgroup of every group is resident at the same time -- they wait on the host, and a workgroup
-// that is not resident cannot answer its slice's go word. 0 when the kernel cannot run at all (device dynamics without its LDS).
-int egp_pd_server_resident_blocks(int device, bool device_dynamics) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    int per_cu = 0;
-    hipError_t e;
-    if (device_dynamics) {
-        const size_t lds = egp_pd_server_dyn_lds_bytes();
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pd_server_tree58<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            return 0;
-        }
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pd_server_tree58<true>, 256, lds);
-    } else {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pd_server_tree58<false>, 256, 0);
+namespace {
+// the resident K1's variants: (device dynamics, envs per wavefront) -> kernel, dynamic LDS
+struct ServerKernel { const void *fn; size_t lds; };
+ServerKernel server_kernel(bool device_dynamics, int ke) {
+    const size_t multi = (size_t)4 * ke * PD_NM_MAX * sizeof(double);
+    if (device_dynamics) return {ke == 1 ? reinterpret_cast<const void *>(&k_pd_server_tree58<true>) : nullptr, egp_pd_server_dyn_lds_bytes()};
+    switch (ke) {
+        case 1: return {reinterpret_cast<const void *>(&k_pd_server_tree58<false>), 0};
+        case 2: return {reinterpret_cast<const void *>(&k_pd_server_tree58_multi<2>), multi};
+        case 4: return {reinterpret_cast<const void *>(&k_pd_server_tree58_multi<4>), multi};
+        default: return {nullptr, 0};
     }
-    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
-    return per_cu * prop.multiProcessorCount;
+}
+int server_kernel_prepare(const ServerKernel &k) {
+    if (!k.fn) { set_error("no resident K1 for this (device dynamics, envs per wave) pair"); return EGP_E_INVALID; }
+    if (k.lds > 0) {
+        hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds);
+        if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipFuncSetAttribute(resident K1, %zu B of LDS): %s", k.lds, hipGetErrorString(e)); return EGP_E_HIP; }
+    }
+    return EGP_OK;
+}
+}  // namespace
+
+// How many workgroups of the resident K1 (variant: device dynamics, `envs_per_wave`) the chip holds at once: the engine runs the
+// resident form only when every workgroup of every group is resident at the same time -- they wait on the host, and a workgroup
+// that is not resident cannot answer its slice's go word. The occupancy calculator's figure x the CUs is the data sheet's answer;
+// the kernel itself, launched in probe mode (server_residency_probe), gives the one that holds on THIS device as this process
+// sees it (EGP_SERVER_PROBE=0: calculator only). 0 when the kernel cannot run at all. Cached per (device, variant).
+int egp_pd_server_resident_blocks(int device, bool device_dynamics, int envs_per_wave) {
+    static std::mutex mu;
+    static std::map<long, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    const long key = ((long)device << 8) | ((long)envs_per_wave << 1) | (device_dynamics ? 1 : 0);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int result = 0;
+    do {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); break; }
+        const ServerKernel k = server_kernel(device_dynamics, envs_per_wave);
+        if (!k.fn || server_kernel_prepare(k) != EGP_OK) break;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k.fn, 256, k.lds) != hipSuccess) { (void)hipGetLastError(); break; }
+        result = per_cu * prop.multiProcessorCount;
+        const char *pe = getenv("EGP_SERVER_PROBE");
+        if (result <= 0 || (pe && atoi(pe) == 0)) break;
+        unsigned *d_probe = nullptr;
+        if (hipMalloc((void **)&d_probe, 4 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); break; }
+        unsigned h[4] = {0, 0, 0, 0};
+        bool ok = hipMemset(d_probe, 0, sizeof(h)) == hipSuccess;
+        if (ok) {
+            PdServe sv{};
+            sv.probe = d_probe;
+            sv.timeout_ticks = 100000;           // 1 ms: a workgroup that is not on the chip by then is not resident
+            DevModel dm{};
+            PdLd ld{};
+            void *args[] = {&dm, &ld, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sv};
+            const double *np = nullptr; double *npw = nullptr; int nn = 0;
+            args[2] = &np; args[3] = &np; args[4] = &np; args[5] = &np; args[6] = &np; args[7] = &nn; args[8] = &npw;
+            ok = hipLaunchKernel(k.fn, dim3(result), dim3(256), args, k.lds, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+                 hipMemcpy(h, d_probe, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        (void)hipFree(d_probe);
+        if (!ok) { (void)hipGetLastError(); break; }
+        if ((int)h[1] > 0 && (int)h[1] < result) result = (int)h[1];
+    } while (false);
+    cache[key] = result;
+    return result;
 }
 
-// engine entry for the resident K1 (see k_pd_server_tree58); all flag arrays are device-visible addresses
+// engine entry for the resident K1 (see k_pd_server_tree58); all flag arrays are device-visible addresses. `envs_per_wave` = 1: the
+// one-env kernel (4 envs per workgroup); 2 / 4: k_pd_server_tree58_multi (block_slice then has one entry per 4 * envs_per_wave envs)
 int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const double *qvel, long ld_qvel, const double *bias,
                          long ld_bias, const double *qM, long ld_qM, const double *qM_host, const double *action, int32_t n,
                          double *torque, hipStream_t stream, const int *block_slice, const unsigned long long *go,
                          unsigned long long base, int n_sub, int *err, double timeout_s, long long *trace, const double *ee_host,
-                         double *out_qpos, double *out_prev_qpos, double *out_qvel, double *out_ee, const int *active, bool device_dynamics) {
+                         double *out_qpos, double *out_prev_qpos, double *out_qvel, double *out_ee, const int *active, bool device_dynamics,
+                         int envs_per_wave) {
     EGP_REQUIRE(ctx && ctx->tree58 && ctx->pd_variant == 0, "the K1 server needs the humanoid tree kernel");
     EGP_REQUIRE(!device_dynamics || ctx->dyn_tables, "device dynamics needs egp_set_dynamics_model on the context");
     EGP_REQUIRE(ee_host && out_qpos && out_prev_qpos && out_qvel && out_ee, "NULL epilogue pointer");
     EGP_REQUIRE(ctx->dm.nq <= 64 && ctx->dm.nv <= 64, "the epilogue moves one state row per wavefront");
     EGP_REQUIRE(qpos && qvel && bias && qM && qM_host && action && torque && block_slice && go && err, "NULL pointer");
     EGP_REQUIRE(n > 0 && n_sub > 0, "n and n_sub must be positive");
+    const ServerKernel k = server_kernel(device_dynamics, envs_per_wave);
+    EGP_REQUIRE(k.fn, "no resident K1 for this (device dynamics, envs per wave) pair");
+    {
+        static std::atomic<int> prepared[2][5];          // (the LDS attribute once per variant; egp_pd_server_resident_blocks set it already)
+        std::atomic<int> &pf = prepared[device_dynamics ? 1 : 0][envs_per_wave];
+        if (pf.load(std::memory_order_acquire) == 0) {
+            const int rc = server_kernel_prepare(k);
+            if (rc != EGP_OK) return rc;
+            pf.store(1, std::memory_order_release);
+        }
+    }
     PdLd ld{ld_qpos, ld_qvel, ctx->dm.nu, ld_qM, ld_bias};
     const int poll_sleep = 2;          // s_sleep(1) repeats between two polls of a go word
     const int nq = ctx->dm.nq, nv = ctx->dm.nv;
@@ -1895,15 +2195,16 @@ int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const d
                            ld_qvel == ld_bias && nq + 2 * nv <= 192 && ld_qpos >= nq + 2 * nv;
     PdServe sv{block_slice, go, base, n_sub, qM_host, const_cast<double *>(qM), err, (long long)(timeout_s * 100.0e6), trace,
                ee_host, out_qpos, out_prev_qpos, out_qvel, out_ee, nq, nv, poll_sleep, active, ctx->dyn_tables,
-               device_dynamics ? const_cast<double *>(bias) : nullptr, row_contig};
+               device_dynamics ? const_cast<double *>(bias) : nullptr, nullptr, row_contig};
+    const dim3 grid((n + 4 * envs_per_wave - 1) / (4 * envs_per_wave));
     if (device_dynamics) {
-        const size_t lds = egp_pd_server_dyn_lds_bytes();
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pd_server_tree58<true>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (attr != hipSuccess) { set_error("hipFuncSetAttribute(k_pd_server_tree58<true>, %zu B of LDS): %s", lds, hipGetErrorString(attr)); return EGP_E_HIP; }
-        k_pd_server_tree58<true><<<dim3((n + 3) / 4), dim3(256), lds, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, bias, n, torque, sv);
+        k_pd_server_tree58<true><<<grid, dim3(256), k.lds, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, bias, n, torque, sv);
+    } else if (envs_per_wave == 1) {
+        k_pd_server_tree58<false><<<grid, dim3(256), 0, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, bias, n, torque, sv);
+    } else if (envs_per_wave == 2) {
+        k_pd_server_tree58_multi<2><<<grid, dim3(256), k.lds, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, bias, n, torque, sv);
     } else {
-        k_pd_server_tree58<false><<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, bias, n, torque, sv);
+        k_pd_server_tree58_multi<4><<<grid, dim3(256), k.lds, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, bias, n, torque, sv);
     }
     return after_launch("k_pd_server_tree58");
 }

@@ -414,6 +414,18 @@ class RolloutEngine:
         """frame_skip when the resident K1 serves a whole env-step per launch, else 1."""
         return int(self.lib.egp_engine_substeps_per_launch(self.handle))
 
+    @property
+    def envs_per_wave(self):
+        """Envs a wavefront of the resident K1 serves in turn (1, 2 or 4; 0: per-substep form)."""
+        return int(self.lib.egp_engine_envs_per_wave(self.handle, None))
+
+    @property
+    def resident_capacity(self):
+        """Workgroups of the resident K1 the chip holds at once (the kernel's own residency probe at engine creation)."""
+        cap = C.c_int32(0)
+        self.lib.egp_engine_envs_per_wave(self.handle, C.byref(cap))
+        return int(cap.value)
+
     def reset(self, env_ids, qpos, qvel):
         import torch
         ids = _np_i32(env_ids)

@@ -659,6 +659,12 @@ int egp_debug_burn(int64_t us, int32_t blocks, float *sink, void *stream);
 /* substeps one K1 launch serves: frame_skip when the engine runs the resident K1 (one launch per env-step that
  * trades go/done words with the physics threads through pinned memory; EGP_SERVER=0 turns it off), else 1 */
 int egp_engine_substeps_per_launch(egp_engine *e);
+/* the resident K1's shape: envs a wavefront serves in turn per substep (1: four envs per workgroup, one per wave; 2 / 4 when the
+ * slots do not fit the chip that way -- more than 4 envs per CU, or fewer CUs to be had; EGP_SERVER_KE forces a count) and, in
+ * `resident_capacity` (may be NULL), how many workgroups of that kernel the chip holds at once as the kernel's own residency probe
+ * counted them at engine creation (the occupancy calculator's figure when EGP_SERVER_PROBE=0). The reference scales its sampler
+ * by the number of worker processes (agents/agent.py:93-100); this is the engine's counterpart. 0 = per-substep form. */
+int32_t egp_engine_envs_per_wave(egp_engine *e, int32_t *resident_capacity);
 /* where the resident K1's go words live: 1 = fine-grained device memory the host writes through the PCIe BAR (large-BAR systems),
  * 0 = pinned host memory the waves poll over PCIe, -1 = the engine does not run the resident K1 */
 int32_t egp_engine_go_words_in_vram(egp_engine *e);

@@ -372,7 +372,12 @@ ENGINE_MODES = {                     # env switches read by egp_engine_create ->
     "resident": ({}, 15),                                          # (go words in HBM, pushed by the host with fenced stores: the default)
     "resident-pinned-go": ({"EGP_BAR_GO": "0"}, 15),               # go words in pinned host memory, pulled by the waves
     "per-substep": ({"EGP_SERVER": "0"}, 1),                       # the fallback: one K1 launch per substep, completion flag polled
+    # a resident wave serving 2 / 4 envs in turn (k_pd_server_tree58_multi: what the engine takes when the slots do not fit the chip
+    # one env per wave -- more than 4 envs per CU, or fewer CUs to be had); forced here at sizes that would fit
+    "resident-2-per-wave": ({"EGP_SERVER_KE": "2"}, 15),
+    "resident-4-per-wave": ({"EGP_SERVER_KE": "4"}, 15),
 }
+ENGINE_KE = {"resident": 1, "resident-pinned-go": 1, "per-substep": 0, "resident-2-per-wave": 2, "resident-4-per-wave": 4}
 
 
 @pytest.mark.parametrize("mode", list(ENGINE_MODES))
@@ -392,7 +397,8 @@ def test_engine_step_matches_host_loop(ctx, skel, mode, monkeypatch):
     for n_groups, n_threads in [(1, 3), (2, 4)]:
         ph = SurrogatePhysics(skel, n)
         eng = RolloutEngine(ctx, ph, n, n_threads=n_threads, n_groups=n_groups)
-        assert eng.substeps_per_launch == ENGINE_MODES[mode][1]
+        assert eng.substeps_per_launch == ENGINE_MODES[mode][1] and eng.envs_per_wave == ENGINE_KE[mode]
+        assert eng.envs_per_wave == 0 or eng.resident_capacity >= 1
         eng.reset(np.arange(n), qpos0, qvel0)
         act_d = dev(action)
         torch.cuda.synchronize()
@@ -422,7 +428,7 @@ def test_engine_step_matches_host_loop(ctx, skel, mode, monkeypatch):
         ref.close()
 
 
-@pytest.mark.parametrize("mode", ["resident", "per-substep"])
+@pytest.mark.parametrize("mode", ["resident", "per-substep", "resident-2-per-wave"])
 def test_engine_step_with_torque_actions(skel, mode, monkeypatch):
     """cfg.action_type = 'torque' through the engine: every substep applies clip(a_ref + a * a_scale) (humanoid_v1.py:167-172),
     no PD solve -- against the host loop with the oracle's control law, in every mode of the substep loop."""
@@ -464,11 +470,13 @@ def test_engine_step_with_torque_actions(skel, mode, monkeypatch):
     ref.close()
 
 
-def test_resident_engine_dealt_slices_are_bit_identical(ctx, skel, monkeypatch):
+@pytest.mark.parametrize("ke", ["1", "4"])
+def test_resident_engine_dealt_slices_are_bit_identical(ctx, skel, monkeypatch, ke):
     """With an active mask the resident engine deals its slices out to the host threads per env-step once a substep of physics
     is expensive enough (2 us per env-substep; the free surrogate stays with fixed ownership): who steps an env changes, the
     env's numbers do not, and an inactive env is never touched."""
     from egopose_amd.physics import SurrogatePhysics, RolloutEngine
+    monkeypatch.setenv("EGP_SERVER_KE", ke)
     g = load_golden("body_quat_obs.npz")
     n = 203
     rng = np.random.RandomState(11)
@@ -556,7 +564,7 @@ def _changing_inertia_env_steps(eng, be, qpos0, qvel0, seed=4):
     return actions, eng.qpos.cpu().numpy(), [np.array(t) for t in be.torques]
 
 
-@pytest.mark.parametrize("mode", ["resident", "per-substep"])
+@pytest.mark.parametrize("mode", ["resident", "per-substep", "resident-2-per-wave"])
 def test_engine_changing_inertia_repeats_bit_identically(ctx, skel, mode, monkeypatch):
     """Stress of the inertia path's orderings (K1 once read inertia rows a reset's scatter kernel was still
     writing -- found by one flaky run): the reset / env-step / partial reset / env-step sequence 50 times on one engine, no host
@@ -689,7 +697,7 @@ def test_fused_policy_step_matches_the_reference_policy_vectors():
     np.testing.assert_allclose(act.cpu().numpy(), g["a"], rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("mode", ["resident", "per-substep"])
+@pytest.mark.parametrize("mode", ["resident", "per-substep", "resident-2-per-wave"])
 def test_engine_reports_backend_failure_instead_of_hanging(ctx, skel, mode, monkeypatch):
     """A physics callback that fails in the middle of an env-step: every engine mode must come back with an error
     (the resident K1 is drained through its go words, nothing is left spinning on the GPU), stay failed for further

@@ -490,19 +490,23 @@ def test_native_tick_is_bit_identical_to_the_torch_tick(workspace, monkeypatch, 
     assert abs(outs[("0", "1")]["r"] - outs[("0", "0")]["r"]) < 1e-6
 
 
-@pytest.mark.parametrize("server", ["1", "0"])
+@pytest.mark.parametrize("server", ["1", "0", "ke2"])
 def test_rollout_repeats_bit_identically_under_resets_on_every_tick(workspace, monkeypatch, server):
     """Stress of the concurrency the rollout depends on (a cross-stream race was once found by a single
     bit-equality run): 50 rollouts of 96 slots with 6-step episodes -- in-batch resets in nearly every tick of both groups, each
     with its scatter kernel on the caller's stream, the env-step kernel and the reward job on the group's stream, host threads
     re-arming torque rows -- from the same seed state on ONE engine, every one bit-identical to the first; resident and
     per-substep form of the env-step. The reward job is held back 30 us so that orderings that only hold by luck fail."""
-    monkeypatch.setenv("EGP_SERVER", server)
+    if server == "ke2":                                # a resident wave serving two envs in turn (k_pd_server_tree58_multi)
+        monkeypatch.setenv("EGP_SERVER_KE", "2")
+    else:
+        monkeypatch.setenv("EGP_SERVER", server)
     monkeypatch.setenv("EGP_REWARD_JOB_DELAY_US", "30")
     tr, cfg = _trainer(workspace, 96, 6, num_threads=4, num_groups=2)
     first = _seeded_sample(tr, 96 * 18)
     ro = tr.agent._get_rollout()
-    assert ro.engine.substeps_per_launch == (15 if server == "1" else 1)
+    assert ro.engine.substeps_per_launch == (1 if server == "0" else 15)
+    assert ro.engine.envs_per_wave == {"1": 1, "0": 0, "ke2": 2}[server]
     ends = np.where(first["masks"] == 0)[0]
     assert len(ends) >= 3 * 96 and ro.timing["ticks"] >= 18          # every slot restarted at least twice
     for rep in range(49):
@@ -652,6 +656,39 @@ def test_device_dynamics_rollout_replayed_by_oracle_env(workspace, skel, monkeyp
     _replay_episodes(tr, cfg, skel, batch, sample, 0.37, device_dynamics=True)
     with pytest.raises(AssertionError):
         _replay_episodes(tr, cfg, skel, batch, sample[:1], 0.37, device_dynamics=False)
+    tr.close()
+
+
+def test_2048_slots_take_the_resident_form_and_replay(tmp_path_factory, skel):
+    """More slots than the chip holds one-env waves for (2 048 > 4 x CUs): the engine keeps the resident env-step by letting a wave
+    serve 2 envs in turn (its own residency probe picks the count) instead of dropping to one launch per substep; a sample of the
+    episodes -- first / last slots of both groups, in-batch restarts -- replays on the oracle's CPU env."""
+    from egopose_amd.bench_support import write_synthetic_dataset
+    from egopose_amd.config import Config
+    from egopose_amd.physics import default_threads
+    from egopose_amd.train import Trainer
+    root = str(tmp_path_factory.mktemp("egp_2048"))
+    write_synthetic_dataset(root, "subject_03", n_takes=4, n_frames=600)
+    os.chdir(root)
+    cfg = Config("subject_03", create_dirs=False)
+    cfg.num_optim_epoch = 1
+    cfg.env_episode_len = 12
+    n_threads = max(2, default_threads(share=1, device_index=0))
+    tr = Trainer(cfg, torch.device("cuda", 0), torch.float32, num_envs=2048, num_threads=n_threads, num_groups=2)
+    tr.pre_iter_update(0)
+    tr.agent.running_state = None
+    tr.env.end_reward = 0.9
+    batch, log = tr.agent.sample(2048 * 20)
+    eng = tr.agent._get_rollout().engine
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert eng.substeps_per_launch == 15, "2 048 slots must keep the resident env-step"
+    assert eng.envs_per_wave >= 2 or cus * 4 >= 2048
+    assert 2048 // (4 * eng.envs_per_wave) <= eng.resident_capacity
+    ends = np.where(batch.masks == 0)[0]
+    n_ep = len(ends)
+    assert len(batch) >= 2048 * 20 and ends[-1] == len(batch) - 1
+    sample = sorted({0, 1, n_ep // 4, n_ep // 2 - 1, n_ep // 2, n_ep - 2, n_ep - 1})
+    _replay_episodes(tr, cfg, skel, batch, sample, 0.9)
     tr.close()
 
 

@@ -4,7 +4,9 @@ Prints one JSON line per (kernel, n): time per launch, algorithmic bytes (SURVEY
 achieved GB/s and fraction of the 8 TB/s HBM peak. (The measurement itself lives in
 egopose_amd/bench_support.py: bench.py reports the same table in its `kernels` block.)
 
-    python tools/microbench.py [n ...] [--only K2_reward[,K8_dynamics...]] [--no-variants]       default sizes: 1024 8192 65536
+    python tools/microbench.py [n ...] [--only K2_reward[,K8_dynamics...]] [--no-variants] [--rotate R]
+default sizes: 1024 8192 65536 1048576. Launches rotate over input sets so that nothing is re-read from the
+256 MiB Infinity Cache (`rotating_sets`, `beyond_mall` in every row); --rotate 1 = round 5's cache-resident figures.
 """
 import json
 import os
@@ -23,8 +25,13 @@ def main():
     if "--no-variants" in argv:
         argv.remove("--no-variants")
         variants = False
-    sizes = [int(s) for s in (argv or ["1024", "8192", "65536"])]
-    for row in kernel_microbench(sizes, variants=variants, only=only):
+    rotate = None
+    if "--rotate" in argv:
+        i = argv.index("--rotate")
+        rotate = int(argv[i + 1])
+        del argv[i:i + 2]
+    sizes = [int(s) for s in (argv or ["1024", "8192", "65536", "1048576"])]
+    for row in kernel_microbench(sizes, variants=variants, only=only, rotate=rotate):
         print(json.dumps(row))
 
 
