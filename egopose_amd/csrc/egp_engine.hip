@@ -91,6 +91,7 @@ struct Server {
     int n_slices = 0, n_blocks = 0, per_thread = 0;
     std::vector<int> e0, e1;                  // env range of each slice
     int *d_block_slice = nullptr;
+    int *d_block_env0 = nullptr;              // multi-env K1: [n_blocks + 1] first env of every workgroup, relative to the group's first
     unsigned long long *h_go = nullptr, *hd_go = nullptr;   // [n_slices * 8]
     bool go_in_vram = false;                  // the go words live in fine-grained device memory (host writes through the BAR)
     int *h_err = nullptr, *hd_err = nullptr;
@@ -224,6 +225,7 @@ struct egp_engine {
     bool server_ok = false;                   // resident-K1 mode allowed (EGP_SERVER, every workgroup of every group fits the chip at once)
     int server_ke = 1;                        // envs a resident wave serves in turn per substep (1: k_pd_server_tree58; 2 / 4: ..._multi)
     int server_cap = 0;                       // workgroups of that kernel the chip holds at once (probed, egp_pd_server_resident_blocks)
+    bool server_ke_forced = false;            // EGP_SERVER_KE (tests): workgroups packed full instead of the envs dealt out over the capacity
     // device-dynamics mode: qM / qfrc_bias come from K8 on the (qpos, qvel) rows the backend drains -- with the reference's timing
     // (ego_pose/envs/humanoid_v1.py:130-144 reads data.qM / data.qfrc_bias as the previous mj_step left them): the torque of a
     // substep is solved with M, C of the state the PREVIOUS substep started from; only a reset (sim.forward(),
@@ -516,7 +518,7 @@ void run_step_server(egp_engine *E, Group &G, int tid) {
                                       S.hd_go, base, FS, S.hd_err, 2.0, S.d_trace, E->hd_ee + (size_t)G.e0 * 15,
                                       E->d_qpos + (size_t)G.e0 * E->nq, E->d_prev_qpos + (size_t)G.e0 * E->nq,
                                       E->d_qvel + (size_t)G.e0 * E->nv, E->d_ee + (size_t)G.e0 * 15,
-                                      G.has_active ? G.hd_active + G.e0 : nullptr, E->device_dynamics, E->server_ke);
+                                      G.has_active ? G.hd_active + G.e0 : nullptr, E->device_dynamics, E->server_ke, S.d_block_env0, S.n_blocks);
         if (rc != EGP_OK) fail(G, rc, "K1 server launch", egp_last_error());
         if (G.prof_now) G_HIP(hipEventRecord(G.k_end[0], G.stream));
         G_HIP(hipEventRecord(G.done, G.stream));      // the kernel's epilogue moves the final state to HBM
@@ -790,6 +792,7 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
         for (int c = 0; c < 3 && usable && E->server_ke == 0; ++c) {
             const int ke = choices[c];
             if (fk && atoi(fk) != ke) continue;
+            E->server_ke_forced = fk != nullptr;
             if (E->device_dynamics && ke != 1) continue;
             long blocks = 0;
             for (int g = 0; g < E->n_groups; ++g) {
@@ -832,7 +835,16 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
             Server &S = G.srv;
             const int m = G.e1 - G.e0;
             const int bw = 4 * E->server_ke;
-            const int nb = (m + bw - 1) / bw;
+            // one env per wave: workgroup b has the envs 4 b .. 4 b + 3. Several: the group's share of the chip's capacity is used in
+            // full and the envs are dealt out evenly over it -- with 240 of 256 CUs to be had that is 4 or 5 envs per workgroup (one
+            // wave in five serves two envs), not 8 in half as many
+            int nb = (m + bw - 1) / bw;
+            if (E->server_ke > 1 && !E->server_ke_forced) {
+                const int share = (int)((long)E->server_cap * m / E->n_env);
+                nb = std::max(nb, std::min((m + 3) / 4, share));
+            }
+            std::vector<int> blk_e0(nb + 1);
+            for (int b = 0; b <= nb; ++b) blk_e0[b] = E->server_ke == 1 ? std::min(m, 4 * b) : (int)((long)m * b / nb);
             int per_thread = 8;
             while (per_thread > 1 && nb < per_thread * G.n_threads) per_thread /= 2;
             const int ns = std::min(per_thread * G.n_threads, nb);       // a slice is at least one workgroup
@@ -847,14 +859,16 @@ int egp_engine_create(egp_ctx *ctx, egp_physics *phys, const egp_engine_desc *d,
                 std::vector<int> block_slice(nb);
                 for (int sl = 0; sl < ns; ++sl) {
                     const int b0 = (int)((long)nb * sl / ns), b1 = (int)((long)nb * (sl + 1) / ns);
-                    S.e0[sl] = G.e0 + bw * b0;
-                    S.e1[sl] = std::min(G.e1, G.e0 + bw * b1);
+                    S.e0[sl] = G.e0 + blk_e0[b0];
+                    S.e1[sl] = G.e0 + blk_e0[b1];
                     S.dirty[sl].store(0);
                     for (int b = b0; b < b1; ++b) block_slice[b] = sl;
                     for (int e = S.e0[sl]; e < S.e1[sl]; ++e) E->env_slice[e] = sl;
                 }
                 E_TRY(hipMalloc((void **)&S.d_block_slice, nb * sizeof(int)));
                 E_TRY(hipMemcpy(S.d_block_slice, block_slice.data(), nb * sizeof(int), hipMemcpyHostToDevice));
+                E_TRY(hipMalloc((void **)&S.d_block_env0, (nb + 1) * sizeof(int)));
+                E_TRY(hipMemcpy(S.d_block_env0, blk_e0.data(), (nb + 1) * sizeof(int), hipMemcpyHostToDevice));
                 void *p = nullptr;
                 if (E->bar_go && hipExtMallocWithFlags(&p, (size_t)ns * 8 * sizeof(unsigned long long), hipDeviceMallocFinegrained) == hipSuccess && p) {
                     // go words next to the state mirror: written by the host through the BAR, polled by the waves in HBM
@@ -905,7 +919,7 @@ int egp_engine_destroy(egp_engine *E) {
             if (t.joinable()) t.join();
         {
             Server &S = G.srv;
-            void *dv[] = {S.d_block_slice, S.d_trace};
+            void *dv[] = {S.d_block_slice, S.d_block_env0, S.d_trace};
             for (void *p : dv) if (p) (void)hipFree(p);
             if (S.h_go) { if (S.go_in_vram) (void)hipFree(S.h_go); else (void)hipHostFree(S.h_go); }
             if (S.h_err) (void)hipHostFree(S.h_err);

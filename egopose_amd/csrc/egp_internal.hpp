@@ -85,7 +85,7 @@ int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const d
                          double *torque, hipStream_t stream, const int *block_slice, const unsigned long long *go,
                          unsigned long long base, int n_sub, int *err, double timeout_s, long long *trace, const double *ee_host,
                          double *out_qpos, double *out_prev_qpos, double *out_qvel, double *out_ee, const int *active, bool device_dynamics,
-                         int envs_per_wave = 1);
+                         int envs_per_wave = 1, const int *block_env0 = nullptr, int n_blocks = 0);
 size_t egp_pd_server_dyn_lds_bytes();
 int egp_pd_server_resident_blocks(int device, bool device_dynamics, int envs_per_wave = 1);
 int egp_launch_dynamics_strided(egp_ctx *ctx, const double *qpos, long ld_q, const double *qvel, long ld_v, int32_t n, double *qM,

@@ -446,6 +446,7 @@ struct PdServe {
     const void *dyn;                      // DYN kernels: the egp_dyn::DynTables of the context (device)
     double *bias_dev;                     // DYN kernels: [n][nv] HBM bias rows -- with qM_dev what the env's last mj_step "left behind"
     unsigned *probe;                      // residency probe (egp_pd_server_resident_blocks): count the workgroups on the chip at once and leave
+    const int *block_env0;                // multi-env kernels: [gridDim.x + 1] first env of every workgroup (the envs dealt out evenly)
     int row_contig;                       // qpos | qvel | bias are ONE row of nq + 2 nv doubles (the engine's state rows): read it as a
                                           // contiguous stream (see the substep loop)
 };
@@ -740,7 +741,10 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58_multi(DevModel m, PdLd
     __shared__ int s_abort;
     if (sv.probe) { server_residency_probe(sv); return; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long env0 = ((long)blockIdx.x * 4 + wave) * KE;
+    // the workgroup's envs [be0, be1) (at most 4 KE of them, dealt out evenly by the engine: with 4.5 envs per workgroup only every
+    // second workgroup has a wave that serves two); wave w takes be0 + w, be0 + w + 4, ...
+    const long be0 = sv.block_env0[blockIdx.x], be1 = sv.block_env0[blockIdx.x + 1];
+    const long env0 = be0 + wave;
     const int row = lane < PD_NV ? lane : PD_NV - 1;
     const int act = row >= 6 ? row - 6 : 0;
     const int slice = sv.block_slice[blockIdx.x];
@@ -748,7 +752,7 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58_multi(DevModel m, PdLd
     bool any = false;
 #pragma unroll
     for (int e = 0; e < KE; ++e) {
-        live[e] = env0 + e < n && (!sv.active || sv.active[env0 + e] != 0);
+        live[e] = env0 + 4 * e < be1 && env0 + 4 * e < n && (!sv.active || sv.active[env0 + 4 * e] != 0);
         any = any || live[e];
     }
     if (__syncthreads_or(any ? 1 : 0) == 0) return;
@@ -757,13 +761,13 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58_multi(DevModel m, PdLd
     const double kd_dt = c_kd * m.sub_dt;
     double target[KE];
 #pragma unroll
-    for (int e = 0; e < KE; ++e) target[e] = c_ref + (live[e] ? action[(env0 + e) * ld.action + act] : 0.0) * c_scale;
+    for (int e = 0; e < KE; ++e) target[e] = c_ref + (live[e] ? action[(env0 + 4 * e) * ld.action + act] : 0.0) * c_scale;
     constexpr int QM_IT = PD_NM_MAX / 64;
     for (int i = threadIdx.x; i < PD_NV * PD_NV; i += 256) s_map[i] = m.m_map[i];
 #pragma unroll
     for (int e = 0; e < KE; ++e) {
         double *F = s_fac + (size_t)(wave * KE + e) * PD_NM_MAX;
-        const double *src = qM + (env0 + e) * ld.qM;
+        const double *src = qM + (env0 + 4 * e) * ld.qM;
 #pragma unroll
         for (int k = 0; k < QM_IT; ++k) {
             const int i = lane + 64 * k;
@@ -772,6 +776,17 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58_multi(DevModel m, PdLd
     }
     if (threadIdx.x == 0) s_abort = 0;
     const int tot = sv.nq + 2 * sv.nv;
+    const bool tracer = sv.trace && blockIdx.x == 0 && threadIdx.x == 0;
+    // sparse index of entry (row, K) / (K, row) -- the same for every env -- or, where the tree has no such entry, a slot of the
+    // row's padding that stays zero (nM = 910 of PD_NM_MAX = 960 doubles)
+    constexpr int ZERO_SLOT = PD_NM_MAX - 1;
+    short idv[PD_NV];
+#pragma unroll
+    for (int K = 0; K < PD_NV; ++K) {
+        const short id = m.m_map[row * PD_NV + K];
+        idv[K] = id >= 0 ? id : (short)ZERO_SLOT;
+    }
+    const int id_diag = m.m_map[row * PD_NV + row];
     for (int sub = 0; sub < sv.n_sub; ++sub) {
         if (threadIdx.x == 0) {
             const unsigned long long want = sv.base + (unsigned long long)sub;
@@ -784,6 +799,7 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58_multi(DevModel m, PdLd
                 if (wall_clock64() - t0 > sv.timeout_ticks) { s_abort = 1; break; }
             }
             s_go[sub & 1] = v;
+            if (tracer) { sv.trace[sub * 8 + 0] = t0; sv.trace[sub * 8 + 1] = wall_clock64(); }
         }
         __syncthreads();
         if (s_abort) {
@@ -795,7 +811,7 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58_multi(DevModel m, PdLd
 #pragma unroll
             for (int e = 0; e < KE; ++e)
                 if (live[e] && lane < PD_NV && row >= 6)
-                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(torque + (env0 + e) * m.nu + act),
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(torque + (env0 + 4 * e) * m.nu + act),
                                        (unsigned long long)__double_as_longlong(fmin(fmax(target[e], -c_lim), c_lim)), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_SYSTEM);
             continue;
@@ -806,7 +822,7 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58_multi(DevModel m, PdLd
         for (int e = 0; e < KE; ++e) {
             c0[e] = c1[e] = c2[e] = 0.0;
             if (!live[e]) continue;
-            const long env = env0 + e;
+            const long env = env0 + 4 * e;
             if (sv.row_contig) {
                 const double *rowp = qpos + env * ld.qpos;
                 if (lane < tot) c0[e] = sys_load_f64(rowp + lane);
@@ -821,7 +837,7 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58_multi(DevModel m, PdLd
 #pragma unroll
         for (int e = 0; e < KE; ++e) {
             if (!live[e]) continue;             // (wave-uniform)
-            const long env = env0 + e;
+            const long env = env0 + 4 * e;
             double *F = s_fac + (size_t)(wave * KE + e) * PD_NM_MAX;
             double r_q = c0[e], r_v = c1[e], r_c = c2[e];
             if (sv.row_contig) {
@@ -870,25 +886,23 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58_multi(DevModel m, PdLd
             }
             const double eq = row >= 6 ? r_q - target[e] : 0.0;
             double b = -r_c - c_kp * eq - c_kd * r_v;
-            double d_own = 0.0;
-            // L^T y = b: leaves -> root
+            if (tracer && e == 0) sv.trace[sub * 8 + 2] = b != 12345.678 ? wall_clock64() : 0;     // (stamps of block 0: its first env, then its last)
+            // the lane's column of L for the sweep towards the root (entries (K, row), K a descendant), then its row for the sweep back
+            // (entries (row, K), K an ancestor): 58 reads in flight at once each time, the entries that do not exist (and the other
+            // sweep's) read a zero slot of the row's padding -- no select, no LDS round trip on the dependent chain readlane -> fma
+            // (with the reads and a K > row select inside the sweeps a solve took 13, then 4 us; now as the one-env kernel's: ~2)
+            double cf[PD_NV];
 #pragma unroll
-            for (int K = PD_NV - 1; K >= 0; --K) {
-                const int id = s_map[row * PD_NV + K];
-                const double cf = id >= 0 ? F[id] : 0.0;
-                const double bk = readlane_f64(b, K);
-                if (K == row) d_own = cf;
-                b = K > row ? fma(-cf, bk, b) : b;
-            }
+            for (int K = 0; K < PD_NV; ++K) cf[K] = F[K > row ? idv[K] : ZERO_SLOT];
+            const double d_own = F[id_diag];
+#pragma unroll
+            for (int K = PD_NV - 1; K >= 0; --K) b = fma(-cf[K], readlane_f64(b, K), b);      // L^T y = b: leaves -> root
             b *= d_own;
-            // L x = z: root -> leaves
 #pragma unroll
-            for (int J = 0; J < PD_NV; ++J) {
-                const int id = s_map[row * PD_NV + J];
-                const double cf = id >= 0 ? F[id] : 0.0;
-                const double xj = readlane_f64(b, J);
-                b = J < row ? fma(-cf, xj, b) : b;
-            }
+            for (int K = 0; K < PD_NV; ++K) cf[K] = F[K < row ? idv[K] : ZERO_SLOT];
+#pragma unroll
+            for (int J = 0; J < PD_NV; ++J) b = fma(-cf[J], readlane_f64(b, J), b);           // L x = z: root -> leaves
+            if (tracer && e == 0) sv.trace[sub * 8 + 3] = b != 12345.678 ? wall_clock64() : 0;
             if (lane < PD_NV && row >= 6) {
                 const double ev = r_v + b * m.sub_dt;
                 const double tau = -c_kp * eq - c_kd * ev;
@@ -896,6 +910,7 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58_multi(DevModel m, PdLd
                                    (unsigned long long)__double_as_longlong(fmin(fmax(tau, -c_lim), c_lim)), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            if (tracer) sv.trace[sub * 8 + (e == 0 ? 4 : 5)] = wall_clock64();
         }
     }
     // epilogue (see k_pd_server_tree58): the final state of the wave's envs to HBM once the slice's last step is drained
@@ -921,7 +936,7 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58_multi(DevModel m, PdLd
 #pragma unroll
         for (int e = 0; e < KE; ++e) {
             if (!live[e]) continue;
-            const long env = env0 + e;
+            const long env = env0 + 4 * e;
             if (lane < sv.nq) {
                 const long d = env * sv.nq + lane;
                 const double q = sys_load_f64(qpos + env * ld.qpos + lane);
@@ -2163,13 +2178,14 @@ int egp_pd_server_resident_blocks(int device, bool device_dynamics, int envs_per
 }
 
 // engine entry for the resident K1 (see k_pd_server_tree58); all flag arrays are device-visible addresses. `envs_per_wave` = 1: the
-// one-env kernel (4 envs per workgroup); 2 / 4: k_pd_server_tree58_multi (block_slice then has one entry per 4 * envs_per_wave envs)
+// one-env kernel (4 envs per workgroup); 2 / 4: k_pd_server_tree58_multi over `n_blocks` workgroups, workgroup b serving the envs
+// [block_env0[b], block_env0[b + 1]) (at most 4 * envs_per_wave; block_slice has one entry per workgroup)
 int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const double *qvel, long ld_qvel, const double *bias,
                          long ld_bias, const double *qM, long ld_qM, const double *qM_host, const double *action, int32_t n,
                          double *torque, hipStream_t stream, const int *block_slice, const unsigned long long *go,
                          unsigned long long base, int n_sub, int *err, double timeout_s, long long *trace, const double *ee_host,
                          double *out_qpos, double *out_prev_qpos, double *out_qvel, double *out_ee, const int *active, bool device_dynamics,
-                         int envs_per_wave) {
+                         int envs_per_wave, const int *block_env0, int n_blocks) {
     EGP_REQUIRE(ctx && ctx->tree58 && ctx->pd_variant == 0, "the K1 server needs the humanoid tree kernel");
     EGP_REQUIRE(!device_dynamics || ctx->dyn_tables, "device dynamics needs egp_set_dynamics_model on the context");
     EGP_REQUIRE(ee_host && out_qpos && out_prev_qpos && out_qvel && out_ee, "NULL epilogue pointer");
@@ -2178,6 +2194,7 @@ int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const d
     EGP_REQUIRE(n > 0 && n_sub > 0, "n and n_sub must be positive");
     const ServerKernel k = server_kernel(device_dynamics, envs_per_wave);
     EGP_REQUIRE(k.fn, "no resident K1 for this (device dynamics, envs per wave) pair");
+    EGP_REQUIRE(envs_per_wave == 1 || ctx->dm.nM < PD_NM_MAX, "the multi-env K1 keeps a zero slot behind the inertia row");
     {
         static std::atomic<int> prepared[2][5];          // (the LDS attribute once per variant; egp_pd_server_resident_blocks set it already)
         std::atomic<int> &pf = prepared[device_dynamics ? 1 : 0][envs_per_wave];
@@ -2195,8 +2212,9 @@ int egp_launch_pd_server(egp_ctx *ctx, const double *qpos, long ld_qpos, const d
                            ld_qvel == ld_bias && nq + 2 * nv <= 192 && ld_qpos >= nq + 2 * nv;
     PdServe sv{block_slice, go, base, n_sub, qM_host, const_cast<double *>(qM), err, (long long)(timeout_s * 100.0e6), trace,
                ee_host, out_qpos, out_prev_qpos, out_qvel, out_ee, nq, nv, poll_sleep, active, ctx->dyn_tables,
-               device_dynamics ? const_cast<double *>(bias) : nullptr, nullptr, row_contig};
-    const dim3 grid((n + 4 * envs_per_wave - 1) / (4 * envs_per_wave));
+               device_dynamics ? const_cast<double *>(bias) : nullptr, nullptr, block_env0, row_contig};
+    EGP_REQUIRE(envs_per_wave == 1 || (block_env0 && n_blocks > 0), "the multi-env K1 needs the workgroups' env ranges");
+    const dim3 grid(envs_per_wave == 1 ? (n + 3) / 4 : n_blocks);
     if (device_dynamics) {
         k_pd_server_tree58<true><<<grid, dim3(256), k.lds, stream>>>(ctx->dm, ld, qpos, qvel, action, qM, bias, n, torque, sv);
     } else if (envs_per_wave == 1) {

@@ -57,13 +57,15 @@ def main():
     print("device (block 0), us since kernel start:  poll | go seen | loaded | solved | stored")
     for s in range(fs):
         r = dev[s] - t0
-        print("  sub %2d  %8.2f %8.2f %8.2f %8.2f %8.2f   | wait %.2f load %.2f solve %.2f store %.2f" % (
-            s, r[0], r[1], r[2], r[3], r[4], r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3]))
+        print("  sub %2d  %8.2f %8.2f %8.2f %8.2f %8.2f   | wait %.2f load %.2f solve %.2f store %.2f%s" % (
+            s, r[0], r[1], r[2], r[3], r[4], r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3],
+            ("  then (last env of the wave stored / K8 + factors done) %.2f" % (r[5] - r[4])) if dev[s, 5] > 0 else ""))
     print("host (owner of slice 0), us since the step was posted:  wait start | first row in | go written")
     for s in range(fs):
         print("  sub %2d  %8.2f %8.2f %8.2f   | waited %.2f physics %.2f" % (s, host[s, 0], host[s, 1], host[s, 2], host[s, 1] - host[s, 0], host[s, 2] - host[s, 1]))
     print("leader, us since the step was posted: launch issued %.1f | own substeps done %.1f | all threads done %.1f | kernel done %.1f" % tuple(host[:4, 3]))
     print("per-thread finish (us since posted; each thread's own clock start):", [round(x) for x in host[4:, 3] if x > 0])
+    print("envs per wave", eng.envs_per_wave, "resident capacity", eng.resident_capacity)
     print("threads", eng.n_threads if hasattr(eng, "n_threads") else "?", "timing", eng.timing())
     eng.close(); ph.close(); ctx.close()
 
