@@ -1537,7 +1537,7 @@ __global__ __launch_bounds__(128) void k_zf_apply(ZfSrc<T> src, int n, int dim, 
 // Affine recurrence -> chunk summaries (P, A) -> block scan over chunks -> per-chunk replay.
 // (round 3: 8 samples per thread instead of 32 -- a workgroup then covers 2 048 samples and keeps 33 kB of LDS, so a 1.6 M-sample
 //  batch is 800 workgroups, four per CU, instead of 200 on 256 CUs, and the update's 135 k samples 66 instead of 17)
-constexpr int GAE_CHUNK = 8;
+constexpr int GAE_CHUNK = 4;
 
 template <typename T>
 __device__ __forceinline__ void gae_coeffs(const T *r, const T *mk, const T *v, int i, int n, double gamma, double gt,
@@ -1559,200 +1559,226 @@ __device__ __forceinline__ int gae_pad(int e) { return e + e / GAE_CHUNK; }     
 
 template <typename T>
 __device__ __forceinline__ void gae_stage(const T *__restrict__ r, const T *__restrict__ mk, const T *__restrict__ v, int n, double gamma,
-                                          double gt, double *s_d, double *s_c) {
-    const long base = (long)blockIdx.x * GAE_BLOCK_ELEMS;
-#pragma unroll 4
+                                          double gt, double *s_d, double *s_c, int tile) {
+    const long base = (long)tile * GAE_BLOCK_ELEMS;
+    double d[GAE_CHUNK], c[GAE_CHUNK];
+#pragma unroll
+    for (int j = 0; j < GAE_CHUNK; ++j) {                 // (every load of the thread in flight before the first LDS store)
+        const long i = base + j * 256 + threadIdx.x;
+        d[j] = 0.0; c[j] = 1.0;                           // (past the end: the identity map)
+        if (i < n) gae_coeffs<T>(r, mk, v, (int)i, n, gamma, gt, d[j], c[j]);
+    }
+#pragma unroll
     for (int j = 0; j < GAE_CHUNK; ++j) {
         const int e = j * 256 + threadIdx.x;
-        const long i = base + e;
-        double d = 0.0, c = 1.0;                          // (past the end: the identity map)
-        if (i < n) gae_coeffs<T>(r, mk, v, (int)i, n, gamma, gt, d, c);
-        s_d[gae_pad(e)] = d;
-        s_c[gae_pad(e)] = c;
+        s_d[gae_pad(e)] = d[j];
+        s_c[gae_pad(e)] = c[j];
     }
     __syncthreads();
 }
 
+// ONE pass over the batch (round 6; rounds 2-5: summary -> scan -> replay, which read r, mask, v twice and sent a (P, A) pair per
+// 8 samples through memory: 68 B per sample moved for 40 algorithmic). A workgroup = a tile of 2 048 consecutive samples:
+//   stage (delta, c) through LDS | compose the tile's 256 chunk maps (suffix scan in LDS) | PUBLISH the tile's map (P, A) |
+//   look RIGHT over the tiles after it, composing their published maps in order until the product of the P's is below 2^-200 (an
+//   episode end makes it exactly 0; 2 048 samples without one leave (gamma tau)^2048) or the batch ends: the carry entering the tile |
+//   replay the chunks with their carries, write adv / ret through LDS, Welford partial of the tile.
+// Nothing waits for another tile's RESULT, only for its map, which every tile publishes before it looks anywhere: the look-back is
+// short (one tile for every gamma tau < 0.93) and its association is fixed -- bit-reproducible, unlike the classic form that takes
+// whichever of (map, inclusive prefix) a predecessor has ready. No fences (a device-scope release writes back the XCD's L2 here,
+// docs/DESIGN_TRAIL.md): the two words of a map are their own flags -- the slots are armed with a NaN pattern no map contains
+// (one hipMemsetD32Async in front of the launch) and travel as relaxed agent-scope atomics. Tiles are handed out by a ticket, right
+// to left, so a tile only ever waits for tiles that started before it.
+constexpr unsigned GAE_ARM32 = 0x7FF8DEADu;                               // both halves of an armed 64-bit slot; the ticket starts there too
+constexpr unsigned long long GAE_ARM64 = ((unsigned long long)GAE_ARM32 << 32) | GAE_ARM32;
+
 template <typename T>
-__global__ __launch_bounds__(256) void k_gae_summary(const T *__restrict__ r, const T *__restrict__ mk,
-                                                     const T *__restrict__ v, int n, double gamma, double gt,
-                                                     double *__restrict__ chunkP, double *__restrict__ chunkA,
-                                                     double *__restrict__ blockP, double *__restrict__ blockA) {
+__global__ __launch_bounds__(256) void k_gae_onepass(const T *__restrict__ r, const T *__restrict__ mk, const T *__restrict__ v, int n,
+                                                     double gamma, double gt, unsigned long long *maps, unsigned *ticket,
+                                                     T *__restrict__ adv, T *__restrict__ ret, double *__restrict__ part) {
     extern __shared__ double s_gae[];
     double *s_d = s_gae, *s_c = s_gae + GAE_LDS_DOUBLES / 2;
-    __shared__ double sP[256], sA[256];
-    const int t = threadIdx.x, ch = blockIdx.x * blockDim.x + t;
-    const int i0 = ch * GAE_CHUNK;
-    gae_stage<T>(r, mk, v, n, gamma, gt, s_d, s_c);
-    double P = 1.0, A = 0.0;                              // (a chunk past the end: the identity map)
+    __shared__ double s_n[256], s_mean[256], s_m2[256];
+    __shared__ double s_bc;
+    const int t = threadIdx.x, nb = gridDim.x;
+    // Tiles right to left in workgroup-index order: a tile only waits for maps of workgroups with a LOWER index, and the dispatcher
+    // hands workgroups out in index order (round-robin over the XCDs, in order within each), so whoever it waits for is on the chip
+    // or done. (A ticket counter makes that independent of the dispatcher -- and cost 30 ns per workgroup, serialised on one
+    // address across eight L2s: 24 of the 36 us at 800 tiles, 390 us at 12 800.) The wait below is bounded all the same.
+    const int tile = nb - 1 - (int)blockIdx.x;
+    (void)ticket;
+    const int i0 = (tile * 256 + t) * GAE_CHUNK;
+    gae_stage<T>(r, mk, v, n, gamma, gt, s_d, s_c, tile);
+    double P = 1.0, A = 0.0;                              // this thread's chunk as a map of the carry entering it (past the end: identity)
     if (i0 < n) {
         const int i1 = min(n, i0 + GAE_CHUNK);
         for (int i = i1 - 1; i >= i0; --i) {
             const int e = gae_pad(t * GAE_CHUNK + (i - i0));
             const double d = s_d[e], c = s_c[e];
-            A = d + c * A;      // value at i given zero carry
-            P = c * P;          // sensitivity of a_i0 to the carry entering the chunk
-        }
-        chunkP[ch] = P;
-        chunkA[ch] = A;
-    }
-    // the block's 256 chunk maps composed in order (f_0 o f_1 o ... o f_255: the sweep runs right to left)
-    sP[t] = P; sA[t] = A;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        if ((t & (2 * off - 1)) == 0) {
-            sA[t] = sA[t] + sP[t] * sA[t + off];
-            sP[t] = sP[t] * sP[t + off];
-        }
-        __syncthreads();
-    }
-    if (t == 0) { blockP[blockIdx.x] = sP[0]; blockA[blockIdx.x] = sA[0]; }
-}
-
-// one block: carry[ch] = a at the first element of chunk ch+1 (0 for the last chunk)
-__global__ __launch_bounds__(1024) void k_gae_scan(int n_chunks, const double *__restrict__ chunkP,
-                                                   const double *__restrict__ chunkA, double *__restrict__ carry) {
-    __shared__ double sP[1024], sA[1024];
-    const int t = threadIdx.x;
-    const int per = (n_chunks + 1023) / 1024;
-    // thread t owns chunks [hi-per+1 .. hi] counted from the END of the array (reverse scan)
-    const int lo_rev = t * per;                       // index in reversed order
-    double P = 1.0, A = 0.0;                          // composition of own chunks, applied right-to-left
-    for (int k = 0; k < per; ++k) {
-        const int rev = lo_rev + k;
-        if (rev < n_chunks) {
-            const int ch = n_chunks - 1 - rev;
-            A = chunkA[ch] + chunkP[ch] * A;
-            P = chunkP[ch] * P;
+            A = d + c * A;
+            P = c * P;
         }
     }
-    sP[t] = P; sA[t] = A;
-    __syncthreads();
-    // inclusive Hillis-Steele scan of affine maps in reversed order: f_t o f_{t-1} o ... o f_0
-    for (int off = 1; off < 1024; off <<= 1) {
-        double pP = 1.0, pA = 0.0;
-        if (t >= off) { pP = sP[t - off]; pA = sA[t - off]; }
-        __syncthreads();
-        if (t >= off) {
-            const double nA = sA[t] + sP[t] * pA;   // apply earlier (pA) first, then own map
-            const double nP = sP[t] * pP;
-            sA[t] = nA; sP[t] = nP;
-        }
-        __syncthreads();
-    }
-    // carry entering thread t's first (right-most) chunk = value produced by threads < t
-    double cin = t > 0 ? sA[t - 1] : 0.0;
-    for (int k = 0; k < per; ++k) {
-        const int rev = lo_rev + k;
-        if (rev < n_chunks) {
-            const int ch = n_chunks - 1 - rev;
-            carry[ch] = cin;
-            cin = chunkA[ch] + chunkP[ch] * cin;
-        }
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_gae_replay(const T *__restrict__ r, const T *__restrict__ mk,
-                                                    const T *__restrict__ v, int n, double gamma, double gt,
-                                                    const double *__restrict__ chunkP, const double *__restrict__ chunkA,
-                                                    const double *__restrict__ block_carry, T *__restrict__ adv,
-                                                    T *__restrict__ ret, double *__restrict__ part) {
-    extern __shared__ double s_gae[];
-    double *s_d = s_gae, *s_c = s_gae + GAE_LDS_DOUBLES / 2;
-    __shared__ double s_n[256], s_mean[256], s_m2[256];
-    const int t = threadIdx.x, ch = blockIdx.x * blockDim.x + t;
-    const int i0 = ch * GAE_CHUNK;
-    gae_stage<T>(r, mk, v, n, gamma, gt, s_d, s_c);
-    // carry entering this thread's chunk = (f_{t+1} o ... o f_255)(carry entering the block): suffix scan of the chunk maps
-    // (s_n / s_mean double as the scan's P / A arrays; they are rewritten after the barrier below)
+    // suffix scan: (s_n, s_mean)[t] = f_t o f_{t+1} o ... o f_255 (the sweep runs right to left; the arrays are rewritten further down):
+    // inside a wave by shuffles, then the waves to its right folded in (two barriers instead of sixteen)
     {
-        const bool real = i0 < n;
-        s_n[t] = real ? chunkP[ch] : 1.0;
-        s_mean[t] = real ? chunkA[ch] : 0.0;
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            double pP = 1.0, pA = 0.0;
-            if (t + off < 256) { pP = s_n[t + off]; pA = s_mean[t + off]; }
-            __syncthreads();
-            if (t + off < 256) {
-                s_mean[t] = s_mean[t] + s_n[t] * pA;
-                s_n[t] = s_n[t] * pP;
+        const int lane = t & 63, w = t >> 6;
+        double sP_ = P, sA_ = A;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double pP = __shfl_down(sP_, off), pA = __shfl_down(sA_, off);
+            if (lane + off < 64) {
+                sA_ = sA_ + sP_ * pA;
+                sP_ = sP_ * pP;
             }
-            __syncthreads();
         }
+        if (lane == 0) { s_m2[w] = sP_; s_m2[4 + w] = sA_; }           // the wave's whole map
+        __syncthreads();
+        double rP = 1.0, rA = 0.0;                                     // waves w + 1 .. 3 composed left to right
+        for (int k = w + 1; k < 4; ++k) {
+            rA = rA + rP * s_m2[4 + k];
+            rP = rP * s_m2[k];
+        }
+        s_mean[t] = sA_ + sP_ * rA;
+        s_n[t] = sP_ * rP;
+        __syncthreads();
     }
-    const double bc = block_carry[blockIdx.x];
+    if (t == 0) {
+        __hip_atomic_store(maps + 2 * (size_t)tile, (unsigned long long)__double_as_longlong(s_n[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(maps + 2 * (size_t)tile + 1, (unsigned long long)__double_as_longlong(s_mean[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t < 64) {                                         // wave 0 looks right, 64 tiles per round, composing strictly in tile order
+        double Pacc = 1.0, Aacc = 0.0;
+        int next = tile + 1;
+        bool done = next >= nb;
+        const long long t_wait0 = wall_clock64();
+        while (!done) {
+            const int j = next + t;
+            unsigned long long pb = GAE_ARM64, ab = GAE_ARM64;
+            bool have = j >= nb;
+            if (!have) {
+                pb = __hip_atomic_load(maps + 2 * (size_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ab = __hip_atomic_load(maps + 2 * (size_t)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                have = pb != GAE_ARM64 && ab != GAE_ARM64;
+            }
+            const unsigned long long ok = __ballot(have);
+            const int avail = ok == ~0ull ? 64 : __ffsll((long long)~ok) - 1;      // the leading run of published tiles
+            for (int l = 0; l < avail && !done; ++l) {
+                if (next + l >= nb) { done = true; break; }
+                const double Pj = __longlong_as_double((long long)__shfl(pb, l)), Aj = __longlong_as_double((long long)__shfl(ab, l));
+                Aacc = Aacc + Pacc * Aj;
+                Pacc = Pacc * Pj;
+                if (fabs(Pacc) < 0x1p-200) done = true;
+            }
+            if (!done) {
+                next += avail;
+                done = next >= nb;
+                if (avail == 0) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (wall_clock64() - t_wait0 > 200000000ll) {      // 2 s without a neighbour's map: give up loudly (NaN), never hang
+                        Aacc = __longlong_as_double((long long)GAE_ARM64);
+                        done = true;
+                    }
+                }
+            }
+        }
+        if (t == 0) s_bc = Aacc;                          // a at the first sample of the next tile (0 behind the last tile)
+    }
+    __syncthreads();
+    const double bc = s_bc;
     const double carry_in = t < 255 ? s_mean[t + 1] + s_n[t + 1] * bc : bc;
     __syncthreads();
     double cnt = 0.0, mean = 0.0, m2 = 0.0;
     if (i0 < n) {
-        const int i1 = min(n, i0 + GAE_CHUNK);
-        double A = carry_in;
-        for (int i = i1 - 1; i >= i0; --i) {
-            const int e = gae_pad(t * GAE_CHUNK + (i - i0));
-            A = s_d[e] + s_c[e] * A;
-            s_d[e] = A;                                   // leaves through the coalesced pass below
-            const T a_out = (T)A;
-            cnt += 1.0;                                   // Welford on the stored (rounded) advantage
-            const double x = (double)a_out, dl = x - mean;
-            mean += dl / cnt;
-            m2 += dl * (x - mean);
+        const int len = min(n, i0 + GAE_CHUNK) - i0;
+        double a = carry_in, x[GAE_CHUNK], sum = 0.0;
+#pragma unroll
+        for (int k = GAE_CHUNK - 1; k >= 0; --k) {
+            x[k] = 0.0;
+            if (k < len) {
+                const int e = gae_pad(t * GAE_CHUNK + k);
+                a = s_d[e] + s_c[e] * a;
+                s_d[e] = a;                               // leaves through the coalesced pass below
+                x[k] = (double)(T)a;                      // statistics of the stored (rounded) advantage
+                sum += x[k];
+            }
         }
+        // the chunk's (n, mean, M2) by two passes over its registers (a Welford step per sample cost a float64 division each)
+        cnt = (double)len;
+        mean = len == GAE_CHUNK ? sum * (1.0 / GAE_CHUNK) : sum / cnt;
+#pragma unroll
+        for (int k = 0; k < GAE_CHUNK; ++k)
+            if (k < len) { const double dl = x[k] - mean; m2 = fma(dl, dl, m2); }
     }
     __syncthreads();
     {
-        const long base = (long)blockIdx.x * GAE_BLOCK_ELEMS;
+        const long base = (long)tile * GAE_BLOCK_ELEMS;
 #pragma unroll 4
         for (int j = 0; j < GAE_CHUNK; ++j) {
             const int e = j * 256 + t;
             const long i = base + e;
             if (i < n) {
-                const double A = s_d[gae_pad(e)];
-                adv[i] = (T)A;
-                ret[i] = (T)((double)v[i] + A);
+                const double a = s_d[gae_pad(e)];
+                adv[i] = (T)a;
+                ret[i] = (T)((double)v[i] + a);
             }
-        }
-    }
-    s_n[threadIdx.x] = cnt; s_mean[threadIdx.x] = mean; s_m2[threadIdx.x] = m2;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) {
-            const double na = s_n[threadIdx.x], nb = s_n[threadIdx.x + off];
-            if (nb > 0.0) {
-                const double tot = na + nb, d = s_mean[threadIdx.x + off] - s_mean[threadIdx.x];
-                s_m2[threadIdx.x] += s_m2[threadIdx.x + off] + d * d * (na * nb / tot);
-                s_mean[threadIdx.x] += d * (nb / tot);
-                s_n[threadIdx.x] = tot;
-            }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        part[blockIdx.x * 3 + 0] = s_n[0];
-        part[blockIdx.x * 3 + 1] = s_mean[0];
-        part[blockIdx.x * 3 + 2] = s_m2[0];
-    }
-}
-
-// stats = {n, mean, M2}: Chan merge of the block partials in a fixed order (deterministic): 256 threads take contiguous
-// runs of partials, then a tree over the threads (one thread walking 200 partials took 45 us of dependent divisions)
-__global__ __launch_bounds__(256) void k_gae_stats(int n_parts, const double *__restrict__ part, double *__restrict__ stats) {
-    __shared__ double s_n[256], s_mean[256], s_m2[256];
-    const int t = threadIdx.x, per = (n_parts + 255) / 256;
-    double cnt = 0.0, mean = 0.0, m2 = 0.0;
-    for (int p = t * per; p < min(n_parts, (t + 1) * per); ++p) {
-        const double nb = part[p * 3];
-        if (nb > 0.0) {
-            const double tot = cnt + nb, d = part[p * 3 + 1] - mean;
-            m2 += part[p * 3 + 2] + d * d * (cnt * nb / tot);
-            mean += d * (nb / tot);
-            cnt = tot;
         }
     }
     s_n[t] = cnt; s_mean[t] = mean; s_m2[t] = m2;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {            // neighbours first: the merge order follows the partials' order
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) {
+            const double na = s_n[t], nbb = s_n[t + off];
+            if (nbb > 0.0) {
+                const double tot = na + nbb, d = s_mean[t + off] - s_mean[t];
+                s_m2[t] += s_m2[t + off] + d * d * (na * nbb / tot);
+                s_mean[t] += d * (nbb / tot);
+                s_n[t] = tot;
+            }
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        part[tile * 3 + 0] = s_n[0];
+        part[tile * 3 + 1] = s_mean[0];
+        part[tile * 3 + 2] = s_m2[0];
+    }
+}
+
+constexpr int GAE_STATS_THREADS = 1024;
+// stats = {n, mean, M2}: Chan merge of the tile partials in a fixed order (deterministic): every thread its strided share, then a
+// tree over the threads (one thread walking 200 partials took 45 us of dependent divisions)
+__global__ __launch_bounds__(GAE_STATS_THREADS) void k_gae_stats(int n_parts, const double *__restrict__ part, double *__restrict__ stats) {
+    constexpr int NT = GAE_STATS_THREADS;
+    __shared__ double s_n[NT], s_mean[NT], s_m2[NT];
+    const int t = threadIdx.x;
+    double cnt = 0.0, mean = 0.0, m2 = 0.0;
+    // thread t merges the partials t, t + NT, t + 2 NT, ...: a wave's loads cover consecutive partials (contiguous runs per thread
+    // made every load instruction touch 64 cache lines, and the one CU this kernel runs on took 75 us over 25 600 partials), eight
+    // of a thread's partials in flight per round
+    for (int p0 = t; p0 < n_parts; p0 += 8 * NT) {
+        double pn[8], pm[8], ps[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = p0 + k * NT;
+            pn[k] = p < n_parts ? part[p * 3] : 0.0;
+            pm[k] = p < n_parts ? part[p * 3 + 1] : 0.0;
+            ps[k] = p < n_parts ? part[p * 3 + 2] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double nb = pn[k];
+            if (nb > 0.0) {
+                const double tot = cnt + nb, d = pm[k] - mean, w = nb / tot;      // (one division per merge)
+                m2 += ps[k] + d * d * (cnt * w);
+                mean += d * w;
+                cnt = tot;
+            }
+        }
+    }
+    s_n[t] = cnt; s_mean[t] = mean; s_m2[t] = m2;
+    __syncthreads();
+    for (int off = 1; off < NT; off <<= 1) {
         if ((t & (2 * off - 1)) == 0) {
             const double na = s_n[t], nb = s_n[t + off];
             if (nb > 0.0) {
@@ -2332,21 +2358,17 @@ static int launch_gae(const T *r, const T *mk, const T *v, int n, double gamma, 
     EGP_REQUIRE(n > 0, "n must be positive");
     const int n_chunks = (n + GAE_CHUNK - 1) / GAE_CHUNK;
     const int n_blocks = (n_chunks + 255) / 256;
-    // three levels: GAE_CHUNK-sample chunks (one thread each) -> blocks of 256 chunks (composed / scanned in LDS) -> ONE block over the
-    // block maps. (Two levels with one block scanning all chunks took 177 of 364 us at 1.6 M samples.)
-    double *chunkP = (double *)ws, *chunkA = chunkP + n_chunks, *part = chunkA + n_chunks, *blockP = part + 3 * n_blocks,
-           *blockA = blockP + n_blocks, *block_carry = blockA + n_blocks;
+    // workspace: [maps: 2 x n_blocks 64-bit slots][ticket + pad: one 64-bit slot][tile partials: 3 x n_blocks doubles]
+    unsigned long long *maps = (unsigned long long *)ws;
+    unsigned *ticket = (unsigned *)(maps + 2 * (size_t)n_blocks);
+    double *part = (double *)(maps + 2 * (size_t)n_blocks + 1);
     hipStream_t s = (hipStream_t)stream;
-    constexpr size_t lds = (size_t)GAE_LDS_DOUBLES * sizeof(double);          // the block's (delta, c) pairs, padded
-    static const hipError_t attr = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gae_summary<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gae_replay<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }();
-    if (attr != hipSuccess) { set_error("hipFuncSetAttribute(k_gae_*, %zu B of LDS): %s", lds, hipGetErrorString(attr)); return EGP_E_HIP; }
-    k_gae_summary<T><<<dim3(n_blocks), dim3(256), lds, s>>>(r, mk, v, n, gamma, gamma * tau, chunkP, chunkA, blockP, blockA);
-    k_gae_scan<<<dim3(1), dim3(1024), 0, s>>>(n_blocks, blockP, blockA, block_carry);
-    k_gae_replay<T><<<dim3(n_blocks), dim3(256), lds, s>>>(r, mk, v, n, gamma, gamma * tau, chunkP, chunkA, block_carry, adv, ret, part);
-    k_gae_stats<<<dim3(1), dim3(256), 0, s>>>(n_blocks, part, stats);
+    constexpr size_t lds = (size_t)GAE_LDS_DOUBLES * sizeof(double);          // the tile's (delta, c) pairs, padded
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gae_onepass<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) { set_error("hipFuncSetAttribute(k_gae_onepass, %zu B of LDS): %s", lds, hipGetErrorString(attr)); return EGP_E_HIP; }
+    EGP_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)maps, (int)GAE_ARM32, (size_t)(2 * (size_t)n_blocks + 1) * 2, s));     // arm the slots and the ticket
+    k_gae_onepass<T><<<dim3(n_blocks), dim3(256), lds, s>>>(r, mk, v, n, gamma, gamma * tau, maps, ticket, adv, ret, part);
+    k_gae_stats<<<dim3(1), dim3(GAE_STATS_THREADS), 0, s>>>(n_blocks, part, stats);
     return after_launch("k_gae_*");
 }
 
