@@ -1288,8 +1288,10 @@ __device__ __forceinline__ void zf_partial_body(const ZfSrc<T> &src, const int *
     __shared__ double s_mean[8][128], s_m2[8][128], s_cnt[8];
     const int G = blockDim.x >> 7, g = threadIdx.x >> 7, lc = threadIdx.x & 127;
     const int r0 = p * rows_per_tile, r1 = min(n, r0 + rows_per_tile);
-    const int per = ((rows_per_tile + G - 1) / G + 7) / 8 * 8;
-    const int g0 = r0 + g * per, g1 = min(r1, g0 + per);
+    // row group g takes the tile's 8-row chunks g, g + G, g + 2 G, ...: at any time the workgroup reads 8 G consecutive rows (with a
+    // contiguous share per group -- 256 rows each in a 2 048-row tile -- a workgroup kept 16 streams a quarter of a megabyte apart
+    // going; 64-row tiles, the rollout's, have one chunk per group either way: same partials bit for bit)
+    const int g0 = r0 + 8 * g, g1 = r1, g_step = 8 * G;
     double *out = ws + (long)p * (1 + 2 * dim);
     for (int cb = 0; cb < dim; cb += 128) {
         const int c = cb + lc;
@@ -1298,7 +1300,7 @@ __device__ __forceinline__ void zf_partial_body(const ZfSrc<T> &src, const int *
         //  out over the wave's lanes -- ZfSrc::load_rows / finish_rows, wave-uniform here: a wave is 64 columns of ONE row group;
         //  with src.at() per row the chunk was 8 dependent rounds of flag -> branch -> loads -> arithmetic)
         if (ROWS || c < dim)
-            for (int rb = g0; rb < g1; rb += 8) {
+            for (int rb = g0; rb < g1; rb += g_step) {
                 double v[8];
                 unsigned on = 0;          // bit i: row rb + i counts
                 int k = 0;
@@ -1325,6 +1327,8 @@ __device__ __forceinline__ void zf_partial_body(const ZfSrc<T> &src, const int *
                         }
                     }
                 } else {
+                    // (requesting the next chunk before this one's arithmetic was tried in round 6: the 1 024-thread workgroup's 128
+                    //  registers do not hold it -- 305 -> 400 us at 1 M rows, 16 -> 34 us at 1 024)
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int r = rb + i;
@@ -1515,6 +1519,29 @@ __global__ __launch_bounds__(128) void k_zf_apply(ZfSrc<T> src, int n, int dim, 
                     y[e] = (T)v;
                     if (y2) y2[e] = (T)v;
                 }
+            }
+        }
+        return;
+    }
+    if (src.x != nullptr && dim <= (int)blockDim.x && !write_mask) {
+        // a plain matrix, one column per thread, eight rows' loads in flight: no per-element division by `dim` (the flat loop below
+        // spent 64-bit e / dim and e % dim on every element: 603 us over 1 M rows of 115 where this form takes ~400)
+        const int c = threadIdx.x;
+        if (c >= dim) return;
+        const double mean = s_ms[c], inv = s_ms[dim + c];
+        const bool clamp = clip > 0.0 && !identity;
+        for (int rb = r0; rb < r1; rb += 8) {
+            double v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = rb + i < r1 ? (double)src.x[(long)(rb + i) * dim + c] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (rb + i >= r1) break;
+                double w = (v[i] - mean) * inv;
+                if (clamp) w = fmin(fmax(w, -clip), clip);
+                const long e = (long)(rb + i) * dim + c;
+                y[e] = (T)w;
+                if (y2) y2[e] = (T)w;
             }
         }
         return;
