@@ -189,7 +189,8 @@ def explain(args, world, eng, ro, t_sample, t_update, per_iter, iter_ms, iter_st
         "value_is": "env-steps of the K timed iterations / their wall time (bench contract); the median / min / max iteration beside it",
         "host_cgroup_throttled_events": (thr1[0] - thr0[0]) if (thr0 and thr1) else None,
         "host_cgroup_throttled_ms_all_threads": round((thr1[1] - thr0[1]) * 1e-3, 1) if (thr0 and thr1) else None,
-        "engine_substeps_per_launch": eng.substeps_per_launch,
+        "engine_substeps_per_launch": eng.substeps_per_launch, "engine_envs_per_wave": eng.envs_per_wave,
+        "engine_resident_capacity": eng.resident_capacity,
         "engine_go_words": {1: "vram(BAR)", 0: "pinned", -1: "n/a"}.get(int(eng.lib.egp_engine_go_words_in_vram(eng.handle)), "?"),
         "rollout_ticks": ro.timing.get("ticks"), "rollout_small_group_ticks": ro.timing.get("small_group_ticks"),
         "rollout_wait_s": round(ro.timing.get("wait", 0.0), 4), "rollout_setup_s": round(ro.timing.get("setup", 0.0), 4),
@@ -220,11 +221,12 @@ def explain(args, world, eng, ro, t_sample, t_update, per_iter, iter_ms, iter_st
 
 
 CONFIG_FIRST = ("workload", "env_steps_per_s_changing_inertia_device", "env_steps_per_s_changing_inertia_host_fed",
-                "env_steps_per_s_20us_substep", "frac_of_host_physics_ceiling_20us", "k1_avg_launch_us_device_dynamics",
+                "env_steps_per_s_20us_substep", "k1_avg_launch_us_device_dynamics",
                 "probe_go_rtt_us_p50", "probe_pcie_read_GBps", "probe_spin_gap_us_max", "host_loadavg_1m",
                 "t_sample_ms_median", "t_update_ms_median", "rollout_setup_prepared_ms", "env_steps_per_s_median_iteration",
-                "env_steps_per_s_min_iteration", "env_steps_per_s_max_iteration", "engine_substeps_per_launch", "envs_per_gpu",
-                "physics", "host_threads_per_gpu", "parallelism", "env_steps_per_s_2048_slots", "env_steps_per_s_4096_slots")
+                "env_steps_per_s_min_iteration", "env_steps_per_s_max_iteration", "env_steps_per_s_2048_slots",
+                "env_steps_per_s_4096_slots", "engine_substeps_per_launch", "engine_envs_per_wave", "physics", "host_threads_per_gpu",
+                "envs_per_gpu", "parallelism", "frac_of_host_physics_ceiling_20us")
 
 
 def order_config(cfg, legs):
@@ -326,7 +328,8 @@ def run_leg(make_trainer, steps, warmup, min_batch, every, env=None, default_dty
         out = {"env_steps_per_s": n_steps / elapsed, "rollout_only_env_steps_per_s": n_steps / max(t_sample, 1e-9),
                "steps": steps, "warmup": warmup, "t_sample_s": t_sample, "t_update_s": t_update, "per_iteration_ms_sample_update": per_iter,
                "indicative": bool(steps < 3 or warmup < 2),      # fewer iterations than that is a smoke run, not a measurement
-               "substeps_per_launch": eng.substeps_per_launch, "device_dynamics": bool(getattr(eng, "device_dynamics", False)),
+               "substeps_per_launch": eng.substeps_per_launch, "envs_per_wave": eng.envs_per_wave,
+               "device_dynamics": bool(getattr(eng, "device_dynamics", False)),
                "inertia_uploads": int(eng.lib.egp_engine_inertia_uploads(eng.handle))}
         if tim["k1_launches"] > 0:
             out["k1_avg_launch_us"] = tim["k1_ms"] * 1e3 / tim["k1_launches"]
@@ -560,9 +563,9 @@ def main():
             legs["step_budget_global"] = run_leg(mk32, args.leg_steps, lw, min_batch, ev, {"EGP_STEP_BUDGET": "global"})
             # more env slots on the one GPU, same physics, the batch scaled with the slots (each slot keeps its 48-step quota): how far
             # the fixed latencies of a tick amortise -- the basis of the weak-scaling claim (1 024 slots = the headline; the resident
-            # K1 serves up to 2 048 slots, beyond that the engine launches per substep)
+            # K1 serves them all: beyond 4 envs per CU a wave serves 2 or 4 envs in turn)
             sweep = {}
-            for n_slots, n_groups in ((512, args.groups), (2048, args.groups), (2048, 2 * args.groups), (4096, 2 * args.groups)):
+            for n_slots, n_groups in ((512, args.groups), (2048, args.groups), (4096, args.groups), (4096, 2 * args.groups)):
                 mkn = lambda n_slots=n_slots, n_groups=n_groups: Trainer(cfg_cls(args.cfg, create_dirs=False), dev, torch.float32, num_envs=n_slots,
                                                                          num_threads=n_threads, num_groups=n_groups)
                 r = run_leg(mkn, args.leg_steps, lw, min_batch * n_slots // args.envs, ev)
@@ -573,7 +576,8 @@ def main():
                     sweep[key] = {"env_steps_per_s": r["env_steps_per_s"], "rollout_only_env_steps_per_s": r["rollout_only_env_steps_per_s"],
                                   "ms_sample_update": [round(1e3 * r["t_sample_s"] / r["steps"], 1), round(1e3 * r["t_update_s"] / r["steps"], 1)],
                                   "ms_sample_update_per_iteration": r.get("per_iteration_ms_sample_update"), "steps": r["steps"], "warmup": r["warmup"],
-                                  "env_steps_per_iteration": r["env_steps_per_iteration"], "substeps_per_launch": r["substeps_per_launch"]}
+                                  "env_steps_per_iteration": r["env_steps_per_iteration"], "substeps_per_launch": r["substeps_per_launch"],
+                                  "envs_per_wave": r.get("envs_per_wave")}
             legs["envs_per_gpu_sweep"] = {k: json.dumps(v) for k, v in sweep.items()}
             # BASELINE config 4: the state regressor's optimisation step (ResNet-18 encoder in bf16 on the matrix cores)
             try:
