@@ -199,15 +199,17 @@ class Agent:
             reward_id = getattr(self.env.cfg, "reward_id", "quat_v3")
             # custom_reward=None (agents/agent.py:53-58): the batch trains on the ENV's reward (HumanoidEnv.step returns 1.0 per
             # step, humanoid_v1.py:188) and the logger sees c_reward = 0, c_info = [0] -- kind 'env', never a silent quat_v3
-            kind = "env" if self.custom_reward is None else getattr(self.custom_reward, "egp_kernel", None)
-            if kind not in ("env", "quat_v3", "constant", "pose_dist"):
-                raise NotImplementedError("custom_reward %r has no HIP kernel (the registry's quat_v3 / constant / pose_dist "
-                                          "do; reward_id=%s)" % (self.custom_reward, reward_id))
+            # a callable without a kernel (anything but the registry's three): the reference's plug point as it is -- evaluated on the
+            # host per stepped slot through env.SlotView, kind 'callable' (slow by construction; the registry's rewards never go there)
+            kind = "env" if self.custom_reward is None else getattr(self.custom_reward, "egp_kernel", "callable")
+            if kind not in ("env", "quat_v3", "constant", "pose_dist", "callable") or (kind == "callable" and not callable(self.custom_reward)):
+                raise NotImplementedError("custom_reward %r: unknown kernel tag %r (reward_id=%s)" % (self.custom_reward, kind, reward_id))
             n_threads = None if self.num_threads in (None, 0) else int(self.num_threads)
             sim = self.env.batched(self.num_envs, idx, n_threads=n_threads, n_groups=self.num_groups)
             seed = int(getattr(self.env.cfg, "seed", 0)) * 1000 + D.rank()
             self._rollout = LockstepRollout(sim, self.cn.policy_net, self._video_net(), self.running_state, seed=seed)
             self._rollout.reward_kind = kind
+            self._rollout.custom_reward = self.custom_reward if kind == "callable" else None
         return self._rollout
 
     def sample(self, min_batch_size):

@@ -64,6 +64,65 @@ class BatchedSim:
         self.ctx.close()
 
 
+class SlotView:
+    """ONE slot of the lockstep rollout behind HumanoidEnv's attribute surface, for a `custom_reward` callable that has no kernel
+    (agents/agent.py:53-54 calls `custom_reward(self.env, state, action, info)`; the registry's three rewards have kernels and
+    never come here). Host copies of the slot's drained state, what the reference's reward functions read: `cfg`, `dt`,
+    `end_reward`, `cur_t`, `start_ind`, `expert_ind`, `expert`, `data.qpos / qvel`, `prev_qpos`, `bquat`, `prev_bquat`,
+    `get_expert_index`, `get_expert_attr`, `get_ee_pos`, `get_body_quat`, `get_pose_dist`, `get_pose_diff`
+    (ego_pose/envs/humanoid_v1.py:98-125,256-287; ego_pose/core/reward_function.py:4-75). A slow path by construction: one
+    Python call per stepped slot and tick."""
+
+    def __init__(self, env):
+        self._env = env
+        self.cfg, self.model, self.skel, self.frame_skip = env.cfg, env.model, env.skel, env.frame_skip
+        self.body_qposaddr = env.body_qposaddr
+        self.expert_arr, self.expert_list = env.expert_arr, env.expert_list
+        self.cur_t = self.start_ind = self.expert_ind = 0
+        self.expert = None
+        self.data = types.SimpleNamespace(qpos=None, qvel=None)
+        self.prev_qpos = self.bquat = self.prev_bquat = self._ee_w = None
+
+    dt = property(lambda self: self._env.dt)
+    end_reward = property(lambda self: self._env.end_reward)
+
+    def load(self, cur_t, start_ind, expert_ind, qpos, qvel, prev_qpos, bquat, prev_bquat, ee_w):
+        self.cur_t, self.start_ind, self.expert_ind = int(cur_t), int(start_ind), int(expert_ind)
+        self.expert = self.expert_arr[self.expert_ind]
+        self.data.qpos, self.data.qvel = qpos, qvel
+        self.prev_qpos, self.bquat, self.prev_bquat, self._ee_w = prev_qpos, bquat, prev_bquat, ee_w
+        return self
+
+    def get_expert_index(self, t):
+        return self.start_ind + t
+
+    def get_expert_attr(self, attr, ind):
+        return self.expert[attr][ind, :]
+
+    def get_body_quat(self):
+        return self.bquat
+
+    def get_ee_pos(self, transform):
+        from .metrics import _heading_q, _rot_matrix
+        w = np.asarray(self._ee_w, float).reshape(-1, 3)
+        if transform is None:
+            return w.ravel()
+        q = self.data.qpos
+        if transform == "root":
+            R = _rot_matrix(q[3:7])
+        elif transform == "heading":
+            R = _rot_matrix(_heading_q(q[3:7]))
+        else:
+            raise AssertionError("unknown transform %r" % (transform,))
+        return ((w - q[:3]) @ R).ravel()
+
+    def get_pose_diff(self):
+        return np.abs((self.expert["qpos"][self.get_expert_index(self.cur_t), :] - self.data.qpos)[2:])
+
+    def get_pose_dist(self):
+        return np.linalg.norm((self.expert["qpos"][self.get_expert_index(self.cur_t), :] - self.data.qpos)[2:])
+
+
 class HumanoidEnv:
 
     def __init__(self, cfg):

@@ -150,6 +150,7 @@ class LockstepRollout:
         self._graphs = None                 # per group: captured hipGraph of the policy step
         self._graph_key = None
         self.reward_kind = "quat_v3"        # which entry of the reward registry the rollout evaluates (Agent sets it)
+        self.custom_reward = None           # reward_kind 'callable': the caller's function, evaluated on the host per slot (env.SlotView)
         self.pool_batch = max(256, self.N // 2)
         self._pool, self._pool_pos = None, 0
         self._reset_scratch = None
@@ -345,7 +346,7 @@ class LockstepRollout:
         rs = getattr(self.running_state, "rs", None)      # the set-up uploads the filter's CONTENTS and runs its first pass: an in-place
         rs_sig = None if rs is None else (int(rs._n), float(np.sum(rs._M)), float(np.sum(rs._S)))       # restore / merge makes it stale
         return (int(min_batch_size), float(end_reward), bool(self.mean_action), bool(self.noise_rate >= 1.0), float(self.cfg.env_init_noise),
-                id(self.running_state), rs_sig, self.reward_kind, getattr(self, "step_budget", None) or os.environ.get("EGP_STEP_BUDGET", "slot"),
+                id(self.running_state), rs_sig, self.reward_kind, id(self.custom_reward), getattr(self, "step_budget", None) or os.environ.get("EGP_STEP_BUDGET", "slot"),
                 getattr(self.env, "fix_len", None), getattr(self.env, "fix_head_lb", None), id(getattr(self.env, "expert_arr", None)),
                 tuple((p.data_ptr(), p._version) for p in nets))
 
@@ -433,7 +434,11 @@ class LockstepRollout:
         f64 = torch.float64
         # reward_kind 'env' (custom_reward=None, agents/agent.py:56-58): the batch's reward is env_reward = 1.0 per step
         # (humanoid_v1.py:188) -- the registry's constant kernel writes exactly that -- and the logger's c_reward / c_info are 0
-        reward_kernel = "constant" if self.reward_kind == "env" else self.reward_kind
+        reward_kernel = "constant" if self.reward_kind in ("env", "callable") else self.reward_kind
+        slot_view = None
+        if self.reward_kind == "callable":
+            from .env import SlotView
+            slot_view = SlotView(self.env)
         # time-major record in HBM. rec["states"][k] IS the policy input of tick k: the filtered observation of
         # tick k-1 is written straight into row k (and into next_states[k-1]) by the fused kernel.
         rec = dict(
@@ -581,8 +586,30 @@ class LockstepRollout:
                 host["t0"][k, a:b] = self.t0[a:b]
             # K3+K6: filtered next observation -> next_states[k] and the policy input of tick k+1;  K2: reward
             self._obs_filter(a, b, rec["next_states"][k, a:b], rec["states"][k + 1, a:b], active=fl[3], phase_t=fl[0])
-            ctx.reward(eng.qpos[a:b], eng.prev_qpos[a:b], eng.ee_wpos[a:b], fl[0], fl[1], fl[2], end_reward, active=fl[3],
-                       reward_out=rec["rewards"][k, a:b], cinfo_out=rec["cinfo"][k, a:b], kind=reward_kernel)
+            if slot_view is None:
+                ctx.reward(eng.qpos[a:b], eng.prev_qpos[a:b], eng.ee_wpos[a:b], fl[0], fl[1], fl[2], end_reward, active=fl[3],
+                           reward_out=rec["rewards"][k, a:b], cinfo_out=rec["cinfo"][k, a:b], kind=reward_kernel)
+            else:
+                # custom_reward(env, state, action, info) (agents/agent.py:53-54) for every stepped slot, on host copies
+                q_h, v_h = eng.qpos.cpu().numpy()[a:b], eng.qvel.cpu().numpy()[a:b]
+                pq_h = eng.prev_qpos[a:b].cpu().numpy()
+                bq_h, pbq_h = ctx.body_quat(eng.qpos[a:b]).cpu().numpy(), ctx.body_quat(eng.prev_qpos[a:b]).cpu().numpy()
+                ee_h = eng.ee_wpos[a:b].cpu().numpy()
+                st_h, ac_h = rec["states"][k, a:b].cpu().numpy(), rec["actions"][k, a:b].cpu().numpy()
+                r_h = np.zeros(b - a)
+                ci_h = None
+                for i in np.nonzero(act_g)[0]:
+                    slot_view.load(self.cur_t[a + i], self.s_ind[a + i], self.e_ind[a + i], q_h[i], v_h[i], pq_h[i], bq_h[i], pbq_h[i], ee_h[i])
+                    r_i, c_i = self.custom_reward(slot_view, st_h[i], ac_h[i], {"fail": bool(fail[i]), "end": bool(end[i])})
+                    c_i = np.atleast_1d(np.asarray(c_i, float))
+                    if ci_h is None:
+                        ci_h = np.zeros((b - a, c_i.shape[0]))
+                    r_h[i], ci_h[i] = float(r_i), c_i
+                if ci_h is not None:
+                    if rec["cinfo"].shape[2] != ci_h.shape[1]:          # (the callable's c_info width is only known now)
+                        rec["cinfo"] = torch.zeros(T_max, N, ci_h.shape[1], dtype=f64, device=dev)
+                    rec["rewards"][k, a:b] = torch.as_tensor(r_h, device=dev)
+                    rec["cinfo"][k, a:b] = torch.as_tensor(ci_h, device=dev)
             steps_done[a:b] += act_g
             t2 = time.time()
             if done.any():

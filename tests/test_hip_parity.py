@@ -428,6 +428,37 @@ def test_engine_step_matches_host_loop(ctx, skel, mode, monkeypatch):
         ref.close()
 
 
+def test_engine_keeps_the_resident_form_when_cus_are_masked():
+    """A process that gets 240 of the 256 CUs (ROC_GLOBAL_CU_MASK; a CU-masked partition, a co-tenant): the occupancy calculator
+    still answers for the whole chip, the kernel's own residency probe counts what is really there, and the engine lets a wave serve
+    two envs instead of waiting for workgroups that never become resident (or dropping to one launch per substep). Two env-steps of
+    1 024 slots under the mask == without it (different K1 forms: 1e-9). The mask must be set before HIP starts: subprocesses."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(repo, "tools", "cu_mask_check.py"), "--envs", "1024", "--step"]
+
+    def run(extra):
+        out = subprocess.run(cmd, env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    full = run({})
+    cus = full["cus_reported"]
+    if cus < 64:
+        pytest.skip("needs a chip with >= 64 CUs")
+    keep = cus - 16
+    masked = run({"ROC_GLOBAL_CU_MASK": "0x" + "f" * (keep // 4)})
+    assert full["substeps_per_launch"] == 15 and masked["substeps_per_launch"] == 15
+    assert full["envs_per_wave"] == 1 or full["resident_capacity"] < 256
+    assert masked["resident_capacity"] <= keep, "the probe must not count more workgroups than CUs were left: %r" % (masked,)
+    if 4 * masked["resident_capacity"] < 1024:
+        assert masked["envs_per_wave"] >= 2
+    assert masked["qpos_abs_sum"] == pytest.approx(full["qpos_abs_sum"], rel=1e-9)
+    np.testing.assert_allclose(masked["qpos_probe"], full["qpos_probe"], rtol=1e-9, atol=1e-9)
+
+
 @pytest.mark.parametrize("mode", ["resident", "per-substep", "resident-2-per-wave"])
 def test_engine_step_with_torque_actions(skel, mode, monkeypatch):
     """cfg.action_type = 'torque' through the engine: every substep applies clip(a_ref + a * a_scale) (humanoid_v1.py:167-172),

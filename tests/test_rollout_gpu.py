@@ -858,13 +858,56 @@ def test_custom_reward_none_trains_on_the_env_reward(workspace, skel):
     tr.agent.update_params(batch)
     assert all(np.isfinite(tr.agent.update_stats["value_loss"]))
     tr.close()
-    # a callable with no HIP kernel behind it is refused, not replaced
-    tr, cfg = _trainer(workspace, 8, 9, num_threads=2, num_groups=1)
-    tr.agent.custom_reward = lambda env, state, action, info: (0.5, np.zeros(1))
-    tr.agent._rollout = None
-    with pytest.raises(NotImplementedError):
-        tr.agent.sample(8)
-    tr.close()
+
+
+def test_custom_reward_callable_is_the_reference_plug_point(workspace, skel):
+    """agents/agent.py:53-54: `custom_reward(self.env, state, action, info)` may be ANY callable. One without a kernel behind it is
+    evaluated on the host per stepped slot through env.SlotView (HumanoidEnv's attribute surface on one slot of the lockstep rollout).
+    Two callables written against that surface exactly as the reference's are -- pose_dist_reward (reward_function.py:70-75 with
+    env.get_pose_dist) and a quat-space one that reads data.qpos / prev_qpos / bquat / prev_bquat / get_ee_pos / get_expert_attr /
+    cur_t / dt / end_reward -- give, from the same seed state, the rewards the registry's KERNELS give (pose_dist: K's arithmetic
+    to round-off; quat_v3: the oracle's restatement of reward_function.py:4-60 on the view's fields)."""
+    from oracle import reward as R
+
+    def py_pose_dist(env, state, action, info):
+        d = env.get_pose_dist()
+        r = 5.0 - 3.0 * d
+        if info["end"]:
+            r += env.end_reward
+        return r, np.array([d])
+
+    seen = {"n": 0, "state_dim": None}
+
+    def py_quat_v3(env, state, action, info):
+        cfg = env.cfg
+        ind = env.get_expert_index(env.cur_t)
+        row = {k: env.get_expert_attr(k, ind) for k in ("qpos", "rlinv_local", "rangv", "rq_rmh", "ee_pos", "bquat", "bangvel")}
+        seen["n"] += 1
+        seen["state_dim"] = np.asarray(state).shape
+        assert np.asarray(action).shape == (52,) and np.allclose(env.get_body_quat(), env.bquat)
+        r, ci = R.quat_v3(env.data.qpos, env.prev_qpos, env.prev_bquat, env.get_ee_pos(None), env.cur_t, row, cfg.reward_weights, cfg.b_diffw,
+                          env.dt, cfg.env_episode_len, info["end"], env.end_reward, env.skel.body_qpos_start, env.skel.body_ndof,
+                          obs_coord=getattr(cfg, "obs_coord", "heading"))
+        return float(r[0]), ci[0]
+
+    for reward_id, fn, tol in (("pose_dist", py_pose_dist, 1e-12), ("quat_v3", py_quat_v3, 1e-9)):
+        out = {}
+        for how in ("kernel", "callable"):
+            tr, cfg = _trainer(workspace, 16, 9, num_threads=2, num_groups=2)
+            cfg.reward_id = reward_id
+            from egopose_amd.reward import reward_func
+            tr.agent.custom_reward = reward_func[reward_id] if how == "kernel" else fn
+            tr.agent._rollout = None
+            tr.agent.prefetch_rollout = False
+            out[how] = _seeded_sample(tr, 16 * 12, end_reward=0.6)
+            assert tr.agent._get_rollout().reward_kind == (reward_id if how == "kernel" else "callable")
+            tr.close()
+        a, b = out["kernel"], out["callable"]
+        np.testing.assert_array_equal(a["states"], b["states"])                 # same trajectories (the reward does not steer a rollout)
+        np.testing.assert_array_equal(a["masks"], b["masks"])
+        np.testing.assert_allclose(b["rewards"], a["rewards"], rtol=tol, atol=tol, err_msg=reward_id)
+        assert a["r"] == pytest.approx(b["r"], rel=1e-9) and (a["masks"] == 0).sum() >= 16
+    assert seen["n"] >= 16 * 12 and seen["state_dim"] == (115,)
 
 
 def test_cross_01_at_1024_slots_replayed_by_oracle_env(tmp_path_factory, skel):

@@ -13,6 +13,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=1024)
     ap.add_argument("--groups", type=int, default=2)
+    ap.add_argument("--step", action="store_true", help="also run two env-steps from a fixed state and print a checksum of the final qpos")
     a = ap.parse_args()
     import torch
     from egopose_amd.hip import EgpContext
@@ -27,6 +28,24 @@ def main():
     out = {"envs": a.envs, "cus_reported": torch.cuda.get_device_properties(0).multi_processor_count,
            "envs_per_wave": eng.envs_per_wave, "resident_capacity": eng.resident_capacity, "substeps_per_launch": eng.substeps_per_launch,
            "HSA_CU_MASK": os.environ.get("HSA_CU_MASK"), "ROC_GLOBAL_CU_MASK": os.environ.get("ROC_GLOBAL_CU_MASK")}
+    if a.step:
+        import numpy as np
+        rng = np.random.RandomState(0)
+        q0 = np.tile(np.r_[0, 0, 1.0, 1, 0, 0, 0, np.zeros(52)], (a.envs, 1))
+        q0[:, 7:] += rng.normal(size=(a.envs, 52)) * 0.1
+        eng.reset(np.arange(a.envs), q0, rng.normal(size=(a.envs, 58)) * 0.1)
+        act = torch.as_tensor(rng.normal(size=(a.envs, 52)) * 0.1, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(2):
+            for g in range(a.groups):
+                eng.step_async(g, act)
+            for g in range(a.groups):
+                eng.wait(g)
+        torch.cuda.synchronize()
+        q = eng.qpos.cpu().numpy()
+        out["qpos_sum"] = float(q.sum())
+        out["qpos_abs_sum"] = float(np.abs(q).sum())
+        out["qpos_probe"] = [float(x) for x in q[[0, a.envs // 2, a.envs - 1], 10]]
     eng.close(); ph.close(); ctx.close()
     print(json.dumps(out))
 
