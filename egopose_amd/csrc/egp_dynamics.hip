@@ -32,10 +32,11 @@ namespace {
 
 using namespace egp_dyn;
 
-// One wavefront per env and the env's intermediates in LDS: at large batches the kernel's rate is (envs a CU holds) / (latency of
-// one env), and the first factor is LDS capacity. 7 envs per workgroup: 7 x 9.8 kB + the 5 kB of tree tables = 74 kB, two
-// workgroups per CU = 14 envs (round 2: 4 x 16.9 + 5 = 73 kB, two workgroups = 8 envs): 787 -> 653 us at 65 536 envs. Small
-// batches (a rollout group) keep 4 envs per workgroup: spread over more CUs, one wave per SIMD (1 024 envs: 22 us against 27).
+// One wavefront per env and the env's intermediates in LDS. Round 6's counters (65 536 envs): SQ_LDS_IDX_ACTIVE = 86 % of the
+// kernel's CU-cycles, a third of them bank-conflict cycles -- the kernel is LDS-bound (496 LDS instructions per env), so the rows of
+// the per-env arrays got odd strides (egp_dynamics_dev.hpp) at the price of 11.0 instead of 9.8 kB per env: 6 envs per workgroup
+// (6 x 11.0 kB + the 9.9 kB of tree tables = 75.8 kB, two workgroups per CU = 12 envs; rounds 3-5: 7 x 9.8 + 9.9 = 78.3 kB, 14 envs).
+// Small batches (a rollout group) keep 4 envs per workgroup: spread over more CUs, one wave per SIMD (1 024 envs: 22 us against 27).
 
 // `list` (optional): the launch covers the envs list[k * list_stride] instead of 0 .. n - 1 (the engine's reset: rows of the envs
 // being reset, = the reference's sim.forward() after set_state); an entry whose list[k * list_stride + 2] is non-zero writes to the
@@ -72,13 +73,13 @@ int egp_launch_dynamics_strided(egp_ctx *ctx, const double *qpos, long ld_q, con
                                 double *qM_alt, double *bias_alt) {
     if (!ctx->dyn_tables) { egp::set_error("egp_set_dynamics_model must be called before egp_dynamics"); return EGP_E_STATE; }
     const int env_doubles = dy_env_doubles(ctx->dm.nbody, ctx->dm.nv - 6, ctx->dm.nv);
-    static const hipError_t attr = hipFuncSetAttribute((const void *)k_dynamics<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    static const hipError_t attr = hipFuncSetAttribute((const void *)k_dynamics<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     const bool wide = n >= 4096;
-    const size_t lds = (size_t)(wide ? 7 : 4) * env_doubles * sizeof(double);
+    const size_t lds = (size_t)(wide ? 6 : 4) * env_doubles * sizeof(double);
     if (attr != hipSuccess || lds > (wide ? 100 : 64) * 1024) { egp::set_error("k_dynamics: LDS budget (%zu bytes)", lds); return EGP_E_HIP; }
     const DynTables *tab = (const DynTables *)ctx->dyn_tables;
     if (wide)
-        k_dynamics<7><<<dim3((n + 6) / 7), dim3(448), lds, stream>>>(tab, qpos, qvel, n, ld_q, ld_v, qM, ld_m, bias, ld_b, xpos, env_doubles,
+        k_dynamics<6><<<dim3((n + 5) / 6), dim3(384), lds, stream>>>(tab, qpos, qvel, n, ld_q, ld_v, qM, ld_m, bias, ld_b, xpos, env_doubles,
                                                                      list, list_stride, qM_alt, bias_alt);
     else
         k_dynamics<4><<<dim3((n + 3) / 4), dim3(256), lds, stream>>>(tab, qpos, qvel, n, ld_q, ld_v, qM, ld_m, bias, ld_b, xpos, env_doubles,

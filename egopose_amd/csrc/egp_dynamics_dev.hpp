@@ -90,11 +90,20 @@ __device__ __forceinline__ Sp ld_sp(const double *p) { return {{p[0], p[1], p[2]
 // (round 3: 16.9 kB -> 9.8 kB per env for the humanoid -- the number of envs a CU holds at once is what bounds this kernel at
 //  large batches -- by the aliasing, by sizing to the model instead of the table maxima, and by dropping the S_d * qvel_d
 //  copy: phase D forms the product. Keeping the copy (12.1 kB, 12 envs per CU) measured 674 us at 65 536 envs against 653.)
+// Row strides of the per-env LDS arrays, in doubles: ODD, so that the lanes of a half-wave (lane = body / hinge / dof reading its own
+// row) fall into different banks. With the natural strides 12 / 6 / 10 (96 / 48 / 80 bytes against 256 bytes of banks) every 8th /
+// 16th / 16th row shares its banks: at 65 536 envs the LDS was busy 86 % of the kernel's time (SQ_LDS_IDX_ACTIVE), a third of that
+// in bank-conflict cycles (SQ_LDS_BANK_CONFLICT) -- K8 is LDS-bound, not latency-bound as rounds 3-5 assumed.
+constexpr int DY_LW = 13;        // frames: R (9), p (3)  [sLoc, sW]
+constexpr int DY_LJ = 7;         // hinge axis (3), anchor (3)  [sJl]
+constexpr int DY_LS = 7;         // spatial vectors  [sS, sX, sF]
+constexpr int DY_LI = 11;        // spatial inertias (10)  [sIb]
 __host__ __device__ inline int dy_env_doubles(int nb, int nj, int nv) {
-    const int r1a = nb * 12 + nj * 6, r1b = nb * 16;
-    return (r1a > r1b ? r1a : r1b) + nb * 12 + nv * 6 + nv;
+    const int r1a = nb * DY_LW + nj * DY_LJ, r1b = nb * (DY_LI + DY_LS), r1c = nv * DY_LS;
+    const int r1 = r1a > r1b ? (r1a > r1c ? r1a : r1c) : (r1b > r1c ? r1b : r1c);
+    return r1 + nb * DY_LW + nv * DY_LS + nv;
 }
-constexpr int DY_ENV_DOUBLES = DY_MAXB * 12 + DY_MAXJ * 6 + DY_MAXB * 12 + DY_MAXV * 6 + DY_MAXV;      // the same for the table maxima
+constexpr int DY_ENV_DOUBLES = DY_MAXB * DY_LW + DY_MAXJ * DY_LJ + DY_MAXB * DY_LW + DY_MAXV * DY_LS + DY_MAXV;      // the same for the table maxima
 
 // Every env is owned by ONE wavefront, so the phases only need the wave's own LDS writes to have landed before its
 // next reads: LDS operations of a wave complete in order; the fences keep the compiler from moving accesses across.
@@ -132,13 +141,13 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
                                               double *qM_out, double *bias_out, double *xpos_out) {
     const int nb = tb.nb, nv = tb.nv, nj = tb.nj;
     double *sLoc = base;                                 // [nb][12]  local transform in the parent frame: Rl (9), tl (3)       (A, B)
-    double *sJl = sLoc + nb * 12;                        // [nj][6]   hinge axis (3) and anchor (3) in the parent frame of its body (A, C)
+    double *sJl = sLoc + nb * DY_LW;                        // [nj][6]   hinge axis (3) and anchor (3) in the parent frame of its body (A, C)
     double *sIb = base;                                  // [nb][10]  own spatial inertia about the world origin        (D, F: over sLoc / sJl)
-    double *sF = sIb + nb * 10;                          // [nb][6]   body force                                        (D, F)
-    const int r1 = nb * 12 + nj * 6 > nb * 16 ? nb * 12 + nj * 6 : nb * 16;
+    double *sF = sIb + nb * DY_LI;                          // [nb][6]   body force                                        (D, F)
+    const int r1 = dy_env_doubles(nb, nj, nv) - (nb * DY_LW + nv * DY_LS + nv);
     double *sW = base + r1;                              // [nb][12]  world frame: R (9), p (3)
-    double *sS = sW + nb * 12;                           // [nv][6]   joint motion vectors (world)
-    double *sQ = sS + nv * 6;                            // [nv]      qvel
+    double *sS = sW + nb * DY_LW;                           // [nv][6]   joint motion vectors (world)
+    double *sQ = sS + nv * DY_LS;                            // [nv]      qvel
     const int b = lane;
     DY_TR(0);
     if (lane < nv) sQ[lane] = qd[lane];
@@ -174,30 +183,30 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
                 const V3 anc_loc = {tb.anc[j][0], tb.anc[j][1], tb.anc[j][2]};
                 const V3 a_p = mul(Rl, a_loc);                   // axis / anchor before this hinge turns, parent-frame coordinates
                 const V3 r_p = tl + mul(Rl, anc_loc);
-                st_v3(sJl + j * 6, a_p);
-                st_v3(sJl + j * 6 + 3, r_p);
+                st_v3(sJl + j * DY_LJ, a_p);
+                st_v3(sJl + j * DY_LJ + 3, r_p);
                 Rl = mul(Rl, axis_angle(a_loc, sS[2 * j], sS[2 * j + 1]));
                 tl = r_p - mul(Rl, anc_loc);
             }
         }
-        st_m3(sLoc + b * 12, Rl);
-        st_v3(sLoc + b * 12 + 9, tl);
+        st_m3(sLoc + b * DY_LW, Rl);
+        st_v3(sLoc + b * DY_LW + 9, tl);
     }
     wave_sync();
     DY_TR(1);
     // ---- B: world frames (compose upwards: T_world = T_root o ... o T_parent o T_b)
     if (b < nb) {
         M3 R;
-        ld_m3(sLoc + b * 12, R);
-        V3 t = ld_v3(sLoc + b * 12 + 9);
+        ld_m3(sLoc + b * DY_LW, R);
+        V3 t = ld_v3(sLoc + b * DY_LW + 9);
         for (int c = tb.parent[b]; c >= 0; c = tb.parent[c]) {
             M3 Rc;
-            ld_m3(sLoc + c * 12, Rc);
-            t = ld_v3(sLoc + c * 12 + 9) + mul(Rc, t);
+            ld_m3(sLoc + c * DY_LW, Rc);
+            t = ld_v3(sLoc + c * DY_LW + 9) + mul(Rc, t);
             R = mul(Rc, R);
         }
-        st_m3(sW + b * 12, R);
-        st_v3(sW + b * 12 + 9, t);
+        st_m3(sW + b * DY_LW, R);
+        st_v3(sW + b * DY_LW + 9, t);
         if (valid && xpos_out) st_v3(xpos_out + b * 3, t);
     }
     wave_sync();
@@ -214,12 +223,12 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
         } else {
             const int j = d - 6, par = tb.parent[tb.dof_body[d]];
             M3 Rp;
-            ld_m3(sW + par * 12, Rp);
-            const V3 a_w = mul(Rp, ld_v3(sJl + j * 6));
-            const V3 r_w = ld_v3(sW + par * 12 + 9) + mul(Rp, ld_v3(sJl + j * 6 + 3));
+            ld_m3(sW + par * DY_LW, Rp);
+            const V3 a_w = mul(Rp, ld_v3(sJl + j * DY_LJ));
+            const V3 r_w = ld_v3(sW + par * DY_LW + 9) + mul(Rp, ld_v3(sJl + j * DY_LJ + 3));
             S = {a_w, cross(r_w, a_w)};
         }
-        st_sp(sS + d * 6, S);
+        st_sp(sS + d * DY_LS, S);
     }
     wave_sync();
     DY_TR(3);
@@ -232,38 +241,38 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
     // so two ancestor-prefix sums by pointer jumping (lane = dof, ceil(log2 28) = 5 rounds each) replace the walks.
     double *sX = base;                                   // [nv][6] scan buffer: over sLoc / sJl (dead after C), under sIb / sF (written at the end of D)
     Sp sq = {{0, 0, 0}, {0, 0, 0}};
-    if (lane < nv) sq = sQ[lane] * ld_sp(sS + lane * 6);
+    if (lane < nv) sq = sQ[lane] * ld_sp(sS + lane * DY_LS);
     auto ancestor_sums = [&](Sp x) -> Sp {              // inclusive sum of x over the lane's dof and its ancestors; leaves the sums in sX
-        if (lane < nv) st_sp(sX + lane * 6, x);
+        if (lane < nv) st_sp(sX + lane * DY_LS, x);
         wave_sync();
         for (int k = 0; k < tb.scan_rounds; ++k) {
             const int an = lane < nv ? tb.dof_anc[k][lane] : -1;
             Sp up = {{0, 0, 0}, {0, 0, 0}};
-            if (an >= 0) up = ld_sp(sX + an * 6);
+            if (an >= 0) up = ld_sp(sX + an * DY_LS);
             wave_sync();                                 // every lane has read round k's values
             x = x + up;
-            if (an >= 0) st_sp(sX + lane * 6, x);
+            if (an >= 0) st_sp(sX + lane * DY_LS, x);
             wave_sync();
         }
         return x;
     };
     ancestor_sums(sq);
     Sp v = {{0, 0, 0}, {0, 0, 0}};
-    if (b < nb) v = ld_sp(sX + tb.last_dof[b] * 6);
+    if (b < nb) v = ld_sp(sX + tb.last_dof[b] * DY_LS);
     Sp cterm = {{0, 0, 0}, {0, 0, 0}};
     if (lane < nv) {
         const int par = (lane >= 3 && lane < 6) ? 2 : tb.dof_parent[lane];
-        if (par >= 0) cterm = cross_m(ld_sp(sX + par * 6), sq);
+        if (par >= 0) cterm = cross_m(ld_sp(sX + par * DY_LS), sq);
     }
     wave_sync();                                         // P has been read; the buffer is reused
     ancestor_sums(cterm);
     Sp a = {{0, 0, 0}, {-tb.g[0], -tb.g[1], -tb.g[2]}};
-    if (b < nb) a = a + ld_sp(sX + tb.last_dof[b] * 6);
+    if (b < nb) a = a + ld_sp(sX + tb.last_dof[b] * DY_LS);
     wave_sync();                                         // ... and again, by sIb / sF below
     if (b < nb) {
         M3 R;
-        ld_m3(sW + b * 12, R);
-        const V3 p = ld_v3(sW + b * 12 + 9);
+        ld_m3(sW + b * DY_LW, R);
+        const V3 p = ld_v3(sW + b * DY_LW + 9);
         const V3 c = p + mul(R, V3{tb.com_l[b][0], tb.com_l[b][1], tb.com_l[b][2]});
         const double *Il = tb.I_l[b];
         M3 I0;
@@ -282,8 +291,8 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
         in10[4] = Iw.m[0] + m * (cc - c.x * c.x); in10[5] = Iw.m[4] + m * (cc - c.y * c.y); in10[6] = Iw.m[8] + m * (cc - c.z * c.z);
         in10[7] = Iw.m[1] - m * c.x * c.y;        in10[8] = Iw.m[2] - m * c.x * c.z;        in10[9] = Iw.m[5] - m * c.y * c.z;
 #pragma unroll
-        for (int i = 0; i < 10; ++i) sIb[b * 10 + i] = in10[i];
-        st_sp(sF + b * 6, inertia_apply(in10, a) + cross_f(v, inertia_apply(in10, v)));
+        for (int i = 0; i < 10; ++i) sIb[b * DY_LI + i] = in10[i];
+        st_sp(sF + b * DY_LS, inertia_apply(in10, a) + cross_f(v, inertia_apply(in10, v)));
     }
     wave_sync();
     DY_TR(4);
@@ -296,27 +305,27 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
         double t16[16];
         if (b < nb) {
 #pragma unroll
-            for (int i = 0; i < 10; ++i) t16[i] = sIb[b * 10 + i];
+            for (int i = 0; i < 10; ++i) t16[i] = sIb[b * DY_LI + i];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) t16[10 + i] = sF[b * 6 + i];
+            for (int i = 0; i < 6; ++i) t16[10 + i] = sF[b * DY_LS + i];
         }
         for (int step = 1; step < nb; step <<= 1) {
             const bool has = b < nb && b + step < nb;
             double up[16];
             if (has) {
 #pragma unroll
-                for (int i = 0; i < 10; ++i) up[i] = sIb[(b + step) * 10 + i];
+                for (int i = 0; i < 10; ++i) up[i] = sIb[(b + step) * DY_LI + i];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) up[10 + i] = sF[(b + step) * 6 + i];
+                for (int i = 0; i < 6; ++i) up[10 + i] = sF[(b + step) * DY_LS + i];
             }
             wave_sync();
             if (has) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) t16[i] += up[i];
 #pragma unroll
-                for (int i = 0; i < 10; ++i) sIb[b * 10 + i] = t16[i];
+                for (int i = 0; i < 10; ++i) sIb[b * DY_LI + i] = t16[i];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) sF[b * 6 + i] = t16[10 + i];
+                for (int i = 0; i < 6; ++i) sF[b * DY_LS + i] = t16[10 + i];
             }
             wave_sync();
         }
@@ -324,16 +333,16 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
         double sub[16];
         if (end < nb) {
 #pragma unroll
-            for (int i = 0; i < 10; ++i) sub[i] = sIb[end * 10 + i];
+            for (int i = 0; i < 10; ++i) sub[i] = sIb[end * DY_LI + i];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) sub[10 + i] = sF[end * 6 + i];
+            for (int i = 0; i < 6; ++i) sub[10 + i] = sF[end * DY_LS + i];
         }
         wave_sync();
         if (end < nb) {
 #pragma unroll
-            for (int i = 0; i < 10; ++i) sIb[b * 10 + i] = t16[i] - sub[i];
+            for (int i = 0; i < 10; ++i) sIb[b * DY_LI + i] = t16[i] - sub[i];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) sF[b * 6 + i] = t16[10 + i] - sub[10 + i];
+            for (int i = 0; i < 6; ++i) sF[b * DY_LS + i] = t16[10 + i] - sub[10 + i];
         }
         wave_sync();
     }
@@ -346,20 +355,20 @@ __device__ __forceinline__ void dynamics_wave(const DynTables &tb, double *base,
         const int d = lane, bd = tb.dof_body[d];
         double ic[10];
 #pragma unroll
-        for (int i = 0; i < 10; ++i) ic[i] = sIb[bd * 10 + i];
-        const Sp fc = ld_sp(sF + bd * 6);
-        const Sp S = ld_sp(sS + d * 6);
+        for (int i = 0; i < 10; ++i) ic[i] = sIb[bd * DY_LI + i];
+        const Sp fc = ld_sp(sF + bd * DY_LS);
+        const Sp S = ld_sp(sS + d * DY_LS);
         Fd = inertia_apply(ic, S);
         if (valid && bias_out) bias_out[d] = sdot(S, fc);
     }
     wave_sync();                                         // the composites have been read: their place takes F
-    if (lane < nv) st_sp(sX + lane * 6, Fd);
+    if (lane < nv) st_sp(sX + lane * DY_LS, Fd);
     wave_sync();
     if (valid && qM_out) {
 #pragma unroll 4
         for (int e = lane; e < tb.nM; e += 64) {
             const int d = tb.ent_row[e], i = tb.ent_col[e];
-            double v = sdot(ld_sp(sS + i * 6), ld_sp(sX + d * 6));
+            double v = sdot(ld_sp(sS + i * DY_LS), ld_sp(sX + d * DY_LS));
             if (i == d && d >= 6) v += tb.armature;
             qM_out[e] = v;
         }
