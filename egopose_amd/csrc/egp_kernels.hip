@@ -562,6 +562,8 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
     double dinv = 0.0;
     const double kd_dt = c_kd * m.sub_dt;
     double c_held = 0.0;                    // DYN: the bias entry of this lane's dof that the previous substep left behind
+    double nx_q = 0.0, nx_v = 0.0;          // DYN: the next substep's state row, when it could be requested early
+    bool have_next = false;
     auto factor_from_lds = [&]() {
 #pragma unroll
         for (int j = 0; j < PD_NV; ++j) {
@@ -607,8 +609,13 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
         } else if (live) {
             double r_q, r_v, r_c;
             if constexpr (DYN) {
-                if (lane < sv.nq) s_q[lane] = sys_load_f64(qpos + env * ld.qpos + lane);
-                if (lane < sv.nv) s_q[64 + lane] = sys_load_f64(qvel + env * ld.qvel + lane);
+                if (have_next) {                // requested under the previous substep's factorisation (below)
+                    if (lane < sv.nq) s_q[lane] = nx_q;
+                    if (lane < sv.nv) s_q[64 + lane] = nx_v;
+                } else {
+                    if (lane < sv.nq) s_q[lane] = sys_load_f64(qpos + env * ld.qpos + lane);
+                    if (lane < sv.nv) s_q[64 + lane] = sys_load_f64(qvel + env * ld.qvel + lane);
+                }
                 egp_dyn::wave_sync();
                 r_q = s_q[7 + act]; r_v = s_q[64 + row]; r_c = c_held;
             } else if (sv.row_contig) {
@@ -673,6 +680,15 @@ __global__ __launch_bounds__(256) void k_pd_server_tree58(DevModel m, PdLd ld, c
                 egp_dyn::dynamics_wave(*tb, s_scr, s_q, s_q + 64, lane, true, &s_qM[wave][0], s_q + 128, nullptr);
                 egp_dyn::wave_sync();
                 c_held = s_q[128 + row];
+                // K8 took its 11 us: if the owner has raised the next go word meanwhile (with free physics it has; the rows were
+                // written before the word, fenced), the next state row is requested NOW and crosses PCIe under the factorisation
+                // instead of in front of the next solve (2.6 us of every 24.6 us substep in the rollout's tail)
+                have_next = false;
+                if (sub + 1 < sv.n_sub && (scalar_poll_u64(sv.go + slice * 8) >> 1) >= sv.base + (unsigned long long)sub + 1ull) {
+                    nx_q = lane < sv.nq ? sys_load_f64(qpos + env * ld.qpos + lane) : 0.0;
+                    nx_v = lane < sv.nv ? sys_load_f64(qvel + env * ld.qvel + lane) : 0.0;
+                    have_next = true;
+                }
                 factor_from_lds();
                 if (sub == sv.n_sub - 1) {       // ... and across launches
                     double *dst = sv.qM_dev + env * ld.qM;
@@ -1614,15 +1630,15 @@ __device__ __forceinline__ void gae_stage(const T *__restrict__ r, const T *__re
 // short (one tile for every gamma tau < 0.93) and its association is fixed -- bit-reproducible, unlike the classic form that takes
 // whichever of (map, inclusive prefix) a predecessor has ready. No fences (a device-scope release writes back the XCD's L2 here,
 // docs/DESIGN_TRAIL.md): the two words of a map are their own flags -- the slots are armed with a NaN pattern no map contains
-// (one hipMemsetD32Async in front of the launch) and travel as relaxed agent-scope atomics. Tiles are handed out by a ticket, right
-// to left, so a tile only ever waits for tiles that started before it.
-constexpr unsigned GAE_ARM32 = 0x7FF8DEADu;                               // both halves of an armed 64-bit slot; the ticket starts there too
+// (one hipMemsetD32Async in front of the launch) and travel as relaxed agent-scope atomics. Tiles go right to left in workgroup-index
+// order (see the kernel), so a tile only ever waits for workgroups that were dispatched before it.
+constexpr unsigned GAE_ARM32 = 0x7FF8DEADu;                               // both halves of an armed 64-bit slot
 constexpr unsigned long long GAE_ARM64 = ((unsigned long long)GAE_ARM32 << 32) | GAE_ARM32;
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_gae_onepass(const T *__restrict__ r, const T *__restrict__ mk, const T *__restrict__ v, int n,
-                                                     double gamma, double gt, unsigned long long *maps, unsigned *ticket,
-                                                     T *__restrict__ adv, T *__restrict__ ret, double *__restrict__ part) {
+                                                     double gamma, double gt, unsigned long long *maps, T *__restrict__ adv,
+                                                     T *__restrict__ ret, double *__restrict__ part) {
     extern __shared__ double s_gae[];
     double *s_d = s_gae, *s_c = s_gae + GAE_LDS_DOUBLES / 2;
     __shared__ double s_n[256], s_mean[256], s_m2[256];
@@ -1633,7 +1649,6 @@ __global__ __launch_bounds__(256) void k_gae_onepass(const T *__restrict__ r, co
     // or done. (A ticket counter makes that independent of the dispatcher -- and cost 30 ns per workgroup, serialised on one
     // address across eight L2s: 24 of the 36 us at 800 tiles, 390 us at 12 800.) The wait below is bounded all the same.
     const int tile = nb - 1 - (int)blockIdx.x;
-    (void)ticket;
     const int i0 = (tile * 256 + t) * GAE_CHUNK;
     gae_stage<T>(r, mk, v, n, gamma, gt, s_d, s_c, tile);
     double P = 1.0, A = 0.0;                              // this thread's chunk as a map of the carry entering it (past the end: identity)
@@ -2385,16 +2400,15 @@ static int launch_gae(const T *r, const T *mk, const T *v, int n, double gamma, 
     EGP_REQUIRE(n > 0, "n must be positive");
     const int n_chunks = (n + GAE_CHUNK - 1) / GAE_CHUNK;
     const int n_blocks = (n_chunks + 255) / 256;
-    // workspace: [maps: 2 x n_blocks 64-bit slots][ticket + pad: one 64-bit slot][tile partials: 3 x n_blocks doubles]
+    // workspace: [maps: 2 x n_blocks 64-bit slots][tile partials: 3 x n_blocks doubles]
     unsigned long long *maps = (unsigned long long *)ws;
-    unsigned *ticket = (unsigned *)(maps + 2 * (size_t)n_blocks);
-    double *part = (double *)(maps + 2 * (size_t)n_blocks + 1);
+    double *part = (double *)(maps + 2 * (size_t)n_blocks);
     hipStream_t s = (hipStream_t)stream;
     constexpr size_t lds = (size_t)GAE_LDS_DOUBLES * sizeof(double);          // the tile's (delta, c) pairs, padded
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gae_onepass<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) { set_error("hipFuncSetAttribute(k_gae_onepass, %zu B of LDS): %s", lds, hipGetErrorString(attr)); return EGP_E_HIP; }
-    EGP_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)maps, (int)GAE_ARM32, (size_t)(2 * (size_t)n_blocks + 1) * 2, s));     // arm the slots and the ticket
-    k_gae_onepass<T><<<dim3(n_blocks), dim3(256), lds, s>>>(r, mk, v, n, gamma, gamma * tau, maps, ticket, adv, ret, part);
+    EGP_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)maps, (int)GAE_ARM32, (size_t)n_blocks * 4, s));     // arm the map slots
+    k_gae_onepass<T><<<dim3(n_blocks), dim3(256), lds, s>>>(r, mk, v, n, gamma, gamma * tau, maps, adv, ret, part);
     k_gae_stats<<<dim3(1), dim3(GAE_STATS_THREADS), 0, s>>>(n_blocks, part, stats);
     return after_launch("k_gae_*");
 }

@@ -25,7 +25,8 @@ def main():
     p = subject_03_params()
     ctx = EgpContext(sk, p["jkp"], p["jkd"], p["a_ref"], p["a_scale"], p["torque_lim"], p["b_diffw"], p["reward_weights"])
     ph = SurrogatePhysics(sk, n)
-    eng = RolloutEngine(ctx, ph, n, n_threads=default_threads(), n_groups=groups)
+    dyn = os.environ.get("EGP_DEVICE_DYNAMICS", "0") == "1"          # K8 inside the resident kernel (stamp 5: K8 + factors done)
+    eng = RolloutEngine(ctx, ph, n, n_threads=default_threads(), n_groups=groups, device_dynamics=dyn)
     rng = np.random.RandomState(0)
     q0 = np.tile(sk.default_qpos() if hasattr(sk, "default_qpos") else np.r_[0, 0, 1.0, 1, 0, 0, 0, np.zeros(52)], (n, 1))
     eng.reset(np.arange(n), q0, np.zeros((n, 58)))
