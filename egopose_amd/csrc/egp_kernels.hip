@@ -1215,8 +1215,10 @@ __device__ __forceinline__ void reward_body(const DevModel &m, const RewardW &w,
     }
 }
 
+// (four workgroups per CU: the multi-pass float64 form needed 132 VGPRs -- one granule past 128 -- and ran three waves per SIMD;
+//  VALUBusy 63 % at 1 M envs said the fourth was missing)
 template <typename T, int PASSES>
-__global__ __launch_bounds__(256) void k_reward_quat_v3(DevModel m, RewardW w, const T *__restrict__ expert_rows,
+__global__ __launch_bounds__(256, 4) void k_reward_quat_v3(DevModel m, RewardW w, const T *__restrict__ expert_rows,
                                                         const T *__restrict__ cur_qpos, const T *__restrict__ prev_qpos,
                                                         const T *__restrict__ ee_wpos, const int *__restrict__ tcur,
                                                         const int *__restrict__ frame, const int *__restrict__ endf,
