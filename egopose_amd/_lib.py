@@ -242,6 +242,7 @@ SIGNATURES = {
     "egp_engine_go_words_in_vram": (_i32, [vp]),
     "egp_engine_envs_per_wave": (_i32, [vp, C.POINTER(C.c_int32)]),
     "egp_host_probe": (C.c_int, [_i32, _i32, _i32, C.POINTER(HostProbeResult)]),
+    "egp_device_usable_cus": (_i32, [_i32]),
 }
 
 _lib = None

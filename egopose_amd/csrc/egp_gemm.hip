@@ -1081,11 +1081,12 @@ int launch_variant(const GemmArgs &g, dim3 grid, size_t lds, hipStream_t s) {
 
 template <int BN, bool FUSED>
 int launch_ws(const GemmArgs &g, hipStream_t s) {
-    static int n_cu = 0;
-    if (!n_cu) {
+    static int n_cu = 0;                        // one persistent workgroup per CU the process really gets (egp_device_usable_cus: under a
+    if (!n_cu) {                                // CU mask the attribute over-reports, and the workgroups without a CU would be a second round)
         int dev = 0;
         EGP_HIP_CHECK(hipGetDevice(&dev));
-        EGP_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cu = egp_device_usable_cus(dev);
+        if (n_cu <= 0) EGP_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const size_t lds = (size_t)2 * 3 * (tile_el(BM) + tile_el(BN)) * sizeof(__bf16) + 4 * 32 * (64 + 4) * sizeof(float);   // + the epilogue patches
     const dim3 grid((unsigned)(g.n_items < n_cu ? g.n_items : n_cu));

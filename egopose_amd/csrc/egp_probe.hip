@@ -22,6 +22,8 @@
 #include <atomic>
 #include <chrono>
 #include <thread>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #if defined(__x86_64__)
@@ -93,6 +95,28 @@ __global__ __launch_bounds__(64) void k_probe_go(const unsigned long long *go, c
     }
 }
 
+// Usable-CU probe (egp_device_usable_cus): one workgroup per CU by construction (each takes more than half of a CU's LDS), every
+// workgroup counts itself in, holds its place until all gridDim.x are there or the timeout passes, and counts itself out; probe[1] =
+// the largest head count seen = the CUs this process really gets. hipDeviceAttributeMultiprocessorCount is the data sheet's answer:
+// under HSA_CU_MASK it stays 256, under ROC_GLOBAL_CU_MASK it reports the mask's bits (240) where 225 workgroups fit.
+__global__ __launch_bounds__(64) void k_cu_probe(unsigned *probe, long long timeout_ticks) {
+    extern __shared__ char s_hold[];
+    if (timeout_ticks < 0) s_hold[threadIdx.x] = 0;          // (keeps the allocation: never taken)
+    if (threadIdx.x != 0) return;
+    unsigned present = atomicAdd(probe, 1u) + 1u, best = present;
+    const long long t0 = wall_clock64();
+    for (;;) {
+        if (present >= gridDim.x) { atomicExch(probe + 2, 1u); break; }
+        if (__hip_atomic_load(probe + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if (wall_clock64() - t0 > timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+        present = __hip_atomic_load(probe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        best = present > best ? present : best;
+    }
+    atomicMax(probe + 1, best);
+    atomicSub(probe, 1u);
+}
+
 inline double percentile(std::vector<double> &v, double q) {
     if (v.empty()) return 0.0;
     std::sort(v.begin(), v.end());
@@ -103,6 +127,38 @@ inline double percentile(std::vector<double> &v, double q) {
 #define P_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { egp::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); rc = EGP_E_HIP; goto done; } } while (0)
 
 }  // namespace
+
+extern "C" int32_t egp_device_usable_cus(int32_t device) {
+    static std::mutex mu;
+    static std::map<int, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(device);
+    if (it != cache.end()) return it->second;
+    int caller = -1, n_cu = 0;
+    if (hipGetDevice(&caller) != hipSuccess) { (void)hipGetLastError(); caller = -1; }
+    int result = 0;
+    do {
+        if (hipSetDevice(device) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); break; }
+        result = n_cu;
+        const char *pe = getenv("EGP_SERVER_PROBE");
+        if (n_cu <= 0 || (pe && atoi(pe) == 0)) break;
+        const size_t lds = 96 * 1024;             // more than half of a CU's 160 kB: at most one of these workgroups per CU
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cu_probe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); break; }
+        unsigned *d_probe = nullptr, h[4] = {0, 0, 0, 0};
+        if (hipMalloc((void **)&d_probe, sizeof(h)) != hipSuccess) { (void)hipGetLastError(); break; }
+        bool ok = hipMemset(d_probe, 0, sizeof(h)) == hipSuccess;
+        if (ok) {
+            k_cu_probe<<<dim3(n_cu), dim3(64), lds, nullptr>>>(d_probe, 100000);        // 1 ms: whoever is not on the chip by then is not resident
+            ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipMemcpy(h, d_probe, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        (void)hipFree(d_probe);
+        if (!ok) { (void)hipGetLastError(); break; }
+        if ((int)h[1] > 0 && (int)h[1] < result) result = (int)h[1];
+    } while (false);
+    if (caller >= 0 && caller != device) (void)hipSetDevice(caller);
+    cache[device] = result;
+    return result;
+}
 
 extern "C" int egp_host_probe(int32_t device, int32_t n_threads, int32_t millis, egp_host_probe_result *out) {
     EGP_REQUIRE(out && n_threads >= 0 && millis > 0 && millis <= 2000, "bad probe arguments");

@@ -64,15 +64,30 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
 
 
+_CUS = {}
+
+
+def usable_cus(device=None):
+    """CUs this process really gets on `device` (egp_device_usable_cus: 256 on a whole MI355X, fewer under a CU mask)."""
+    if not torch.cuda.is_available():
+        return 256
+    dev = torch.cuda.current_device() if device is None else int(device)
+    if dev not in _CUS:
+        n = int(L.load().egp_device_usable_cus(dev))
+        _CUS[dev] = n if n > 0 else 256
+    return _CUS[dev]
+
+
 def pick_splits(M, n_out, K):
     """Split-K factor of a weight-gradient shaped product: one work item per CU of the persistent kernel (tiles x splits <=
     256, rounded DOWN: 6 tiles x 86 splits = 516 items used to mean a third round for four workgroups), at least 8 k-tiles
     each. Measured on the update's shapes against two items per CU: the products themselves take the same time, the
     split-K reductions half (1.29 -> 0.74 ms per update)."""
+    cus = usable_cus()
     if M == 1:          # a one-column dy (the value head): k_colsum streams the activations, one workgroup per split -- one per CU
-        return max(1, min(256, K // 128))      # (128 / 256 / 512 / 1 024 splits: 52.9 / 37.8 / 41.3 / 61.2 us for 134 k x 200)
+        return max(1, min(cus, K // 128))      # (128 / 256 / 512 / 1 024 splits: 52.9 / 37.8 / 41.3 / 61.2 us for 134 k x 200)
     tiles = ((M + 127) // 128) * ((n_out + 127) // 128)
-    return max(1, min(256 // tiles, K // 256))
+    return max(1, min(cus // tiles, K // 256))
 
 
 def _index(t, name):

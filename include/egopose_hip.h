@@ -690,6 +690,12 @@ typedef struct egp_host_probe_result {
     int32_t pcie_read_rows, go_rtt_n, go_in_vram, large_bar, spin_threads, spin_gaps_over_5us;
 } egp_host_probe_result;
 int egp_host_probe(int32_t device, int32_t n_threads, int32_t millis, egp_host_probe_result *out);
+/* CUs of `device` this process really gets: workgroups that each take more than half a CU's LDS are launched one per reported CU and
+ * count how many are on the chip at once (cached per device; EGP_SERVER_PROBE=0: the attribute's figure). The attribute
+ * multiProcessorCount is the data sheet's answer -- under HSA_CU_MASK it stays 256, under ROC_GLOBAL_CU_MASK it says 240 where 225
+ * fit --, and kernels that launch ONE persistent workgroup per CU (the update's products, gemm.pick_splits) would run a second round
+ * for the missing ones. The reference has no counterpart (it sizes its sampler by --num-threads, agents/agent.py:93-100). */
+int32_t egp_device_usable_cus(int32_t device);
 int32_t egp_physics_n_env(const egp_physics *p);
 
 #ifdef __cplusplus
