@@ -80,26 +80,37 @@ class TrajBatchEgo(TrajBatch):
 
 
 class LoggerRL:
-    """Per-worker sampling statistics + ``merge``. Field names are the reference's (the driver reads
-    sample_time, avg_c_reward, avg_c_info, min/max_c_reward, avg_episode_reward)."""
+    """Sampling statistics of one worker (one env slot, or a whole lockstep pass via ``from_totals``) and their ``merge``.
 
+    The attribute schema is the reference's (core/logger_rl.py:6-20): the unmodified driver reads ``sample_time``,
+    ``avg_c_reward``, ``avg_c_info``, ``min_c_reward`` / ``max_c_reward`` and ``avg_episode_reward`` off the merged object
+    (ego_pose/ego_mimic.py:120-131). The schema lives in three tables here -- additive counters, running extrema, derived
+    averages -- and every method is a loop over them."""
+
+    # additive over steps / episodes / workers
     _SUMS = ("total_reward", "num_episodes", "num_steps", "total_c_reward", "total_c_info")
+    # running extrema: (attribute, reducer inside a worker, reducer across workers). The reference folds the workers'
+    # minimum episode rewards with max() (core/logger_rl.py:52); kept, the driver's printout depends on it.
+    _EXTREMA = (("min_episode_reward", min, max), ("max_episode_reward", max, max),
+                ("min_c_reward", min, min), ("max_c_reward", max, max))
+    # derived at the end of a sampling pass: attribute = numerator / denominator
+    _AVERAGES = (("avg_episode_reward", "total_reward", "num_episodes"), ("avg_c_reward", "total_c_reward", "num_steps"),
+                 ("avg_c_info", "total_c_info", "num_steps"))
 
     def __init__(self):
-        self.num_steps = 0
-        self.num_episodes = 0
-        self.total_reward = 0
-        self.min_episode_reward = math.inf
-        self.max_episode_reward = -math.inf
-        self.total_c_reward = 0
-        self.min_c_reward = math.inf
-        self.max_c_reward = -math.inf
-        self.episode_reward = 0
-        self.avg_episode_reward = 0
-        self.avg_c_reward = 0
-        self.total_c_info = 0
-        self.avg_c_info = 0
-        self.sample_time = 0
+        for name in self._SUMS:
+            setattr(self, name, 0)
+        for name, inner, _ in self._EXTREMA:
+            setattr(self, name, math.inf if inner is min else -math.inf)
+        for name, _, _ in self._AVERAGES:
+            setattr(self, name, 0)
+        self.episode_reward = 0          # the running episode's return
+        self.sample_time = 0             # filled in by the sampler
+
+    def _fold(self, name, value):
+        for attr, inner, _ in self._EXTREMA:
+            if attr == name:
+                setattr(self, attr, inner(getattr(self, attr), value))
 
     def start_episode(self, env):
         self.episode_reward = 0
@@ -109,25 +120,26 @@ class LoggerRL:
         self.episode_reward += reward
         self.total_c_reward += c_reward
         self.total_c_info += c_info
-        self.min_c_reward = min(self.min_c_reward, c_reward)
-        self.max_c_reward = max(self.max_c_reward, c_reward)
+        self._fold("min_c_reward", c_reward)
+        self._fold("max_c_reward", c_reward)
 
     def end_episode(self, env):
+        ret = self.episode_reward
         self.num_episodes += 1
-        self.total_reward += self.episode_reward
-        self.min_episode_reward = min(self.min_episode_reward, self.episode_reward)
-        self.max_episode_reward = max(self.max_episode_reward, self.episode_reward)
+        self.total_reward += ret
+        self._fold("min_episode_reward", ret)
+        self._fold("max_episode_reward", ret)
 
     def end_sampling(self):
         self._averages()
 
     def _averages(self):
-        self.avg_episode_reward = self.total_reward / self.num_episodes
-        self.avg_c_reward = self.total_c_reward / self.num_steps
-        self.avg_c_info = self.total_c_info / self.num_steps
+        for name, num, den in self._AVERAGES:
+            setattr(self, name, getattr(self, num) / getattr(self, den))
 
     @classmethod
     def from_totals(cls, num_steps, num_episodes, total_reward, min_ep, max_ep, total_c_reward, min_c, max_c, total_c_info):
+        """The statistics of a whole lockstep pass, reduced on the device (rollout.LockstepRollout)."""
         lg = cls()
         lg.num_steps, lg.num_episodes, lg.total_reward = int(num_steps), int(num_episodes), float(total_reward)
         lg.min_episode_reward, lg.max_episode_reward = float(min_ep), float(max_ep)
@@ -141,10 +153,7 @@ class LoggerRL:
         out = cls()
         for name in cls._SUMS:
             setattr(out, name, sum(getattr(x, name) for x in logger_list))
-        out.max_episode_reward = max(x.max_episode_reward for x in logger_list)
-        # the reference merges the per-worker minima with max() (core/logger_rl.py:52) -- kept
-        out.min_episode_reward = max(x.min_episode_reward for x in logger_list)
-        out.max_c_reward = max(x.max_c_reward for x in logger_list)
-        out.min_c_reward = min(x.min_c_reward for x in logger_list)
+        for name, _, across in cls._EXTREMA:
+            setattr(out, name, across(getattr(x, name) for x in logger_list))
         out._averages()
         return out
