@@ -10,6 +10,7 @@
 #   r06_pmc_{k1_grid58,k2_reward,k5_gae,k6_zfilter,k8_dynamics}_{65536,1048576}.txt      VALUBusy / occupancy / SALUBusy of K1, K2, K5, K6, K8
 #   r06_statereg_mfma_util.csv, r06_statereg_kernel_stats.csv                         config 4 (256 x 224 x 224, bf16 encoder)
 #   r06_phase_profile.txt                                                             one rollout and one update separately (torch profiler)
+#   r06_update_epoch_trace.txt                                                        one epoch of the update call by call (HIP events; shapes, TB/s, TFLOP/s)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_round6
 C=${ROUND_COMMIT:-unknown}
@@ -48,4 +49,6 @@ stamp $GRAFT_REPO_ROOT/gpurun_out/prof_statereg/kernel_stats.csv $OUT/r06_stater
 tail -3 $GRAFT_REPO_ROOT/gpurun_out/prof_statereg/bench.log > $OUT/r06_statereg_bench_tail.txt
 python tools/phase_profile.py --out $OUT/r06_phase_profile.txt > $OUT/phase_profile.log 2>&1
 sed -i "1i # commit $C" $OUT/r06_phase_profile.txt
+# one epoch of the update call by call (HIP events around every product and sweep: shapes, TB/s, float32-equivalent TFLOP/s)
+{ echo "# commit $C (tools/epoch_trace.py --epoch 5: backward of epoch 5, then the forward of epoch 6; bytes = operands + result once, TF/s = 2MNK)"; python tools/epoch_trace.py --epoch 5; } > $OUT/r06_update_epoch_trace.txt 2> $OUT/epoch_trace.err
 ls -la $OUT
