@@ -522,6 +522,9 @@ struct WsStage {
 #pragma unroll
             for (int u = 0; u < R / 64; ++u) {
                 const unsigned o = second ? off2[u] : off[u];
+                // (the non-temporal hint on these loads was measured in round 6 and is wrong here: the three n-tiles' re-reads of an activation
+                //  tile and every m-tile's re-reads of the weights must hit L2 -- forward products 183 -> 256 us with it, the row-contiguous
+                //  forms of the weight gradients 183 -> 204 us)
                 asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[2 * u]) : "v"(o), "s"(base));
                 asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(r[2 * u + 1]) : "v"(o), "s"(base));
             }
@@ -730,6 +733,9 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
             const int kz = cur.kbeg + cur.s * BK;
             const int k0 = last ? cur.kend - BK : kz;
             zrel[SET] = kz - k0;
+#if defined(EGP_WS_SKIP) && EGP_WS_SKIP == 3      // timing probe: no operand loads at all (the staged registers hold whatever they held)
+            if (g.M < 0)
+#endif
             if constexpr (FUSED) {
                 const bool a_second = A_KC && g.A2 && k0 >= g.a_split;        // (a_split is a multiple of BK: a k-tile has one source)
                 sa.load(a_second ? g.A2 : g.A, a_second ? g.lda2 : g.lda, a_second ? k0 - g.a_split : k0, wave, ra[SET], a_second,
@@ -773,7 +779,8 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
             EGP_TRW(1, 30);
             if (p + 1 < P) {
                 prefetch();
-#if !defined(EGP_WS_SKIP) || EGP_WS_SKIP != 2
+#if !defined(EGP_WS_SKIP) || EGP_WS_SKIP != 2      // (timing probes, garbage numerics: 1 consumers idle, 3 no operand loads; 2 -- no staging --
+                                                   //  ends in a memory access fault since round 6, do not run it)
                 stage(setc, (p + 1) & 1);
 #endif
                 EGP_TRW(1, 31);
@@ -812,17 +819,40 @@ __global__ __launch_bounds__(512) void k_gemm_ws(GemmArgs g) {
         // every fragment of the k-tile is requested before the first MFMA (the matrix pipe then runs the 48 products
         // back to back instead of idling through an LDS round trip in the middle)
         bf16x8 fa[BK / 16][NIMG][MI], fb[BK / 16][NIMG][NJ];
+#ifndef EGP_GEMM_FRAG_ORDER
+#define EGP_GEMM_FRAG_ORDER 0
+#endif
+#define EGP_LD_FA(ks, c, i) fa[ks][c][i] = *(const bf16x8 *)(pa + (c) * A_EL + (2 * (ks) + fkh) * panel_el(BM) + (wm * WROWS + 32 * (i) + frow) * 8)
+#define EGP_LD_FB(ks, c, j) fb[ks][c][j] = *(const bf16x8 *)(pb + (c) * B_EL + (2 * (ks) + fkh) * panel_el(BN) + (wn * 64 + 32 * (j) + frow) * 8)
+#if EGP_GEMM_FRAG_ORDER
+        // the fragments in the order the products below consume them: the first MFMA waits for two reads, not for ten
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            constexpr int CB[3] = {0, 2, 1}, CA[3] = {2, 0, 1};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { EGP_LD_FB(ks, CB[q], 0); EGP_LD_FA(ks, CA[q], 0); }
+#pragma unroll
+            for (int j = 1; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) EGP_LD_FB(ks, CB[q], j);
+#pragma unroll
+            for (int i = 1; i < MI; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) EGP_LD_FA(ks, CA[q], i);
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks)
 #pragma unroll
             for (int c = 0; c < NIMG; ++c) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    fa[ks][c][i] = *(const bf16x8 *)(pa + c * A_EL + (2 * ks + fkh) * panel_el(BM) + (wm * WROWS + 32 * i + frow) * 8);
+                for (int i = 0; i < MI; ++i) EGP_LD_FA(ks, c, i);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    fb[ks][c][j] = *(const bf16x8 *)(pb + c * B_EL + (2 * ks + fkh) * panel_el(BN) + (wn * 64 + 32 * j + frow) * 8);
+                for (int j = 0; j < NJ; ++j) EGP_LD_FB(ks, c, j);
             }
+#endif
+#undef EGP_LD_FA
+#undef EGP_LD_FB
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks)
 #pragma unroll

@@ -49,6 +49,23 @@ __device__ __forceinline__ float tanhf_(float x) { return 2.0f * __builtin_amdgc
 // barrier ~0.25 us, stores ~0.1 us, the 64 MFMAs hide behind both. NQ = row quads per workgroup.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// The save-set (activated gates, cell states: written once by the forward sweep, read once by the backward sweep a few
+// milliseconds later, 1.3 GB per grouped sweep of the update) and d_pre go past the caches with the non-temporal hint
+// (EGP_LSTM_NT bit 0: save-set stores and loads, bit 1: d_pre stores; default both. A/B/C inside one lease, tools/probes/abn.sh +
+// update_time.py, three rounds: T_update 44.85 / 44.55 / 44.84 ms without, 44.29 / 45.17 / 44.86 with bit 0, 44.04 / 44.31 / 44.56 with both.)
+#ifndef EGP_LSTM_NT
+#define EGP_LSTM_NT 3
+#endif
+template <typename V> __device__ __forceinline__ void st_save(V *p, V v) {
+    if constexpr ((EGP_LSTM_NT & 1) != 0) __builtin_nontemporal_store(v, p); else *p = v;
+}
+template <typename V> __device__ __forceinline__ V ld_save(const V *p) {
+    if constexpr ((EGP_LSTM_NT & 1) != 0) return __builtin_nontemporal_load(p); else return *p;
+}
+template <typename V> __device__ __forceinline__ void st_dpre(V *p, V v) {
+    if constexpr ((EGP_LSTM_NT & 2) != 0) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
 // Several sweeps over the same (T, B) in one launch (blockIdx.y = problem): the directions of a bi-LSTM, or the LSTMs of
 // the critic's and the actor's video nets -- a sweep is latency-bound and 320 workgroups leave 64 CUs with double
 // duty; 4 x 320 = 5 per CU. Problems share one gate buffer [T*B][P*4H] (columns p*4H.. belong to problem p: what ONE
@@ -212,8 +229,8 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_fwd_mfma(const float *__restric
                 const long row = (long)t * B + rowc[q];
                 h_out[row * ld_h + u] = hn;
                 if (TRAIN) {
-                    *reinterpret_cast<f32x4 *>(gates_out + row * ld + 4 * u) = f32x4{ig, fg, gg, og};
-                    c_out[row * LH + u] = cn;
+                    st_save(reinterpret_cast<f32x4 *>(gates_out + row * ld + 4 * u), f32x4{ig, fg, gg, og});
+                    st_save(c_out + row * LH + u, cn);
                 }
             }
         }
@@ -318,8 +335,8 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
         _Pragma("unroll") for (int qq = 0; qq < NP; ++qq) {                                          \
             const int j = (threadIdx.x + NT * qq) % LH;                                              \
             const long row = (long)f_t * B + rowc[qq];                                               \
-            pg[D][qq] = *reinterpret_cast<const f32x4 *>(gates + row * ld + 4 * j);                  \
-            pc[D][qq] = cells[row * LH + j];                                                         \
+            pg[D][qq] = ld_save(reinterpret_cast<const f32x4 *>(gates + row * ld + 4 * j));         \
+            pc[D][qq] = ld_save(cells + row * LH + j);                                               \
             pdh[D][qq] = dh_out[row * ld_dh + j];                                                    \
         }                                                                                            \
     }
@@ -341,7 +358,7 @@ __global__ __launch_bounds__(4 * LH) void k_lstm_bwd_mfma(const float *__restric
             const float dg = dc * ig * (1.f - gg * gg);
             dc_next[qq] = dc * fg;
             const f32x4 d4 = f32x4{di, df, dg, d_o};
-            if (FULL || live[qq]) { *reinterpret_cast<f32x4 *>(dpre + ((long)t * B + rowc[qq]) * ld + 4 * j) = d4; dsum[qq] += d4; }
+            if (FULL || live[qq]) { st_dpre(reinterpret_cast<f32x4 *>(dpre + ((long)t * B + rowc[qq]) * ld + 4 * j), d4); dsum[qq] += d4; }
             *reinterpret_cast<f32x4 *>(&s_d[r][4 * j]) = d4;
         }
         __syncthreads();
